@@ -1,0 +1,251 @@
+/*
+ * nrs.h -- C-ABI of the MI355X-native NeRFshop render path ("nrs" = NeRFshop Render path, Standalone).
+ *
+ * This is the drop-in boundary for ONE hot path of graphdeco-inria/nerfshop: the volumetric render path
+ * (occupancy-grid marching -> cage/tet warp of samples -> hash-grid encoding -> fused MLPs -> compositing).
+ * The reference has no FFI for this path; it sits behind C++ members called from one host thread on one
+ * stream.  Every entry point below names the reference interface it replaces (paths relative to the
+ * reference checkout):
+ *
+ *   nrs_render_nerf          <- Testbed::render_nerf                   src/testbed_nerf.cu:3066 (decl testbed.h:305)
+ *                               = NerfTracer::init_rays_from_camera    src/testbed_nerf.cu:2683
+ *                               + NerfTracer::trace                    src/testbed_nerf.cu:2772
+ *                               + shade_kernel_nerf                    src/testbed_nerf.cu:2448
+ *   nrs_network_inference    <- NerfNetwork<T>::inference_mixed_precision   include/.../nerf_network_full.h:62
+ *   nrs_network_density      <- NerfNetwork<T>::density                     include/.../nerf_network_full.h:223
+ *   nrs_model_set_params     <- NerfNetwork<T>::set_params                  include/.../nerf_network_full.h:316
+ *   nrs_model_set_density_grid <- Testbed::update_density_grid_mean_and_bitfield   src/testbed_nerf.cu:3642
+ *   nrs_edit_create / nrs_edit_update_vertices <- TetMesh GPU members + upload     tet_mesh.h:80-94, tet_mesh.cu:651-667
+ *   nrs_edit_map_rays        <- EditOperator::map_rays      edit_operator.h:43, CageDeformation::map_rays  cage_deformation.cu:547
+ *   nrs_edit_map_positions   <- EditOperator::map_positions edit_operator.h:51, cage_deformation.cu:624
+ *   nrs_tet_lut_build        <- TetMesh::build_tet_grid / build_original_tet_grid  tet_mesh.cu:368 / :76   (host, "next" row f1)
+ *   nrs_mvc_compute / nrs_mvc_apply <- Cage::compute_mvc / interpolate_with_mvc    cage.cu:6 / :38          (host, "next" row f1)
+ *   nrs_tet_local_rotations  <- TetMesh::update_local_rotations                    tet_mesh.cu:37           (host, "next" row f1)
+ *   nrs_trace_samples        <- (test hook) the (t, dt) stream generate_next_nerf_network_inputs emits, testbed_nerf.cu:637
+ *   nrs_detile               <- (new) inverse of the multi-GPU tile packing, no reference counterpart
+ *
+ * Conventions: every function returns NRS_OK (0) or a negative nrs_status; nrs_last_error() returns a
+ * thread-local message.  All buffers named d_* are DEVICE pointers owned by the caller; h_* are HOST
+ * pointers.  `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous
+ * on `stream` unless stated; the caller synchronises (the reference does the same, src/testbed.cu:2843).
+ * A context is not thread-safe; use one per host thread / GPU.  No torch / C++ types cross this boundary.
+ */
+#ifndef NRS_H
+#define NRS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRS_ABI_VERSION 1
+
+typedef enum nrs_status {
+	NRS_OK = 0,
+	NRS_ERR_INVALID_ARG = -1,
+	NRS_ERR_UNSUPPORTED = -2,   /* configuration outside configs/nerf/base.json's architecture */
+	NRS_ERR_HIP = -3,           /* a HIP runtime call failed; message carries hipGetErrorString */
+	NRS_ERR_NO_DEVICE = -4,     /* no gfx950 device visible: the product path never falls back to CPU */
+	NRS_ERR_STATE = -5          /* e.g. rendering before params / density grid were set */
+} nrs_status;
+
+/* ENerfActivation, include/neural-graphics-primitives/common.h:107 */
+typedef enum nrs_activation {
+	NRS_ACT_NONE = 0, NRS_ACT_RELU = 1, NRS_ACT_LOGISTIC = 2, NRS_ACT_EXPONENTIAL = 3
+} nrs_activation;
+
+/* ERenderMode, common.h:71.  Only Shade (and Cost's step counter) are on the parity path. */
+typedef enum nrs_render_mode {
+	NRS_RENDER_AO = 0, NRS_RENDER_SHADE = 1, NRS_RENDER_NORMALS = 2, NRS_RENDER_POSITIONS = 3,
+	NRS_RENDER_DEPTH = 4, NRS_RENDER_DISTANCE = 5, NRS_RENDER_STEPSIZE = 6, NRS_RENDER_DISTORTION = 7,
+	NRS_RENDER_COST = 8, NRS_RENDER_SLICE = 9
+} nrs_render_mode;
+
+/* GPUMatrixDynamic<T>::layout() of the network output: planes = row-major [16 x n_el]
+ * (renderer, density-grid update), interleaved = column-major, 16 halfs per sample (selection, Poisson). */
+typedef enum nrs_layout { NRS_PLANES = 0, NRS_INTERLEAVED = 1 } nrs_layout;
+
+/* Network hyper-parameters: configs/nerf/base.json:23-58 + src/testbed.cu:2257-2333. */
+typedef struct nrs_model_desc {
+	uint32_t n_levels;             /* 16 */
+	uint32_t n_features_per_level; /* 2  */
+	uint32_t log2_hashmap_size;    /* 19 */
+	uint32_t base_resolution;      /* 16 */
+	float    per_level_scale;      /* exp(ln(2048*aabb_scale/16)/15), testbed.cu:2288-2292 */
+	uint32_t n_neurons;            /* 64 (both MLPs) */
+	uint32_t density_hidden_layers;/* 1  */
+	uint32_t density_output_dims;  /* 16, nerf_network_full.h:47-49 */
+	uint32_t rgb_hidden_layers;    /* 2  */
+	uint32_t sh_degree;            /* 4  */
+	uint32_t rgb_activation;       /* nrs_activation; lego: Logistic   (testbed.h:636) */
+	uint32_t density_activation;   /* nrs_activation; Exponential      (testbed.h:637) */
+	float    aabb_min[3];          /* Testbed::m_aabb (training box): [0,1]^3 for aabb_scale 1 */
+	float    aabb_max[3];
+} nrs_model_desc;
+
+#define NRS_GRID_SIZE       128u                     /* NERF_GRIDSIZE,  common_nerf.h:16 */
+#define NRS_GRID_CASCADES   5u                       /* NERF_CASCADES,  common_nerf.h:26 */
+#define NRS_GRID_VOLUME     (128u * 128u * 128u)
+#define NRS_BITFIELD_BYTES  (NRS_GRID_VOLUME * NRS_GRID_CASCADES / 8u)   /* 1 310 720 */
+#define NRS_NETWORK_INPUT_FLOATS 7u                  /* NerfCoordinate: pos3, dt, dir3; nerf.h:73 */
+#define NRS_NETWORK_OUTPUT_WIDTH 16u                 /* padded_output_width() */
+
+/* One cage-deformation operator as the renderer consumes it: the GPU members of TetMesh (tet_mesh.h:80-94)
+ * plus the flags CageDeformation::map_rays passes (cage_deformation.cu:547-572).  All arrays are HOST
+ * pointers; nrs_edit_create copies them to the device. */
+typedef struct nrs_tet_mesh {
+	uint32_t        n_vertices;
+	uint32_t        n_tets;
+	const float*    h_vertices;          /* [V*3] deformed, un-warped world units */
+	const float*    h_original_vertices; /* [V*3] canonical */
+	const uint32_t* h_tets;              /* [T*4] */
+	const uint32_t* h_lut_offsets;       /* [5*128^3 + 1] CSR over level*128^3 + morton, deformed mesh */
+	const uint32_t* h_lut_idx;           /* [h_lut_offsets[last]] */
+	const uint8_t*  h_original_bitfield; /* [NRS_BITFIELD_BYTES] cells touched by the canonical mesh */
+	const float*    h_local_rotations;   /* [T*9] Eigen column-major, or NULL (m_correct_direction off) */
+	uint32_t        copy;                /* GrowingSelection::m_copy: keep the source visible */
+	/* membrane ("Poisson") correction, cage_deformation.h:163; arrays may be NULL when apply_poisson == 0 */
+	uint32_t        apply_poisson;
+	float           residual_amplitude;
+	const float*    h_boundary_shs;              /* [V*27] SH9RGB per vertex, Eigen col-major 9x3 */
+	const float*    h_boundary_outside_density;  /* [V] */
+	const float*    h_boundary_residual_density; /* [V] */
+} nrs_tet_mesh;
+
+/* Arguments + implicit Testbed members of render_nerf (SURVEY 8b "Renderer"). */
+typedef struct nrs_render_params {
+	int32_t  resolution[2];       /* render_buffer.in_resolution() */
+	float    focal_length[2];
+	float    camera_matrix0[12];  /* 3x4, Eigen column-major: col0,col1,col2 = axes, col3 = origin */
+	float    camera_matrix1[12];
+	float    rolling_shutter[4];
+	float    screen_center[2];
+	float    render_aabb_min[3];  /* m_render_aabb */
+	float    render_aabb_max[3];
+	uint32_t spp_index;           /* render_buffer.spp(): Sobol sample index */
+	uint32_t snap_to_pixel_centers;
+	float    min_transmittance;   /* m_nerf.rendering_min_transmittance (0.01) */
+	float    cone_angle_constant; /* m_nerf.cone_angle_constant: 0 for aabb_scale 1, 1/256 otherwise */
+	uint32_t render_mode;         /* nrs_render_mode; Shade and Cost implemented */
+	uint32_t linear_colors;       /* m_nerf.training.linear_colors: skip srgb_to_linear in shade */
+	uint32_t apply_operators;     /* m_enable_edits && !m_distill */
+	uint32_t poisson_target;      /* NerfTracer::m_poisson_target */
+	uint32_t min_mip;             /* show_accel >= 0 ? show_accel : 0 (marching only) */
+	uint32_t max_march_steps;     /* 0 = reference bound (MARCH_ITER, testbed_nerf.cu:56) */
+	/* Multi-GPU image-tile sharding (no reference counterpart).  The image is cut into
+	 * tile_size x tile_size pixel tiles in row-major tile order; this call renders tiles
+	 * t = tile_first, tile_first + tile_stride, ...  tile_size == 0 means "whole image" and frame/depth
+	 * are indexed x + W*y.  With tiling, pixel (tx,ty) of the k-th owned tile is written at
+	 * ((k * tile_size + ty) * tile_size + tx): a compact buffer ready for one RCCL gather. */
+	uint32_t tile_size;           /* multiple of 8, or 0 */
+	uint32_t tile_first;
+	uint32_t tile_stride;
+} nrs_render_params;
+
+typedef struct nrs_render_stats {
+	uint64_t n_samples;      /* network-evaluated live samples (sum of per-ray n_steps)            */
+	uint32_t n_rays_alive;   /* rays that found an occupied cell (entered the sample loop)          */
+	uint32_t n_rays_hit;     /* rays shaded into the frame buffer (alpha > 0.001), = trace()'s n_hit */
+} nrs_render_stats;
+
+typedef struct nrs_ctx   nrs_ctx;
+typedef struct nrs_model nrs_model;
+typedef struct nrs_edit  nrs_edit;
+
+const char* nrs_last_error(void);
+int         nrs_abi_version(void);
+
+/* ---- context / model ------------------------------------------------------------------------------- */
+int  nrs_ctx_create(int device, nrs_ctx** out);
+void nrs_ctx_destroy(nrs_ctx* ctx);
+int  nrs_ctx_device_info(const nrs_ctx* ctx, char* name_out, size_t name_len, int* n_cus, size_t* hbm_bytes);
+
+int    nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out);
+void   nrs_model_destroy(nrs_model* model);
+/* number of fp16 parameters the description implies (density MLP | rgb MLP | hash grid), host-only */
+size_t nrs_model_n_params(const nrs_model_desc* desc);
+/* per-level hash-grid table (host-only): scale, resolution, first entry, entry count, hashed flag */
+int    nrs_model_level_table(const nrs_model_desc* desc, float* scale, uint32_t* resolution,
+                             uint32_t* entry_offset, uint32_t* entry_count, uint32_t* hashed);
+/* fp16 parameter blob in tiny-cuda-nn order: density MLP | rgb MLP | hash grid (nerf_network_full.h:316-349).
+ * h_params is a HOST pointer (what Trainer::deserialize hands over); synchronous. */
+int    nrs_model_set_params(nrs_model* model, const void* h_params_fp16, size_t n_params);
+/* occupancy: either the ready-made bitfield (NRS_BITFIELD_BYTES, Morton order, mips pooled) ... */
+int    nrs_model_set_density_bitfield(nrs_model* model, const uint8_t* h_bitfield, size_t n_bytes);
+/* ... or the float density grid [5*128^3]; thresholded with min(0.01, mean) and OR-pooled on the device
+ * exactly as update_density_grid_mean_and_bitfield does (testbed_nerf.cu:514-555, 3642-3657). */
+int    nrs_model_set_density_grid(nrs_model* model, const float* h_grid, size_t n_floats);
+int    nrs_model_get_density_bitfield(nrs_model* model, uint8_t* h_bitfield_out, size_t n_bytes);
+
+/* ---- NerfNetwork operator -------------------------------------------------------------------------- */
+/* d_in: [n x 7] f32 (column-major 7 x n in tcnn terms).  d_out: fp16, n_el = n_padded samples wide:
+ * planes -> d_out[c * ld_out + s], interleaved -> d_out[s * 16 + c]; c 0..2 rgb raw, c 3 density raw,
+ * c 4..15 the rgb network's padding outputs.  ld_out >= n (planes only). */
+int nrs_network_inference(nrs_model* model, void* stream, uint32_t n, const float* d_in,
+                          void* d_out_fp16, uint32_t ld_out, int layout);
+/* density(): d_in is [n x ld_in] f32 with ld_in 3..7, only floats 0..2 of each record are read
+ * (nerf_network_full.h:231-236).  Output = the density MLP's 16 outputs (c 0 = density raw). */
+int nrs_network_density(nrs_model* model, void* stream, uint32_t n, const float* d_in, uint32_t ld_in,
+                        void* d_out_fp16, uint32_t ld_out, int layout);
+/* hash-grid encoding alone (test hook; tcnn Encoding::inference_mixed_precision): d_out [n x 32] fp16 */
+int nrs_hashgrid_encode(nrs_model* model, void* stream, uint32_t n, const float* d_in, uint32_t ld_in,
+                        void* d_out_fp16);
+
+/* ---- edit operators -------------------------------------------------------------------------------- */
+int  nrs_edit_create(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_tet_mesh* mesh, nrs_edit** out);
+void nrs_edit_destroy(nrs_edit* edit);
+/* map_rays: in-place on d_coords [n x 7] f32, OR-accumulates into d_empty_mask [n] u8 */
+int  nrs_edit_map_rays(nrs_edit* edit, void* stream, uint32_t n, float* d_coords, uint8_t* d_empty_mask);
+/* map_positions: in-place on d_pos [n x ld] f32 (ld >= 3), OR-accumulates into d_empty_mask */
+int  nrs_edit_map_positions(nrs_edit* edit, void* stream, uint32_t n, float* d_pos, uint32_t ld,
+                            uint8_t* d_empty_mask);
+
+/* ---- renderer -------------------------------------------------------------------------------------- */
+/* d_frame: f32x4 premultiplied linear RGBA, pre-cleared by the caller (clear_frame, testbed.cu:2635);
+ * d_depth: f32 (written 1e10 for every pixel of the owned tiles first, as init_rays does);
+ * d_steps: optional u32 per pixel = samples composited (payload.n_steps - 1 ... see DESIGN.md), may be NULL.
+ * edits are applied last-to-first (testbed_nerf.cu:2899).  h_stats may be NULL; when non-NULL the call
+ * synchronises the stream before returning (the reference's trace() syncs to read n_hit). */
+int nrs_render_nerf(nrs_model* model, const nrs_render_params* params, nrs_edit* const* edits, int n_edits,
+                    float* d_frame, float* d_depth, uint32_t* d_steps, void* stream, nrs_render_stats* h_stats);
+/* number of tiles this rank owns / pixels of the compact buffer for given params (host-only) */
+uint32_t nrs_render_owned_tiles(const nrs_render_params* params);
+/* scatter compact tile buffers of all ranks (concatenated rank-major, as all_gather delivers them)
+ * back into a full W x H image.  n_ranks * tiles_per_rank_padded tiles are read. */
+int nrs_detile(nrs_ctx* ctx, void* stream, const nrs_render_params* params, uint32_t n_ranks,
+               uint32_t tiles_per_rank_padded, const float* d_tiles, uint32_t channels, float* d_image);
+/* Test hook for bit-exact ray/sample indexing: for each listed pixel, march exactly as the renderer does
+ * (init -> jitter -> first hit -> successive samples) ignoring compositing, and emit up to max_samples
+ * (t, dt) pairs.  d_t, d_dt: [n_pixels x max_samples] f32; d_count: [n_pixels] u32. */
+int nrs_trace_samples(nrs_model* model, const nrs_render_params* params, void* stream, uint32_t n_pixels,
+                      const uint32_t* d_pixel_idx, uint32_t max_samples, float* d_t, float* d_dt, uint32_t* d_count);
+
+/* ---- host-side edit authoring ("next" row f1; CPU like the reference, no device needed) -------------- */
+typedef struct nrs_tet_lut nrs_tet_lut;
+/* builds the cell->tet CSR of `h_vertices` and the touched-cell bitfield; n_threads 0 = hardware */
+int  nrs_tet_lut_build(const float* h_vertices, uint32_t n_vertices, const uint32_t* h_tets, uint32_t n_tets,
+                       int n_threads, nrs_tet_lut** out);
+uint32_t        nrs_tet_lut_n_idx(const nrs_tet_lut* lut);
+uint32_t        nrs_tet_lut_max_per_cell(const nrs_tet_lut* lut);
+const uint32_t* nrs_tet_lut_offsets(const nrs_tet_lut* lut);   /* [5*128^3+1] */
+const uint32_t* nrs_tet_lut_idx(const nrs_tet_lut* lut);
+const uint8_t*  nrs_tet_lut_bitfield(const nrs_tet_lut* lut);  /* [NRS_BITFIELD_BYTES] */
+void            nrs_tet_lut_destroy(nrs_tet_lut* lut);
+/* MVC weights of n_points points w.r.t. a closed triangulated cage (mvc.h:125-188), float arithmetic.
+ * h_weights_out [n_points x n_cage_vertices]; h_labels_out [n_points] (1 = degenerate case hit), may be NULL */
+int nrs_mvc_compute(const float* h_cage_vertices, uint32_t n_cage_vertices, const uint32_t* h_cage_triangles,
+                    uint32_t n_cage_triangles, const float* h_points, uint32_t n_points,
+                    float* h_weights_out, uint8_t* h_labels_out);
+/* points[i] = sum_j w[i][j] * cage[j]   (cage.cu:38-49) */
+int nrs_mvc_apply(const float* h_weights, const float* h_cage_vertices, uint32_t n_cage_vertices,
+                  uint32_t n_points, float* h_points_out);
+/* per-tet deformed->canonical rotation R = U V^T of sum (orig-c0)(def-c1)^T (tet_mesh.cu:37-74); [T*9] col-major */
+int nrs_tet_local_rotations(const float* h_vertices, const float* h_original_vertices, const uint32_t* h_tets,
+                            uint32_t n_tets, float* h_rotations_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NRS_H */

@@ -1,0 +1,173 @@
+"""ctypes mirror of include/nrs.h (the C-ABI of the render path) and the loader of libnrs.so.
+
+The library is the product: hand-written HIP kernels for gfx950 + the C++ host code around them.  There is
+no CPU fallback anywhere in this package -- if the shared library is missing, `load()` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnrs.so")
+
+NRS_OK = 0
+GRID_SIZE = 128
+GRID_CASCADES = 5
+GRID_VOLUME = GRID_SIZE ** 3
+BITFIELD_BYTES = GRID_VOLUME * GRID_CASCADES // 8
+N_LUT_CELLS = GRID_VOLUME * GRID_CASCADES
+
+ACT_NONE, ACT_RELU, ACT_LOGISTIC, ACT_EXPONENTIAL = 0, 1, 2, 3
+RENDER_SHADE, RENDER_COST = 1, 8
+LAYOUT_PLANES, LAYOUT_INTERLEAVED = 0, 1
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_uint32),
+        ("n_features_per_level", C.c_uint32),
+        ("log2_hashmap_size", C.c_uint32),
+        ("base_resolution", C.c_uint32),
+        ("per_level_scale", C.c_float),
+        ("n_neurons", C.c_uint32),
+        ("density_hidden_layers", C.c_uint32),
+        ("density_output_dims", C.c_uint32),
+        ("rgb_hidden_layers", C.c_uint32),
+        ("sh_degree", C.c_uint32),
+        ("rgb_activation", C.c_uint32),
+        ("density_activation", C.c_uint32),
+        ("aabb_min", C.c_float * 3),
+        ("aabb_max", C.c_float * 3),
+    ]
+
+
+class TetMesh(C.Structure):
+    _fields_ = [
+        ("n_vertices", C.c_uint32),
+        ("n_tets", C.c_uint32),
+        ("h_vertices", C.c_void_p),
+        ("h_original_vertices", C.c_void_p),
+        ("h_tets", C.c_void_p),
+        ("h_lut_offsets", C.c_void_p),
+        ("h_lut_idx", C.c_void_p),
+        ("h_original_bitfield", C.c_void_p),
+        ("h_local_rotations", C.c_void_p),
+        ("copy", C.c_uint32),
+        ("apply_poisson", C.c_uint32),
+        ("residual_amplitude", C.c_float),
+        ("h_boundary_shs", C.c_void_p),
+        ("h_boundary_outside_density", C.c_void_p),
+        ("h_boundary_residual_density", C.c_void_p),
+    ]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [
+        ("resolution", C.c_int32 * 2),
+        ("focal_length", C.c_float * 2),
+        ("camera_matrix0", C.c_float * 12),
+        ("camera_matrix1", C.c_float * 12),
+        ("rolling_shutter", C.c_float * 4),
+        ("screen_center", C.c_float * 2),
+        ("render_aabb_min", C.c_float * 3),
+        ("render_aabb_max", C.c_float * 3),
+        ("spp_index", C.c_uint32),
+        ("snap_to_pixel_centers", C.c_uint32),
+        ("min_transmittance", C.c_float),
+        ("cone_angle_constant", C.c_float),
+        ("render_mode", C.c_uint32),
+        ("linear_colors", C.c_uint32),
+        ("apply_operators", C.c_uint32),
+        ("poisson_target", C.c_uint32),
+        ("min_mip", C.c_uint32),
+        ("max_march_steps", C.c_uint32),
+        ("tile_size", C.c_uint32),
+        ("tile_first", C.c_uint32),
+        ("tile_stride", C.c_uint32),
+    ]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("n_samples", C.c_uint64), ("n_rays_alive", C.c_uint32), ("n_rays_hit", C.c_uint32)]
+
+
+# every symbol include/nrs.h declares; tests check the library exports exactly these
+EXPORTS = [
+    "nrs_last_error", "nrs_abi_version",
+    "nrs_ctx_create", "nrs_ctx_destroy", "nrs_ctx_device_info",
+    "nrs_model_create", "nrs_model_destroy", "nrs_model_n_params", "nrs_model_level_table",
+    "nrs_model_set_params", "nrs_model_set_density_bitfield", "nrs_model_set_density_grid",
+    "nrs_model_get_density_bitfield",
+    "nrs_network_inference", "nrs_network_density", "nrs_hashgrid_encode",
+    "nrs_edit_create", "nrs_edit_destroy", "nrs_edit_map_rays", "nrs_edit_map_positions",
+    "nrs_render_nerf", "nrs_render_owned_tiles", "nrs_detile", "nrs_trace_samples",
+    "nrs_tet_lut_build", "nrs_tet_lut_n_idx", "nrs_tet_lut_max_per_cell", "nrs_tet_lut_offsets",
+    "nrs_tet_lut_idx", "nrs_tet_lut_bitfield", "nrs_tet_lut_destroy",
+    "nrs_mvc_compute", "nrs_mvc_apply", "nrs_tet_local_rotations",
+]
+
+_lib = None
+
+
+class NrsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libnrs.so (built in-tree by __graft_entry__.build()).  Fails loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NrsError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P, U32, I = C.c_void_p, C.c_uint32, C.c_int
+    lib.nrs_last_error.restype = C.c_char_p
+    lib.nrs_abi_version.restype = I
+    lib.nrs_ctx_create.argtypes = [I, C.POINTER(P)]
+    lib.nrs_ctx_destroy.argtypes = [P]
+    lib.nrs_ctx_destroy.restype = None
+    lib.nrs_ctx_device_info.argtypes = [P, C.c_char_p, C.c_size_t, C.POINTER(I), C.POINTER(C.c_size_t)]
+    lib.nrs_model_create.argtypes = [P, C.POINTER(ModelDesc), C.POINTER(P)]
+    lib.nrs_model_destroy.argtypes = [P]
+    lib.nrs_model_destroy.restype = None
+    lib.nrs_model_n_params.argtypes = [C.POINTER(ModelDesc)]
+    lib.nrs_model_n_params.restype = C.c_size_t
+    lib.nrs_model_level_table.argtypes = [C.POINTER(ModelDesc), P, P, P, P, P]
+    lib.nrs_model_set_params.argtypes = [P, P, C.c_size_t]
+    lib.nrs_model_set_density_bitfield.argtypes = [P, P, C.c_size_t]
+    lib.nrs_model_set_density_grid.argtypes = [P, P, C.c_size_t]
+    lib.nrs_model_get_density_bitfield.argtypes = [P, P, C.c_size_t]
+    lib.nrs_network_inference.argtypes = [P, P, U32, P, P, U32, I]
+    lib.nrs_network_density.argtypes = [P, P, U32, P, U32, P, U32, I]
+    lib.nrs_hashgrid_encode.argtypes = [P, P, U32, P, U32, P]
+    lib.nrs_edit_create.argtypes = [P, C.POINTER(ModelDesc), C.POINTER(TetMesh), C.POINTER(P)]
+    lib.nrs_edit_destroy.argtypes = [P]
+    lib.nrs_edit_destroy.restype = None
+    lib.nrs_edit_map_rays.argtypes = [P, P, U32, P, P]
+    lib.nrs_edit_map_positions.argtypes = [P, P, U32, P, U32, P]
+    lib.nrs_render_nerf.argtypes = [P, C.POINTER(RenderParams), C.POINTER(P), I, P, P, P, P, C.POINTER(RenderStats)]
+    lib.nrs_render_owned_tiles.argtypes = [C.POINTER(RenderParams)]
+    lib.nrs_render_owned_tiles.restype = U32
+    lib.nrs_detile.argtypes = [P, P, C.POINTER(RenderParams), U32, U32, P, U32, P]
+    lib.nrs_trace_samples.argtypes = [P, C.POINTER(RenderParams), P, U32, P, U32, P, P, P]
+    lib.nrs_tet_lut_build.argtypes = [P, U32, P, U32, I, C.POINTER(P)]
+    for name in ("nrs_tet_lut_n_idx", "nrs_tet_lut_max_per_cell"):
+        getattr(lib, name).argtypes = [P]
+        getattr(lib, name).restype = U32
+    for name in ("nrs_tet_lut_offsets", "nrs_tet_lut_idx", "nrs_tet_lut_bitfield"):
+        getattr(lib, name).argtypes = [P]
+        getattr(lib, name).restype = P
+    lib.nrs_tet_lut_destroy.argtypes = [P]
+    lib.nrs_tet_lut_destroy.restype = None
+    lib.nrs_mvc_compute.argtypes = [P, U32, P, U32, P, U32, P, P]
+    lib.nrs_mvc_apply.argtypes = [P, P, U32, U32, P]
+    lib.nrs_tet_local_rotations.argtypes = [P, P, P, U32, P]
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != NRS_OK:
+        raise NrsError(f"nrs error {status}: {load().nrs_last_error().decode()}")

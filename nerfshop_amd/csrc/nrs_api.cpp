@@ -1,0 +1,487 @@
+// nrs_api.cpp -- C++ host code behind the C-ABI of include/nrs.h: context, model, edit operators, render call.
+// Plain C++17 + the HIP runtime API; no torch, no third-party dependencies.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "nrs_internal.h"
+
+using namespace nrs;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+	g_err = msg;
+	return code;
+}
+static int fail_hip(hipError_t e, const char* what) {
+	g_err = std::string(what) + ": " + hipGetErrorString(e);
+	return NRS_ERR_HIP;
+}
+#define HIP_TRY(call)                                      \
+	do {                                                   \
+		hipError_t e_ = (call);                            \
+		if (e_ != hipSuccess) return fail_hip(e_, #call);  \
+	} while (0)
+#define NRS_TRY(call)                                                       \
+	do {                                                                    \
+		int s_ = (call);                                                    \
+		if (s_ != NRS_OK) return (g_err = launch_last_error(), s_);         \
+	} while (0)
+
+struct nrs_ctx {
+	int device = 0;
+	int n_cus = 0;
+	size_t hbm_bytes = 0;
+	char name[256] = {0};
+	RenderCounters* d_counters = nullptr;
+	DeviceEdit* d_edits = nullptr; // scratch array for render calls
+	float* d_mean = nullptr;
+	static constexpr int kMaxEdits = 32;
+};
+
+struct nrs_model {
+	nrs_ctx* ctx = nullptr;
+	nrs_model_desc desc{};
+	DeviceModel dm{};
+	uint32_t total_entries = 0;
+	uint32_t* d_grid = nullptr;
+	uint16_t* d_wfrag = nullptr;
+	uint8_t* d_bitfield = nullptr;
+	bool have_params = false, have_bitfield = false;
+};
+
+struct nrs_edit {
+	nrs_ctx* ctx = nullptr;
+	DeviceEdit de{};
+	std::vector<void*> allocs;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+static bool desc_supported(const nrs_model_desc& d) {
+	return d.n_levels == 16 && d.n_features_per_level == 2 && d.n_neurons == 64 && d.density_hidden_layers == 1 &&
+	       d.density_output_dims == 16 && d.rgb_hidden_layers == 2 && d.sh_degree == 4 && d.log2_hashmap_size >= 8 &&
+	       d.log2_hashmap_size <= 24 && d.base_resolution >= 1;
+}
+
+// tcnn GridEncoding level geometry: scale = exp2(l*log2(b))*Nmin - 1, res = ceil(scale)+1,
+// entries = min(align8(res^3), 2^log2_T).  Evaluated in double on the host, rounded to float once.
+static uint32_t make_levels(const nrs_model_desc& d, LevelParams* lv) {
+	uint32_t off = 0;
+	const double l2 = std::log2((double)d.per_level_scale);
+	for (uint32_t l = 0; l < d.n_levels; ++l) {
+		LevelParams& p = lv[l];
+		const double s = std::exp2((double)l * l2) * (double)d.base_resolution - 1.0;
+		p.scale = (float)s;
+		p.resolution = (uint32_t)std::ceil((double)p.scale) + 1u;
+		p.res2 = p.resolution * p.resolution;
+		uint64_t n = (uint64_t)p.resolution * p.resolution * p.resolution;
+		n = (n + 7ull) / 8ull * 8ull;
+		p.count = (uint32_t)std::min<uint64_t>(n, 1ull << d.log2_hashmap_size);
+		uint64_t stride = 1;
+		for (int dim = 0; dim < 3 && stride <= p.count; ++dim) stride *= p.resolution;
+		p.hashed = p.count < stride ? 1u : 0u;
+		p.mask = p.hashed ? p.count - 1u : 0u;
+		p.offset = off;
+		p.pad = 0;
+		off += p.count;
+	}
+	return off;
+}
+
+// Arrange the five row-major fp16 weight matrices (tcnn FullyFusedMLP: [out x in], no biases) as MFMA A operands
+// in the order nrs_mlp.cuh consumes them.  For fragment F, lane l = (i = l & 31, g = l >> 5), element e: the weight
+// of output unit (32*mb + i) for the input that the B operand's element e of lane-half g carries.
+static void make_weight_fragments(const uint16_t* w, uint16_t* frag) {
+	const uint16_t* Wd1 = w;                 // [64 x 32]
+	const uint16_t* Wd2 = Wd1 + 64 * 32;     // [16 x 64]
+	const uint16_t* Wr1 = Wd2 + 16 * 64;     // [64 x 32]
+	const uint16_t* Wr2 = Wr1 + 64 * 32;     // [64 x 64]
+	const uint16_t* Wr3 = Wr2 + 64 * 64;     // [16 x 64]
+	auto hidden_row = [](int mb, int g, int r) { return 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * g; }; // D-tile row of reg r
+	auto at = [&](int f, int lane, int e) -> uint16_t& { return frag[((size_t)f * 64 + lane) * 8 + e]; };
+	memset(frag, 0, kWfragBytes);
+	for (int lane = 0; lane < 64; ++lane) {
+		const int i = lane & 31, g = lane >> 5;
+		for (int e = 0; e < 8; ++e) {
+			for (int mb = 0; mb < 2; ++mb)
+				for (int ks = 0; ks < 2; ++ks) {
+					const int feat = 2 * (2 * (4 * ks + (e >> 1)) + g) + (e & 1); // level 2*it+g, it = 4ks + e/2
+					at(mb * 2 + ks, lane, e) = Wd1[(32 * mb + i) * 32 + feat];
+				}
+			for (int ks = 0; ks < 4; ++ks) {
+				const int k = hidden_row(ks >> 1, g, 8 * (ks & 1) + e);
+				if (i < 16) at(4 + ks, lane, e) = Wd2[i * 64 + k];
+				if (i < 16) at(20 + ks, lane, e) = Wr3[i * 64 + k];
+				for (int mb = 0; mb < 2; ++mb) at(12 + mb * 4 + ks, lane, e) = Wr2[(32 * mb + i) * 64 + k];
+			}
+			for (int mb = 0; mb < 2; ++mb) {
+				const int kd = (e & 3) + 8 * (e >> 2) + 4 * g; // density-output row in element e
+				at(8 + mb * 2 + 0, lane, e) = Wr1[(32 * mb + i) * 32 + kd];
+				at(8 + mb * 2 + 1, lane, e) = Wr1[(32 * mb + i) * 32 + 16 + 8 * g + e]; // SH coefficient 8g+e
+			}
+		}
+	}
+}
+
+static void box_of(const float* v, uint32_t n, Box3& b) {
+	const float inf = std::numeric_limits<float>::infinity();
+	for (int k = 0; k < 3; ++k) { b.mn[k] = inf; b.mx[k] = -inf; }
+	for (uint32_t i = 0; i < n; ++i)
+		for (int k = 0; k < 3; ++k) {
+			b.mn[k] = std::fmin(b.mn[k], v[3 * i + k]);
+			b.mx[k] = std::fmax(b.mx[k], v[3 * i + k]);
+		}
+}
+static void warp_box(const Box3& b, const Box3& aabb, Box3& out) { // BoundingBox::warp_box, bounding_box.cuh:272
+	for (int k = 0; k < 3; ++k) {
+		const float diag = aabb.mx[k] - aabb.mn[k];
+		out.mn[k] = (b.mn[k] - aabb.mn[k]) / diag;
+		out.mx[k] = (b.mx[k] - aabb.mn[k]) / diag;
+	}
+}
+
+template <typename T>
+static int upload(nrs_edit* e, const T* h, size_t count, const T** d_out) {
+	void* d = nullptr;
+	HIP_TRY(hipMalloc(&d, std::max<size_t>(count * sizeof(T), 16)));
+	e->allocs.push_back(d);
+	if (count) HIP_TRY(hipMemcpy(d, h, count * sizeof(T), hipMemcpyHostToDevice));
+	*d_out = (const T*)d;
+	return NRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* nrs_last_error(void) { return g_err.c_str(); }
+int nrs_abi_version(void) { return NRS_ABI_VERSION; }
+
+int nrs_ctx_create(int device, nrs_ctx** out) {
+	if (!out) return fail(NRS_ERR_INVALID_ARG, "nrs_ctx_create: out is NULL");
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) return fail(NRS_ERR_NO_DEVICE, "nrs_ctx_create: no HIP device visible (this library has no CPU fallback)");
+	if (device < 0 || device >= n) return fail(NRS_ERR_INVALID_ARG, "nrs_ctx_create: device index out of range");
+	HIP_TRY(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	nrs_ctx* c = new (std::nothrow) nrs_ctx();
+	if (!c) return fail(NRS_ERR_STATE, "out of host memory");
+	c->device = device;
+	c->n_cus = prop.multiProcessorCount;
+	c->hbm_bytes = prop.totalGlobalMem;
+	snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+	HIP_TRY(hipMalloc((void**)&c->d_counters, sizeof(RenderCounters)));
+	HIP_TRY(hipMalloc((void**)&c->d_edits, sizeof(DeviceEdit) * nrs_ctx::kMaxEdits));
+	HIP_TRY(hipMalloc((void**)&c->d_mean, 16));
+	*out = c;
+	return NRS_OK;
+}
+void nrs_ctx_destroy(nrs_ctx* c) {
+	if (!c) return;
+	(void)hipFree(c->d_counters);
+	(void)hipFree(c->d_edits);
+	(void)hipFree(c->d_mean);
+	delete c;
+}
+int nrs_ctx_device_info(const nrs_ctx* c, char* name_out, size_t name_len, int* n_cus, size_t* hbm_bytes) {
+	if (!c) return fail(NRS_ERR_INVALID_ARG, "ctx is NULL");
+	if (name_out && name_len) snprintf(name_out, name_len, "%s", c->name);
+	if (n_cus) *n_cus = c->n_cus;
+	if (hbm_bytes) *hbm_bytes = c->hbm_bytes;
+	return NRS_OK;
+}
+
+size_t nrs_model_n_params(const nrs_model_desc* d) {
+	if (!d || !desc_supported(*d)) return 0;
+	LevelParams lv[kLevels];
+	return (size_t)kDensityW + kRgbW + (size_t)make_levels(*d, lv) * 2;
+}
+int nrs_model_level_table(const nrs_model_desc* d, float* scale, uint32_t* resolution, uint32_t* entry_offset, uint32_t* entry_count,
+                          uint32_t* hashed) {
+	if (!d || !desc_supported(*d)) return fail(NRS_ERR_UNSUPPORTED, "model description outside configs/nerf/base.json's architecture");
+	LevelParams lv[kLevels];
+	make_levels(*d, lv);
+	for (uint32_t l = 0; l < d->n_levels; ++l) {
+		if (scale) scale[l] = lv[l].scale;
+		if (resolution) resolution[l] = lv[l].resolution;
+		if (entry_offset) entry_offset[l] = lv[l].offset;
+		if (entry_count) entry_count[l] = lv[l].count;
+		if (hashed) hashed[l] = lv[l].hashed;
+	}
+	return NRS_OK;
+}
+
+int nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out) {
+	if (!ctx || !desc || !out) return fail(NRS_ERR_INVALID_ARG, "nrs_model_create: NULL argument");
+	if (!desc_supported(*desc)) return fail(NRS_ERR_UNSUPPORTED, "model description outside configs/nerf/base.json's architecture");
+	for (int k = 0; k < 3; ++k)
+		if (!(desc->aabb_max[k] > desc->aabb_min[k])) return fail(NRS_ERR_INVALID_ARG, "nrs_model_create: empty aabb");
+	HIP_TRY(hipSetDevice(ctx->device));
+	nrs_model* m = new (std::nothrow) nrs_model();
+	if (!m) return fail(NRS_ERR_STATE, "out of host memory");
+	m->ctx = ctx;
+	m->desc = *desc;
+	m->total_entries = make_levels(*desc, m->dm.levels);
+	for (int k = 0; k < 3; ++k) { m->dm.aabb.mn[k] = desc->aabb_min[k]; m->dm.aabb.mx[k] = desc->aabb_max[k]; }
+	m->dm.rgb_activation = desc->rgb_activation;
+	m->dm.density_activation = desc->density_activation;
+	HIP_TRY(hipMalloc((void**)&m->d_grid, (size_t)m->total_entries * 4));
+	HIP_TRY(hipMalloc((void**)&m->d_wfrag, kWfragBytes));
+	HIP_TRY(hipMalloc((void**)&m->d_bitfield, NRS_BITFIELD_BYTES));
+	m->dm.grid = m->d_grid;
+	m->dm.wfrag = m->d_wfrag;
+	m->dm.bitfield = m->d_bitfield;
+	*out = m;
+	return NRS_OK;
+}
+void nrs_model_destroy(nrs_model* m) {
+	if (!m) return;
+	(void)hipFree(m->d_grid);
+	(void)hipFree(m->d_wfrag);
+	(void)hipFree(m->d_bitfield);
+	delete m;
+}
+int nrs_model_set_params(nrs_model* m, const void* h_params_fp16, size_t n_params) {
+	if (!m || !h_params_fp16) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_params: NULL argument");
+	const size_t expect = (size_t)kDensityW + kRgbW + (size_t)m->total_entries * 2;
+	if (n_params != expect) {
+		char buf[160];
+		snprintf(buf, sizeof(buf), "nrs_model_set_params: got %zu params, the description implies %zu", n_params, expect);
+		return fail(NRS_ERR_INVALID_ARG, buf);
+	}
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	const uint16_t* w = (const uint16_t*)h_params_fp16;
+	std::vector<uint16_t> frag(kWfragBytes / 2);
+	make_weight_fragments(w, frag.data());
+	HIP_TRY(hipMemcpy(m->d_wfrag, frag.data(), kWfragBytes, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(m->d_grid, w + kDensityW + kRgbW, (size_t)m->total_entries * 4, hipMemcpyHostToDevice));
+	m->have_params = true;
+	return NRS_OK;
+}
+int nrs_model_set_density_bitfield(nrs_model* m, const uint8_t* h_bitfield, size_t n_bytes) {
+	if (!m || !h_bitfield) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_density_bitfield: NULL argument");
+	if (n_bytes != NRS_BITFIELD_BYTES) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_density_bitfield: expected 5*128^3/8 bytes");
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	HIP_TRY(hipMemcpy(m->d_bitfield, h_bitfield, n_bytes, hipMemcpyHostToDevice));
+	m->have_bitfield = true;
+	return NRS_OK;
+}
+int nrs_model_set_density_grid(nrs_model* m, const float* h_grid, size_t n_floats) {
+	if (!m || !h_grid) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_density_grid: NULL argument");
+	if (n_floats != (size_t)kGridVol * kCascades) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_density_grid: expected 5*128^3 floats");
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	float* d_grid = nullptr;
+	HIP_TRY(hipMalloc((void**)&d_grid, n_floats * 4));
+	hipError_t e = hipMemcpy(d_grid, h_grid, n_floats * 4, hipMemcpyHostToDevice);
+	int s = NRS_OK;
+	if (e == hipSuccess) e = hipMemset(m->d_bitfield, 0, NRS_BITFIELD_BYTES);
+	if (e == hipSuccess) s = launch_grid_to_bitfield(d_grid, m->d_bitfield, m->ctx->d_mean, nullptr);
+	if (e == hipSuccess && s == NRS_OK) e = hipDeviceSynchronize();
+	(void)hipFree(d_grid);
+	if (e != hipSuccess) return fail_hip(e, "nrs_model_set_density_grid");
+	if (s != NRS_OK) return (g_err = launch_last_error(), s);
+	m->have_bitfield = true;
+	return NRS_OK;
+}
+int nrs_model_get_density_bitfield(nrs_model* m, uint8_t* h_out, size_t n_bytes) {
+	if (!m || !h_out || n_bytes != NRS_BITFIELD_BYTES) return fail(NRS_ERR_INVALID_ARG, "nrs_model_get_density_bitfield: bad argument");
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	HIP_TRY(hipMemcpy(h_out, m->d_bitfield, n_bytes, hipMemcpyDeviceToHost));
+	return NRS_OK;
+}
+
+// ---- NerfNetwork operator ------------------------------------------------------------------------------------
+static int check_net(nrs_model* m, const void* in, const void* out, const char* who) {
+	if (!m || !in || !out) return fail(NRS_ERR_INVALID_ARG, std::string(who) + ": NULL argument");
+	if (!m->have_params) return fail(NRS_ERR_STATE, std::string(who) + ": parameters not set (nrs_model_set_params)");
+	return NRS_OK;
+}
+int nrs_network_inference(nrs_model* m, void* stream, uint32_t n, const float* d_in, void* d_out, uint32_t ld_out, int layout) {
+	int s = check_net(m, d_in, d_out, "nrs_network_inference");
+	if (s != NRS_OK) return s;
+	if (layout == NRS_PLANES && ld_out < n) return fail(NRS_ERR_INVALID_ARG, "nrs_network_inference: ld_out < n");
+	NRS_TRY(launch_network(m->dm, 0, n, d_in, NRS_NETWORK_INPUT_FLOATS, d_out, ld_out, layout, m->ctx->n_cus, stream));
+	return NRS_OK;
+}
+int nrs_network_density(nrs_model* m, void* stream, uint32_t n, const float* d_in, uint32_t ld_in, void* d_out, uint32_t ld_out, int layout) {
+	int s = check_net(m, d_in, d_out, "nrs_network_density");
+	if (s != NRS_OK) return s;
+	if (ld_in < 3) return fail(NRS_ERR_INVALID_ARG, "nrs_network_density: ld_in < 3");
+	if (layout == NRS_PLANES && ld_out < n) return fail(NRS_ERR_INVALID_ARG, "nrs_network_density: ld_out < n");
+	NRS_TRY(launch_network(m->dm, 1, n, d_in, ld_in, d_out, ld_out, layout, m->ctx->n_cus, stream));
+	return NRS_OK;
+}
+int nrs_hashgrid_encode(nrs_model* m, void* stream, uint32_t n, const float* d_in, uint32_t ld_in, void* d_out) {
+	int s = check_net(m, d_in, d_out, "nrs_hashgrid_encode");
+	if (s != NRS_OK) return s;
+	if (ld_in < 3) return fail(NRS_ERR_INVALID_ARG, "nrs_hashgrid_encode: ld_in < 3");
+	NRS_TRY(launch_network(m->dm, 2, n, d_in, ld_in, d_out, 0, NRS_INTERLEAVED, m->ctx->n_cus, stream));
+	return NRS_OK;
+}
+
+// ---- edit operators ------------------------------------------------------------------------------------------------
+int nrs_edit_create(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_tet_mesh* mesh, nrs_edit** out) {
+	if (!ctx || !desc || !mesh || !out) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create: NULL argument");
+	if (!mesh->h_vertices || !mesh->h_original_vertices || !mesh->h_tets || !mesh->h_lut_offsets || !mesh->h_original_bitfield)
+		return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create: missing mesh array");
+	if (mesh->n_tets == 0 || mesh->n_vertices == 0) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create: empty mesh");
+	if (mesh->apply_poisson && (!mesh->h_boundary_shs || !mesh->h_boundary_outside_density || !mesh->h_boundary_residual_density))
+		return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create: apply_poisson set without the per-vertex membrane arrays");
+	for (size_t i = 0; i < 4 * (size_t)mesh->n_tets; ++i)
+		if (mesh->h_tets[i] >= mesh->n_vertices) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create: tet index out of range");
+	const size_t n_cells = (size_t)kGridVol * kCascades;
+	const uint32_t n_idx = mesh->h_lut_offsets[n_cells];
+	if (n_idx && !mesh->h_lut_idx) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create: h_lut_idx is NULL");
+	HIP_TRY(hipSetDevice(ctx->device));
+	nrs_edit* e = new (std::nothrow) nrs_edit();
+	if (!e) return fail(NRS_ERR_STATE, "out of host memory");
+	e->ctx = ctx;
+	DeviceEdit& de = e->de;
+	for (int k = 0; k < 3; ++k) { de.aabb.mn[k] = desc->aabb_min[k]; de.aabb.mx[k] = desc->aabb_max[k]; }
+	Box3 orig_bbox;
+	box_of(mesh->h_vertices, mesh->n_vertices, de.bbox);           // post_update_vertices, tet_mesh.cu:12-20
+	warp_box(de.bbox, de.aabb, de.warped_bbox);
+	box_of(mesh->h_original_vertices, mesh->n_vertices, orig_bbox); // ctor, tet_mesh.h:100-107
+	warp_box(orig_bbox, de.aabb, de.orig_warped_bbox);
+	int s = NRS_OK;
+	auto chk = [&](int r) { if (s == NRS_OK) s = r; };
+	chk(upload(e, mesh->h_vertices, 3 * (size_t)mesh->n_vertices, &de.verts));
+	chk(upload(e, mesh->h_original_vertices, 3 * (size_t)mesh->n_vertices, &de.orig));
+	chk(upload(e, mesh->h_tets, 4 * (size_t)mesh->n_tets, &de.tets));
+	chk(upload(e, mesh->h_lut_offsets, n_cells + 1, &de.lut_off));
+	chk(upload(e, mesh->h_lut_idx, (size_t)n_idx, &de.lut_idx));
+	chk(upload(e, mesh->h_original_bitfield, (size_t)NRS_BITFIELD_BYTES, &de.orig_bitfield));
+	if (mesh->h_local_rotations) chk(upload(e, mesh->h_local_rotations, 9 * (size_t)mesh->n_tets, &de.rot));
+	de.copy = mesh->copy;
+	de.apply_poisson = mesh->apply_poisson;
+	de.residual_amplitude = mesh->residual_amplitude;
+	if (mesh->apply_poisson) {
+		chk(upload(e, mesh->h_boundary_shs, 27 * (size_t)mesh->n_vertices, &de.shs));
+		chk(upload(e, mesh->h_boundary_outside_density, (size_t)mesh->n_vertices, &de.out_density));
+		chk(upload(e, mesh->h_boundary_residual_density, (size_t)mesh->n_vertices, &de.res_density));
+	}
+	if (s != NRS_OK) { nrs_edit_destroy(e); return s; }
+	*out = e;
+	return NRS_OK;
+}
+void nrs_edit_destroy(nrs_edit* e) {
+	if (!e) return;
+	for (void* p : e->allocs) (void)hipFree(p);
+	delete e;
+}
+int nrs_edit_map_rays(nrs_edit* e, void* stream, uint32_t n, float* d_coords, uint8_t* d_empty_mask) {
+	if (!e || !d_coords || !d_empty_mask) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_map_rays: NULL argument");
+	NRS_TRY(launch_map_rays(e->de, n, d_coords, NRS_NETWORK_INPUT_FLOATS, 1, d_empty_mask, stream));
+	return NRS_OK;
+}
+int nrs_edit_map_positions(nrs_edit* e, void* stream, uint32_t n, float* d_pos, uint32_t ld, uint8_t* d_empty_mask) {
+	if (!e || !d_pos || !d_empty_mask) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_map_positions: NULL argument");
+	if (ld < 3) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_map_positions: ld < 3");
+	NRS_TRY(launch_map_rays(e->de, n, d_pos, ld, 0, d_empty_mask, stream));
+	return NRS_OK;
+}
+
+// ---- renderer --------------------------------------------------------------------------------------------------------
+static int tile_geometry(const nrs_render_params& p, uint32_t& tiles_x, uint32_t& owned, uint32_t& n_packets, uint32_t& ppt_x) {
+	const uint32_t W = (uint32_t)p.resolution[0], H = (uint32_t)p.resolution[1];
+	if (p.tile_size == 0) {
+		tiles_x = (W + 7) / 8;
+		owned = 1;
+		ppt_x = 0;
+		n_packets = tiles_x * ((H + 7) / 8);
+		return NRS_OK;
+	}
+	if (p.tile_size % 8) return fail(NRS_ERR_INVALID_ARG, "tile_size must be a multiple of 8");
+	tiles_x = (W + p.tile_size - 1) / p.tile_size;
+	const uint32_t tiles_y = (H + p.tile_size - 1) / p.tile_size, total = tiles_x * tiles_y;
+	const uint32_t stride = p.tile_stride ? p.tile_stride : 1;
+	owned = p.tile_first < total ? (total - p.tile_first + stride - 1) / stride : 0;
+	ppt_x = p.tile_size / 8;
+	n_packets = owned * ppt_x * ppt_x;
+	return NRS_OK;
+}
+uint32_t nrs_render_owned_tiles(const nrs_render_params* p) {
+	if (!p || p->resolution[0] <= 0 || p->resolution[1] <= 0) return 0;
+	uint32_t tx, owned, np, ppt;
+	if (tile_geometry(*p, tx, owned, np, ppt) != NRS_OK) return 0;
+	return owned;
+}
+
+int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* edits, int n_edits, float* d_frame, float* d_depth,
+                    uint32_t* d_steps, void* stream, nrs_render_stats* h_stats) {
+	if (!m || !p || !d_frame || !d_depth) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: NULL argument");
+	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_render_nerf: parameters not set (nrs_model_set_params)");
+	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_render_nerf: occupancy not set (nrs_model_set_density_bitfield/_grid)");
+	if (p->resolution[0] <= 0 || p->resolution[1] <= 0 || p->resolution[0] > 65535 || p->resolution[1] > 65535)
+		return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: resolution out of range (1..65535)");
+	if (p->render_mode != NRS_RENDER_SHADE && p->render_mode != NRS_RENDER_COST)
+		return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: only render modes Shade and Cost are implemented (debug visualisations are out of scope)");
+	if (n_edits < 0 || n_edits > nrs_ctx::kMaxEdits) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: too many edit operators");
+	if (n_edits > 0 && !edits) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: edits is NULL");
+	nrs_ctx* ctx = m->ctx;
+	HIP_TRY(hipSetDevice(ctx->device));
+	hipStream_t s = (hipStream_t)stream;
+
+	RenderArgs a{};
+	a.p = *p;
+	uint32_t owned_tiles = 0;
+	int st = tile_geometry(*p, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x);
+	if (st != NRS_OK) return st;
+	a.n_edits = n_edits;
+	a.any_poisson = 0;
+	if (n_edits > 0) {
+		DeviceEdit host_edits[nrs_ctx::kMaxEdits];
+		for (int i = 0; i < n_edits; ++i) {
+			if (!edits[i]) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: NULL edit operator");
+			host_edits[i] = edits[i]->de;
+			a.any_poisson |= edits[i]->de.apply_poisson;
+		}
+		HIP_TRY(hipMemcpyAsync(ctx->d_edits, host_edits, sizeof(DeviceEdit) * n_edits, hipMemcpyHostToDevice, s));
+	}
+	if (a.any_poisson) return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: membrane (Poisson) correction is not implemented in this build");
+	a.edits = ctx->d_edits;
+	a.max_steps = p->max_march_steps ? p->max_march_steps : 10000u; // MARCH_ITER, testbed_nerf.cu:56
+	a.frame = d_frame;
+	a.depth = d_depth;
+	a.steps = d_steps;
+	a.counters = ctx->d_counters;
+	HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(RenderCounters), s));
+	NRS_TRY(launch_render(m->dm, a, ctx->n_cus, s));
+	if (h_stats) {
+		RenderCounters c;
+		HIP_TRY(hipMemcpyAsync(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		h_stats->n_samples = c.n_samples;
+		h_stats->n_rays_alive = c.n_rays_alive;
+		h_stats->n_rays_hit = c.n_rays_hit;
+	}
+	return NRS_OK;
+}
+
+int nrs_detile(nrs_ctx* ctx, void* stream, const nrs_render_params* p, uint32_t n_ranks, uint32_t tiles_per_rank_padded, const float* d_tiles,
+               uint32_t channels, float* d_image) {
+	if (!ctx || !p || !d_tiles || !d_image) return fail(NRS_ERR_INVALID_ARG, "nrs_detile: NULL argument");
+	if (p->tile_size == 0 || p->tile_size % 8 || n_ranks == 0 || channels == 0) return fail(NRS_ERR_INVALID_ARG, "nrs_detile: bad tiling");
+	HIP_TRY(hipSetDevice(ctx->device));
+	NRS_TRY(launch_detile(*p, n_ranks, tiles_per_rank_padded, d_tiles, channels, d_image, stream));
+	return NRS_OK;
+}
+
+int nrs_trace_samples(nrs_model* m, const nrs_render_params* p, void* stream, uint32_t n_pixels, const uint32_t* d_pixel_idx, uint32_t max_samples,
+                      float* d_t, float* d_dt, uint32_t* d_count) {
+	if (!m || !p || !d_pixel_idx || !d_t || !d_dt || !d_count) return fail(NRS_ERR_INVALID_ARG, "nrs_trace_samples: NULL argument");
+	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_trace_samples: occupancy not set");
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	NRS_TRY(launch_trace_samples(m->dm, *p, n_pixels, d_pixel_idx, max_samples, d_t, d_dt, d_count, stream));
+	return NRS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,335 @@
+// nrs_authoring.cpp -- host-side edit authoring behind include/nrs.h: cell->tet LUT builder, MVC weights, per-tet
+// rotations.  SURVEY 8(f) row 1: the steps that run on the CPU in the reference too, immediately BEFORE the render path
+// on every gizmo move.  They are here so a cage edit can be produced without the reference's GUI; a device version of
+// the LUT builder is later-round work.  No HIP calls: usable without a GPU.
+//
+//   nrs_tet_lut_build        TetMesh::build_tet_grid / build_original_tet_grid   src/editing/datastructures/tet_mesh.cu:368 / :76
+//   nrs_mvc_compute / apply  Cage::compute_mvc / interpolate_with_mvc            src/editing/datastructures/cage.cu:6 / :38,
+//                            MVC3D::computeCoordinatesCustomCode                 include/.../editing/tools/mvc.h:125-188
+//   nrs_tet_local_rotations  TetMesh::update_local_rotations                     tet_mesh.cu:37-74
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "nrs_internal.h"
+
+using namespace nrs;
+
+namespace {
+
+struct P3 { float x, y, z; };
+inline P3 sub(P3 a, P3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline P3 add(P3 a, P3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline P3 mul(P3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline float dotp(P3 a, P3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline P3 crossp(P3 a, P3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float at(const P3& p, int i) { return i == 0 ? p.x : (i == 1 ? p.y : p.z); }
+
+inline uint32_t spread3(uint32_t v) {
+	v = (v * 0x00010001u) & 0xFF0000FFu;
+	v = (v * 0x00000101u) & 0x0F00F00Fu;
+	v = (v * 0x00000011u) & 0xC30C30C3u;
+	v = (v * 0x00000005u) & 0x49249249u;
+	return v;
+}
+inline uint32_t morton(uint32_t x, uint32_t y, uint32_t z) { return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2); }
+
+inline bool same_side(P3 v1, P3 v2, P3 v3, P3 v4, P3 p) { // selection_utils.h:33-39
+	P3 n = crossp(sub(v2, v1), sub(v3, v1));
+	return std::signbit(dotp(n, sub(v4, v1))) == std::signbit(dotp(n, sub(p, v1)));
+}
+inline bool in_tet(const P3 t[4], P3 p) { // selection_utils.h:41-47
+	return same_side(t[0], t[1], t[2], t[3], p) && same_side(t[1], t[2], t[3], t[0], p) && same_side(t[2], t[3], t[0], t[1], p) &&
+	       same_side(t[3], t[0], t[1], t[2], p);
+}
+
+inline void span(const P3* pts, int n, P3 axis, float& lo, float& hi) {
+	lo = std::numeric_limits<float>::infinity();
+	hi = -lo;
+	for (int i = 0; i < n; ++i) {
+		float v = dotp(axis, pts[i]);
+		if (v < lo) lo = v;
+		if (v > hi) hi = v;
+	}
+}
+// BoundingBox::intersects(Triangle), bounding_box.cuh:126-178 (separating axes: 3 box normals, the triangle normal,
+// 9 edge x axis products)
+bool cube_hits_triangle(P3 bmin, P3 bmax, P3 a, P3 b, P3 c) {
+	const P3 axes[3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+	P3 tri[3] = {a, b, c};
+	float tlo, thi, blo, bhi;
+	for (int i = 0; i < 3; ++i) {
+		span(tri, 3, axes[i], tlo, thi);
+		if (thi < at(bmin, i) || tlo > at(bmax, i)) return false;
+	}
+	P3 n = crossp(sub(b, a), sub(c, a));
+	const float len = std::sqrt(dotp(n, n));
+	n = {n.x / len, n.y / len, n.z / len};
+	const P3 corners[8] = {{bmin.x, bmin.y, bmin.z}, {bmin.x, bmin.y, bmax.z}, {bmin.x, bmax.y, bmin.z}, {bmin.x, bmax.y, bmax.z},
+	                       {bmax.x, bmin.y, bmin.z}, {bmax.x, bmin.y, bmax.z}, {bmax.x, bmax.y, bmin.z}, {bmax.x, bmax.y, bmax.z}};
+	const float off = dotp(n, a);
+	span(corners, 8, n, blo, bhi);
+	if (bhi < off || blo > off) return false;
+	const P3 edges[3] = {sub(a, b), sub(a, c), sub(b, c)};
+	for (int i = 0; i < 3; ++i)
+		for (int j = 0; j < 3; ++j) {
+			P3 ax = crossp(edges[i], axes[j]);
+			span(corners, 8, ax, blo, bhi);
+			span(tri, 3, ax, tlo, thi);
+			if (bhi < tlo || blo > thi) return false;
+		}
+	return true;
+}
+
+inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+inline void cell_of(P3 p, uint32_t level, int out[3]) { // get_cell_at_pos, selection_utils.cu:70-83
+	const float s = std::scalbn(1.0f, -(int)level);
+	p = sub(p, {0.5f, 0.5f, 0.5f});
+	p = mul(p, s);
+	p = add(p, {0.5f, 0.5f, 0.5f});
+	out[0] = clampi((int)(p.x * (float)kGrid), 0, kGrid - 1);
+	out[1] = clampi((int)(p.y * (float)kGrid), 0, kGrid - 1);
+	out[2] = clampi((int)(p.z * (float)kGrid), 0, kGrid - 1);
+}
+inline P3 cell_centre(uint32_t x, uint32_t y, uint32_t z, uint32_t level) { // get_cell_pos, selection_utils.cu:65-68
+	const float s = std::scalbn(1.0f, (int)level);
+	return {(((float)x + 0.5f) / (float)kGrid - 0.5f) * s + 0.5f, (((float)y + 0.5f) / (float)kGrid - 0.5f) * s + 0.5f,
+	        (((float)z + 0.5f) / (float)kGrid - 0.5f) * s + 0.5f};
+}
+const P3 kCorners[8] = {{-0.5f, -0.5f, -0.5f}, {-0.5f, -0.5f, 0.5f}, {-0.5f, 0.5f, -0.5f}, {0.5f, -0.5f, -0.5f},
+                        {0.5f, 0.5f, -0.5f}, {-0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.5f, 0.5f, 0.5f}}; // tet_mesh.h:34-43
+
+struct Mark { uint32_t cell, tet; };
+
+// first pass of build_tet_grid for tets [t0, t1): which (cell, tet) pairs exist
+void mark_range(const P3* verts, const uint32_t* tets, uint32_t t0, uint32_t t1, std::vector<Mark>& marks) {
+	for (uint32_t i = t0; i < t1; ++i) {
+		const P3 tv[4] = {verts[tets[4 * i]], verts[tets[4 * i + 1]], verts[tets[4 * i + 2]], verts[tets[4 * i + 3]]};
+		const float inf = std::numeric_limits<float>::infinity();
+		P3 lo = {inf, inf, inf}, hi = {-inf, -inf, -inf};
+		for (int j = 0; j < 4; ++j) {
+			lo = {std::fmin(lo.x, tv[j].x), std::fmin(lo.y, tv[j].y), std::fmin(lo.z, tv[j].z)};
+			hi = {std::fmax(hi.x, tv[j].x), std::fmax(hi.y, tv[j].y), std::fmax(hi.z, tv[j].z)};
+		}
+		for (uint32_t level = 0; level < kCascades; ++level) {
+			const float cell = std::scalbn(1.0f, (int)level) * (1.0f / (float)kGrid); // cell edge at this cascade
+			int c0[3], c1[3];
+			cell_of(lo, level, c0);
+			cell_of(hi, level, c1);
+			for (int x = c0[0]; x <= c1[0]; ++x)
+				for (int y = c0[1]; y <= c1[1]; ++y)
+					for (int z = c0[2]; z <= c1[2]; ++z) {
+						const P3 ctr = cell_centre((uint32_t)x, (uint32_t)y, (uint32_t)z, level);
+						bool hit = false;
+						for (int k = 0; k < 8 && !hit; ++k) hit = in_tet(tv, add(ctr, mul(kCorners[k], cell)));
+						if (!hit) {
+							const P3 h = mul({0.5f, 0.5f, 0.5f}, cell);
+							const P3 a = sub(ctr, h), b = add(ctr, h);
+							const P3 bmin = {std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmin(a.z, b.z)};
+							const P3 bmax = {std::fmax(a.x, b.x), std::fmax(a.y, b.y), std::fmax(a.z, b.z)};
+							for (int j = 0; j < 4 && !hit; ++j) hit = cube_hits_triangle(bmin, bmax, tv[j], tv[(j + 1) % 4], tv[(j + 2) % 4]);
+						}
+						if (hit) marks.push_back({level * kGridVol + morton((uint32_t)x, (uint32_t)y, (uint32_t)z), i});
+					}
+		}
+	}
+}
+
+} // namespace
+
+struct nrs_tet_lut {
+	std::vector<uint32_t> offsets, idx;
+	std::vector<uint8_t> bitfield;
+	uint32_t max_per_cell = 0;
+};
+
+static thread_local std::string g_auth_err;
+
+extern "C" {
+
+int nrs_tet_lut_build(const float* h_vertices, uint32_t n_vertices, const uint32_t* h_tets, uint32_t n_tets, int n_threads, nrs_tet_lut** out) {
+	if (!h_vertices || !h_tets || !out || n_tets == 0) return NRS_ERR_INVALID_ARG;
+	for (size_t i = 0; i < 4 * (size_t)n_tets; ++i)
+		if (h_tets[i] >= n_vertices) return NRS_ERR_INVALID_ARG;
+	nrs_tet_lut* lut = new (std::nothrow) nrs_tet_lut();
+	if (!lut) return NRS_ERR_STATE;
+	const P3* verts = reinterpret_cast<const P3*>(h_vertices);
+	uint32_t nt = n_threads > 0 ? (uint32_t)n_threads : std::max(1u, std::thread::hardware_concurrency());
+	nt = std::min(nt, n_tets);
+	// contiguous tet ranges per thread, merged in thread order: within a cell the LUT lists tets in ascending index
+	// (the order the reference's thread-ordered second pass produces, tet_mesh.cu:496-512)
+	std::vector<std::vector<Mark>> marks(nt);
+	std::vector<std::thread> pool;
+	const uint32_t chunk = n_tets / nt;
+	for (uint32_t t = 0; t < nt; ++t) {
+		const uint32_t t0 = chunk * t, t1 = (t == nt - 1) ? n_tets : chunk * (t + 1);
+		pool.emplace_back([&, t, t0, t1]() { mark_range(verts, h_tets, t0, t1, marks[t]); });
+	}
+	for (auto& th : pool) th.join();
+
+	const uint32_t n_cells = kGridVol * kCascades;
+	lut->offsets.assign((size_t)n_cells + 1, 0);
+	lut->bitfield.assign(n_cells / 8, 0);
+	size_t total = 0;
+	for (auto& v : marks) {
+		total += v.size();
+		for (const Mark& mk : v) lut->offsets[(size_t)mk.cell + 1]++;
+	}
+	for (uint32_t c = 0; c < n_cells; ++c) {
+		const uint32_t n_in_cell = lut->offsets[(size_t)c + 1];
+		lut->max_per_cell = std::max(lut->max_per_cell, n_in_cell);
+		if (n_in_cell) lut->bitfield[c / 8] |= (uint8_t)(1u << (c % 8)); // byte (level*128^3 + morton)/8 == morton/8 + level*128^3/8
+		lut->offsets[(size_t)c + 1] = lut->offsets[c] + n_in_cell;
+	}
+	lut->idx.assign(total, 0);
+	std::vector<uint32_t> cursor(lut->offsets.begin(), lut->offsets.end() - 1);
+	for (auto& v : marks)
+		for (const Mark& mk : v) lut->idx[cursor[mk.cell]++] = mk.tet;
+	*out = lut;
+	return NRS_OK;
+}
+uint32_t nrs_tet_lut_n_idx(const nrs_tet_lut* l) { return l ? (uint32_t)l->idx.size() : 0; }
+uint32_t nrs_tet_lut_max_per_cell(const nrs_tet_lut* l) { return l ? l->max_per_cell : 0; }
+const uint32_t* nrs_tet_lut_offsets(const nrs_tet_lut* l) { return l ? l->offsets.data() : nullptr; }
+const uint32_t* nrs_tet_lut_idx(const nrs_tet_lut* l) { return l ? l->idx.data() : nullptr; }
+const uint8_t* nrs_tet_lut_bitfield(const nrs_tet_lut* l) { return l ? l->bitfield.data() : nullptr; }
+void nrs_tet_lut_destroy(nrs_tet_lut* l) { delete l; }
+
+// mean value coordinates, Ju/Schaefer/Warren 2005 as coded in mvc.h:125-188 (float_t = float, growing_selection.h:89)
+int nrs_mvc_compute(const float* h_cage_vertices, uint32_t n_cv, const uint32_t* h_cage_triangles, uint32_t n_tris, const float* h_points,
+                    uint32_t n_points, float* h_weights_out, uint8_t* h_labels_out) {
+	if (!h_cage_vertices || !h_cage_triangles || !h_points || !h_weights_out || n_cv == 0) return NRS_ERR_INVALID_ARG;
+	for (size_t i = 0; i < 3 * (size_t)n_tris; ++i)
+		if (h_cage_triangles[i] >= n_cv) return NRS_ERR_INVALID_ARG;
+	const P3* cv = reinterpret_cast<const P3*>(h_cage_vertices);
+	const float eps = 0.00000001f;
+	std::vector<float> dist(n_cv), acc(n_cv);
+	std::vector<P3> unit(n_cv);
+	for (uint32_t pi = 0; pi < n_points; ++pi) {
+		const P3 eta = {h_points[3 * pi], h_points[3 * pi + 1], h_points[3 * pi + 2]};
+		float* w_out = h_weights_out + (size_t)pi * n_cv;
+		std::fill(w_out, w_out + n_cv, 0.f);
+		bool early = false;
+		for (uint32_t v = 0; v < n_cv && !early; ++v) {
+			const P3 e = sub(eta, cv[v]);
+			dist[v] = std::sqrt(dotp(e, e));
+			if (dist[v] < eps) { w_out[v] = 1.0f; early = true; break; }
+			const P3 q = sub(cv[v], eta);
+			unit[v] = {q.x / dist[v], q.y / dist[v], q.z / dist[v]};
+		}
+		if (!early) {
+			std::fill(acc.begin(), acc.end(), 0.f);
+			float sum = 0.f;
+			for (uint32_t t = 0; t < n_tris && !early; ++t) {
+				const uint32_t id[3] = {h_cage_triangles[3 * t], h_cage_triangles[3 * t + 1], h_cage_triangles[3 * t + 2]};
+				float len[3], theta[3], w[3], c[3], s[3];
+				for (int i = 0; i < 3; ++i) {
+					const P3 q = sub(unit[id[(i + 1) % 3]], unit[id[(i + 2) % 3]]);
+					len[i] = std::sqrt(dotp(q, q));
+					theta[i] = (float)(2.0 * std::asin((double)len[i] / 2.0));
+				}
+				const float h = (float)((double)(theta[0] + theta[1] + theta[2]) / 2.0);
+				if (M_PI - (double)h < (double)eps) { // eta lies on the triangle: 2-D barycentric
+					for (int i = 0; i < 3; ++i) w[i] = (float)(std::sin((double)theta[i]) * (double)len[(i + 2) % 3] * (double)len[(i + 1) % 3]);
+					const float sw = w[0] + w[1] + w[2];
+					std::fill(w_out, w_out + n_cv, 0.f);
+					for (int i = 0; i < 3; ++i) w_out[id[i]] = w[i] / sw;
+					early = true;
+					break;
+				}
+				for (int i = 0; i < 3; ++i)
+					c[i] = (float)((2.0 * std::sin((double)h) * std::sin((double)(h - theta[i]))) /
+					               (std::sin((double)theta[(i + 1) % 3]) * std::sin((double)theta[(i + 2) % 3])) - 1.0);
+				const float sgn = ((double)dotp(crossp(unit[id[0]], unit[id[1]]), unit[id[2]]) < 0.0) ? -1.f : 1.f;
+				for (int i = 0; i < 3; ++i) s[i] = (float)((double)sgn * std::sqrt(std::max(0.0, 1.0 - (double)(c[i] * c[i]))));
+				if (std::fabs(s[0]) < eps || std::fabs(s[1]) < eps || std::fabs(s[2]) < eps) continue; // coplanar, outside the triangle
+				for (int i = 0; i < 3; ++i)
+					w[i] = (float)(((double)(theta[i] - c[(i + 1) % 3] * theta[(i + 2) % 3] - c[(i + 2) % 3] * theta[(i + 1) % 3])) /
+					               (2.0 * (double)dist[id[i]] * std::sin((double)theta[(i + 1) % 3]) * (double)s[(i + 2) % 3]));
+				sum += (w[0] + w[1] + w[2]);
+				acc[id[0]] += w[0]; acc[id[1]] += w[1]; acc[id[2]] += w[2];
+			}
+			if (!early)
+				for (uint32_t v = 0; v < n_cv; ++v) w_out[v] = acc[v] / sum;
+		}
+		// Cage::compute_mvc sets labels[i] = 1 when the routine returns false, i.e. on the regular path (cage.cu:19-21)
+		if (h_labels_out) h_labels_out[pi] = early ? 0 : 1;
+	}
+	return NRS_OK;
+}
+
+int nrs_mvc_apply(const float* h_weights, const float* h_cage_vertices, uint32_t n_cv, uint32_t n_points, float* h_points_out) {
+	if (!h_weights || !h_cage_vertices || !h_points_out) return NRS_ERR_INVALID_ARG;
+	for (uint32_t i = 0; i < n_points; ++i) { // cage.cu:38-49: points[i] += weights[i][v] * vertices[v], v ascending
+		P3 p = {0.f, 0.f, 0.f};
+		for (uint32_t v = 0; v < n_cv; ++v) {
+			const float w = h_weights[(size_t)i * n_cv + v];
+			p = add(p, {w * h_cage_vertices[3 * v], w * h_cage_vertices[3 * v + 1], w * h_cage_vertices[3 * v + 2]});
+		}
+		h_points_out[3 * i] = p.x; h_points_out[3 * i + 1] = p.y; h_points_out[3 * i + 2] = p.z;
+	}
+	return NRS_OK;
+}
+
+// Polar rotation of a 3x3 correlation matrix by Higham's scaled Newton iteration on the polar factor (double).
+// For C = U S V^T the orthogonal polar factor is U V^T -- exactly the R the reference forms from its approximate SVD
+// (tet_mesh.cu:66-70); degenerate (rank-deficient) C falls back to the identity.
+static void polar_rotation(const double C[9], double R[9]) {
+	double X[9];
+	memcpy(X, C, sizeof(X));
+	auto det3 = [](const double* m) {
+		return m[0] * (m[4] * m[8] - m[7] * m[5]) - m[3] * (m[1] * m[8] - m[7] * m[2]) + m[6] * (m[1] * m[5] - m[4] * m[2]);
+	};
+	for (int it = 0; it < 100; ++it) {
+		const double d = det3(X);
+		if (std::fabs(d) < 1e-300) { // singular: no unique rotation
+			for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+			return;
+		}
+		double inv_t[9]; // inverse transpose = cofactor / det (column-major indices m[3*col + row])
+		inv_t[0] = (X[4] * X[8] - X[7] * X[5]) / d; inv_t[3] = (X[7] * X[2] - X[1] * X[8]) / d; inv_t[6] = (X[1] * X[5] - X[4] * X[2]) / d;
+		inv_t[1] = (X[6] * X[5] - X[3] * X[8]) / d; inv_t[4] = (X[0] * X[8] - X[6] * X[2]) / d; inv_t[7] = (X[3] * X[2] - X[0] * X[5]) / d;
+		inv_t[2] = (X[3] * X[7] - X[6] * X[4]) / d; inv_t[5] = (X[6] * X[1] - X[0] * X[7]) / d; inv_t[8] = (X[0] * X[4] - X[3] * X[1]) / d;
+		double nx = 0, ni = 0;
+		for (int i = 0; i < 9; ++i) { nx += X[i] * X[i]; ni += inv_t[i] * inv_t[i]; }
+		const double gamma = std::sqrt(std::sqrt(ni / nx));
+		double diff = 0;
+		for (int i = 0; i < 9; ++i) {
+			const double nv = 0.5 * (gamma * X[i] + inv_t[i] / gamma);
+			diff = std::max(diff, std::fabs(nv - X[i]));
+			X[i] = nv;
+		}
+		if (diff < 1e-14) break;
+	}
+	memcpy(R, X, sizeof(X));
+}
+
+int nrs_tet_local_rotations(const float* h_vertices, const float* h_original_vertices, const uint32_t* h_tets, uint32_t n_tets, float* h_out) {
+	if (!h_vertices || !h_original_vertices || !h_tets || !h_out) return NRS_ERR_INVALID_ARG;
+	const P3* def = reinterpret_cast<const P3*>(h_vertices);
+	const P3* org = reinterpret_cast<const P3*>(h_original_vertices);
+	for (uint32_t i = 0; i < n_tets; ++i) {
+		P3 c0 = {0, 0, 0}, c1 = {0, 0, 0};
+		for (int j = 0; j < 4; ++j) { c0 = add(c0, org[h_tets[4 * i + j]]); c1 = add(c1, def[h_tets[4 * i + j]]); }
+		c0 = {c0.x / 4.f, c0.y / 4.f, c0.z / 4.f};
+		c1 = {c1.x / 4.f, c1.y / 4.f, c1.z / 4.f};
+		double C[9] = {0};
+		for (int j = 0; j < 4; ++j) {
+			const P3 a = sub(org[h_tets[4 * i + j]], c0), b = sub(def[h_tets[4 * i + j]], c1);
+			const float av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
+			for (int r = 0; r < 3; ++r)
+				for (int c = 0; c < 3; ++c) C[3 * c + r] += (double)(av[r] * bv[c]);
+		}
+		double R[9];
+		polar_rotation(C, R);
+		for (int k = 0; k < 9; ++k) h_out[9 * (size_t)i + k] = (float)R[k];
+	}
+	return NRS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,394 @@
+// nrs_device.cuh -- per-ray / per-sample device math of the render path for gfx950.
+//
+// Everything here is plain fp32/u32 arithmetic whose operation ORDER is part of the contract: the file is
+// compiled with -ffp-contract=off and the only fused multiply-adds are explicit fmaf(), so that the
+// (t, dt, mip, cell) stream of every ray is bit-identical to the CPU oracle.  Citations are file:line in the
+// reference checkout ("tn" = src/testbed_nerf.cu, "cn" = src/common_nerf.cu).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "nrs_internal.h"
+
+namespace nrs {
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+__device__ __forceinline__ bool box_contains(const Box3& b, f3 p) { // BoundingBox::contains, bounding_box.cuh:243
+	return p.x >= b.mn[0] && p.x <= b.mx[0] && p.y >= b.mn[1] && p.y <= b.mx[1] && p.z >= b.mn[2] && p.z <= b.mx[2];
+}
+
+// ---- constants (common_nerf.h:16-39) ------------------------------------------------------------------------
+#define NRS_SQRT3 1.73205080757f
+#define NRS_MIN_STEP (NRS_SQRT3 / 1024)
+#define NRS_MAX_STEP (NRS_MIN_STEP * (1 << (kCascades - 1)) * 1024 / kGrid)
+#define NRS_NEAR_DISTANCE 0.05f
+
+// ---- Morton (tcnn morton3D; x in the lowest bit) --------------------------------------------------------------
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
+	v = (v * 0x00010001u) & 0xFF0000FFu;
+	v = (v * 0x00000101u) & 0x0F00F00Fu;
+	v = (v * 0x00000011u) & 0xC30C30C3u;
+	v = (v * 0x00000005u) & 0x49249249u;
+	return v;
+}
+__device__ __forceinline__ uint32_t morton3D(uint32_t x, uint32_t y, uint32_t z) {
+	return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+__device__ __forceinline__ uint32_t morton3D_invert(uint32_t x) {
+	x = x & 0x49249249u;
+	x = (x | (x >> 2)) & 0xc30c30c3u;
+	x = (x | (x >> 4)) & 0x0f00f00fu;
+	x = (x | (x >> 8)) & 0xff0000ffu;
+	x = (x | (x >> 16)) & 0x0000ffffu;
+	return x;
+}
+
+// ---- scrambled Sobol (random_val.cuh:159-288, 317-322); dims 0 and 1 only ---------------------------------------
+// dim 0 direction numbers are 0x80000000 >> bit, i.e. sobol(index, 0) = bit reversal of the index;
+// dim 1 obeys v[b] = v[b-1] ^ (v[b-1] >> 1).
+__device__ __forceinline__ uint32_t sobol_dim0(uint32_t index) { return __brev(index); }
+__device__ __forceinline__ uint32_t sobol_dim1(uint32_t index) {
+	uint32_t X = 0, v = 0x80000000u;
+	#pragma unroll
+	for (uint32_t bit = 0; bit < 32; ++bit) {
+		X ^= ((index >> bit) & 1u) ? v : 0u;
+		v ^= v >> 1;
+	}
+	return X;
+}
+__device__ __forceinline__ uint32_t hash_combine(uint32_t seed, uint32_t v) { return seed ^ (v + (seed << 6) + (seed >> 2)); }
+__device__ __forceinline__ uint32_t laine_karras_permutation(uint32_t x, uint32_t seed) {
+	x += seed;
+	x ^= x * 0x6c50b47cu;
+	x ^= x * 0xb82f1e52u;
+	x ^= x * 0xc7afe638u;
+	x ^= x * 0x8d22f6e6u;
+	return x;
+}
+__device__ __forceinline__ uint32_t nested_uniform_scramble_base2(uint32_t x, uint32_t seed) {
+	x = __brev(x);
+	x = laine_karras_permutation(x, seed);
+	x = __brev(x);
+	return x;
+}
+#define NRS_SOBOL_S 2.3283064365386963e-10f /* float(1.0 / 2^32) */
+__device__ __forceinline__ float ld_random_val(uint32_t index, uint32_t seed) { // dim 0
+	index = nested_uniform_scramble_base2(index, seed);
+	return (float)nested_uniform_scramble_base2(sobol_dim0(index), hash_combine(seed, 0u)) * NRS_SOBOL_S;
+}
+__device__ __forceinline__ void ld_random_val_2d(uint32_t index, uint32_t seed, float& a, float& b) {
+	index = nested_uniform_scramble_base2(index, seed);
+	a = (float)nested_uniform_scramble_base2(sobol_dim0(index), hash_combine(seed, 0u)) * NRS_SOBOL_S;
+	b = (float)nested_uniform_scramble_base2(sobol_dim1(index), hash_combine(seed, 1u)) * NRS_SOBOL_S;
+}
+__device__ __forceinline__ float fractf_(float x) { return x - floorf(x); }
+__device__ __forceinline__ void ld_random_pixel_offset(uint32_t spp, float& ox, float& oy) {
+	float a0, a1, b0, b1;
+	ld_random_val_2d(0u, 0xdeadbeefu, a0, a1);
+	ld_random_val_2d(spp, 0xdeadbeefu, b0, b1);
+	ox = fractf_((0.5f - a0) + b0);
+	oy = fractf_((0.5f - a1) + b1);
+}
+
+// ---- step / grid math (cn:80-177) -------------------------------------------------------------------------------
+__device__ __forceinline__ float clampf_(float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); }
+__device__ __forceinline__ float calc_dt(float t, float cone_angle) { return clampf_(t * cone_angle, NRS_MIN_STEP, NRS_MAX_STEP); }
+__device__ __forceinline__ float signf_(float x) { return copysignf(1.0f, x); }
+
+// frexpf's exponent: x = m * 2^e, 0.5 <= |m| < 1; 0 for x == 0
+__device__ __forceinline__ int frexp_exponent(float x) {
+	uint32_t u = __float_as_uint(x) & 0x7fffffffu;
+	if (u == 0) return 0;
+	uint32_t ef = u >> 23;
+	if (ef == 0) return -117 - __clz((int)u);
+	return (int)ef - 126;
+}
+__device__ __forceinline__ float distance_to_next_voxel(f3 pos, f3 dir, f3 idir, uint32_t res) {
+	f3 p = (float)res * pos;
+	float tx = (floorf(p.x + 0.5f + 0.5f * signf_(dir.x)) - p.x) * idir.x;
+	float ty = (floorf(p.y + 0.5f + 0.5f * signf_(dir.y)) - p.y) * idir.y;
+	float tz = (floorf(p.z + 0.5f + 0.5f * signf_(dir.z)) - p.z) * idir.z;
+	float t = fminf(fminf(tx, ty), tz);
+	return fmaxf(t / (float)res, 0.0f);
+}
+__device__ __forceinline__ float advance_to_next_voxel(float t, float cone_angle, f3 pos, f3 dir, f3 idir, uint32_t res) {
+	float t_target = t + distance_to_next_voxel(pos, dir, idir, res);
+	do {
+		t += calc_dt(t, cone_angle);
+	} while (t < t_target);
+	return t;
+}
+__device__ __forceinline__ int clampi_(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ uint32_t cascaded_grid_idx_at(f3 pos, uint32_t mip) {
+	float mip_scale = ldexpf(1.0f, -(int)mip);
+	pos = pos - mk3(0.5f, 0.5f, 0.5f);
+	pos = pos * mip_scale;
+	pos = pos + mk3(0.5f, 0.5f, 0.5f);
+	int ix = (int)(pos.x * (float)kGrid), iy = (int)(pos.y * (float)kGrid), iz = (int)(pos.z * (float)kGrid);
+	return morton3D((uint32_t)clampi_(ix, 0, kGrid - 1), (uint32_t)clampi_(iy, 0, kGrid - 1), (uint32_t)clampi_(iz, 0, kGrid - 1));
+}
+__device__ __forceinline__ bool get_bitfield_at(uint32_t cell_idx, uint32_t level, const uint8_t* __restrict__ bitfield) {
+	return bitfield[cell_idx / 8 + (kGridVol * level) / 8] & (1 << (cell_idx % 8));
+}
+__device__ __forceinline__ bool density_grid_occupied_at(f3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip) {
+	return get_bitfield_at(cascaded_grid_idx_at(pos, mip), mip, bitfield);
+}
+__device__ __forceinline__ int mip_from_pos(f3 pos) {
+	float maxval = fmaxf(fmaxf(fabsf(pos.x - 0.5f), fabsf(pos.y - 0.5f)), fabsf(pos.z - 0.5f));
+	int exponent = frexp_exponent(maxval);
+	return min((int)kCascades - 1, max(0, exponent + 1));
+}
+__device__ __forceinline__ int mip_from_dt(float dt, f3 pos) {
+	int mip = mip_from_pos(pos);
+	dt *= 2 * kGrid;
+	if (dt < 1.f) return mip;
+	int exponent = frexp_exponent(dt);
+	return min((int)kCascades - 1, max(exponent, mip));
+}
+__device__ __forceinline__ f3 warp_position(f3 pos, const Box3& aabb) {
+	return {(pos.x - aabb.mn[0]) / (aabb.mx[0] - aabb.mn[0]), (pos.y - aabb.mn[1]) / (aabb.mx[1] - aabb.mn[1]),
+	        (pos.z - aabb.mn[2]) / (aabb.mx[2] - aabb.mn[2])};
+}
+__device__ __forceinline__ f3 unwarp_position(f3 pos, const Box3& aabb) {
+	return {aabb.mn[0] + pos.x * (aabb.mx[0] - aabb.mn[0]), aabb.mn[1] + pos.y * (aabb.mx[1] - aabb.mn[1]),
+	        aabb.mn[2] + pos.z * (aabb.mx[2] - aabb.mn[2])};
+}
+__device__ __forceinline__ f3 warp_direction(f3 d) { return {(d.x + 1.0f) * 0.5f, (d.y + 1.0f) * 0.5f, (d.z + 1.0f) * 0.5f}; }
+__device__ __forceinline__ f3 unwarp_direction(f3 d) { return {d.x * 2.0f - 1.0f, d.y * 2.0f - 1.0f, d.z * 2.0f - 1.0f}; }
+__device__ __forceinline__ float warp_dt(float dt) {
+	float max_stepsize = NRS_MIN_STEP * (1 << (kCascades - 1));
+	return (dt - NRS_MIN_STEP) / (max_stepsize - NRS_MIN_STEP);
+}
+__device__ __forceinline__ float unwarp_dt(float dt) {
+	float max_stepsize = NRS_MIN_STEP * (1 << (kCascades - 1));
+	return dt * (max_stepsize - NRS_MIN_STEP) + NRS_MIN_STEP;
+}
+
+// ---- primary rays: pixel_to_ray (common_device.cuh:245-295) + init_rays_with_payload_kernel_nerf (tn:2512-2616) -------
+__device__ __forceinline__ void ray_intersect(const float* mn, const float* mx, f3 pos, f3 dir, float& tmin_out) {
+	const float FMAX = 3.402823466e+38f;
+	float tmin = (mn[0] - pos.x) / dir.x, tmax = (mx[0] - pos.x) / dir.x;
+	if (tmin > tmax) { float s = tmin; tmin = tmax; tmax = s; }
+	float tymin = (mn[1] - pos.y) / dir.y, tymax = (mx[1] - pos.y) / dir.y;
+	if (tymin > tymax) { float s = tymin; tymin = tymax; tymax = s; }
+	if (tmin > tymax || tymin > tmax) { tmin_out = FMAX; return; }
+	if (tymin > tmin) tmin = tymin;
+	if (tymax < tmax) tmax = tymax;
+	float tzmin = (mn[2] - pos.z) / dir.z, tzmax = (mx[2] - pos.z) / dir.z;
+	if (tzmin > tzmax) { float s = tzmin; tzmin = tzmax; tzmax = s; }
+	if (tmin > tzmax || tzmin > tmax) { tmin_out = FMAX; return; }
+	if (tzmin > tmin) tmin = tzmin;
+	tmin_out = tmin;
+}
+
+struct Ray { f3 o, d; float t; bool alive; };
+
+// offset = ld_random_pixel_offset(snap ? 0 : spp), computed once per thread by the caller
+__device__ __forceinline__ Ray init_ray(const nrs_render_params& p, uint32_t x, uint32_t y, float off_x, float off_y) {
+	const float W = (float)p.resolution[0], H = (float)p.resolution[1];
+	const uint32_t idx = x + (uint32_t)p.resolution[0] * y;
+	float u = ((float)x + 0.5f) * (1.f / W);
+	float v = ((float)y + 0.5f) * (1.f / H);
+	float ray_time = p.rolling_shutter[0] + p.rolling_shutter[1] * u + p.rolling_shutter[2] * v;
+	float rs_rand = (p.rolling_shutter[3] != 0.f) ? ld_random_val(p.spp_index, idx * 72239731u) : 0.f; // x * 0 == 0 for finite x
+	ray_time = ray_time + p.rolling_shutter[3] * rs_rand;
+	float cam[12];
+	#pragma unroll
+	for (int i = 0; i < 12; ++i) cam[i] = p.camera_matrix0[i] * ray_time + p.camera_matrix1[i] * (1.f - ray_time);
+	float uvx = ((float)x + off_x) / W;
+	float uvy = ((float)y + off_y) / H;
+	f3 dir = {(uvx - p.screen_center[0]) * W / p.focal_length[0], (uvy - p.screen_center[1]) * H / p.focal_length[1], 1.0f};
+	f3 d = {(cam[0] * dir.x + cam[3] * dir.y) + cam[6] * dir.z,
+	        (cam[1] * dir.x + cam[4] * dir.y) + cam[7] * dir.z,
+	        (cam[2] * dir.x + cam[5] * dir.y) + cam[8] * dir.z};
+	f3 o = {cam[9], cam[10], cam[11]};
+	float n = sqrtf(dot3(d, d));
+	d = {d.x / n, d.y / n, d.z / n};
+	float tmin;
+	ray_intersect(p.render_aabb_min, p.render_aabb_max, o, d, tmin);
+	float t = fmaxf(tmin, NRS_NEAR_DISTANCE) + 1e-6f;
+	Ray r;
+	r.o = o; r.d = d; r.t = t;
+	Box3 bb;
+	#pragma unroll
+	for (int i = 0; i < 3; ++i) { bb.mn[i] = p.render_aabb_min[i]; bb.mx[i] = p.render_aabb_max[i]; }
+	r.alive = box_contains(bb, o + d * t);
+	return r;
+}
+
+// The inner loop shared by advance_pos_nerf (tn:589-603) and generate_next_nerf_network_inputs (tn:668-692):
+// advance t until the ray sits in an occupied cell (returns true; pos/dt valid) or leaves the render box (false).
+__device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, const uint8_t* __restrict__ bitfield, f3 o, f3 d, f3 idir,
+                                                  float& t, f3& pos, float& dt) {
+	Box3 bb;
+	#pragma unroll
+	for (int i = 0; i < 3; ++i) { bb.mn[i] = p.render_aabb_min[i]; bb.mx[i] = p.render_aabb_max[i]; }
+	const float cone = p.cone_angle_constant;
+	while (1) {
+		pos = o + d * t;
+		if (!box_contains(bb, pos)) return false;
+		dt = calc_dt(t, cone);
+		uint32_t mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
+		if (density_grid_occupied_at(pos, bitfield, mip)) return true;
+		uint32_t res = kGrid >> mip;
+		t = advance_to_next_voxel(t, cone, pos, d, idir, res);
+	}
+}
+
+// advance_pos_nerf, tn:557-606: jitter by one Sobol value, then skip to the first occupied cell
+__device__ __forceinline__ bool first_hit(const nrs_render_params& p, const uint8_t* __restrict__ bitfield, uint32_t pixel_idx, Ray& r) {
+	f3 idir = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+	float dt = calc_dt(r.t, p.cone_angle_constant);
+	r.t += ld_random_val(p.spp_index, pixel_idx * 786433u) * dt;
+	f3 pos;
+	return march_to_occupied(p, bitfield, r.o, r.d, idir, r.t, pos, dt);
+}
+
+// ---- tet warp: selection_utils.h:10-47, cage_deformation.cu:136-269 -----------------------------------------------
+__device__ __forceinline__ float scalar_tp(f3 a, f3 b, f3 c) { return dot3(a, cross3(b, c)); }
+__device__ __forceinline__ bool same_side_tet(f3 v1, f3 v2, f3 v3, f3 v4, f3 p) {
+	f3 normal = cross3(v2 - v1, v3 - v1);
+	float dotV4 = dot3(normal, v4 - v1);
+	float dotP = dot3(normal, p - v1);
+	return signbit(dotV4) == signbit(dotP);
+}
+__device__ __forceinline__ bool point_in_tet(f3 v1, f3 v2, f3 v3, f3 v4, f3 p) {
+	return same_side_tet(v1, v2, v3, v4, p) && same_side_tet(v2, v3, v4, v1, p) && same_side_tet(v3, v4, v1, v2, p) &&
+	       same_side_tet(v4, v1, v2, v3, p);
+}
+__device__ __forceinline__ void bary_tet(f3 a, f3 b, f3 c, f3 d, f3 p, float out[4]) {
+	f3 vap = p - a, vbp = p - b, vab = b - a, vac = c - a, vad = d - a, vbc = c - b, vbd = d - b;
+	float va6 = scalar_tp(vbp, vbd, vbc);
+	float vb6 = scalar_tp(vap, vac, vad);
+	float vc6 = scalar_tp(vap, vad, vab);
+	float vd6 = scalar_tp(vap, vab, vac);
+	float v6 = (float)(1. / (double)scalar_tp(vab, vac, vad)); // the reference divides in double ("1. / float")
+	out[0] = va6 * v6; out[1] = vb6 * v6; out[2] = vc6 * v6; out[3] = vd6 * v6;
+}
+__device__ __forceinline__ f3 ld3(const float* __restrict__ a, uint32_t i) { return {a[3 * i], a[3 * i + 1], a[3 * i + 2]}; }
+
+// interpolate_tet (with_dir, honours copy) / interpolate_tet_pos (!with_dir, ignores copy).  pos/dir are the warped
+// [0,1] values of the NerfCoordinate; returns true if the sample must be treated as empty space.
+__device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3& wpos, f3& wdir) {
+	bool in_deformed = false;
+	if (box_contains(e.warped_bbox, wpos)) {
+		f3 u = unwarp_position(wpos, e.aabb);
+		int level = mip_from_pos(u);
+		uint32_t cell = (uint32_t)level * kGridVol + cascaded_grid_idx_at(u, (uint32_t)level);
+		uint32_t j0 = e.lut_off[cell], j1 = e.lut_off[cell + 1];
+		for (uint32_t j = j0; j < j1; ++j) {
+			uint32_t t = e.lut_idx[j];
+			uint4 tv = reinterpret_cast<const uint4*>(e.tets)[t];
+			f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), d = ld3(e.verts, tv.w);
+			if (point_in_tet(a, b, c, d, u)) {
+				float bc[4];
+				bary_tet(a, b, c, d, u, bc);
+				f3 o0 = ld3(e.orig, tv.x), o1 = ld3(e.orig, tv.y), o2 = ld3(e.orig, tv.z), o3 = ld3(e.orig, tv.w);
+				f3 canon = ((bc[0] * o0 + bc[1] * o1) + bc[2] * o2) + bc[3] * o3;
+				wpos = warp_position(canon, e.aabb);
+				if (with_dir && e.rot) {
+					f3 ud = unwarp_direction(wdir);
+					const float* R = e.rot + 9 * (size_t)t;
+					f3 rd = {(R[0] * ud.x + R[3] * ud.y) + R[6] * ud.z, (R[1] * ud.x + R[4] * ud.y) + R[7] * ud.z,
+					         (R[2] * ud.x + R[5] * ud.y) + R[8] * ud.z};
+					wdir = warp_direction(rd);
+				}
+				in_deformed = true;
+				break;
+			}
+		}
+	}
+	bool empty = false;
+	if (!(with_dir && e.copy)) {
+		if (!in_deformed && box_contains(e.orig_warped_bbox, wpos)) {
+			f3 u = unwarp_position(wpos, e.aabb);
+			int level = mip_from_pos(u);
+			uint32_t pos_idx = cascaded_grid_idx_at(u, (uint32_t)level);
+			empty = get_bitfield_at(pos_idx, (uint32_t)level, e.orig_bitfield);
+		}
+	}
+	return empty;
+}
+
+// compute_residual_poisson_kernel body (cage_deformation.cu:467-507): barycentric interpolation of the per-vertex
+// membrane terms at a sample position in DEFORMED space.  Outputs are left untouched when no tet contains it.
+__device__ __forceinline__ void poisson_residual(const DeviceEdit& e, f3 wpos, float sh[27], float& out_density, float& res_density) {
+	f3 pos = unwarp_position(wpos, e.aabb);
+	if (!box_contains(e.bbox, pos)) return;
+	int level = mip_from_pos(pos);
+	uint32_t cell = (uint32_t)level * kGridVol + cascaded_grid_idx_at(pos, (uint32_t)level);
+	uint32_t j0 = e.lut_off[cell], j1 = e.lut_off[cell + 1];
+	for (uint32_t j = j0; j < j1; ++j) {
+		uint32_t t = e.lut_idx[j];
+		uint4 tv = reinterpret_cast<const uint4*>(e.tets)[t];
+		f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), d = ld3(e.verts, tv.w);
+		if (point_in_tet(a, b, c, d, pos)) {
+			float bc[4];
+			bary_tet(a, b, c, d, pos, bc);
+			#pragma unroll
+			for (int k = 0; k < 27; ++k)
+				sh[k] = ((bc[0] * e.shs[27 * (size_t)tv.x + k] + bc[1] * e.shs[27 * (size_t)tv.y + k]) + bc[2] * e.shs[27 * (size_t)tv.z + k]) +
+				        bc[3] * e.shs[27 * (size_t)tv.w + k];
+			float lo = ((bc[0] * e.out_density[tv.x] + bc[1] * e.out_density[tv.y]) + bc[2] * e.out_density[tv.z]) + bc[3] * e.out_density[tv.w];
+			float lr = ((bc[0] * e.res_density[tv.x] + bc[1] * e.res_density[tv.y]) + bc[2] * e.res_density[tv.z]) + bc[3] * e.res_density[tv.w];
+			out_density = e.residual_amplitude * lo;
+			res_density = e.residual_amplitude * lr;
+			return;
+		}
+	}
+}
+
+// evaluate_sh9, cn:218-245 (SH9RGB = 9x3 column-major)
+__device__ __forceinline__ void evaluate_sh9(const float sh[27], f3 dir, float rgb[3]) {
+	float fZ2 = dir.z * dir.z;
+	float pSH[9];
+	pSH[0] = 0.2820947917738781f;
+	pSH[2] = 0.4886025119029199f * dir.z;
+	pSH[6] = 0.9461746957575601f * fZ2 + -0.3153915652525201f;
+	float fC0 = dir.x, fS0 = dir.y;
+	float fTmpA = -0.48860251190292f;
+	pSH[3] = fTmpA * fC0; pSH[1] = fTmpA * fS0;
+	float fTmpB = -1.092548430592079f * dir.z;
+	pSH[7] = fTmpB * fC0; pSH[5] = fTmpB * fS0;
+	float fC1 = dir.x * fC0 - dir.y * fS0;
+	float fS1 = dir.x * fS0 + dir.y * fC0;
+	float fTmpC = 0.5462742152960395f;
+	pSH[8] = fTmpC * fC1; pSH[4] = fTmpC * fS1;
+	#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		float s = 0.f;
+		#pragma unroll
+		for (int k = 0; k < 9; ++k) s += pSH[k] * sh[9 * c + k];
+		rgb[c] = s;
+	}
+}
+
+// ---- activations (cn:38-66) and shade (common_device.cuh:31-37) ---------------------------------------------------
+__device__ __forceinline__ float network_to_rgb(float v, uint32_t act) {
+	switch (act) {
+		case NRS_ACT_RELU: return v > 0.f ? v : 0.f;
+		case NRS_ACT_LOGISTIC: return 1.0f / (1.0f + __expf(-v));
+		case NRS_ACT_EXPONENTIAL: return __expf(clampf_(v, -10.f, 10.f));
+		default: return v;
+	}
+}
+__device__ __forceinline__ float network_to_density(float v, uint32_t act) {
+	switch (act) {
+		case NRS_ACT_RELU: return v > 0.f ? v : 0.f;
+		case NRS_ACT_LOGISTIC: return 1.0f / (1.0f + __expf(-v));
+		case NRS_ACT_EXPONENTIAL: return __expf(v);
+		default: return v;
+	}
+}
+__device__ __forceinline__ float srgb_to_linear(float s) {
+	if (s <= 0.04045f) return s / 12.92f;
+	return powf((s + 0.055f) / 1.055f, 2.4f);
+}
+
+} // namespace nrs

@@ -1,0 +1,104 @@
+// nrs_internal.h -- PODs shared between the C++ host code (nrs_api.cpp) and the HIP kernels (nrs_kernels.hip).
+// Nothing here is part of the public ABI (that is include/nrs.h).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/nrs.h"
+
+namespace nrs {
+
+constexpr uint32_t kGrid = 128;                  // NERF_GRIDSIZE
+constexpr uint32_t kCascades = 5;                // NERF_CASCADES
+constexpr uint32_t kGridVol = kGrid * kGrid * kGrid;
+constexpr uint32_t kLevels = 16;
+constexpr uint32_t kDensityW = 64 * 32 + 16 * 64;           // density MLP params (base.json:30-36)
+constexpr uint32_t kRgbW = 64 * 32 + 64 * 64 + 16 * 64;     // rgb MLP params (base.json:52-58)
+
+// One hash-grid level as the kernels consume it (staged in LDS, 32 B).
+struct LevelParams {
+	float    scale;       // exp2(l*log2(b))*Nmin - 1
+	uint32_t resolution;  // ceil(scale) + 1
+	uint32_t res2;        // resolution^2
+	uint32_t offset;      // first entry of the level in the concatenated table (in entries = u32 words)
+	uint32_t count;       // entries in the level
+	uint32_t hashed;      // 1: spatial hash (count is a power of two), 0: dense x + y*res + z*res^2
+	uint32_t mask;        // count - 1 when hashed
+	uint32_t pad;
+};
+
+// MFMA A-operand image of the five weight matrices: kNumFrags fragments of 64 lanes x 8 halfs (1 KiB each).
+// Fragment order (see nrs_mlp.cuh): D1[mb][ks] (4), D2[ks] (4), R1[mb][ks] (4), R2[mb][ks] (8), R3[ks] (4).
+constexpr uint32_t kNumFrags = 24;
+constexpr uint32_t kFragBytes = 64 * 8 * 2;
+constexpr uint32_t kWfragBytes = kNumFrags * kFragBytes; // 24 KiB
+
+struct Box3 { float mn[3]; float mx[3]; };
+
+struct DeviceModel {
+	const uint32_t* grid;      // fp16x2 entries
+	const uint16_t* wfrag;     // kWfragBytes
+	const uint8_t*  bitfield;  // NRS_BITFIELD_BYTES
+	LevelParams     levels[kLevels];
+	Box3            aabb;      // train aabb (m_aabb)
+	uint32_t        rgb_activation;
+	uint32_t        density_activation;
+};
+
+struct DeviceEdit {
+	Box3 aabb;                 // scene aabb
+	Box3 bbox;                 // deformed mesh, world units           (TetMesh::bbox)
+	Box3 warped_bbox;          // bbox in warped [0,1] coordinates     (TetMesh::warped_bbox)
+	Box3 orig_warped_bbox;     // canonical mesh, warped               (TetMesh::original_warped_bbox)
+	const uint32_t* lut_off;
+	const uint32_t* lut_idx;
+	const uint32_t* tets;
+	const float*    verts;
+	const float*    orig;
+	const float*    rot;           // nullable
+	const uint8_t*  orig_bitfield;
+	const float*    shs;           // nullable unless apply_poisson
+	const float*    out_density;
+	const float*    res_density;
+	float           residual_amplitude;
+	uint32_t        copy;
+	uint32_t        apply_poisson;
+	uint32_t        pad;
+};
+
+struct RenderCounters {    // zeroed before every launch
+	unsigned long long n_samples;
+	uint32_t next_packet;
+	uint32_t n_rays_alive;
+	uint32_t n_rays_hit;
+	uint32_t pad;
+};
+
+struct RenderArgs {
+	nrs_render_params p;
+	const DeviceEdit* edits;   // device array, applied last-to-first
+	int32_t  n_edits;
+	uint32_t any_poisson;      // some edit has apply_poisson set
+	uint32_t n_packets;        // 8x8 pixel packets owned by this call
+	uint32_t tiles_x;          // image width in tiles (tiled mode) or in packets (whole-image mode)
+	uint32_t packets_per_tile_x;
+	uint32_t max_steps;
+	float*    frame;           // f32x4
+	float*    depth;
+	uint32_t* steps;           // nullable
+	RenderCounters* counters;
+};
+
+// kernel launchers (nrs_kernels.hip).  stream is a hipStream_t.
+int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* stream);
+int launch_trace_samples(const DeviceModel& m, const nrs_render_params& p, uint32_t n_pixels, const uint32_t* d_pixel_idx,
+                         uint32_t max_samples, float* d_t, float* d_dt, uint32_t* d_count, void* stream);
+// mode 0: full inference (16 channels, c3 = density), 1: density MLP outputs, 2: hash-grid features [n x 32]
+int launch_network(const DeviceModel& m, int mode, uint32_t n, const float* d_in, uint32_t ld_in, void* d_out, uint32_t ld_out,
+                   int layout, int n_cus, void* stream);
+int launch_map_rays(const DeviceEdit& e, uint32_t n, float* d_coords, uint32_t ld, int with_dir, uint8_t* d_empty, void* stream);
+int launch_grid_to_bitfield(const float* d_grid, uint8_t* d_bitfield, float* d_scratch_mean, void* stream);
+int launch_detile(const nrs_render_params& p, uint32_t n_ranks, uint32_t tiles_per_rank_padded, const float* d_tiles,
+                  uint32_t channels, float* d_image, void* stream);
+const char* launch_last_error();
+
+} // namespace nrs

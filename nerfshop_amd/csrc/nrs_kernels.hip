@@ -1,0 +1,479 @@
+// nrs_kernels.hip -- HIP kernels of the NeRFshop render path for gfx950 (MI355X), wave64.
+//
+//   render_kernel        one persistent launch per frame: rays are pulled in 8x8-pixel packets from a device-side
+//                        queue, marched, warped, encoded, evaluated on MFMA and composited in registers.  It replaces
+//                        the reference's per-iteration launch train + host syncs: no NerfPayload / network
+//                        input / network output arrays exist in HBM; the only traffic is the hash-table gather, the
+//                        occupancy bitfield, the cage tables and one float4 per hit pixel.
+//   network_kernel       NerfNetwork::inference_mixed_precision / density / hash-grid encode on caller batches.
+//   map_rays_kernel      EditOperator::map_rays / map_positions on caller batches.
+//   trace_samples_kernel test hook: the (t, dt) stream of listed pixels.
+//   grid -> bitfield     update_density_grid_mean_and_bitfield.
+//   detile_kernel        multi-GPU tile scatter.
+#include <hip/hip_runtime.h>
+#include "nrs_internal.h"
+#include "nrs_device.cuh"
+#include "nrs_mlp.cuh"
+
+namespace nrs {
+
+static thread_local char g_launch_err[512];
+const char* launch_last_error() { return g_launch_err; }
+static int hip_fail(hipError_t e, const char* what) {
+	snprintf(g_launch_err, sizeof(g_launch_err), "%s: %s", what, hipGetErrorString(e));
+	return NRS_ERR_HIP;
+}
+#define NRS_LAUNCH_CHECK(what)                               \
+	do {                                                     \
+		hipError_t e_ = hipGetLastError();                   \
+		if (e_ != hipSuccess) return hip_fail(e_, what);     \
+	} while (0)
+
+constexpr int kRing = 128; // pending-ray ring entries per wave (>= 63 + 64)
+
+struct RenderSmem {
+	half8 w[kNumFrags * 64];
+	LevelParams levels[kLevels];
+	uint4 ring[4][kRing]; // {x | y << 16, t bits, output index, -}
+};
+
+// packet -> pixel of this lane.  Packets are 8x8 pixel blocks.
+__device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, int lane, uint32_t& x, uint32_t& y, uint32_t& out_idx) {
+	const uint32_t W = (uint32_t)a.p.resolution[0], H = (uint32_t)a.p.resolution[1];
+	const uint32_t lx = lane & 7, ly = lane >> 3;
+	if (a.p.tile_size == 0) {
+		const uint32_t bx = pk % a.tiles_x, by = pk / a.tiles_x;
+		x = bx * 8 + lx;
+		y = by * 8 + ly;
+		out_idx = x + W * y;
+	} else {
+		const uint32_t ppt = a.packets_per_tile_x * a.packets_per_tile_x;
+		const uint32_t k = pk / ppt, b = pk % ppt;
+		const uint32_t stride = a.p.tile_stride ? a.p.tile_stride : 1;
+		const uint32_t T = a.p.tile_first + k * stride;
+		const uint32_t Tx = T % a.tiles_x, Ty = T / a.tiles_x;
+		const uint32_t tx = (b % a.packets_per_tile_x) * 8 + lx, ty = (b / a.packets_per_tile_x) * 8 + ly;
+		x = Tx * a.p.tile_size + tx;
+		y = Ty * a.p.tile_size + ty;
+		out_idx = (k * a.p.tile_size + ty) * a.p.tile_size + tx;
+	}
+	return x < W && y < H;
+}
+
+__global__ __launch_bounds__(256) void render_kernel(const DeviceModel m, const RenderArgs a) {
+	__shared__ RenderSmem sm;
+	stage_model_to_lds(m, sm.w, sm.levels);
+
+	const int lane = threadIdx.x & 63;
+	const int wave = threadIdx.x >> 6;
+	const int g = lane >> 5;
+	uint4* ring = sm.ring[wave];
+	const nrs_render_params& p = a.p;
+	const bool ops = p.apply_operators && a.n_edits > 0;
+	const f3 cam_fwd = mk3(p.camera_matrix1[6], p.camera_matrix1[7], p.camera_matrix1[8]);
+	const f3 cam_o = mk3(p.camera_matrix1[9], p.camera_matrix1[10], p.camera_matrix1[11]);
+
+	float off_x, off_y;
+	ld_random_pixel_offset(p.snap_to_pixel_centers ? 0u : p.spp_index, off_x, off_y);
+
+	// ---- per-lane ray state (registers) ----
+	bool have = false;
+	f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), idir = mk3(0, 0, 0);
+	float t = 0.f;
+	float cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f; // accumulated premultiplied colour / alpha
+	float ray_depth = 0.f, max_weight = 0.f;
+	uint32_t out_idx = 0, n_steps = 0;
+	// ---- wave-uniform queue state ----
+	uint32_t ring_head = 0, ring_count = 0;
+	bool more = true;
+	// ---- statistics ----
+	uint32_t st_samples = 0, st_alive = 0, st_hit = 0;
+
+	for (;;) {
+		const unsigned long long free_mask = __ballot(!have);
+		const uint32_t nfree = (uint32_t)__popcll(free_mask);
+
+		// ---- fill the ring with rays that found an occupied cell (init_rays + advance_pos_nerf) ----
+		while (more && ring_count < nfree) {
+			uint32_t pk = 0;
+			if (lane == 0) pk = atomicAdd(&a.counters->next_packet, 1u);
+			pk = __builtin_amdgcn_readfirstlane(pk);
+			if (pk >= a.n_packets) { more = false; break; }
+			uint32_t x, y, oi;
+			bool alive = false;
+			float t0 = 0.f;
+			if (packet_pixel(a, pk, lane, x, y, oi)) {
+				Ray r = init_ray(p, x, y, off_x, off_y);
+				a.depth[oi] = 1e10f; // tn:2586
+				if (a.steps) a.steps[oi] = 0;
+				alive = r.alive;
+				if (alive) alive = first_hit(p, m.bitfield, x + (uint32_t)p.resolution[0] * y, r);
+				t0 = r.t;
+			}
+			const unsigned long long am = __ballot(alive);
+			if (alive) {
+				const uint32_t slot = ring_head + ring_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+				ring[slot & (kRing - 1)] = make_uint4(x | (y << 16), __float_as_uint(t0), oi, 0u);
+				++st_alive;
+			}
+			ring_count += (uint32_t)__popcll(am);
+		}
+		__builtin_amdgcn_wave_barrier();
+
+		// ---- hand pending rays to idle lanes ----
+		if (nfree && ring_count) {
+			const uint32_t take = min(nfree, ring_count);
+			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
+			if (!have && rank < take) {
+				const uint4 e = ring[(ring_head + rank) & (kRing - 1)];
+				const uint32_t x = e.x & 0xffffu, y = e.x >> 16;
+				Ray r = init_ray(p, x, y, off_x, off_y); // same arithmetic as at enqueue time -> same bits
+				o = r.o; d = r.d;
+				idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+				t = __uint_as_float(e.y);
+				out_idx = e.z;
+				cr = cg = cb = ca = 0.f;
+				ray_depth = 0.f; max_weight = 0.f; n_steps = 0;
+				have = true;
+			}
+			ring_head += take;
+			ring_count -= take;
+		}
+		__builtin_amdgcn_wave_barrier();
+
+		if (!__any(have)) {
+			if (!more && ring_count == 0) break;
+			continue;
+		}
+
+		// ---- one sample per live ray: generate_next_nerf_network_inputs body (tn:668-692) ----
+		f3 pos = o + d * t;
+		float dt = calc_dt(t, p.cone_angle_constant);
+		f3 wpos = warp_position(pos, m.aabb);
+		f3 wdir = warp_direction(d);
+		const float wdt = warp_dt(dt);
+		bool empty = false;
+		if (ops && have) { // map_rays, last-to-first (tn:2899-2902)
+			for (int ei = a.n_edits - 1; ei >= 0; --ei) empty |= tet_warp(a.edits[ei], true, wpos, wdir);
+		}
+
+		// ---- encode: own sample -> block g, partner's sample -> block 1-g ----
+		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
+		const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
+		const bool phave = __shfl_xor((int)have, 32, 64) != 0;
+		half8 own0, own1, par0, par1;
+		encode_levels(m.grid, sm.levels, g, wpos, have, own0, own1);
+		encode_levels(m.grid, sm.levels, g, ppos, phave, par0, par1);
+		half8 x[2][2];
+		x[0][0] = g ? par0 : own0; x[0][1] = g ? par1 : own1;
+		x[1][0] = g ? own0 : par0; x[1][1] = g ? own1 : par1;
+		const half8 sh_own = encode_sh4(g, wdir), sh_par = encode_sh4(g, pdir);
+		half8 sh[2];
+		sh[0] = g ? sh_par : sh_own;
+		sh[1] = g ? sh_own : sh_par;
+
+		// ---- fused MLPs on MFMA ----
+		half8 dout[2], rout[2];
+		density_mlp(sm.w, lane, x, dout);
+		rgb_mlp(sm.w, lane, dout, sh, rout);
+
+		// results of block 0 sit in lanes 0..31 (their own rays); block 1's are fetched from the partner lane
+		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+		const u32x4 d0 = __builtin_bit_cast(u32x4, dout[0]), d1 = __builtin_bit_cast(u32x4, dout[1]);
+		const u32x4 r0 = __builtin_bit_cast(u32x4, rout[0]), r1 = __builtin_bit_cast(u32x4, rout[1]);
+		const uint32_t xd = xchg32u(d1[0]), xrg = xchg32u(r1[0]), xb = xchg32u(r1[1]);
+		const uint32_t wd_ = g ? xd : d0[0], wrg = g ? xrg : r0[0], wb = g ? xb : r0[1];
+		const half2v hd = __builtin_bit_cast(half2v, wd_), hrg = __builtin_bit_cast(half2v, wrg), hb = __builtin_bit_cast(half2v, wb);
+		const float sigma_raw = (float)hd[0];
+		const float raw_r = (float)hrg[0], raw_g = (float)hrg[1], raw_b = (float)hb[0];
+
+		// ---- composite_kernel_nerf body (tn:750-955, Shade mode) + next-sample march ----
+		if (have) {
+			const f3 cpos = unwarp_position(wpos, m.aabb);
+			const float T = 1.f - ca;
+			const float cdt = unwarp_dt(wdt);
+			float alpha = empty ? 0.0f : 1.f - __expf(-network_to_density(sigma_raw, m.density_activation) * cdt);
+			const float weight = alpha * T;
+			cr += network_to_rgb(raw_r, m.rgb_activation) * weight;
+			cg += network_to_rgb(raw_g, m.rgb_activation) * weight;
+			cb += network_to_rgb(raw_b, m.rgb_activation) * weight;
+			ca += weight;
+			if (weight > max_weight) {
+				max_weight = weight;
+				ray_depth = dot3(cam_fwd, cpos - cam_o);
+			}
+			++n_steps;
+			++st_samples;
+			bool done = false, shade = true;
+			if (ca > (1.0f - p.min_transmittance)) {
+				cr /= ca; cg /= ca; cb /= ca; ca /= ca;
+				done = true;
+			} else if (n_steps >= a.max_steps) {
+				done = true; shade = false; // MARCH_ITER exhausted: the reference never compacts such a ray into the hit list
+			} else {
+				t += dt;
+				f3 npos; float ndt;
+				done = !march_to_occupied(p, m.bitfield, o, d, idir, t, npos, ndt);
+			}
+			if (done) {
+				if (shade && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
+					float tr = cr, tg = cg, tb = cb, ta = ca;
+					if (p.render_mode == NRS_RENDER_COST) {
+						const float col = (float)n_steps / 128;
+						tr = tg = tb = col; ta = 1.0f;
+					} else if (!p.linear_colors) {
+						tr = srgb_to_linear(tr); tg = srgb_to_linear(tg); tb = srgb_to_linear(tb);
+					}
+					float4* fb = reinterpret_cast<float4*>(a.frame) + out_idx;
+					const float4 prev = *fb;
+					const float om = 1.0f - ta;
+					*fb = make_float4(tr + prev.x * om, tg + prev.y * om, tb + prev.z * om, ta + prev.w * om);
+					if (ta > 0.2f) a.depth[out_idx] = ray_depth;
+					++st_hit;
+				}
+				if (a.steps) a.steps[out_idx] = n_steps;
+				have = false;
+			}
+		}
+	}
+
+	atomicAdd(&a.counters->n_samples, (unsigned long long)st_samples);
+	atomicAdd(&a.counters->n_rays_alive, st_alive);
+	atomicAdd(&a.counters->n_rays_hit, st_hit);
+}
+
+int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* stream) {
+	int blocks_per_cu = 0;
+	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel, 256, 0);
+	if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(render_kernel)");
+	if (blocks_per_cu < 1) blocks_per_cu = 1;
+	uint32_t grid = (uint32_t)(n_cus * blocks_per_cu);
+	const uint32_t max_useful = (a.n_packets + 3) / 4; // one packet per wave at least
+	if (grid > max_useful) grid = max_useful;
+	if (grid == 0) return NRS_OK;
+	hipLaunchKernelGGL(render_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, m, a);
+	NRS_LAUNCH_CHECK("render_kernel launch");
+	return NRS_OK;
+}
+
+// ---- trace_samples ------------------------------------------------------------------------------------------------
+__global__ void trace_samples_kernel(const DeviceModel m, const nrs_render_params p, uint32_t n_pixels, const uint32_t* __restrict__ pixel_idx,
+                                     uint32_t max_samples, float* __restrict__ t_out, float* __restrict__ dt_out, uint32_t* __restrict__ count_out) {
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n_pixels) return;
+	float off_x, off_y;
+	ld_random_pixel_offset(p.snap_to_pixel_centers ? 0u : p.spp_index, off_x, off_y);
+	const uint32_t idx = pixel_idx[k], W = (uint32_t)p.resolution[0];
+	Ray r = init_ray(p, idx % W, idx / W, off_x, off_y);
+	uint32_t cnt = 0;
+	if (r.alive && first_hit(p, m.bitfield, idx, r)) {
+		const f3 idir = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+		float t = r.t;
+		while (cnt < max_samples) {
+			f3 pos; float dt;
+			if (!march_to_occupied(p, m.bitfield, r.o, r.d, idir, t, pos, dt)) break;
+			t_out[(size_t)k * max_samples + cnt] = t;
+			dt_out[(size_t)k * max_samples + cnt] = dt;
+			++cnt;
+			t += dt;
+		}
+	}
+	count_out[k] = cnt;
+}
+
+int launch_trace_samples(const DeviceModel& m, const nrs_render_params& p, uint32_t n_pixels, const uint32_t* d_pixel_idx, uint32_t max_samples,
+                         float* d_t, float* d_dt, uint32_t* d_count, void* stream) {
+	if (n_pixels == 0) return NRS_OK;
+	hipLaunchKernelGGL(trace_samples_kernel, dim3((n_pixels + 127) / 128), dim3(128), 0, (hipStream_t)stream, m, p, n_pixels, d_pixel_idx, max_samples,
+	                   d_t, d_dt, d_count);
+	NRS_LAUNCH_CHECK("trace_samples_kernel launch");
+	return NRS_OK;
+}
+
+// ---- NerfNetwork operator on caller batches ----------------------------------------------------------------------------
+struct NetSmem {
+	half8 w[kNumFrags * 64];
+	LevelParams levels[kLevels];
+};
+
+// MODE 0: inference_mixed_precision (16 channels, c3 = density raw), 1: density(), 2: hash-grid features [n x 32]
+template <int MODE>
+__global__ __launch_bounds__(256) void network_kernel(const DeviceModel m, uint32_t n, const float* __restrict__ in, uint32_t ld_in,
+                                                      _Float16* __restrict__ out, uint32_t ld_out, int layout) {
+	__shared__ NetSmem sm;
+	stage_model_to_lds(m, sm.w, sm.levels);
+	const int lane = threadIdx.x & 63;
+	const int g = lane >> 5, j = lane & 31;
+	const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+	const uint32_t n_tiles = (n + 63) / 64;
+	for (uint32_t tile = wave_global; tile < n_tiles; tile += n_waves) {
+		const uint32_t s = tile * 64 + lane;
+		const bool have = s < n;
+		f3 wpos = mk3(0, 0, 0), wdir = mk3(0.5f, 0.5f, 0.5f);
+		if (have) {
+			const float* c = in + (size_t)s * ld_in;
+			wpos = mk3(c[0], c[1], c[2]);
+			if (MODE == 0) wdir = mk3(c[4], c[5], c[6]);
+		}
+		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
+		const bool phave = __shfl_xor((int)have, 32, 64) != 0;
+		half8 own0, own1, par0, par1;
+		encode_levels(m.grid, sm.levels, g, wpos, have, own0, own1);
+		encode_levels(m.grid, sm.levels, g, ppos, phave, par0, par1);
+		half8 x[2][2];
+		x[0][0] = g ? par0 : own0; x[0][1] = g ? par1 : own1;
+		x[1][0] = g ? own0 : par0; x[1][1] = g ? own1 : par1;
+
+		if (MODE == 2) {
+			#pragma unroll
+			for (int b = 0; b < 2; ++b) {
+				const uint32_t sb = tile * 64 + 32 * b + j;
+				if (sb < n) {
+					#pragma unroll
+					for (int ks = 0; ks < 2; ++ks)
+						#pragma unroll
+						for (int e = 0; e < 8; ++e) {
+							const int level = 2 * (4 * ks + (e >> 1)) + g;
+							out[(size_t)sb * 32 + 2 * level + (e & 1)] = x[b][ks][e];
+						}
+				}
+			}
+			continue;
+		}
+
+		half8 dout[2], rout[2];
+		density_mlp(sm.w, lane, x, dout);
+		if (MODE == 0) {
+			const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
+			const half8 sh_own = encode_sh4(g, wdir), sh_par = encode_sh4(g, pdir);
+			half8 sh[2];
+			sh[0] = g ? sh_par : sh_own;
+			sh[1] = g ? sh_own : sh_par;
+			rgb_mlp(sm.w, lane, dout, sh, rout);
+		}
+		#pragma unroll
+		for (int b = 0; b < 2; ++b) {
+			const uint32_t sb = tile * 64 + 32 * b + j;
+			if (sb < n) {
+				#pragma unroll
+				for (int e = 0; e < 8; ++e) {
+					const int row = (e & 3) + 8 * (e >> 2) + 4 * g;
+					_Float16 v = (MODE == 0) ? rout[b][e] : dout[b][e];
+					if (MODE == 0 && row == 3) v = dout[b][0]; // extract_density, nerf_network_full.h:89-95 (row 3 and density row 0 both live on g == 0)
+					if (layout == NRS_PLANES) out[(size_t)row * ld_out + sb] = v;
+					else out[(size_t)sb * 16 + row] = v;
+				}
+			}
+		}
+	}
+}
+
+int launch_network(const DeviceModel& m, int mode, uint32_t n, const float* d_in, uint32_t ld_in, void* d_out, uint32_t ld_out, int layout,
+                   int n_cus, void* stream) {
+	if (n == 0) return NRS_OK;
+	const uint32_t n_tiles = (n + 63) / 64;
+	uint32_t grid = (n_tiles + 3) / 4;
+	const uint32_t cap = (uint32_t)n_cus * 8;
+	if (grid > cap) grid = cap;
+	hipStream_t s = (hipStream_t)stream;
+	_Float16* out = (_Float16*)d_out;
+	if (mode == 0) hipLaunchKernelGGL(network_kernel<0>, dim3(grid), dim3(256), 0, s, m, n, d_in, ld_in, out, ld_out, layout);
+	else if (mode == 1) hipLaunchKernelGGL(network_kernel<1>, dim3(grid), dim3(256), 0, s, m, n, d_in, ld_in, out, ld_out, layout);
+	else hipLaunchKernelGGL(network_kernel<2>, dim3(grid), dim3(256), 0, s, m, n, d_in, ld_in, out, ld_out, layout);
+	NRS_LAUNCH_CHECK("network_kernel launch");
+	return NRS_OK;
+}
+
+// ---- EditOperator::map_rays / map_positions on caller batches --------------------------------------------------------------
+__global__ void map_rays_kernel(const DeviceEdit e, uint32_t n, float* __restrict__ coords, uint32_t ld, int with_dir, uint8_t* __restrict__ empty_mask) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	float* c = coords + (size_t)i * ld;
+	f3 wpos = mk3(c[0], c[1], c[2]);
+	f3 wdir = with_dir ? mk3(c[4], c[5], c[6]) : mk3(0.5f, 0.5f, 0.5f);
+	const f3 p0 = wpos, d0 = wdir;
+	const bool empty = tet_warp(e, with_dir != 0, wpos, wdir);
+	if (wpos.x != p0.x || wpos.y != p0.y || wpos.z != p0.z) { c[0] = wpos.x; c[1] = wpos.y; c[2] = wpos.z; }
+	if (with_dir && (wdir.x != d0.x || wdir.y != d0.y || wdir.z != d0.z)) { c[4] = wdir.x; c[5] = wdir.y; c[6] = wdir.z; }
+	if (empty) empty_mask[i] = 1;
+}
+
+int launch_map_rays(const DeviceEdit& e, uint32_t n, float* d_coords, uint32_t ld, int with_dir, uint8_t* d_empty, void* stream) {
+	if (n == 0) return NRS_OK;
+	hipLaunchKernelGGL(map_rays_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, e, n, d_coords, ld, with_dir, d_empty);
+	NRS_LAUNCH_CHECK("map_rays_kernel launch");
+	return NRS_OK;
+}
+
+// ---- density grid -> bitfield (tn:514-555, 3642-3657) ----------------------------------------------------------------------
+__global__ void grid_mean_kernel(const float* __restrict__ grid, float* __restrict__ mean_out) {
+	// one block, fixed summation order: deterministic.  mean of max(v, 0) / n over level 0.
+	__shared__ double part[1024];
+	double acc = 0.0;
+	for (uint32_t i = threadIdx.x; i < kGridVol; i += 1024) acc += (double)(fmaxf(grid[i], 0.f) / (float)kGridVol);
+	part[threadIdx.x] = acc;
+	__syncthreads();
+	for (int s = 512; s > 0; s >>= 1) {
+		if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) mean_out[0] = (float)part[0];
+}
+__global__ void grid_to_bitfield_kernel(uint32_t n_elements, const float* __restrict__ grid, uint8_t* __restrict__ bitfield, const float* __restrict__ mean) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_elements) return;
+	const float thresh = fminf(0.01f, *mean); // NERF_MIN_OPTICAL_THICKNESS
+	uint8_t bits = 0;
+	#pragma unroll
+	for (uint32_t j = 0; j < 8; ++j) bits |= grid[(size_t)i * 8 + j] > thresh ? (uint8_t)(1u << j) : 0;
+	bitfield[i] = bits;
+}
+__global__ void bitfield_max_pool_kernel(uint32_t n_elements, const uint8_t* __restrict__ prev_level, uint8_t* __restrict__ next_level) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_elements) return;
+	uint8_t bits = 0;
+	#pragma unroll
+	for (uint32_t j = 0; j < 8; ++j) bits |= prev_level[i * 8 + j] > 0 ? (uint8_t)(1u << j) : 0;
+	const uint32_t x = morton3D_invert(i >> 0) + kGrid / 8, y = morton3D_invert(i >> 1) + kGrid / 8, z = morton3D_invert(i >> 2) + kGrid / 8;
+	next_level[morton3D(x, y, z)] |= bits;
+}
+
+int launch_grid_to_bitfield(const float* d_grid, uint8_t* d_bitfield, float* d_scratch_mean, void* stream) {
+	hipStream_t s = (hipStream_t)stream;
+	hipLaunchKernelGGL(grid_mean_kernel, dim3(1), dim3(1024), 0, s, d_grid, d_scratch_mean);
+	const uint32_t n = kGridVol / 8 * kCascades;
+	hipLaunchKernelGGL(grid_to_bitfield_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_grid, d_bitfield, d_scratch_mean);
+	for (uint32_t level = 1; level < kCascades; ++level) {
+		const uint32_t ne = kGridVol / 64;
+		hipLaunchKernelGGL(bitfield_max_pool_kernel, dim3((ne + 255) / 256), dim3(256), 0, s, ne, d_bitfield + (size_t)(level - 1) * kGridVol / 8,
+		                   d_bitfield + (size_t)level * kGridVol / 8);
+	}
+	NRS_LAUNCH_CHECK("grid_to_bitfield launch");
+	return NRS_OK;
+}
+
+// ---- multi-GPU de-tiling ---------------------------------------------------------------------------------------------------
+__global__ void detile_kernel(int W, int H, uint32_t tile, uint32_t tiles_x, uint32_t n_ranks, uint32_t tiles_per_rank_padded,
+                              const float* __restrict__ tiles, uint32_t channels, float* __restrict__ image) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (uint32_t)(W * H)) return;
+	const uint32_t x = i % (uint32_t)W, y = i / (uint32_t)W;
+	const uint32_t T = (y / tile) * tiles_x + (x / tile);
+	const uint32_t r = T % n_ranks, k = T / n_ranks;
+	const size_t src = (((size_t)r * tiles_per_rank_padded + k) * tile + (y % tile)) * tile + (x % tile);
+	for (uint32_t c = 0; c < channels; ++c) image[(size_t)i * channels + c] = tiles[src * channels + c];
+}
+
+int launch_detile(const nrs_render_params& p, uint32_t n_ranks, uint32_t tiles_per_rank_padded, const float* d_tiles, uint32_t channels,
+                  float* d_image, void* stream) {
+	const int W = p.resolution[0], H = p.resolution[1];
+	const uint32_t tiles_x = ((uint32_t)W + p.tile_size - 1) / p.tile_size;
+	const uint32_t n = (uint32_t)(W * H);
+	hipLaunchKernelGGL(detile_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, H, p.tile_size, tiles_x, n_ranks,
+	                   tiles_per_rank_padded, d_tiles, channels, d_image);
+	NRS_LAUNCH_CHECK("detile_kernel launch");
+	return NRS_OK;
+}
+
+} // namespace nrs

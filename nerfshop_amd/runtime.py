@@ -1,0 +1,294 @@
+"""Host-side mirror of the reference's operator surface for the render path, over the C-ABI of libnrs.so.
+
+Names, argument meaning and error behaviour follow the reference classes so call sites read the same:
+
+    NerfNetwork            <- ngp::NerfNetwork<T> / NerfNetworkFull<T>   include/neural-graphics-primitives/nerf_network.h:86
+    CageDeformation        <- ngp::CageDeformation : EditOperator        include/.../editing/edit_operator.h:25, cage_deformation.cu:547
+    RenderBuffer           <- ngp::CudaRenderBuffer (frame_buffer / depth_buffer / spp / clear_frame)   render_buffer.h:164
+    Testbed.render_nerf    <- Testbed::render_nerf                        src/testbed_nerf.cu:3066
+
+PyTorch is plumbing only: device memory (torch tensors), streams.  All arithmetic happens in the HIP kernels;
+there is no CPU path -- a missing library or GPU raises NrsError.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._abi import NrsError, RenderParams, RenderStats, check
+
+
+def _stream_handle(stream):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    if isinstance(stream, torch.cuda.Stream):
+        return C.c_void_p(stream.cuda_stream)
+    return C.c_void_p(int(stream))
+
+
+def _require_cuda(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise NrsError(f"{name} must be a CUDA (HIP) tensor")
+    if t.dtype != dtype:
+        raise NrsError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise NrsError(f"{name} must be contiguous")
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = _abi.load()
+        self.h = C.c_void_p()
+        check(self.lib.nrs_ctx_create(int(device), C.byref(self.h)))
+        self.device = int(device)
+        name = C.create_string_buffer(256)
+        ncu, hbm = C.c_int(), C.c_size_t()
+        check(self.lib.nrs_ctx_device_info(self.h, name, 256, C.byref(ncu), C.byref(hbm)))
+        self.device_name, self.n_cus, self.hbm_bytes = name.value.decode(), ncu.value, hbm.value
+
+    def close(self):
+        if self.h:
+            self.lib.nrs_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NerfNetwork:
+    """pos-encoding (HashGrid) -> density MLP -> (SH dir-encoding | density features) -> RGB MLP -> extract_density."""
+
+    def __init__(self, ctx, desc):
+        self.ctx, self.lib, self.desc = ctx, ctx.lib, desc
+        self.h = C.c_void_p()
+        check(self.lib.nrs_model_create(ctx.h, C.byref(desc), C.byref(self.h)))
+
+    # -- NerfNetwork<T> accessors (nerf_network.h:97-120)
+    def padded_output_width(self):
+        return 16
+
+    def input_width(self):
+        return 7
+
+    def n_extra_dims(self):
+        return 0
+
+    def n_params(self):
+        return int(self.lib.nrs_model_n_params(C.byref(self.desc)))
+
+    def set_params(self, params_fp16):
+        """fp16 parameter blob in tiny-cuda-nn order (density | rgb | grid), a host array (numpy uint16/float16)."""
+        p = np.ascontiguousarray(params_fp16)
+        if p.dtype == np.float16:
+            p = p.view(np.uint16)
+        if p.dtype != np.uint16:
+            raise NrsError("set_params expects fp16 parameters (numpy float16 or their uint16 bits)")
+        check(self.lib.nrs_model_set_params(self.h, p.ctypes.data, p.size))
+
+    def set_density_bitfield(self, bitfield_u8):
+        b = np.ascontiguousarray(bitfield_u8, np.uint8)
+        check(self.lib.nrs_model_set_density_bitfield(self.h, b.ctypes.data, b.size))
+
+    def set_density_grid(self, grid_f32):
+        g = np.ascontiguousarray(grid_f32, np.float32)
+        check(self.lib.nrs_model_set_density_grid(self.h, g.ctypes.data, g.size))
+
+    def get_density_bitfield(self):
+        out = np.zeros(_abi.BITFIELD_BYTES, np.uint8)
+        check(self.lib.nrs_model_get_density_bitfield(self.h, out.ctypes.data, out.size))
+        return out
+
+    def inference_mixed_precision(self, stream, input, output):
+        """input: [n, 7] f32 (tcnn: column-major 7 x n).  output: fp16, [16, n_el] (row-major planes, n_el >= n)
+        or [n, 16] (column-major / interleaved), as GPUMatrixDynamic's layout selects in the reference."""
+        _require_cuda(input, torch.float32, "input")
+        _require_cuda(output, torch.float16, "output")
+        if input.dim() != 2 or input.shape[1] != 7:
+            raise NrsError("NerfNetwork::inference_mixed_precision input must be [n, 7]")
+        n = input.shape[0]
+        layout, ld = self._out_layout(output, n)
+        check(self.lib.nrs_network_inference(self.h, _stream_handle(stream), n, input.data_ptr(), output.data_ptr(), ld, layout))
+
+    def density(self, stream, input, output):
+        """input: [n, ld] f32 with ld in 3..7 (only the position is read); output as above, the density MLP's 16 outputs."""
+        _require_cuda(input, torch.float32, "input")
+        _require_cuda(output, torch.float16, "output")
+        if input.dim() != 2 or not (3 <= input.shape[1] <= 7):
+            raise NrsError("NerfNetwork::density input must be in column major format ([n, 3..7] here).")
+        n = input.shape[0]
+        layout, ld = self._out_layout(output, n)
+        check(self.lib.nrs_network_density(self.h, _stream_handle(stream), n, input.data_ptr(), input.shape[1], output.data_ptr(), ld, layout))
+
+    def hashgrid_encode(self, stream, input, output):
+        _require_cuda(input, torch.float32, "input")
+        _require_cuda(output, torch.float16, "output")
+        n = input.shape[0]
+        if tuple(output.shape) != (n, 32):
+            raise NrsError("hashgrid_encode output must be [n, 32]")
+        check(self.lib.nrs_hashgrid_encode(self.h, _stream_handle(stream), n, input.data_ptr(), input.shape[1], output.data_ptr()))
+
+    @staticmethod
+    def _out_layout(output, n):
+        if output.dim() == 2 and output.shape[0] == 16 and output.shape[1] >= n:
+            return _abi.LAYOUT_PLANES, int(output.shape[1])
+        if output.dim() == 2 and output.shape[1] == 16 and output.shape[0] >= n:
+            return _abi.LAYOUT_INTERLEAVED, 16
+        raise NrsError("output must be [16, n_el] (planes) or [n, 16] (interleaved) fp16")
+
+    def close(self):
+        if self.h:
+            self.lib.nrs_model_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CageDeformation:
+    """One cage-deformation edit operator; owns its GPU tables (tet_mesh.h:80-94)."""
+
+    def __init__(self, ctx, desc, cage_edit):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.host = cage_edit  # keeps the numpy arrays alive
+        self.h = C.c_void_p()
+        mesh = cage_edit.tet_mesh_struct()
+        check(self.lib.nrs_edit_create(ctx.h, C.byref(desc), C.byref(mesh), C.byref(self.h)))
+
+    def map_rays(self, stream, nerf_coords, empty_mask):
+        _require_cuda(nerf_coords, torch.float32, "nerf_coords")
+        _require_cuda(empty_mask, torch.uint8, "empty_mask")
+        if nerf_coords.dim() != 2 or nerf_coords.shape[1] != 7 or empty_mask.numel() < nerf_coords.shape[0]:
+            raise NrsError("map_rays expects coords [n, 7] and an empty mask of n bytes")
+        check(self.lib.nrs_edit_map_rays(self.h, _stream_handle(stream), nerf_coords.shape[0], nerf_coords.data_ptr(), empty_mask.data_ptr()))
+
+    def map_positions(self, stream, nerf_pos, empty_mask):
+        _require_cuda(nerf_pos, torch.float32, "nerf_pos")
+        _require_cuda(empty_mask, torch.uint8, "empty_mask")
+        if nerf_pos.dim() != 2 or nerf_pos.shape[1] < 3 or empty_mask.numel() < nerf_pos.shape[0]:
+            raise NrsError("map_positions expects positions [n, >=3] and an empty mask of n bytes")
+        check(self.lib.nrs_edit_map_positions(self.h, _stream_handle(stream), nerf_pos.shape[0], nerf_pos.data_ptr(), nerf_pos.shape[1],
+                                              empty_mask.data_ptr()))
+
+    def close(self):
+        if self.h:
+            self.lib.nrs_edit_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RenderBuffer:
+    """frame_buffer(): f32x4 premultiplied linear RGBA [H, W, 4]; depth_buffer(): f32 [H, W]; spp(): Sobol sample index."""
+
+    def __init__(self, width, height, device="cuda:0", with_steps=False):
+        self.width, self.height = int(width), int(height)
+        self._frame = torch.zeros((self.height, self.width, 4), dtype=torch.float32, device=device)
+        self._depth = torch.zeros((self.height, self.width), dtype=torch.float32, device=device)
+        self._steps = torch.zeros((self.height, self.width), dtype=torch.int32, device=device) if with_steps else None
+        self._spp = 0
+
+    def in_resolution(self):
+        return (self.width, self.height)
+
+    def frame_buffer(self):
+        return self._frame
+
+    def depth_buffer(self):
+        return self._depth
+
+    def steps_buffer(self):
+        return self._steps
+
+    def spp(self):
+        return self._spp
+
+    def set_spp(self, v):
+        self._spp = int(v)
+
+    def clear_frame(self, stream=None):
+        self._frame.zero_()
+        self._depth.zero_()
+
+
+class Testbed:
+    """The slice of ngp::Testbed the render path reads: network, occupancy, edit operators and the render knobs."""
+
+    def __init__(self, ctx, desc, aabb_scale=1):
+        self.ctx, self.lib, self.desc = ctx, ctx.lib, desc
+        self.nerf_network = NerfNetwork(ctx, desc)
+        self.edit_operators = []          # NerfTracer::m_edit_operators, applied last-to-first
+        self.enable_edits = True          # m_enable_edits
+        self.snap_to_pixel_centers = True
+        self.rendering_min_transmittance = 0.01
+        self.cone_angle_constant = 0.0 if aabb_scale <= 1 else 1.0 / 256.0
+        self.render_mode = _abi.RENDER_SHADE
+        self.linear_colors = False
+        mn, mx = list(desc.aabb_min), list(desc.aabb_max)
+        self.render_aabb = (mn, mx)       # m_render_aabb
+        self.last_stats = None
+
+    def add_edit_operator(self, op):
+        self.edit_operators.append(op)
+
+    def make_params(self, render_buffer, focal_length, camera_matrix0, camera_matrix1, rolling_shutter, screen_center, apply_operators):
+        p = RenderParams()
+        p.resolution[:] = render_buffer.in_resolution()
+        p.focal_length[:] = list(focal_length)
+        p.camera_matrix0[:] = [float(v) for v in np.asarray(camera_matrix0, np.float32).reshape(-1)]
+        p.camera_matrix1[:] = [float(v) for v in np.asarray(camera_matrix1, np.float32).reshape(-1)]
+        p.rolling_shutter[:] = list(rolling_shutter)
+        p.screen_center[:] = list(screen_center)
+        p.render_aabb_min[:] = self.render_aabb[0]
+        p.render_aabb_max[:] = self.render_aabb[1]
+        p.spp_index = render_buffer.spp()
+        p.snap_to_pixel_centers = 1 if self.snap_to_pixel_centers else 0
+        p.min_transmittance = self.rendering_min_transmittance
+        p.cone_angle_constant = self.cone_angle_constant
+        p.render_mode = self.render_mode
+        p.linear_colors = 1 if self.linear_colors else 0
+        p.apply_operators = 1 if apply_operators else 0
+        return p
+
+    def render_nerf(self, network, render_buffer, max_res, focal_length, camera_matrix0, camera_matrix1, rolling_shutter, screen_center,
+                    apply_operators, stream=None, want_stats=False):
+        """Testbed::render_nerf(network, render_buffer, max_res, focal_length, camera_matrix0, camera_matrix1, rolling_shutter,
+        screen_center, apply_operators, stream).  The frame buffer must have been cleared by the caller (render_frame does)."""
+        p = self.make_params(render_buffer, focal_length, camera_matrix0, camera_matrix1, rolling_shutter, screen_center,
+                             apply_operators and self.enable_edits)
+        return self.render_with_params(network, p, render_buffer.frame_buffer(), render_buffer.depth_buffer(), render_buffer.steps_buffer(),
+                                       stream, want_stats)
+
+    def render_with_params(self, network, p, frame, depth, steps=None, stream=None, want_stats=False):
+        _require_cuda(frame, torch.float32, "frame_buffer")
+        _require_cuda(depth, torch.float32, "depth_buffer")
+        n = len(self.edit_operators)
+        arr = (C.c_void_p * max(n, 1))(*[op.h for op in self.edit_operators])
+        stats = RenderStats() if want_stats else None
+        check(self.lib.nrs_render_nerf(network.h, C.byref(p), arr, n, frame.data_ptr(), depth.data_ptr(),
+                                       steps.data_ptr() if steps is not None else None, _stream_handle(stream),
+                                       C.byref(stats) if stats is not None else None))
+        self.last_stats = stats
+        return stats
+
+    def trace_samples(self, p, pixel_idx, max_samples, stream=None):
+        """Test hook: (t, dt) stream per listed pixel -> (t [n, max], dt [n, max], count [n]) as CUDA tensors."""
+        _require_cuda(pixel_idx, torch.int32, "pixel_idx")
+        n = pixel_idx.numel()
+        dev = pixel_idx.device
+        t = torch.zeros((n, max_samples), dtype=torch.float32, device=dev)
+        dt = torch.zeros((n, max_samples), dtype=torch.float32, device=dev)
+        cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+        check(self.lib.nrs_trace_samples(self.nerf_network.h, C.byref(p), _stream_handle(stream), n, pixel_idx.data_ptr(), max_samples,
+                                         t.data_ptr(), dt.data_ptr(), cnt.data_ptr()))
+        return t, dt, cnt

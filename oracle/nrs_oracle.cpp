@@ -1,0 +1,1471 @@
+/*
+ * nrs_oracle.cpp -- CPU ORACLE for the NeRFshop volumetric render path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is a plain C++ restatement (no Eigen, no tiny-cuda-nn, no GPU) of the reference's algorithm
+ * for the path BASELINE.json:north_star names.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg may load it -- as the checker, never as the thing measured or shipped.  Nothing
+ * under nerfshop_amd/ imports, links or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors, fixtures or snapshots for this path
+ * (SURVEY.md F3, 8c), its hash-grid / fully-fused-MLP / SH arithmetic lives in tiny-cuda-nn, an EMPTY,
+ * un-pinned submodule (fork gitlab.inria.fr/cjambon/tcnn-pyngp, branch pyngp-api, .gitmodules:16-19), and
+ * the reference cannot be compiled here (needs nvcc, Eigen, tcnn, GLFW...).  What IS pinned: the Sobol
+ * direction numbers / scramble (tests/golden/sobol_golden.json is generated from the reference's own
+ * table in include/neural-graphics-primitives/random_val.cuh by tests/golden/make_sobol_golden.py) and
+ * hand-derived known-answer values for the in-tree formulas.  The tcnn parts restate upstream
+ * NVlabs/tiny-cuda-nn semantics as published; where upstream rounding is ambiguous we
+ * state ours: hash-grid trilinear sum in fp32 (fmaf per corner, corners 0..7) rounded to fp16; MLP dot
+ * products of fp16 x fp16 accumulated exactly (double) then rounded fp32 -> ReLU -> fp16.
+ *
+ * Floating point: built with -ffp-contract=off; fused multiply-adds appear only as explicit fmaf().
+ * The HIP kernels are built the same way so that ray/sample indexing is bit-exact oracle <-> HIP.
+ *
+ * Citations are file:line in the reference checkout.  "tn" = src/testbed_nerf.cu, "cn" = src/common_nerf.cu.
+ */
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/nrs.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// fp16 <-> fp32 (software, round-to-nearest-even; gcc 11 has no _Float16 on x86)
+// ------------------------------------------------------------------------------------------------
+inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+inline float h2f(uint16_t h) {
+	uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+	uint32_t exp = (h >> 10) & 0x1fu;
+	uint32_t man = h & 0x3ffu;
+	if (exp == 0) {
+		if (man == 0) return u2f(sign);
+		// subnormal: value = man * 2^-24
+		float v = (float)man * 5.9604644775390625e-08f;
+		return sign ? -v : v;
+	}
+	if (exp == 31) return u2f(sign | 0x7f800000u | (man << 13));
+	return u2f(sign | ((exp + 112u) << 23) | (man << 13));
+}
+
+inline uint16_t f2h(float f) {
+	uint32_t x = f2u(f);
+	uint32_t sign = (x >> 16) & 0x8000u;
+	uint32_t ax = x & 0x7fffffffu;
+	if (ax >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((ax > 0x7f800000u) ? 0x200u : 0u)); // inf / nan
+	if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u); // >= 65520 rounds to inf
+	if (ax < 0x33000001u) return (uint16_t)sign;              // < 2^-25 (and exactly 2^-25 ties to even -> 0)
+	int e = (int)(ax >> 23) - 127;
+	uint32_t m = (ax & 0x7fffffu) | 0x800000u; // 24-bit significand
+	int shift = (e < -14) ? (13 + (-14 - e)) : 13; // bits to drop
+	uint32_t kept = m >> shift;
+	uint32_t rem = m & ((1u << shift) - 1u);
+	uint32_t half = 1u << (shift - 1);
+	if (rem > half || (rem == half && (kept & 1u))) kept++;
+	uint32_t h;
+	if (e < -14) h = kept;                       // subnormal (kept may carry into the normal range: fine)
+	else h = ((uint32_t)(e + 15) << 10) + (kept - 0x400u); // kept has the implicit bit at 0x400; carry propagates
+	return (uint16_t)(sign | h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small vectors
+// ------------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float comp(const V3& a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+struct Box { V3 mn, mx; };
+inline bool box_contains(const Box& b, V3 p) { // bounding_box.cuh:243-248
+	return p.x >= b.mn.x && p.x <= b.mx.x && p.y >= b.mn.y && p.y <= b.mx.y && p.z >= b.mn.z && p.z <= b.mx.z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// constants, common_nerf.h:16-39, tn:56-59
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t GRID = 128;
+constexpr uint32_t CASCADES = 5;
+constexpr uint32_t GRIDVOL = GRID * GRID * GRID;
+constexpr float SQRT3 = 1.73205080757f;
+constexpr float MIN_STEP = SQRT3 / 1024;                          // MIN_CONE_STEPSIZE
+constexpr float MAX_STEP = MIN_STEP * (1 << (CASCADES - 1)) * 1024 / GRID; // MAX_CONE_STEPSIZE
+constexpr float NEAR_DISTANCE = 0.05f;
+constexpr uint32_t MARCH_ITER = 10000;
+constexpr uint32_t MIN_STEPS_INBETWEEN_COMPACTION = 1, MAX_STEPS_INBETWEEN_COMPACTION = 8;
+
+// ------------------------------------------------------------------------------------------------
+// Morton code (tcnn morton3D: 10 bits per axis, x lowest)
+// ------------------------------------------------------------------------------------------------
+inline uint32_t expand_bits(uint32_t v) {
+	v = (v * 0x00010001u) & 0xFF0000FFu;
+	v = (v * 0x00000101u) & 0x0F00F00Fu;
+	v = (v * 0x00000011u) & 0xC30C30C3u;
+	v = (v * 0x00000005u) & 0x49249249u;
+	return v;
+}
+inline uint32_t morton3D(uint32_t x, uint32_t y, uint32_t z) { return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2); }
+inline uint32_t morton3D_invert(uint32_t x) {
+	x = x & 0x49249249u;
+	x = (x | (x >> 2)) & 0xc30c30c3u;
+	x = (x | (x >> 4)) & 0x0f00f00fu;
+	x = (x | (x >> 8)) & 0xff0000ffu;
+	x = (x | (x >> 16)) & 0x0000ffffu;
+	return x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scrambled Sobol, random_val.cuh:159-288, 317-322.  Only dimensions 0 and 1 are used on the path.
+// Direction numbers are generated, not tabulated: dim 0 is the van der Corput sequence (bit b ->
+// 0x80000000 >> b), dim 1 satisfies v[b] = v[b-1] ^ (v[b-1] >> 1); tests/golden pins both against
+// the reference's table.
+// ------------------------------------------------------------------------------------------------
+inline uint32_t sobol_dir(uint32_t dim, uint32_t bit) {
+	if (dim == 0) return 0x80000000u >> bit;
+	uint32_t v = 0x80000000u;
+	for (uint32_t b = 0; b < bit; ++b) v ^= v >> 1;
+	return v;
+}
+inline uint32_t sobol(uint32_t index, uint32_t dim) { // random_val.cuh:159-216
+	uint32_t X = 0;
+	for (uint32_t bit = 0; bit < 32; ++bit)
+		if ((index >> bit) & 1u) X ^= sobol_dir(dim, bit);
+	return X;
+}
+inline uint32_t hash_combine(uint32_t seed, uint32_t v) { return seed ^ (v + (seed << 6) + (seed >> 2)); } // :226
+inline uint32_t reverse_bits(uint32_t x) { // :230
+	x = (((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1));
+	x = (((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2));
+	x = (((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4));
+	x = (((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8));
+	return (x >> 16) | (x << 16);
+}
+inline uint32_t laine_karras_permutation(uint32_t x, uint32_t seed) { // :238
+	x += seed;
+	x ^= x * 0x6c50b47cu;
+	x ^= x * 0xb82f1e52u;
+	x ^= x * 0xc7afe638u;
+	x ^= x * 0x8d22f6e6u;
+	return x;
+}
+inline uint32_t nested_uniform_scramble_base2(uint32_t x, uint32_t seed) { // :247
+	x = reverse_bits(x);
+	x = laine_karras_permutation(x, seed);
+	x = reverse_bits(x);
+	return x;
+}
+constexpr float SOBOL_S = 2.3283064365386963e-10f; // float(1.0 / 2^32)
+inline float ld_random_val(uint32_t index, uint32_t seed, uint32_t dim = 0) { // :284
+	index = nested_uniform_scramble_base2(index, seed);
+	return (float)nested_uniform_scramble_base2(sobol(index, dim), hash_combine(seed, dim)) * SOBOL_S;
+}
+inline void ld_random_val_2d(uint32_t index, uint32_t seed, float out[2]) { // :278 via shuffled_scrambled_sobol2d :263
+	index = nested_uniform_scramble_base2(index, seed);
+	for (uint32_t i = 0; i < 2; ++i)
+		out[i] = (float)nested_uniform_scramble_base2(sobol(index, i), hash_combine(seed, i)) * SOBOL_S;
+}
+inline float fractf(float x) { return x - floorf(x); } // :76
+inline void ld_random_pixel_offset(uint32_t spp, float out[2]) { // :317-322
+	float a[2], b[2];
+	ld_random_val_2d(0, 0xdeadbeefu, a);
+	ld_random_val_2d(spp, 0xdeadbeefu, b);
+	out[0] = fractf((0.5f - a[0]) + b[0]);
+	out[1] = fractf((0.5f - a[1]) + b[1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid / step math, cn:80-177
+// ------------------------------------------------------------------------------------------------
+inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); }
+inline float calc_dt(float t, float cone_angle) { return clampf(t * cone_angle, MIN_STEP, MAX_STEP); } // cn:89
+inline float signf(float x) { return copysignf(1.0f, x); }                                             // common.h:183
+
+// exponent e such that x = m * 2^e with 0.5 <= |m| < 1 (frexpf's second result); 0 for x == 0
+inline int frexp_exponent(float x) {
+	uint32_t u = f2u(x) & 0x7fffffffu;
+	if (u == 0) return 0;
+	uint32_t ef = u >> 23;
+	if (ef == 0) return -117 - __builtin_clz(u); // subnormal: value = man * 2^-149, top bit b = 31 - clz -> e = b - 148
+	return (int)ef - 126;
+}
+
+inline float distance_to_next_voxel(V3 pos, V3 dir, V3 idir, uint32_t res) { // cn:93-101
+	V3 p = (float)res * pos;
+	float tx = (floorf(p.x + 0.5f + 0.5f * signf(dir.x)) - p.x) * idir.x;
+	float ty = (floorf(p.y + 0.5f + 0.5f * signf(dir.y)) - p.y) * idir.y;
+	float tz = (floorf(p.z + 0.5f + 0.5f * signf(dir.z)) - p.z) * idir.z;
+	float t = fminf(fminf(tx, ty), tz);
+	return fmaxf(t / (float)res, 0.0f);
+}
+inline float advance_to_next_voxel(float t, float cone_angle, V3 pos, V3 dir, V3 idir, uint32_t res) { // cn:103-115
+	float t_target = t + distance_to_next_voxel(pos, dir, idir, res);
+	do {
+		t += calc_dt(t, cone_angle);
+	} while (t < t_target);
+	return t;
+}
+inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+inline uint32_t cascaded_grid_idx_at(V3 pos, uint32_t mip) { // cn:117-136
+	float mip_scale = scalbnf(1.0f, -(int)mip);
+	pos = pos - v3(0.5f, 0.5f, 0.5f);
+	pos = pos * mip_scale;
+	pos = pos + v3(0.5f, 0.5f, 0.5f);
+	int ix = (int)(pos.x * (float)GRID), iy = (int)(pos.y * (float)GRID), iz = (int)(pos.z * (float)GRID);
+	return morton3D((uint32_t)clampi(ix, 0, GRID - 1), (uint32_t)clampi(iy, 0, GRID - 1), (uint32_t)clampi(iz, 0, GRID - 1));
+}
+inline uint32_t grid_mip_offset(uint32_t mip) { return GRIDVOL * mip; } // cn:76
+inline bool get_bitfield_at(uint32_t cell_idx, uint32_t level, const uint8_t* bitfield) { // cn:153
+	return bitfield[cell_idx / 8 + grid_mip_offset(level) / 8] & (1 << (cell_idx % 8));
+}
+inline void set_bitfield_at(uint32_t cell_idx, uint32_t level, bool value, uint8_t* bitfield) { // cn:157
+	uint32_t bit = cell_idx % 8, mask = 1u << bit;
+	uint8_t& b = bitfield[cell_idx / 8 + grid_mip_offset(level) / 8];
+	b = (uint8_t)((b & ~mask) | ((uint32_t)value << bit));
+}
+inline bool density_grid_occupied_at(V3 pos, const uint8_t* bitfield, uint32_t mip) { // cn:138
+	return get_bitfield_at(cascaded_grid_idx_at(pos, mip), mip, bitfield);
+}
+inline int mip_from_pos(V3 pos) { // cn:163-168
+	float maxval = fmaxf(fmaxf(fabsf(pos.x - 0.5f), fabsf(pos.y - 0.5f)), fabsf(pos.z - 0.5f));
+	int exponent = frexp_exponent(maxval);
+	return std::min((int)CASCADES - 1, std::max(0, exponent + 1));
+}
+inline int mip_from_dt(float dt, V3 pos) { // cn:170-177
+	int mip = mip_from_pos(pos);
+	dt *= 2 * GRID;
+	if (dt < 1.f) return mip;
+	int exponent = frexp_exponent(dt);
+	return std::min((int)CASCADES - 1, std::max(exponent, mip));
+}
+inline V3 warp_position(V3 pos, const Box& aabb) { // cn:5 -> bounding_box.cuh:96 relative_pos
+	V3 d = aabb.mx - aabb.mn;
+	return {(pos.x - aabb.mn.x) / d.x, (pos.y - aabb.mn.y) / d.y, (pos.z - aabb.mn.z) / d.z};
+}
+inline V3 unwarp_position(V3 pos, const Box& aabb) { // cn:12
+	V3 d = aabb.mx - aabb.mn;
+	return {aabb.mn.x + pos.x * d.x, aabb.mn.y + pos.y * d.y, aabb.mn.z + pos.z * d.z};
+}
+inline V3 warp_direction(V3 d) { return {(d.x + 1.0f) * 0.5f, (d.y + 1.0f) * 0.5f, (d.z + 1.0f) * 0.5f}; }   // cn:20
+inline V3 unwarp_direction(V3 d) { return {d.x * 2.0f - 1.0f, d.y * 2.0f - 1.0f, d.z * 2.0f - 1.0f}; }       // cn:24
+inline float warp_dt(float dt) { // cn:28
+	float max_stepsize = MIN_STEP * (1 << (CASCADES - 1));
+	return (dt - MIN_STEP) / (max_stepsize - MIN_STEP);
+}
+inline float unwarp_dt(float dt) { // cn:33
+	float max_stepsize = MIN_STEP * (1 << (CASCADES - 1));
+	return dt * (max_stepsize - MIN_STEP) + MIN_STEP;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rays: pixel_to_ray (common_device.cuh:245-295), init_rays_with_payload_kernel_nerf (tn:2512-2616)
+// ------------------------------------------------------------------------------------------------
+struct Payload { // nerf.h:23
+	V3 origin, dir;
+	float t, max_weight;
+	uint32_t idx;
+	uint32_t n_steps;
+	bool alive;
+};
+
+inline void ray_intersect(const Box& b, V3 pos, V3 dir, float& tmin_out, float& tmax_out) { // bounding_box.cuh:180-238
+	const float FMAX = std::numeric_limits<float>::max();
+	float tmin = (b.mn.x - pos.x) / dir.x, tmax = (b.mx.x - pos.x) / dir.x;
+	if (tmin > tmax) std::swap(tmin, tmax);
+	float tymin = (b.mn.y - pos.y) / dir.y, tymax = (b.mx.y - pos.y) / dir.y;
+	if (tymin > tymax) std::swap(tymin, tymax);
+	if (tmin > tymax || tymin > tmax) { tmin_out = FMAX; tmax_out = FMAX; return; }
+	if (tymin > tmin) tmin = tymin;
+	if (tymax < tmax) tmax = tymax;
+	float tzmin = (b.mn.z - pos.z) / dir.z, tzmax = (b.mx.z - pos.z) / dir.z;
+	if (tzmin > tzmax) std::swap(tzmin, tzmax);
+	if (tmin > tzmax || tzmin > tmax) { tmin_out = FMAX; tmax_out = FMAX; return; }
+	if (tzmin > tmin) tmin = tzmin;
+	if (tzmax < tmax) tmax = tzmax;
+	tmin_out = tmin; tmax_out = tmax;
+}
+
+struct Camera { float m[12]; }; // 3x4 column-major
+inline V3 cam_col(const float* m, int c) { return {m[3 * c + 0], m[3 * c + 1], m[3 * c + 2]}; }
+
+inline void init_ray(const nrs_render_params& p, uint32_t x, uint32_t y, Payload& payload, float& depth_out) {
+	const uint32_t W = (uint32_t)p.resolution[0], H = (uint32_t)p.resolution[1];
+	const uint32_t idx = x + W * y;
+	const Box aabb{v3(p.render_aabb_min[0], p.render_aabb_min[1], p.render_aabb_min[2]),
+	               v3(p.render_aabb_max[0], p.render_aabb_max[1], p.render_aabb_max[2])};
+	// tn:2551-2553
+	float u = ((float)x + 0.5f) * (1.f / (float)W);
+	float v = ((float)y + 0.5f) * (1.f / (float)H);
+	float ray_time = p.rolling_shutter[0] + p.rolling_shutter[1] * u + p.rolling_shutter[2] * v +
+	                 p.rolling_shutter[3] * ld_random_val(p.spp_index, idx * 72239731u);
+	float cam[12];
+	for (int i = 0; i < 12; ++i) cam[i] = p.camera_matrix0[i] * ray_time + p.camera_matrix1[i] * (1.f - ray_time); // tn:2559
+
+	// pixel_to_ray, common_device.cuh:259-284 (no distortion, no DoF: SURVEY App. A)
+	float offset[2];
+	ld_random_pixel_offset(p.snap_to_pixel_centers ? 0 : p.spp_index, offset);
+	float uvx = ((float)x + offset[0]) / (float)W;
+	float uvy = ((float)y + offset[1]) / (float)H;
+	V3 dir = {(uvx - p.screen_center[0]) * (float)W / p.focal_length[0],
+	          (uvy - p.screen_center[1]) * (float)H / p.focal_length[1], 1.0f};
+	V3 c0 = cam_col(cam, 0), c1 = cam_col(cam, 1), c2 = cam_col(cam, 2);
+	V3 d = {(c0.x * dir.x + c1.x * dir.y) + c2.x * dir.z,
+	        (c0.y * dir.x + c1.y * dir.y) + c2.y * dir.z,
+	        (c0.z * dir.x + c1.z * dir.y) + c2.z * dir.z};
+	V3 o = cam_col(cam, 3);
+
+	payload.max_weight = 0.0f; // tn:2573
+	depth_out = 1e10f;         // tn:2586
+	float n = sqrtf(dot(d, d)); // .normalized(), tn:2588
+	d = {d.x / n, d.y / n, d.z / n};
+	float tmin, tmax;
+	ray_intersect(aabb, o, d, tmin, tmax);
+	float t = fmaxf(tmin, NEAR_DISTANCE) + 1e-6f; // tn:2594
+	payload.idx = idx;
+	payload.n_steps = 0;
+	payload.origin = o;
+	payload.dir = d;
+	payload.t = t;
+	if (!box_contains(aabb, o + d * t)) { // tn:2596-2600
+		payload.alive = false;
+		return;
+	}
+	payload.alive = true;
+}
+
+// advance_pos_nerf, tn:557-606
+inline void advance_pos(const nrs_render_params& p, const uint8_t* bitfield, Payload& payload, uint32_t pixel_i) {
+	if (!payload.alive) return;
+	const Box aabb{v3(p.render_aabb_min[0], p.render_aabb_min[1], p.render_aabb_min[2]),
+	               v3(p.render_aabb_max[0], p.render_aabb_max[1], p.render_aabb_max[2])};
+	V3 origin = payload.origin, dir = payload.dir;
+	V3 idir = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+	float cone_angle = p.cone_angle_constant; // calc_cone_angle returns the constant, cn:80-87
+	float t = payload.t;
+	float dt = calc_dt(t, cone_angle);
+	t += ld_random_val(p.spp_index, pixel_i * 786433u) * dt;
+	V3 pos;
+	while (1) {
+		pos = origin + dir * t;
+		if (!box_contains(aabb, pos)) { payload.alive = false; break; }
+		dt = calc_dt(t, cone_angle);
+		uint32_t mip = std::max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
+		if (density_grid_occupied_at(pos, bitfield, mip)) break;
+		uint32_t res = GRID >> mip;
+		t = advance_to_next_voxel(t, cone_angle, pos, dir, idir, res);
+	}
+	payload.t = t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Network: hash grid + SH + two MLPs (tiny-cuda-nn semantics; wiring nerf_network_full.h:40-96)
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t MAX_LEVELS = 16;
+struct LevelTable {
+	float scale[MAX_LEVELS];
+	uint32_t resolution[MAX_LEVELS], offset[MAX_LEVELS], count[MAX_LEVELS], hashed[MAX_LEVELS];
+	uint32_t total_entries;
+};
+
+bool desc_supported(const nrs_model_desc& d) {
+	return d.n_levels == 16 && d.n_features_per_level == 2 && d.n_neurons == 64 && d.density_hidden_layers == 1 &&
+	       d.density_output_dims == 16 && d.rgb_hidden_layers == 2 && d.sh_degree == 4 && d.log2_hashmap_size >= 8 &&
+	       d.log2_hashmap_size <= 24 && d.base_resolution >= 1;
+}
+
+void make_level_table(const nrs_model_desc& d, LevelTable& lt) {
+	// tcnn GridEncoding ctor: scale = exp2(l*log2(pls))*base - 1; res = ceil(scale)+1;
+	// params_in_level = min(align8(res^3), 2^log2_T).  Scales are evaluated in double on the HOST and
+	// rounded to float once (our choice: keeps device exp2f out of the indexing path).
+	uint32_t off = 0;
+	const double l2 = std::log2((double)d.per_level_scale);
+	for (uint32_t l = 0; l < d.n_levels; ++l) {
+		double s = std::exp2((double)l * l2) * (double)d.base_resolution - 1.0;
+		lt.scale[l] = (float)s;
+		uint32_t res = (uint32_t)std::ceil((double)lt.scale[l]) + 1u;
+		lt.resolution[l] = res;
+		uint64_t n = (uint64_t)res * res * res;
+		uint64_t cap = 1ull << d.log2_hashmap_size;
+		n = (n + 7ull) / 8ull * 8ull;
+		uint32_t cnt = (uint32_t)std::min<uint64_t>(n, cap);
+		lt.count[l] = cnt;
+		lt.offset[l] = off;
+		// hashed iff the dense stride product exceeds the level's entry count (tcnn grid_index)
+		uint64_t stride = 1;
+		for (int dim = 0; dim < 3 && stride <= cnt; ++dim) stride *= res;
+		lt.hashed[l] = cnt < stride ? 1u : 0u;
+		off += cnt;
+	}
+	lt.total_entries = off;
+}
+
+constexpr uint32_t N_DENSITY_W = 64 * 32 + 16 * 64;           // 3072
+constexpr uint32_t N_RGB_W = 64 * 32 + 64 * 64 + 16 * 64;     // 7168
+
+struct Model {
+	nrs_model_desc desc;
+	LevelTable lt;
+	Box aabb;
+	std::vector<uint16_t> params; // tcnn order: density | rgb | grid
+	std::vector<float> wf;        // MLP weights converted to float once
+	std::vector<uint8_t> bitfield;
+	const uint16_t* grid() const { return params.data() + N_DENSITY_W + N_RGB_W; }
+};
+
+inline uint32_t grid_index(const LevelTable& lt, uint32_t l, uint32_t gx, uint32_t gy, uint32_t gz) {
+	const uint32_t res = lt.resolution[l], cnt = lt.count[l];
+	uint32_t index;
+	if (lt.hashed[l]) {
+		index = (gx * 1u) ^ (gy * 2654435761u) ^ (gz * 805459861u);
+	} else {
+		// stride loop of tcnn grid_index with N_DIMS = 3 (stride <= count holds for all three dims when not hashed)
+		index = gx + gy * res + gz * res * res;
+	}
+	return index % cnt;
+}
+
+// one sample -> 32 fp16 features, level-major [l*2+f]
+void hashgrid_encode_one(const Model& m, const float pos[3], uint16_t out[32]) {
+	const uint16_t* grid = m.grid();
+	for (uint32_t l = 0; l < m.desc.n_levels; ++l) {
+		const float scale = m.lt.scale[l];
+		float p[3], w[3];
+		uint32_t g[3];
+		for (int d = 0; d < 3; ++d) {
+			p[d] = fmaf(scale, pos[d], 0.5f);
+			float fl = floorf(p[d]);
+			g[d] = (uint32_t)(int)fl;
+			w[d] = p[d] - fl;
+		}
+		float acc0 = 0.f, acc1 = 0.f;
+		for (uint32_t c = 0; c < 8; ++c) {
+			float weight = 1.0f;
+			uint32_t gl[3];
+			for (int d = 0; d < 3; ++d) {
+				if ((c & (1u << d)) == 0) { weight *= 1.0f - w[d]; gl[d] = g[d]; }
+				else { weight *= w[d]; gl[d] = g[d] + 1u; }
+			}
+			uint32_t e = m.lt.offset[l] + grid_index(m.lt, l, gl[0], gl[1], gl[2]);
+			acc0 = fmaf(weight, h2f(grid[2 * (size_t)e + 0]), acc0);
+			acc1 = fmaf(weight, h2f(grid[2 * (size_t)e + 1]), acc1);
+		}
+		out[2 * l + 0] = f2h(acc0);
+		out[2 * l + 1] = f2h(acc1);
+	}
+}
+
+// SH degree 4 of the direction given as (d+1)/2 in [0,1]^3 -> 16 fp16 (tcnn SphericalHarmonics encoding)
+void sh4_encode_one(const float dir01[3], uint16_t out[16]) {
+	float x = dir01[0] * 2.f - 1.f, y = dir01[1] * 2.f - 1.f, z = dir01[2] * 2.f - 1.f;
+	float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+	float o[16];
+	o[0] = 0.28209479177387814f;
+	o[1] = -0.48860251190291987f * y;
+	o[2] = 0.48860251190291987f * z;
+	o[3] = -0.48860251190291987f * x;
+	o[4] = 1.0925484305920792f * xy;
+	o[5] = -1.0925484305920792f * yz;
+	o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+	o[7] = -1.0925484305920792f * xz;
+	o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+	o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+	o[10] = 2.8906114426405538f * xy * z;
+	o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+	o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+	o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+	o[14] = 1.4453057213202769f * z * (x2 - y2);
+	o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+	for (int i = 0; i < 16; ++i) out[i] = f2h(o[i]);
+}
+
+// out[j] = act( sum_k W[j*n_in + k] * in[k] ), fp16 in/out, exact accumulation
+inline void dense_layer(const float* W, uint32_t n_out, uint32_t n_in, const uint16_t* in, uint16_t* out, bool relu) {
+	float inf[64];
+	for (uint32_t k = 0; k < n_in; ++k) inf[k] = h2f(in[k]);
+	for (uint32_t j = 0; j < n_out; ++j) {
+		double acc = 0.0;
+		const float* w = W + (size_t)j * n_in;
+		for (uint32_t k = 0; k < n_in; ++k) acc += (double)w[k] * (double)inf[k];
+		float r = (float)acc;
+		if (relu && !(r > 0.f)) r = 0.f;
+		out[j] = f2h(r);
+	}
+}
+
+// density MLP 32->64->16 (base.json:30-36).  feat: 32 fp16.  out: 16 fp16.
+void density_mlp_one(const Model& m, const uint16_t feat[32], uint16_t out[16]) {
+	const float* W1 = m.wf.data();
+	const float* W2 = W1 + 64 * 32;
+	uint16_t h[64];
+	dense_layer(W1, 64, 32, feat, h, true);
+	dense_layer(W2, 16, 64, h, out, false);
+}
+// rgb MLP 32->64->64->16 (base.json:52-58); input = [density out 16 | SH 16] (nerf_network_full.h:65-87)
+void rgb_mlp_one(const Model& m, const uint16_t in32[32], uint16_t out[16]) {
+	const float* W1 = m.wf.data() + N_DENSITY_W;
+	const float* W2 = W1 + 64 * 32;
+	const float* W3 = W2 + 64 * 64;
+	uint16_t h1[64], h2[64];
+	dense_layer(W1, 64, 32, in32, h1, true);
+	dense_layer(W2, 64, 64, h1, h2, true);
+	dense_layer(W3, 16, 64, h2, out, false);
+}
+// NerfNetworkFull::inference_mixed_precision_impl, nerf_network_full.h:62-96.  coord: 7 floats. out16: channels
+// 0..2 rgb raw, 3 = density raw (extract_density :89-95), 4..15 rgb-net padding outputs.
+void network_inference_one(const Model& m, const float coord[7], uint16_t out16[16]) {
+	uint16_t feat[32], in32[32];
+	hashgrid_encode_one(m, coord, feat);
+	density_mlp_one(m, feat, in32);          // rows 0..15 of rgb_network_input
+	sh4_encode_one(coord + 4, in32 + 16);    // dir_offset = 4 (testbed.cu:2328)
+	rgb_mlp_one(m, in32, out16);
+	out16[3] = in32[0];
+}
+
+inline float logistic(float x) { return 1.0f / (1.0f + expf(-x)); }
+inline float network_to_rgb(float v, uint32_t act) { // cn:38-47
+	switch (act) {
+		case NRS_ACT_NONE: return v;
+		case NRS_ACT_RELU: return v > 0.f ? v : 0.f;
+		case NRS_ACT_LOGISTIC: return logistic(v);
+		case NRS_ACT_EXPONENTIAL: return expf(clampf(v, -10.f, 10.f));
+	}
+	return 0.f;
+}
+inline float network_to_density(float v, uint32_t act) { // cn:57-66
+	switch (act) {
+		case NRS_ACT_NONE: return v;
+		case NRS_ACT_RELU: return v > 0.f ? v : 0.f;
+		case NRS_ACT_LOGISTIC: return logistic(v);
+		case NRS_ACT_EXPONENTIAL: return expf(v);
+	}
+	return 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cage / tet warp: selection_utils.h:10-47, cage_deformation.cu:136-269, 431-541
+// ------------------------------------------------------------------------------------------------
+inline float scalar_tp(V3 a, V3 b, V3 c) { return dot(a, cross(b, c)); }
+inline void bary_tet(V3 a, V3 b, V3 c, V3 d, V3 p, float out[4]) { // selection_utils.h:14-31
+	V3 vap = p - a, vbp = p - b, vab = b - a, vac = c - a, vad = d - a, vbc = c - b, vbd = d - b;
+	float va6 = scalar_tp(vbp, vbd, vbc);
+	float vb6 = scalar_tp(vap, vac, vad);
+	float vc6 = scalar_tp(vap, vad, vab);
+	float vd6 = scalar_tp(vap, vab, vac);
+	float v6 = (float)(1. / (double)scalar_tp(vab, vac, vad)); // "1. / float" is a double division rounded to float
+	out[0] = va6 * v6; out[1] = vb6 * v6; out[2] = vc6 * v6; out[3] = vd6 * v6;
+}
+inline bool same_side_tet(V3 v1, V3 v2, V3 v3_, V3 v4, V3 p) { // :33-39
+	V3 normal = cross(v2 - v1, v3_ - v1);
+	float dotV4 = dot(normal, v4 - v1);
+	float dotP = dot(normal, p - v1);
+	return std::signbit(dotV4) == std::signbit(dotP);
+}
+inline bool point_in_tet(V3 v1, V3 v2, V3 v3_, V3 v4, V3 p) { // :41-47
+	return same_side_tet(v1, v2, v3_, v4, p) && same_side_tet(v2, v3_, v4, v1, p) &&
+	       same_side_tet(v3_, v4, v1, v2, p) && same_side_tet(v4, v1, v2, v3_, p);
+}
+
+struct Edit {
+	Box aabb;                                   // scene aabb (m_scene_aabb)
+	Box bbox, warped_bbox, orig_bbox, orig_warped_bbox; // tet_mesh.cu:12-20, tet_mesh.h:100-107
+	std::vector<V3> verts, orig;
+	std::vector<uint32_t> tets, lut_off, lut_idx;
+	std::vector<uint8_t> orig_bitfield;
+	std::vector<float> rot; // [T*9] col-major or empty
+	bool copy = false;
+	bool apply_poisson = false;
+	float residual_amplitude = 1.f;
+	std::vector<float> shs, out_density, res_density;
+};
+
+inline V3 ldv(const std::vector<V3>& a, uint32_t i) { return a[i]; }
+
+Box bbox_of(const std::vector<V3>& v) {
+	const float inf = std::numeric_limits<float>::infinity();
+	Box b{v3(inf, inf, inf), v3(-inf, -inf, -inf)};
+	for (const V3& p : v) {
+		b.mn = v3(fminf(b.mn.x, p.x), fminf(b.mn.y, p.y), fminf(b.mn.z, p.z));
+		b.mx = v3(fmaxf(b.mx.x, p.x), fmaxf(b.mx.y, p.y), fmaxf(b.mx.z, p.z));
+	}
+	return b;
+}
+Box warp_box(const Box& b, const Box& aabb) { return Box{warp_position(b.mn, aabb), warp_position(b.mx, aabb)}; } // bounding_box.cuh:272
+
+// interpolate_tet, cage_deformation.cu:197-269.  coord: 7 floats, in place.  returns through *empty.
+void map_ray_one(const Edit& e, float coord[7], uint8_t* empty) {
+	V3 p = {coord[0], coord[1], coord[2]};
+	bool in_deformed = false;
+	if (box_contains(e.warped_bbox, p)) {
+		V3 u = unwarp_position(p, e.aabb);
+		int level = mip_from_pos(u);
+		uint32_t cell = (uint32_t)level * GRIDVOL + cascaded_grid_idx_at(u, (uint32_t)level);
+		for (uint32_t j = e.lut_off[cell]; j < e.lut_off[cell + 1]; ++j) {
+			uint32_t t = e.lut_idx[j];
+			V3 a = e.verts[e.tets[4 * t]], b = e.verts[e.tets[4 * t + 1]], c = e.verts[e.tets[4 * t + 2]], d = e.verts[e.tets[4 * t + 3]];
+			if (point_in_tet(a, b, c, d, u)) {
+				float bc[4];
+				bary_tet(a, b, c, d, u, bc);
+				V3 o0 = e.orig[e.tets[4 * t]], o1 = e.orig[e.tets[4 * t + 1]], o2 = e.orig[e.tets[4 * t + 2]], o3 = e.orig[e.tets[4 * t + 3]];
+				V3 canon = ((bc[0] * o0 + bc[1] * o1) + bc[2] * o2) + bc[3] * o3;
+				V3 wp = warp_position(canon, e.aabb);
+				coord[0] = wp.x; coord[1] = wp.y; coord[2] = wp.z;
+				if (!e.rot.empty()) {
+					V3 ud = unwarp_direction(v3(coord[4], coord[5], coord[6]));
+					const float* R = &e.rot[9 * (size_t)t]; // column-major
+					V3 rd = {(R[0] * ud.x + R[3] * ud.y) + R[6] * ud.z,
+					         (R[1] * ud.x + R[4] * ud.y) + R[7] * ud.z,
+					         (R[2] * ud.x + R[5] * ud.y) + R[8] * ud.z};
+					V3 wd = warp_direction(rd);
+					coord[4] = wd.x; coord[5] = wd.y; coord[6] = wd.z;
+				}
+				in_deformed = true;
+				break;
+			}
+		}
+	}
+	if (!e.copy) {
+		V3 q = {coord[0], coord[1], coord[2]};
+		if (!in_deformed && box_contains(e.orig_warped_bbox, q)) {
+			V3 u = unwarp_position(q, e.aabb);
+			int level = mip_from_pos(u);
+			uint32_t pos_idx = cascaded_grid_idx_at(u, (uint32_t)level);
+			if (get_bitfield_at(pos_idx, (uint32_t)level, e.orig_bitfield.data())) *empty = 1;
+		}
+	}
+}
+
+// interpolate_tet_pos, cage_deformation.cu:136-192 (no direction, no copy flag)
+void map_position_one(const Edit& e, float pos[3], uint8_t* empty) {
+	V3 p = {pos[0], pos[1], pos[2]};
+	bool in_deformed = false;
+	if (box_contains(e.warped_bbox, p)) {
+		V3 u = unwarp_position(p, e.aabb);
+		int level = mip_from_pos(u);
+		uint32_t cell = (uint32_t)level * GRIDVOL + cascaded_grid_idx_at(u, (uint32_t)level);
+		for (uint32_t j = e.lut_off[cell]; j < e.lut_off[cell + 1]; ++j) {
+			uint32_t t = e.lut_idx[j];
+			V3 a = e.verts[e.tets[4 * t]], b = e.verts[e.tets[4 * t + 1]], c = e.verts[e.tets[4 * t + 2]], d = e.verts[e.tets[4 * t + 3]];
+			if (point_in_tet(a, b, c, d, u)) {
+				float bc[4];
+				bary_tet(a, b, c, d, u, bc);
+				V3 o0 = e.orig[e.tets[4 * t]], o1 = e.orig[e.tets[4 * t + 1]], o2 = e.orig[e.tets[4 * t + 2]], o3 = e.orig[e.tets[4 * t + 3]];
+				V3 canon = ((bc[0] * o0 + bc[1] * o1) + bc[2] * o2) + bc[3] * o3;
+				V3 wp = warp_position(canon, e.aabb);
+				pos[0] = wp.x; pos[1] = wp.y; pos[2] = wp.z;
+				in_deformed = true;
+				break;
+			}
+		}
+	}
+	V3 q = {pos[0], pos[1], pos[2]};
+	if (!in_deformed && box_contains(e.orig_warped_bbox, q)) {
+		V3 u = unwarp_position(q, e.aabb);
+		int level = mip_from_pos(u);
+		uint32_t pos_idx = cascaded_grid_idx_at(u, (uint32_t)level);
+		if (get_bitfield_at(pos_idx, (uint32_t)level, e.orig_bitfield.data())) *empty = 1;
+	}
+}
+
+// compute_residual_poisson_kernel body for one sample, cage_deformation.cu:467-507
+void poisson_residual_one(const Edit& e, const float coord[7], float sh_out[27], float* out_density, float* res_density) {
+	V3 pos = unwarp_position(v3(coord[0], coord[1], coord[2]), e.aabb);
+	if (!box_contains(e.bbox, pos)) return;
+	int level = mip_from_pos(pos);
+	uint32_t cell = (uint32_t)level * GRIDVOL + cascaded_grid_idx_at(pos, (uint32_t)level);
+	for (uint32_t j = e.lut_off[cell]; j < e.lut_off[cell + 1]; ++j) {
+		uint32_t t = e.lut_idx[j];
+		const uint32_t* tv = &e.tets[4 * (size_t)t];
+		V3 a = e.verts[tv[0]], b = e.verts[tv[1]], c = e.verts[tv[2]], d = e.verts[tv[3]];
+		if (point_in_tet(a, b, c, d, pos)) {
+			float bc[4];
+			bary_tet(a, b, c, d, pos, bc);
+			for (int k = 0; k < 27; ++k)
+				sh_out[k] = ((bc[0] * e.shs[27 * (size_t)tv[0] + k] + bc[1] * e.shs[27 * (size_t)tv[1] + k]) +
+				             bc[2] * e.shs[27 * (size_t)tv[2] + k]) + bc[3] * e.shs[27 * (size_t)tv[3] + k];
+			float lo = ((bc[0] * e.out_density[tv[0]] + bc[1] * e.out_density[tv[1]]) + bc[2] * e.out_density[tv[2]]) + bc[3] * e.out_density[tv[3]];
+			float lr = ((bc[0] * e.res_density[tv[0]] + bc[1] * e.res_density[tv[1]]) + bc[2] * e.res_density[tv[2]]) + bc[3] * e.res_density[tv[3]];
+			*out_density = e.residual_amplitude * lo;
+			*res_density = e.residual_amplitude * lr;
+			break;
+		}
+	}
+}
+
+// evaluate_sh9 (SH9RGB = 9x3 column-major), cn:218-245
+void evaluate_sh9(const float sh[27], V3 dir, float rgb[3]) {
+	float fC0, fC1, fS0, fS1, fTmpA, fTmpB, fTmpC;
+	float fZ2 = dir.z * dir.z;
+	float pSH[9];
+	pSH[0] = 0.2820947917738781f;
+	pSH[2] = 0.4886025119029199f * dir.z;
+	pSH[6] = 0.9461746957575601f * fZ2 + -0.3153915652525201f;
+	fC0 = dir.x; fS0 = dir.y;
+	fTmpA = -0.48860251190292f;
+	pSH[3] = fTmpA * fC0; pSH[1] = fTmpA * fS0;
+	fTmpB = -1.092548430592079f * dir.z;
+	pSH[7] = fTmpB * fC0; pSH[5] = fTmpB * fS0;
+	fC1 = dir.x * fC0 - dir.y * fS0;
+	fS1 = dir.x * fS0 + dir.y * fC0;
+	fTmpC = 0.5462742152960395f;
+	pSH[8] = fTmpC * fC1; pSH[4] = fTmpC * fS1;
+	for (int c = 0; c < 3; ++c) {
+		float s = 0.f;
+		for (int k = 0; k < 9; ++k) s += pSH[k] * sh[9 * c + k];
+		rgb[c] = s;
+	}
+}
+
+inline float srgb_to_linear(float s) { // common_device.cuh:31-37
+	if (s <= 0.04045f) return s / 12.92f;
+	return powf((s + 0.055f) / 1.055f, 2.4f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The render loop: Testbed::render_nerf tn:3066 = init_rays_from_camera tn:2683 + trace tn:2772 + shade tn:2448
+// ------------------------------------------------------------------------------------------------
+struct RayState {
+	Payload payload;
+	float rgba[4];
+	float depth;
+	bool in_hit_list;
+};
+
+struct RenderStats { uint64_t generated, composited; uint32_t n_alive0, n_hit, iterations; };
+
+void render(const Model& m, const nrs_render_params& p, const Edit* const* edits, int n_edits,
+            float* frame, float* depth_buf, uint32_t* steps_buf, RenderStats* stats, int fixed_S) {
+	const uint32_t W = (uint32_t)p.resolution[0], H = (uint32_t)p.resolution[1];
+	const uint32_t N = W * H;
+	const Box render_aabb{v3(p.render_aabb_min[0], p.render_aabb_min[1], p.render_aabb_min[2]),
+	                      v3(p.render_aabb_max[0], p.render_aabb_max[1], p.render_aabb_max[2])};
+	const Box train_aabb = m.aabb;
+	const uint8_t* grid = m.bitfield.data();
+	const bool ops = p.apply_operators && n_edits > 0;
+	const uint32_t march_iter = p.max_march_steps ? p.max_march_steps : MARCH_ITER;
+
+	std::vector<RayState> rays(N);
+	// tiles: a pixel belongs to this call iff its tile index matches (tile_first, tile_stride)
+	auto owned = [&](uint32_t x, uint32_t y) -> bool {
+		if (p.tile_size == 0) return true;
+		uint32_t tiles_x = (W + p.tile_size - 1) / p.tile_size;
+		uint32_t t = (y / p.tile_size) * tiles_x + (x / p.tile_size);
+		uint32_t stride = p.tile_stride ? p.tile_stride : 1;
+		return t >= p.tile_first && (t - p.tile_first) % stride == 0;
+	};
+
+#pragma omp parallel for schedule(dynamic, 256)
+	for (int64_t i = 0; i < (int64_t)N; ++i) {
+		uint32_t x = (uint32_t)i % W, y = (uint32_t)i / W;
+		RayState& r = rays[i];
+		memset(&r, 0, sizeof(r));
+		if (!owned(x, y)) { r.payload.alive = false; r.payload.idx = (uint32_t)i; continue; }
+		float d0;
+		init_ray(p, x, y, r.payload, d0);
+		depth_buf[i] = d0;
+		advance_pos(p, grid, r.payload, (uint32_t)i);
+		if (steps_buf) steps_buf[i] = 0;
+	}
+
+	std::vector<uint32_t> alive, next_alive;
+	alive.reserve(N);
+	for (uint32_t i = 0; i < N; ++i) alive.push_back(i);
+	uint32_t n_rays_initialized = N; // m_n_rays_initialized = res.x*res.y, tn:2739
+	// (with tiling the reference has no counterpart; S then differs but per-pixel results do not)
+	uint64_t generated = 0, composited = 0;
+	uint32_t n_hit = 0, n_alive0 = 0, iterations = 0;
+	std::vector<uint32_t> hit;
+
+	uint32_t i_step = 1;
+	bool first = true;
+	while (i_step < march_iter) { // tn:2812
+		// compact_kernel_nerf, tn:2485-2510 (order is irrelevant per pixel; we keep index order)
+		next_alive.clear();
+		for (uint32_t ri : alive) {
+			RayState& r = rays[ri];
+			if (r.payload.alive) next_alive.push_back(ri);
+			else if (r.rgba[3] > 0.001f) hit.push_back(ri);
+		}
+		alive.swap(next_alive);
+		const uint32_t n_alive = (uint32_t)alive.size();
+		if (first) { n_alive0 = n_alive; first = false; }
+		if (n_alive == 0) break;
+		uint32_t S = std::min(std::max(n_rays_initialized / n_alive, MIN_STEPS_INBETWEEN_COMPACTION), MAX_STEPS_INBETWEEN_COMPACTION); // tn:2835
+		if (fixed_S > 0) S = (uint32_t)fixed_S;
+		++iterations;
+
+		uint64_t gen_local = 0, comp_local = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : gen_local, comp_local)
+		for (int64_t ai = 0; ai < (int64_t)n_alive; ++ai) {
+			RayState& r = rays[alive[ai]];
+			Payload& payload = r.payload;
+			float coords[8][7];
+			uint8_t empty[8] = {0};
+			float sh_b[8][27];
+			float dens_out_b[8], dens_res_b[8];
+
+			// ---- generate_next_nerf_network_inputs, tn:637-696
+			{
+				V3 origin = payload.origin, dir = payload.dir;
+				V3 idir = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+				float cone_angle = p.cone_angle_constant;
+				float t = payload.t;
+				uint32_t j = 0;
+				bool exited = false;
+				for (; j < S; ++j) {
+					V3 pos;
+					float dt = 0.0f;
+					while (1) {
+						pos = origin + dir * t;
+						if (!box_contains(render_aabb, pos)) { exited = true; break; }
+						dt = calc_dt(t, cone_angle);
+						uint32_t mip = std::max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
+						if (density_grid_occupied_at(pos, grid, mip)) break;
+						uint32_t res = GRID >> mip;
+						t = advance_to_next_voxel(t, cone_angle, pos, dir, idir, res);
+					}
+					if (exited) break;
+					V3 wp = warp_position(pos, train_aabb);
+					V3 wd = warp_direction(dir);
+					coords[j][0] = wp.x; coords[j][1] = wp.y; coords[j][2] = wp.z;
+					coords[j][3] = warp_dt(dt);
+					coords[j][4] = wd.x; coords[j][5] = wd.y; coords[j][6] = wd.z;
+					t += dt;
+				}
+				payload.n_steps = j;
+				if (!exited) payload.t = t; // tn:675-677: on exit payload.t is NOT updated
+			}
+			const uint32_t actual_n_steps = payload.n_steps;
+			gen_local += actual_n_steps;
+
+			// ---- membrane residuals in deformed space, tn:2863-2883 (memset 0, then every operator last-to-first)
+			for (uint32_t j = 0; j < actual_n_steps; ++j) {
+				memset(sh_b[j], 0, sizeof(sh_b[j]));
+				dens_out_b[j] = 0.f; dens_res_b[j] = 0.f;
+			}
+			if (ops)
+				for (int oi = n_edits - 1; oi >= 0; --oi)
+					if (edits[oi]->apply_poisson)
+						for (uint32_t j = 0; j < actual_n_steps; ++j)
+							poisson_residual_one(*edits[oi], coords[j], sh_b[j], &dens_out_b[j], &dens_res_b[j]);
+
+			// ---- first network pass on un-deformed coordinates, tn:2890-2892.  The reference runs it
+			// unconditionally; its result is consumed only where density_out_boundary > 1e-9 (tn:770-773).
+			uint16_t out_old[8][16];
+			for (uint32_t j = 0; j < actual_n_steps; ++j)
+				if (dens_out_b[j] > 1e-9f) network_inference_one(m, coords[j], out_old[j]);
+
+			// ---- map_rays, last-to-first, in place, tn:2896-2904
+			if (ops)
+				for (int oi = n_edits - 1; oi >= 0; --oi)
+					for (uint32_t j = 0; j < actual_n_steps; ++j) map_ray_one(*edits[oi], coords[j], &empty[j]);
+
+			// ---- second network pass, tn:2908-2913
+			uint16_t out[8][16];
+			for (uint32_t j = 0; j < actual_n_steps; ++j) network_inference_one(m, coords[j], out[j]);
+
+			// ---- composite_kernel_nerf, tn:698-979 (Shade mode)
+			{
+				float lr = r.rgba[0], lg = r.rgba[1], lb = r.rgba[2], la = r.rgba[3];
+				float local_depth = r.depth;
+				V3 cam_fwd = cam_col(p.camera_matrix1, 2), cam_o = cam_col(p.camera_matrix1, 3);
+				uint32_t j = 0;
+				for (; j < actual_n_steps; ++j) {
+					V3 pos = unwarp_position(v3(coords[j][0], coords[j][1], coords[j][2]), train_aabb);
+					float T = 1.f - la;
+					float dt = unwarp_dt(coords[j][3]);
+					float alpha;
+					const bool has_res = dens_out_b[j] > 1e-9f;
+					float sigma_raw = h2f(out[j][3]);
+					if (ops && empty[j]) {
+						alpha = 0.0f;
+					} else if (has_res) {
+						float sourceval = network_to_density(sigma_raw, m.desc.density_activation);
+						float targetval = network_to_density(h2f(out_old[j][3]), m.desc.density_activation);
+						float val = p.poisson_target ? fminf(fmaxf(targetval, sourceval), sourceval + dens_res_b[j]) : sourceval + dens_res_b[j];
+						alpha = 1.f - expf(-(val) * dt);
+					} else {
+						alpha = 1.f - expf(-network_to_density(sigma_raw, m.desc.density_activation) * dt);
+					}
+					float weight = alpha * T;
+					float rgb[3] = {network_to_rgb(h2f(out[j][0]), m.desc.rgb_activation), network_to_rgb(h2f(out[j][1]), m.desc.rgb_activation),
+					                network_to_rgb(h2f(out[j][2]), m.desc.rgb_activation)};
+					if (has_res) {
+						float alpha_N = 1.f - expf(-network_to_density(sigma_raw, m.desc.density_activation) * dt);
+						float alpha_R = 1.f - expf(-dens_out_b[j] * dt);
+						float w_N = alpha_N / (alpha_N + alpha_R), w_R = alpha_R / (alpha_N + alpha_R);
+						float res_rgb[3];
+						evaluate_sh9(sh_b[j], unwarp_direction(v3(coords[j][4], coords[j][5], coords[j][6])), res_rgb);
+						lr += weight * (w_N * rgb[0] + w_R * res_rgb[0]);
+						lg += weight * (w_N * rgb[1] + w_R * res_rgb[1]);
+						lb += weight * (w_N * rgb[2] + w_R * res_rgb[2]);
+					} else {
+						lr += rgb[0] * weight; lg += rgb[1] * weight; lb += rgb[2] * weight;
+					}
+					la += weight;
+					if (weight > payload.max_weight) {
+						payload.max_weight = weight;
+						local_depth = dot(cam_fwd, pos - cam_o);
+					}
+					++comp_local;
+					if (steps_buf) steps_buf[payload.idx] += 1;
+					if (la > (1.0f - p.min_transmittance)) {
+						lr /= la; lg /= la; lb /= la; la /= la;
+						break;
+					}
+				}
+				if (j < S) { // tn:957-960
+					payload.alive = false;
+					payload.n_steps = j + i_step;
+				}
+				r.rgba[0] = lr; r.rgba[1] = lg; r.rgba[2] = lb; r.rgba[3] = la;
+				r.depth = local_depth;
+			}
+		}
+		generated += gen_local;
+		composited += comp_local;
+		i_step += S; // tn:2989
+	}
+
+	// shade_kernel_nerf, tn:2448-2483
+	n_hit = (uint32_t)hit.size();
+	for (uint32_t ri : hit) {
+		RayState& r = rays[ri];
+		float tmp[4] = {r.rgba[0], r.rgba[1], r.rgba[2], r.rgba[3]};
+		if (p.render_mode == NRS_RENDER_COST) {
+			float col = (float)r.payload.n_steps / 128;
+			tmp[0] = tmp[1] = tmp[2] = col; tmp[3] = 1.0f;
+		}
+		if (!p.linear_colors && p.render_mode == NRS_RENDER_SHADE) {
+			tmp[0] = srgb_to_linear(tmp[0]); tmp[1] = srgb_to_linear(tmp[1]); tmp[2] = srgb_to_linear(tmp[2]);
+		}
+		float* f = frame + 4 * (size_t)r.payload.idx;
+		float one_minus = 1.0f - tmp[3];
+		for (int c = 0; c < 4; ++c) f[c] = tmp[c] + f[c] * one_minus;
+		if (tmp[3] > 0.2f) depth_buf[r.payload.idx] = r.depth;
+	}
+	if (stats) { stats->generated = generated; stats->composited = composited; stats->n_alive0 = n_alive0; stats->n_hit = n_hit; stats->iterations = iterations; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host authoring restatements: LUT builder (tet_mesh.cu:76-237, 368-673), SAT (bounding_box.cuh:126-178),
+// MVC (mvc.h:125-188), local rotations (tet_mesh.cu:37-74), grid->bitfield (tn:514-555, 3642-3657)
+// ------------------------------------------------------------------------------------------------
+inline void project_pts(const V3* pts, int n, V3 axis, float& mn, float& mx) { // bounding_box.cuh:25-40
+	mn = std::numeric_limits<float>::infinity(); mx = -mn;
+	for (int i = 0; i < n; ++i) {
+		float val = dot(axis, pts[i]);
+		if (val < mn) mn = val;
+		if (val > mx) mx = val;
+	}
+}
+bool box_intersects_triangle(const Box& b, V3 ta, V3 tb, V3 tc) { // bounding_box.cuh:126-178
+	float tmin, tmax, bmin, bmax;
+	const V3 box_normals[3] = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
+	V3 tn = cross(tb - ta, tc - ta);
+	float nn = sqrtf(dot(tn, tn));
+	tn = {tn.x / nn, tn.y / nn, tn.z / nn}; // triangle.normal() is .normalized(), triangle.cuh:39
+	V3 tverts[3] = {ta, tb, tc};
+	for (int i = 0; i < 3; ++i) {
+		project_pts(tverts, 3, box_normals[i], tmin, tmax);
+		if (tmax < comp(b.mn, i) || tmin > comp(b.mx, i)) return false;
+	}
+	V3 verts[8] = {v3(b.mn.x, b.mn.y, b.mn.z), v3(b.mn.x, b.mn.y, b.mx.z), v3(b.mn.x, b.mx.y, b.mn.z), v3(b.mn.x, b.mx.y, b.mx.z),
+	               v3(b.mx.x, b.mn.y, b.mn.z), v3(b.mx.x, b.mn.y, b.mx.z), v3(b.mx.x, b.mx.y, b.mn.z), v3(b.mx.x, b.mx.y, b.mx.z)};
+	float toff = dot(tn, ta);
+	project_pts(verts, 8, tn, bmin, bmax);
+	if (bmax < toff || bmin > toff) return false;
+	V3 edges[3] = {ta - tb, ta - tc, tb - tc};
+	for (int i = 0; i < 3; ++i)
+		for (int j = 0; j < 3; ++j) {
+			V3 axis = cross(edges[i], box_normals[j]);
+			project_pts(verts, 8, axis, bmin, bmax);
+			project_pts(tverts, 3, axis, tmin, tmax);
+			if (bmax < tmin || bmin > tmax) return false;
+		}
+	return true;
+}
+inline V3 get_cell_pos(uint32_t x, uint32_t y, uint32_t z, uint32_t level) { // selection_utils.cu:65-68
+	float s = scalbnf(1.0f, (int)level);
+	return {(((float)x + 0.5f) / (float)GRID - 0.5f) * s + 0.5f, (((float)y + 0.5f) / (float)GRID - 0.5f) * s + 0.5f,
+	        (((float)z + 0.5f) / (float)GRID - 0.5f) * s + 0.5f};
+}
+inline void get_cell_at_pos(V3 pos, uint32_t level, int out[3]) { // selection_utils.cu:70-83
+	float mip_scale = scalbnf(1.0f, -(int)level);
+	pos = pos - v3(0.5f, 0.5f, 0.5f);
+	pos = pos * mip_scale;
+	pos = pos + v3(0.5f, 0.5f, 0.5f);
+	out[0] = clampi((int)(pos.x * (float)GRID), 0, GRID - 1);
+	out[1] = clampi((int)(pos.y * (float)GRID), 0, GRID - 1);
+	out[2] = clampi((int)(pos.z * (float)GRID), 0, GRID - 1);
+}
+const V3 corner_offsets[8] = {{-0.5f, -0.5f, -0.5f}, {-0.5f, -0.5f, 0.5f}, {-0.5f, 0.5f, -0.5f}, {0.5f, -0.5f, -0.5f},
+                              {0.5f, 0.5f, -0.5f}, {-0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.5f, 0.5f, 0.5f}}; // tet_mesh.h:34-43
+
+struct TetLut {
+	std::vector<uint32_t> offsets, idx;
+	std::vector<uint8_t> bitfield;
+	uint32_t max_per_cell = 0;
+};
+// membership rule of build_tet_grid (tet_mesh.cu:405-466): per tet, per level, per cell of the tet's bbox:
+// any of the 8 cell corners inside the tet, else any of the 4 faces intersecting the cell box.
+// CSR order inside a cell = ascending tet index (what the reference gets from its thread-ordered second pass).
+void build_tet_lut(const V3* verts, const uint32_t* tets, uint32_t n_tets, TetLut& out) {
+	const uint32_t n_elements = GRIDVOL * CASCADES;
+	std::vector<std::pair<uint32_t, uint32_t>> marks; // (cell, tet)
+	out.bitfield.assign(n_elements / 8, 0);
+	for (uint32_t i = 0; i < n_tets; ++i) {
+		V3 tv[4] = {verts[tets[4 * i]], verts[tets[4 * i + 1]], verts[tets[4 * i + 2]], verts[tets[4 * i + 3]]};
+		const float inf = std::numeric_limits<float>::infinity();
+		V3 mn = v3(inf, inf, inf), mx = v3(-inf, -inf, -inf);
+		for (int j = 0; j < 4; ++j) {
+			mn = v3(fminf(mn.x, tv[j].x), fminf(mn.y, tv[j].y), fminf(mn.z, tv[j].z));
+			mx = v3(fmaxf(mx.x, tv[j].x), fmaxf(mx.y, tv[j].y), fmaxf(mx.z, tv[j].z));
+		}
+		for (uint32_t level = 0; level < CASCADES; ++level) {
+			float scale = scalbnf(1.0f, (int)level);
+			int mi[3], ma[3];
+			get_cell_at_pos(mn, level, mi);
+			get_cell_at_pos(mx, level, ma);
+			for (int x = mi[0]; x <= ma[0]; ++x)
+				for (int y = mi[1]; y <= ma[1]; ++y)
+					for (int z = mi[2]; z <= ma[2]; ++z) {
+						V3 ps = get_cell_pos((uint32_t)x, (uint32_t)y, (uint32_t)z, level);
+						bool inside = false;
+						for (int c = 0; c < 8 && !inside; ++c) {
+							V3 q = ps + corner_offsets[c] * scale * (1.0f / (float)GRID) ;
+							// reference: pos + corner * scale / GRIDSIZE  (Eigen: (corner*scale)/128) -- /128 == *(1/128) exactly
+							if (point_in_tet(tv[0], tv[1], tv[2], tv[3], q)) inside = true;
+						}
+						if (!inside) {
+							V3 h = v3(0.5f, 0.5f, 0.5f) * scale * (1.0f / (float)GRID);
+							Box cube;
+							V3 a = ps - h, b = ps + h;
+							cube.mn = v3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z));
+							cube.mx = v3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z));
+							for (int j = 0; j < 4 && !inside; ++j)
+								if (box_intersects_triangle(cube, tv[j], tv[(j + 1) % 4], tv[(j + 2) % 4])) inside = true;
+						}
+						if (inside) {
+							uint32_t pos_idx = morton3D((uint32_t)x, (uint32_t)y, (uint32_t)z);
+							marks.emplace_back(level * GRIDVOL + pos_idx, i);
+							set_bitfield_at(pos_idx, level, true, out.bitfield.data());
+						}
+					}
+		}
+	}
+	out.offsets.assign((size_t)n_elements + 1, 0);
+	for (auto& mk : marks) out.offsets[(size_t)mk.first + 1]++;
+	out.max_per_cell = 0;
+	for (uint32_t c = 0; c < n_elements; ++c) {
+		out.max_per_cell = std::max(out.max_per_cell, out.offsets[(size_t)c + 1]);
+		out.offsets[(size_t)c + 1] += out.offsets[c];
+	}
+	out.idx.assign(marks.size(), 0);
+	std::vector<uint32_t> fill(out.offsets.begin(), out.offsets.end() - 1);
+	for (auto& mk : marks) out.idx[fill[mk.first]++] = mk.second; // marks are in ascending tet order already
+}
+
+// MVC3D::computeCoordinatesCustomCode with float_t = float, mvc.h:125-188.  Returns true on the degenerate exits.
+bool mvc_one(V3 eta, const uint32_t* tris, uint32_t n_tris, const V3* cv, uint32_t n_v, float* weights, std::vector<float>& w_weights,
+             std::vector<float>& d, std::vector<V3>& u) {
+	typedef float T;
+	T epsilon = 0.00000001;
+	for (uint32_t v = 0; v < n_v; ++v) weights[v] = 0.f;
+	T sumWeights = 0.0;
+	d.assign(n_v, 0.f); u.resize(n_v);
+	for (uint32_t v = 0; v < n_v; ++v) {
+		V3 e = eta - cv[v];
+		d[v] = sqrtf(dot(e, e));
+		if (d[v] < epsilon) { weights[v] = 1.0; return true; }
+		V3 q = cv[v] - eta;
+		u[v] = {q.x / d[v], q.y / d[v], q.z / d[v]};
+	}
+	w_weights.assign(n_v, 0.f);
+	uint32_t vid[3]; T l[3], theta[3], w[3], c[3], s[3];
+	for (uint32_t t = 0; t < n_tris; ++t) {
+		for (int i = 0; i < 3; ++i) vid[i] = tris[3 * t + i];
+		for (int i = 0; i < 3; ++i) { V3 q = u[vid[(i + 1) % 3]] - u[vid[(i + 2) % 3]]; l[i] = sqrtf(dot(q, q)); }
+		for (int i = 0; i < 3; ++i) theta[i] = (T)(2.0 * asin((double)l[i] / 2.0));
+		T h = (T)(((double)(theta[0] + theta[1] + theta[2])) / 2.0);
+		if (M_PI - (double)h < (double)epsilon) {
+			for (int i = 0; i < 3; ++i) w[i] = (T)(sin((double)theta[i]) * (double)l[(i + 2) % 3] * (double)l[(i + 1) % 3]);
+			sumWeights = w[0] + w[1] + w[2];
+			weights[vid[0]] = w[0] / sumWeights; weights[vid[1]] = w[1] / sumWeights; weights[vid[2]] = w[2] / sumWeights;
+			return true;
+		}
+		for (int i = 0; i < 3; ++i)
+			c[i] = (T)((2.0 * sin((double)h) * sin((double)(h - theta[i]))) / (sin((double)theta[(i + 1) % 3]) * sin((double)theta[(i + 2) % 3])) - 1.0);
+		T sign_basis = 1;
+		if ((double)dot(cross(u[vid[0]], u[vid[1]]), u[vid[2]]) < 0.0) sign_basis = -1;
+		for (int i = 0; i < 3; ++i) s[i] = (T)((double)sign_basis * sqrt(std::max<double>(0.0, 1.0 - (double)(c[i] * c[i]))));
+		if (fabs(s[0]) < epsilon || fabs(s[1]) < epsilon || fabs(s[2]) < epsilon) continue;
+		for (int i = 0; i < 3; ++i)
+			w[i] = (T)(((double)(theta[i] - c[(i + 1) % 3] * theta[(i + 2) % 3] - c[(i + 2) % 3] * theta[(i + 1) % 3])) /
+			           (2.0 * (double)d[vid[i]] * sin((double)theta[(i + 1) % 3]) * (double)s[(i + 2) % 3]));
+		sumWeights += (w[0] + w[1] + w[2]);
+		w_weights[vid[0]] += w[0]; w_weights[vid[1]] += w[1]; w_weights[vid[2]] += w[2];
+	}
+	for (uint32_t v = 0; v < n_v; ++v) weights[v] = w_weights[v] / sumWeights;
+	return false;
+}
+
+// 3x3 SVD via one-sided Jacobi in double (the reference uses the approximate McAdams SVD, svd3.h:405-420;
+// R is compared with tolerance 1e-4).  A = U S V^T, column-major 3x3 arrays.
+void svd3(const double A[9], double U[9], double S[3], double V[9]) {
+	double B[9];
+	memcpy(B, A, sizeof(B)); // columns of B get orthogonalised: B = A V
+	for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+	for (int sweep = 0; sweep < 60; ++sweep) {
+		double off = 0.0;
+		for (int p = 0; p < 2; ++p)
+			for (int q = p + 1; q < 3; ++q) {
+				double alpha = 0, beta = 0, gamma = 0;
+				for (int k = 0; k < 3; ++k) { alpha += B[3 * p + k] * B[3 * p + k]; beta += B[3 * q + k] * B[3 * q + k]; gamma += B[3 * p + k] * B[3 * q + k]; }
+				off = std::max(off, fabs(gamma) / (sqrt(alpha * beta) + 1e-300));
+				if (fabs(gamma) < 1e-300) continue;
+				double zeta = (beta - alpha) / (2.0 * gamma);
+				double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+				double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+				for (int k = 0; k < 3; ++k) {
+					double bp = B[3 * p + k], bq = B[3 * q + k];
+					B[3 * p + k] = cs * bp - sn * bq; B[3 * q + k] = sn * bp + cs * bq;
+					double vp = V[3 * p + k], vq = V[3 * q + k];
+					V[3 * p + k] = cs * vp - sn * vq; V[3 * q + k] = sn * vp + cs * vq;
+				}
+			}
+		if (off < 1e-15) break;
+	}
+	for (int j = 0; j < 3; ++j) {
+		double n = sqrt(B[3 * j] * B[3 * j] + B[3 * j + 1] * B[3 * j + 1] + B[3 * j + 2] * B[3 * j + 2]);
+		S[j] = n;
+		for (int k = 0; k < 3; ++k) U[3 * j + k] = n > 1e-300 ? B[3 * j + k] / n : 0.0;
+	}
+	// complete U to an orthonormal basis if a singular value vanished (flat tets): use cross products
+	for (int j = 0; j < 3; ++j)
+		if (S[j] <= 1e-300) {
+			int a = (j + 1) % 3, b = (j + 2) % 3;
+			U[3 * j + 0] = U[3 * a + 1] * U[3 * b + 2] - U[3 * a + 2] * U[3 * b + 1];
+			U[3 * j + 1] = U[3 * a + 2] * U[3 * b + 0] - U[3 * a + 0] * U[3 * b + 2];
+			U[3 * j + 2] = U[3 * a + 0] * U[3 * b + 1] - U[3 * a + 1] * U[3 * b + 0];
+		}
+}
+
+} // namespace
+
+// =================================================================================================
+// C interface for ctypes (tests / smoke / bench cpu_baseline only)
+// =================================================================================================
+extern "C" {
+
+uint16_t orc_f2h(float f) { return f2h(f); }
+float orc_h2f(uint16_t h) { return h2f(h); }
+uint32_t orc_morton3D(uint32_t x, uint32_t y, uint32_t z) { return morton3D(x, y, z); }
+uint32_t orc_morton3D_invert(uint32_t x) { return morton3D_invert(x); }
+uint32_t orc_sobol(uint32_t index, uint32_t dim) { return sobol(index, dim); }
+float orc_ld_random_val(uint32_t index, uint32_t seed, uint32_t dim) { return ld_random_val(index, seed, dim); }
+void orc_ld_random_pixel_offset(uint32_t spp, float* out2) { ld_random_pixel_offset(spp, out2); }
+int orc_mip_from_pos(const float* pos) { return mip_from_pos(v3(pos[0], pos[1], pos[2])); }
+int orc_mip_from_dt(float dt, const float* pos) { return mip_from_dt(dt, v3(pos[0], pos[1], pos[2])); }
+uint32_t orc_cascaded_grid_idx_at(const float* pos, uint32_t mip) { return cascaded_grid_idx_at(v3(pos[0], pos[1], pos[2]), mip); }
+float orc_calc_dt(float t, float cone) { return calc_dt(t, cone); }
+float orc_min_step(void) { return MIN_STEP; }
+float orc_max_step(void) { return MAX_STEP; }
+float orc_warp_dt(float dt) { return warp_dt(dt); }
+float orc_unwarp_dt(float dt) { return unwarp_dt(dt); }
+float orc_distance_to_next_voxel(const float* pos, const float* dir, uint32_t res) {
+	V3 d = v3(dir[0], dir[1], dir[2]);
+	return distance_to_next_voxel(v3(pos[0], pos[1], pos[2]), d, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), res);
+}
+float orc_advance_to_next_voxel(float t, float cone, const float* pos, const float* dir, uint32_t res) {
+	V3 d = v3(dir[0], dir[1], dir[2]);
+	return advance_to_next_voxel(t, cone, v3(pos[0], pos[1], pos[2]), d, v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), res);
+}
+int orc_frexp_exponent(float x) { return frexp_exponent(x); }
+float orc_srgb_to_linear(float x) { return srgb_to_linear(x); }
+void orc_evaluate_sh9(const float* sh27, const float* dir, float* rgb) { evaluate_sh9(sh27, v3(dir[0], dir[1], dir[2]), rgb); }
+void orc_bary_tet(const float* abcd12, const float* p, float* out4) {
+	bary_tet(v3(abcd12[0], abcd12[1], abcd12[2]), v3(abcd12[3], abcd12[4], abcd12[5]), v3(abcd12[6], abcd12[7], abcd12[8]),
+	         v3(abcd12[9], abcd12[10], abcd12[11]), v3(p[0], p[1], p[2]), out4);
+}
+int orc_point_in_tet(const float* abcd12, const float* p) {
+	return point_in_tet(v3(abcd12[0], abcd12[1], abcd12[2]), v3(abcd12[3], abcd12[4], abcd12[5]), v3(abcd12[6], abcd12[7], abcd12[8]),
+	                    v3(abcd12[9], abcd12[10], abcd12[11]), v3(p[0], p[1], p[2])) ? 1 : 0;
+}
+int orc_box_intersects_triangle(const float* box6, const float* tri9) {
+	Box b{v3(box6[0], box6[1], box6[2]), v3(box6[3], box6[4], box6[5])};
+	return box_intersects_triangle(b, v3(tri9[0], tri9[1], tri9[2]), v3(tri9[3], tri9[4], tri9[5]), v3(tri9[6], tri9[7], tri9[8])) ? 1 : 0;
+}
+
+size_t orc_model_n_params(const nrs_model_desc* d) {
+	if (!desc_supported(*d)) return 0;
+	LevelTable lt;
+	make_level_table(*d, lt);
+	return (size_t)N_DENSITY_W + N_RGB_W + (size_t)lt.total_entries * 2;
+}
+int orc_model_level_table(const nrs_model_desc* d, float* scale, uint32_t* res, uint32_t* off, uint32_t* cnt, uint32_t* hashed) {
+	if (!desc_supported(*d)) return -1;
+	LevelTable lt;
+	make_level_table(*d, lt);
+	for (uint32_t l = 0; l < d->n_levels; ++l) { scale[l] = lt.scale[l]; res[l] = lt.resolution[l]; off[l] = lt.offset[l]; cnt[l] = lt.count[l]; hashed[l] = lt.hashed[l]; }
+	return 0;
+}
+void* orc_model_create(const nrs_model_desc* d, const uint16_t* params, size_t n_params, const uint8_t* bitfield) {
+	if (!desc_supported(*d)) return nullptr;
+	Model* m = new Model();
+	m->desc = *d;
+	make_level_table(*d, m->lt);
+	if (n_params != (size_t)N_DENSITY_W + N_RGB_W + (size_t)m->lt.total_entries * 2) { delete m; return nullptr; }
+	m->aabb = Box{v3(d->aabb_min[0], d->aabb_min[1], d->aabb_min[2]), v3(d->aabb_max[0], d->aabb_max[1], d->aabb_max[2])};
+	m->params.assign(params, params + n_params);
+	m->wf.resize(N_DENSITY_W + N_RGB_W);
+	for (uint32_t i = 0; i < N_DENSITY_W + N_RGB_W; ++i) m->wf[i] = h2f(params[i]);
+	if (bitfield) m->bitfield.assign(bitfield, bitfield + NRS_BITFIELD_BYTES);
+	else m->bitfield.assign(NRS_BITFIELD_BYTES, 0);
+	return m;
+}
+void orc_model_set_bitfield(void* model, const uint8_t* bitfield) { ((Model*)model)->bitfield.assign(bitfield, bitfield + NRS_BITFIELD_BYTES); }
+void orc_model_destroy(void* model) { delete (Model*)model; }
+
+// out: [n x 32] fp16 interleaved
+void orc_hashgrid_encode(void* model, uint32_t n, const float* in, uint32_t ld_in, uint16_t* out) {
+	const Model& m = *(Model*)model;
+#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < (int64_t)n; ++i) hashgrid_encode_one(m, in + (size_t)i * ld_in, out + (size_t)i * 32);
+}
+void orc_sh4_encode(uint32_t n, const float* dir01, uint32_t ld, uint16_t* out) {
+	for (uint32_t i = 0; i < n; ++i) sh4_encode_one(dir01 + (size_t)i * ld, out + (size_t)i * 16);
+}
+// layout: 0 = planes out[c*ld_out + s], 1 = interleaved out[s*16 + c]
+void orc_network_inference(void* model, uint32_t n, const float* in7, uint16_t* out, uint32_t ld_out, int layout) {
+	const Model& m = *(Model*)model;
+#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < (int64_t)n; ++i) {
+		uint16_t o[16];
+		network_inference_one(m, in7 + (size_t)i * 7, o);
+		for (int c = 0; c < 16; ++c)
+			if (layout == NRS_PLANES) out[(size_t)c * ld_out + i] = o[c];
+			else out[(size_t)i * 16 + c] = o[c];
+	}
+}
+void orc_network_density(void* model, uint32_t n, const float* in, uint32_t ld_in, uint16_t* out, uint32_t ld_out, int layout) {
+	const Model& m = *(Model*)model;
+#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < (int64_t)n; ++i) {
+		uint16_t feat[32], o[16];
+		hashgrid_encode_one(m, in + (size_t)i * ld_in, feat);
+		density_mlp_one(m, feat, o);
+		for (int c = 0; c < 16; ++c)
+			if (layout == NRS_PLANES) out[(size_t)c * ld_out + i] = o[c];
+			else out[(size_t)i * 16 + c] = o[c];
+	}
+}
+
+void* orc_edit_create(const nrs_model_desc* d, const nrs_tet_mesh* mesh) {
+	Edit* e = new Edit();
+	e->aabb = Box{v3(d->aabb_min[0], d->aabb_min[1], d->aabb_min[2]), v3(d->aabb_max[0], d->aabb_max[1], d->aabb_max[2])};
+	e->verts.resize(mesh->n_vertices); e->orig.resize(mesh->n_vertices);
+	for (uint32_t i = 0; i < mesh->n_vertices; ++i) {
+		e->verts[i] = v3(mesh->h_vertices[3 * i], mesh->h_vertices[3 * i + 1], mesh->h_vertices[3 * i + 2]);
+		e->orig[i] = v3(mesh->h_original_vertices[3 * i], mesh->h_original_vertices[3 * i + 1], mesh->h_original_vertices[3 * i + 2]);
+	}
+	e->tets.assign(mesh->h_tets, mesh->h_tets + 4 * (size_t)mesh->n_tets);
+	const size_t n_cells = (size_t)GRIDVOL * CASCADES;
+	e->lut_off.assign(mesh->h_lut_offsets, mesh->h_lut_offsets + n_cells + 1);
+	e->lut_idx.assign(mesh->h_lut_idx, mesh->h_lut_idx + e->lut_off[n_cells]);
+	e->orig_bitfield.assign(mesh->h_original_bitfield, mesh->h_original_bitfield + NRS_BITFIELD_BYTES);
+	if (mesh->h_local_rotations) e->rot.assign(mesh->h_local_rotations, mesh->h_local_rotations + 9 * (size_t)mesh->n_tets);
+	e->copy = mesh->copy != 0;
+	e->apply_poisson = mesh->apply_poisson != 0;
+	e->residual_amplitude = mesh->residual_amplitude;
+	if (e->apply_poisson) {
+		e->shs.assign(mesh->h_boundary_shs, mesh->h_boundary_shs + 27 * (size_t)mesh->n_vertices);
+		e->out_density.assign(mesh->h_boundary_outside_density, mesh->h_boundary_outside_density + mesh->n_vertices);
+		e->res_density.assign(mesh->h_boundary_residual_density, mesh->h_boundary_residual_density + mesh->n_vertices);
+	}
+	e->bbox = bbox_of(e->verts);            // post_update_vertices, tet_mesh.cu:12-20
+	e->warped_bbox = warp_box(e->bbox, e->aabb);
+	e->orig_bbox = bbox_of(e->orig);        // ctor, tet_mesh.h:100-107
+	e->orig_warped_bbox = warp_box(e->orig_bbox, e->aabb);
+	return e;
+}
+void orc_edit_destroy(void* e) { delete (Edit*)e; }
+void orc_edit_map_rays(void* edit, uint32_t n, float* coords7, uint8_t* empty) {
+	const Edit& e = *(Edit*)edit;
+#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < (int64_t)n; ++i) map_ray_one(e, coords7 + (size_t)i * 7, empty + i);
+}
+void orc_edit_map_positions(void* edit, uint32_t n, float* pos, uint32_t ld, uint8_t* empty) {
+	const Edit& e = *(Edit*)edit;
+#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < (int64_t)n; ++i) map_position_one(e, pos + (size_t)i * ld, empty + i);
+}
+
+struct orc_render_stats { uint64_t generated, composited; uint32_t n_alive0, n_hit, iterations, pad; };
+// frame must be pre-cleared by the caller; depth/steps are written for owned pixels.
+// fixed_S: 0 = the reference's dynamic S, else force n_steps_between_compaction (S-invariance tests).
+void orc_render(void* model, const nrs_render_params* p, void* const* edits, int n_edits, float* frame, float* depth, uint32_t* steps,
+                orc_render_stats* stats, int fixed_S, int n_threads) {
+#ifdef _OPENMP
+	if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+	RenderStats rs{};
+	render(*(Model*)model, *p, (const Edit* const*)edits, n_edits, frame, depth, steps, &rs, fixed_S);
+	if (stats) { stats->generated = rs.generated; stats->composited = rs.composited; stats->n_alive0 = rs.n_alive0; stats->n_hit = rs.n_hit; stats->iterations = rs.iterations; stats->pad = 0; }
+}
+int orc_max_threads(void) {
+#ifdef _OPENMP
+	return omp_get_max_threads();
+#else
+	return 1;
+#endif
+}
+
+// per listed pixel: the (t, dt) stream of init -> jitter -> first hit -> successive samples, ignoring compositing
+void orc_trace_samples(void* model, const nrs_render_params* p, uint32_t n_pixels, const uint32_t* pixel_idx, uint32_t max_samples,
+                       float* t_out, float* dt_out, uint32_t* count_out) {
+	const Model& m = *(Model*)model;
+	const uint32_t W = (uint32_t)p->resolution[0];
+	const Box render_aabb{v3(p->render_aabb_min[0], p->render_aabb_min[1], p->render_aabb_min[2]),
+	                      v3(p->render_aabb_max[0], p->render_aabb_max[1], p->render_aabb_max[2])};
+	const uint8_t* grid = m.bitfield.data();
+#pragma omp parallel for schedule(dynamic, 64)
+	for (int64_t k = 0; k < (int64_t)n_pixels; ++k) {
+		uint32_t idx = pixel_idx[k];
+		Payload pl;
+		float d0;
+		init_ray(*p, idx % W, idx / W, pl, d0);
+		advance_pos(*p, grid, pl, idx);
+		uint32_t cnt = 0;
+		if (pl.alive) {
+			V3 origin = pl.origin, dir = pl.dir;
+			V3 idir = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+			float t = pl.t;
+			while (cnt < max_samples) {
+				V3 pos;
+				float dt = 0.f;
+				bool exited = false;
+				while (1) {
+					pos = origin + dir * t;
+					if (!box_contains(render_aabb, pos)) { exited = true; break; }
+					dt = calc_dt(t, p->cone_angle_constant);
+					uint32_t mip = std::max(p->min_mip, (uint32_t)mip_from_dt(dt, pos));
+					if (density_grid_occupied_at(pos, grid, mip)) break;
+					t = advance_to_next_voxel(t, p->cone_angle_constant, pos, dir, idir, GRID >> mip);
+				}
+				if (exited) break;
+				t_out[(size_t)k * max_samples + cnt] = t;
+				dt_out[(size_t)k * max_samples + cnt] = dt;
+				++cnt;
+				t += dt;
+			}
+		}
+		count_out[k] = cnt;
+	}
+}
+
+// ---- authoring restatements -------------------------------------------------------------------------
+void* orc_tet_lut_build(const float* verts, uint32_t n_vertices, const uint32_t* tets, uint32_t n_tets) {
+	(void)n_vertices;
+	TetLut* l = new TetLut();
+	build_tet_lut((const V3*)verts, tets, n_tets, *l);
+	return l;
+}
+uint32_t orc_tet_lut_n_idx(void* l) { return (uint32_t)((TetLut*)l)->idx.size(); }
+uint32_t orc_tet_lut_max_per_cell(void* l) { return ((TetLut*)l)->max_per_cell; }
+void orc_tet_lut_copy(void* l, uint32_t* offsets, uint32_t* idx, uint8_t* bitfield) {
+	TetLut* t = (TetLut*)l;
+	if (offsets) memcpy(offsets, t->offsets.data(), t->offsets.size() * 4);
+	if (idx) memcpy(idx, t->idx.data(), t->idx.size() * 4);
+	if (bitfield) memcpy(bitfield, t->bitfield.data(), t->bitfield.size());
+}
+void orc_tet_lut_destroy(void* l) { delete (TetLut*)l; }
+
+void orc_mvc_compute(const float* cage_v, uint32_t n_cv, const uint32_t* tris, uint32_t n_tris, const float* pts, uint32_t n_pts,
+                     float* weights, uint8_t* labels) {
+	std::vector<float> ww, d;
+	std::vector<V3> u;
+	for (uint32_t i = 0; i < n_pts; ++i) {
+		bool degenerate = mvc_one(v3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), tris, n_tris, (const V3*)cage_v, n_cv, weights + (size_t)i * n_cv, ww, d, u);
+		// Cage::compute_mvc marks labels[i] = 1 when the call returns false (cage.cu:19-21)
+		if (labels) labels[i] = degenerate ? 0 : 1;
+	}
+}
+void orc_mvc_apply(const float* weights, const float* cage_v, uint32_t n_cv, uint32_t n_pts, float* out) { // cage.cu:38-49
+	for (uint32_t i = 0; i < n_pts; ++i) {
+		V3 p = v3(0, 0, 0);
+		for (uint32_t v = 0; v < n_cv; ++v) p = p + weights[(size_t)i * n_cv + v] * v3(cage_v[3 * v], cage_v[3 * v + 1], cage_v[3 * v + 2]);
+		out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z;
+	}
+}
+void orc_tet_local_rotations(const float* verts, const float* orig, const uint32_t* tets, uint32_t n_tets, float* out) { // tet_mesh.cu:37-74
+	for (uint32_t i = 0; i < n_tets; ++i) {
+		V3 cc = v3(0, 0, 0), dc = v3(0, 0, 0);
+		for (int j = 0; j < 4; ++j) {
+			uint32_t v = tets[4 * i + j];
+			cc = cc + v3(orig[3 * v], orig[3 * v + 1], orig[3 * v + 2]);
+			dc = dc + v3(verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]);
+		}
+		cc = v3(cc.x / 4.f, cc.y / 4.f, cc.z / 4.f); dc = v3(dc.x / 4.f, dc.y / 4.f, dc.z / 4.f);
+		double C[9] = {0};
+		for (int j = 0; j < 4; ++j) {
+			uint32_t v = tets[4 * i + j];
+			V3 a = v3(orig[3 * v], orig[3 * v + 1], orig[3 * v + 2]) - cc, b = v3(verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]) - dc;
+			float av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
+			for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) C[3 * c + r] += (double)(av[r] * bv[c]); // (orig-c)(def-c)^T
+		}
+		double U[9], S[3], V[9];
+		svd3(C, U, S, V);
+		for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { // R = U V^T
+			double s = 0;
+			for (int k = 0; k < 3; ++k) s += U[3 * k + r] * V[3 * k + c];
+			out[9 * (size_t)i + 3 * c + r] = (float)s;
+		}
+	}
+}
+
+// update_density_grid_mean_and_bitfield, tn:3642-3657 + grid_to_bitfield tn:514-532 + bitfield_max_pool tn:534-555
+void orc_density_grid_to_bitfield(const float* grid, uint8_t* bitfield) {
+	double mean = 0.0;
+	for (uint32_t i = 0; i < GRIDVOL; ++i) mean += (double)(fmaxf(grid[i], 0.f) / (float)GRIDVOL);
+	float thresh = std::min(0.01f, (float)mean);
+	for (uint32_t i = 0; i < GRIDVOL / 8 * CASCADES; ++i) {
+		uint8_t bits = 0;
+		for (uint32_t j = 0; j < 8; ++j) bits |= grid[(size_t)i * 8 + j] > thresh ? (uint8_t)(1u << j) : 0;
+		bitfield[i] = bits;
+	}
+	for (uint32_t level = 1; level < CASCADES; ++level) {
+		const uint8_t* prev = bitfield + grid_mip_offset(level - 1) / 8;
+		uint8_t* next = bitfield + grid_mip_offset(level) / 8;
+		for (uint32_t i = 0; i < GRIDVOL / 64; ++i) {
+			uint8_t bits = 0;
+			for (uint32_t j = 0; j < 8; ++j) bits |= prev[i * 8 + j] > 0 ? (uint8_t)(1u << j) : 0;
+			uint32_t x = morton3D_invert(i >> 0) + GRID / 8, y = morton3D_invert(i >> 1) + GRID / 8, z = morton3D_invert(i >> 2) + GRID / 8;
+			next[morton3D(x, y, z)] |= bits;
+		}
+	}
+}
+float orc_density_grid_threshold(const float* grid) {
+	double mean = 0.0;
+	for (uint32_t i = 0; i < GRIDVOL; ++i) mean += (double)(fmaxf(grid[i], 0.f) / (float)GRIDVOL);
+	return std::min(0.01f, (float)mean);
+}
+
+} // extern "C"

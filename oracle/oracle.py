@@ -1,0 +1,200 @@
+"""ctypes wrapper of the CPU oracle (oracle/nrs_oracle.cpp).  TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never from nerfshop_amd/.
+PARITY UNPINNED at the tiny-cuda-nn boundary (see the .cpp header).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnrs_oracle.so")
+_lib = None
+
+
+class OrcRenderStats(C.Structure):
+    _fields_ = [("generated", C.c_uint64), ("composited", C.c_uint64), ("n_alive0", C.c_uint32), ("n_hit", C.c_uint32),
+                ("iterations", C.c_uint32), ("pad", C.c_uint32)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    P, U32, F, I = C.c_void_p, C.c_uint32, C.c_float, C.c_int
+    sig = {
+        "orc_f2h": (C.c_uint16, [F]), "orc_h2f": (F, [C.c_uint16]),
+        "orc_morton3D": (U32, [U32, U32, U32]), "orc_morton3D_invert": (U32, [U32]),
+        "orc_sobol": (U32, [U32, U32]), "orc_ld_random_val": (F, [U32, U32, U32]), "orc_ld_random_pixel_offset": (None, [U32, P]),
+        "orc_mip_from_pos": (I, [P]), "orc_mip_from_dt": (I, [F, P]), "orc_cascaded_grid_idx_at": (U32, [P, U32]),
+        "orc_calc_dt": (F, [F, F]), "orc_min_step": (F, []), "orc_max_step": (F, []), "orc_warp_dt": (F, [F]), "orc_unwarp_dt": (F, [F]),
+        "orc_distance_to_next_voxel": (F, [P, P, U32]), "orc_advance_to_next_voxel": (F, [F, F, P, P, U32]),
+        "orc_frexp_exponent": (I, [F]), "orc_srgb_to_linear": (F, [F]), "orc_evaluate_sh9": (None, [P, P, P]),
+        "orc_bary_tet": (None, [P, P, P]), "orc_point_in_tet": (I, [P, P]), "orc_box_intersects_triangle": (I, [P, P]),
+        "orc_model_n_params": (C.c_size_t, [P]), "orc_model_level_table": (I, [P, P, P, P, P, P]),
+        "orc_model_create": (P, [P, P, C.c_size_t, P]), "orc_model_set_bitfield": (None, [P, P]), "orc_model_destroy": (None, [P]),
+        "orc_hashgrid_encode": (None, [P, U32, P, U32, P]), "orc_sh4_encode": (None, [U32, P, U32, P]),
+        "orc_network_inference": (None, [P, U32, P, P, U32, I]), "orc_network_density": (None, [P, U32, P, U32, P, U32, I]),
+        "orc_edit_create": (P, [P, P]), "orc_edit_destroy": (None, [P]),
+        "orc_edit_map_rays": (None, [P, U32, P, P]), "orc_edit_map_positions": (None, [P, U32, P, U32, P]),
+        "orc_render": (None, [P, P, P, I, P, P, P, P, I, I]), "orc_max_threads": (I, []),
+        "orc_trace_samples": (None, [P, P, U32, P, U32, P, P, P]),
+        "orc_tet_lut_build": (P, [P, U32, P, U32]), "orc_tet_lut_n_idx": (U32, [P]), "orc_tet_lut_max_per_cell": (U32, [P]),
+        "orc_tet_lut_copy": (None, [P, P, P, P]), "orc_tet_lut_destroy": (None, [P]),
+        "orc_mvc_compute": (None, [P, U32, P, U32, P, U32, P, P]), "orc_mvc_apply": (None, [P, P, U32, U32, P]),
+        "orc_tet_local_rotations": (None, [P, P, P, U32, P]),
+        "orc_density_grid_to_bitfield": (None, [P, P]), "orc_density_grid_threshold": (F, [P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+class Model:
+    """NerfNetwork + occupancy on the CPU."""
+
+    def __init__(self, desc, params_u16, bitfield=None):
+        self.lib = load()
+        self.desc = desc
+        params_u16 = np.ascontiguousarray(params_u16, np.uint16)
+        bf = np.ascontiguousarray(bitfield, np.uint8) if bitfield is not None else None
+        self.h = self.lib.orc_model_create(C.byref(desc), params_u16.ctypes.data, params_u16.size, bf.ctypes.data if bf is not None else None)
+        if not self.h:
+            raise ValueError("oracle: unsupported model description or wrong parameter count")
+
+    def set_bitfield(self, bitfield):
+        bf = np.ascontiguousarray(bitfield, np.uint8)
+        self.lib.orc_model_set_bitfield(self.h, bf.ctypes.data)
+
+    def hashgrid_encode(self, pos):
+        pos = _f32(pos)
+        out = np.zeros((pos.shape[0], 32), np.uint16)
+        self.lib.orc_hashgrid_encode(self.h, pos.shape[0], pos.ctypes.data, pos.shape[1], out.ctypes.data)
+        return out
+
+    def inference(self, coords7, layout=0):
+        coords7 = _f32(coords7)
+        n = coords7.shape[0]
+        out = np.zeros((16, n) if layout == 0 else (n, 16), np.uint16)
+        self.lib.orc_network_inference(self.h, n, coords7.ctypes.data, out.ctypes.data, n, layout)
+        return out
+
+    def density(self, pos, layout=0):
+        pos = _f32(pos)
+        n = pos.shape[0]
+        out = np.zeros((16, n) if layout == 0 else (n, 16), np.uint16)
+        self.lib.orc_network_density(self.h, n, pos.ctypes.data, pos.shape[1], out.ctypes.data, n, layout)
+        return out
+
+    def trace_samples(self, params, pixel_idx, max_samples):
+        pixel_idx = np.ascontiguousarray(pixel_idx, np.uint32)
+        n = pixel_idx.size
+        t = np.zeros((n, max_samples), np.float32)
+        dt = np.zeros((n, max_samples), np.float32)
+        cnt = np.zeros(n, np.uint32)
+        self.lib.orc_trace_samples(self.h, C.byref(params), n, pixel_idx.ctypes.data, max_samples, t.ctypes.data, dt.ctypes.data, cnt.ctypes.data)
+        return t, dt, cnt
+
+    def render(self, params, edits=(), fixed_S=0, n_threads=0):
+        W, H = params.resolution[0], params.resolution[1]
+        frame = np.zeros((H, W, 4), np.float32)
+        depth = np.zeros((H, W), np.float32)
+        steps = np.zeros((H, W), np.uint32)
+        stats = OrcRenderStats()
+        arr = (C.c_void_p * max(len(edits), 1))(*[e.h for e in edits])
+        self.lib.orc_render(self.h, C.byref(params), arr, len(edits), frame.ctypes.data, depth.ctypes.data, steps.ctypes.data, C.byref(stats),
+                            fixed_S, n_threads)
+        return frame, depth, steps, stats
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_model_destroy(self.h)
+            self.h = None
+
+
+class Edit:
+    def __init__(self, desc, tet_mesh_struct, keepalive=None):
+        self.lib = load()
+        self.keepalive = keepalive
+        self.h = self.lib.orc_edit_create(C.byref(desc), C.byref(tet_mesh_struct))
+
+    def map_rays(self, coords7):
+        c = np.array(coords7, np.float32, copy=True)
+        empty = np.zeros(c.shape[0], np.uint8)
+        self.lib.orc_edit_map_rays(self.h, c.shape[0], c.ctypes.data, empty.ctypes.data)
+        return c, empty
+
+    def map_positions(self, pos):
+        c = np.array(pos, np.float32, copy=True)
+        empty = np.zeros(c.shape[0], np.uint8)
+        self.lib.orc_edit_map_positions(self.h, c.shape[0], c.ctypes.data, c.shape[1], empty.ctypes.data)
+        return c, empty
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_edit_destroy(self.h)
+            self.h = None
+
+
+def tet_lut_build(vertices, tets):
+    lib = load()
+    v = _f32(vertices)
+    t = np.ascontiguousarray(tets, np.uint32)
+    h = lib.orc_tet_lut_build(v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0])
+    n_idx = lib.orc_tet_lut_n_idx(h)
+    offsets = np.zeros(5 * 128 ** 3 + 1, np.uint32)
+    idx = np.zeros(max(n_idx, 1), np.uint32)
+    bitfield = np.zeros(5 * 128 ** 3 // 8, np.uint8)
+    lib.orc_tet_lut_copy(h, offsets.ctypes.data, idx.ctypes.data, bitfield.ctypes.data)
+    mx = lib.orc_tet_lut_max_per_cell(h)
+    lib.orc_tet_lut_destroy(h)
+    return offsets, idx[:n_idx], bitfield, mx
+
+
+def mvc_compute(cage_v, cage_t, points):
+    lib = load()
+    cv, tr, pts = _f32(cage_v), np.ascontiguousarray(cage_t, np.uint32), _f32(points)
+    w = np.zeros((pts.shape[0], cv.shape[0]), np.float32)
+    labels = np.zeros(pts.shape[0], np.uint8)
+    lib.orc_mvc_compute(cv.ctypes.data, cv.shape[0], tr.ctypes.data, tr.shape[0], pts.ctypes.data, pts.shape[0], w.ctypes.data, labels.ctypes.data)
+    return w, labels
+
+
+def mvc_apply(weights, cage_v):
+    lib = load()
+    w, cv = _f32(weights), _f32(cage_v)
+    out = np.zeros((w.shape[0], 3), np.float32)
+    lib.orc_mvc_apply(w.ctypes.data, cv.ctypes.data, cv.shape[0], w.shape[0], out.ctypes.data)
+    return out
+
+
+def local_rotations(vertices, original, tets):
+    lib = load()
+    v, o, t = _f32(vertices), _f32(original), np.ascontiguousarray(tets, np.uint32)
+    out = np.zeros((t.shape[0], 9), np.float32)
+    lib.orc_tet_local_rotations(v.ctypes.data, o.ctypes.data, t.ctypes.data, t.shape[0], out.ctypes.data)
+    return out
+
+
+def density_grid_to_bitfield(grid):
+    lib = load()
+    g = _f32(grid)
+    out = np.zeros(5 * 128 ** 3 // 8, np.uint8)
+    lib.orc_density_grid_to_bitfield(g.ctypes.data, out.ctypes.data)
+    return out

@@ -1,0 +1,291 @@
+"""Parity of the HIP path (through the C-ABI of libnrs.so) against the CPU oracle, on an MI355X.
+
+Bars: bit-exact for integer / index work and for every fp32 quantity whose operation order we control (hash-grid
+features, ray/sample positions, cage warp); stated tolerances where the MFMA's fp32 accumulation order or a fast
+exp() enters (network outputs, composited colour).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_coords(n, seed):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(0.0, 1.0, size=(n, 7)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    c[:, 4:7] = ((d + 1.0) * 0.5).astype(np.float32)
+    return c
+
+
+def _half_ulp_distance(a_u16, b_u16):
+    """distance in fp16 ulps between two fp16 bit patterns (monotone integer mapping)."""
+    def key(u):
+        u = u.astype(np.int32)
+        return np.where(u & 0x8000, -(u & 0x7FFF), u & 0x7FFF)
+    return np.abs(key(a_u16) - key(b_u16))
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 100003])
+def test_hashgrid_bit_exact(rig, n):
+    torch = rig.torch
+    c = _rand_coords(n, 11 + n)
+    # include the corners of the unit cube and exact cell boundaries
+    c[: min(n, 8), :3] = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], np.float32)[: min(n, 8)]
+    ref = rig.scene.oracle_model.hashgrid_encode(c)
+    out = torch.zeros((n, 32), dtype=torch.float16, device="cuda:0")
+    rig.net.hashgrid_encode(None, torch.from_numpy(c).cuda(), out)
+    got = out.cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, ref), f"{(got != ref).sum()} of {got.size} features differ"
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_network_inference_tolerance(rig, layout):
+    """fp16 outputs within 4 fp16 ulps (or 2e-3 abs near zero): the MFMA sums fp16 products in fp32 in its own order, the
+    oracle sums them exactly; a hidden activation that lands on the other side of an fp16 rounding boundary moves the
+    outputs by a few ulps."""
+    torch = rig.torch
+    n = 20000
+    c = _rand_coords(n, 5)
+    ref = rig.scene.oracle_model.inference(c, layout)
+    out = torch.zeros((16, n) if layout == 0 else (n, 16), dtype=torch.float16, device="cuda:0")
+    rig.net.inference_mixed_precision(None, torch.from_numpy(c).cuda(), out)
+    got = out.cpu().numpy()
+    ulps = _half_ulp_distance(got.view(np.uint16), ref)
+    absd = np.abs(got.astype(np.float32) - ref.view(np.float16).astype(np.float32))
+    ok = (ulps <= 4) | (absd <= 2e-3)
+    assert ok.all(), f"max ulps {ulps.max()}, max abs {absd.max()}, bad {np.count_nonzero(~ok)}"
+    assert (ulps == 0).mean() > 0.9  # the vast majority is bit-identical
+
+
+def test_network_density_tolerance(rig):
+    torch = rig.torch
+    n = 10001
+    c = _rand_coords(n, 6)[:, :3].copy()
+    ref = rig.scene.oracle_model.density(c, 0)
+    out = torch.zeros((16, n), dtype=torch.float16, device="cuda:0")
+    rig.net.density(None, torch.from_numpy(c).cuda(), out)
+    got = out.cpu().numpy()
+    ulps = _half_ulp_distance(got.view(np.uint16), ref)
+    absd = np.abs(got.astype(np.float32) - ref.view(np.float16).astype(np.float32))
+    assert ((ulps <= 4) | (absd <= 2e-3)).all(), f"max ulps {ulps.max()} max abs {absd.max()}"
+
+
+def test_network_padded_planes(rig):
+    """planes layout with n_el > n (the renderer pads to 128): only the first n columns are written."""
+    torch = rig.torch
+    n, n_el = 100, 128
+    c = _rand_coords(n, 7)
+    out = torch.full((16, n_el), 7.0, dtype=torch.float16, device="cuda:0")
+    rig.net.inference_mixed_precision(None, torch.from_numpy(c).cuda(), out)
+    got = out.cpu().numpy()
+    assert (got[:, n:] == 7.0).all()
+    ref = rig.scene.oracle_model.inference(c, 0).view(np.float16).astype(np.float32)
+    assert np.abs(got[:, :n].astype(np.float32) - ref).max() < 5e-2
+
+
+@pytest.mark.parametrize("az", [30.0, 120.0, 255.0])
+def test_trace_samples_bit_exact(rig, az):
+    """ray / sample indexing: every (t, dt) the marcher emits is bit-identical to the oracle's."""
+    torch = rig.torch
+    rig.use_edit(False)
+    W, H = 160, 90
+    p = rig.scene.params_for(W, H, az, snap=False, spp_index=3)
+    idx = np.arange(W * H, dtype=np.uint32)
+    t_ref, dt_ref, c_ref = rig.scene.oracle_model.trace_samples(p, idx, 48)
+    t, dt, c = rig.testbed.trace_samples(p, torch.from_numpy(idx.astype(np.int32)).cuda(), 48)
+    assert np.array_equal(c.cpu().numpy().astype(np.uint32), c_ref)
+    assert c_ref.max() > 10
+    assert np.array_equal(t.cpu().numpy().view(np.uint32), t_ref.view(np.uint32))
+    assert np.array_equal(dt.cpu().numpy().view(np.uint32), dt_ref.view(np.uint32))
+
+
+def test_map_rays_bit_exact(rig):
+    torch = rig.torch
+    e = rig.scene.edit
+    rng = np.random.default_rng(3)
+    lo, hi = e.vertices.min(0) - 0.05, e.vertices.max(0) + 0.05
+    n = 50000
+    c = _rand_coords(n, 9)
+    c[:, :3] = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)  # aabb_scale 1: warped == world
+    c[: n // 4, :3] = rng.uniform(e.original_vertices.min(0) - 0.02, e.original_vertices.max(0) + 0.02, size=(n // 4, 3)).astype(np.float32)
+    ref_c, ref_empty = rig.scene.oracle_edit.map_rays(c)
+    dc = torch.from_numpy(c).cuda()
+    mask = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    rig.op.map_rays(None, dc, mask)
+    got = dc.cpu().numpy()
+    assert (ref_c != c).any() and ref_empty.any()
+    assert np.array_equal(got.view(np.uint32), ref_c.view(np.uint32))
+    assert np.array_equal(mask.cpu().numpy(), ref_empty)
+    # map_positions (no direction, ignores the copy flag)
+    pos = c[:, :3].copy()
+    ref_p, ref_e2 = rig.scene.oracle_edit.map_positions(pos)
+    dp = torch.from_numpy(pos).cuda()
+    mask2 = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    rig.op.map_positions(None, dp, mask2)
+    assert np.array_equal(dp.cpu().numpy().view(np.uint32), ref_p.view(np.uint32))
+    assert np.array_equal(mask2.cpu().numpy(), ref_e2)
+
+
+def _compare_frames(frame, depth, steps, ref_frame, ref_depth, ref_steps):
+    """RGBA tolerance: 6e-3 max abs after srgb_to_linear (slope <= 2.3), 2e-4 mean abs.  It covers (i) network outputs
+    differing by a few fp16 ulps (test above), (ii) __expf vs expf in alpha, (iii) the rare ray whose accumulated alpha
+    crosses 1 - min_transmittance one sample earlier/later (|d rgba| <= alpha_sample * min_transmittance ~ 1.4e-3
+    before shading).  Sample counts must agree for >= 99.8 % of the pixels and never differ by more than 1."""
+    d = np.abs(frame - ref_frame)
+    assert d.max() < 6e-3, d.max()
+    assert d.mean() < 2e-4, d.mean()
+    ds = np.abs(steps.astype(np.int64) - ref_steps.astype(np.int64))
+    assert ds.max() <= 1, ds.max()
+    assert (ds == 0).mean() >= 0.998, (ds == 0).mean()
+    same = ds == 0
+    hit = (ref_frame[..., 3] > 0.2) & (frame[..., 3] > 0.2) & same
+    assert np.allclose(depth[hit], ref_depth[hit], rtol=0, atol=2e-3)
+    miss = (ref_frame[..., 3] == 0) & (frame[..., 3] == 0)
+    assert (depth[miss] == 1e10).all() and (ref_depth[miss] == 1e10).all()
+
+
+@pytest.mark.parametrize("az,snap", [(30.0, True), (200.0, False)])
+def test_render_no_edit(rig, az, snap):
+    rig.use_edit(False)
+    p = rig.scene.params_for(256, 144, az, snap=snap, spp_index=0 if snap else 5)
+    frame, depth, steps, stats = rig.render(p)
+    ref_frame, ref_depth, ref_steps, ref_stats = rig.scene.oracle_model.render(p)
+    assert ref_stats.n_hit > 1000
+    assert stats.n_rays_alive == ref_stats.n_alive0
+    _compare_frames(frame, depth, steps, ref_frame, ref_depth, ref_steps)
+    assert abs(int(stats.n_samples) - int(ref_stats.composited)) <= 0.002 * ref_stats.composited
+    assert abs(int(stats.n_rays_hit) - int(ref_stats.n_hit)) <= 2
+
+
+def test_render_with_cage_edit(rig):
+    rig.use_edit(True)
+    try:
+        p = rig.scene.params_for(256, 144, 60.0)
+        frame, depth, steps, stats = rig.render(p)
+        ref_frame, ref_depth, ref_steps, ref_stats = rig.scene.oracle_model.render(p, [rig.scene.oracle_edit])
+        _compare_frames(frame, depth, steps, ref_frame, ref_depth, ref_steps)
+        # the edit must actually change the picture
+        p0 = rig.scene.params_for(256, 144, 60.0, apply_operators=False)
+        frame0, _, _, _ = rig.render(p0)
+        assert np.abs(frame0 - frame).max() > 0.05
+    finally:
+        rig.use_edit(False)
+
+
+def test_render_empty_and_degenerate(rig):
+    """A camera looking away from the box: nothing alive, frame untouched, depth 1e10 everywhere."""
+    rig.use_edit(False)
+    cam = rig.scene.camera(30.0).copy()
+    cam[6:9] *= -1.0  # flip the forward axis
+    p = rig.scene.synth.render_params(64, 40, cam)
+    frame, depth, steps, stats = rig.render(p)
+    assert stats.n_samples == 0 and stats.n_rays_hit == 0
+    assert (frame == 0).all() and (depth == 1e10).all() and (steps == 0).all()
+    # ragged resolution (not a multiple of the 8x8 packet)
+    p = rig.scene.params_for(61, 37, 30.0)
+    frame, depth, steps, stats = rig.render(p)
+    ref_frame, ref_depth, ref_steps, _ = rig.scene.oracle_model.render(p)
+    _compare_frames(frame, depth, steps, ref_frame, ref_depth, ref_steps)
+
+
+def test_render_accumulates_into_frame(rig):
+    """shade_kernel_nerf composites over what is already in the frame buffer: frame = tmp + frame * (1 - tmp.a)."""
+    rig.use_edit(False)
+    torch = rig.torch
+    p = rig.scene.params_for(96, 54, 30.0)
+    base, _, _, _ = rig.render(p)
+    frame = torch.full((54, 96, 4), 0.25, dtype=torch.float32, device="cuda:0")
+    depth = torch.zeros((54, 96), dtype=torch.float32, device="cuda:0")
+    rig.testbed.render_with_params(rig.net, p, frame, depth, None, None, want_stats=True)
+    got = frame.cpu().numpy()
+    expect = base + 0.25 * (1.0 - base[..., 3:4])
+    assert np.allclose(got, expect, atol=1e-6)
+
+
+def test_tiled_render_matches_whole(rig):
+    """image-tile sharding: rendering tiles rank by rank into compact buffers and de-tiling reproduces the un-tiled frame
+    bit for bit (per-pixel results do not depend on which rays share a launch)."""
+    import ctypes as C
+    rig.use_edit(False)
+    torch = rig.torch
+    W, H, tile, n_ranks = 200, 120, 32, 3
+    p = rig.scene.params_for(W, H, 30.0)
+    whole, whole_depth, _, whole_stats = rig.render(p, want_steps=False)
+    lib = rig.ctx.lib
+    p.tile_size, p.tile_stride = tile, n_ranks
+    counts = []
+    for r in range(n_ranks):
+        p.tile_first = r
+        counts.append(lib.nrs_render_owned_tiles(C.byref(p)))
+    pad = max(counts)
+    tiles = torch.zeros((n_ranks, pad, tile, tile, 4), dtype=torch.float32, device="cuda:0")
+    dtiles = torch.zeros((n_ranks, pad, tile, tile), dtype=torch.float32, device="cuda:0")
+    total = 0
+    for r in range(n_ranks):
+        p.tile_first = r
+        st = rig.testbed.render_with_params(rig.net, p, tiles[r], dtiles[r], None, None, want_stats=True)
+        total += st.n_samples
+    image = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    dimage = torch.zeros((H, W), dtype=torch.float32, device="cuda:0")
+    from nerfshop_amd._abi import check
+    check(lib.nrs_detile(rig.ctx.h, None, C.byref(p), n_ranks, pad, tiles.data_ptr(), 4, image.data_ptr()))
+    check(lib.nrs_detile(rig.ctx.h, None, C.byref(p), n_ranks, pad, dtiles.data_ptr(), 1, dimage.data_ptr()))
+    torch.cuda.synchronize()
+    assert total == whole_stats.n_samples
+    assert np.array_equal(image.cpu().numpy(), whole)
+    assert np.array_equal(dimage.cpu().numpy(), whole_depth)
+
+
+def test_density_grid_to_bitfield_device(rig):
+    """nrs_model_set_density_grid == update_density_grid_mean_and_bitfield: bit-exact vs the oracle."""
+    from oracle import oracle as orc
+    try:
+        rig.net.set_density_grid(rig.scene.grid)
+        got = rig.net.get_density_bitfield()
+        assert np.array_equal(got, orc.density_grid_to_bitfield(rig.scene.grid))
+    finally:
+        rig.use_edit(False)
+
+
+def test_render_aabb16_with_edit(rig16):
+    """garden-style configuration: aabb_scale 16, 5 cascades, cone stepping (dt grows with t), one cage edit."""
+    rig16.use_edit(True)
+    try:
+        p = rig16.scene.params_for(192, 108, 40.0)
+        assert p.cone_angle_constant > 0
+        frame, depth, steps, stats = rig16.render(p)
+        ref_frame, ref_depth, ref_steps, ref_stats = rig16.scene.oracle_model.render(p, [rig16.scene.oracle_edit])
+        assert ref_stats.n_hit > 500
+        _compare_frames(frame, depth, steps, ref_frame, ref_depth, ref_steps)
+        idx = np.arange(192 * 108, dtype=np.uint32)
+        t_ref, dt_ref, c_ref = rig16.scene.oracle_model.trace_samples(p, idx, 64)
+        t, dt, c = rig16.testbed.trace_samples(p, rig16.torch.from_numpy(idx.astype(np.int32)).cuda(), 64)
+        assert np.array_equal(c.cpu().numpy().astype(np.uint32), c_ref)
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), t_ref.view(np.uint32))
+        assert len(np.unique(dt_ref[dt_ref > 0])) > 10  # cone stepping really varies dt
+    finally:
+        rig16.use_edit(False)
+
+
+def test_errors_are_loud(rig):
+    import ctypes as C
+    from nerfshop_amd import runtime, synth
+    from nerfshop_amd._abi import NrsError
+    torch = rig.torch
+    net = runtime.NerfNetwork(rig.ctx, rig.scene.desc)
+    with pytest.raises(NrsError):  # parameters not set
+        net.inference_mixed_precision(None, torch.zeros((4, 7), device="cuda:0"), torch.zeros((16, 4), dtype=torch.float16, device="cuda:0"))
+    with pytest.raises(NrsError):  # wrong parameter count
+        net.set_params(rig.scene.params[:-2])
+    with pytest.raises(NrsError):  # CPU tensor
+        rig.net.inference_mixed_precision(None, torch.zeros((4, 7)), torch.zeros((16, 4), dtype=torch.float16, device="cuda:0"))
+    bad = synth.model_desc(1)
+    bad.n_levels = 8
+    with pytest.raises(NrsError):
+        runtime.NerfNetwork(rig.ctx, bad)
+    p = rig.scene.params_for(32, 32, 30.0)
+    p.render_mode = 2  # Normals: out of scope
+    with pytest.raises(NrsError):
+        rig.render(p)
