@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- the render path's headline benchmark: Msamples/s (+ FPS) at 1920x1080 on the lego-like snapshot.
+
+    python bench.py --gpus 1 --steps 8 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one full frame: clear -> nrs_render_nerf (one persistent HIP launch) [-> RCCL gather of the image tiles to
+rank 0 + de-tile when N > 1].  The camera orbits (azimuth = 45 deg * step) so steps are not replays of one view.
+All inputs (parameters, bitfield, cage tables) are resident in HBM before the timed region.  With N > 1 the SAME frame
+is cut into 64x64 tiles dealt round-robin to the ranks ("scaling": "strong": total work per step is fixed).
+
+Workloads (BASELINE.json configs): lego_cage (default; config[2]/[4]: one active cage edit -- the configuration the
+north-star target is quoted on), lego (config[1], no edit; also reported as `noedit` in the default line), garden_cage
+(config[3]: aabb_scale 16, cone stepping, one cage edit).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BYTES_PER_SAMPLE = 512          # 16 levels x 8 corners x (2 x fp16): SURVEY 8(d)
+FLOP_PER_SAMPLE = 20480         # density MLP 6144 + rgb MLP 14336
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+TILE = 64
+
+
+def build_scene(workload, rt, synth, ctx, torch):
+    aabb_scale = 16 if workload.startswith("garden") else 1
+    with_edit = workload.endswith("cage")
+    desc = synth.model_desc(aabb_scale)
+    params = synth.make_params(desc, sigma_raw=synth.default_sigma_raw(aabb_scale))
+    grid = synth.density_grid(aabb_scale)
+    tb = rt.Testbed(ctx, desc, aabb_scale)
+    tb.nerf_network.set_params(params)
+    edit = None
+    if with_edit:
+        edit = synth.make_cage_edit(lattice_n=10, scene_scale=1.0 if aabb_scale == 1 else 6.0)
+        op = rt.CageDeformation(ctx, desc, edit)
+        tb.add_edit_operator(op)
+
+        def map_positions(warped):  # deformed-space occupancy refresh through the HIP operator
+            d = torch.from_numpy(np.ascontiguousarray(warped, np.float32)).cuda()
+            m = torch.zeros(d.shape[0], dtype=torch.uint8, device=d.device)
+            op.map_positions(None, d, m)
+            torch.cuda.synchronize()
+            return d.cpu().numpy(), m.cpu().numpy()
+
+        grid = synth.deformed_density_grid(grid, desc, map_positions, aabb_scale)
+    tb.nerf_network.set_density_grid(grid)  # threshold + mip pooling on the device
+    return dict(desc=desc, params=params, grid=grid, edit=edit, tb=tb, aabb_scale=aabb_scale)
+
+
+def camera_for(step, synth, aabb_scale):
+    scale = 0.33 if aabb_scale == 1 else 0.33 * 6.0
+    return synth.orbit_camera(45.0 * (step % 8) + 30.0, 30.0, scale=scale)
+
+
+def cpu_baseline(scene, synth, width, height, n_frames=1):
+    """The oracle (our CPU restatement; the reference has no CPU path and cannot be built here) on a bounded sample:
+    the same first frame at 1/16 of the pixels (480x270), all host cores."""
+    from oracle import oracle as orc
+    desc, params = scene["desc"], scene["params"]
+    bitfield = scene["tb"].nerf_network.get_density_bitfield()
+    model = orc.Model(desc, params, bitfield)
+    edits = []
+    if scene["edit"] is not None:
+        edits = [orc.Edit(desc, scene["edit"].tet_mesh_struct(), keepalive=scene["edit"])]
+    w, h = width // 4, height // 4
+    cores = orc.load().orc_max_threads()
+    total, t_total = 0, 0.0
+    for f in range(n_frames):
+        p = synth.render_params(w, h, camera_for(f, synth, scene["aabb_scale"]), aabb_scale=scene["aabb_scale"])
+        t0 = time.perf_counter()
+        _, _, _, st = model.render(p, edits)
+        t_total += time.perf_counter() - t0
+        total += st.composited
+    return {"value": round(total / t_total / 1e6, 4), "unit": "Msamples/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n_frames} frame(s) of the same workload at {w}x{h} (1/16 of the pixels), {total} samples, {t_total:.1f} s",
+            "fps_equiv_1080p": round(1.0 / (t_total / n_frames * 16.0), 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary no-edit measurement")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from nerfshop_amd import runtime as rt
+    from nerfshop_amd import synth, tiles
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ctx = rt.Context(local_rank)
+    scene = build_scene(args.workload, rt, synth, ctx, torch)
+    tb = scene["tb"]
+    W, H = args.width, args.height
+
+    sharder = tiles.TileSharder(W, H, TILE, rank, world, dev) if world > 1 else None
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    depth = torch.zeros((H, W), dtype=torch.float32, device=dev)
+
+    def make_params(step, apply_ops=True):
+        p = synth.render_params(W, H, camera_for(step, synth, scene["aabb_scale"]), aabb_scale=scene["aabb_scale"], apply_operators=apply_ops)
+        if sharder is not None:
+            sharder.fill(p)
+        return p
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def one_step(step, timed_idx=None, apply_ops=True, want_stats=False):
+        p = make_params(step, apply_ops)
+        if sharder is None:
+            frame.zero_()  # clear_frame (testbed.cu:2635)
+            if timed_idx is not None:
+                ev0[timed_idx].record()
+            st = tb.render_with_params(tb.nerf_network, p, frame, depth, None, None, want_stats=want_stats)
+            if timed_idx is not None:
+                ev1[timed_idx].record()
+        else:
+            sharder.clear()
+            if timed_idx is not None:
+                ev0[timed_idx].record()
+            st = tb.render_with_params(tb.nerf_network, p, sharder.local_frame, sharder.local_depth, None, None, want_stats=want_stats)
+            if timed_idx is not None:
+                ev1[timed_idx].record()
+            sharder.gather(ctx, p, frame, depth)  # RCCL gather to rank 0 + de-tile
+        return st
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # sample counts per view (untimed; the stats read-back synchronises, so it stays out of the timed region)
+    samples_per_step = []
+    for s in range(8):
+        st = one_step(s, want_stats=True)
+        samples_per_step.append(int(st.n_samples))
+    for s in range(args.warmup):
+        one_step(s)
+    sync_all()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        one_step(s, timed_idx=s)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    local_samples = sum(samples_per_step[s % 8] for s in range(args.steps))
+    kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    stats = torch.tensor([elapsed, float(local_samples), kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, total_samples, kernel_ms = float(mx[0]), float(sm[1]), float(mx[2])
+    else:
+        total_samples = float(local_samples)
+
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_extra and args.workload == "lego_cage":
+        # secondary: BASELINE config[1] (no edit operators; same occupancy so the sample set is comparable)
+        for s in range(2):
+            one_step(s, apply_ops=False)
+        torch.cuda.synchronize()
+        ns = sum(int(one_step(s, apply_ops=False, want_stats=True).n_samples) for s in range(8))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for s in range(8):
+            one_step(s, apply_ops=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        extra["noedit"] = {"msamples_per_s": round(ns / dt / 1e6, 2), "fps": round(8 / dt, 2)}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_samples / elapsed / 1e6
+        # roofline of the dominant kernel (render_kernel): algorithmic bytes per launch / mean launch duration (HIP events)
+        per_launch_samples = total_samples / args.steps / world
+        ach = per_launch_samples * BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "render_msamples_per_s_1080p",
+            "value": round(value, 2),
+            "unit": "Msamples/s",
+            "fps": round(args.steps / elapsed, 2),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f16 storage / f32 accumulate (MFMA), f32 marching+compositing",
+            "data": "synthetic",
+            "config": {"workload": {"lego_cage": "lego-like snapshot 1920x1080, one cage edit (BASELINE configs[2]/[4])",
+                                    "lego": "lego-like snapshot 1920x1080, no edits (BASELINE configs[1])",
+                                    "garden_cage": "garden-style aabb_scale 16 1920x1080, one cage edit (BASELINE configs[3])"}[args.workload],
+                       "resolution": [W, H], "samples_per_frame": int(total_samples / args.steps),
+                       "sharding": f"{TILE}x{TILE} image tiles round-robin over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 3),
+                         "algorithmic_bytes_per_launch": int(per_launch_samples * BYTES_PER_SAMPLE),
+                         "mfma_tflops": round(per_launch_samples * FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12, 2)},
+        }
+        line.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scene, synth, W, H)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

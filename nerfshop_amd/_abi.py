@@ -121,6 +121,10 @@ def load():
         raise NrsError(
             f"{LIB_PATH} is missing: the HIP extension has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  Importing torch
+    # first makes the dynamic linker bind libnrs.so's NEEDED libamdhip64.so.7 to that already-loaded copy, so torch
+    # tensors and our kernels share a device context (two runtimes in one process cannot both open the GPU).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     P, U32, I = C.c_void_p, C.c_uint32, C.c_int
     lib.nrs_last_error.restype = C.c_char_p

@@ -1,0 +1,84 @@
+"""Image-tile sharding of one frame across the GPUs of a node (the reference is single-GPU, README.md:423).
+
+Rays are independent, so the only exchange step is the final gather of the rendered tiles.  The image is cut into
+tile x tile pixel tiles in row-major tile order and dealt round-robin: rank r owns tiles r, r + N, r + 2N, ...
+(lego rays are spatially clustered; an interleave balances the load where contiguous strips would not).  Each rank
+renders its tiles into a COMPACT buffer [tiles_per_rank, tile, tile, C] (nrs_render_params.tile_*), one
+torch.distributed gather (RCCL over xGMI on GPUs, gloo in the CPU tests) collects them on rank 0, and nrs_detile
+scatters them back into the W x H image.  The model (~26 MB) is replicated; nothing else is exchanged per frame.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _abi
+
+
+def tile_counts(width, height, tile, world):
+    tiles_x = (width + tile - 1) // tile
+    tiles_y = (height + tile - 1) // tile
+    total = tiles_x * tiles_y
+    per_rank = [(total - r + world - 1) // world if r < total else 0 for r in range(world)]
+    return tiles_x, tiles_y, total, per_rank
+
+
+def detile_index(width, height, tile, world, padded):
+    """For every pixel of the full image, the flat pixel index inside the rank-major gathered buffer
+    [world, padded, tile, tile].  (CPU twin of the nrs_detile kernel, used by the gloo tests.)"""
+    tiles_x = (width + tile - 1) // tile
+    y = torch.arange(height).view(-1, 1).expand(height, width)
+    x = torch.arange(width).view(1, -1).expand(height, width)
+    T = (y // tile) * tiles_x + (x // tile)
+    r, k = T % world, T // world
+    return (((r * padded + k) * tile + (y % tile)) * tile + (x % tile)).reshape(-1)
+
+
+class TileSharder:
+    def __init__(self, width, height, tile, rank, world, device):
+        if tile % 8:
+            raise ValueError("tile size must be a multiple of 8 (ray packets are 8x8 pixels)")
+        self.width, self.height, self.tile, self.rank, self.world = width, height, tile, rank, world
+        self.device = torch.device(device)
+        self.tiles_x, self.tiles_y, self.total, self.per_rank = tile_counts(width, height, tile, world)
+        self.padded = max(self.per_rank)  # equal-sized contributions: one collective, no ragged sends
+        self.local_frame = torch.zeros((self.padded, tile, tile, 4), dtype=torch.float32, device=self.device)
+        self.local_depth = torch.zeros((self.padded, tile, tile), dtype=torch.float32, device=self.device)
+        if rank == 0:
+            self.all_frame = torch.zeros((world, self.padded, tile, tile, 4), dtype=torch.float32, device=self.device)
+            self.all_depth = torch.zeros((world, self.padded, tile, tile), dtype=torch.float32, device=self.device)
+        else:
+            self.all_frame = self.all_depth = None
+        self._index = None
+
+    def fill(self, p):
+        """Write the sharding fields of an nrs_render_params."""
+        p.tile_size, p.tile_first, p.tile_stride = self.tile, self.rank, self.world
+        return p
+
+    def clear(self):
+        self.local_frame.zero_()
+        self.local_depth.zero_()
+
+    def gather(self, ctx, p, frame, depth):
+        """One gather per buffer to rank 0, then de-tile there.  `frame` [H, W, 4] / `depth` [H, W] are written on rank 0."""
+        if self.world > 1:
+            fl = list(self.all_frame.unbind(0)) if self.rank == 0 else None
+            dl = list(self.all_depth.unbind(0)) if self.rank == 0 else None
+            dist.gather(self.local_frame, fl, dst=0)
+            dist.gather(self.local_depth, dl, dst=0)
+        elif self.rank == 0:
+            self.all_frame[0].copy_(self.local_frame)
+            self.all_depth[0].copy_(self.local_depth)
+        if self.rank != 0:
+            return
+        if self.device.type == "cuda":
+            lib = _abi.load()
+            s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _abi.check(lib.nrs_detile(ctx.h, s, C.byref(p), self.world, self.padded, self.all_frame.data_ptr(), 4, frame.data_ptr()))
+            _abi.check(lib.nrs_detile(ctx.h, s, C.byref(p), self.world, self.padded, self.all_depth.data_ptr(), 1, depth.data_ptr()))
+        else:
+            if self._index is None:
+                self._index = detile_index(self.width, self.height, self.tile, self.world, self.padded)
+            frame.view(-1, 4).copy_(self.all_frame.view(-1, 4)[self._index])
+            depth.view(-1).copy_(self.all_depth.view(-1)[self._index])
