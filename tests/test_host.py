@@ -1,0 +1,201 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol of include/nrs.h, the host-side authoring code of the
+product (LUT builder, MVC, rotations) agrees with the oracle's independent restatement, and the oracle's render loop has
+the size-independent properties the design relies on.  No compute call touches a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from nerfshop_amd import _abi, synth
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = _abi.load()
+    header = open(os.path.join(ROOT, "include", "nrs.h")).read()
+    body = header[header.index("const char* nrs_last_error"):]  # prototypes start here
+    declared = set(re.findall(r"\b(nrs_[a-z0-9_]+)\s*\(", body))
+    assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.nrs_abi_version() == 1
+
+
+def test_struct_layouts_match_header(built):
+    """ctypes mirrors must have the C compiler's sizes (checked against a tiny C program's sizeof)."""
+    import subprocess, tempfile
+    src = '#include <stdio.h>\n#include "nrs.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(nrs_model_desc), sizeof(nrs_tet_mesh), sizeof(nrs_render_params), sizeof(nrs_render_stats));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        sizes = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
+    assert sizes == [C.sizeof(_abi.ModelDesc), C.sizeof(_abi.TetMesh), C.sizeof(_abi.RenderParams), C.sizeof(_abi.RenderStats)]
+
+
+def test_no_gpu_is_a_loud_error(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = _abi.load()
+    h = C.c_void_p()
+    assert lib.nrs_ctx_create(0, C.byref(h)) == -4  # NRS_ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.nrs_last_error()
+
+
+def test_model_desc_validation(built):
+    lib = _abi.load()
+    d = synth.model_desc(1)
+    assert lib.nrs_model_n_params(C.byref(d)) == 3072 + 7168 + 12196240
+    d16 = synth.model_desc(16)
+    assert abs(d16.per_level_scale - 1.662476) < 1e-5 and abs(d.per_level_scale - 1.381913) < 1e-5
+    assert lib.nrs_model_n_params(C.byref(d16)) == 3072 + 7168 + 13623184
+    d.n_levels = 8
+    assert lib.nrs_model_n_params(C.byref(d)) == 0
+    assert orc.load().orc_model_n_params(C.byref(d)) == 0
+
+
+def test_grid_to_bitfield_numpy_vs_oracle(scene):
+    assert np.array_equal(scene.bitfield, orc.density_grid_to_bitfield(scene.grid))
+    assert np.array_equal(scene.edited_bitfield, orc.density_grid_to_bitfield(scene.edited_grid))
+    lvl = 128 ** 3 // 8
+    bits = [int(np.unpackbits(scene.bitfield[l * lvl:(l + 1) * lvl]).sum()) for l in range(5)]
+    assert bits[0] > 100000 and bits[0] > bits[1] > bits[2] > bits[3] > bits[4] > 0   # OR-pooled mips shrink 8x-ish per level
+    # a cell set at level l implies its parent set at level l+1 (max pooling); check on a sample of set cells
+    idx = np.flatnonzero(np.unpackbits(scene.bitfield[:lvl], bitorder="little"))[::997]
+    x, y, z = synth.morton3d_invert(idx), synth.morton3d_invert(idx >> 1), synth.morton3d_invert(idx >> 2)
+    parent = synth.morton3d(x // 2 + 32, y // 2 + 32, z // 2 + 32)
+    l1 = np.unpackbits(scene.bitfield[lvl:2 * lvl], bitorder="little")
+    assert l1[parent].all()
+
+
+def test_tet_lut_builder_matches_oracle(scene):
+    """product host LUT builder (multi-threaded) == oracle restatement of TetMesh::build_tet_grid: CSR bit-exact."""
+    e = scene.edit
+    o_off, o_idx, o_bits, o_max = orc.tet_lut_build(e.vertices, e.tets)
+    assert np.array_equal(o_off, e.lut_offsets) and np.array_equal(o_idx, e.lut_idx) and o_max == e.max_per_cell
+    _, _, ob2, _ = orc.tet_lut_build(e.original_vertices, e.tets)
+    assert np.array_equal(ob2, e.original_bitfield)
+    # thread-count independence
+    off1, idx1, bits1, _ = synth.build_tet_lut(e.vertices, e.tets, n_threads=1)
+    off3, idx3, bits3, _ = synth.build_tet_lut(e.vertices, e.tets, n_threads=3)
+    assert np.array_equal(off1, off3) and np.array_equal(idx1, idx3) and np.array_equal(bits1, bits3) and np.array_equal(bits1, o_bits)
+    # every point inside a tet finds that tet through the LUT at its own cascade level (what interpolate_tet relies on)
+    rng = np.random.default_rng(0)
+    t = rng.integers(0, e.tets.shape[0], 300)
+    b = rng.dirichlet(np.ones(4), 300).astype(np.float32)
+    pts = np.einsum("nk,nkd->nd", b, e.vertices[e.tets[t]]).astype(np.float32)
+    lib = orc.load()
+    for p, ti in zip(pts, t):
+        a = np.ascontiguousarray(p)
+        lvl = lib.orc_mip_from_pos(a.ctypes.data)
+        cell = lvl * 128 ** 3 + lib.orc_cascaded_grid_idx_at(a.ctypes.data, lvl)
+        assert ti in e.lut_idx[e.lut_offsets[cell]:e.lut_offsets[cell + 1]]
+
+
+def test_mvc_and_rotations_match_oracle(scene):
+    e = scene.edit
+    w, labels = orc.mvc_compute(e.cage_vertices, e.cage_triangles, e.original_vertices)
+    assert np.array_equal(labels, e.mvc_labels)
+    assert np.abs(w - e.mvc_weights).max() < 1e-6
+    # partition of unity + linear precision: the undeformed cage reproduces the points
+    assert np.abs(e.mvc_weights.sum(1) - 1).max() < 1e-5
+    assert np.abs(synth.mvc_apply(e.mvc_weights, e.cage_vertices) - e.original_vertices).max() < 1e-5
+    assert np.array_equal(orc.mvc_apply(e.mvc_weights, e.cage_deformed), e.vertices)   # same float summation order
+    assert (e.mvc_weights > -1e-6).all()        # points strictly inside a convex cage: non-negative coordinates
+    r_orc = orc.local_rotations(e.vertices, e.original_vertices, e.tets)
+    assert np.abs(r_orc - e.local_rotations).max() < 1e-4   # SURVEY App. A #14 tolerance (different SVD / polar algorithms)
+    R = e.local_rotations.reshape(-1, 3, 3)
+    assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-5   # orthonormal
+    # a rigidly rotated tet mesh recovers the inverse rotation (deformed -> canonical)
+    th = 0.7
+    Q = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], np.float32)
+    rot_v = (e.original_vertices - 0.5) @ Q.T + 0.5
+    Rr = synth.local_rotations(rot_v.astype(np.float32), e.original_vertices, e.tets[:50]).reshape(-1, 3, 3).transpose(0, 2, 1)  # col-major -> row
+    assert np.abs(Rr - Q.T).max() < 1e-4
+
+
+def test_cage_edit_geometry(scene):
+    e = scene.edit
+    assert e.vertices.shape == ((6 + 1) ** 3, 3) and e.tets.shape == (6 * 6 ** 3, 4)
+    # Kuhn lattice: all tets have the same positive volume and tile the box
+    v = e.original_vertices[e.tets]
+    vol = np.einsum("ni,ni->n", np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]), v[:, 3] - v[:, 0]) / 6
+    box = e.original_vertices.max(0) - e.original_vertices.min(0)
+    assert np.allclose(np.abs(vol).sum(), box.prod(), rtol=1e-4)
+    assert np.abs(e.vertices - e.original_vertices).max() > 0.05
+    assert e.vertices.min() > 0.0 and e.vertices.max() < 1.0
+
+
+def test_map_rays_oracle_properties(scene):
+    """identity outside the cage, exact inverse of the forward deformation inside, empty mask on the vacated source."""
+    e, oe = scene.edit, scene.oracle_edit
+    rng = np.random.default_rng(5)
+    n = 4000
+    c = rng.uniform(0, 1, (n, 7)).astype(np.float32)
+    far = c.copy()
+    far[:, :3] = rng.uniform(0.01, 0.15, (n, 3))
+    out, empty = oe.map_rays(far)
+    assert np.array_equal(out, far) and not empty.any()
+    # forward-deform canonical points barycentrically, then map_rays must bring them back
+    t = rng.integers(0, e.tets.shape[0], n)
+    b = rng.dirichlet(np.ones(4) * 2, n).astype(np.float32)
+    canon = np.einsum("nk,nkd->nd", b, e.original_vertices[e.tets[t]])
+    deformed = np.einsum("nk,nkd->nd", b, e.vertices[e.tets[t]])
+    c[:, :3] = deformed
+    out, _ = oe.map_rays(c)
+    assert np.abs(out[:, :3] - canon).max() < 2e-5
+    assert (np.abs(out[:, 4:7] - c[:, 4:7]).max(axis=1) > 0).mean() > 0.3   # directions get rotated where tets are twisted
+    # positions in the canonical mesh that the deformed mesh no longer covers are masked empty (move, not copy)
+    c[:, :3] = canon
+    out2, empty2 = oe.map_rays(c)
+    inside_def = np.any(out2[:, :3] != c[:, :3], axis=1)
+    assert empty2[~inside_def].all() and not empty2[inside_def].any()
+
+
+@pytest.mark.parametrize("with_edit", [False, True])
+def test_render_is_invariant_to_S_and_tiling(scene, with_edit):
+    """The reference's n_steps_between_compaction (global, 1..8) and any partition of the image into tiles leave every
+    pixel's result unchanged -- the property that lets the HIP path march each ray on its own and
+    shard the frame across GPUs."""
+    m = scene.oracle_model
+    m.set_bitfield(scene.edited_bitfield if with_edit else scene.bitfield)
+    edits = [scene.oracle_edit] if with_edit else []
+    try:
+        p = scene.params_for(96, 64, 75.0)
+        f0, d0, s0, st0 = m.render(p, edits)
+        for S in (1, 3, 8):
+            f, d, s, st = m.render(p, edits, fixed_S=S)
+            assert np.array_equal(f, f0) and np.array_equal(d, d0) and np.array_equal(s, s0)
+            assert st.composited == st0.composited and st.generated >= st.composited
+        acc_f, acc_s = np.zeros_like(f0), np.zeros_like(s0)
+        for r in range(3):
+            p.tile_size, p.tile_first, p.tile_stride = 16, r, 3
+            f, d, s, st = m.render(p, edits)
+            acc_f += f
+            acc_s += s
+        assert np.array_equal(acc_f, f0) and np.array_equal(acc_s, s0)
+        assert st0.n_hit > 500 and st0.composited == s0.sum()
+    finally:
+        m.set_bitfield(scene.bitfield)
+
+
+def test_oracle_render_golden(scene):
+    """Committed golden frame (tests/golden/oracle_render_golden.npz, made by tests/golden/make_render_golden.py): guards the
+    oracle -- the checker of every GPU parity test -- against silent drift."""
+    path = os.path.join(os.path.dirname(__file__), "golden", "oracle_render_golden.npz")
+    g = np.load(path)
+    m = scene.oracle_model
+    m.set_bitfield(scene.edited_bitfield)
+    try:
+        p = scene.params_for(64, 36, 60.0)
+        f, d, s, st = m.render(p, [scene.oracle_edit])
+    finally:
+        m.set_bitfield(scene.bitfield)
+    assert np.array_equal(s, g["steps"])                     # integer work: exact
+    assert np.abs(f - g["frame"]).max() < 1e-5               # libm expf/powf may differ in the last bit across hosts
+    hit = g["frame"][..., 3] > 0.2
+    assert np.abs(d[hit] - g["depth"][hit]).max() < 1e-5

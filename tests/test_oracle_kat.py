@@ -1,0 +1,223 @@
+"""Known-answer tests that pin the CPU oracle: the reference's Sobol table (golden JSON generated from the reference's own
+data), and hand-derived values for the in-tree formulas of SURVEY.md App. A.  No GPU."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def lib(built):
+    return orc.load()
+
+
+def f3(*v):
+    a = np.array(v, np.float32)
+    return a, a.ctypes.data
+
+
+def test_sobol_matches_reference_table(lib):
+    g = json.load(open(os.path.join(GOLDEN, "sobol_golden.json")))
+    # the oracle GENERATES direction numbers for dims 0/1; the golden file holds the reference's tabulated ones
+    for bit in range(32):
+        assert lib.orc_sobol(1 << bit, 0) == g["directions_dim0"][bit]
+        assert lib.orc_sobol(1 << bit, 1) == g["directions_dim1"][bit]
+    for i, d, v in g["sobol"]:
+        assert lib.orc_sobol(i, d) == v
+    for i, s, v in g["ld_random_val"]:
+        assert lib.orc_ld_random_val(i, s, 0) == np.float32(v)
+    out = np.zeros(2, np.float32)
+    for spp, v in g["pixel_offset"]:
+        lib.orc_ld_random_pixel_offset(spp, out.ctypes.data)
+        assert out[0] == np.float32(v[0]) and out[1] == np.float32(v[1])
+    # snap_to_pixel_centers uses spp 0: offset is exactly the pixel centre
+    lib.orc_ld_random_pixel_offset(0, out.ctypes.data)
+    assert out[0] == 0.5 and out[1] == 0.5
+
+
+def test_fp16_conversion_all_values(lib):
+    """software fp16 <-> fp32 of the oracle against numpy for every fp16 bit pattern and for rounding boundaries."""
+    bits = np.arange(65536, dtype=np.uint16)
+    ref = bits.view(np.float16).astype(np.float32)
+    for b in list(range(0, 65536, 97)) + [0, 1, 0x3ff, 0x400, 0x7bff, 0x7c00, 0x8000, 0x8001, 0xfbff, 0xfc00]:
+        v = lib.orc_h2f(b)
+        if np.isnan(ref[b]):
+            assert math.isnan(v)
+        else:
+            assert np.float32(v) == ref[b]
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.normal(size=2000).astype(np.float32) * s for s in (1e-8, 1e-5, 1e-3, 1.0, 100.0, 7e4)])
+    # exact ties between neighbouring halfs
+    h = rng.integers(0, 0x7bff, size=500).astype(np.uint16)
+    lo, hi = h.view(np.float16).astype(np.float64), (h + 1).astype(np.uint16).view(np.float16).astype(np.float64)
+    xs = np.concatenate([xs, ((lo + hi) / 2).astype(np.float32), np.array([65504.0, 65519.9, 65520.0, 1e9, 5.96e-8, 2.98e-8, 2.99e-8], np.float32)])
+    with np.errstate(over="ignore"):
+        want = xs.astype(np.float16).view(np.uint16)
+    for x, w in zip(xs, want):
+        assert lib.orc_f2h(float(x)) == w, (x, w)
+
+
+def test_morton(lib):
+    assert lib.orc_morton3D(1, 0, 0) == 1 and lib.orc_morton3D(0, 1, 0) == 2 and lib.orc_morton3D(0, 0, 1) == 4
+    assert lib.orc_morton3D(127, 127, 127) == 128 ** 3 - 1
+    for x, y, z in [(5, 3, 6), (100, 27, 64), (0, 127, 1)]:
+        m = lib.orc_morton3D(x, y, z)
+        assert (lib.orc_morton3D_invert(m), lib.orc_morton3D_invert(m >> 1), lib.orc_morton3D_invert(m >> 2)) == (x, y, z)
+    # bit interleave by hand: x=5 (101), y=3 (011), z=6 (110): bits z2y2x2 z1y1x1 z0y0x0 = 101 110 011
+    assert lib.orc_morton3D(5, 3, 6) == 0b101110011
+
+
+def test_step_constants_and_dt(lib):
+    mn = np.float32(1.73205080757) / np.float32(1024)
+    assert lib.orc_min_step() == mn
+    assert lib.orc_max_step() == mn * np.float32(128)            # STEPSIZE * 16 * 1024 / 128
+    assert lib.orc_calc_dt(1.0, 0.0) == mn                        # cone 0: constant step (lego)
+    assert lib.orc_calc_dt(2.0, 1.0 / 256.0) == np.float32(2.0 / 256.0)
+    assert lib.orc_calc_dt(100.0, 1.0 / 256.0) == mn * np.float32(128)
+    # warp_dt / unwarp_dt use MIN * 16 as the upper end (common_nerf.cu:28-36)
+    assert lib.orc_warp_dt(float(mn)) == 0.0
+    assert abs(lib.orc_warp_dt(float(mn * 16)) - 1.0) < 1e-6
+    assert abs(lib.orc_unwarp_dt(0.5) - float(mn) * 8.5) < 1e-9
+
+
+def test_mip_selection(lib):
+    """mip_from_pos: frexpf(max|pos - 0.5|) -> min(4, max(0, e + 1)) (common_nerf.cu:163-168)."""
+    cases = [((0.5, 0.5, 0.5), 1),      # frexpf(0) yields exponent 0 -> mip 1 (reference quirk, kept)
+             ((0.6, 0.5, 0.5), 0), ((0.99, 0.5, 0.5), 0),   # 0.49 = 0.98 * 2^-1 -> e = -1
+             ((1.0, 0.5, 0.5), 1),      # 0.5 = 0.5 * 2^0 -> e = 0
+             ((1.49, 0.5, 0.5), 1), ((1.5, 0.5, 0.5), 2), ((0.5, -1.6, 0.5), 3), ((4.6, 0.5, 0.5), 4), ((100.0, 0.5, 0.5), 4)]
+    for pos, want in cases:
+        _, ptr = a = f3(*pos)
+        assert lib.orc_mip_from_pos(a[1]) == want, pos
+    a = f3(0.6, 0.5, 0.5)
+    assert lib.orc_mip_from_dt(1.0 / 512.0, a[1]) == 0          # dt * 256 < 1 -> position mip
+    assert lib.orc_mip_from_dt(1.0 / 256.0, a[1]) == 1          # dt * 256 = 1 = 0.5 * 2^1
+    assert lib.orc_mip_from_dt(3.0 / 256.0, a[1]) == 2
+    assert lib.orc_mip_from_dt(1.0, a[1]) == 4
+    for x, want in [(0.0, 0), (1.0, 1), (0.5, 0), (0.75, 0), (3.0, 2), (1e-40, -132), (2.0 ** -126, -125)]:
+        assert lib.orc_frexp_exponent(x) == want, x
+        if x:
+            assert math.frexp(np.float32(x))[1] == want
+
+
+def test_cascaded_grid_index(lib):
+    a = f3(0.5 + 0.25, 0.5, 0.5)      # level 0: cell (96, 64, 64)
+    assert lib.orc_cascaded_grid_idx_at(a[1], 0) == lib.orc_morton3D(96, 64, 64)
+    assert lib.orc_cascaded_grid_idx_at(a[1], 1) == lib.orc_morton3D(80, 64, 64)   # (0.25/2 + 0.5) * 128
+    a = f3(-3.0, 0.5, 9.0)           # clamped to the grid
+    assert lib.orc_cascaded_grid_idx_at(a[1], 0) == lib.orc_morton3D(0, 64, 127)
+
+
+def test_dda(lib):
+    """distance_to_next_voxel / advance_to_next_voxel (common_nerf.cu:93-115) on an axis-aligned ray."""
+    pos, d = f3(0.503, 0.5, 0.5), f3(1.0, 1e-9, 1e-9)
+    dist = lib.orc_distance_to_next_voxel(pos[1], d[1], 128)
+    # p = 64.384 -> next boundary 65 -> (65 - 64.384) / 128
+    assert abs(dist - (65 - 0.503 * 128) / 128) < 1e-6
+    mn = float(lib.orc_min_step())
+    t0 = 0.2
+    t1 = lib.orc_advance_to_next_voxel(t0, 0.0, pos[1], d[1], 128)
+    n = round((t1 - t0) / mn)
+    assert n == math.ceil(dist / mn) or n == math.ceil(dist / mn) + 1   # first t >= t_target, stepping by dt
+    assert t1 >= t0 + dist - 1e-7 and t1 - mn < t0 + dist + 1e-7
+
+
+def test_tet_primitives(lib):
+    tet = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    out = np.zeros(4, np.float32)
+    p = f3(0.1, 0.2, 0.3)
+    lib.orc_bary_tet(tet.ctypes.data, p[1], out.ctypes.data)
+    assert np.allclose(out, [0.4, 0.1, 0.2, 0.3], atol=1e-6)
+    assert lib.orc_point_in_tet(tet.ctypes.data, p[1]) == 1
+    assert lib.orc_point_in_tet(tet.ctypes.data, f3(0.5, 0.5, 0.5)[1]) == 0
+    assert lib.orc_point_in_tet(tet.ctypes.data, f3(-0.01, 0.2, 0.2)[1]) == 0
+    # a flipped (negatively oriented) tet gives the same answers: the test compares signs, not orientation
+    flipped = tet[[1, 0, 2, 3]].copy()
+    assert lib.orc_point_in_tet(flipped.ctypes.data, p[1]) == 1
+    box = np.array([0.2, 0.2, 0.2, 0.4, 0.4, 0.4], np.float32)
+    tri_hit = np.array([0.0, 0.3, 0.3, 1.0, 0.3, 0.3, 0.3, 1.0, 0.3], np.float32)
+    tri_miss = np.array([0.0, 0.0, 0.9, 1.0, 0.0, 0.9, 0.0, 1.0, 0.9], np.float32)
+    tri_diag_miss = np.array([0.41, 0.2, 0.2, 0.6, 0.2, 0.39, 0.6, 0.41, 0.2], np.float32)  # bbox overlaps, plane separates
+    assert lib.orc_box_intersects_triangle(box.ctypes.data, tri_hit.ctypes.data) == 1
+    assert lib.orc_box_intersects_triangle(box.ctypes.data, tri_miss.ctypes.data) == 0
+    assert lib.orc_box_intersects_triangle(box.ctypes.data, tri_diag_miss.ctypes.data) == 0
+
+
+def test_srgb_and_sh9(lib):
+    assert lib.orc_srgb_to_linear(0.04) == np.float32(0.04) / np.float32(12.92)
+    assert abs(lib.orc_srgb_to_linear(1.0) - 1.0) < 1e-6
+    assert abs(lib.orc_srgb_to_linear(0.5) - ((0.5 + 0.055) / 1.055) ** 2.4) < 1e-6
+    sh = np.zeros(27, np.float32)
+    sh[0], sh[9 + 2], sh[18 + 6] = 1.0, 1.0, 1.0   # R: Y00, G: Y10 (z), B: Y20
+    rgb = np.zeros(3, np.float32)
+    d = f3(0.0, 0.0, 1.0)
+    lib.orc_evaluate_sh9(sh.ctypes.data, d[1], rgb.ctypes.data)
+    assert np.allclose(rgb, [0.2820947917738781, 0.4886025119029199, 0.9461746957575601 - 0.3153915652525201], atol=1e-7)
+
+
+def test_hashgrid_level_table_and_lookup(scene):
+    """tcnn grid geometry: instant-ngp's well-known 12 196 240 encoding parameters for lego, dense levels 0-4."""
+    lt = scene.synth.level_table(scene.desc)
+    assert list(lt["resolution"][:6]) == [16, 23, 31, 43, 59, 81]
+    assert list(lt["count"][:5]) == [4096, 12168, 29792, 79512, 205384]
+    assert all(lt["count"][5:] == 2 ** 19) and list(lt["hashed"]) == [0] * 5 + [1] * 11
+    assert int(lt["count"].sum()) * 2 == 12196240
+    assert len(scene.params) == 3072 + 7168 + 12196240
+    lib = orc.load()
+    scale = np.zeros(16, np.float32)
+    res, off, cnt, hashed = (np.zeros(16, np.uint32) for _ in range(4))
+    assert lib.orc_model_level_table(C.byref(scene.desc), scale.ctypes.data, res.ctypes.data, off.ctypes.data, cnt.ctypes.data, hashed.ctypes.data) == 0
+    assert np.array_equal(scale, lt["scale"]) and np.array_equal(off, lt["offset"]) and np.array_equal(cnt, lt["count"])
+    # level 0, feature 0 is the constant 1.0 everywhere (synthetic opacity channel); a lattice point returns its entry
+    feats = scene.oracle_model.hashgrid_encode(np.array([[0.3, 0.7, 0.2], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]], np.float32)).view(np.float16)
+    assert (feats[:, 0] == 1.0).all()
+    grid = scene.params[3072 + 7168:].view(np.float16)
+    # position whose level-0 coordinates are exact integers: x*15 + 0.5 = g + 0.5 -> weights 0.5 ... use level-0 cell centre shift:
+    # pos = (g - 0.5 + 0.5) / 15 -> fractional part 0 -> only corner 0 contributes
+    g = np.array([3, 7, 11])
+    pos = ((g - 0.5) / 15.0).astype(np.float32)
+    f = scene.oracle_model.hashgrid_encode(pos[None, :]).view(np.float16)[0]
+    frac = np.float32(15.0) * pos + np.float32(0.5)
+    if np.all(frac == np.floor(frac)):
+        idx = int(g[0] + g[1] * 16 + g[2] * 256)
+        assert f[1] == grid[2 * idx + 1]
+
+
+def test_network_oracle_against_numpy(scene):
+    """The C++ oracle's MLP wiring against an independent numpy evaluation (float64 accumulate, fp16 rounding points)."""
+    rng = np.random.default_rng(1)
+    n = 64
+    c = rng.uniform(0, 1, size=(n, 7)).astype(np.float32)
+    out = scene.oracle_model.inference(c, 1).view(np.float16)          # [n, 16]
+    feat = scene.oracle_model.hashgrid_encode(c).view(np.float16).astype(np.float64)
+    w = scene.params[:3072 + 7168].view(np.float16).astype(np.float64)
+    dw1, dw2 = w[:2048].reshape(64, 32), w[2048:3072].reshape(16, 64)
+    rw1, rw2, rw3 = w[3072:5120].reshape(64, 32), w[5120:9216].reshape(64, 64), w[9216:].reshape(16, 64)
+    r16 = lambda x: x.astype(np.float32).astype(np.float16).astype(np.float64)
+    h = r16(np.maximum(feat @ dw1.T, 0))
+    dout = r16(h @ dw2.T)
+    x, y, z = (c[:, 4:7].astype(np.float32) * np.float32(2) - np.float32(1)).T
+    sh = np.stack([np.full(n, 0.28209479177387814, np.float32), -0.48860251190291987 * y, 0.48860251190291987 * z, -0.48860251190291987 * x,
+                   1.0925484305920792 * x * y, -1.0925484305920792 * y * z, 0.94617469575755997 * z * z - 0.31539156525251999,
+                   -1.0925484305920792 * x * z, 0.54627421529603959 * x * x - 0.54627421529603959 * y * y,
+                   0.59004358992664352 * y * (-3.0 * x * x + y * y), 2.8906114426405538 * x * y * z,
+                   0.45704579946446572 * y * (1.0 - 5.0 * z * z), 0.3731763325901154 * z * (5.0 * z * z - 3.0),
+                   0.45704579946446572 * x * (1.0 - 5.0 * z * z), 1.4453057213202769 * z * (x * x - y * y),
+                   0.59004358992664352 * x * (-x * x + 3.0 * y * y)], axis=1)
+    rin = np.concatenate([dout, r16(sh)], axis=1)
+    h1 = r16(np.maximum(rin @ rw1.T, 0))
+    h2 = r16(np.maximum(h1 @ rw2.T, 0))
+    rout = r16(h2 @ rw3.T)
+    rout[:, 3] = dout[:, 0]
+    got = out.astype(np.float64)
+    # SH is evaluated in float32 by the oracle and float64-ish here: allow one fp16 ulp of slack on the colour rows
+    assert np.abs(got - rout).max() <= 2e-2 * max(1.0, np.abs(rout).max())
+    assert (got[:, 3] == rout[:, 3]).all()                      # density path has no transcendental / SH: exact
+    assert (got == rout).mean() > 0.95
