@@ -11,6 +11,7 @@
 //   grid -> bitfield     update_density_grid_mean_and_bitfield.
 //   detile_kernel        multi-GPU tile scatter.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "nrs_internal.h"
 #include "nrs_device.cuh"
 #include "nrs_mlp.cuh"
@@ -60,7 +61,9 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 	return x < W && y < H;
 }
 
-__global__ __launch_bounds__(256) void render_kernel(const DeviceModel m, const RenderArgs a) {
+// OCC = waves per SIMD the register allocator must leave room for (__launch_bounds__' second argument).
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void render_kernel(const DeviceModel m, const RenderArgs a) {
 	__shared__ RenderSmem sm;
 	stage_model_to_lds(m, sm.w, sm.levels);
 
@@ -242,18 +245,37 @@ __global__ __launch_bounds__(256) void render_kernel(const DeviceModel m, const 
 	atomicAdd(&a.counters->n_rays_hit, st_hit);
 }
 
-int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* stream) {
+template <int OCC>
+static int launch_render_occ(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream) {
 	int blocks_per_cu = 0;
-	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel, 256, 0);
+	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<OCC>, 256, 0);
 	if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(render_kernel)");
 	if (blocks_per_cu < 1) blocks_per_cu = 1;
+	if (blocks_per_cu > OCC) blocks_per_cu = OCC;
 	uint32_t grid = (uint32_t)(n_cus * blocks_per_cu);
-	const uint32_t max_useful = (a.n_packets + 3) / 4; // one packet per wave at least
+	const uint32_t max_useful = (a.n_packets + 3) / 4; // at least one packet per wave
 	if (grid > max_useful) grid = max_useful;
 	if (grid == 0) return NRS_OK;
-	hipLaunchKernelGGL(render_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, m, a);
+	hipLaunchKernelGGL(render_kernel<OCC>, dim3(grid), dim3(256), 0, stream, m, a);
 	NRS_LAUNCH_CHECK("render_kernel launch");
 	return NRS_OK;
+}
+
+int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* stream) {
+	// waves per SIMD: tuned default, NRS_RENDER_OCC overrides it for A/B measurements (profiles/)
+	static const int occ = []() {
+		const char* e = getenv("NRS_RENDER_OCC");
+		const int v = e ? atoi(e) : 0;
+		return (v >= 1 && v <= 4) ? v : 3;
+	}();
+	hipStream_t s = (hipStream_t)stream;
+	switch (occ) {
+		case 1: return launch_render_occ<1>(m, a, n_cus, s);
+		case 3: return launch_render_occ<3>(m, a, n_cus, s);
+		case 4: return launch_render_occ<4>(m, a, n_cus, s);
+		case 2: return launch_render_occ<2>(m, a, n_cus, s);
+		default: return launch_render_occ<3>(m, a, n_cus, s);
+	}
 }
 
 // ---- trace_samples ------------------------------------------------------------------------------------------------
