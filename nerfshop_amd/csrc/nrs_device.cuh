@@ -109,16 +109,17 @@ __device__ __forceinline__ int frexp_exponent(float x) {
 	if (ef == 0) return -117 - __clz((int)u);
 	return (int)ef - 126;
 }
-__device__ __forceinline__ float distance_to_next_voxel(f3 pos, f3 dir, f3 idir, uint32_t res) {
+// res is a power of two (128 >> mip): dividing by it equals multiplying by inv_res = 1/res exactly, bit for bit
+__device__ __forceinline__ float distance_to_next_voxel(f3 pos, f3 dir, f3 idir, uint32_t res, float inv_res) {
 	f3 p = (float)res * pos;
 	float tx = (floorf(p.x + 0.5f + 0.5f * signf_(dir.x)) - p.x) * idir.x;
 	float ty = (floorf(p.y + 0.5f + 0.5f * signf_(dir.y)) - p.y) * idir.y;
 	float tz = (floorf(p.z + 0.5f + 0.5f * signf_(dir.z)) - p.z) * idir.z;
 	float t = fminf(fminf(tx, ty), tz);
-	return fmaxf(t / (float)res, 0.0f);
+	return fmaxf(t * inv_res, 0.0f);
 }
-__device__ __forceinline__ float advance_to_next_voxel(float t, float cone_angle, f3 pos, f3 dir, f3 idir, uint32_t res) {
-	float t_target = t + distance_to_next_voxel(pos, dir, idir, res);
+__device__ __forceinline__ float advance_to_next_voxel(float t, float cone_angle, f3 pos, f3 dir, f3 idir, uint32_t res, float inv_res) {
+	float t_target = t + distance_to_next_voxel(pos, dir, idir, res, inv_res);
 	do {
 		t += calc_dt(t, cone_angle);
 	} while (t < t_target);
@@ -237,7 +238,7 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 		uint32_t mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
 		if (density_grid_occupied_at(pos, bitfield, mip)) return true;
 		uint32_t res = kGrid >> mip;
-		t = advance_to_next_voxel(t, cone, pos, d, idir, res);
+		t = advance_to_next_voxel(t, cone, pos, d, idir, res, ldexpf(1.0f, (int)mip - 7));
 	}
 }
 
@@ -373,7 +374,7 @@ __device__ __forceinline__ void evaluate_sh9(const float sh[27], f3 dir, float r
 __device__ __forceinline__ float network_to_rgb(float v, uint32_t act) {
 	switch (act) {
 		case NRS_ACT_RELU: return v > 0.f ? v : 0.f;
-		case NRS_ACT_LOGISTIC: return 1.0f / (1.0f + __expf(-v));
+		case NRS_ACT_LOGISTIC: return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); // 1-ulp rcp: inside the stated colour tolerance
 		case NRS_ACT_EXPONENTIAL: return __expf(clampf_(v, -10.f, 10.f));
 		default: return v;
 	}

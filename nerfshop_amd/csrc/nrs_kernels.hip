@@ -32,10 +32,11 @@ static int hip_fail(hipError_t e, const char* what) {
 
 constexpr int kRing = 128; // pending-ray ring entries per wave (>= 63 + 64)
 
+template <int WAVES>
 struct RenderSmem {
-	half8 w[kNumFrags * 64];
-	LevelParams levels[kLevels];
-	uint4 ring[4][kRing]; // {x | y << 16, t bits, output index, -}
+	ModelLds ml;
+	FeatLds fl[WAVES];
+	uint4 ring[WAVES][kRing]; // {x | y << 16, t bits, output index, -}
 };
 
 // packet -> pixel of this lane.  Packets are 8x8 pixel blocks.
@@ -61,16 +62,19 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 	return x < W && y < H;
 }
 
-// OCC = waves per SIMD the register allocator must leave room for (__launch_bounds__' second argument).
-template <int OCC>
-__global__ __launch_bounds__(256, OCC) void render_kernel(const DeviceModel m, const RenderArgs a) {
-	__shared__ RenderSmem sm;
-	stage_model_to_lds(m, sm.w, sm.levels);
+// WAVES = waves per workgroup (they share one LDS copy of the weights); OCC = waves per SIMD the register allocator must
+// leave room for (__launch_bounds__' second argument).
+template <int WAVES, int OCC>
+__global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceModel m, const RenderArgs a) {
+	__shared__ RenderSmem<WAVES> sm;
+	stage_model_to_lds(m, sm.ml);
 
 	const int lane = threadIdx.x & 63;
-	const int wave = threadIdx.x >> 6;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int g = lane >> 5;
 	uint4* ring = sm.ring[wave];
+	FeatLds& fl = sm.fl[wave];
+	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count);
 	const nrs_render_params& p = a.p;
 	const bool ops = p.apply_operators && a.n_edits > 0;
 	const f3 cam_fwd = mk3(p.camera_matrix1[6], p.camera_matrix1[7], p.camera_matrix1[8]);
@@ -150,8 +154,8 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(const DeviceModel m, c
 		}
 
 		// ---- one sample per live ray: generate_next_nerf_network_inputs body (tn:668-692) ----
-		f3 pos = o + d * t;
-		float dt = calc_dt(t, p.cone_angle_constant);
+		const f3 pos = o + d * t;
+		const float dt = calc_dt(t, p.cone_angle_constant);
 		f3 wpos = warp_position(pos, m.aabb);
 		f3 wdir = warp_direction(d);
 		const float wdt = warp_dt(dt);
@@ -160,33 +164,28 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(const DeviceModel m, c
 			for (int ei = a.n_edits - 1; ei >= 0; --ei) empty |= tet_warp(a.edits[ei], true, wpos, wdir);
 		}
 
-		// ---- encode: own sample -> block g, partner's sample -> block 1-g ----
+		// ---- gather: own sample (block g) and the partner lane's sample (block 1-g), levels 2*it+g ----
 		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
 		const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
 		const bool phave = __shfl_xor((int)have, 32, 64) != 0;
-		half8 own0, own1, par0, par1;
-		encode_levels(m.grid, sm.levels, g, wpos, have, own0, own1);
-		encode_levels(m.grid, sm.levels, g, ppos, phave, par0, par1);
-		half8 x[2][2];
-		x[0][0] = g ? par0 : own0; x[0][1] = g ? par1 : own1;
-		x[1][0] = g ? own0 : par0; x[1][1] = g ? own1 : par1;
+		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, have, ppos, phave);
 		const half8 sh_own = encode_sh4(g, wdir), sh_par = encode_sh4(g, pdir);
-		half8 sh[2];
-		sh[0] = g ? sh_par : sh_own;
-		sh[1] = g ? sh_own : sh_par;
 
-		// ---- fused MLPs on MFMA ----
-		half8 dout[2], rout[2];
-		density_mlp(sm.w, lane, x, dout);
-		rgb_mlp(sm.w, lane, dout, sh, rout);
-
-		// results of block 0 sit in lanes 0..31 (their own rays); block 1's are fetched from the partner lane
-		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-		const u32x4 d0 = __builtin_bit_cast(u32x4, dout[0]), d1 = __builtin_bit_cast(u32x4, dout[1]);
-		const u32x4 r0 = __builtin_bit_cast(u32x4, rout[0]), r1 = __builtin_bit_cast(u32x4, rout[1]);
-		const uint32_t xd = xchg32u(d1[0]), xrg = xchg32u(r1[0]), xb = xchg32u(r1[1]);
-		const uint32_t wd_ = g ? xd : d0[0], wrg = g ? xrg : r0[0], wb = g ? xb : r0[1];
-		const half2v hd = __builtin_bit_cast(half2v, wd_), hrg = __builtin_bit_cast(half2v, wrg), hb = __builtin_bit_cast(half2v, wb);
+		// ---- fused MLPs on MFMA, one 32-sample block at a time ----
+		uint32_t res_d = 0, res_rg = 0, res_b = 0;
+		#pragma unroll 1
+		for (int b = 0; b < 2; ++b) {
+			const int sel = (b != g) ? 1 : 0;
+			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
+			const half8 dout = density_mlp(sm.ml.w, lane, x0, x1);
+			const half8 rout = rgb_mlp(sm.ml.w, lane, dout, sel ? sh_par : sh_own);
+			const u32x4 dd = __builtin_bit_cast(u32x4, dout), rr = __builtin_bit_cast(u32x4, rout);
+			// rows 0..2 of a block sit in its lanes 0..31; block 1's samples belong to the rays of lanes 32..63
+			uint32_t vd = dd[0], vrg = rr[0], vb = rr[1];
+			if (b == 1) { vd = xchg32u(vd); vrg = xchg32u(vrg); vb = xchg32u(vb); }
+			if (g == b) { res_d = vd; res_rg = vrg; res_b = vb; }
+		}
+		const half2v hd = __builtin_bit_cast(half2v, res_d), hrg = __builtin_bit_cast(half2v, res_rg), hb = __builtin_bit_cast(half2v, res_b);
 		const float sigma_raw = (float)hd[0];
 		const float raw_r = (float)hrg[0], raw_g = (float)hrg[1], raw_b = (float)hb[0];
 
@@ -245,36 +244,36 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(const DeviceModel m, c
 	atomicAdd(&a.counters->n_rays_hit, st_hit);
 }
 
-template <int OCC>
-static int launch_render_occ(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream) {
+template <int WAVES, int OCC>
+static int launch_render_cfg(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream) {
 	int blocks_per_cu = 0;
-	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<OCC>, 256, 0);
+	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC>, 64 * WAVES, 0);
 	if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(render_kernel)");
 	if (blocks_per_cu < 1) blocks_per_cu = 1;
-	if (blocks_per_cu > OCC) blocks_per_cu = OCC;
 	uint32_t grid = (uint32_t)(n_cus * blocks_per_cu);
-	const uint32_t max_useful = (a.n_packets + 3) / 4; // at least one packet per wave
+	const uint32_t max_useful = (a.n_packets + WAVES - 1) / WAVES; // at least one packet per wave
 	if (grid > max_useful) grid = max_useful;
 	if (grid == 0) return NRS_OK;
-	hipLaunchKernelGGL(render_kernel<OCC>, dim3(grid), dim3(256), 0, stream, m, a);
+	hipLaunchKernelGGL((render_kernel<WAVES, OCC>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
 	NRS_LAUNCH_CHECK("render_kernel launch");
 	return NRS_OK;
 }
 
 int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* stream) {
-	// waves per SIMD: tuned default, NRS_RENDER_OCC overrides it for A/B measurements (profiles/)
-	static const int occ = []() {
-		const char* e = getenv("NRS_RENDER_OCC");
-		const int v = e ? atoi(e) : 0;
-		return (v >= 1 && v <= 4) ? v : 3;
+	// launch shape: tuned default; NRS_RENDER_CFG = <waves per workgroup><waves per SIMD> (e.g. "84") overrides it for
+	// the A/B measurements recorded under profiles/
+	static const int cfg = []() {
+		const char* e = getenv("NRS_RENDER_CFG");
+		return e ? atoi(e) : 0;
 	}();
 	hipStream_t s = (hipStream_t)stream;
-	switch (occ) {
-		case 1: return launch_render_occ<1>(m, a, n_cus, s);
-		case 3: return launch_render_occ<3>(m, a, n_cus, s);
-		case 4: return launch_render_occ<4>(m, a, n_cus, s);
-		case 2: return launch_render_occ<2>(m, a, n_cus, s);
-		default: return launch_render_occ<3>(m, a, n_cus, s);
+	switch (cfg) {
+		case 42: return launch_render_cfg<4, 2>(m, a, n_cus, s);
+		case 43: return launch_render_cfg<4, 3>(m, a, n_cus, s);
+		case 83: return launch_render_cfg<8, 3>(m, a, n_cus, s);
+		case 85: return launch_render_cfg<8, 5>(m, a, n_cus, s);
+		case 84: return launch_render_cfg<8, 4>(m, a, n_cus, s);
+		default: return launch_render_cfg<4, 3>(m, a, n_cus, s);
 	}
 }
 
@@ -314,8 +313,8 @@ int launch_trace_samples(const DeviceModel& m, const nrs_render_params& p, uint3
 
 // ---- NerfNetwork operator on caller batches ----------------------------------------------------------------------------
 struct NetSmem {
-	half8 w[kNumFrags * 64];
-	LevelParams levels[kLevels];
+	ModelLds ml;
+	FeatLds fl[4];
 };
 
 // MODE 0: inference_mixed_precision (16 channels, c3 = density raw), 1: density(), 2: hash-grid features [n x 32]
@@ -323,9 +322,11 @@ template <int MODE>
 __global__ __launch_bounds__(256) void network_kernel(const DeviceModel m, uint32_t n, const float* __restrict__ in, uint32_t ld_in,
                                                       _Float16* __restrict__ out, uint32_t ld_out, int layout) {
 	__shared__ NetSmem sm;
-	stage_model_to_lds(m, sm.w, sm.levels);
+	stage_model_to_lds(m, sm.ml);
 	const int lane = threadIdx.x & 63;
 	const int g = lane >> 5, j = lane & 31;
+	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count);
 	const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
 	const uint32_t n_tiles = (n + 63) / 64;
@@ -340,49 +341,42 @@ __global__ __launch_bounds__(256) void network_kernel(const DeviceModel m, uint3
 		}
 		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
 		const bool phave = __shfl_xor((int)have, 32, 64) != 0;
-		half8 own0, own1, par0, par1;
-		encode_levels(m.grid, sm.levels, g, wpos, have, own0, own1);
-		encode_levels(m.grid, sm.levels, g, ppos, phave, par0, par1);
-		half8 x[2][2];
-		x[0][0] = g ? par0 : own0; x[0][1] = g ? par1 : own1;
-		x[1][0] = g ? own0 : par0; x[1][1] = g ? own1 : par1;
+		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, have, ppos, phave);
 
 		if (MODE == 2) {
-			#pragma unroll
+			#pragma unroll 1
 			for (int b = 0; b < 2; ++b) {
 				const uint32_t sb = tile * 64 + 32 * b + j;
+				const int sel = (b != g) ? 1 : 0;
 				if (sb < n) {
 					#pragma unroll
-					for (int ks = 0; ks < 2; ++ks)
-						#pragma unroll
-						for (int e = 0; e < 8; ++e) {
-							const int level = 2 * (4 * ks + (e >> 1)) + g;
-							out[(size_t)sb * 32 + 2 * level + (e & 1)] = x[b][ks][e];
-						}
+					for (int it = 0; it < 8; ++it) // level 2*it+g, two features per dword
+						reinterpret_cast<uint32_t*>(out)[(size_t)sb * 16 + 2 * it + g] = fl.feat[it][sel][lane];
 				}
 			}
 			continue;
 		}
 
-		half8 dout[2], rout[2];
-		density_mlp(sm.w, lane, x, dout);
+		half8 sh_own, sh_par;
 		if (MODE == 0) {
 			const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
-			const half8 sh_own = encode_sh4(g, wdir), sh_par = encode_sh4(g, pdir);
-			half8 sh[2];
-			sh[0] = g ? sh_par : sh_own;
-			sh[1] = g ? sh_own : sh_par;
-			rgb_mlp(sm.w, lane, dout, sh, rout);
+			sh_own = encode_sh4(g, wdir);
+			sh_par = encode_sh4(g, pdir);
 		}
-		#pragma unroll
+		#pragma unroll 1
 		for (int b = 0; b < 2; ++b) {
+			const int sel = (b != g) ? 1 : 0;
+			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
+			const half8 dout = density_mlp(sm.ml.w, lane, x0, x1);
+			half8 rout = dout;
+			if (MODE == 0) rout = rgb_mlp(sm.ml.w, lane, dout, sel ? sh_par : sh_own);
 			const uint32_t sb = tile * 64 + 32 * b + j;
 			if (sb < n) {
 				#pragma unroll
 				for (int e = 0; e < 8; ++e) {
 					const int row = (e & 3) + 8 * (e >> 2) + 4 * g;
-					_Float16 v = (MODE == 0) ? rout[b][e] : dout[b][e];
-					if (MODE == 0 && row == 3) v = dout[b][0]; // extract_density, nerf_network_full.h:89-95 (row 3 and density row 0 both live on g == 0)
+					_Float16 v = rout[e];
+					if (MODE == 0 && e == 3) v = g ? v : dout[0]; // extract_density (nerf_network_full.h:89-95): row 3 <- density row 0, both on g == 0
 					if (layout == NRS_PLANES) out[(size_t)row * ld_out + sb] = v;
 					else out[(size_t)sb * 16 + row] = v;
 				}

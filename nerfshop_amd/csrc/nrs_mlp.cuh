@@ -1,22 +1,24 @@
 // nrs_mlp.cuh -- hash-grid gather + fused MLPs on MFMA for one wavefront (gfx950).
 //
 // Replaces tiny-cuda-nn's kernel_grid + 2x kernel_mlp_fused + SH encoding + extract_density with one
-// register-resident pipeline.  A wave owns 64 samples, processed as two 32-sample MFMA column blocks:
+// on-chip pipeline.  A wave owns 64 samples, processed as two 32-sample MFMA column blocks:
 //
 //   block b holds the samples of lanes 32b..32b+31.  Lane l = (j = l & 31, g = l >> 5) works for sample j of each
-//   block and owns, of that sample, the hash-grid levels L(g, it) = 2*it + g (it = 0..7) -- so the two lane halves
-//   split the 16 levels even/odd -- and the SH coefficients 8g..8g+7.
+//   block and owns, of that sample, the hash-grid levels L(g, it) = 2*it + g (it = 0..7) -- the two lane halves split
+//   the 16 levels even/odd, so both halves of an iteration are of the same kind (dense / hashed) except for at most one
+//   mixed pair -- and the SH coefficients 8g..8g+7.
 //
 // Every layer is computed transposed, H^T[unit][sample] = W[unit][k] * X^T[k][sample], with
-// v_mfma_f32_32x32x16_f16: A = a 32x16 weight tile (from LDS, pre-arranged on the host), B = 16 x 32 samples.
-// The D tile of one layer (lane = sample column, 16 rows per lane) is, after ReLU + fp16 rounding, directly the B
-// operand of the next layer: the k index of an MFMA is free as long as A and B agree, so the host arranges the
-// weight tiles in the order the D registers come out (make_weight_fragments in nrs_api.cpp).  No cross-lane
-// traffic, no LDS round trip, no global intermediates.
+// v_mfma_f32_32x32x16_f16: A = a 32x16 weight tile (LDS, pre-arranged on the host), B = 16 x 32 samples.  The D tile of
+// one layer (lane = sample column, 16 rows per lane) is, after ReLU + fp16 rounding, directly the B operand of the next
+// layer: the k index of an MFMA is free as long as A and B agree, so the host arranges the weight tiles in the order the
+// D registers come out (make_weight_fragments in nrs_api.cpp).  No cross-lane shuffles between layers, no global
+// intermediates.  The gathered features pass through a 4 KiB per-wave LDS slab only because the level loop is kept
+// rolled (small code, few live registers, which buys occupancy for the gather latency).
 //
-// Numerics (stated; parity at the tcnn boundary is unpinned): grid entries fp16, trilinear sum in
-// fp32 via fmaf in corner order 0..7, rounded to fp16; MLP products fp16 x fp16 accumulated in fp32 by the MFMA,
-// ReLU, rounded to fp16 between layers; outputs rounded to fp16.
+// Numerics (stated; parity at the tcnn boundary is unpinned): grid entries fp16, trilinear sum in fp32 via
+// fmaf in corner order 0..7, rounded to fp16; MLP products fp16 x fp16 accumulated in fp32 by the MFMA, ReLU, rounded to
+// fp16 between layers; outputs rounded to fp16.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "nrs_device.cuh"
@@ -26,6 +28,7 @@ namespace nrs {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // fragment indices inside the LDS weight image
 #define NRS_FRAG_D1(mb, ks) ((mb) * 2 + (ks))
@@ -34,54 +37,148 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define NRS_FRAG_R2(mb, ks) (12 + (mb) * 4 + (ks))
 #define NRS_FRAG_R3(ks) (20 + (ks))
 
-__device__ __forceinline__ uint32_t fast_wrap(uint32_t index, const LevelParams& lp) {
-	if (lp.hashed) return index & lp.mask;
-	// dense level: index < 2*count for every in-range position; the exact modulo is the (never taken) slow path
-	if (index >= lp.count) {
-		index -= lp.count;
-		if (index >= lp.count) index %= lp.count;
+enum { KIND_DENSE = 0, KIND_HASHED = 1, KIND_MIXED = 2 };
+
+// Per-block model state in LDS: weight fragments, level table (index 2*it+g), kind of each level pair.
+struct ModelLds {
+	half8 w[kNumFrags * 64];
+	LevelParams levels[kLevels];
+	uint32_t kinds[8];
+	uint32_t pad[8];
+};
+// Per-wave feature slab: feat[it][sel][lane], sel 0 = the lane's own sample, 1 = its partner's (lane ^ 32) sample.
+struct FeatLds { uint32_t feat[8][2][64]; };
+
+__device__ __forceinline__ void stage_model_to_lds(const DeviceModel& m, ModelLds& s) {
+	const uint4* src = reinterpret_cast<const uint4*>(m.wfrag);
+	uint4* dst = reinterpret_cast<uint4*>(s.w);
+	for (uint32_t i = threadIdx.x; i < kWfragBytes / 16; i += blockDim.x) dst[i] = src[i];
+	if (threadIdx.x < kLevels) s.levels[threadIdx.x] = m.levels[threadIdx.x];
+	if (threadIdx.x < 8) {
+		const uint32_t h0 = m.levels[2 * threadIdx.x].hashed, h1 = m.levels[2 * threadIdx.x + 1].hashed;
+		s.kinds[threadIdx.x] = (h0 && h1) ? KIND_HASHED : ((!h0 && !h1) ? KIND_DENSE : KIND_MIXED);
 	}
-	return index;
+	__syncthreads();
 }
 
-// Gather + trilinear interpolation of the 8 levels this lane owns for one sample position (warped, [0,1]^3).
-// Result: 16 fp16 features as two MFMA B operands (k-step 0: it 0..3, k-step 1: it 4..7; element 2*(it&3)+f).
-__device__ __forceinline__ void encode_levels(const uint32_t* __restrict__ grid, const LevelParams* lds_levels, int g, f3 pos, bool active,
-                                              half8& k0, half8& k1) {
-	_Float16 feat[16];
-	#pragma unroll
-	for (int it = 0; it < 8; ++it) {
-		float acc0 = 0.f, acc1 = 0.f;
-		if (active) {
-			const LevelParams lp = lds_levels[2 * it + g];
-			float px = fmaf(lp.scale, pos.x, 0.5f), py = fmaf(lp.scale, pos.y, 0.5f), pz = fmaf(lp.scale, pos.z, 0.5f);
-			float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
-			uint32_t gx = (uint32_t)(int)fx, gy = (uint32_t)(int)fy, gz = (uint32_t)(int)fz;
-			float wx = px - fx, wy = py - fy, wz = pz - fz;
+// The table is read through a buffer descriptor: one 32-bit offset per gather instead of 64-bit pointer arithmetic.
+struct GridView { __amdgpu_buffer_rsrc_t rsrc; };
+__device__ __forceinline__ GridView make_grid_view(const uint32_t* grid, uint32_t n_entries) {
+	GridView v;
+	v.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)grid, 0, (int)(n_entries * 4u), 0x00020000);
+	return v;
+}
+__device__ __forceinline__ uint32_t grid_load(const GridView& v, uint32_t entry) {
+	return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(v.rsrc, (int)(entry * 4u), 0, 0);
+}
+
+// Exact tcnn index for any position (also far outside [0,1]^3): the rarely taken out-of-line path.
+__device__ __forceinline__ void level_eval_slow(const GridView gv, const LevelParams lp, uint32_t gx, uint32_t gy, uint32_t gz,
+                                                          float wx, float wy, float wz, float* out0, float* out1) {
+	float acc0 = 0.f, acc1 = 0.f;
+	#pragma unroll 1
+	for (int c = 0; c < 8; ++c) {
+		const uint32_t cx = gx + (c & 1), cy = gy + ((c >> 1) & 1), cz = gz + ((c >> 2) & 1);
+		uint32_t index = lp.hashed ? ((cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u)) : (cx + cy * lp.resolution + cz * lp.res2);
+		index %= lp.count;
+		float weight = 1.0f;
+		weight *= (c & 1) ? wx : 1.0f - wx;
+		weight *= (c & 2) ? wy : 1.0f - wy;
+		weight *= (c & 4) ? wz : 1.0f - wz;
+		const half2v hv = __builtin_bit_cast(half2v, grid_load(gv, lp.offset + index));
+		acc0 = fmaf(weight, (float)hv[0], acc0);
+		acc1 = fmaf(weight, (float)hv[1], acc1);
+	}
+	*out0 = acc0;
+	*out1 = acc1;
+}
+
+// One level of one sample: 8 gathers + trilinear interpolation -> two fp16 features packed in a dword.
+template <int KIND>
+__device__ __forceinline__ uint32_t level_eval(const GridView& gv, const LevelParams& lp, f3 pos, bool active) {
+	float acc0 = 0.f, acc1 = 0.f;
+	if (active) {
+		const float px = fmaf(lp.scale, pos.x, 0.5f), py = fmaf(lp.scale, pos.y, 0.5f), pz = fmaf(lp.scale, pos.z, 0.5f);
+		const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+		const uint32_t gx = (uint32_t)(int)fx, gy = (uint32_t)(int)fy, gz = (uint32_t)(int)fz;
+		const float wx = px - fx, wy = py - fy, wz = pz - fz;
+		// dense indices stay below 2*count only while every corner coordinate is <= resolution
+		const bool need_slow = (KIND != KIND_HASHED) && !lp.hashed && (gx >= lp.resolution || gy >= lp.resolution || gz >= lp.resolution);
+		if (__builtin_expect(need_slow, 0)) {
+			level_eval_slow(gv, lp, gx, gy, gz, wx, wy, wz, &acc0, &acc1);
+		} else {
+			uint32_t idx[8];
+			if (KIND == KIND_HASHED) {
+				const uint32_t hx0 = gx, hx1 = gx + 1u, hy0 = gy * 2654435761u, hy1 = hy0 + 2654435761u, hz0 = gz * 805459861u, hz1 = hz0 + 805459861u;
+				#pragma unroll
+				for (int c = 0; c < 8; ++c) idx[c] = (((c & 1) ? hx1 : hx0) ^ ((c & 2) ? hy1 : hy0) ^ ((c & 4) ? hz1 : hz0)) & lp.mask;
+			} else if (KIND == KIND_DENSE) {
+				const uint32_t base = gx + gy * lp.resolution + gz * lp.res2;
+				#pragma unroll
+				for (int c = 0; c < 8; ++c) {
+					const uint32_t i = base + ((c & 1) ? 1u : 0u) + ((c & 2) ? lp.resolution : 0u) + ((c & 4) ? lp.res2 : 0u);
+					idx[c] = i >= lp.count ? i - lp.count : i;
+				}
+			} else {
+				const uint32_t hx0 = gx, hx1 = gx + 1u, hy0 = gy * 2654435761u, hy1 = hy0 + 2654435761u, hz0 = gz * 805459861u, hz1 = hz0 + 805459861u;
+				const uint32_t base = gx + gy * lp.resolution + gz * lp.res2;
+				#pragma unroll
+				for (int c = 0; c < 8; ++c) {
+					const uint32_t h = (((c & 1) ? hx1 : hx0) ^ ((c & 2) ? hy1 : hy0) ^ ((c & 4) ? hz1 : hz0)) & lp.mask;
+					const uint32_t i = base + ((c & 1) ? 1u : 0u) + ((c & 2) ? lp.resolution : 0u) + ((c & 4) ? lp.res2 : 0u);
+					idx[c] = lp.hashed ? h : (i >= lp.count ? i - lp.count : i);
+				}
+			}
 			uint32_t vals[8];
 			#pragma unroll
-			for (int c = 0; c < 8; ++c) {
-				uint32_t cx = gx + (c & 1), cy = gy + ((c >> 1) & 1), cz = gz + ((c >> 2) & 1);
-				uint32_t index = lp.hashed ? ((cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u)) : (cx + cy * lp.resolution + cz * lp.res2);
-				index = fast_wrap(index, lp);
-				vals[c] = grid[lp.offset + index];
-			}
+			for (int c = 0; c < 8; ++c) vals[c] = grid_load(gv, lp.offset + idx[c]);
+			const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+			const float wxy[4] = {ux * uy, wx * uy, ux * wy, wx * wy}; // (wx' * wy') * wz', as the oracle multiplies
 			#pragma unroll
 			for (int c = 0; c < 8; ++c) {
-				float weight = 1.0f;
-				weight *= (c & 1) ? wx : 1.0f - wx;
-				weight *= (c & 2) ? wy : 1.0f - wy;
-				weight *= (c & 4) ? wz : 1.0f - wz;
-				half2v hv = __builtin_bit_cast(half2v, vals[c]);
+				const float weight = wxy[c & 3] * ((c & 4) ? wz : uz);
+				const half2v hv = __builtin_bit_cast(half2v, vals[c]);
 				acc0 = fmaf(weight, (float)hv[0], acc0);
 				acc1 = fmaf(weight, (float)hv[1], acc1);
 			}
 		}
-		feat[2 * it + 0] = (_Float16)acc0;
-		feat[2 * it + 1] = (_Float16)acc1;
 	}
-	#pragma unroll
-	for (int e = 0; e < 8; ++e) { k0[e] = feat[e]; k1[e] = feat[8 + e]; }
+	half2v r;
+	r[0] = (_Float16)acc0;
+	r[1] = (_Float16)acc1;
+	return __builtin_bit_cast(uint32_t, r);
+}
+
+// All 8 level pairs of two positions (own sample A, partner's sample B) -> the wave's feature slab.
+__device__ __forceinline__ void encode_to_lds(const GridView& gv, const ModelLds& ml, FeatLds& fl, int lane, int g, f3 posA, bool actA, f3 posB, bool actB) {
+	#pragma unroll 1
+	for (int it = 0; it < 8; ++it) {
+		const LevelParams lp = ml.levels[2 * it + g];
+		const uint32_t kind = __builtin_amdgcn_readfirstlane(ml.kinds[it]);
+		uint32_t fa, fb;
+		if (kind == KIND_HASHED) {
+			fa = level_eval<KIND_HASHED>(gv, lp, posA, actA);
+			fb = level_eval<KIND_HASHED>(gv, lp, posB, actB);
+		} else if (kind == KIND_DENSE) {
+			fa = level_eval<KIND_DENSE>(gv, lp, posA, actA);
+			fb = level_eval<KIND_DENSE>(gv, lp, posB, actB);
+		} else {
+			fa = level_eval<KIND_MIXED>(gv, lp, posA, actA);
+			fb = level_eval<KIND_MIXED>(gv, lp, posB, actB);
+		}
+		fl.feat[it][0][lane] = fa;
+		fl.feat[it][1][lane] = fb;
+	}
+}
+
+// B operand of block b for k-step ks: levels it = 4ks..4ks+3 of sample (b, j) as this lane gathered them
+__device__ __forceinline__ half8 load_features(const FeatLds& fl, int lane, int sel, int ks) {
+	u32x4 v;
+	v[0] = fl.feat[4 * ks + 0][sel][lane];
+	v[1] = fl.feat[4 * ks + 1][sel][lane];
+	v[2] = fl.feat[4 * ks + 2][sel][lane];
+	v[3] = fl.feat[4 * ks + 3][sel][lane];
+	return __builtin_bit_cast(half8, v);
 }
 
 // SH degree 4 (tcnn SphericalHarmonics) of a direction given as (d+1)/2: the 8 coefficients 8g..8g+7 this lane owns.
@@ -114,11 +211,13 @@ __device__ __forceinline__ half8 encode_sh4(int g, f3 dir01) {
 	return r;
 }
 
+// ReLU + fp16 rounding of 8 accumulator rows.  max(round(x), 0) == round(max(x, 0)); done on packed halfs.
 __device__ __forceinline__ half8 relu_pack(const floatx16& d, int base) {
 	half8 r;
 	#pragma unroll
-	for (int e = 0; e < 8; ++e) r[e] = (_Float16)fmaxf(d[base + e], 0.f);
-	return r;
+	for (int e = 0; e < 8; ++e) r[e] = (_Float16)d[base + e];
+	const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+	return __builtin_elementwise_max(r, zero);
 }
 __device__ __forceinline__ half8 pack(const floatx16& d, int base) {
 	half8 r;
@@ -126,106 +225,78 @@ __device__ __forceinline__ half8 pack(const floatx16& d, int base) {
 	for (int e = 0; e < 8; ++e) r[e] = (_Float16)d[base + e];
 	return r;
 }
-
-#define NRS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
-
-// Density MLP 32 -> 64 (ReLU) -> 16 for both sample blocks.  x[b][ks]: features of block b.
-// dout[b] = fp16-rounded outputs as the next B operand: element e of lane (j, g) = output row (e&3) + 8*(e>>2) + 4g.
-__device__ __forceinline__ void density_mlp(const half8* lds_w, int lane, const half8 x[2][2], half8 dout[2]) {
-	floatx16 h[2][2]; // [block][mb]
+__device__ __forceinline__ floatx16 zero16() {
+	floatx16 z;
 	#pragma unroll
-	for (int b = 0; b < 2; ++b)
-		#pragma unroll
-		for (int mb = 0; mb < 2; ++mb)
-			#pragma unroll
-			for (int i = 0; i < 16; ++i) h[b][mb][i] = 0.f;
-	#pragma unroll
-	for (int mb = 0; mb < 2; ++mb)
-		#pragma unroll
-		for (int ks = 0; ks < 2; ++ks) {
-			half8 a = lds_w[NRS_FRAG_D1(mb, ks) * 64 + lane];
-			h[0][mb] = NRS_MFMA(a, x[0][ks], h[0][mb]);
-			h[1][mb] = NRS_MFMA(a, x[1][ks], h[1][mb]);
-		}
-	floatx16 o[2];
-	#pragma unroll
-	for (int b = 0; b < 2; ++b)
-		#pragma unroll
-		for (int i = 0; i < 16; ++i) o[b][i] = 0.f;
-	#pragma unroll
-	for (int ks = 0; ks < 4; ++ks) {
-		half8 a = lds_w[NRS_FRAG_D2(ks) * 64 + lane];
-		o[0] = NRS_MFMA(a, relu_pack(h[0][ks >> 1], 8 * (ks & 1)), o[0]);
-		o[1] = NRS_MFMA(a, relu_pack(h[1][ks >> 1], 8 * (ks & 1)), o[1]);
-	}
-	dout[0] = pack(o[0], 0);
-	dout[1] = pack(o[1], 0);
+	for (int i = 0; i < 16; ++i) z[i] = 0.f;
+	return z;
 }
 
-// RGB MLP [density out 16 | SH 16] -> 64 -> 64 -> 16 (3 used) for both blocks.  rout[b]: fp16 outputs, same row map.
-__device__ __forceinline__ void rgb_mlp(const half8* lds_w, int lane, const half8 din[2], const half8 sh[2], half8 rout[2]) {
-	floatx16 h1[2][2];
-	#pragma unroll
-	for (int b = 0; b < 2; ++b)
-		#pragma unroll
-		for (int mb = 0; mb < 2; ++mb)
-			#pragma unroll
-			for (int i = 0; i < 16; ++i) h1[b][mb][i] = 0.f;
-	#pragma unroll
-	for (int mb = 0; mb < 2; ++mb) {
-		half8 a0 = lds_w[NRS_FRAG_R1(mb, 0) * 64 + lane];
-		h1[0][mb] = NRS_MFMA(a0, din[0], h1[0][mb]);
-		h1[1][mb] = NRS_MFMA(a0, din[1], h1[1][mb]);
-		half8 a1 = lds_w[NRS_FRAG_R1(mb, 1) * 64 + lane];
-		h1[0][mb] = NRS_MFMA(a1, sh[0], h1[0][mb]);
-		h1[1][mb] = NRS_MFMA(a1, sh[1], h1[1][mb]);
-	}
-	half8 b1[2][4]; // B operands of layer 2: [block][ks]
-	#pragma unroll
-	for (int b = 0; b < 2; ++b)
-		#pragma unroll
-		for (int ks = 0; ks < 4; ++ks) b1[b][ks] = relu_pack(h1[b][ks >> 1], 8 * (ks & 1));
-	floatx16 h2[2][2];
-	#pragma unroll
-	for (int b = 0; b < 2; ++b)
-		#pragma unroll
-		for (int mb = 0; mb < 2; ++mb)
-			#pragma unroll
-			for (int i = 0; i < 16; ++i) h2[b][mb][i] = 0.f;
-	#pragma unroll
-	for (int mb = 0; mb < 2; ++mb)
-		#pragma unroll
-		for (int ks = 0; ks < 4; ++ks) {
-			half8 a = lds_w[NRS_FRAG_R2(mb, ks) * 64 + lane];
-			h2[0][mb] = NRS_MFMA(a, b1[0][ks], h2[0][mb]);
-			h2[1][mb] = NRS_MFMA(a, b1[1][ks], h2[1][mb]);
-		}
-	floatx16 o[2];
-	#pragma unroll
-	for (int b = 0; b < 2; ++b)
-		#pragma unroll
-		for (int i = 0; i < 16; ++i) o[b][i] = 0.f;
-	#pragma unroll
-	for (int ks = 0; ks < 4; ++ks) {
-		half8 a = lds_w[NRS_FRAG_R3(ks) * 64 + lane];
-		o[0] = NRS_MFMA(a, relu_pack(h2[0][ks >> 1], 8 * (ks & 1)), o[0]);
-		o[1] = NRS_MFMA(a, relu_pack(h2[1][ks >> 1], 8 * (ks & 1)), o[1]);
-	}
-	rout[0] = pack(o[0], 0);
-	rout[1] = pack(o[1], 0);
+#define NRS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+// Scheduling fence between MLP stages: without it hipcc hoists all 24 weight-fragment LDS reads (96 VGPRs) to the top of
+// the MLP, which costs a wave of occupancy.  The gather, not the MLP, is the phase that needs the latency hiding.
+#define NRS_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Density MLP 32 -> 64 (ReLU) -> 16 for one 32-sample block.  x0/x1: features (k-steps 0/1).
+// Returns the fp16-rounded outputs as the next B operand: element e of lane (j, g) = output row (e&3) + 8*(e>>2) + 4g.
+__device__ __forceinline__ half8 density_mlp(const half8* lds_w, int lane, half8 x0, half8 x1) {
+	// hidden rows 0..31 then 32..63, each reduced to its two packed B operands before the next accumulator is started
+	floatx16 h = zero16();
+	h = NRS_MFMA(lds_w[NRS_FRAG_D1(0, 0) * 64 + lane], x0, h);
+	h = NRS_MFMA(lds_w[NRS_FRAG_D1(0, 1) * 64 + lane], x1, h);
+	const half8 p0 = relu_pack(h, 0), p1 = relu_pack(h, 8);
+	NRS_STAGE_FENCE();
+	h = zero16();
+	h = NRS_MFMA(lds_w[NRS_FRAG_D1(1, 0) * 64 + lane], x0, h);
+	h = NRS_MFMA(lds_w[NRS_FRAG_D1(1, 1) * 64 + lane], x1, h);
+	const half8 p2 = relu_pack(h, 0), p3 = relu_pack(h, 8);
+	NRS_STAGE_FENCE();
+	floatx16 o = zero16();
+	o = NRS_MFMA(lds_w[NRS_FRAG_D2(0) * 64 + lane], p0, o);
+	o = NRS_MFMA(lds_w[NRS_FRAG_D2(1) * 64 + lane], p1, o);
+	o = NRS_MFMA(lds_w[NRS_FRAG_D2(2) * 64 + lane], p2, o);
+	o = NRS_MFMA(lds_w[NRS_FRAG_D2(3) * 64 + lane], p3, o);
+	NRS_STAGE_FENCE();
+	return pack(o, 0);
+}
+
+// RGB MLP [density out 16 | SH 16] -> 64 -> 64 -> 16 (3 used) for one block.  Same output row map.
+__device__ __forceinline__ half8 rgb_mlp(const half8* lds_w, int lane, half8 din, half8 sh) {
+	floatx16 a = zero16();
+	a = NRS_MFMA(lds_w[NRS_FRAG_R1(0, 0) * 64 + lane], din, a);
+	a = NRS_MFMA(lds_w[NRS_FRAG_R1(0, 1) * 64 + lane], sh, a);
+	const half8 b0 = relu_pack(a, 0), b1 = relu_pack(a, 8);
+	NRS_STAGE_FENCE();
+	a = zero16();
+	a = NRS_MFMA(lds_w[NRS_FRAG_R1(1, 0) * 64 + lane], din, a);
+	a = NRS_MFMA(lds_w[NRS_FRAG_R1(1, 1) * 64 + lane], sh, a);
+	const half8 b2 = relu_pack(a, 0), b3 = relu_pack(a, 8);
+	NRS_STAGE_FENCE();
+	floatx16 c = zero16();
+	c = NRS_MFMA(lds_w[NRS_FRAG_R2(0, 0) * 64 + lane], b0, c);
+	c = NRS_MFMA(lds_w[NRS_FRAG_R2(0, 1) * 64 + lane], b1, c);
+	c = NRS_MFMA(lds_w[NRS_FRAG_R2(0, 2) * 64 + lane], b2, c);
+	c = NRS_MFMA(lds_w[NRS_FRAG_R2(0, 3) * 64 + lane], b3, c);
+	const half8 q0 = relu_pack(c, 0), q1 = relu_pack(c, 8);
+	NRS_STAGE_FENCE();
+	c = zero16();
+	c = NRS_MFMA(lds_w[NRS_FRAG_R2(1, 0) * 64 + lane], b0, c);
+	c = NRS_MFMA(lds_w[NRS_FRAG_R2(1, 1) * 64 + lane], b1, c);
+	c = NRS_MFMA(lds_w[NRS_FRAG_R2(1, 2) * 64 + lane], b2, c);
+	c = NRS_MFMA(lds_w[NRS_FRAG_R2(1, 3) * 64 + lane], b3, c);
+	const half8 q2 = relu_pack(c, 0), q3 = relu_pack(c, 8);
+	NRS_STAGE_FENCE();
+	floatx16 o = zero16();
+	o = NRS_MFMA(lds_w[NRS_FRAG_R3(0) * 64 + lane], q0, o);
+	o = NRS_MFMA(lds_w[NRS_FRAG_R3(1) * 64 + lane], q1, o);
+	o = NRS_MFMA(lds_w[NRS_FRAG_R3(2) * 64 + lane], q2, o);
+	o = NRS_MFMA(lds_w[NRS_FRAG_R3(3) * 64 + lane], q3, o);
+	NRS_STAGE_FENCE();
+	return pack(o, 0);
 }
 
 // Exchange a value with the partner lane (l ^ 32): one ds_bpermute.
 __device__ __forceinline__ float xchg32(float v) { return __shfl_xor(v, 32, 64); }
 __device__ __forceinline__ uint32_t xchg32u(uint32_t v) { return (uint32_t)__shfl_xor((int)v, 32, 64); }
-
-// Cooperative copy of the weight-fragment image and the level table into LDS (all threads of the block).
-__device__ __forceinline__ void stage_model_to_lds(const DeviceModel& m, half8* lds_w, LevelParams* lds_levels) {
-	const uint4* src = reinterpret_cast<const uint4*>(m.wfrag);
-	uint4* dst = reinterpret_cast<uint4*>(lds_w);
-	for (uint32_t i = threadIdx.x; i < kWfragBytes / 16; i += blockDim.x) dst[i] = src[i];
-	if (threadIdx.x < kLevels) lds_levels[threadIdx.x] = m.levels[threadIdx.x];
-	__syncthreads();
-}
 
 } // namespace nrs
