@@ -276,41 +276,53 @@ __device__ __forceinline__ f3 ld3(const float* __restrict__ a, uint32_t i) { ret
 
 // interpolate_tet (with_dir, honours copy) / interpolate_tet_pos (!with_dir, ignores copy).  pos/dir are the warped
 // [0,1] values of the NerfCoordinate; returns true if the sample must be treated as empty space.
+// Two phases on purpose: the LUT scan only decides WHICH tet contains the sample; the barycentric map-back reloads that
+// tet's vertices afterwards.  Fusing them keeps ~48 more VGPRs live across the scan and costs the kernel a wave of occupancy.
 __device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3& wpos, f3& wdir) {
 	bool in_deformed = false;
 	if (box_contains(e.warped_bbox, wpos)) {
-		f3 u = unwarp_position(wpos, e.aabb);
-		int level = mip_from_pos(u);
-		uint32_t cell = (uint32_t)level * kGridVol + cascaded_grid_idx_at(u, (uint32_t)level);
-		uint32_t j0 = e.lut_off[cell], j1 = e.lut_off[cell + 1];
+		const f3 u = unwarp_position(wpos, e.aabb);
+		const int level = mip_from_pos(u);
+		const uint32_t cell = (uint32_t)level * kGridVol + cascaded_grid_idx_at(u, (uint32_t)level);
+		const uint32_t j0 = e.lut_off[cell], j1 = e.lut_off[cell + 1];
+		uint32_t found = 0xffffffffu;
+		#pragma unroll 1
 		for (uint32_t j = j0; j < j1; ++j) {
-			uint32_t t = e.lut_idx[j];
-			uint4 tv = reinterpret_cast<const uint4*>(e.tets)[t];
-			f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), d = ld3(e.verts, tv.w);
-			if (point_in_tet(a, b, c, d, u)) {
-				float bc[4];
+			const uint32_t t = e.lut_idx[j];
+			const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[t];
+			const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), d = ld3(e.verts, tv.w);
+			if (point_in_tet(a, b, c, d, u)) { found = t; break; }
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		if (found != 0xffffffffu) {
+			const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[found];
+			float bc[4];
+			{
+				const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), d = ld3(e.verts, tv.w);
 				bary_tet(a, b, c, d, u, bc);
-				f3 o0 = ld3(e.orig, tv.x), o1 = ld3(e.orig, tv.y), o2 = ld3(e.orig, tv.z), o3 = ld3(e.orig, tv.w);
-				f3 canon = ((bc[0] * o0 + bc[1] * o1) + bc[2] * o2) + bc[3] * o3;
-				wpos = warp_position(canon, e.aabb);
-				if (with_dir && e.rot) {
-					f3 ud = unwarp_direction(wdir);
-					const float* R = e.rot + 9 * (size_t)t;
-					f3 rd = {(R[0] * ud.x + R[3] * ud.y) + R[6] * ud.z, (R[1] * ud.x + R[4] * ud.y) + R[7] * ud.z,
-					         (R[2] * ud.x + R[5] * ud.y) + R[8] * ud.z};
-					wdir = warp_direction(rd);
-				}
-				in_deformed = true;
-				break;
 			}
+			__builtin_amdgcn_sched_barrier(0);
+			f3 canon = bc[0] * ld3(e.orig, tv.x) + bc[1] * ld3(e.orig, tv.y);
+			canon = canon + bc[2] * ld3(e.orig, tv.z);
+			canon = canon + bc[3] * ld3(e.orig, tv.w);
+			wpos = warp_position(canon, e.aabb);
+			__builtin_amdgcn_sched_barrier(0);
+			if (with_dir && e.rot) {
+				const f3 ud = unwarp_direction(wdir);
+				const float* R = e.rot + 9 * (size_t)found;
+				const f3 rd = {(R[0] * ud.x + R[3] * ud.y) + R[6] * ud.z, (R[1] * ud.x + R[4] * ud.y) + R[7] * ud.z,
+				               (R[2] * ud.x + R[5] * ud.y) + R[8] * ud.z};
+				wdir = warp_direction(rd);
+			}
+			in_deformed = true;
 		}
 	}
 	bool empty = false;
 	if (!(with_dir && e.copy)) {
 		if (!in_deformed && box_contains(e.orig_warped_bbox, wpos)) {
-			f3 u = unwarp_position(wpos, e.aabb);
-			int level = mip_from_pos(u);
-			uint32_t pos_idx = cascaded_grid_idx_at(u, (uint32_t)level);
+			const f3 u = unwarp_position(wpos, e.aabb);
+			const int level = mip_from_pos(u);
+			const uint32_t pos_idx = cascaded_grid_idx_at(u, (uint32_t)level);
 			empty = get_bitfield_at(pos_idx, (uint32_t)level, e.orig_bitfield);
 		}
 	}
