@@ -271,7 +271,6 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 		case 42: return launch_render_cfg<4, 2>(m, a, n_cus, s);
 		case 43: return launch_render_cfg<4, 3>(m, a, n_cus, s);
 		case 83: return launch_render_cfg<8, 3>(m, a, n_cus, s);
-		case 43: return launch_render_cfg<4, 3>(m, a, n_cus, s);
 		default: return launch_render_cfg<8, 4>(m, a, n_cus, s);
 	}
 }
