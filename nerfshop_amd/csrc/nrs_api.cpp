@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -147,6 +148,40 @@ static void warp_box(const Box3& b, const Box3& aabb, Box3& out) { // BoundingBo
 	}
 }
 
+// World-space bounds of every occupied cell of every cascade (cell (x,y,z) of level l spans
+// ((x/128 - 0.5) * 2^l + 0.5, ((x+1)/128 - 0.5) * 2^l + 0.5) per axis), inflated by 1/16 of a cell of the level.
+static uint32_t compact3(uint32_t x) {
+	x &= 0x49249249u;
+	x = (x | (x >> 2)) & 0xc30c30c3u;
+	x = (x | (x >> 4)) & 0x0f00f00fu;
+	x = (x | (x >> 8)) & 0xff0000ffu;
+	x = (x | (x >> 16)) & 0x0000ffffu;
+	return x;
+}
+static void occupied_bounds(const uint8_t* bitfield, Box3& out) {
+	const float inf = std::numeric_limits<float>::infinity();
+	for (int k = 0; k < 3; ++k) { out.mn[k] = inf; out.mx[k] = -inf; }
+	for (uint32_t level = 0; level < kCascades; ++level) {
+		uint32_t lo[3] = {kGrid, kGrid, kGrid}, hi[3] = {0, 0, 0};
+		bool any = false;
+		const uint8_t* b = bitfield + (size_t)level * kGridVol / 8;
+		for (uint32_t byte = 0; byte < kGridVol / 8; ++byte) {
+			if (!b[byte]) continue;
+			any = true;
+			// the 8 cells of a byte are one 2x2x2 Morton block: bounds of the block are exact enough (<= 1 cell slack)
+			const uint32_t m = byte * 8;
+			const uint32_t c[3] = {compact3(m), compact3(m >> 1), compact3(m >> 2)};
+			for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], c[k]); hi[k] = std::max(hi[k], c[k] + 2u); }
+		}
+		if (!any) continue;
+		const float s = std::ldexp(1.0f, (int)level), margin = s / (float)kGrid / 16.f;
+		for (int k = 0; k < 3; ++k) {
+			out.mn[k] = std::fmin(out.mn[k], ((float)lo[k] / (float)kGrid - 0.5f) * s + 0.5f - margin);
+			out.mx[k] = std::fmax(out.mx[k], ((float)hi[k] / (float)kGrid - 0.5f) * s + 0.5f + margin);
+		}
+	}
+}
+
 template <typename T>
 static int upload(nrs_edit* e, const T* h, size_t count, const T** d_out) {
 	void* d = nullptr;
@@ -271,6 +306,7 @@ int nrs_model_set_density_bitfield(nrs_model* m, const uint8_t* h_bitfield, size
 	if (n_bytes != NRS_BITFIELD_BYTES) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_density_bitfield: expected 5*128^3/8 bytes");
 	HIP_TRY(hipSetDevice(m->ctx->device));
 	HIP_TRY(hipMemcpy(m->d_bitfield, h_bitfield, n_bytes, hipMemcpyHostToDevice));
+	occupied_bounds(h_bitfield, m->dm.occ_box);
 	m->have_bitfield = true;
 	return NRS_OK;
 }
@@ -288,6 +324,11 @@ int nrs_model_set_density_grid(nrs_model* m, const float* h_grid, size_t n_float
 	(void)hipFree(d_grid);
 	if (e != hipSuccess) return fail_hip(e, "nrs_model_set_density_grid");
 	if (s != NRS_OK) return (g_err = launch_last_error(), s);
+	{
+		std::vector<uint8_t> host_bits(NRS_BITFIELD_BYTES);
+		HIP_TRY(hipMemcpy(host_bits.data(), m->d_bitfield, NRS_BITFIELD_BYTES, hipMemcpyDeviceToHost));
+		occupied_bounds(host_bits.data(), m->dm.occ_box);
+	}
 	m->have_bitfield = true;
 	return NRS_OK;
 }
@@ -449,6 +490,10 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	if (a.any_poisson) return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: membrane (Poisson) correction is not implemented in this build");
 	a.edits = ctx->d_edits;
 	a.max_steps = p->max_march_steps ? p->max_march_steps : 10000u; // MARCH_ITER, testbed_nerf.cu:56
+	{
+		static const uint32_t dbg = []() { const char* e = getenv("NRS_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
+		a.dbg = dbg;
+	}
 	a.frame = d_frame;
 	a.depth = d_depth;
 	a.steps = d_steps;
@@ -462,6 +507,15 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		h_stats->n_samples = c.n_samples;
 		h_stats->n_rays_alive = c.n_rays_alive;
 		h_stats->n_rays_hit = c.n_rays_hit;
+		if (a.dbg & 4u) {
+			static const char* names[8] = {"fill", "refill", "setup+warp", "gather", "sh+mlp", "composite+march+shade", "-", "exit"};
+			unsigned long long tot = 0;
+			for (int i = 0; i < 8; ++i) tot += c.phase_cycles[i];
+			fprintf(stderr, "[nrs phases] samples=%llu", (unsigned long long)c.n_samples);
+			for (int i = 0; i < 8; ++i)
+				if (c.phase_cycles[i]) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)c.phase_cycles[i] / (double)tot);
+			fprintf(stderr, "\n");
+		}
 	}
 	return NRS_OK;
 }

@@ -30,11 +30,13 @@ __device__ __forceinline__ bool box_contains(const Box3& b, f3 p) { // BoundingB
 #define NRS_NEAR_DISTANCE 0.05f
 
 // ---- Morton (tcnn morton3D; x in the lowest bit) --------------------------------------------------------------
+// (v * 0x00010001) & mask etc. of tcnn's expand_bits equals (v | v << s) & mask for v < 2^10: written with shifts because
+// v_mul_lo_u32 is a quarter-rate instruction and this runs once per DDA step.
 __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
-	v = (v * 0x00010001u) & 0xFF0000FFu;
-	v = (v * 0x00000101u) & 0x0F00F00Fu;
-	v = (v * 0x00000011u) & 0xC30C30C3u;
-	v = (v * 0x00000005u) & 0x49249249u;
+	v = (v | (v << 16)) & 0xFF0000FFu;
+	v = (v | (v << 8)) & 0x0F00F00Fu;
+	v = (v | (v << 4)) & 0xC30C30C3u;
+	v = (v | (v << 2)) & 0x49249249u;
 	return v;
 }
 __device__ __forceinline__ uint32_t morton3D(uint32_t x, uint32_t y, uint32_t z) {
@@ -190,8 +192,9 @@ __device__ __forceinline__ void ray_intersect(const float* mn, const float* mx, 
 
 struct Ray { f3 o, d; float t; bool alive; };
 
-// offset = ld_random_pixel_offset(snap ? 0 : spp), computed once per thread by the caller
-__device__ __forceinline__ Ray init_ray(const nrs_render_params& p, uint32_t x, uint32_t y, float off_x, float off_y) {
+// pixel_to_ray: origin and normalised direction of pixel (x, y).  offset = ld_random_pixel_offset(snap ? 0 : spp),
+// computed once per thread by the caller.
+__device__ __forceinline__ void ray_origin_dir(const nrs_render_params& p, uint32_t x, uint32_t y, float off_x, float off_y, f3& o, f3& d) {
 	const float W = (float)p.resolution[0], H = (float)p.resolution[1];
 	const uint32_t idx = x + (uint32_t)p.resolution[0] * y;
 	float u = ((float)x + 0.5f) * (1.f / W);
@@ -205,28 +208,46 @@ __device__ __forceinline__ Ray init_ray(const nrs_render_params& p, uint32_t x, 
 	float uvx = ((float)x + off_x) / W;
 	float uvy = ((float)y + off_y) / H;
 	f3 dir = {(uvx - p.screen_center[0]) * W / p.focal_length[0], (uvy - p.screen_center[1]) * H / p.focal_length[1], 1.0f};
-	f3 d = {(cam[0] * dir.x + cam[3] * dir.y) + cam[6] * dir.z,
-	        (cam[1] * dir.x + cam[4] * dir.y) + cam[7] * dir.z,
-	        (cam[2] * dir.x + cam[5] * dir.y) + cam[8] * dir.z};
-	f3 o = {cam[9], cam[10], cam[11]};
+	d = {(cam[0] * dir.x + cam[3] * dir.y) + cam[6] * dir.z,
+	     (cam[1] * dir.x + cam[4] * dir.y) + cam[7] * dir.z,
+	     (cam[2] * dir.x + cam[5] * dir.y) + cam[8] * dir.z};
+	o = {cam[9], cam[10], cam[11]};
 	float n = sqrtf(dot3(d, d));
 	d = {d.x / n, d.y / n, d.z / n};
-	float tmin;
-	ray_intersect(p.render_aabb_min, p.render_aabb_max, o, d, tmin);
-	float t = fmaxf(tmin, NRS_NEAR_DISTANCE) + 1e-6f;
+}
+
+__device__ __forceinline__ Ray init_ray(const nrs_render_params& p, uint32_t x, uint32_t y, float off_x, float off_y) {
 	Ray r;
-	r.o = o; r.d = d; r.t = t;
+	ray_origin_dir(p, x, y, off_x, off_y, r.o, r.d);
+	float tmin;
+	ray_intersect(p.render_aabb_min, p.render_aabb_max, r.o, r.d, tmin);
+	r.t = fmaxf(tmin, NRS_NEAR_DISTANCE) + 1e-6f;
 	Box3 bb;
 	#pragma unroll
 	for (int i = 0; i < 3; ++i) { bb.mn[i] = p.render_aabb_min[i]; bb.mx[i] = p.render_aabb_max[i]; }
-	r.alive = box_contains(bb, o + d * t);
+	r.alive = box_contains(bb, r.o + r.d * r.t);
 	return r;
+}
+
+// Does the ray o + d*s, s >= t, still meet the box?  (slab test; NaNs from 0 * inf drop out of fminf / fmaxf)
+__device__ __forceinline__ bool ray_meets_box_ahead(const Box3& b, f3 o, f3 idir, float t) {
+	const float ax = (b.mn[0] - o.x) * idir.x, bx = (b.mx[0] - o.x) * idir.x;
+	const float ay = (b.mn[1] - o.y) * idir.y, by = (b.mx[1] - o.y) * idir.y;
+	const float az = (b.mn[2] - o.z) * idir.z, bz = (b.mx[2] - o.z) * idir.z;
+	const float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), t));
+	const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+	return tnear <= tfar;
 }
 
 // The inner loop shared by advance_pos_nerf (tn:589-603) and generate_next_nerf_network_inputs (tn:668-692):
 // advance t until the ray sits in an occupied cell (returns true; pos/dt valid) or leaves the render box (false).
-__device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, const uint8_t* __restrict__ bitfield, f3 o, f3 d, f3 idir,
-                                                  float& t, f3& pos, float& dt) {
+//
+// occ_box bounds all occupied cells of all cascades (inflated).  Outside it every occupancy test of the reference is
+// false, so (i) the bitfield lookup is skipped -- the DDA recurrence that decides WHICH t values get tested is still
+// executed verbatim, so the first accepted t is bit-identical -- and (ii) once the remaining ray cannot meet the box any
+// more, no further sample can ever be emitted and the walk to the far side of the render box is cut short.
+__device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, const uint8_t* __restrict__ bitfield, const Box3& occ_box, f3 o, f3 d,
+                                                  f3 idir, float& t, f3& pos, float& dt) {
 	Box3 bb;
 	#pragma unroll
 	for (int i = 0; i < 3; ++i) { bb.mn[i] = p.render_aabb_min[i]; bb.mx[i] = p.render_aabb_max[i]; }
@@ -236,19 +257,23 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 		if (!box_contains(bb, pos)) return false;
 		dt = calc_dt(t, cone);
 		uint32_t mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
-		if (density_grid_occupied_at(pos, bitfield, mip)) return true;
+		if (box_contains(occ_box, pos)) {
+			if (density_grid_occupied_at(pos, bitfield, mip)) return true;
+		} else if (!ray_meets_box_ahead(occ_box, o, idir, t)) {
+			return false;
+		}
 		uint32_t res = kGrid >> mip;
 		t = advance_to_next_voxel(t, cone, pos, d, idir, res, ldexpf(1.0f, (int)mip - 7));
 	}
 }
 
 // advance_pos_nerf, tn:557-606: jitter by one Sobol value, then skip to the first occupied cell
-__device__ __forceinline__ bool first_hit(const nrs_render_params& p, const uint8_t* __restrict__ bitfield, uint32_t pixel_idx, Ray& r) {
+__device__ __forceinline__ bool first_hit(const nrs_render_params& p, const uint8_t* __restrict__ bitfield, const Box3& occ_box, uint32_t pixel_idx, Ray& r) {
 	f3 idir = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
 	float dt = calc_dt(r.t, p.cone_angle_constant);
 	r.t += ld_random_val(p.spp_index, pixel_idx * 786433u) * dt;
 	f3 pos;
-	return march_to_occupied(p, bitfield, r.o, r.d, idir, r.t, pos, dt);
+	return march_to_occupied(p, bitfield, occ_box, r.o, r.d, idir, r.t, pos, dt);
 }
 
 // ---- tet warp: selection_utils.h:10-47, cage_deformation.cu:136-269 -----------------------------------------------
@@ -399,9 +424,11 @@ __device__ __forceinline__ float network_to_density(float v, uint32_t act) {
 		default: return v;
 	}
 }
+// x^2.4 as exp2(2.4 * log2 x) on the transcendental unit (v_log_f32 / v_exp_f32, ~1 ulp each): |rel. error| < 1e-5 on
+// (0.04, 1], far inside the stated colour tolerance, and ~100 instructions cheaper per channel than powf.
 __device__ __forceinline__ float srgb_to_linear(float s) {
 	if (s <= 0.04045f) return s / 12.92f;
-	return powf((s + 0.055f) / 1.055f, 2.4f);
+	return __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf((s + 0.055f) / 1.055f));
 }
 
 } // namespace nrs

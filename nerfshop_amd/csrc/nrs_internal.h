@@ -40,6 +40,7 @@ struct DeviceModel {
 	const uint8_t*  bitfield;  // NRS_BITFIELD_BYTES
 	LevelParams     levels[kLevels];
 	Box3            aabb;      // train aabb (m_aabb)
+	Box3            occ_box;   // world-space bounds of every occupied cell of every cascade, slightly inflated (marching shortcut)
 	uint32_t        rgb_activation;
 	uint32_t        density_activation;
 };
@@ -71,6 +72,7 @@ struct RenderCounters {    // zeroed before every launch
 	uint32_t n_rays_alive;
 	uint32_t n_rays_hit;
 	uint32_t pad;
+	unsigned long long phase_cycles[8]; // NRS_DEBUG & 4: per-phase wave cycles (profiling build of the kernel only)
 };
 
 struct RenderArgs {
@@ -82,6 +84,7 @@ struct RenderArgs {
 	uint32_t tiles_x;          // image width in tiles (tiled mode) or in packets (whole-image mode)
 	uint32_t packets_per_tile_x;
 	uint32_t max_steps;
+	uint32_t dbg;              // NRS_DEBUG ablation bits (profiling only; 0 in production): 1 = all gathers hit entry 0, 2 = skip the MLPs
 	float*    frame;           // f32x4
 	float*    depth;
 	uint32_t* steps;           // nullable

@@ -64,7 +64,18 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 
 // WAVES = waves per workgroup (they share one LDS copy of the weights); OCC = waves per SIMD the register allocator must
 // leave room for (__launch_bounds__' second argument).
-template <int WAVES, int OCC>
+// PROF adds s_memtime stamps around the phases of a round (NRS_DEBUG & 4); the production instantiation has none.
+#define NRS_PHASE(i)                                                         \
+	do {                                                                     \
+		if (PROF) {                                                          \
+			const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+			ph_acc[ph_cur] += now_ - ph_last;                                \
+			ph_last = now_;                                                  \
+			ph_cur = (i);                                                    \
+		}                                                                    \
+	} while (0)
+
+template <int WAVES, int OCC, bool PROF>
 __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceModel m, const RenderArgs a) {
 	__shared__ RenderSmem<WAVES> sm;
 	stage_model_to_lds(m, sm.ml);
@@ -74,7 +85,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	const int g = lane >> 5;
 	uint4* ring = sm.ring[wave];
 	FeatLds& fl = sm.fl[wave];
-	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count);
+	const GridView gv = make_grid_view(m.grid, (a.dbg & 1u) ? 1u : m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count);
 	const nrs_render_params& p = a.p;
 	const bool ops = p.apply_operators && a.n_edits > 0;
 	const f3 cam_fwd = mk3(p.camera_matrix1[6], p.camera_matrix1[7], p.camera_matrix1[8]);
@@ -95,12 +106,17 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	bool more = true;
 	// ---- statistics ----
 	uint32_t st_samples = 0, st_alive = 0, st_hit = 0;
+	unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+	int ph_cur = 0;
 
 	for (;;) {
+		NRS_PHASE(0); // fill
 		const unsigned long long free_mask = __ballot(!have);
 		const uint32_t nfree = (uint32_t)__popcll(free_mask);
 
 		// ---- fill the ring with rays that found an occupied cell (init_rays + advance_pos_nerf) ----
+		// (Measured: moving this into its own lean kernel does not pay -- the DDA's dependent bitfield loads overlap with
+		// other waves' gather/MLP work here for free, while a separate launch adds ~1 ms of serial time at 1080p.)
 		while (more && ring_count < nfree) {
 			uint32_t pk = 0;
 			if (lane == 0) pk = atomicAdd(&a.counters->next_packet, 1u);
@@ -114,7 +130,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				a.depth[oi] = 1e10f; // tn:2586
 				if (a.steps) a.steps[oi] = 0;
 				alive = r.alive;
-				if (alive) alive = first_hit(p, m.bitfield, x + (uint32_t)p.resolution[0] * y, r);
+				if (alive) alive = first_hit(p, m.bitfield, m.occ_box, x + (uint32_t)p.resolution[0] * y, r);
 				t0 = r.t;
 			}
 			const unsigned long long am = __ballot(alive);
@@ -126,6 +142,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			ring_count += (uint32_t)__popcll(am);
 		}
 		__builtin_amdgcn_wave_barrier();
+		NRS_PHASE(1); // refill
 
 		// ---- hand pending rays to idle lanes ----
 		if (nfree && ring_count) {
@@ -134,8 +151,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			if (!have && rank < take) {
 				const uint4 e = ring[(ring_head + rank) & (kRing - 1)];
 				const uint32_t x = e.x & 0xffffu, y = e.x >> 16;
-				Ray r = init_ray(p, x, y, off_x, off_y); // same arithmetic as at enqueue time -> same bits
-				o = r.o; d = r.d;
+				ray_origin_dir(p, x, y, off_x, off_y, o, d); // same arithmetic as at enqueue time -> same bits
 				idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 				t = __uint_as_float(e.y);
 				out_idx = e.z;
@@ -153,6 +169,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			continue;
 		}
 
+		NRS_PHASE(2); // sample set-up + cage warp
 		// ---- one sample per live ray: generate_next_nerf_network_inputs body (tn:668-692) ----
 		const f3 pos = o + d * t;
 		const float dt = calc_dt(t, p.cone_angle_constant);
@@ -164,11 +181,13 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			for (int ei = a.n_edits - 1; ei >= 0; --ei) empty |= tet_warp(a.edits[ei], true, wpos, wdir);
 		}
 
+		NRS_PHASE(3); // gather
 		// ---- gather: own sample (block g) and the partner lane's sample (block 1-g), levels 2*it+g ----
 		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
 		const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
 		const bool phave = __shfl_xor((int)have, 32, 64) != 0;
 		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, have, ppos, phave);
+		NRS_PHASE(4); // SH + MLP
 		const half8 sh_own = encode_sh4(g, wdir), sh_par = encode_sh4(g, pdir);
 
 		// ---- fused MLPs on MFMA, one 32-sample block at a time ----
@@ -177,8 +196,11 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		for (int b = 0; b < 2; ++b) {
 			const int sel = (b != g) ? 1 : 0;
 			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
-			const half8 dout = density_mlp(sm.ml.w, lane, x0, x1);
-			const half8 rout = rgb_mlp(sm.ml.w, lane, dout, sel ? sh_par : sh_own);
+			half8 dout = x0, rout = x1;
+			if (!(a.dbg & 2u)) {
+				dout = density_mlp(sm.ml.w, lane, x0, x1);
+				rout = rgb_mlp(sm.ml.w, lane, dout, sel ? sh_par : sh_own);
+			}
 			const u32x4 dd = __builtin_bit_cast(u32x4, dout), rr = __builtin_bit_cast(u32x4, rout);
 			// rows 0..2 of a block sit in its lanes 0..31; block 1's samples belong to the rays of lanes 32..63
 			uint32_t vd = dd[0], vrg = rr[0], vb = rr[1];
@@ -189,6 +211,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		const float sigma_raw = (float)hd[0];
 		const float raw_r = (float)hrg[0], raw_g = (float)hrg[1], raw_b = (float)hb[0];
 
+		NRS_PHASE(5); // composite + march + shade
 		// ---- composite_kernel_nerf body (tn:750-955, Shade mode) + next-sample march ----
 		if (have) {
 			const f3 cpos = unwarp_position(wpos, m.aabb);
@@ -215,7 +238,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			} else {
 				t += dt;
 				f3 npos; float ndt;
-				done = !march_to_occupied(p, m.bitfield, o, d, idir, t, npos, ndt);
+				done = !march_to_occupied(p, m.bitfield, m.occ_box, o, d, idir, t, npos, ndt);
 			}
 			if (done) {
 				if (shade && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
@@ -239,22 +262,27 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		}
 	}
 
+	if (PROF) {
+		NRS_PHASE(7);
+		if (lane == 0)
+			for (int i = 0; i < 8; ++i) atomicAdd(&a.counters->phase_cycles[i], ph_acc[i]);
+	}
 	atomicAdd(&a.counters->n_samples, (unsigned long long)st_samples);
 	atomicAdd(&a.counters->n_rays_alive, st_alive);
 	atomicAdd(&a.counters->n_rays_hit, st_hit);
 }
 
-template <int WAVES, int OCC>
+template <int WAVES, int OCC, bool PROF = false>
 static int launch_render_cfg(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream) {
 	int blocks_per_cu = 0;
-	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC>, 64 * WAVES, 0);
+	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC, PROF>, 64 * WAVES, 0);
 	if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(render_kernel)");
 	if (blocks_per_cu < 1) blocks_per_cu = 1;
 	uint32_t grid = (uint32_t)(n_cus * blocks_per_cu);
 	const uint32_t max_useful = (a.n_packets + WAVES - 1) / WAVES; // at least one packet per wave
 	if (grid > max_useful) grid = max_useful;
 	if (grid == 0) return NRS_OK;
-	hipLaunchKernelGGL((render_kernel<WAVES, OCC>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
+	hipLaunchKernelGGL((render_kernel<WAVES, OCC, PROF>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
 	NRS_LAUNCH_CHECK("render_kernel launch");
 	return NRS_OK;
 }
@@ -267,6 +295,7 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 		return e ? atoi(e) : 0;
 	}();
 	hipStream_t s = (hipStream_t)stream;
+	if (a.dbg & 4u) return launch_render_cfg<8, 4, true>(m, a, n_cus, s);
 	switch (cfg) {
 		case 42: return launch_render_cfg<4, 2>(m, a, n_cus, s);
 		case 43: return launch_render_cfg<4, 3>(m, a, n_cus, s);
@@ -285,12 +314,12 @@ __global__ void trace_samples_kernel(const DeviceModel m, const nrs_render_param
 	const uint32_t idx = pixel_idx[k], W = (uint32_t)p.resolution[0];
 	Ray r = init_ray(p, idx % W, idx / W, off_x, off_y);
 	uint32_t cnt = 0;
-	if (r.alive && first_hit(p, m.bitfield, idx, r)) {
+	if (r.alive && first_hit(p, m.bitfield, m.occ_box, idx, r)) {
 		const f3 idir = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
 		float t = r.t;
 		while (cnt < max_samples) {
 			f3 pos; float dt;
-			if (!march_to_occupied(p, m.bitfield, r.o, r.d, idir, t, pos, dt)) break;
+			if (!march_to_occupied(p, m.bitfield, m.occ_box, r.o, r.d, idir, t, pos, dt)) break;
 			t_out[(size_t)k * max_samples + cnt] = t;
 			dt_out[(size_t)k * max_samples + cnt] = dt;
 			++cnt;
