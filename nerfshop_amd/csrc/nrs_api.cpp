@@ -434,10 +434,11 @@ int nrs_edit_map_positions(nrs_edit* e, void* stream, uint32_t n, float* d_pos, 
 static int tile_geometry(const nrs_render_params& p, uint32_t& tiles_x, uint32_t& owned, uint32_t& n_packets, uint32_t& ppt_x) {
 	const uint32_t W = (uint32_t)p.resolution[0], H = (uint32_t)p.resolution[1];
 	if (p.tile_size == 0) {
-		tiles_x = (W + 7) / 8;
+		const uint32_t side = 8 * kRunSide; // super-tiles of kPacketRun packets (Morton order inside), see packet_pixel()
+		tiles_x = (W + side - 1) / side;
 		owned = 1;
 		ppt_x = 0;
-		n_packets = tiles_x * ((H + 7) / 8);
+		n_packets = tiles_x * ((H + side - 1) / side) * kPacketRun;
 		return NRS_OK;
 	}
 	if (p.tile_size % 8) return fail(NRS_ERR_INVALID_ARG, "tile_size must be a multiple of 8");

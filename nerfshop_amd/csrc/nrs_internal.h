@@ -11,6 +11,10 @@ constexpr uint32_t kGrid = 128;                  // NERF_GRIDSIZE
 constexpr uint32_t kCascades = 5;                // NERF_CASCADES
 constexpr uint32_t kGridVol = kGrid * kGrid * kGrid;
 constexpr uint32_t kLevels = 16;
+// Packets (8x8 pixels) a wave claims from the frame's work queue at a time; in whole-image mode they form one
+// kRunSide x kRunSide block of packets (Morton order).  Larger runs = more coherent gathers but coarser load balance.
+constexpr uint32_t kPacketRun = 1;
+constexpr uint32_t kRunSide = 1;  // sqrt(kPacketRun)
 constexpr uint32_t kDensityW = 64 * 32 + 16 * 64;           // density MLP params (base.json:30-36)
 constexpr uint32_t kRgbW = 64 * 32 + 64 * 64 + 16 * 64;     // rgb MLP params (base.json:52-58)
 
@@ -81,7 +85,7 @@ struct RenderArgs {
 	int32_t  n_edits;
 	uint32_t any_poisson;      // some edit has apply_poisson set
 	uint32_t n_packets;        // 8x8 pixel packets owned by this call
-	uint32_t tiles_x;          // image width in tiles (tiled mode) or in packets (whole-image mode)
+	uint32_t tiles_x;          // image width in tiles (tiled mode) or in 32x32 super-tiles (whole-image mode)
 	uint32_t packets_per_tile_x;
 	uint32_t max_steps;
 	uint32_t dbg;              // NRS_DEBUG ablation bits (profiling only; 0 in production): 1 = all gathers hit entry 0, 2 = skip the MLPs

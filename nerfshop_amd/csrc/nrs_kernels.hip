@@ -44,7 +44,11 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 	const uint32_t W = (uint32_t)a.p.resolution[0], H = (uint32_t)a.p.resolution[1];
 	const uint32_t lx = lane & 7, ly = lane >> 3;
 	if (a.p.tile_size == 0) {
-		const uint32_t bx = pk % a.tiles_x, by = pk / a.tiles_x;
+		// whole image: super-tiles of kPacketRun packets in Morton order, so that the run of packets a wave claims (and with
+		// it the rays it marches together) stays spatially compact -> fewer distinct cache lines per gather
+		const uint32_t tile = pk / kPacketRun, sub = pk % kPacketRun;
+		const uint32_t bx = (tile % a.tiles_x) * kRunSide + ((sub & 1u) | ((sub >> 1) & 2u));
+		const uint32_t by = (tile / a.tiles_x) * kRunSide + (((sub >> 1) & 1u) | ((sub >> 2) & 2u));
 		x = bx * 8 + lx;
 		y = by * 8 + ly;
 		out_idx = x + W * y;
@@ -103,6 +107,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	uint32_t out_idx = 0, n_steps = 0;
 	// ---- wave-uniform queue state ----
 	uint32_t ring_head = 0, ring_count = 0;
+	uint32_t run_next = 0, run_left = 0;
 	bool more = true;
 	// ---- statistics ----
 	uint32_t st_samples = 0, st_alive = 0, st_hit = 0;
@@ -118,10 +123,16 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		// (Measured: moving this into its own lean kernel does not pay -- the DDA's dependent bitfield loads overlap with
 		// other waves' gather/MLP work here for free, while a separate launch adds ~1 ms of serial time at 1080p.)
 		while (more && ring_count < nfree) {
-			uint32_t pk = 0;
-			if (lane == 0) pk = atomicAdd(&a.counters->next_packet, 1u);
-			pk = __builtin_amdgcn_readfirstlane(pk);
+			if (run_left == 0) { // claim a run of kPacketRun neighbouring packets
+				uint32_t base = 0;
+				if (lane == 0) base = atomicAdd(&a.counters->next_packet, kPacketRun);
+				run_next = __builtin_amdgcn_readfirstlane(base);
+				run_left = kPacketRun;
+			}
+			const uint32_t pk = run_next;
 			if (pk >= a.n_packets) { more = false; break; }
+			++run_next;
+			--run_left;
 			uint32_t x, y, oi;
 			bool alive = false;
 			float t0 = 0.f;
