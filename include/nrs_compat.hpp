@@ -1,0 +1,159 @@
+// nrs_compat.hpp -- header-only C++ adaptor over the C-ABI of nrs.h that gives the render path the SHAPE of the reference's
+// own C++ interfaces, so call sites in src/testbed.cu / src/testbed_nerf.cu map 1:1:
+//
+//   ngp::NerfNetwork<T>        include/neural-graphics-primitives/nerf_network.h:86        -> nrs::compat::NerfNetwork
+//   ngp::CageDeformation       include/neural-graphics-primitives/editing/edit_operator.h  -> nrs::compat::CageDeformation
+//   ngp::CudaRenderBuffer      include/neural-graphics-primitives/render_buffer.h:164      -> nrs::compat::RenderBuffer (view)
+//   ngp::Testbed::render_nerf  src/testbed_nerf.cu:3066                                    -> nrs::compat::Testbed::render_nerf
+//
+// No Eigen / tiny-cuda-nn types: matrices are column-major float arrays (what Eigen::Matrix<float,3,4>::data() yields),
+// streams are passed as void* (hipStream_t), errors become std::runtime_error (the reference throws from CUDA_CHECK_THROW).
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "nrs.h"
+
+namespace nrs {
+namespace compat {
+
+inline void check(int status, const char* what) {
+	if (status != NRS_OK) throw std::runtime_error(std::string(what) + ": " + nrs_last_error());
+}
+
+class Context {
+public:
+	explicit Context(int device = 0) { check(nrs_ctx_create(device, &m_ctx), "nrs_ctx_create"); }
+	~Context() { nrs_ctx_destroy(m_ctx); }
+	Context(const Context&) = delete;
+	Context& operator=(const Context&) = delete;
+	nrs_ctx* get() const { return m_ctx; }
+
+private:
+	nrs_ctx* m_ctx = nullptr;
+};
+
+// Non-owning matrix views with tcnn's meaning: GPUMatrixDynamic<float> (column-major, m rows = floats per sample) and
+// GPUMatrixDynamic<T> with a selectable layout for the fp16 output.
+struct InputMatrix {
+	const float* data;  // device
+	uint32_t rows;      // floats per sample (7 for inference, 3..7 for density)
+	uint32_t n;         // samples (columns)
+};
+struct OutputMatrix {
+	void* data;         // device, fp16
+	uint32_t rows;      // 16
+	uint32_t n;         // columns allocated (n_el >= samples for the planes layout)
+	nrs_layout layout;  // NRS_PLANES = tcnn RM (row-major 16 x n), NRS_INTERLEAVED = tcnn CM
+};
+
+class NerfNetwork {
+public:
+	NerfNetwork(Context& ctx, const nrs_model_desc& desc) : m_desc(desc) { check(nrs_model_create(ctx.get(), &desc, &m_model), "nrs_model_create"); }
+	~NerfNetwork() { nrs_model_destroy(m_model); }
+	NerfNetwork(const NerfNetwork&) = delete;
+	NerfNetwork& operator=(const NerfNetwork&) = delete;
+
+	// tcnn::Network interface subset used on the path (nerf_network.h:97-120)
+	uint32_t padded_output_width() const { return NRS_NETWORK_OUTPUT_WIDTH; }
+	uint32_t input_width() const { return NRS_NETWORK_INPUT_FLOATS; }
+	uint32_t n_extra_dims() const { return 0; }
+	size_t n_params() const { return nrs_model_n_params(&m_desc); }
+
+	// set_params(params, inference_params, ...) of the reference takes device pointers into the trainer's blob; here the fp16
+	// blob (density MLP | rgb MLP | hash grid, nerf_network_full.h:316-349) is handed over from the host once.
+	void set_params(const void* h_params_fp16, size_t n) { check(nrs_model_set_params(m_model, h_params_fp16, n), "nrs_model_set_params"); }
+
+	void inference_mixed_precision(void* stream, const InputMatrix& input, OutputMatrix& output, bool /*use_inference_params*/ = true) {
+		if (input.rows != NRS_NETWORK_INPUT_FLOATS) throw std::runtime_error("NerfNetwork::inference_mixed_precision: input must have 7 rows");
+		check(nrs_network_inference(m_model, stream, input.n, input.data, output.data, output.n, output.layout), "nrs_network_inference");
+	}
+	void density(void* stream, const InputMatrix& input, OutputMatrix& output, bool /*use_inference_params*/ = true) {
+		check(nrs_network_density(m_model, stream, input.n, input.data, input.rows, output.data, output.n, output.layout), "nrs_network_density");
+	}
+
+	// Testbed::m_nerf.density_grid_bitfield / update_density_grid_mean_and_bitfield
+	void set_density_bitfield(const uint8_t* h_bits, size_t n) { check(nrs_model_set_density_bitfield(m_model, h_bits, n), "nrs_model_set_density_bitfield"); }
+	void set_density_grid(const float* h_grid, size_t n) { check(nrs_model_set_density_grid(m_model, h_grid, n), "nrs_model_set_density_grid"); }
+
+	nrs_model* get() const { return m_model; }
+	const nrs_model_desc& desc() const { return m_desc; }
+
+private:
+	nrs_model_desc m_desc;
+	nrs_model* m_model = nullptr;
+};
+
+// EditOperator subset on the render path (edit_operator.h:43-91)
+class CageDeformation {
+public:
+	CageDeformation(Context& ctx, const nrs_model_desc& desc, const nrs_tet_mesh& mesh) { check(nrs_edit_create(ctx.get(), &desc, &mesh, &m_edit), "nrs_edit_create"); }
+	~CageDeformation() { nrs_edit_destroy(m_edit); }
+	CageDeformation(const CageDeformation&) = delete;
+	CageDeformation& operator=(const CageDeformation&) = delete;
+
+	void map_rays(void* stream, float* d_nerf_coords /*[n x 7]*/, uint8_t* d_empty_mask, uint32_t n_elements) const {
+		check(nrs_edit_map_rays(m_edit, stream, n_elements, d_nerf_coords, d_empty_mask), "nrs_edit_map_rays");
+	}
+	void map_positions(void* stream, float* d_nerf_pos, uint32_t stride_floats, uint8_t* d_empty_mask, uint32_t n_elements) const {
+		check(nrs_edit_map_positions(m_edit, stream, n_elements, d_nerf_pos, stride_floats, d_empty_mask), "nrs_edit_map_positions");
+	}
+	nrs_edit* get() const { return m_edit; }
+
+private:
+	nrs_edit* m_edit = nullptr;
+};
+
+// View over the caller's frame / depth device arrays (CudaRenderBuffer::frame_buffer() / depth_buffer() / spp()).
+struct RenderBuffer {
+	float* frame_buffer;   // float4 [H*W], premultiplied linear RGBA; the caller clears it (clear_frame, testbed.cu:2635)
+	float* depth_buffer;   // float [H*W]
+	int width, height;     // in_resolution()
+	uint32_t spp;          // sample index of this frame
+};
+
+// The slice of ngp::Testbed that render_nerf reads (SURVEY 8b "implicit inputs"), with the reference's member names.
+class Testbed {
+public:
+	struct Nerf {
+		float cone_angle_constant = 0.f;            // 0 for aabb_scale 1, 1/256 otherwise (testbed_nerf.cu:3410-3425)
+		float rendering_min_transmittance = 0.01f;
+		bool training_linear_colors = false;
+	} m_nerf;
+	float m_render_aabb_min[3] = {0, 0, 0}, m_render_aabb_max[3] = {1, 1, 1};
+	bool m_snap_to_pixel_centers = true;
+	bool m_enable_edits = true;
+	nrs_render_mode m_render_mode = NRS_RENDER_SHADE;
+	std::vector<const CageDeformation*> m_edit_operators; // NerfTracer::m_edit_operators, applied last-to-first
+
+	// void Testbed::render_nerf(NerfNetwork<precision_t>&, CudaRenderBuffer&, const Vector2i& max_res, const Vector2f& focal_length,
+	//     const Matrix<float,3,4>& camera_matrix0, const Matrix<float,3,4>& camera_matrix1, const Vector4f& rolling_shutter,
+	//     const Vector2f& screen_center, bool apply_operators, cudaStream_t stream)              -- testbed.h:305
+	void render_nerf(NerfNetwork& network, RenderBuffer& render_buffer, const int /*max_res*/[2], const float focal_length[2],
+	                 const float camera_matrix0[12], const float camera_matrix1[12], const float rolling_shutter[4], const float screen_center[2],
+	                 bool apply_operators, void* stream, nrs_render_stats* stats = nullptr) {
+		nrs_render_params p{};
+		p.resolution[0] = render_buffer.width;
+		p.resolution[1] = render_buffer.height;
+		for (int i = 0; i < 2; ++i) { p.focal_length[i] = focal_length[i]; p.screen_center[i] = screen_center[i]; }
+		for (int i = 0; i < 12; ++i) { p.camera_matrix0[i] = camera_matrix0[i]; p.camera_matrix1[i] = camera_matrix1[i]; }
+		for (int i = 0; i < 4; ++i) p.rolling_shutter[i] = rolling_shutter[i];
+		for (int i = 0; i < 3; ++i) { p.render_aabb_min[i] = m_render_aabb_min[i]; p.render_aabb_max[i] = m_render_aabb_max[i]; }
+		p.spp_index = render_buffer.spp;
+		p.snap_to_pixel_centers = m_snap_to_pixel_centers;
+		p.min_transmittance = m_nerf.rendering_min_transmittance;
+		p.cone_angle_constant = m_nerf.cone_angle_constant;
+		p.render_mode = m_render_mode;
+		p.linear_colors = m_nerf.training_linear_colors;
+		p.apply_operators = apply_operators && m_enable_edits;
+		std::vector<nrs_edit*> edits;
+		for (const CageDeformation* op : m_edit_operators) edits.push_back(op->get());
+		check(nrs_render_nerf(network.get(), &p, edits.data(), (int)edits.size(), render_buffer.frame_buffer, render_buffer.depth_buffer, nullptr, stream,
+		                      stats),
+		      "nrs_render_nerf");
+	}
+};
+
+} // namespace compat
+} // namespace nrs
