@@ -488,7 +488,6 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		}
 		HIP_TRY(hipMemcpyAsync(ctx->d_edits, host_edits, sizeof(DeviceEdit) * n_edits, hipMemcpyHostToDevice, s));
 	}
-	if (a.any_poisson) return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: membrane (Poisson) correction is not implemented in this build");
 	a.edits = ctx->d_edits;
 	a.max_steps = p->max_march_steps ? p->max_march_steps : 10000u; // MARCH_ITER, testbed_nerf.cu:56
 	{

@@ -354,57 +354,65 @@ __device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3&
 	return empty;
 }
 
-// compute_residual_poisson_kernel body (cage_deformation.cu:467-507): barycentric interpolation of the per-vertex
-// membrane terms at a sample position in DEFORMED space.  Outputs are left untouched when no tet contains it.
-__device__ __forceinline__ void poisson_residual(const DeviceEdit& e, f3 wpos, float sh[27], float& out_density, float& res_density) {
-	f3 pos = unwarp_position(wpos, e.aabb);
+// Membrane ("Poisson") correction inputs of one sample: compute_residual_poisson_kernel's body (cage_deformation.cu:467-507)
+// fused with the evaluate_sh9 (cn:218-245) that composite_kernel_nerf applies to its result (tn:800-805).  wpos0 is the
+// sample position BEFORE map_rays (residuals live in deformed space), dir the un-warped view direction AFTER map_rays.
+// The barycentric interpolation of the 27 SH9RGB coefficients and the dot product with the SH basis are evaluated in the
+// reference's order, coefficient by coefficient, so no 27-float array is kept.  Outputs untouched when no tet contains it.
+__device__ __forceinline__ void poisson_residual_rgb(const DeviceEdit& e, f3 wpos0, f3 dir, float rgb[3], float& out_density, float& res_density) {
+	const f3 pos = unwarp_position(wpos0, e.aabb);
 	if (!box_contains(e.bbox, pos)) return;
-	int level = mip_from_pos(pos);
-	uint32_t cell = (uint32_t)level * kGridVol + cascaded_grid_idx_at(pos, (uint32_t)level);
-	uint32_t j0 = e.lut_off[cell], j1 = e.lut_off[cell + 1];
+	const int level = mip_from_pos(pos);
+	const uint32_t cell = (uint32_t)level * kGridVol + cascaded_grid_idx_at(pos, (uint32_t)level);
+	const uint32_t j0 = e.lut_off[cell], j1 = e.lut_off[cell + 1];
+	uint32_t found = 0xffffffffu;
+	#pragma unroll 1
 	for (uint32_t j = j0; j < j1; ++j) {
-		uint32_t t = e.lut_idx[j];
-		uint4 tv = reinterpret_cast<const uint4*>(e.tets)[t];
-		f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), d = ld3(e.verts, tv.w);
-		if (point_in_tet(a, b, c, d, pos)) {
-			float bc[4];
-			bary_tet(a, b, c, d, pos, bc);
-			#pragma unroll
-			for (int k = 0; k < 27; ++k)
-				sh[k] = ((bc[0] * e.shs[27 * (size_t)tv.x + k] + bc[1] * e.shs[27 * (size_t)tv.y + k]) + bc[2] * e.shs[27 * (size_t)tv.z + k]) +
-				        bc[3] * e.shs[27 * (size_t)tv.w + k];
-			float lo = ((bc[0] * e.out_density[tv.x] + bc[1] * e.out_density[tv.y]) + bc[2] * e.out_density[tv.z]) + bc[3] * e.out_density[tv.w];
-			float lr = ((bc[0] * e.res_density[tv.x] + bc[1] * e.res_density[tv.y]) + bc[2] * e.res_density[tv.z]) + bc[3] * e.res_density[tv.w];
-			out_density = e.residual_amplitude * lo;
-			res_density = e.residual_amplitude * lr;
-			return;
-		}
+		const uint32_t t = e.lut_idx[j];
+		const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[t];
+		const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), dd = ld3(e.verts, tv.w);
+		if (point_in_tet(a, b, c, dd, pos)) { found = t; break; }
 	}
-}
-
-// evaluate_sh9, cn:218-245 (SH9RGB = 9x3 column-major)
-__device__ __forceinline__ void evaluate_sh9(const float sh[27], f3 dir, float rgb[3]) {
-	float fZ2 = dir.z * dir.z;
+	if (found == 0xffffffffu) return;
+	const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[found];
+	float bc[4];
+	{
+		const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), dd = ld3(e.verts, tv.w);
+		bary_tet(a, b, c, dd, pos, bc);
+	}
+	// SH basis, cn:222-240
+	const float fZ2 = dir.z * dir.z;
 	float pSH[9];
 	pSH[0] = 0.2820947917738781f;
 	pSH[2] = 0.4886025119029199f * dir.z;
 	pSH[6] = 0.9461746957575601f * fZ2 + -0.3153915652525201f;
-	float fC0 = dir.x, fS0 = dir.y;
-	float fTmpA = -0.48860251190292f;
+	const float fC0 = dir.x, fS0 = dir.y;
+	const float fTmpA = -0.48860251190292f;
 	pSH[3] = fTmpA * fC0; pSH[1] = fTmpA * fS0;
-	float fTmpB = -1.092548430592079f * dir.z;
+	const float fTmpB = -1.092548430592079f * dir.z;
 	pSH[7] = fTmpB * fC0; pSH[5] = fTmpB * fS0;
-	float fC1 = dir.x * fC0 - dir.y * fS0;
-	float fS1 = dir.x * fS0 + dir.y * fC0;
-	float fTmpC = 0.5462742152960395f;
+	const float fC1 = dir.x * fC0 - dir.y * fS0;
+	const float fS1 = dir.x * fS0 + dir.y * fC0;
+	const float fTmpC = 0.5462742152960395f;
 	pSH[8] = fTmpC * fC1; pSH[4] = fTmpC * fS1;
+	const float* s0 = e.shs + 27 * (size_t)tv.x;
+	const float* s1 = e.shs + 27 * (size_t)tv.y;
+	const float* s2 = e.shs + 27 * (size_t)tv.z;
+	const float* s3 = e.shs + 27 * (size_t)tv.w;
 	#pragma unroll
 	for (int c = 0; c < 3; ++c) {
 		float s = 0.f;
 		#pragma unroll
-		for (int k = 0; k < 9; ++k) s += pSH[k] * sh[9 * c + k];
+		for (int k = 0; k < 9; ++k) {
+			const float sh = ((bc[0] * s0[9 * c + k] + bc[1] * s1[9 * c + k]) + bc[2] * s2[9 * c + k]) + bc[3] * s3[9 * c + k];
+			s += pSH[k] * sh;
+		}
 		rgb[c] = s;
 	}
+	const float lo = ((bc[0] * e.out_density[tv.x] + bc[1] * e.out_density[tv.y]) + bc[2] * e.out_density[tv.z]) + bc[3] * e.out_density[tv.w];
+	const float lr = ((bc[0] * e.res_density[tv.x] + bc[1] * e.res_density[tv.y]) + bc[2] * e.res_density[tv.z]) + bc[3] * e.res_density[tv.w];
+	out_density = e.residual_amplitude * lo;
+	res_density = e.residual_amplitude * lr;
 }
 
 // ---- activations (cn:38-66) and shade (common_device.cuh:31-37) ---------------------------------------------------

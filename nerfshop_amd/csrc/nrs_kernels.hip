@@ -79,7 +79,9 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 		}                                                                    \
 	} while (0)
 
-template <int WAVES, int OCC, bool PROF>
+// POISSON compiles in the membrane correction (off by default in the reference): a separate instantiation, so
+// the common path pays neither its registers nor its code.
+template <int WAVES, int OCC, bool PROF, bool POISSON>
 __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceModel m, const RenderArgs a) {
 	__shared__ RenderSmem<WAVES> sm;
 	stage_model_to_lds(m, sm.ml);
@@ -188,8 +190,35 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		f3 wdir = warp_direction(d);
 		const float wdt = warp_dt(dt);
 		bool empty = false;
+		const f3 wpos0 = wpos; // un-deformed sample position (membrane terms live in deformed space)
 		if (ops && have) { // map_rays, last-to-first (tn:2899-2902)
 			for (int ei = a.n_edits - 1; ei >= 0; --ei) empty |= tet_warp(a.edits[ei], true, wpos, wdir);
+		}
+		// ---- membrane correction inputs (compute_poisson_full_residuals, tn:2867-2883) + first network pass (tn:2890-2892) ----
+		float p_rgb[3] = {0.f, 0.f, 0.f}, p_out = 0.f, p_res = 0.f, sigma_old_raw = 0.f;
+		bool has_res = false;
+		if (POISSON) {
+			if (ops && have) {
+				const f3 udir = unwarp_direction(wdir);
+				for (int ei = a.n_edits - 1; ei >= 0; --ei)
+					if (a.edits[ei].apply_poisson) poisson_residual_rgb(a.edits[ei], wpos0, udir, p_rgb, p_out, p_res);
+			}
+			has_res = have && p_out > 1e-9f;
+			if (__any(has_res)) { // the reference evaluates the un-deformed network everywhere; only these samples consume it (tn:770-773)
+				const f3 ppos0 = mk3(xchg32(wpos0.x), xchg32(wpos0.y), xchg32(wpos0.z));
+				const bool phas = __shfl_xor((int)has_res, 32, 64) != 0;
+				encode_to_lds(gv, sm.ml, fl, lane, g, wpos0, has_res, ppos0, phas);
+				uint32_t old_d = 0;
+				#pragma unroll 1
+				for (int b = 0; b < 2; ++b) {
+					const int sel = (b != g) ? 1 : 0;
+					const half8 dout = density_mlp(sm.ml.w, lane, load_features(fl, lane, sel, 0), load_features(fl, lane, sel, 1));
+					uint32_t vd = __builtin_bit_cast(u32x4, dout)[0];
+					if (b == 1) vd = xchg32u(vd);
+					if (g == b) old_d = vd;
+				}
+				sigma_old_raw = (float)__builtin_bit_cast(half2v, old_d)[0];
+			}
 		}
 
 		NRS_PHASE(3); // gather
@@ -228,11 +257,28 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			const f3 cpos = unwarp_position(wpos, m.aabb);
 			const float T = 1.f - ca;
 			const float cdt = unwarp_dt(wdt);
-			float alpha = empty ? 0.0f : 1.f - __expf(-network_to_density(sigma_raw, m.density_activation) * cdt);
+			const float sigma = network_to_density(sigma_raw, m.density_activation);
+			float alpha = 1.f - __expf(-sigma * cdt);
+			if (POISSON && has_res) { // tn:770-780
+				const float targetval = network_to_density(sigma_old_raw, m.density_activation);
+				const float val = p.poisson_target ? fminf(fmaxf(targetval, sigma), sigma + p_res) : sigma + p_res;
+				alpha = 1.f - __expf(-(val) * cdt);
+			}
+			if (empty) alpha = 0.0f;
 			const float weight = alpha * T;
-			cr += network_to_rgb(raw_r, m.rgb_activation) * weight;
-			cg += network_to_rgb(raw_g, m.rgb_activation) * weight;
-			cb += network_to_rgb(raw_b, m.rgb_activation) * weight;
+			const float sr = network_to_rgb(raw_r, m.rgb_activation), sg = network_to_rgb(raw_g, m.rgb_activation), sb = network_to_rgb(raw_b, m.rgb_activation);
+			if (POISSON && has_res) { // tn:796-805, 939-943
+				const float alpha_N = 1.f - __expf(-sigma * cdt);
+				const float alpha_R = 1.f - __expf(-p_out * cdt);
+				const float w_N = alpha_N / (alpha_N + alpha_R), w_R = alpha_R / (alpha_N + alpha_R);
+				cr += weight * (w_N * sr + w_R * p_rgb[0]);
+				cg += weight * (w_N * sg + w_R * p_rgb[1]);
+				cb += weight * (w_N * sb + w_R * p_rgb[2]);
+			} else {
+				cr += sr * weight;
+				cg += sg * weight;
+				cb += sb * weight;
+			}
 			ca += weight;
 			if (weight > max_weight) {
 				max_weight = weight;
@@ -283,17 +329,17 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	atomicAdd(&a.counters->n_rays_hit, st_hit);
 }
 
-template <int WAVES, int OCC, bool PROF = false>
+template <int WAVES, int OCC, bool PROF = false, bool POISSON = false>
 static int launch_render_cfg(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream) {
 	int blocks_per_cu = 0;
-	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC, PROF>, 64 * WAVES, 0);
+	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC, PROF, POISSON>, 64 * WAVES, 0);
 	if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(render_kernel)");
 	if (blocks_per_cu < 1) blocks_per_cu = 1;
 	uint32_t grid = (uint32_t)(n_cus * blocks_per_cu);
 	const uint32_t max_useful = (a.n_packets + WAVES - 1) / WAVES; // at least one packet per wave
 	if (grid > max_useful) grid = max_useful;
 	if (grid == 0) return NRS_OK;
-	hipLaunchKernelGGL((render_kernel<WAVES, OCC, PROF>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
+	hipLaunchKernelGGL((render_kernel<WAVES, OCC, PROF, POISSON>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
 	NRS_LAUNCH_CHECK("render_kernel launch");
 	return NRS_OK;
 }
@@ -306,6 +352,7 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 		return e ? atoi(e) : 0;
 	}();
 	hipStream_t s = (hipStream_t)stream;
+	if (a.any_poisson) return launch_render_cfg<8, 2, false, true>(m, a, n_cus, s);
 	if (a.dbg & 4u) return launch_render_cfg<8, 4, true>(m, a, n_cus, s);
 	switch (cfg) {
 		case 42: return launch_render_cfg<4, 2>(m, a, n_cus, s);

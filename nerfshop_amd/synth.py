@@ -355,9 +355,35 @@ class CageEdit:
         m.h_original_bitfield = self.original_bitfield.ctypes.data
         m.h_local_rotations = self.local_rotations.ctypes.data if self.local_rotations is not None else None
         m.copy = 1 if self.copy else 0
-        m.apply_poisson = 0
-        m.residual_amplitude = 1.0
+        shs = getattr(self, "boundary_shs", None)
+        if shs is not None:  # membrane ("Poisson") correction, cage_deformation.h:163
+            m.apply_poisson = 1
+            m.residual_amplitude = float(getattr(self, "residual_amplitude", 1.0))
+            m.h_boundary_shs = self.boundary_shs.ctypes.data
+            m.h_boundary_outside_density = self.boundary_outside_density.ctypes.data
+            m.h_boundary_residual_density = self.boundary_residual_density.ctypes.data
+        else:
+            m.apply_poisson = 0
+            m.residual_amplitude = 1.0
         return m
+
+    def with_membrane(self, seed=7, residual_amplitude=1.0):
+        """A copy of this edit with synthetic per-vertex membrane terms (what GrowingSelection::interpolate_poisson_boundary
+        leaves on the tet mesh, growing_selection.cu:2350): SH9RGB boundary colour, outside density, residual density.
+        A third of the vertices get zero outside density so that both branches of composite_kernel_nerf are exercised."""
+        import copy as _copy
+        e = _copy.copy(self)
+        rng = np.random.default_rng(seed)
+        V = self.vertices.shape[0]
+        shs = rng.normal(0.0, 0.15, size=(V, 27)).astype(np.float32)
+        shs[:, 0::9] += np.float32(0.5 / 0.2820947917738781)  # DC term: mid-grey
+        dens = rng.uniform(5.0, 60.0, size=V).astype(np.float32)
+        dens[self.original_vertices[:, 0] < np.quantile(self.original_vertices[:, 0], 0.33)] = 0.0
+        e.boundary_shs = np.ascontiguousarray(shs)
+        e.boundary_outside_density = np.ascontiguousarray(dens)
+        e.boundary_residual_density = np.ascontiguousarray(rng.uniform(-10.0, 40.0, size=V).astype(np.float32))
+        e.residual_amplitude = residual_amplitude
+        return e
 
 
 def build_tet_lut(vertices, tets, n_threads=0):

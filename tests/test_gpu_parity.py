@@ -174,6 +174,34 @@ def test_render_with_cage_edit(rig):
         rig.use_edit(False)
 
 
+@pytest.mark.parametrize("poisson_target", [0, 1])
+def test_render_with_membrane_correction(rig, poisson_target):
+    """compute_poisson_full_residuals + the Poisson branches of composite_kernel_nerf (second, un-deformed network
+    pass only where density_out_boundary > 1e-9)."""
+    from nerfshop_amd import runtime
+    from oracle import oracle as orc
+    scene = rig.scene
+    edit = scene.edit.with_membrane(residual_amplitude=0.8)
+    op = runtime.CageDeformation(rig.ctx, scene.desc, edit)
+    o_edit = orc.Edit(scene.desc, edit.tet_mesh_struct(), keepalive=edit)
+    rig.use_edit(True)
+    saved = rig.testbed.edit_operators
+    try:
+        rig.testbed.edit_operators = [op]
+        p = scene.params_for(256, 144, 60.0)
+        p.poisson_target = poisson_target
+        frame, depth, steps, stats = rig.render(p)
+        ref_frame, ref_depth, ref_steps, ref_stats = scene.oracle_model.render(p, [o_edit])
+        _compare_frames(frame, depth, steps, ref_frame, ref_depth, ref_steps)
+        # the correction must be visible: compare with the same edit without membrane terms
+        rig.testbed.edit_operators = saved
+        plain, _, _, _ = rig.render(p)
+        assert np.abs(plain - frame).max() > 0.02
+    finally:
+        rig.testbed.edit_operators = saved
+        rig.use_edit(False)
+
+
 def test_render_empty_and_degenerate(rig):
     """A camera looking away from the box: nothing alive, frame untouched, depth 1e10 everywhere."""
     rig.use_edit(False)
