@@ -266,6 +266,13 @@ int nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out) 
 	m->desc = *desc;
 	m->total_entries = make_levels(*desc, m->dm.levels);
 	for (int k = 0; k < 3; ++k) { m->dm.aabb.mn[k] = desc->aabb_min[k]; m->dm.aabb.mx[k] = desc->aabb_max[k]; }
+	m->dm.diag_pow2 = 1;
+	for (int k = 0; k < 3; ++k) {
+		const float diag = desc->aabb_max[k] - desc->aabb_min[k];
+		int e = 0;
+		if (std::frexp(diag, &e) != 0.5f) m->dm.diag_pow2 = 0;
+		m->dm.inv_diag[k] = 1.0f / diag;
+	}
 	m->dm.rgb_activation = desc->rgb_activation;
 	m->dm.density_activation = desc->density_activation;
 	HIP_TRY(hipMalloc((void**)&m->d_grid, (size_t)m->total_entries * 4));
@@ -510,10 +517,11 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		if (a.dbg & 4u) {
 			static const char* names[8] = {"fill", "refill", "setup+warp", "gather", "sh+mlp", "composite+march+shade", "-", "exit"};
 			unsigned long long tot = 0;
-			for (int i = 0; i < 8; ++i) tot += c.phase_cycles[i];
+			for (int i = 0; i < 8; ++i) if (i != 6) tot += c.phase_cycles[i];
 			fprintf(stderr, "[nrs phases] samples=%llu", (unsigned long long)c.n_samples);
 			for (int i = 0; i < 8; ++i)
-				if (c.phase_cycles[i]) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)c.phase_cycles[i] / (double)tot);
+				if (c.phase_cycles[i] && i != 6) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)c.phase_cycles[i] / (double)tot);
+			fprintf(stderr, " | mean wave lifetime = %.1f%% of the longest (%.2f Mcycles)", 100.0 * ((double)tot / 4096.0) / (double)c.phase_cycles[6], (double)c.phase_cycles[6] / 1e6);
 			fprintf(stderr, "\n");
 		}
 	}

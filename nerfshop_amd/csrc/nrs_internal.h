@@ -44,6 +44,8 @@ struct DeviceModel {
 	const uint8_t*  bitfield;  // NRS_BITFIELD_BYTES
 	LevelParams     levels[kLevels];
 	Box3            aabb;      // train aabb (m_aabb)
+	float           inv_diag[3]; // 1 / (aabb.max - aabb.min), exact when diag_pow2
+	uint32_t        diag_pow2; // every aabb extent is a power of two (always so for NGP scene boxes): x / d == x * (1/d) bit for bit
 	Box3            occ_box;   // world-space bounds of every occupied cell of every cascade, slightly inflated (marching shortcut)
 	uint32_t        rgb_activation;
 	uint32_t        density_activation;

@@ -84,14 +84,14 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 template <int WAVES, int OCC, bool PROF, bool POISSON>
 __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceModel m, const RenderArgs a) {
 	__shared__ RenderSmem<WAVES> sm;
-	stage_model_to_lds(m, sm.ml);
+	stage_model_to_lds(m, sm.ml, a.dbg);
 
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int g = lane >> 5;
 	uint4* ring = sm.ring[wave];
 	FeatLds& fl = sm.fl[wave];
-	const GridView gv = make_grid_view(m.grid, (a.dbg & 1u) ? 1u : m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count);
+	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count);
 	const nrs_render_params& p = a.p;
 	const bool ops = p.apply_operators && a.n_edits > 0;
 	const f3 cam_fwd = mk3(p.camera_matrix1[6], p.camera_matrix1[7], p.camera_matrix1[8]);
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		// ---- one sample per live ray: generate_next_nerf_network_inputs body (tn:668-692) ----
 		const f3 pos = o + d * t;
 		const float dt = calc_dt(t, p.cone_angle_constant);
-		f3 wpos = warp_position(pos, m.aabb);
+		f3 wpos = m.diag_pow2 ? mk3((pos.x - m.aabb.mn[0]) * m.inv_diag[0], (pos.y - m.aabb.mn[1]) * m.inv_diag[1], (pos.z - m.aabb.mn[2]) * m.inv_diag[2])
+		                      : warp_position(pos, m.aabb);
 		f3 wdir = warp_direction(d);
 		const float wdt = warp_dt(dt);
 		bool empty = false;
@@ -321,8 +322,11 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 
 	if (PROF) {
 		NRS_PHASE(7);
-		if (lane == 0)
-			for (int i = 0; i < 8; ++i) atomicAdd(&a.counters->phase_cycles[i], ph_acc[i]);
+		if (lane == 0) {
+			unsigned long long life = 0;
+			for (int i = 0; i < 8; ++i) { life += ph_acc[i]; if (i != 6) atomicAdd(&a.counters->phase_cycles[i], ph_acc[i]); }
+			atomicMax(&a.counters->phase_cycles[6], life); // longest-lived wave
+		}
 	}
 	atomicAdd(&a.counters->n_samples, (unsigned long long)st_samples);
 	atomicAdd(&a.counters->n_rays_alive, st_alive);

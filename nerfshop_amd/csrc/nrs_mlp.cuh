@@ -49,13 +49,17 @@ struct ModelLds {
 // Per-wave feature slab: feat[it][sel][lane], sel 0 = the lane's own sample, 1 = its partner's (lane ^ 32) sample.
 struct FeatLds { uint32_t feat[8][2][64]; };
 
-__device__ __forceinline__ void stage_model_to_lds(const DeviceModel& m, ModelLds& s) {
+__device__ __forceinline__ void stage_model_to_lds(const DeviceModel& m, ModelLds& s, uint32_t dbg = 0) {
 	const uint4* src = reinterpret_cast<const uint4*>(m.wfrag);
 	uint4* dst = reinterpret_cast<uint4*>(s.w);
 	for (uint32_t i = threadIdx.x; i < kWfragBytes / 16; i += blockDim.x) dst[i] = src[i];
-	if (threadIdx.x < kLevels) s.levels[threadIdx.x] = m.levels[threadIdx.x];
+	if (threadIdx.x < kLevels) {
+		LevelParams lp = m.levels[threadIdx.x];
+		if (dbg & 1u) { lp.hashed = 1; lp.mask = 31; lp.offset = 0; lp.count = 32; } // profiling: every gather of a wave hits one 128-byte line
+		s.levels[threadIdx.x] = lp;
+	}
 	if (threadIdx.x < 8) {
-		const uint32_t h0 = m.levels[2 * threadIdx.x].hashed, h1 = m.levels[2 * threadIdx.x + 1].hashed;
+		const uint32_t h0 = (dbg & 1u) ? 1u : m.levels[2 * threadIdx.x].hashed, h1 = (dbg & 1u) ? 1u : m.levels[2 * threadIdx.x + 1].hashed;
 		s.kinds[threadIdx.x] = (h0 && h1) ? KIND_HASHED : ((!h0 && !h1) ? KIND_DENSE : KIND_MIXED);
 	}
 	__syncthreads();
@@ -70,6 +74,21 @@ __device__ __forceinline__ GridView make_grid_view(const uint32_t* grid, uint32_
 }
 __device__ __forceinline__ uint32_t grid_load(const GridView& v, uint32_t entry) {
 	return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(v.rsrc, (int)(entry * 4u), 0, 0);
+}
+__device__ __forceinline__ uint32_t grid_load_bytes(const GridView& v, uint32_t byte_offset) {
+	return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(v.rsrc, (int)byte_offset, 0, 0);
+}
+// acc + w * half(lo/hi 16 bits of a table entry): v_fma_mix_f32 converts the fp16 operand on the fly (exactly) and fuses the
+// multiply-add with one rounding, i.e. fmaf(w, (float)h, acc) without the separate v_cvt_f32_f16.
+__device__ __forceinline__ float fma_mix_lo(float w, uint32_t entry, float acc) {
+	float r;
+	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(entry), "v"(acc));
+	return r;
+}
+__device__ __forceinline__ float fma_mix_hi(float w, uint32_t entry, float acc) {
+	float r;
+	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(entry), "v"(acc));
+	return r;
 }
 
 // Exact tcnn index for any position (also far outside [0,1]^3): the rarely taken out-of-line path.
@@ -93,60 +112,107 @@ __device__ __forceinline__ void level_eval_slow(const GridView gv, const LevelPa
 	*out1 = acc1;
 }
 
-// One level of one sample: 8 gathers + trilinear interpolation -> two fp16 features packed in a dword.
-template <int KIND>
-__device__ __forceinline__ uint32_t level_eval(const GridView& gv, const LevelParams& lp, f3 pos, bool active) {
-	float acc0 = 0.f, acc1 = 0.f;
-	if (active) {
-		const float px = fmaf(lp.scale, pos.x, 0.5f), py = fmaf(lp.scale, pos.y, 0.5f), pz = fmaf(lp.scale, pos.z, 0.5f);
-		const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
-		const uint32_t gx = (uint32_t)(int)fx, gy = (uint32_t)(int)fy, gz = (uint32_t)(int)fz;
-		const float wx = px - fx, wy = py - fy, wz = pz - fz;
-		// dense indices stay below 2*count only while every corner coordinate is <= resolution
-		const bool need_slow = (KIND != KIND_HASHED) && !lp.hashed && (gx >= lp.resolution || gy >= lp.resolution || gz >= lp.resolution);
-		if (__builtin_expect(need_slow, 0)) {
-			level_eval_slow(gv, lp, gx, gy, gz, wx, wy, wz, &acc0, &acc1);
-		} else {
-			uint32_t idx[8];
-			if (KIND == KIND_HASHED) {
-				const uint32_t hx0 = gx, hx1 = gx + 1u, hy0 = gy * 2654435761u, hy1 = hy0 + 2654435761u, hz0 = gz * 805459861u, hz1 = hz0 + 805459861u;
-				#pragma unroll
-				for (int c = 0; c < 8; ++c) idx[c] = (((c & 1) ? hx1 : hx0) ^ ((c & 2) ? hy1 : hy0) ^ ((c & 4) ? hz1 : hz0)) & lp.mask;
-			} else if (KIND == KIND_DENSE) {
-				const uint32_t base = gx + gy * lp.resolution + gz * lp.res2;
-				#pragma unroll
-				for (int c = 0; c < 8; ++c) {
-					const uint32_t i = base + ((c & 1) ? 1u : 0u) + ((c & 2) ? lp.resolution : 0u) + ((c & 4) ? lp.res2 : 0u);
-					idx[c] = i >= lp.count ? i - lp.count : i;
-				}
-			} else {
-				const uint32_t hx0 = gx, hx1 = gx + 1u, hy0 = gy * 2654435761u, hy1 = hy0 + 2654435761u, hz0 = gz * 805459861u, hz1 = hz0 + 805459861u;
-				const uint32_t base = gx + gy * lp.resolution + gz * lp.res2;
-				#pragma unroll
-				for (int c = 0; c < 8; ++c) {
-					const uint32_t h = (((c & 1) ? hx1 : hx0) ^ ((c & 2) ? hy1 : hy0) ^ ((c & 4) ? hz1 : hz0)) & lp.mask;
-					const uint32_t i = base + ((c & 1) ? 1u : 0u) + ((c & 2) ? lp.resolution : 0u) + ((c & 4) ? lp.res2 : 0u);
-					idx[c] = lp.hashed ? h : (i >= lp.count ? i - lp.count : i);
-				}
-			}
-			uint32_t vals[8];
-			#pragma unroll
-			for (int c = 0; c < 8; ++c) vals[c] = grid_load(gv, lp.offset + idx[c]);
-			const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
-			const float wxy[4] = {ux * uy, wx * uy, ux * wy, wx * wy}; // (wx' * wy') * wz', as the oracle multiplies
-			#pragma unroll
-			for (int c = 0; c < 8; ++c) {
-				const float weight = wxy[c & 3] * ((c & 4) ? wz : uz);
-				const half2v hv = __builtin_bit_cast(half2v, vals[c]);
-				acc0 = fmaf(weight, (float)hv[0], acc0);
-				acc1 = fmaf(weight, (float)hv[1], acc1);
-			}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 grid_load2_bytes(const GridView& v, uint32_t byte_offset) {
+	return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(v.rsrc, (int)byte_offset, 0, 0));
+}
+
+// Grid cell + interpolation weights of one sample at one level.
+struct CellCoords { uint32_t gx, gy, gz; float wx, wy, wz; };
+__device__ __forceinline__ CellCoords cell_coords(const LevelParams& lp, f3 pos) {
+	CellCoords c;
+	const float px = fmaf(lp.scale, pos.x, 0.5f), py = fmaf(lp.scale, pos.y, 0.5f), pz = fmaf(lp.scale, pos.z, 0.5f);
+	const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+	c.gx = (uint32_t)(int)fx; c.gy = (uint32_t)(int)fy; c.gz = (uint32_t)(int)fz;
+	c.wx = px - fx; c.wy = py - fy; c.wz = pz - fz;
+	return c;
+}
+// dense fast path precondition: no index of the cell reaches `count`, so no wrap and x-neighbours are adjacent entries
+__device__ __forceinline__ bool dense_needs_slow(const LevelParams& lp, const CellCoords& c) {
+	return c.gx >= lp.resolution || c.gy >= lp.resolution || c.gz >= lp.resolution ||
+	       c.gx + c.gy * lp.resolution + c.gz * lp.res2 + 1u + lp.resolution + lp.res2 >= lp.count;
+}
+// Issue the gathers of one sample at one level: v[2q + bx] = entry of corner (bx, q&1, q>>1).
+// Dense levels fetch the two x-neighbours with ONE 8-byte load (entry(x+1) = entry(x) + 1; MUBUF needs dword alignment only).
+template <bool HASHED>
+__device__ __forceinline__ void issue_gathers(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t v[8]) {
+	const uint32_t off4 = lp.offset * 4u;
+	if (HASHED) {
+		const uint32_t hx0 = c.gx, hx1 = c.gx + 1u, hy0 = c.gy * 2654435761u, hy1 = hy0 + 2654435761u, hz0 = c.gz * 805459861u, hz1 = hz0 + 805459861u;
+		#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const uint32_t e = (((k & 1) ? hx1 : hx0) ^ ((k & 2) ? hy1 : hy0) ^ ((k & 4) ? hz1 : hz0)) & lp.mask;
+			v[k] = grid_load_bytes(gv, (e << 2) + off4);
 		}
+	} else {
+		const uint32_t base = c.gx + c.gy * lp.resolution + c.gz * lp.res2;
+		#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const uint32_t i = base + ((q & 1) ? lp.resolution : 0u) + ((q & 2) ? lp.res2 : 0u);
+			const u32x2 pr = grid_load2_bytes(gv, (i << 2) + off4);
+			v[2 * q] = pr[0];
+			v[2 * q + 1] = pr[1];
+		}
+	}
+}
+// Trilinear interpolation in the oracle's order (corner 0..7, x fastest; weight = (wx' * wy') * wz') -> packed fp16 pair.
+__device__ __forceinline__ uint32_t interpolate(const CellCoords& c, const uint32_t v[8]) {
+	const float ux = 1.0f - c.wx, uy = 1.0f - c.wy, uz = 1.0f - c.wz;
+	const float wxy[4] = {ux * uy, c.wx * uy, ux * c.wy, c.wx * c.wy};
+	float acc0 = 0.f, acc1 = 0.f;
+	#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const float weight = wxy[k & 3] * ((k & 4) ? c.wz : uz);
+		acc0 = fma_mix_lo(weight, v[k], acc0);
+		acc1 = fma_mix_hi(weight, v[k], acc1);
 	}
 	half2v r;
 	r[0] = (_Float16)acc0;
 	r[1] = (_Float16)acc1;
 	return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t level_eval_exact(const GridView& gv, const LevelParams& lp, const CellCoords& c) {
+	float a0, a1;
+	level_eval_slow(gv, lp, c.gx, c.gy, c.gz, c.wx, c.wy, c.wz, &a0, &a1);
+	half2v r;
+	r[0] = (_Float16)a0;
+	r[1] = (_Float16)a1;
+	return __builtin_bit_cast(uint32_t, r);
+}
+
+// One level of TWO samples (the lane's own, A, and its partner's, B).  All gathers of both samples are issued before the
+// first is consumed: a round is a chain of dependent memory round trips, and when few waves are left on a CU (the end of a
+// frame) its latency, not its throughput, sets the frame time.  Idle lanes gather for position 0 (one shared cache line)
+// so that the code stays branch-free; their result is zeroed.
+template <int KIND>
+__device__ __forceinline__ void level_eval_pair(const GridView& gv, const LevelParams& lp, f3 posA, bool actA, f3 posB, bool actB, uint32_t& fa, uint32_t& fb) {
+	const f3 zero = mk3(0.f, 0.f, 0.f);
+	const CellCoords ca = cell_coords(lp, actA ? posA : zero), cb = cell_coords(lp, actB ? posB : zero);
+	const bool lane_hashed = (KIND == KIND_HASHED) || (KIND == KIND_MIXED && lp.hashed);
+	const bool slowA = !lane_hashed && dense_needs_slow(lp, ca), slowB = !lane_hashed && dense_needs_slow(lp, cb);
+	if (KIND != KIND_HASHED && __builtin_expect(__any(slowA || slowB), 0)) { // exact tcnn wrap for samples outside [0,1)^3: rare
+		fa = level_eval_exact(gv, lp, ca);
+		fb = level_eval_exact(gv, lp, cb);
+	} else {
+		uint32_t va[8], vb[8];
+		if (KIND == KIND_HASHED) {
+			issue_gathers<true>(gv, lp, ca, va);
+			issue_gathers<true>(gv, lp, cb, vb);
+		} else if (KIND == KIND_DENSE) {
+			issue_gathers<false>(gv, lp, ca, va);
+			issue_gathers<false>(gv, lp, cb, vb);
+		} else if (lane_hashed) { // mixed pair: the two lane halves are of different kinds
+			issue_gathers<true>(gv, lp, ca, va);
+			issue_gathers<true>(gv, lp, cb, vb);
+		} else {
+			issue_gathers<false>(gv, lp, ca, va);
+			issue_gathers<false>(gv, lp, cb, vb);
+		}
+		fa = interpolate(ca, va);
+		fb = interpolate(cb, vb);
+	}
+	if (!actA) fa = 0u;
+	if (!actB) fb = 0u;
 }
 
 // All 8 level pairs of two positions (own sample A, partner's sample B) -> the wave's feature slab.
@@ -156,16 +222,9 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const ModelLds
 		const LevelParams lp = ml.levels[2 * it + g];
 		const uint32_t kind = __builtin_amdgcn_readfirstlane(ml.kinds[it]);
 		uint32_t fa, fb;
-		if (kind == KIND_HASHED) {
-			fa = level_eval<KIND_HASHED>(gv, lp, posA, actA);
-			fb = level_eval<KIND_HASHED>(gv, lp, posB, actB);
-		} else if (kind == KIND_DENSE) {
-			fa = level_eval<KIND_DENSE>(gv, lp, posA, actA);
-			fb = level_eval<KIND_DENSE>(gv, lp, posB, actB);
-		} else {
-			fa = level_eval<KIND_MIXED>(gv, lp, posA, actA);
-			fb = level_eval<KIND_MIXED>(gv, lp, posB, actB);
-		}
+		if (kind == KIND_HASHED) level_eval_pair<KIND_HASHED>(gv, lp, posA, actA, posB, actB, fa, fb);
+		else if (kind == KIND_DENSE) level_eval_pair<KIND_DENSE>(gv, lp, posA, actA, posB, actB, fa, fb);
+		else level_eval_pair<KIND_MIXED>(gv, lp, posA, actA, posB, actB, fa, fb);
 		fl.feat[it][0][lane] = fa;
 		fl.feat[it][1][lane] = fb;
 	}
