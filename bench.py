@@ -63,9 +63,9 @@ def camera_for(step, synth, aabb_scale):
     return synth.orbit_camera(45.0 * (step % 8) + 30.0, 30.0, scale=scale)
 
 
-def cpu_baseline(scene, synth, width, height, n_frames=1):
+def cpu_baseline(scene, synth, width, height, n_frames=8):
     """The oracle (our CPU restatement; the reference has no CPU path and cannot be built here) on a bounded sample:
-    the same first frame at 1/16 of the pixels (480x270), all host cores."""
+    the bench's 8 views at 1/16 of the pixels (480x270), all host cores (~10-20 s of CPU work)."""
     from oracle import oracle as orc
     desc, params = scene["desc"], scene["params"]
     bitfield = scene["tb"].nerf_network.get_density_bitfield()
@@ -83,8 +83,21 @@ def cpu_baseline(scene, synth, width, height, n_frames=1):
         t_total += time.perf_counter() - t0
         total += st.composited
     return {"value": round(total / t_total / 1e6, 4), "unit": "Msamples/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n_frames} frame(s) of the same workload at {w}x{h} (1/16 of the pixels), {total} samples, {t_total:.1f} s",
+            "sample": f"the {n_frames} bench views of the same workload at {w}x{h} (1/16 of the pixels each), {total} samples, {t_total:.1f} s",
             "fps_equiv_1080p": round(1.0 / (t_total / n_frames * 16.0), 4)}
+
+
+def measured_traffic(workload):
+    """HBM bytes per render_kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
+    MI355X_MICROARCH.md prescribes).  PMC counters cannot be sampled from inside this process, so the number comes from
+    profiles/r01_traffic.json (same workload, same kernel); null for the other workloads."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if workload != "lego_cage" or not os.path.exists(path):
+        return None
+    try:
+        return int(json.load(open(path))["traffic_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def main():
@@ -225,7 +238,7 @@ def main():
                        "resolution": [W, H], "samples_per_frame": int(total_samples / args.steps),
                        "sharding": f"{TILE}x{TILE} image tiles round-robin over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 3),
+                         "traffic": measured_traffic(args.workload) if world == 1 else None, "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 3),
                          "algorithmic_bytes_per_launch": int(per_launch_samples * BYTES_PER_SAMPLE),
                          "mfma_tflops": round(per_launch_samples * FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12, 2)},
         }
