@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -44,6 +45,7 @@ struct nrs_ctx {
 	RenderCounters* d_counters = nullptr;
 	DeviceEdit* d_edits = nullptr; // scratch array for render calls
 	float* d_mean = nullptr;
+	unsigned long long* d_wave_log = nullptr; // profiling only (NRS_DEBUG & 4)
 	static constexpr int kMaxEdits = 32;
 };
 
@@ -216,6 +218,7 @@ int nrs_ctx_create(int device, nrs_ctx** out) {
 	HIP_TRY(hipMalloc((void**)&c->d_counters, sizeof(RenderCounters)));
 	HIP_TRY(hipMalloc((void**)&c->d_edits, sizeof(DeviceEdit) * nrs_ctx::kMaxEdits));
 	HIP_TRY(hipMalloc((void**)&c->d_mean, 16));
+	HIP_TRY(hipMalloc((void**)&c->d_wave_log, 8192 * 4 * 8));
 	*out = c;
 	return NRS_OK;
 }
@@ -224,6 +227,7 @@ void nrs_ctx_destroy(nrs_ctx* c) {
 	(void)hipFree(c->d_counters);
 	(void)hipFree(c->d_edits);
 	(void)hipFree(c->d_mean);
+	(void)hipFree(c->d_wave_log);
 	delete c;
 }
 int nrs_ctx_device_info(const nrs_ctx* c, char* name_out, size_t name_len, int* n_cus, size_t* hbm_bytes) {
@@ -505,6 +509,8 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	a.depth = d_depth;
 	a.steps = d_steps;
 	a.counters = ctx->d_counters;
+	a.wave_log = (a.dbg & 4u) ? ctx->d_wave_log : nullptr;
+	if (a.wave_log) HIP_TRY(hipMemsetAsync(ctx->d_wave_log, 0, 8192 * 4 * 8, s));
 	HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(RenderCounters), s));
 	NRS_TRY(launch_render(m->dm, a, ctx->n_cus, s));
 	if (h_stats) {
@@ -523,6 +529,31 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 				if (c.phase_cycles[i] && i != 6) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)c.phase_cycles[i] / (double)tot);
 			fprintf(stderr, " | mean wave lifetime = %.1f%% of the longest (%.2f Mcycles)", 100.0 * ((double)tot / 4096.0) / (double)c.phase_cycles[6], (double)c.phase_cycles[6] / 1e6);
 			fprintf(stderr, "\n");
+			// per-wave log: when did each wave finish (wall clock), when did it first find the frame's queue empty
+			std::vector<unsigned long long> wl(8192 * 4);
+			HIP_TRY(hipMemcpy(wl.data(), ctx->d_wave_log, wl.size() * 8, hipMemcpyDeviceToHost));
+			std::vector<std::array<unsigned long long, 4>> rec; // {end tick (10 ns), rounds | rounds before queue-empty << 16 | t_queue_empty << 32, packets, xcc}
+			unsigned long long t0min = ~0ull;
+			for (size_t i = 0; i < 8192; ++i) if (wl[4 * i]) t0min = std::min(t0min, wl[4 * i + 3] >> 32);
+			for (size_t i = 0; i < 8192; ++i)
+				if (wl[4 * i]) {
+					const unsigned long long wall = wl[4 * i + 3] & 0xffffffffull, start = (wl[4 * i + 3] >> 32) - t0min;
+					const unsigned long long rq = (wl[4 * i + 1] >> 16) & 0xffff, tq = (wl[4 * i + 1] >> 32) + start;
+					rec.push_back({wall + start, (wl[4 * i + 1] & 0xffffull) | (rq << 16) | (tq << 32), wl[4 * i + 2] & 0xffffffffull, wl[4 * i + 2] >> 56});
+				}
+			std::sort(rec.begin(), rec.end());
+			if (!rec.empty()) {
+				auto pr = [&](const char* tag, size_t i) {
+					fprintf(stderr, "   %s: end=%.1f us, queue found empty at %.1f us, rounds=%llu (%llu after that), packets=%llu, xcc=%llu\n", tag, rec[i][0] / 100.0,
+					        (rec[i][1] >> 32) / 100.0, rec[i][1] & 0xffff, (rec[i][1] & 0xffff) - ((rec[i][1] >> 16) & 0xffff), rec[i][2], rec[i][3]);
+				};
+				double mean = 0;
+				for (auto& r : rec) mean += (double)r[0];
+				mean /= rec.size();
+				fprintf(stderr, "[nrs waves] n=%zu, mean end = %.1f%% of the last end\n", rec.size(), 100.0 * mean / (double)rec.back()[0]);
+				pr("min", 0); pr("p25", rec.size() / 4); pr("p50", rec.size() / 2); pr("p75", rec.size() * 3 / 4); pr("p95", rec.size() * 95 / 100);
+				pr("p99", rec.size() * 99 / 100); pr("max", rec.size() - 1);
+			}
 		}
 	}
 	return NRS_OK;

@@ -95,6 +95,7 @@ struct RenderArgs {
 	float*    depth;
 	uint32_t* steps;           // nullable
 	RenderCounters* counters;
+	unsigned long long* wave_log; // NRS_DEBUG & 4: 4 words per wave (see nrs_render_nerf)
 };
 
 // kernel launchers (nrs_kernels.hip).  stream is a hipStream_t.

@@ -114,6 +114,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	// ---- statistics ----
 	uint32_t st_samples = 0, st_alive = 0, st_hit = 0;
 	unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+	unsigned long long pf_rounds = 0, pf_packets = 0, pf_tq = 0, pf_rounds_q = 0;
+	const unsigned long long pf_wall0 = PROF ? wall_clock64() : 0ull; // 100 MHz, identical on every XCD (s_memtime is the per-XCD shader clock)
 	int ph_cur = 0;
 
 	for (;;) {
@@ -132,7 +134,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				run_left = kPacketRun;
 			}
 			const uint32_t pk = run_next;
-			if (pk >= a.n_packets) { more = false; break; }
+			if (pk >= a.n_packets) { more = false; if (PROF) { pf_tq = wall_clock64() - pf_wall0; pf_rounds_q = pf_rounds; } break; }
+			if (PROF) ++pf_packets;
 			++run_next;
 			--run_left;
 			uint32_t x, y, oi;
@@ -183,6 +186,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		}
 
 		NRS_PHASE(2); // sample set-up + cage warp
+		if (PROF) ++pf_rounds;
 		// ---- one sample per live ray: generate_next_nerf_network_inputs body (tn:668-692) ----
 		const f3 pos = o + d * t;
 		const float dt = calc_dt(t, p.cone_angle_constant);
@@ -326,6 +330,15 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			unsigned long long life = 0;
 			for (int i = 0; i < 8; ++i) { life += ph_acc[i]; if (i != 6) atomicAdd(&a.counters->phase_cycles[i], ph_acc[i]); }
 			atomicMax(&a.counters->phase_cycles[6], life); // longest-lived wave
+			if (a.wave_log) {
+				unsigned int xcc = 0;
+				asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+				unsigned long long* w = a.wave_log + 4 * (size_t)(blockIdx.x * WAVES + wave);
+				w[0] = life;
+				w[1] = pf_rounds | (pf_rounds_q << 16) | (pf_tq << 32);
+				w[2] = pf_packets | ((unsigned long long)(xcc & 0xf) << 56);
+				w[3] = (wall_clock64() - pf_wall0) | ((pf_wall0 & 0xffffffffull) << 32);
+			}
 		}
 	}
 	atomicAdd(&a.counters->n_samples, (unsigned long long)st_samples);
