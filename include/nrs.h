@@ -18,6 +18,7 @@
  *   nrs_edit_create / nrs_edit_update_vertices <- TetMesh GPU members + upload     tet_mesh.h:80-94, tet_mesh.cu:651-667
  *   nrs_edit_map_rays        <- EditOperator::map_rays      edit_operator.h:43, CageDeformation::map_rays  cage_deformation.cu:547
  *   nrs_edit_map_positions   <- EditOperator::map_positions edit_operator.h:51, cage_deformation.cu:624
+ *   nrs_model_update_density_grid <- Testbed::update_density_grid_nerf_operator       src/testbed_nerf.cu:3533   ("next" row f2)
  *   nrs_tet_lut_build        <- TetMesh::build_tet_grid / build_original_tet_grid  tet_mesh.cu:368 / :76   (host, "next" row f1)
  *   nrs_mvc_compute / nrs_mvc_apply <- Cage::compute_mvc / interpolate_with_mvc    cage.cu:6 / :38          (host, "next" row f1)
  *   nrs_tet_local_rotations  <- TetMesh::update_local_rotations                    tet_mesh.cu:37           (host, "next" row f1)
@@ -150,6 +151,20 @@ typedef struct nrs_render_stats {
 	uint32_t n_rays_hit;     /* rays shaded into the frame buffer (alpha > 0.001), = trace()'s n_hit */
 } nrs_render_stats;
 
+/* State update_density_grid_nerf_operator reads and advances on Testbed (src/testbed_nerf.cu:3533-3640), handed over
+ * explicitly.  One call = one iteration of update_density_grid_nerf_render's loop (:3514-3520), which passes
+ * n_uniform = 128^3 * (max_cascade + 1), n_nonuniform = 0 and reset_grid on its first iteration. */
+typedef struct nrs_grid_update {
+	uint32_t n_uniform_samples;    /* cells drawn with threshold -0.01 (every trained cell)            :3565 */
+	uint32_t n_nonuniform_samples; /* cells drawn with threshold NERF_MIN_OPTICAL_THICKNESS (occupied)  :3578 */
+	uint32_t reset_grid;           /* zero the float grid first                                         :3558 */
+	uint32_t max_cascade;          /* m_nerf.max_cascade: cascades 0..max_cascade are sampled                 */
+	float    decay;                /* m_nerf.training.density_grid_decay, 0.95 (testbed.h:604)                */
+	uint32_t ema_step;             /* IN/OUT m_nerf.density_grid_ema_step (incremented by the call)     :3636 */
+	uint64_t rng_state;            /* IN/OUT m_rng (tcnn::pcg32) state; advanced by 2 * 2^32            :3577,3590 */
+	uint64_t rng_inc;              /* m_rng stream constant                                                   */
+} nrs_grid_update;
+
 typedef struct nrs_ctx   nrs_ctx;
 typedef struct nrs_model nrs_model;
 typedef struct nrs_edit  nrs_edit;
@@ -178,6 +193,18 @@ int    nrs_model_set_density_bitfield(nrs_model* model, const uint8_t* h_bitfiel
  * exactly as update_density_grid_mean_and_bitfield does (testbed_nerf.cu:514-555, 3642-3657). */
 int    nrs_model_set_density_grid(nrs_model* model, const float* h_grid, size_t n_floats);
 int    nrs_model_get_density_bitfield(nrs_model* model, uint8_t* h_bitfield_out, size_t n_bytes);
+/* The float grid the bitfield was last derived from ([5*128^3]; zeros if only a bitfield was ever set). */
+int    nrs_model_get_density_grid(nrs_model* model, float* h_grid_out, size_t n_floats);
+/* Deformed-space occupancy refresh ("next" row f2): Testbed::update_density_grid_nerf_operator, testbed_nerf.cu:3533.
+ * Draws grid-cell samples (generate_grid_samples_nerf_nonuniform, common_nerf.cu:179), maps them through the edit
+ * operators last-to-first (map_positions, cage_deformation.cu:624), evaluates density(), empties masked samples
+ * (clear_empty_space :2759), activates, adds the membrane residual (compute_poisson_residual_density,
+ * cage_deformation.cu:645), max-splats per cell (:447), decays (ema_grid_samples_nerf :483) and rebuilds mean,
+ * bitfield and mips (:3642) -- all on the device, one fused kernel for everything up to the splat.
+ * Synchronous (the reference syncs m_inference_stream at :3519); updates *u. */
+int    nrs_model_update_density_grid(nrs_model* model, nrs_edit* const* edits, int n_edits, nrs_grid_update* u, void* stream);
+/* tcnn::pcg32(seed) -- Testbed seeds m_rng = default_rng_t{m_seed = 1337} (src/testbed.cu:2220). host-only */
+void   nrs_rng_seed(uint64_t seed, uint64_t* state_out, uint64_t* inc_out);
 
 /* ---- NerfNetwork operator -------------------------------------------------------------------------- */
 /* d_in: [n x 7] f32 (column-major 7 x n in tcnn terms).  d_out: fp16, n_el = n_padded samples wide:

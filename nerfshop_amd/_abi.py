@@ -90,13 +90,26 @@ class RenderStats(C.Structure):
     _fields_ = [("n_samples", C.c_uint64), ("n_rays_alive", C.c_uint32), ("n_rays_hit", C.c_uint32)]
 
 
+class GridUpdate(C.Structure):
+    _fields_ = [
+        ("n_uniform_samples", C.c_uint32),
+        ("n_nonuniform_samples", C.c_uint32),
+        ("reset_grid", C.c_uint32),
+        ("max_cascade", C.c_uint32),
+        ("decay", C.c_float),
+        ("ema_step", C.c_uint32),
+        ("rng_state", C.c_uint64),
+        ("rng_inc", C.c_uint64),
+    ]
+
+
 # every symbol include/nrs.h declares; tests check the library exports exactly these
 EXPORTS = [
     "nrs_last_error", "nrs_abi_version",
     "nrs_ctx_create", "nrs_ctx_destroy", "nrs_ctx_device_info",
     "nrs_model_create", "nrs_model_destroy", "nrs_model_n_params", "nrs_model_level_table",
     "nrs_model_set_params", "nrs_model_set_density_bitfield", "nrs_model_set_density_grid",
-    "nrs_model_get_density_bitfield",
+    "nrs_model_get_density_bitfield", "nrs_model_get_density_grid", "nrs_model_update_density_grid", "nrs_rng_seed",
     "nrs_network_inference", "nrs_network_density", "nrs_hashgrid_encode",
     "nrs_edit_create", "nrs_edit_destroy", "nrs_edit_map_rays", "nrs_edit_map_positions",
     "nrs_render_nerf", "nrs_render_owned_tiles", "nrs_detile", "nrs_trace_samples",
@@ -143,6 +156,10 @@ def load():
     lib.nrs_model_set_density_bitfield.argtypes = [P, P, C.c_size_t]
     lib.nrs_model_set_density_grid.argtypes = [P, P, C.c_size_t]
     lib.nrs_model_get_density_bitfield.argtypes = [P, P, C.c_size_t]
+    lib.nrs_model_get_density_grid.argtypes = [P, P, C.c_size_t]
+    lib.nrs_model_update_density_grid.argtypes = [P, C.POINTER(P), I, C.POINTER(GridUpdate), P]
+    lib.nrs_rng_seed.argtypes = [C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.nrs_rng_seed.restype = None
     lib.nrs_network_inference.argtypes = [P, P, U32, P, P, U32, I]
     lib.nrs_network_density.argtypes = [P, P, U32, P, U32, P, U32, I]
     lib.nrs_hashgrid_encode.argtypes = [P, P, U32, P, U32, P]

@@ -57,6 +57,8 @@ struct nrs_model {
 	uint32_t* d_grid = nullptr;
 	uint16_t* d_wfrag = nullptr;
 	uint8_t* d_bitfield = nullptr;
+	float* d_density_grid = nullptr;   // m_nerf.density_grid [5*128^3], kept for the occupancy refresh
+	uint32_t* d_density_tmp = nullptr; // density_grid_tmp (float bits), allocated on first refresh
 	bool have_params = false, have_bitfield = false;
 };
 
@@ -282,6 +284,8 @@ int nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out) 
 	HIP_TRY(hipMalloc((void**)&m->d_grid, (size_t)m->total_entries * 4));
 	HIP_TRY(hipMalloc((void**)&m->d_wfrag, kWfragBytes));
 	HIP_TRY(hipMalloc((void**)&m->d_bitfield, NRS_BITFIELD_BYTES));
+	HIP_TRY(hipMalloc((void**)&m->d_density_grid, (size_t)kGridVol * kCascades * 4));
+	HIP_TRY(hipMemset(m->d_density_grid, 0, (size_t)kGridVol * kCascades * 4));
 	m->dm.grid = m->d_grid;
 	m->dm.wfrag = m->d_wfrag;
 	m->dm.bitfield = m->d_bitfield;
@@ -293,6 +297,8 @@ void nrs_model_destroy(nrs_model* m) {
 	(void)hipFree(m->d_grid);
 	(void)hipFree(m->d_wfrag);
 	(void)hipFree(m->d_bitfield);
+	(void)hipFree(m->d_density_grid);
+	(void)hipFree(m->d_density_tmp);
 	delete m;
 }
 int nrs_model_set_params(nrs_model* m, const void* h_params_fp16, size_t n_params) {
@@ -321,27 +327,83 @@ int nrs_model_set_density_bitfield(nrs_model* m, const uint8_t* h_bitfield, size
 	m->have_bitfield = true;
 	return NRS_OK;
 }
+// bitfield + mips from m->d_density_grid, then the marching shortcut's bounds (host pass over 1.3 MB; synchronises)
+static int refresh_bitfield(nrs_model* m, void* stream) {
+	hipStream_t s = (hipStream_t)stream;
+	HIP_TRY(hipMemsetAsync(m->d_bitfield, 0, NRS_BITFIELD_BYTES, s));
+	NRS_TRY(launch_grid_to_bitfield(m->d_density_grid, m->d_bitfield, m->ctx->d_mean, stream));
+	std::vector<uint8_t> host_bits(NRS_BITFIELD_BYTES);
+	HIP_TRY(hipMemcpyAsync(host_bits.data(), m->d_bitfield, NRS_BITFIELD_BYTES, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	occupied_bounds(host_bits.data(), m->dm.occ_box);
+	m->have_bitfield = true;
+	return NRS_OK;
+}
 int nrs_model_set_density_grid(nrs_model* m, const float* h_grid, size_t n_floats) {
 	if (!m || !h_grid) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_density_grid: NULL argument");
 	if (n_floats != (size_t)kGridVol * kCascades) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_density_grid: expected 5*128^3 floats");
 	HIP_TRY(hipSetDevice(m->ctx->device));
-	float* d_grid = nullptr;
-	HIP_TRY(hipMalloc((void**)&d_grid, n_floats * 4));
-	hipError_t e = hipMemcpy(d_grid, h_grid, n_floats * 4, hipMemcpyHostToDevice);
-	int s = NRS_OK;
-	if (e == hipSuccess) e = hipMemset(m->d_bitfield, 0, NRS_BITFIELD_BYTES);
-	if (e == hipSuccess) s = launch_grid_to_bitfield(d_grid, m->d_bitfield, m->ctx->d_mean, nullptr);
-	if (e == hipSuccess && s == NRS_OK) e = hipDeviceSynchronize();
-	(void)hipFree(d_grid);
-	if (e != hipSuccess) return fail_hip(e, "nrs_model_set_density_grid");
-	if (s != NRS_OK) return (g_err = launch_last_error(), s);
-	{
-		std::vector<uint8_t> host_bits(NRS_BITFIELD_BYTES);
-		HIP_TRY(hipMemcpy(host_bits.data(), m->d_bitfield, NRS_BITFIELD_BYTES, hipMemcpyDeviceToHost));
-		occupied_bounds(host_bits.data(), m->dm.occ_box);
-	}
-	m->have_bitfield = true;
+	HIP_TRY(hipMemcpy(m->d_density_grid, h_grid, n_floats * 4, hipMemcpyHostToDevice));
+	return refresh_bitfield(m, nullptr);
+}
+int nrs_model_get_density_grid(nrs_model* m, float* h_out, size_t n_floats) {
+	if (!m || !h_out || n_floats != (size_t)kGridVol * kCascades) return fail(NRS_ERR_INVALID_ARG, "nrs_model_get_density_grid: bad argument");
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	HIP_TRY(hipMemcpy(h_out, m->d_density_grid, n_floats * 4, hipMemcpyDeviceToHost));
 	return NRS_OK;
+}
+
+// tcnn::pcg32 on the host: only seeding and the skip-ahead the refresh needs
+static const uint64_t kPcgMult = 0x5851f42d4c957f2dULL;
+static uint64_t pcg_advance(uint64_t state, uint64_t inc, uint64_t delta) {
+	uint64_t cur_mult = kPcgMult, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+	while (delta > 0) {
+		if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+		cur_plus = (cur_mult + 1) * cur_plus;
+		cur_mult *= cur_mult;
+		delta >>= 1;
+	}
+	return acc_mult * state + acc_plus;
+}
+void nrs_rng_seed(uint64_t seed, uint64_t* state_out, uint64_t* inc_out) {
+	const uint64_t inc = (1u << 1u) | 1u; // initseq = 1
+	uint64_t state = 0u;
+	state = state * kPcgMult + inc;
+	state += seed;
+	state = state * kPcgMult + inc;
+	if (state_out) *state_out = state;
+	if (inc_out) *inc_out = inc;
+}
+
+int nrs_model_update_density_grid(nrs_model* m, nrs_edit* const* edits, int n_edits, nrs_grid_update* u, void* stream) {
+	if (!m || !u) return fail(NRS_ERR_INVALID_ARG, "nrs_model_update_density_grid: NULL argument");
+	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_model_update_density_grid: parameters not set (nrs_model_set_params)");
+	if (u->max_cascade >= kCascades) return fail(NRS_ERR_INVALID_ARG, "nrs_model_update_density_grid: max_cascade must be < 5");
+	if (n_edits < 0 || n_edits > nrs_ctx::kMaxEdits) return fail(NRS_ERR_INVALID_ARG, "nrs_model_update_density_grid: too many edit operators");
+	if (n_edits > 0 && !edits) return fail(NRS_ERR_INVALID_ARG, "nrs_model_update_density_grid: edits is NULL");
+	if ((uint64_t)u->n_uniform_samples + u->n_nonuniform_samples > 0x40000000ull)
+		return fail(NRS_ERR_INVALID_ARG, "nrs_model_update_density_grid: more than 2^30 samples");
+	nrs_ctx* ctx = m->ctx;
+	HIP_TRY(hipSetDevice(ctx->device));
+	hipStream_t s = (hipStream_t)stream;
+	const size_t grid_bytes = (size_t)kGridVol * kCascades * 4;
+	if (!m->d_density_tmp) HIP_TRY(hipMalloc((void**)&m->d_density_tmp, grid_bytes));
+	if (n_edits > 0) {
+		DeviceEdit host_edits[nrs_ctx::kMaxEdits];
+		for (int i = 0; i < n_edits; ++i) {
+			if (!edits[i]) return fail(NRS_ERR_INVALID_ARG, "nrs_model_update_density_grid: NULL edit operator");
+			host_edits[i] = edits[i]->de;
+		}
+		HIP_TRY(hipMemcpyAsync(ctx->d_edits, host_edits, sizeof(DeviceEdit) * n_edits, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s)); // host_edits is a stack array
+	}
+	if (u->reset_grid) HIP_TRY(hipMemsetAsync(m->d_density_grid, 0, grid_bytes, s));
+	HIP_TRY(hipMemsetAsync(m->d_density_tmp, 0, grid_bytes, s));
+	const uint64_t rng_nonuniform = pcg_advance(u->rng_state, u->rng_inc, 1ull << 32); // m_rng.advance() between the two draws
+	NRS_TRY(launch_grid_update(m->dm, ctx->d_edits, n_edits, *u, rng_nonuniform, m->d_density_grid, m->d_density_tmp, ctx->n_cus, stream));
+	u->rng_state = pcg_advance(u->rng_state, u->rng_inc, 2ull << 32);
+	u->ema_step += 1;
+	return refresh_bitfield(m, stream);
 }
 int nrs_model_get_density_bitfield(nrs_model* m, uint8_t* h_out, size_t n_bytes) {
 	if (!m || !h_out || n_bytes != NRS_BITFIELD_BYTES) return fail(NRS_ERR_INVALID_ARG, "nrs_model_get_density_bitfield: bad argument");

@@ -415,6 +415,75 @@ __device__ __forceinline__ void poisson_residual_rgb(const DeviceEdit& e, f3 wpo
 	res_density = e.residual_amplitude * lr;
 }
 
+// ---- occupancy refresh pieces (update_density_grid_nerf_operator, tn:3533-3640) ----------------------------------------
+// tcnn::pcg32 = PCG32 XSH-RR (see oracle/nrs_oracle.cpp for the provenance note); advance() is the LCG skip-ahead.
+struct Pcg32 {
+	uint64_t state, inc;
+	__device__ __forceinline__ uint32_t next_uint() {
+		const uint64_t old = state;
+		state = old * 0x5851f42d4c957f2dULL + inc;
+		const uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+		const uint32_t rot = (uint32_t)(old >> 59u);
+		return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+	}
+	__device__ __forceinline__ float next_float() { return __uint_as_float((next_uint() >> 9) | 0x3f800000u) - 1.0f; }
+	__device__ __forceinline__ void advance(uint64_t delta) {
+		uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+		while (delta > 0) {
+			if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+			cur_plus = (cur_mult + 1) * cur_plus;
+			cur_mult *= cur_mult;
+			delta >>= 1;
+		}
+		state = acc_mult * state + acc_plus;
+	}
+};
+
+// generate_grid_samples_nerf_nonuniform, cn:179-208: cell index + a uniformly random warped position inside that cell
+__device__ __forceinline__ uint32_t generate_grid_sample(Pcg32 rng, uint32_t i, uint32_t n_elements, uint32_t step, const Box3& aabb,
+                                                         const float* __restrict__ grid_in, uint32_t n_cascades, float thresh, f3& wpos) {
+	rng.advance((uint64_t)(i * 4u));
+	const uint32_t level = (uint32_t)(rng.next_float() * n_cascades) % n_cascades;
+	uint32_t idx = 0;
+	#pragma unroll 1
+	for (uint32_t j = 0; j < 10; ++j) {
+		idx = ((i + step * n_elements) * 56924617u + j * 19349663u + 96925573u) % kGridVol;
+		idx += level * kGridVol;
+		if (grid_in[idx] > thresh) break;
+	}
+	const uint32_t pos_idx = idx % kGridVol;
+	const float x = (float)morton3D_invert(pos_idx >> 0), y = (float)morton3D_invert(pos_idx >> 1), z = (float)morton3D_invert(pos_idx >> 2);
+	const float rx = rng.next_float(), ry = rng.next_float(), rz = rng.next_float();
+	const float s = __uint_as_float((127u + level) << 23); // scalbnf(1, level)
+	const float inv = 1.0f / (float)kGrid;                  // exact: x / 128 == x * 2^-7
+	const f3 pos = {((x + rx) * inv - 0.5f) * s + 0.5f, ((y + ry) * inv - 0.5f) * s + 0.5f, ((z + rz) * inv - 0.5f) * s + 0.5f};
+	wpos = warp_position(pos, aabb);
+	return idx;
+}
+
+// compute_poisson_residual_density_kernel, cage_deformation.cu:341-384.  wpos is the position AFTER map_positions; the
+// look-up nevertheless uses the deformed mesh's LUT, as the reference does.
+__device__ __forceinline__ bool poisson_residual_density(const DeviceEdit& e, f3 wpos, float& residual) {
+	const f3 pos = unwarp_position(wpos, e.aabb);
+	if (!box_contains(e.bbox, pos)) return false;
+	const int level = mip_from_pos(pos);
+	const uint32_t cell = (uint32_t)level * kGridVol + cascaded_grid_idx_at(pos, (uint32_t)level);
+	const uint32_t j0 = e.lut_off[cell], j1 = e.lut_off[cell + 1];
+	#pragma unroll 1
+	for (uint32_t j = j0; j < j1; ++j) {
+		const uint32_t t = e.lut_idx[j];
+		const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[t];
+		const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), d = ld3(e.verts, tv.w);
+		if (point_in_tet(a, b, c, d, pos)) {
+			float bc[4];
+			bary_tet(a, b, c, d, pos, bc);
+			residual = ((bc[0] * e.res_density[tv.x] + bc[1] * e.res_density[tv.y]) + bc[2] * e.res_density[tv.z]) + bc[3] * e.res_density[tv.w];
+			return true;
+		}
+	}
+	return false;
+}
+
 // ---- activations (cn:38-66) and shade (common_device.cuh:31-37) ---------------------------------------------------
 __device__ __forceinline__ float network_to_rgb(float v, uint32_t act) {
 	switch (act) {

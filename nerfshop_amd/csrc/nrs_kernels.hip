@@ -571,6 +571,110 @@ int launch_grid_to_bitfield(const float* d_grid, uint8_t* d_bitfield, float* d_s
 	return NRS_OK;
 }
 
+// ---- deformed-space occupancy refresh (update_density_grid_nerf_operator, tn:3533-3640) ----------------------------------
+// One fused kernel replaces the reference's generate x2 -> map_positions per operator -> density() -> clear_empty_space ->
+// activate -> residual -> splat train and its four scratch arrays (positions, indices, mlp_out, empty mask): each lane draws
+// its cell sample, walks it through the operators, the wave evaluates hash grid + density MLP on MFMA, and the lane
+// max-splats the optical thickness into grid_tmp.  atomicMax on the bit pattern is order-independent => deterministic.
+struct GridUpdateArgs {
+	const float* grid;        // current density grid (read by the sampler)
+	uint32_t* grid_tmp;       // zeroed; float bits
+	const DeviceEdit* edits;
+	int32_t n_edits;
+	uint32_t n_uniform, n_nonuniform, step, n_cascades;
+	uint64_t rng_state, rng_inc, rng_state_nonuniform;
+};
+
+__global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, const GridUpdateArgs a) {
+	__shared__ NetSmem sm;
+	stage_model_to_lds(m, sm.ml);
+	const int lane = threadIdx.x & 63;
+	const int g = lane >> 5;
+	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count);
+	const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+	const uint32_t n = a.n_uniform + a.n_nonuniform;
+	const uint32_t n_tiles = (n + 63) / 64;
+	for (uint32_t tile = wave_global; tile < n_tiles; tile += n_waves) {
+		const uint32_t s = tile * 64 + lane;
+		const bool have = s < n;
+		f3 wpos = mk3(0, 0, 0);
+		uint32_t cell = 0;
+		bool empty = false;
+		if (have) {
+			const bool uni = s < a.n_uniform;
+			const Pcg32 rng{uni ? a.rng_state : a.rng_state_nonuniform, a.rng_inc};
+			cell = generate_grid_sample(rng, uni ? s : s - a.n_uniform, uni ? a.n_uniform : a.n_nonuniform, a.step, m.aabb, a.grid, a.n_cascades,
+			                            uni ? -0.01f : 0.01f, wpos);
+			f3 unused = mk3(0.5f, 0.5f, 0.5f);
+			for (int k = a.n_edits - 1; k >= 0; --k) empty |= tet_warp(a.edits[k], false, wpos, unused);
+		}
+		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
+		const bool phave = __shfl_xor((int)have, 32, 64) != 0;
+		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, have, ppos, phave);
+		_Float16 raw_b[2];
+		#pragma unroll 1
+		for (int b = 0; b < 2; ++b) {
+			const int sel = (b != g) ? 1 : 0;
+			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
+			const half8 dout = density_mlp(sm.ml.w, lane, x0, x1);
+			raw_b[b] = dout[0]; // row 0 of sample 32*b + (lane & 31) sits on the g == 0 lanes
+		}
+		// lane l < 32 owns block 0's sample l; lane 32 + j owns block 1's sample, computed on lane j
+		const float from_partner = xchg32((float)raw_b[1]);
+		_Float16 raw = g ? (_Float16)from_partner : raw_b[0];
+		if (!have) continue;
+		if (a.n_edits > 0 && empty) raw = (_Float16)(-10000.f);
+		_Float16 act = (_Float16)network_to_density((float)raw, m.density_activation);
+		for (int k = a.n_edits - 1; k >= 0; --k) {
+			const DeviceEdit& e = a.edits[k];
+			float r;
+			if (e.apply_poisson && poisson_residual_density(e, wpos, r)) act = act + (_Float16)r;
+		}
+		const float thickness = (float)act * NRS_MIN_STEP;
+		atomicMax(a.grid_tmp + cell, __float_as_uint(thickness));
+	}
+}
+
+__global__ void grid_ema_kernel(uint32_t n_elements, float decay, float* __restrict__ grid, const uint32_t* __restrict__ grid_tmp) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_elements) return;
+	const float importance = __uint_as_float(grid_tmp[i]);
+	const float prev = grid[i];
+	grid[i] = (prev < 0.f) ? prev : fmaxf(prev * decay, importance);
+}
+
+int launch_grid_update(const DeviceModel& m, const DeviceEdit* d_edits, int n_edits, const nrs_grid_update& u, uint64_t rng_state_nonuniform,
+                       float* d_grid, uint32_t* d_grid_tmp, int n_cus, void* stream) {
+	hipStream_t s = (hipStream_t)stream;
+	const uint32_t n_elements = kGridVol * kCascades;
+	GridUpdateArgs a{};
+	a.grid = d_grid;
+	a.grid_tmp = d_grid_tmp;
+	a.edits = d_edits;
+	a.n_edits = n_edits;
+	a.n_uniform = u.n_uniform_samples;
+	a.n_nonuniform = u.n_nonuniform_samples;
+	a.step = u.ema_step;
+	a.n_cascades = u.max_cascade + 1;
+	a.rng_state = u.rng_state;
+	a.rng_inc = u.rng_inc;
+	a.rng_state_nonuniform = rng_state_nonuniform;
+	const uint32_t n = a.n_uniform + a.n_nonuniform;
+	if (n > 0) {
+		const uint32_t n_tiles = (n + 63) / 64;
+		uint32_t grid = (n_tiles + 3) / 4;
+		const uint32_t cap = (uint32_t)n_cus * 8;
+		if (grid > cap) grid = cap;
+		hipLaunchKernelGGL(grid_refresh_kernel, dim3(grid), dim3(256), 0, s, m, a);
+		NRS_LAUNCH_CHECK("grid_refresh_kernel launch");
+	}
+	hipLaunchKernelGGL(grid_ema_kernel, dim3((n_elements + 255) / 256), dim3(256), 0, s, n_elements, u.decay, d_grid, d_grid_tmp);
+	NRS_LAUNCH_CHECK("grid_ema_kernel launch");
+	return NRS_OK;
+}
+
 // ---- multi-GPU de-tiling ---------------------------------------------------------------------------------------------------
 __global__ void detile_kernel(int W, int H, uint32_t tile, uint32_t tiles_x, uint32_t n_ranks, uint32_t tiles_per_rank_padded,
                               const float* __restrict__ tiles, uint32_t channels, float* __restrict__ image) {

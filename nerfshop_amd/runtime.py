@@ -102,6 +102,11 @@ class NerfNetwork:
         check(self.lib.nrs_model_get_density_bitfield(self.h, out.ctypes.data, out.size))
         return out
 
+    def get_density_grid(self):
+        out = np.zeros(_abi.GRID_VOLUME * _abi.GRID_CASCADES, np.float32)
+        check(self.lib.nrs_model_get_density_grid(self.h, out.ctypes.data, out.size))
+        return out
+
     def inference_mixed_precision(self, stream, input, output):
         """input: [n, 7] f32 (tcnn: column-major 7 x n).  output: fp16, [16, n_el] (row-major planes, n_el >= n)
         or [n, 16] (column-major / interleaved), as GPUMatrixDynamic's layout selects in the reference."""
@@ -280,6 +285,34 @@ class Testbed:
                                        C.byref(stats) if stats is not None else None))
         self.last_stats = stats
         return stats
+
+    def new_grid_update(self, max_cascade=0, seed=1337, decay=0.95):
+        """The Testbed members update_density_grid_nerf_operator reads: m_rng = default_rng_t{m_seed} (testbed.cu:2220),
+        density_grid_ema_step = 0, density_grid_decay = 0.95 (testbed.h:604), sized as update_density_grid_nerf_render does."""
+        u = _abi.GridUpdate()
+        u.n_uniform_samples = _abi.GRID_VOLUME * (max_cascade + 1)
+        u.n_nonuniform_samples = 0
+        u.reset_grid = 0
+        u.max_cascade = max_cascade
+        u.decay = decay
+        u.ema_step = 0
+        st, inc = C.c_uint64(), C.c_uint64()
+        self.lib.nrs_rng_seed(seed, C.byref(st), C.byref(inc))
+        u.rng_state, u.rng_inc = st.value, inc.value
+        return u
+
+    def update_density_grid_nerf_operator(self, update, stream=None, apply_operators=True):
+        """Testbed::update_density_grid_nerf_operator (testbed_nerf.cu:3533): one refresh of the occupancy in deformed space."""
+        ops = self.edit_operators if (apply_operators and self.enable_edits) else []
+        arr = (C.c_void_p * max(len(ops), 1))(*[op.h for op in ops])
+        check(self.lib.nrs_model_update_density_grid(self.nerf_network.h, arr, len(ops), C.byref(update), _stream_handle(stream)))
+
+    def update_density_grid_nerf_render(self, n_iterations, reset_grid, update, stream=None):
+        """Testbed::update_density_grid_nerf_render (testbed_nerf.cu:3514)."""
+        for i in range(n_iterations):
+            update.reset_grid = 1 if (reset_grid and i == 0) else 0
+            self.update_density_grid_nerf_operator(update, stream)
+        update.reset_grid = 0
 
     def trace_samples(self, p, pixel_idx, max_samples, stream=None):
         """Test hook: (t, dt) stream per listed pixel -> (t [n, max], dt [n, max], count [n]) as CUDA tensors."""

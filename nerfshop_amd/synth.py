@@ -109,7 +109,7 @@ def default_sigma_raw(aabb_scale=1):
     return math.log(0.15 / dt)
 
 
-def make_params(desc, seed=SEED, sigma_raw=None, density_noise=0.25):
+def make_params(desc, seed=SEED, sigma_raw=None, density_noise=0.25, shaped=False, aabb_scale=1, shape_gain=12.0):
     """fp16 parameter blob (uint16 bits) in tiny-cuda-nn order: density MLP | rgb MLP | hash grid.
 
     Draw order from numpy.random.Generator(PCG64(seed)): density W1 [64x32], density W2 [16x64], rgb W1 [64x32],
@@ -118,6 +118,11 @@ def make_params(desc, seed=SEED, sigma_raw=None, density_noise=0.25):
     every level-0 entry is 1.0, hidden unit 0 of the density MLP sees only that input (W1[0,0] = 1), and
     W2[0,0] = sigma_raw, so density_raw = sigma_raw + density_noise * (Xavier mix of the other hidden units).
     Default sigma_raw makes exp(sigma_raw) * dt_min = 0.15, i.e. alpha ~ 0.14 per sample.
+
+    shaped=True additionally puts the scene's geometry INTO the network, as a trained snapshot has it (needed by the
+    occupancy refresh, which derives the grid from density()): feature 0 of the finest dense level holds the solid's
+    indicator at the level's vertices, hidden unit 1 reads only that feature, and W2[0,1] = shape_gain while the constant
+    channel drops to sigma_raw - shape_gain: density_raw ~ sigma_raw inside the solid, sigma_raw - shape_gain outside.
     """
     lib = _abi.load()
     n = lib.nrs_model_n_params(C.byref(desc))
@@ -143,6 +148,19 @@ def make_params(desc, seed=SEED, sigma_raw=None, density_noise=0.25):
     dw2[0, :] *= density_noise
     dw2[0, 0] = sigma_raw
     rw1[:, 0] = 0.0          # keep the large density channel out of the colour network
+    if shaped:
+        ls = int(np.nonzero(lt["hashed"] == 0)[0].max())          # finest dense level
+        res, sc, off = int(lt["resolution"][ls]), np.float32(lt["scale"][ls]), int(lt["offset"][ls])
+        ax = (np.arange(res, dtype=np.float32) - np.float32(0.5)) / sc   # warped coordinate of vertex i (pos * scale + 0.5 = i)
+        zz, yy, xx = np.meshgrid(ax, ax, ax, indexing="ij")            # entry = x + y * res + z * res^2
+        mn, mx = np.asarray(desc.aabb_min, np.float32), np.asarray(desc.aabb_max, np.float32)
+        pts = np.stack([xx.ravel(), yy.ravel(), zz.ravel()], axis=1) * (mx - mn) + mn
+        ind = scene_indicator(pts, aabb_scale)
+        grid[2 * off: 2 * (off + res ** 3): 2] = ind
+        dw1[1, :] = 0.0
+        dw1[1, 2 * ls] = 1.0
+        dw2[0, 1] = shape_gain
+        dw2[0, 0] = sigma_raw - shape_gain
     blob = np.concatenate([dw1.ravel(), dw2.ravel(), rw1.ravel(), rw2.ravel(), rw3.ravel(), grid]).astype(np.float16)
     assert blob.size == n
     return blob.view(np.uint16)

@@ -1462,6 +1462,159 @@ void orc_density_grid_to_bitfield(const float* grid, uint8_t* bitfield) {
 		}
 	}
 }
+// ---- deformed-space occupancy refresh: Testbed::update_density_grid_nerf_operator, tn:3533-3640 -----------------------
+// tcnn::pcg32 (dependencies/tiny-cuda-nn/include/tiny-cuda-nn/common_device.h at the submodule pin, ABSENT from the
+// checkout): M.E. O'Neill's PCG32 XSH-RR as published (pcg-random.org, Apache-2.0 "pcg32.h" by W. Jakob), restated:
+//   state' = state * 0x5851f42d4c957f2d + inc;  out = ror32(((state >> 18) ^ state) >> 27, state >> 59)
+//   pcg32(seed): state = 0, inc = (1 << 1) | 1, next, state += seed, next
+//   next_float = bit_cast<float>((next_uint() >> 9) | 0x3f800000) - 1
+//   advance(delta) = LCG skip-ahead (Brown, "Random number generation with arbitrary strides");  tcnn's default delta is 2^32
+struct Pcg32 {
+	uint64_t state, inc;
+	uint32_t next_uint() {
+		uint64_t old = state;
+		state = old * 0x5851f42d4c957f2dULL + inc;
+		uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+		uint32_t rot = (uint32_t)(old >> 59u);
+		return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+	}
+	float next_float() {
+		uint32_t u = (next_uint() >> 9) | 0x3f800000u;
+		float f;
+		memcpy(&f, &u, 4);
+		return f - 1.0f;
+	}
+	void advance(uint64_t delta) {
+		uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+		while (delta > 0) {
+			if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+			cur_plus = (cur_mult + 1) * cur_plus;
+			cur_mult *= cur_mult;
+			delta >>= 1;
+		}
+		state = acc_mult * state + acc_plus;
+	}
+};
+void orc_pcg32_seed(uint64_t seed, uint64_t* state, uint64_t* inc) {
+	Pcg32 r{0u, (1u << 1u) | 1u};
+	r.next_uint();
+	r.state += seed;
+	r.next_uint();
+	*state = r.state; *inc = r.inc;
+}
+uint32_t orc_pcg32_next_uint(uint64_t* state, uint64_t inc) { Pcg32 r{*state, inc}; uint32_t v = r.next_uint(); *state = r.state; return v; }
+float orc_pcg32_next_float(uint64_t* state, uint64_t inc) { Pcg32 r{*state, inc}; float v = r.next_float(); *state = r.state; return v; }
+void orc_pcg32_advance(uint64_t* state, uint64_t inc, uint64_t delta) { Pcg32 r{*state, inc}; r.advance(delta); *state = r.state; }
+
+// __hadd: the exact sum of two halfs rounded ONCE to half.  The sum is exact in double; it is brought to float with
+// round-to-odd (sticky bit) so that the final round-to-nearest-even to 11 bits cannot double-round.
+static uint16_t hadd(uint16_t a, uint16_t b) {
+	double d = (double)h2f(a) + (double)h2f(b);
+	float f = (float)d;
+	if ((double)f == d) return f2h(f);
+	float other = ((double)f < d) ? nextafterf(f, INFINITY) : nextafterf(f, -INFINITY);
+	return f2h((f2u(f) & 1u) ? f : other);
+}
+
+// generate_grid_samples_nerf_nonuniform, cn:179-208.  Returns the cell index; pos_out = warped position.
+static uint32_t generate_grid_sample(Pcg32 rng, uint32_t i, uint32_t n_elements, uint32_t step, const Box& aabb, const float* grid_in,
+                                     uint32_t n_cascades, float thresh, V3& pos_out) {
+	rng.advance((uint64_t)(int64_t)(uint32_t)(i * 4u));
+	uint32_t level = (uint32_t)(rng.next_float() * n_cascades) % n_cascades;
+	uint32_t idx = 0;
+	for (uint32_t j = 0; j < 10; ++j) {
+		idx = ((i + step * n_elements) * 56924617u + j * 19349663u + 96925573u) % GRIDVOL;
+		idx += level * GRIDVOL;
+		if (grid_in[idx] > thresh) break;
+	}
+	uint32_t pos_idx = idx % GRIDVOL;
+	uint32_t x = morton3D_invert(pos_idx >> 0), y = morton3D_invert(pos_idx >> 1), z = morton3D_invert(pos_idx >> 2);
+	float rx = rng.next_float(), ry = rng.next_float(), rz = rng.next_float();
+	float s = scalbnf(1.0f, (int)level);
+	V3 pos = {(((float)x + rx) / (float)GRID - 0.5f) * s + 0.5f, (((float)y + ry) / (float)GRID - 0.5f) * s + 0.5f,
+	          (((float)z + rz) / (float)GRID - 0.5f) * s + 0.5f};
+	pos_out = warp_position(pos, aabb);
+	return idx;
+}
+
+// compute_poisson_residual_density_kernel, cage_deformation.cu:341-384: barycentric residual density of the tet of the
+// DEFORMED mesh that contains the (already mapped) position; 0 contribution if none.  Returns true if a tet was found.
+static bool poisson_residual_density_one(const Edit& e, V3 warped_pos, float* residual) {
+	V3 pos = unwarp_position(warped_pos, e.aabb);
+	if (!box_contains(e.bbox, pos)) return false;
+	int level = mip_from_pos(pos);
+	uint32_t cell = (uint32_t)level * GRIDVOL + cascaded_grid_idx_at(pos, (uint32_t)level);
+	for (uint32_t j = e.lut_off[cell]; j < e.lut_off[cell + 1]; ++j) {
+		uint32_t t = e.lut_idx[j];
+		const uint32_t* tv = &e.tets[4 * (size_t)t];
+		V3 a = e.verts[tv[0]], b = e.verts[tv[1]], c = e.verts[tv[2]], d = e.verts[tv[3]];
+		if (point_in_tet(a, b, c, d, pos)) {
+			float bc[4];
+			bary_tet(a, b, c, d, pos, bc);
+			*residual = ((bc[0] * e.res_density[tv[0]] + bc[1] * e.res_density[tv[1]]) + bc[2] * e.res_density[tv[2]]) + bc[3] * e.res_density[tv[3]];
+			return true;
+		}
+	}
+	return false;
+}
+
+// One call of update_density_grid_nerf_operator.  grid: [5*128^3] in/out; bitfield: [NRS_BITFIELD_BYTES] out.
+// u: nrs_grid_update (include/nrs.h), rng / ema_step advanced as the reference advances m_rng / density_grid_ema_step.
+// Deviation, stated: the reference launches clear_empty_space / compute_poisson_residual_density over n_elements =
+// 5*128^3 threads although only n_samples positions exist (tn:3606, 3622) -- an out-of-bounds read when max_cascade < 4;
+// here both run over the n_samples samples that exist.
+void orc_update_density_grid(void* model, void* const* edits, int n_edits, float* grid, uint8_t* bitfield, nrs_grid_update* u) {
+	const Model& m = *(Model*)model;
+	const uint32_t n_elements = GRIDVOL * CASCADES;
+	if (u->reset_grid) memset(grid, 0, sizeof(float) * n_elements);
+	std::vector<uint32_t> tmp(n_elements, 0u); // density_grid_tmp, float bits (atomicMax on uint)
+	const uint32_t n_cascades = u->max_cascade + 1;
+	Pcg32 rng0{u->rng_state, u->rng_inc};
+	Pcg32 rng1 = rng0;
+	rng1.advance(1ull << 32);
+	const uint32_t n_total = u->n_uniform_samples + u->n_nonuniform_samples;
+	std::vector<uint32_t> cell(n_total);
+	std::vector<uint32_t> val(n_total);
+#pragma omp parallel for schedule(static)
+	for (int64_t s = 0; s < (int64_t)n_total; ++s) {
+		const bool uni = (uint32_t)s < u->n_uniform_samples;
+		const uint32_t i = uni ? (uint32_t)s : (uint32_t)s - u->n_uniform_samples;
+		V3 wpos;
+		uint32_t idx = generate_grid_sample(uni ? rng0 : rng1, i, uni ? u->n_uniform_samples : u->n_nonuniform_samples, u->ema_step, m.aabb, grid,
+		                                    n_cascades, uni ? -0.01f : 0.01f, wpos);
+		float p[3] = {wpos.x, wpos.y, wpos.z};
+		uint8_t empty = 0;
+		for (int k = n_edits - 1; k >= 0; --k) map_position_one(*(const Edit*)edits[k], p, &empty);
+		uint16_t feat[32], o[16];
+		hashgrid_encode_one(m, p, feat);
+		density_mlp_one(m, feat, o);
+		uint16_t raw = o[0];
+		if (n_edits > 0 && empty) raw = f2h(-10000.f);                              // clear_empty_space, tn:2759
+		uint16_t act = f2h(network_to_density(h2f(raw), m.desc.density_activation)); // activate_network_density, tn:3522
+		for (int k = n_edits - 1; k >= 0; --k) {
+			const Edit& e = *(const Edit*)edits[k];
+			float r;
+			if (e.apply_poisson && poisson_residual_density_one(e, v3(p[0], p[1], p[2]), &r)) act = hadd(act, f2h(r)); // __half += (__half)r
+		}
+		float thickness = h2f(act) * MIN_STEP; // scalbnf(MIN_CONE_STEPSIZE(), 0)
+		uint32_t bits;
+		memcpy(&bits, &thickness, 4);
+		cell[s] = idx;
+		val[s] = bits;
+	}
+	for (uint32_t s = 0; s < n_total; ++s) tmp[cell[s]] = std::max(tmp[cell[s]], val[s]); // atomicMax on the bit pattern, tn:447-462
+	for (uint32_t i = 0; i < n_elements; ++i) { // ema_grid_samples_nerf, tn:483-506
+		float importance;
+		memcpy(&importance, &tmp[i], 4);
+		float prev = grid[i];
+		grid[i] = (prev < 0.f) ? prev : fmaxf(prev * u->decay, importance);
+	}
+	rng0.advance(2ull << 32); // m_rng.advance() twice
+	u->rng_state = rng0.state;
+	u->ema_step += 1;
+	orc_density_grid_to_bitfield(grid, bitfield);
+}
+
 float orc_density_grid_threshold(const float* grid) {
 	double mean = 0.0;
 	for (uint32_t i = 0; i < GRIDVOL; ++i) mean += (double)(fmaxf(grid[i], 0.f) / (float)GRIDVOL);

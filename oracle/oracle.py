@@ -53,6 +53,9 @@ def load():
         "orc_mvc_compute": (None, [P, U32, P, U32, P, U32, P, P]), "orc_mvc_apply": (None, [P, P, U32, U32, P]),
         "orc_tet_local_rotations": (None, [P, P, P, U32, P]),
         "orc_density_grid_to_bitfield": (None, [P, P]), "orc_density_grid_threshold": (F, [P]),
+        "orc_pcg32_seed": (None, [C.c_uint64, P, P]), "orc_pcg32_next_uint": (U32, [P, C.c_uint64]),
+        "orc_pcg32_next_float": (F, [P, C.c_uint64]), "orc_pcg32_advance": (None, [P, C.c_uint64, C.c_uint64]),
+        "orc_update_density_grid": (None, [P, P, I, P, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -101,6 +104,16 @@ class Model:
         out = np.zeros((16, n) if layout == 0 else (n, 16), np.uint16)
         self.lib.orc_network_density(self.h, n, pos.ctypes.data, pos.shape[1], out.ctypes.data, n, layout)
         return out
+
+    def update_density_grid(self, grid, update, edits=()):
+        """One update_density_grid_nerf_operator call.  grid [5*128^3] f32 is updated in place; `update` (a
+        nerfshop_amd._abi.GridUpdate) has rng / ema_step advanced.  Returns the new bitfield (also installed)."""
+        assert grid.dtype == np.float32 and grid.flags.c_contiguous and grid.size == 5 * 128 ** 3
+        bits = np.zeros(5 * 128 ** 3 // 8, np.uint8)
+        arr = (C.c_void_p * max(len(edits), 1))(*[e.h for e in edits])
+        self.lib.orc_update_density_grid(self.h, arr, len(edits), grid.ctypes.data, bits.ctypes.data, C.byref(update))
+        self.set_bitfield(bits)
+        return bits
 
     def trace_samples(self, params, pixel_idx, max_samples):
         pixel_idx = np.ascontiguousarray(pixel_idx, np.uint32)
@@ -190,6 +203,24 @@ def local_rotations(vertices, original, tets):
     out = np.zeros((t.shape[0], 9), np.float32)
     lib.orc_tet_local_rotations(v.ctypes.data, o.ctypes.data, t.ctypes.data, t.shape[0], out.ctypes.data)
     return out
+
+
+class Pcg32:
+    """tcnn::pcg32 restated (see nrs_oracle.cpp)."""
+
+    def __init__(self, seed=1337):
+        self.lib = load()
+        self.state, self.inc = C.c_uint64(), C.c_uint64()
+        self.lib.orc_pcg32_seed(seed, C.byref(self.state), C.byref(self.inc))
+
+    def next_uint(self):
+        return self.lib.orc_pcg32_next_uint(C.byref(self.state), self.inc)
+
+    def next_float(self):
+        return self.lib.orc_pcg32_next_float(C.byref(self.state), self.inc)
+
+    def advance(self, delta=1 << 32):
+        self.lib.orc_pcg32_advance(C.byref(self.state), self.inc, delta)
 
 
 def density_grid_to_bitfield(grid):

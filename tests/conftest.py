@@ -32,13 +32,13 @@ def built():
 class Scene:
     """Synthetic lego-like scene (nerfshop_amd.synth) + the CPU oracle's view of it."""
 
-    def __init__(self, aabb_scale=1, with_edit=True, lattice_n=6):
+    def __init__(self, aabb_scale=1, with_edit=True, lattice_n=6, shaped=False):
         from nerfshop_amd import synth
         from oracle import oracle as orc
         self.synth, self.orc = synth, orc
         self.aabb_scale = aabb_scale
         self.desc = synth.model_desc(aabb_scale)
-        self.params = synth.make_params(self.desc, sigma_raw=synth.default_sigma_raw(aabb_scale))
+        self.params = synth.make_params(self.desc, sigma_raw=synth.default_sigma_raw(aabb_scale), shaped=shaped, aabb_scale=aabb_scale)
         self.grid = synth.density_grid(aabb_scale)
         self.bitfield = synth.grid_to_bitfield(self.grid)
         self.oracle_model = orc.Model(self.desc, self.params, self.bitfield)
@@ -69,6 +69,17 @@ def scene(built):
 @pytest.fixture(scope="session")
 def scene16(built):
     return Scene(aabb_scale=16, with_edit=True, lattice_n=5)
+
+
+@pytest.fixture(scope="session")
+def scene_shaped(built):
+    """Geometry inside the network (synth.make_params(shaped=True)): what the occupancy refresh needs."""
+    return Scene(aabb_scale=1, with_edit=True, lattice_n=6, shaped=True)
+
+
+@pytest.fixture(scope="session")
+def scene16_shaped(built):
+    return Scene(aabb_scale=16, with_edit=True, lattice_n=5, shaped=True)
 
 
 class GpuRig:
@@ -110,3 +121,13 @@ def rig(scene):
 @pytest.fixture(scope="session")
 def rig16(scene16):
     return GpuRig(scene16)
+
+
+@pytest.fixture(scope="session")
+def rig_shaped(scene_shaped):
+    return GpuRig(scene_shaped)
+
+
+@pytest.fixture(scope="session")
+def rig16_shaped(scene16_shaped):
+    return GpuRig(scene16_shaped)

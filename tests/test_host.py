@@ -28,12 +28,13 @@ def test_library_exports_every_declared_symbol(built):
 def test_struct_layouts_match_header(built):
     """ctypes mirrors must have the C compiler's sizes (checked against a tiny C program's sizeof)."""
     import subprocess, tempfile
-    src = '#include <stdio.h>\n#include "nrs.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(nrs_model_desc), sizeof(nrs_tet_mesh), sizeof(nrs_render_params), sizeof(nrs_render_stats));return 0;}\n'
+    src = '#include <stdio.h>\n#include "nrs.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(nrs_model_desc), sizeof(nrs_tet_mesh), sizeof(nrs_render_params), sizeof(nrs_render_stats), sizeof(nrs_grid_update));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         sizes = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
-    assert sizes == [C.sizeof(_abi.ModelDesc), C.sizeof(_abi.TetMesh), C.sizeof(_abi.RenderParams), C.sizeof(_abi.RenderStats)]
+    assert sizes == [C.sizeof(_abi.ModelDesc), C.sizeof(_abi.TetMesh), C.sizeof(_abi.RenderParams), C.sizeof(_abi.RenderStats),
+                     C.sizeof(_abi.GridUpdate)]
 
 
 def test_no_gpu_is_a_loud_error(built):
@@ -234,3 +235,13 @@ int main() {
                            "-L", libdir, "-lnrs", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)], text=True)
     assert out.startswith("gpu 12206480") or "no HIP device visible" in out or "no CPU fallback" in out, out
+
+
+def test_rng_seed_matches_oracle(built):
+    """nrs_rng_seed (host part of the C-ABI) against the oracle's pcg32 restatement."""
+    lib = _abi.load()
+    for seed in (0, 1337, 2 ** 40 + 7):
+        st, inc = C.c_uint64(), C.c_uint64()
+        lib.nrs_rng_seed(seed, C.byref(st), C.byref(inc))
+        r = orc.Pcg32(seed)
+        assert (st.value, inc.value) == (r.state.value, r.inc.value)

@@ -221,3 +221,78 @@ def test_network_oracle_against_numpy(scene):
     assert np.abs(got - rout).max() <= 2e-2 * max(1.0, np.abs(rout).max())
     assert (got[:, 3] == rout[:, 3]).all()                      # density path has no transcendental / SH: exact
     assert (got == rout).mean() > 0.95
+
+
+def test_pcg32_published_vector(built):
+    """PCG32 XSH-RR known-answer vector: the output of the reference implementation's demo (pcg32-demo, seed 42, stream 54),
+    as printed in the PCG C library's expected output.  tcnn::pcg32 is this generator (absent submodule; see oracle header)."""
+    import ctypes as C
+    lib = orc.load()
+    st, inc = C.c_uint64(0), (54 << 1) | 1
+    lib.orc_pcg32_next_uint(C.byref(st), inc)
+    st.value = (st.value + 42) & (2 ** 64 - 1)
+    lib.orc_pcg32_next_uint(C.byref(st), inc)
+    got = [lib.orc_pcg32_next_uint(C.byref(st), inc) for _ in range(6)]
+    assert got == [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293, 0xbfa4784b, 0xcbed606e]
+    # advance(n) == n x next_uint; next_float in [0, 1) from the top 23 bits
+    a, b = orc.Pcg32(1337), orc.Pcg32(1337)
+    for _ in range(1000):
+        a.next_uint()
+    b.advance(1000)
+    assert a.state.value == b.state.value
+    b.advance(1 << 32)
+    c = orc.Pcg32(1337)
+    c.advance((1 << 32) + 1000)
+    assert b.state.value == c.state.value
+    r = orc.Pcg32(7)
+    u = orc.Pcg32(7).next_uint()
+    assert r.next_float() == np.float32(np.uint32((u >> 9) | 0x3F800000).view(np.float32) - np.float32(1.0))
+
+
+def test_occupancy_refresh_oracle_properties(built):
+    """update_density_grid_nerf_operator restated (tn:3533): the uniform draw of 128^3 samples visits every cell of
+    cascade 0 exactly once ((i * 56924617 + c) mod 2^21 is a bijection), the refreshed occupancy is the network's solid,
+    a cage edit moves it, and the Testbed-side state advances."""
+    from nerfshop_amd import _abi, synth
+    from conftest import Scene
+    sc = Scene(1, True, 6, shaped=True)
+    VOL = 128 ** 3
+
+    def new_update(seed=1337):
+        u = _abi.GridUpdate()
+        u.n_uniform_samples, u.n_nonuniform_samples, u.reset_grid, u.max_cascade, u.decay, u.ema_step = VOL, 0, 1, 0, 0.95, 0
+        r = orc.Pcg32(seed)
+        u.rng_state, u.rng_inc = r.state.value, r.inc.value
+        return u
+
+    grid = np.full(5 * VOL, 3.0, np.float32)
+    u = new_update()
+    bits = sc.oracle_model.update_density_grid(grid, u, [])
+    assert u.ema_step == 1
+    r = orc.Pcg32(1337)
+    r.advance(2 << 32)
+    assert u.rng_state == r.state.value
+    assert (grid[:VOL] > 0).all() and (grid[VOL:] == 0).all()        # reset + every cell of cascade 0 written once
+    occ = np.unpackbits(bits[: VOL // 8], bitorder="little").astype(bool)
+    solid = np.unpackbits(sc.bitfield[: VOL // 8], bitorder="little").astype(bool)
+    assert 0.02 * VOL < occ.sum() < solid.sum()                        # trilinear shoulder erodes the border cells
+    assert (occ & ~solid).sum() < 0.02 * occ.sum()                     # essentially inside the solid
+    inside = grid[:VOL][occ]
+    assert abs(np.median(inside) - 0.15) < 0.03                        # exp(sigma_raw) * dt_min, synth.default_sigma_raw
+    # untrained cells (negative) stay negative and are never chosen by either draw
+    grid2 = grid.copy()
+    grid2[:1000] = -1.0
+    u2 = new_update()
+    u2.reset_grid = 0
+    sc.oracle_model.update_density_grid(grid2, u2, [])
+    assert (grid2[:1000] == -1.0).all()
+    # with the cage edit the occupancy moves: cells appear where the deformed cage carries content
+    grid3 = np.zeros(5 * VOL, np.float32)
+    u3 = new_update()
+    bits3 = sc.oracle_model.update_density_grid(grid3, u3, [sc.oracle_edit])
+    occ3 = np.unpackbits(bits3[: VOL // 8], bitorder="little").astype(bool)
+    moved_ref = np.unpackbits(sc.edited_bitfield[: VOL // 8], bitorder="little").astype(bool)
+    gained, lost = occ3 & ~occ, occ & ~occ3
+    assert gained.sum() > 500 and lost.sum() > 500
+    assert (gained & ~moved_ref).sum() < 0.1 * gained.sum()            # new cells lie where the analytic deformed solid is
+    sc.oracle_model.set_bitfield(sc.bitfield)
