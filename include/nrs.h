@@ -15,7 +15,8 @@
  *   nrs_network_density      <- NerfNetwork<T>::density                     include/.../nerf_network_full.h:223
  *   nrs_model_set_params     <- NerfNetwork<T>::set_params                  include/.../nerf_network_full.h:316
  *   nrs_model_set_density_grid <- Testbed::update_density_grid_mean_and_bitfield   src/testbed_nerf.cu:3642
- *   nrs_edit_create / nrs_edit_update_vertices <- TetMesh GPU members + upload     tet_mesh.h:80-94, tet_mesh.cu:651-667
+ *   nrs_edit_create          <- TetMesh GPU members + upload                       tet_mesh.h:80-94, tet_mesh.cu:651-667
+ *   nrs_edit_update_cage / _vertices <- interpolate_with_mvc + build_tet_grid + update_local_rotations, on the device   ("next" row f1)
  *   nrs_edit_map_rays        <- EditOperator::map_rays      edit_operator.h:43, CageDeformation::map_rays  cage_deformation.cu:547
  *   nrs_edit_map_positions   <- EditOperator::map_positions edit_operator.h:51, cage_deformation.cu:624
  *   nrs_model_update_density_grid <- Testbed::update_density_grid_nerf_operator       src/testbed_nerf.cu:3533   ("next" row f2)
@@ -113,6 +114,12 @@ typedef struct nrs_tet_mesh {
 	const float*    h_boundary_shs;              /* [V*27] SH9RGB per vertex, Eigen col-major 9x3 */
 	const float*    h_boundary_outside_density;  /* [V] */
 	const float*    h_boundary_residual_density; /* [V] */
+	/* Device-side authoring ("next" row f1).  h_lut_offsets == NULL: nrs_edit_create builds the cell->tet LUT of
+	 * h_vertices on the device (TetMesh::build_tet_grid, tet_mesh.cu:368); h_original_bitfield == NULL: likewise the
+	 * touched cells of h_original_vertices (build_original_tet_grid, :76); h_local_rotations == NULL with
+	 * correct_direction != 0: the rotations are computed on the device (update_local_rotations, :37) and kept current
+	 * by nrs_edit_update_*.  (m_correct_direction, cage_deformation.h) */
+	uint32_t        correct_direction;
 } nrs_tet_mesh;
 
 /* Arguments + implicit Testbed members of render_nerf (SURVEY 8b "Renderer"). */
@@ -228,6 +235,22 @@ int  nrs_edit_map_rays(nrs_edit* edit, void* stream, uint32_t n, float* d_coords
 /* map_positions: in-place on d_pos [n x ld] f32 (ld >= 3), OR-accumulates into d_empty_mask */
 int  nrs_edit_map_positions(nrs_edit* edit, void* stream, uint32_t n, float* d_pos, uint32_t ld,
                             uint8_t* d_empty_mask);
+
+/* Per-gizmo-move chain on the device ("next" row f1).  The reference redoes all of this on the CPU for every move and
+ * re-uploads ~45 MB (tet_mesh.cu:651-667); here only the cage vertices (or the tet vertices) cross PCIe.
+ *   nrs_edit_set_mvc          <- Cage::compute_mvc's result (cage.cu:6), [V x n_cage_vertices] row-major, uploaded once
+ *   nrs_edit_update_cage      <- Cage::interpolate_with_mvc (cage.cu:38) + TetMesh::post_update_vertices (tet_mesh.cu:12)
+ *                                + build_tet_grid (:368) + update_local_rotations (:37)
+ *   nrs_edit_update_vertices  <- the same chain from explicit deformed tet vertices (TetMesh::update_vertices)
+ * Both synchronise `stream` (the LUT size and the bounding box come back to the host), like the reference's host code. */
+int  nrs_edit_set_mvc(nrs_edit* edit, const float* h_weights, uint32_t n_cage_vertices);
+int  nrs_edit_update_cage(nrs_edit* edit, void* stream, const float* h_cage_vertices, uint32_t n_cage_vertices);
+int  nrs_edit_update_vertices(nrs_edit* edit, void* stream, const float* h_vertices, uint32_t n_vertices);
+int  nrs_edit_lut_size(const nrs_edit* edit, uint32_t* n_idx_out, uint32_t* max_per_cell_out);
+/* read the device-side tables back (tests / inspection); any pointer may be NULL.  h_lut_idx holds n_idx entries,
+ * h_bbox6 = min xyz, max xyz of the deformed mesh. */
+int  nrs_edit_download(nrs_edit* edit, float* h_vertices, uint32_t* h_lut_offsets, uint32_t* h_lut_idx, float* h_rotations,
+                       uint8_t* h_original_bitfield, float* h_bbox6);
 
 /* ---- renderer -------------------------------------------------------------------------------------- */
 /* d_frame: f32x4 premultiplied linear RGBA, pre-cleared by the caller (clear_frame, testbed.cu:2635);

@@ -57,6 +57,7 @@ class TetMesh(C.Structure):
         ("h_boundary_shs", C.c_void_p),
         ("h_boundary_outside_density", C.c_void_p),
         ("h_boundary_residual_density", C.c_void_p),
+        ("correct_direction", C.c_uint32),
     ]
 
 
@@ -112,6 +113,7 @@ EXPORTS = [
     "nrs_model_get_density_bitfield", "nrs_model_get_density_grid", "nrs_model_update_density_grid", "nrs_rng_seed",
     "nrs_network_inference", "nrs_network_density", "nrs_hashgrid_encode",
     "nrs_edit_create", "nrs_edit_destroy", "nrs_edit_map_rays", "nrs_edit_map_positions",
+    "nrs_edit_set_mvc", "nrs_edit_update_cage", "nrs_edit_update_vertices", "nrs_edit_lut_size", "nrs_edit_download",
     "nrs_render_nerf", "nrs_render_owned_tiles", "nrs_detile", "nrs_trace_samples",
     "nrs_tet_lut_build", "nrs_tet_lut_n_idx", "nrs_tet_lut_max_per_cell", "nrs_tet_lut_offsets",
     "nrs_tet_lut_idx", "nrs_tet_lut_bitfield", "nrs_tet_lut_destroy",
@@ -168,6 +170,11 @@ def load():
     lib.nrs_edit_destroy.restype = None
     lib.nrs_edit_map_rays.argtypes = [P, P, U32, P, P]
     lib.nrs_edit_map_positions.argtypes = [P, P, U32, P, U32, P]
+    lib.nrs_edit_set_mvc.argtypes = [P, P, U32]
+    lib.nrs_edit_update_cage.argtypes = [P, P, P, U32]
+    lib.nrs_edit_update_vertices.argtypes = [P, P, P, U32]
+    lib.nrs_edit_lut_size.argtypes = [P, C.POINTER(U32), C.POINTER(U32)]
+    lib.nrs_edit_download.argtypes = [P, P, P, P, P, P, P]
     lib.nrs_render_nerf.argtypes = [P, C.POINTER(RenderParams), C.POINTER(P), I, P, P, P, P, C.POINTER(RenderStats)]
     lib.nrs_render_owned_tiles.argtypes = [C.POINTER(RenderParams)]
     lib.nrs_render_owned_tiles.restype = U32

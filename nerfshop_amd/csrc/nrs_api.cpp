@@ -66,6 +66,20 @@ struct nrs_edit {
 	nrs_ctx* ctx = nullptr;
 	DeviceEdit de{};
 	std::vector<void*> allocs;
+	uint32_t n_vertices = 0, n_tets = 0;
+	// device-side authoring state (nrs_cage.hip): everything a cage move rewrites
+	float* d_verts = nullptr;          // == de.verts
+	uint32_t* d_lut_off = nullptr;     // == de.lut_off, [5*128^3 + 1]
+	uint32_t* d_lut_idx = nullptr;     // == de.lut_idx
+	size_t lut_idx_cap = 0;            // entries allocated
+	float* d_rot = nullptr;            // == de.rot when rotations are on
+	uint32_t* d_counts = nullptr;      // [5*128^3], all zero between builds
+	uint32_t* d_tile_sums = nullptr;
+	uint32_t* d_scratch = nullptr;     // [0..5] bbox (float bits), [6] total entries, [7] max tets per cell
+	float* d_mvc = nullptr;            // [V x n_cv] weights
+	float* d_cage = nullptr;           // [n_cv x 3]
+	uint32_t n_cv = 0;
+	uint32_t lut_n_idx = 0, lut_max_per_cell = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -442,22 +456,79 @@ int nrs_hashgrid_encode(nrs_model* m, void* stream, uint32_t n, const float* d_i
 }
 
 // ---- edit operators ------------------------------------------------------------------------------------------------
+// ---- device-side tet LUT (nrs_cage.hip) ------------------------------------------------------------------------------
+#define CAGE_TRY(expr)                                                     \
+	do {                                                                   \
+		int st_ = (expr);                                                  \
+		if (st_ != NRS_OK) { g_err = cage_last_error(); return st_; }      \
+	} while (0)
+
+static int ensure_build_scratch(nrs_edit* e) {
+	const size_t n_cells = (size_t)kGridVol * kCascades;
+	if (!e->d_counts) {
+		HIP_TRY(hipMalloc((void**)&e->d_counts, n_cells * 4));
+		HIP_TRY(hipMemset(e->d_counts, 0, n_cells * 4));
+	}
+	if (!e->d_tile_sums) HIP_TRY(hipMalloc((void**)&e->d_tile_sums, kLutScanTiles * 4));
+	if (!e->d_scratch) HIP_TRY(hipMalloc((void**)&e->d_scratch, 64));
+	return NRS_OK;
+}
+// cell -> tet CSR of `d_verts` into e->d_lut_off / e->d_lut_idx (grown as needed); optionally the touched-cell bitfield.
+// Synchronises the stream once (the entry count decides the idx allocation), like the reference's host builder does.
+static int build_lut_on_device(nrs_edit* e, const float* d_verts, uint8_t* d_bitfield_out, hipStream_t s) {
+	NRS_TRY(ensure_build_scratch(e));
+	CAGE_TRY(launch_lut_count_scan(e->n_tets, d_verts, e->de.tets, e->d_counts, e->d_tile_sums, e->d_lut_off, e->d_scratch + 6, s));
+	uint32_t total = 0;
+	HIP_TRY(hipMemcpyAsync(&total, e->d_scratch + 6, 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	if ((size_t)total > e->lut_idx_cap) {
+		const size_t cap = std::max<size_t>((size_t)total + total / 2, 1024);
+		uint32_t* fresh = nullptr;
+		HIP_TRY(hipMalloc((void**)&fresh, cap * 4));
+		(void)hipFree(e->d_lut_idx);
+		e->d_lut_idx = fresh;
+		e->lut_idx_cap = cap;
+		e->de.lut_idx = fresh;
+	}
+	HIP_TRY(hipMemsetAsync(e->d_scratch + 7, 0, 4, s));
+	CAGE_TRY(launch_lut_fill(e->n_tets, d_verts, e->de.tets, e->d_counts, e->d_lut_off, e->d_lut_idx, d_bitfield_out, e->d_scratch + 7, s));
+	e->lut_n_idx = total;
+	return NRS_OK;
+}
+// everything that follows new deformed vertices in e->d_verts: bbox, LUT, rotations.  Synchronous.
+static int rebuild_after_vertices(nrs_edit* e, hipStream_t s) {
+	NRS_TRY(ensure_build_scratch(e));
+	CAGE_TRY(launch_bbox(e->n_vertices, e->d_verts, (float*)e->d_scratch, s));
+	NRS_TRY(build_lut_on_device(e, e->d_verts, nullptr, s));
+	if (e->d_rot) CAGE_TRY(launch_local_rotations(e->n_tets, e->d_verts, e->de.orig, e->de.tets, e->d_rot, s));
+	uint32_t host[8];
+	HIP_TRY(hipMemcpyAsync(host, e->d_scratch, sizeof(host), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	memcpy(e->de.bbox.mn, host, 12);      // post_update_vertices, tet_mesh.cu:12-20
+	memcpy(e->de.bbox.mx, host + 3, 12);
+	warp_box(e->de.bbox, e->de.aabb, e->de.warped_bbox);
+	e->lut_max_per_cell = host[7];
+	return NRS_OK;
+}
+
 int nrs_edit_create(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_tet_mesh* mesh, nrs_edit** out) {
 	if (!ctx || !desc || !mesh || !out) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create: NULL argument");
-	if (!mesh->h_vertices || !mesh->h_original_vertices || !mesh->h_tets || !mesh->h_lut_offsets || !mesh->h_original_bitfield)
-		return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create: missing mesh array");
+	if (!mesh->h_vertices || !mesh->h_original_vertices || !mesh->h_tets) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create: missing mesh array");
 	if (mesh->n_tets == 0 || mesh->n_vertices == 0) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create: empty mesh");
 	if (mesh->apply_poisson && (!mesh->h_boundary_shs || !mesh->h_boundary_outside_density || !mesh->h_boundary_residual_density))
 		return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create: apply_poisson set without the per-vertex membrane arrays");
 	for (size_t i = 0; i < 4 * (size_t)mesh->n_tets; ++i)
 		if (mesh->h_tets[i] >= mesh->n_vertices) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create: tet index out of range");
 	const size_t n_cells = (size_t)kGridVol * kCascades;
-	const uint32_t n_idx = mesh->h_lut_offsets[n_cells];
+	const bool host_lut = mesh->h_lut_offsets != nullptr;
+	const uint32_t n_idx = host_lut ? mesh->h_lut_offsets[n_cells] : 0;
 	if (n_idx && !mesh->h_lut_idx) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create: h_lut_idx is NULL");
 	HIP_TRY(hipSetDevice(ctx->device));
 	nrs_edit* e = new (std::nothrow) nrs_edit();
 	if (!e) return fail(NRS_ERR_STATE, "out of host memory");
 	e->ctx = ctx;
+	e->n_vertices = mesh->n_vertices;
+	e->n_tets = mesh->n_tets;
 	DeviceEdit& de = e->de;
 	for (int k = 0; k < 3; ++k) { de.aabb.mn[k] = desc->aabb_min[k]; de.aabb.mx[k] = desc->aabb_max[k]; }
 	Box3 orig_bbox;
@@ -467,13 +538,25 @@ int nrs_edit_create(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_tet_mesh
 	warp_box(orig_bbox, de.aabb, de.orig_warped_bbox);
 	int s = NRS_OK;
 	auto chk = [&](int r) { if (s == NRS_OK) s = r; };
-	chk(upload(e, mesh->h_vertices, 3 * (size_t)mesh->n_vertices, &de.verts));
+	auto dev_alloc = [&](void** p, size_t bytes) { return hipMalloc(p, std::max<size_t>(bytes, 16)) == hipSuccess ? NRS_OK : fail(NRS_ERR_HIP, "nrs_edit_create: hipMalloc failed"); };
 	chk(upload(e, mesh->h_original_vertices, 3 * (size_t)mesh->n_vertices, &de.orig));
 	chk(upload(e, mesh->h_tets, 4 * (size_t)mesh->n_tets, &de.tets));
-	chk(upload(e, mesh->h_lut_offsets, n_cells + 1, &de.lut_off));
-	chk(upload(e, mesh->h_lut_idx, (size_t)n_idx, &de.lut_idx));
-	chk(upload(e, mesh->h_original_bitfield, (size_t)NRS_BITFIELD_BYTES, &de.orig_bitfield));
-	if (mesh->h_local_rotations) chk(upload(e, mesh->h_local_rotations, 9 * (size_t)mesh->n_tets, &de.rot));
+	// the tables a cage move rewrites are owned individually (not in `allocs`)
+	chk(dev_alloc((void**)&e->d_verts, 12 * (size_t)mesh->n_vertices));
+	chk(dev_alloc((void**)&e->d_lut_off, (n_cells + 1) * 4));
+	if (s == NRS_OK && hipMemcpy(e->d_verts, mesh->h_vertices, 12 * (size_t)mesh->n_vertices, hipMemcpyHostToDevice) != hipSuccess)
+		s = fail(NRS_ERR_HIP, "nrs_edit_create: vertex upload failed");
+	de.verts = e->d_verts;
+	de.lut_off = e->d_lut_off;
+	const bool want_rot = mesh->h_local_rotations != nullptr || mesh->correct_direction != 0;
+	if (want_rot) {
+		chk(dev_alloc((void**)&e->d_rot, 36 * (size_t)mesh->n_tets));
+		de.rot = e->d_rot;
+	}
+	uint8_t* d_orig_bits = nullptr;
+	chk(dev_alloc((void**)&d_orig_bits, NRS_BITFIELD_BYTES));
+	if (d_orig_bits) e->allocs.push_back(d_orig_bits);
+	de.orig_bitfield = d_orig_bits;
 	de.copy = mesh->copy;
 	de.apply_poisson = mesh->apply_poisson;
 	de.residual_amplitude = mesh->residual_amplitude;
@@ -483,13 +566,101 @@ int nrs_edit_create(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_tet_mesh
 		chk(upload(e, mesh->h_boundary_residual_density, (size_t)mesh->n_vertices, &de.res_density));
 	}
 	if (s != NRS_OK) { nrs_edit_destroy(e); return s; }
+	auto bail = [&](int st) { nrs_edit_destroy(e); return st; };
+	// touched cells of the CANONICAL mesh (build_original_tet_grid, tet_mesh.cu:76): handed over, or built here
+	if (mesh->h_original_bitfield) {
+		if (hipMemcpy(d_orig_bits, mesh->h_original_bitfield, NRS_BITFIELD_BYTES, hipMemcpyHostToDevice) != hipSuccess)
+			return bail(fail(NRS_ERR_HIP, "nrs_edit_create: bitfield upload failed"));
+	} else {
+		int st = build_lut_on_device(e, de.orig, d_orig_bits, nullptr);
+		if (st != NRS_OK) return bail(st);
+	}
+	if (host_lut) {
+		hipError_t he = hipMemcpy(e->d_lut_off, mesh->h_lut_offsets, (n_cells + 1) * 4, hipMemcpyHostToDevice);
+		(void)hipFree(e->d_lut_idx); // (a canonical-mesh build above may have left its list here)
+		e->d_lut_idx = nullptr;
+		if (he == hipSuccess) he = hipMalloc((void**)&e->d_lut_idx, std::max<size_t>((size_t)n_idx * 4, 16));
+		if (he == hipSuccess && n_idx) he = hipMemcpy(e->d_lut_idx, mesh->h_lut_idx, (size_t)n_idx * 4, hipMemcpyHostToDevice);
+		if (he != hipSuccess) return bail(fail_hip(he, "nrs_edit_create: LUT upload"));
+		e->lut_idx_cap = n_idx;
+		e->lut_n_idx = n_idx;
+		de.lut_idx = e->d_lut_idx;
+		if (mesh->h_local_rotations) {
+			he = hipMemcpy(e->d_rot, mesh->h_local_rotations, 36 * (size_t)mesh->n_tets, hipMemcpyHostToDevice);
+			if (he != hipSuccess) return bail(fail_hip(he, "nrs_edit_create: rotation upload"));
+		} else if (want_rot) {
+			int st = launch_local_rotations(e->n_tets, e->d_verts, de.orig, de.tets, e->d_rot, nullptr);
+			if (st != NRS_OK) return bail((g_err = cage_last_error(), st));
+			if (hipDeviceSynchronize() != hipSuccess) return bail(fail(NRS_ERR_HIP, "nrs_edit_create: rotation kernel failed"));
+		}
+	} else {
+		int st = rebuild_after_vertices(e, nullptr); // LUT (+ rotations) of the deformed mesh, on the device
+		if (st != NRS_OK) return bail(st);
+		if (mesh->h_local_rotations && hipMemcpy(e->d_rot, mesh->h_local_rotations, 36 * (size_t)mesh->n_tets, hipMemcpyHostToDevice) != hipSuccess)
+			return bail(fail(NRS_ERR_HIP, "nrs_edit_create: rotation upload failed"));
+	}
 	*out = e;
 	return NRS_OK;
 }
 void nrs_edit_destroy(nrs_edit* e) {
 	if (!e) return;
 	for (void* p : e->allocs) (void)hipFree(p);
+	(void)hipFree(e->d_verts); (void)hipFree(e->d_lut_off); (void)hipFree(e->d_lut_idx); (void)hipFree(e->d_rot);
+	(void)hipFree(e->d_counts); (void)hipFree(e->d_tile_sums); (void)hipFree(e->d_scratch); (void)hipFree(e->d_mvc); (void)hipFree(e->d_cage);
 	delete e;
+}
+
+// ---- per-move updates --------------------------------------------------------------------------------------------
+int nrs_edit_set_mvc(nrs_edit* e, const float* h_weights, uint32_t n_cage_vertices) {
+	if (!e || !h_weights || n_cage_vertices == 0) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_set_mvc: bad argument");
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	(void)hipFree(e->d_mvc); (void)hipFree(e->d_cage);
+	e->d_mvc = nullptr; e->d_cage = nullptr; e->n_cv = 0;
+	const size_t nw = (size_t)e->n_vertices * n_cage_vertices;
+	HIP_TRY(hipMalloc((void**)&e->d_mvc, nw * 4));
+	HIP_TRY(hipMalloc((void**)&e->d_cage, (size_t)n_cage_vertices * 12));
+	HIP_TRY(hipMemcpy(e->d_mvc, h_weights, nw * 4, hipMemcpyHostToDevice));
+	e->n_cv = n_cage_vertices;
+	return NRS_OK;
+}
+int nrs_edit_update_cage(nrs_edit* e, void* stream, const float* h_cage_vertices, uint32_t n_cage_vertices) {
+	if (!e || !h_cage_vertices) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_update_cage: NULL argument");
+	if (!e->d_mvc) return fail(NRS_ERR_STATE, "nrs_edit_update_cage: MVC weights not set (nrs_edit_set_mvc)");
+	if (n_cage_vertices != e->n_cv) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_update_cage: cage vertex count differs from the MVC weights'");
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	hipStream_t s = (hipStream_t)stream;
+	HIP_TRY(hipMemcpyAsync(e->d_cage, h_cage_vertices, (size_t)n_cage_vertices * 12, hipMemcpyHostToDevice, s));
+	CAGE_TRY(launch_mvc_apply(e->n_vertices, e->n_cv, e->d_mvc, e->d_cage, e->d_verts, s));
+	return rebuild_after_vertices(e, s);
+}
+int nrs_edit_update_vertices(nrs_edit* e, void* stream, const float* h_vertices, uint32_t n_vertices) {
+	if (!e || !h_vertices) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_update_vertices: NULL argument");
+	if (n_vertices != e->n_vertices) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_update_vertices: vertex count differs from the mesh's");
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	hipStream_t s = (hipStream_t)stream;
+	HIP_TRY(hipMemcpyAsync(e->d_verts, h_vertices, (size_t)n_vertices * 12, hipMemcpyHostToDevice, s));
+	return rebuild_after_vertices(e, s);
+}
+int nrs_edit_lut_size(const nrs_edit* e, uint32_t* n_idx, uint32_t* max_per_cell) {
+	if (!e) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_lut_size: NULL argument");
+	if (n_idx) *n_idx = e->lut_n_idx;
+	if (max_per_cell) *max_per_cell = e->lut_max_per_cell;
+	return NRS_OK;
+}
+int nrs_edit_download(nrs_edit* e, float* h_vertices, uint32_t* h_lut_offsets, uint32_t* h_lut_idx, float* h_rotations, uint8_t* h_original_bitfield,
+                      float* h_bbox6) {
+	if (!e) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_download: NULL argument");
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	if (h_vertices) HIP_TRY(hipMemcpy(h_vertices, e->d_verts, (size_t)e->n_vertices * 12, hipMemcpyDeviceToHost));
+	if (h_lut_offsets) HIP_TRY(hipMemcpy(h_lut_offsets, e->d_lut_off, ((size_t)kGridVol * kCascades + 1) * 4, hipMemcpyDeviceToHost));
+	if (h_lut_idx && e->lut_n_idx) HIP_TRY(hipMemcpy(h_lut_idx, e->d_lut_idx, (size_t)e->lut_n_idx * 4, hipMemcpyDeviceToHost));
+	if (h_rotations) {
+		if (!e->d_rot) return fail(NRS_ERR_STATE, "nrs_edit_download: the edit has no local rotations");
+		HIP_TRY(hipMemcpy(h_rotations, e->d_rot, (size_t)e->n_tets * 36, hipMemcpyDeviceToHost));
+	}
+	if (h_original_bitfield) HIP_TRY(hipMemcpy(h_original_bitfield, e->de.orig_bitfield, NRS_BITFIELD_BYTES, hipMemcpyDeviceToHost));
+	if (h_bbox6) { memcpy(h_bbox6, e->de.bbox.mn, 12); memcpy(h_bbox6 + 3, e->de.bbox.mx, 12); }
+	return NRS_OK;
 }
 int nrs_edit_map_rays(nrs_edit* e, void* stream, uint32_t n, float* d_coords, uint8_t* d_empty_mask) {
 	if (!e || !d_coords || !d_empty_mask) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_map_rays: NULL argument");

@@ -1,0 +1,360 @@
+// nrs_cage.hip -- the per-gizmo-move chain of a cage edit, on the device.
+//
+// In the reference every cage move runs on the CPU and re-uploads ~45 MB (tet_mesh.cu:651-667):
+//   Cage::interpolate_with_mvc        src/editing/datastructures/cage.cu:38        V_tet x V_cage weights applied to the cage
+//   TetMesh::post_update_vertices     tet_mesh.cu:12-20                            bbox of the deformed vertices
+//   TetMesh::build_tet_grid           tet_mesh.cu:368-673                          cell -> tet CSR over 5 x 128^3 cells
+//   TetMesh::update_local_rotations   tet_mesh.cu:37-74                            per-tet rotation for the view direction
+// Here the tables never leave HBM: count -> scan -> fill -> per-cell sort, all integer-exact against the host builder
+// (nrs_authoring.cpp) and the oracle (oracle/nrs_oracle.cpp build_tet_lut): same float tests in the same operation order
+// (-ffp-contract=off), and each cell lists its tets in ascending index, the order the reference's merge produces.
+//
+// Kernels are HBM/latency-bound integer work: one wave per (tet, cascade) strides over the cells of the tet's bounding
+// box; the CSR scan streams the 42 MB count array twice.  Nothing here is GEMM-shaped.
+#include <hip/hip_runtime.h>
+#include "nrs_internal.h"
+#include "nrs_device.cuh"
+
+namespace nrs {
+
+static thread_local char g_cage_err[512];
+const char* cage_last_error() { return g_cage_err; }
+#define NRS_CAGE_CHECK(what)                                                                          \
+	do {                                                                                              \
+		hipError_t e_ = hipGetLastError();                                                            \
+		if (e_ != hipSuccess) {                                                                       \
+			snprintf(g_cage_err, sizeof(g_cage_err), "%s: %s", what, hipGetErrorString(e_));          \
+			return NRS_ERR_HIP;                                                                       \
+		}                                                                                             \
+	} while (0)
+
+constexpr uint32_t kCells = kGridVol * kCascades;
+constexpr uint32_t kScanTile = 4096; // cells per scan block: 256 threads x 16
+static_assert(kCells % kScanTile == 0, "scan tiles must cover the cell array exactly");
+constexpr uint32_t kScanTiles = kCells / kScanTile; // 2560
+
+// ---- Cage::interpolate_with_mvc (cage.cu:38-49): points[i] = sum_v w[i][v] * cage[v], v ascending, per component ----------
+__global__ void mvc_apply_kernel(uint32_t n_points, uint32_t n_cv, const float* __restrict__ weights, const float* __restrict__ cage,
+                                 float* __restrict__ points) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_points) return;
+	f3 p = mk3(0.f, 0.f, 0.f);
+	const float* w = weights + (size_t)i * n_cv;
+	for (uint32_t v = 0; v < n_cv; ++v) {
+		const float wv = w[v];
+		p = p + mk3(wv * cage[3 * v], wv * cage[3 * v + 1], wv * cage[3 * v + 2]);
+	}
+	points[3 * i] = p.x; points[3 * i + 1] = p.y; points[3 * i + 2] = p.z;
+}
+
+// ---- bbox of the vertices (min/max are order-independent => exact) -> out[0..2] = min, out[3..5] = max ----------------------
+__global__ void bbox_kernel(uint32_t n, const float* __restrict__ v, float* __restrict__ out) {
+	__shared__ float lo[3][256], hi[3][256];
+	const float inf = __builtin_huge_valf();
+	float l[3] = {inf, inf, inf}, h[3] = {-inf, -inf, -inf};
+	for (uint32_t i = threadIdx.x; i < n; i += 256)
+		for (int k = 0; k < 3; ++k) { l[k] = fminf(l[k], v[3 * i + k]); h[k] = fmaxf(h[k], v[3 * i + k]); }
+	for (int k = 0; k < 3; ++k) { lo[k][threadIdx.x] = l[k]; hi[k][threadIdx.x] = h[k]; }
+	__syncthreads();
+	for (int s = 128; s > 0; s >>= 1) {
+		if ((int)threadIdx.x < s)
+			for (int k = 0; k < 3; ++k) {
+				lo[k][threadIdx.x] = fminf(lo[k][threadIdx.x], lo[k][threadIdx.x + s]);
+				hi[k][threadIdx.x] = fmaxf(hi[k][threadIdx.x], hi[k][threadIdx.x + s]);
+			}
+		__syncthreads();
+	}
+	if (threadIdx.x < 3) { out[threadIdx.x] = lo[threadIdx.x][0]; out[3 + threadIdx.x] = hi[threadIdx.x][0]; }
+}
+
+// ---- cell / tet intersection tests of build_tet_grid (tet_mesh.cu:402-470) -------------------------------------------------
+__device__ __forceinline__ float comp3(const f3& p, int i) { return i == 0 ? p.x : (i == 1 ? p.y : p.z); }
+__device__ __forceinline__ void span3(const f3* pts, int n, f3 axis, float& lo, float& hi) {
+	lo = __builtin_huge_valf();
+	hi = -lo;
+	for (int i = 0; i < n; ++i) {
+		const float v = dot3(axis, pts[i]);
+		if (v < lo) lo = v;
+		if (v > hi) hi = v;
+	}
+}
+// BoundingBox::intersects(Triangle), bounding_box.cuh:126-178: separating axes = 3 box normals, the triangle normal, 9 edge x axis
+__device__ bool cube_hits_triangle(f3 bmin, f3 bmax, f3 a, f3 b, f3 c) {
+	const f3 axes[3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+	const f3 tri[3] = {a, b, c};
+	float tlo, thi, blo, bhi;
+	for (int i = 0; i < 3; ++i) {
+		span3(tri, 3, axes[i], tlo, thi);
+		if (thi < comp3(bmin, i) || tlo > comp3(bmax, i)) return false;
+	}
+	f3 n = cross3(b - a, c - a);
+	const float len = sqrtf(dot3(n, n));
+	n = {n.x / len, n.y / len, n.z / len};
+	const f3 corners[8] = {{bmin.x, bmin.y, bmin.z}, {bmin.x, bmin.y, bmax.z}, {bmin.x, bmax.y, bmin.z}, {bmin.x, bmax.y, bmax.z},
+	                       {bmax.x, bmin.y, bmin.z}, {bmax.x, bmin.y, bmax.z}, {bmax.x, bmax.y, bmin.z}, {bmax.x, bmax.y, bmax.z}};
+	const float off = dot3(n, a);
+	span3(corners, 8, n, blo, bhi);
+	if (bhi < off || blo > off) return false;
+	const f3 edges[3] = {a - b, a - c, b - c};
+	for (int i = 0; i < 3; ++i)
+		for (int j = 0; j < 3; ++j) {
+			const f3 ax = cross3(edges[i], axes[j]);
+			span3(corners, 8, ax, blo, bhi);
+			span3(tri, 3, ax, tlo, thi);
+			if (bhi < tlo || blo > thi) return false;
+		}
+	return true;
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t)(127 + e) << 23); } // scalbnf(1, e), |e| <= 4
+__device__ __forceinline__ void cell_of(f3 p, uint32_t level, int out[3]) { // get_cell_at_pos, selection_utils.cu:70-83
+	const float s = pow2f(-(int)level);
+	p = p - mk3(0.5f, 0.5f, 0.5f);
+	p = p * s;
+	p = p + mk3(0.5f, 0.5f, 0.5f);
+	out[0] = clampi_((int)(p.x * (float)kGrid), 0, kGrid - 1);
+	out[1] = clampi_((int)(p.y * (float)kGrid), 0, kGrid - 1);
+	out[2] = clampi_((int)(p.z * (float)kGrid), 0, kGrid - 1);
+}
+__device__ __forceinline__ f3 cell_centre(uint32_t x, uint32_t y, uint32_t z, uint32_t level) { // get_cell_pos, selection_utils.cu:65-68
+	const float s = pow2f((int)level);
+	return {(((float)x + 0.5f) / (float)kGrid - 0.5f) * s + 0.5f, (((float)y + 0.5f) / (float)kGrid - 0.5f) * s + 0.5f,
+	        (((float)z + 0.5f) / (float)kGrid - 0.5f) * s + 0.5f};
+}
+__device__ bool cell_meets_tet(const f3 tv[4], uint32_t x, uint32_t y, uint32_t z, uint32_t level) {
+	const float kC[8][3] = {{-0.5f, -0.5f, -0.5f}, {-0.5f, -0.5f, 0.5f}, {-0.5f, 0.5f, -0.5f}, {0.5f, -0.5f, -0.5f},
+	                        {0.5f, 0.5f, -0.5f}, {-0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.5f, 0.5f, 0.5f}}; // tet_mesh.h:34-43
+	const float cell = pow2f((int)level) * (1.0f / (float)kGrid);
+	const f3 ctr = cell_centre(x, y, z, level);
+	for (int k = 0; k < 8; ++k)
+		if (point_in_tet(tv[0], tv[1], tv[2], tv[3], ctr + mk3(kC[k][0], kC[k][1], kC[k][2]) * cell)) return true;
+	const f3 h = mk3(0.5f, 0.5f, 0.5f) * cell;
+	const f3 a = ctr - h, b = ctr + h;
+	const f3 bmin = {fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)};
+	const f3 bmax = {fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)};
+	for (int j = 0; j < 4; ++j)
+		if (cube_hits_triangle(bmin, bmax, tv[j], tv[(j + 1) & 3], tv[(j + 2) & 3])) return true;
+	return false;
+}
+
+// One wave per (tet, cascade); lanes stride over the cells of the tet's bounding box at that cascade.
+// FILL == false: counts[cell] += 1.   FILL == true: idx[offsets[cell] + --counts[cell]] = tet (leaves counts zeroed).
+template <bool FILL>
+__global__ __launch_bounds__(256) void tet_mark_kernel(uint32_t n_tets, const float* __restrict__ verts, const uint32_t* __restrict__ tets,
+                                                        uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                                                        uint32_t* __restrict__ idx) {
+	const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (w >= n_tets * kCascades) return;
+	const uint32_t t = w / kCascades, level = w % kCascades;
+	const uint4 tvid = reinterpret_cast<const uint4*>(tets)[t];
+	const f3 tv[4] = {ld3(verts, tvid.x), ld3(verts, tvid.y), ld3(verts, tvid.z), ld3(verts, tvid.w)};
+	f3 lo = tv[0], hi = tv[0];
+	for (int j = 1; j < 4; ++j) {
+		lo = {fminf(lo.x, tv[j].x), fminf(lo.y, tv[j].y), fminf(lo.z, tv[j].z)};
+		hi = {fmaxf(hi.x, tv[j].x), fmaxf(hi.y, tv[j].y), fmaxf(hi.z, tv[j].z)};
+	}
+	int c0[3], c1[3];
+	cell_of(lo, level, c0);
+	cell_of(hi, level, c1);
+	const uint32_t ny = (uint32_t)(c1[1] - c0[1] + 1), nz = (uint32_t)(c1[2] - c0[2] + 1);
+	const uint32_t total = (uint32_t)(c1[0] - c0[0] + 1) * ny * nz;
+	for (uint32_t k = (uint32_t)lane; k < total; k += 64) {
+		const uint32_t x = (uint32_t)c0[0] + k / (ny * nz), y = (uint32_t)c0[1] + (k / nz) % ny, z = (uint32_t)c0[2] + k % nz;
+		if (!cell_meets_tet(tv, x, y, z, level)) continue;
+		const uint32_t cell = level * kGridVol + morton3D(x, y, z);
+		if (!FILL) atomicAdd(counts + cell, 1u);
+		else idx[offsets[cell] + (atomicSub(counts + cell, 1u) - 1u)] = t;
+	}
+}
+
+// ---- exclusive scan of counts[kCells] -> offsets[kCells + 1] ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void scan_tile_sum_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ tile_sums) {
+	__shared__ uint32_t part[256];
+	const uint4* src = reinterpret_cast<const uint4*>(counts + (size_t)blockIdx.x * kScanTile) + threadIdx.x * 4;
+	uint32_t s = 0;
+	#pragma unroll
+	for (int q = 0; q < 4; ++q) { const uint4 v = src[q]; s += v.x + v.y + v.z + v.w; }
+	part[threadIdx.x] = s;
+	__syncthreads();
+	for (int st = 128; st > 0; st >>= 1) {
+		if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) tile_sums[blockIdx.x] = part[0];
+}
+// one block: tile_sums -> exclusive prefix in place; total -> offsets[kCells] and scratch_total
+__global__ __launch_bounds__(1024) void scan_tile_prefix_kernel(uint32_t* __restrict__ tile_sums, uint32_t* __restrict__ offsets_last,
+                                                                 uint32_t* __restrict__ total_out) {
+	__shared__ uint32_t part[1024];
+	constexpr uint32_t per = (kScanTiles + 1023) / 1024;
+	uint32_t v[per], s = 0;
+	for (uint32_t q = 0; q < per; ++q) {
+		const uint32_t i = threadIdx.x * per + q;
+		v[q] = i < kScanTiles ? tile_sums[i] : 0u;
+		s += v[q];
+	}
+	part[threadIdx.x] = s;
+	__syncthreads();
+	for (uint32_t d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan
+		const uint32_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+		__syncthreads();
+		part[threadIdx.x] += add;
+		__syncthreads();
+	}
+	uint32_t run = part[threadIdx.x] - s;
+	for (uint32_t q = 0; q < per; ++q) {
+		const uint32_t i = threadIdx.x * per + q;
+		if (i < kScanTiles) tile_sums[i] = run;
+		run += v[q];
+	}
+	if (threadIdx.x == 1023) { *offsets_last = part[1023]; *total_out = part[1023]; }
+}
+__global__ __launch_bounds__(256) void scan_write_kernel(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ tile_prefix,
+                                                          uint32_t* __restrict__ offsets) {
+	__shared__ uint32_t part[256];
+	const size_t base = (size_t)blockIdx.x * kScanTile + threadIdx.x * 16;
+	const uint4* src = reinterpret_cast<const uint4*>(counts + base);
+	uint32_t c[16], s = 0;
+	#pragma unroll
+	for (int q = 0; q < 4; ++q) { const uint4 v = src[q]; c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w; }
+	#pragma unroll
+	for (int q = 0; q < 16; ++q) s += c[q];
+	part[threadIdx.x] = s;
+	__syncthreads();
+	for (uint32_t d = 1; d < 256; d <<= 1) {
+		const uint32_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+		__syncthreads();
+		part[threadIdx.x] += add;
+		__syncthreads();
+	}
+	uint32_t run = tile_prefix[blockIdx.x] + part[threadIdx.x] - s;
+	uint4* dst = reinterpret_cast<uint4*>(offsets + base);
+	#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		uint4 o;
+		o.x = run; run += c[4 * q];
+		o.y = run; run += c[4 * q + 1];
+		o.z = run; run += c[4 * q + 2];
+		o.w = run; run += c[4 * q + 3];
+		dst[q] = o;
+	}
+}
+
+// ---- per byte of the touched-cell bitfield: sort each of its 8 cells' tet lists ascending, emit the byte, track the maximum ----
+__global__ __launch_bounds__(256) void lut_finish_kernel(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx,
+                                                          uint8_t* __restrict__ bitfield, uint32_t* __restrict__ max_per_cell) {
+	const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; // kCells / 8 bytes, grid sized exactly
+	uint32_t o[9];
+	#pragma unroll
+	for (int q = 0; q < 9; ++q) o[q] = offsets[(size_t)b * 8 + q];
+	uint32_t bits = 0, mx = 0;
+	if (o[8] != o[0]) {
+		for (int q = 0; q < 8; ++q) {
+			const uint32_t n = o[q + 1] - o[q];
+			if (n == 0) continue;
+			bits |= 1u << q;
+			mx = max(mx, n);
+			uint32_t* a = idx + o[q];
+			for (uint32_t i = 1; i < n; ++i) { // insertion sort; lists are short (max_tet_lookup, tet_mesh.h:69)
+				const uint32_t key = a[i];
+				uint32_t j = i;
+				while (j > 0 && a[j - 1] > key) { a[j] = a[j - 1]; --j; }
+				a[j] = key;
+			}
+		}
+	}
+	if (bitfield) bitfield[b] = (uint8_t)bits;
+	if (mx) atomicMax(max_per_cell, mx);
+}
+
+// ---- TetMesh::update_local_rotations (tet_mesh.cu:37-74): R = polar factor of sum (orig - c0)(def - c1)^T ---------------------
+// Higham's scaled Newton iteration in double, the same sequence of operations as nrs_authoring.cpp's polar_rotation.
+__device__ void polar_rotation(const double C[9], double R[9]) {
+	double X[9];
+	for (int i = 0; i < 9; ++i) X[i] = C[i];
+	for (int it = 0; it < 100; ++it) {
+		const double d = X[0] * (X[4] * X[8] - X[7] * X[5]) - X[3] * (X[1] * X[8] - X[7] * X[2]) + X[6] * (X[1] * X[5] - X[4] * X[2]);
+		if (fabs(d) < 1e-300) {
+			for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+			return;
+		}
+		double inv_t[9];
+		inv_t[0] = (X[4] * X[8] - X[7] * X[5]) / d; inv_t[3] = (X[7] * X[2] - X[1] * X[8]) / d; inv_t[6] = (X[1] * X[5] - X[4] * X[2]) / d;
+		inv_t[1] = (X[6] * X[5] - X[3] * X[8]) / d; inv_t[4] = (X[0] * X[8] - X[6] * X[2]) / d; inv_t[7] = (X[3] * X[2] - X[0] * X[5]) / d;
+		inv_t[2] = (X[3] * X[7] - X[6] * X[4]) / d; inv_t[5] = (X[6] * X[1] - X[0] * X[7]) / d; inv_t[8] = (X[0] * X[4] - X[3] * X[1]) / d;
+		double nx = 0, ni = 0;
+		for (int i = 0; i < 9; ++i) { nx += X[i] * X[i]; ni += inv_t[i] * inv_t[i]; }
+		const double gamma = sqrt(sqrt(ni / nx));
+		double diff = 0;
+		for (int i = 0; i < 9; ++i) {
+			const double nv = 0.5 * (gamma * X[i] + inv_t[i] / gamma);
+			diff = fmax(diff, fabs(nv - X[i]));
+			X[i] = nv;
+		}
+		if (diff < 1e-14) break;
+	}
+	for (int i = 0; i < 9; ++i) R[i] = X[i];
+}
+__global__ void local_rotations_kernel(uint32_t n_tets, const float* __restrict__ def, const float* __restrict__ org,
+                                       const uint32_t* __restrict__ tets, float* __restrict__ out) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_tets) return;
+	const uint4 tv = reinterpret_cast<const uint4*>(tets)[i];
+	const uint32_t id[4] = {tv.x, tv.y, tv.z, tv.w};
+	f3 c0 = mk3(0, 0, 0), c1 = mk3(0, 0, 0);
+	for (int j = 0; j < 4; ++j) { c0 = c0 + ld3(org, id[j]); c1 = c1 + ld3(def, id[j]); }
+	c0 = {c0.x / 4.f, c0.y / 4.f, c0.z / 4.f};
+	c1 = {c1.x / 4.f, c1.y / 4.f, c1.z / 4.f};
+	double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	for (int j = 0; j < 4; ++j) {
+		const f3 a = ld3(org, id[j]) - c0, b = ld3(def, id[j]) - c1;
+		const float av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
+		for (int r = 0; r < 3; ++r)
+			for (int c = 0; c < 3; ++c) C[3 * c + r] += (double)(av[r] * bv[c]);
+	}
+	double R[9];
+	polar_rotation(C, R);
+	for (int k = 0; k < 9; ++k) out[9 * (size_t)i + k] = (float)R[k];
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------------------
+int launch_mvc_apply(uint32_t n_points, uint32_t n_cv, const float* d_weights, const float* d_cage, float* d_points, void* stream) {
+	hipLaunchKernelGGL(mvc_apply_kernel, dim3((n_points + 127) / 128), dim3(128), 0, (hipStream_t)stream, n_points, n_cv, d_weights, d_cage, d_points);
+	NRS_CAGE_CHECK("mvc_apply_kernel launch");
+	return NRS_OK;
+}
+int launch_bbox(uint32_t n, const float* d_verts, float* d_out6, void* stream) {
+	hipLaunchKernelGGL(bbox_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n, d_verts, d_out6);
+	NRS_CAGE_CHECK("bbox_kernel launch");
+	return NRS_OK;
+}
+// counts must be all zero on entry (it is again on exit of launch_lut_fill).  Writes offsets[kCells + 1] and *d_total.
+int launch_lut_count_scan(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, uint32_t* d_tile_sums,
+                          uint32_t* d_offsets, uint32_t* d_total, void* stream) {
+	hipStream_t s = (hipStream_t)stream;
+	const uint32_t n_waves = n_tets * kCascades;
+	hipLaunchKernelGGL(tet_mark_kernel<false>, dim3((n_waves + 3) / 4), dim3(256), 0, s, n_tets, d_verts, d_tets, d_counts, (const uint32_t*)nullptr,
+	                   (uint32_t*)nullptr);
+	hipLaunchKernelGGL(scan_tile_sum_kernel, dim3(kScanTiles), dim3(256), 0, s, d_counts, d_tile_sums);
+	hipLaunchKernelGGL(scan_tile_prefix_kernel, dim3(1), dim3(1024), 0, s, d_tile_sums, d_offsets + kCells, d_total);
+	hipLaunchKernelGGL(scan_write_kernel, dim3(kScanTiles), dim3(256), 0, s, d_counts, d_tile_sums, d_offsets);
+	NRS_CAGE_CHECK("tet LUT count/scan launch");
+	return NRS_OK;
+}
+// d_max_per_cell must be zeroed by the caller; d_bitfield may be NULL
+int launch_lut_fill(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, const uint32_t* d_offsets, uint32_t* d_idx,
+                    uint8_t* d_bitfield, uint32_t* d_max_per_cell, void* stream) {
+	hipStream_t s = (hipStream_t)stream;
+	const uint32_t n_waves = n_tets * kCascades;
+	hipLaunchKernelGGL(tet_mark_kernel<true>, dim3((n_waves + 3) / 4), dim3(256), 0, s, n_tets, d_verts, d_tets, d_counts, d_offsets, d_idx);
+	hipLaunchKernelGGL(lut_finish_kernel, dim3(kCells / 8 / 256), dim3(256), 0, s, d_offsets, d_idx, d_bitfield, d_max_per_cell);
+	NRS_CAGE_CHECK("tet LUT fill launch");
+	return NRS_OK;
+}
+int launch_local_rotations(uint32_t n_tets, const float* d_verts, const float* d_orig, const uint32_t* d_tets, float* d_out, void* stream) {
+	hipLaunchKernelGGL(local_rotations_kernel, dim3((n_tets + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_tets, d_verts, d_orig, d_tets, d_out);
+	NRS_CAGE_CHECK("local_rotations_kernel launch");
+	return NRS_OK;
+}
+
+} // namespace nrs

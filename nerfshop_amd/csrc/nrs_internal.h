@@ -114,4 +114,15 @@ int launch_detile(const nrs_render_params& p, uint32_t n_ranks, uint32_t tiles_p
                   uint32_t channels, float* d_image, void* stream);
 const char* launch_last_error();
 
+// cage-move chain on the device (nrs_cage.hip)
+constexpr uint32_t kLutScanTiles = kGridVol * kCascades / 4096;
+int launch_mvc_apply(uint32_t n_points, uint32_t n_cv, const float* d_weights, const float* d_cage, float* d_points, void* stream);
+int launch_bbox(uint32_t n, const float* d_verts, float* d_out6, void* stream);
+int launch_lut_count_scan(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, uint32_t* d_tile_sums,
+                          uint32_t* d_offsets, uint32_t* d_total, void* stream);
+int launch_lut_fill(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, const uint32_t* d_offsets, uint32_t* d_idx,
+                    uint8_t* d_bitfield, uint32_t* d_max_per_cell, void* stream);
+int launch_local_rotations(uint32_t n_tets, const float* d_verts, const float* d_orig, const uint32_t* d_tets, float* d_out, void* stream);
+const char* cage_last_error();
+
 } // namespace nrs

@@ -159,12 +159,47 @@ class NerfNetwork:
 class CageDeformation:
     """One cage-deformation edit operator; owns its GPU tables (tet_mesh.h:80-94)."""
 
-    def __init__(self, ctx, desc, cage_edit):
+    def __init__(self, ctx, desc, cage_edit, device_authoring=False):
         self.ctx, self.lib = ctx, ctx.lib
         self.host = cage_edit  # keeps the numpy arrays alive
         self.h = C.c_void_p()
-        mesh = cage_edit.tet_mesh_struct()
+        mesh = cage_edit.tet_mesh_struct(device_authoring) if device_authoring else cage_edit.tet_mesh_struct()
+        self.n_vertices, self.n_tets = int(mesh.n_vertices), int(mesh.n_tets)
         check(self.lib.nrs_edit_create(ctx.h, C.byref(desc), C.byref(mesh), C.byref(self.h)))
+
+    # ---- the per-gizmo-move chain on the device (nrs.h "next" row f1) ----
+    def set_mvc(self, weights):
+        """Cage::compute_mvc's [V, n_cage_vertices] weights, uploaded once."""
+        w = np.ascontiguousarray(weights, np.float32)
+        if w.ndim != 2 or w.shape[0] != self.n_vertices:
+            raise NrsError("set_mvc expects weights [n_vertices, n_cage_vertices]")
+        check(self.lib.nrs_edit_set_mvc(self.h, w.ctypes.data, w.shape[1]))
+
+    def update_cage(self, stream, cage_vertices):
+        """Cage::interpolate_with_mvc + post_update_vertices + build_tet_grid + update_local_rotations for a moved cage."""
+        c = np.ascontiguousarray(cage_vertices, np.float32)
+        check(self.lib.nrs_edit_update_cage(self.h, _stream_handle(stream), c.ctypes.data, c.shape[0]))
+
+    def update_vertices(self, stream, vertices):
+        v = np.ascontiguousarray(vertices, np.float32)
+        check(self.lib.nrs_edit_update_vertices(self.h, _stream_handle(stream), v.ctypes.data, v.shape[0]))
+
+    def lut_size(self):
+        n, m = C.c_uint32(), C.c_uint32()
+        check(self.lib.nrs_edit_lut_size(self.h, C.byref(n), C.byref(m)))
+        return n.value, m.value
+
+    def download(self, rotations=True):
+        """-> dict(vertices, lut_offsets, lut_idx, rotations | None, original_bitfield, bbox)"""
+        n_idx, _ = self.lut_size()
+        out = dict(vertices=np.zeros((self.n_vertices, 3), np.float32), lut_offsets=np.zeros(_abi.N_LUT_CELLS + 1, np.uint32),
+                   lut_idx=np.zeros(max(n_idx, 1), np.uint32), rotations=np.zeros((self.n_tets, 9), np.float32) if rotations else None,
+                   original_bitfield=np.zeros(_abi.BITFIELD_BYTES, np.uint8), bbox=np.zeros(6, np.float32))
+        check(self.lib.nrs_edit_download(self.h, out["vertices"].ctypes.data, out["lut_offsets"].ctypes.data, out["lut_idx"].ctypes.data,
+                                         out["rotations"].ctypes.data if rotations else None, out["original_bitfield"].ctypes.data,
+                                         out["bbox"].ctypes.data))
+        out["lut_idx"] = out["lut_idx"][:n_idx]
+        return out
 
     def map_rays(self, stream, nerf_coords, empty_mask):
         _require_cuda(nerf_coords, torch.float32, "nerf_coords")

@@ -362,16 +362,22 @@ class CageEdit:
     def __init__(self, **kw):
         self.__dict__.update(kw)
 
-    def tet_mesh_struct(self):
+    def tet_mesh_struct(self, device_authoring=False):
+        """device_authoring=True hands over only vertices + tets: libnrs builds the LUT, the canonical bitfield and the
+        local rotations on the device (nrs.h, "next" row f1)."""
         m = TetMesh()
         m.n_vertices, m.n_tets = self.vertices.shape[0], self.tets.shape[0]
         m.h_vertices = self.vertices.ctypes.data
         m.h_original_vertices = self.original_vertices.ctypes.data
         m.h_tets = self.tets.ctypes.data
-        m.h_lut_offsets = self.lut_offsets.ctypes.data
-        m.h_lut_idx = self.lut_idx.ctypes.data
-        m.h_original_bitfield = self.original_bitfield.ctypes.data
-        m.h_local_rotations = self.local_rotations.ctypes.data if self.local_rotations is not None else None
+        if device_authoring:
+            m.h_lut_offsets = m.h_lut_idx = m.h_original_bitfield = m.h_local_rotations = None
+            m.correct_direction = 1 if self.local_rotations is not None else 0
+        else:
+            m.h_lut_offsets = self.lut_offsets.ctypes.data
+            m.h_lut_idx = self.lut_idx.ctypes.data
+            m.h_original_bitfield = self.original_bitfield.ctypes.data
+            m.h_local_rotations = self.local_rotations.ctypes.data if self.local_rotations is not None else None
         m.copy = 1 if self.copy else 0
         shs = getattr(self, "boundary_shs", None)
         if shs is not None:  # membrane ("Poisson") correction, cage_deformation.h:163
