@@ -75,7 +75,8 @@ struct nrs_edit {
 	float* d_rot = nullptr;            // == de.rot when rotations are on
 	uint32_t* d_counts = nullptr;      // [5*128^3], all zero between builds
 	uint32_t* d_tile_sums = nullptr;
-	uint32_t* d_scratch = nullptr;     // [0..5] bbox (float bits), [6] total entries, [7] max tets per cell
+	uint32_t* d_scratch = nullptr;     // [0..5] bbox (float bits), [6] total entries, [7] max tets per cell, [8] long-list counter
+	uint32_t* d_big_cells = nullptr;   // worklist of cells with long tet lists (sized with d_lut_idx)
 	float* d_mvc = nullptr;            // [V x n_cv] weights
 	float* d_cage = nullptr;           // [n_cv x 3]
 	uint32_t n_cv = 0;
@@ -481,17 +482,19 @@ static int build_lut_on_device(nrs_edit* e, const float* d_verts, uint8_t* d_bit
 	uint32_t total = 0;
 	HIP_TRY(hipMemcpyAsync(&total, e->d_scratch + 6, 4, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
-	if ((size_t)total > e->lut_idx_cap) {
+	if ((size_t)total > e->lut_idx_cap || !e->d_big_cells) {
 		const size_t cap = std::max<size_t>((size_t)total + total / 2, 1024);
-		uint32_t* fresh = nullptr;
+		uint32_t *fresh = nullptr, *fresh_big = nullptr;
 		HIP_TRY(hipMalloc((void**)&fresh, cap * 4));
+		HIP_TRY(hipMalloc((void**)&fresh_big, (size_t)lut_big_list_capacity(cap) * 4));
 		(void)hipFree(e->d_lut_idx);
+		(void)hipFree(e->d_big_cells);
 		e->d_lut_idx = fresh;
+		e->d_big_cells = fresh_big;
 		e->lut_idx_cap = cap;
 		e->de.lut_idx = fresh;
 	}
-	HIP_TRY(hipMemsetAsync(e->d_scratch + 7, 0, 4, s));
-	CAGE_TRY(launch_lut_fill(e->n_tets, d_verts, e->de.tets, e->d_counts, e->d_lut_off, e->d_lut_idx, d_bitfield_out, e->d_scratch + 7, s));
+	CAGE_TRY(launch_lut_fill(e->n_tets, d_verts, e->de.tets, e->d_counts, e->d_lut_off, e->d_lut_idx, d_bitfield_out, e->d_scratch + 7, e->d_big_cells, s));
 	e->lut_n_idx = total;
 	return NRS_OK;
 }
@@ -578,7 +581,9 @@ int nrs_edit_create(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_tet_mesh
 	if (host_lut) {
 		hipError_t he = hipMemcpy(e->d_lut_off, mesh->h_lut_offsets, (n_cells + 1) * 4, hipMemcpyHostToDevice);
 		(void)hipFree(e->d_lut_idx); // (a canonical-mesh build above may have left its list here)
+		(void)hipFree(e->d_big_cells);
 		e->d_lut_idx = nullptr;
+		e->d_big_cells = nullptr; // re-sized together with the list on the next device build
 		if (he == hipSuccess) he = hipMalloc((void**)&e->d_lut_idx, std::max<size_t>((size_t)n_idx * 4, 16));
 		if (he == hipSuccess && n_idx) he = hipMemcpy(e->d_lut_idx, mesh->h_lut_idx, (size_t)n_idx * 4, hipMemcpyHostToDevice);
 		if (he != hipSuccess) return bail(fail_hip(he, "nrs_edit_create: LUT upload"));
@@ -606,7 +611,7 @@ void nrs_edit_destroy(nrs_edit* e) {
 	if (!e) return;
 	for (void* p : e->allocs) (void)hipFree(p);
 	(void)hipFree(e->d_verts); (void)hipFree(e->d_lut_off); (void)hipFree(e->d_lut_idx); (void)hipFree(e->d_rot);
-	(void)hipFree(e->d_counts); (void)hipFree(e->d_tile_sums); (void)hipFree(e->d_scratch); (void)hipFree(e->d_mvc); (void)hipFree(e->d_cage);
+	(void)hipFree(e->d_big_cells); (void)hipFree(e->d_counts); (void)hipFree(e->d_tile_sums); (void)hipFree(e->d_scratch); (void)hipFree(e->d_mvc); (void)hipFree(e->d_cage);
 	delete e;
 }
 

@@ -241,8 +241,12 @@ __global__ __launch_bounds__(256) void scan_write_kernel(const uint32_t* __restr
 }
 
 // ---- per byte of the touched-cell bitfield: sort each of its 8 cells' tet lists ascending, emit the byte, track the maximum ----
+// Lists of up to kSmallList tets are sorted by the thread (insertion sort); longer ones -- the few coarse-cascade cells that
+// contain most of the mesh -- go to a worklist that lut_sort_big_kernel sorts with one workgroup each.
+constexpr uint32_t kSmallList = 24;
 __global__ __launch_bounds__(256) void lut_finish_kernel(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx,
-                                                          uint8_t* __restrict__ bitfield, uint32_t* __restrict__ max_per_cell) {
+                                                          uint8_t* __restrict__ bitfield, uint32_t* __restrict__ max_per_cell,
+                                                          uint32_t* __restrict__ big_cells, uint32_t* __restrict__ n_big) {
 	const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; // kCells / 8 bytes, grid sized exactly
 	uint32_t o[9];
 	#pragma unroll
@@ -254,8 +258,9 @@ __global__ __launch_bounds__(256) void lut_finish_kernel(const uint32_t* __restr
 			if (n == 0) continue;
 			bits |= 1u << q;
 			mx = max(mx, n);
+			if (n > kSmallList) { big_cells[atomicAdd(n_big, 1u)] = b * 8 + q; continue; }
 			uint32_t* a = idx + o[q];
-			for (uint32_t i = 1; i < n; ++i) { // insertion sort; lists are short (max_tet_lookup, tet_mesh.h:69)
+			for (uint32_t i = 1; i < n; ++i) {
 				const uint32_t key = a[i];
 				uint32_t j = i;
 				while (j > 0 && a[j - 1] > key) { a[j] = a[j - 1]; --j; }
@@ -265,6 +270,47 @@ __global__ __launch_bounds__(256) void lut_finish_kernel(const uint32_t* __restr
 	}
 	if (bitfield) bitfield[b] = (uint8_t)bits;
 	if (mx) atomicMax(max_per_cell, mx);
+}
+
+// Normalised bitonic network (every comparator puts the smaller key at the lower index): valid for any n, because the
+// virtual +inf keys at positions >= n never have to move.  Stage k: first step pairs i with its mirror i ^ (k - 1), the
+// remaining steps pair i with i ^ j for j = k/4 .. 1.
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_ascending(Ptr a, uint32_t n, uint32_t tid, uint32_t n_threads) {
+	uint32_t p2 = 1;
+	while (p2 < n) p2 <<= 1;
+	for (uint32_t k = 2; k <= p2; k <<= 1) {
+		for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+			const uint32_t mask = (j == (k >> 1)) ? (k - 1) : j;
+			for (uint32_t i = tid; i < p2; i += n_threads) {
+				const uint32_t l = i ^ mask;
+				if (l > i && l < n) {
+					const uint32_t x = a[i], y = a[l];
+					if (x > y) { a[i] = y; a[l] = x; }
+				}
+			}
+			__syncthreads();
+		}
+	}
+}
+constexpr uint32_t kSortLdsEntries = 16384; // 64 KiB of LDS per workgroup
+__global__ __launch_bounds__(1024) void lut_sort_big_kernel(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx,
+                                                             const uint32_t* __restrict__ big_cells, const uint32_t* __restrict__ n_big) {
+	__shared__ uint32_t sh[kSortLdsEntries];
+	const uint32_t nb = *n_big;
+	for (uint32_t w = blockIdx.x; w < nb; w += gridDim.x) {
+		const uint32_t cell = big_cells[w];
+		const uint32_t o = offsets[cell], n = offsets[cell + 1] - o;
+		if (n <= kSortLdsEntries) {
+			for (uint32_t i = threadIdx.x; i < n; i += 1024) sh[i] = idx[o + i];
+			__syncthreads();
+			bitonic_ascending(sh, n, threadIdx.x, 1024u);
+			for (uint32_t i = threadIdx.x; i < n; i += 1024) idx[o + i] = sh[i];
+			__syncthreads();
+		} else {
+			bitonic_ascending(idx + o, n, threadIdx.x, 1024u); // in HBM/L2: only meshes with > 16 K tets in ONE cell get here
+		}
+	}
 }
 
 // ---- TetMesh::update_local_rotations (tet_mesh.cu:37-74): R = polar factor of sum (orig - c0)(def - c1)^T ---------------------
@@ -341,16 +387,21 @@ int launch_lut_count_scan(uint32_t n_tets, const float* d_verts, const uint32_t*
 	NRS_CAGE_CHECK("tet LUT count/scan launch");
 	return NRS_OK;
 }
-// d_max_per_cell must be zeroed by the caller; d_bitfield may be NULL
+// d_scratch_u32[0] = max tets per cell (out), [1] = big-cell counter; both zeroed here.  d_bitfield may be NULL.
+// d_big_cells: worklist of at least (entries / kSmallList + 1) cells.
 int launch_lut_fill(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, const uint32_t* d_offsets, uint32_t* d_idx,
-                    uint8_t* d_bitfield, uint32_t* d_max_per_cell, void* stream) {
+                    uint8_t* d_bitfield, uint32_t* d_scratch_u32, uint32_t* d_big_cells, void* stream) {
 	hipStream_t s = (hipStream_t)stream;
 	const uint32_t n_waves = n_tets * kCascades;
+	if (hipMemsetAsync(d_scratch_u32, 0, 8, s) != hipSuccess) { snprintf(g_cage_err, sizeof(g_cage_err), "tet LUT fill: memset failed"); return NRS_ERR_HIP; }
 	hipLaunchKernelGGL(tet_mark_kernel<true>, dim3((n_waves + 3) / 4), dim3(256), 0, s, n_tets, d_verts, d_tets, d_counts, d_offsets, d_idx);
-	hipLaunchKernelGGL(lut_finish_kernel, dim3(kCells / 8 / 256), dim3(256), 0, s, d_offsets, d_idx, d_bitfield, d_max_per_cell);
+	hipLaunchKernelGGL(lut_finish_kernel, dim3(kCells / 8 / 256), dim3(256), 0, s, d_offsets, d_idx, d_bitfield, d_scratch_u32, d_big_cells,
+	                   d_scratch_u32 + 1);
+	hipLaunchKernelGGL(lut_sort_big_kernel, dim3(512), dim3(1024), 0, s, d_offsets, d_idx, d_big_cells, d_scratch_u32 + 1);
 	NRS_CAGE_CHECK("tet LUT fill launch");
 	return NRS_OK;
 }
+uint32_t lut_big_list_capacity(size_t idx_capacity) { return (uint32_t)(idx_capacity / kSmallList + 1); }
 int launch_local_rotations(uint32_t n_tets, const float* d_verts, const float* d_orig, const uint32_t* d_tets, float* d_out, void* stream) {
 	hipLaunchKernelGGL(local_rotations_kernel, dim3((n_tets + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_tets, d_verts, d_orig, d_tets, d_out);
 	NRS_CAGE_CHECK("local_rotations_kernel launch");

@@ -121,7 +121,8 @@ int launch_bbox(uint32_t n, const float* d_verts, float* d_out6, void* stream);
 int launch_lut_count_scan(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, uint32_t* d_tile_sums,
                           uint32_t* d_offsets, uint32_t* d_total, void* stream);
 int launch_lut_fill(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, const uint32_t* d_offsets, uint32_t* d_idx,
-                    uint8_t* d_bitfield, uint32_t* d_max_per_cell, void* stream);
+                    uint8_t* d_bitfield, uint32_t* d_scratch_u32, uint32_t* d_big_cells, void* stream);
+uint32_t lut_big_list_capacity(size_t idx_capacity);
 int launch_local_rotations(uint32_t n_tets, const float* d_verts, const float* d_orig, const uint32_t* d_tets, float* d_out, void* stream);
 const char* cage_last_error();
 
