@@ -234,7 +234,7 @@ int nrs_ctx_create(int device, nrs_ctx** out) {
 	snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
 	HIP_TRY(hipMalloc((void**)&c->d_counters, sizeof(RenderCounters)));
 	HIP_TRY(hipMalloc((void**)&c->d_edits, sizeof(DeviceEdit) * nrs_ctx::kMaxEdits));
-	HIP_TRY(hipMalloc((void**)&c->d_mean, 16));
+	HIP_TRY(hipMalloc((void**)&c->d_mean, 8 + 256 * 8)); // mean + partial sums (launch_grid_to_bitfield)
 	HIP_TRY(hipMalloc((void**)&c->d_wave_log, 8192 * 4 * 8));
 	*out = c;
 	return NRS_OK;

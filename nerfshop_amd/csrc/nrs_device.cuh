@@ -427,7 +427,8 @@ struct Pcg32 {
 		return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
 	}
 	__device__ __forceinline__ float next_float() { return __uint_as_float((next_uint() >> 9) | 0x3f800000u) - 1.0f; }
-	__device__ __forceinline__ void advance(uint64_t delta) {
+	// state after `delta` steps = mult * state + plus (mod 2^64)
+	__device__ __forceinline__ static void skip_coefficients(uint64_t inc, uint64_t delta, uint64_t& mult, uint64_t& plus) {
 		uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
 		while (delta > 0) {
 			if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
@@ -435,14 +436,20 @@ struct Pcg32 {
 			cur_mult *= cur_mult;
 			delta >>= 1;
 		}
-		state = acc_mult * state + acc_plus;
+		mult = acc_mult;
+		plus = acc_plus;
+	}
+	__device__ __forceinline__ void advance(uint64_t delta) {
+		uint64_t m, p;
+		skip_coefficients(inc, delta, m, p);
+		state = m * state + p;
 	}
 };
 
 // generate_grid_samples_nerf_nonuniform, cn:179-208: cell index + a uniformly random warped position inside that cell
+// `rng` arrives already advanced by 4 * i (the kernel splits that skip into a wave-uniform and a per-lane part).
 __device__ __forceinline__ uint32_t generate_grid_sample(Pcg32 rng, uint32_t i, uint32_t n_elements, uint32_t step, const Box3& aabb,
                                                          const float* __restrict__ grid_in, uint32_t n_cascades, float thresh, f3& wpos) {
-	rng.advance((uint64_t)(i * 4u));
 	const uint32_t level = (uint32_t)(rng.next_float() * n_cascades) % n_cascades;
 	uint32_t idx = 0;
 	#pragma unroll 1

@@ -525,14 +525,27 @@ int launch_map_rays(const DeviceEdit& e, uint32_t n, float* d_coords, uint32_t l
 }
 
 // ---- density grid -> bitfield (tn:514-555, 3642-3657) ----------------------------------------------------------------------
-__global__ void grid_mean_kernel(const float* __restrict__ grid, float* __restrict__ mean_out) {
-	// one block, fixed summation order: deterministic.  mean of max(v, 0) / n over level 0.
-	__shared__ double part[1024];
+// mean of max(v, 0) / n over cascade 0 (tn:3650), in double, in a fixed two-stage order: deterministic.
+constexpr uint32_t kMeanBlocks = 256;
+__global__ __launch_bounds__(256) void grid_mean_partial_kernel(const float* __restrict__ grid, double* __restrict__ partial) {
+	__shared__ double part[256];
 	double acc = 0.0;
-	for (uint32_t i = threadIdx.x; i < kGridVol; i += 1024) acc += (double)(fmaxf(grid[i], 0.f) / (float)kGridVol);
+	const uint32_t per = kGridVol / kMeanBlocks; // 8192 contiguous cells per block
+	const float* g = grid + (size_t)blockIdx.x * per;
+	for (uint32_t i = threadIdx.x; i < per; i += 256) acc += (double)(fmaxf(g[i], 0.f) / (float)kGridVol);
 	part[threadIdx.x] = acc;
 	__syncthreads();
-	for (int s = 512; s > 0; s >>= 1) {
+	for (int s = 128; s > 0; s >>= 1) {
+		if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) partial[blockIdx.x] = part[0];
+}
+__global__ __launch_bounds__(256) void grid_mean_final_kernel(const double* __restrict__ partial, float* __restrict__ mean_out) {
+	__shared__ double part[256];
+	part[threadIdx.x] = partial[threadIdx.x];
+	__syncthreads();
+	for (int s = 128; s > 0; s >>= 1) {
 		if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
 		__syncthreads();
 	}
@@ -559,7 +572,10 @@ __global__ void bitfield_max_pool_kernel(uint32_t n_elements, const uint8_t* __r
 
 int launch_grid_to_bitfield(const float* d_grid, uint8_t* d_bitfield, float* d_scratch_mean, void* stream) {
 	hipStream_t s = (hipStream_t)stream;
-	hipLaunchKernelGGL(grid_mean_kernel, dim3(1), dim3(1024), 0, s, d_grid, d_scratch_mean);
+	// d_scratch_mean: [0] the mean (float), [2..] kMeanBlocks doubles of partial sums
+	double* partial = reinterpret_cast<double*>(d_scratch_mean + 2);
+	hipLaunchKernelGGL(grid_mean_partial_kernel, dim3(kMeanBlocks), dim3(256), 0, s, d_grid, partial);
+	hipLaunchKernelGGL(grid_mean_final_kernel, dim3(1), dim3(256), 0, s, partial, d_scratch_mean);
 	const uint32_t n = kGridVol / 8 * kCascades;
 	hipLaunchKernelGGL(grid_to_bitfield_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_grid, d_bitfield, d_scratch_mean);
 	for (uint32_t level = 1; level < kCascades; ++level) {
@@ -592,8 +608,10 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 	const int g = lane >> 5;
 	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
 	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count);
-	const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+	uint64_t lane_mult, lane_plus;
+	Pcg32::skip_coefficients(a.rng_inc, (uint64_t)(4 * lane), lane_mult, lane_plus);
 	const uint32_t n = a.n_uniform + a.n_nonuniform;
 	const uint32_t n_tiles = (n + 63) / 64;
 	for (uint32_t tile = wave_global; tile < n_tiles; tile += n_waves) {
@@ -604,9 +622,21 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 		bool empty = false;
 		if (have) {
 			const bool uni = s < a.n_uniform;
-			const Pcg32 rng{uni ? a.rng_state : a.rng_state_nonuniform, a.rng_inc};
-			cell = generate_grid_sample(rng, uni ? s : s - a.n_uniform, uni ? a.n_uniform : a.n_nonuniform, a.step, m.aabb, a.grid, a.n_cascades,
-			                            uni ? -0.01f : 0.01f, wpos);
+			const uint32_t i = uni ? s : s - a.n_uniform;
+			Pcg32 rng{uni ? a.rng_state : a.rng_state_nonuniform, a.rng_inc};
+			// rng.advance(4 * i): the 64-bit skip-ahead loop costs more than the density MLP when every lane runs it, so for
+			// a tile that lies in one draw it is split into a wave-uniform skip to the tile's first sample (scalar unit) and
+			// the per-lane skip by 4 * lane whose coefficients were computed once (LCG skips compose exactly mod 2^64).
+			const uint32_t t0 = tile * 64, t1 = t0 + 63;
+			if ((t0 < a.n_uniform) == (t1 < a.n_uniform)) {
+				const uint32_t i0 = (t0 < a.n_uniform) ? t0 : t0 - a.n_uniform;
+				uint64_t mt, pt;
+				Pcg32::skip_coefficients(a.rng_inc, (uint64_t)(i0 * 4u), mt, pt);
+				rng.state = lane_mult * (mt * rng.state + pt) + lane_plus;
+			} else {
+				rng.advance((uint64_t)(i * 4u));
+			}
+			cell = generate_grid_sample(rng, i, uni ? a.n_uniform : a.n_nonuniform, a.step, m.aabb, a.grid, a.n_cascades, uni ? -0.01f : 0.01f, wpos);
 			f3 unused = mk3(0.5f, 0.5f, 0.5f);
 			for (int k = a.n_edits - 1; k >= 0; --k) empty |= tet_warp(a.edits[k], false, wpos, unused);
 		}
