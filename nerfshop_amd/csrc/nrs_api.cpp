@@ -185,6 +185,11 @@ static void occupied_bounds(const uint8_t* bitfield, Box3& out) {
 		bool any = false;
 		const uint8_t* b = bitfield + (size_t)level * kGridVol / 8;
 		for (uint32_t byte = 0; byte < kGridVol / 8; ++byte) {
+			if ((byte & 7u) == 0) { // most of the field is empty: skip 8 bytes (64 cells) at a time
+				uint64_t w;
+				memcpy(&w, b + byte, 8);
+				if (!w) { byte += 7; continue; }
+			}
 			if (!b[byte]) continue;
 			any = true;
 			// the 8 cells of a byte are one 2x2x2 Morton block: bounds of the block are exact enough (<= 1 cell slack)
