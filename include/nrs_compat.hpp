@@ -77,6 +77,8 @@ public:
 	void set_density_bitfield(const uint8_t* h_bits, size_t n) { check(nrs_model_set_density_bitfield(m_model, h_bits, n), "nrs_model_set_density_bitfield"); }
 	void set_density_grid(const float* h_grid, size_t n) { check(nrs_model_set_density_grid(m_model, h_grid, n), "nrs_model_set_density_grid"); }
 
+	void get_density_grid(float* h_grid, size_t n) { check(nrs_model_get_density_grid(m_model, h_grid, n), "nrs_model_get_density_grid"); }
+
 	nrs_model* get() const { return m_model; }
 	const nrs_model_desc& desc() const { return m_desc; }
 
@@ -98,6 +100,15 @@ public:
 	}
 	void map_positions(void* stream, float* d_nerf_pos, uint32_t stride_floats, uint8_t* d_empty_mask, uint32_t n_elements) const {
 		check(nrs_edit_map_positions(m_edit, stream, n_elements, d_nerf_pos, stride_floats, d_empty_mask), "nrs_edit_map_positions");
+	}
+	// The per-gizmo-move chain (Cage::interpolate_with_mvc -> TetMesh::post_update_vertices -> build_tet_grid ->
+	// update_local_rotations), on the device.  set_mvc once after Cage::compute_mvc; update_cage per move.
+	void set_mvc(const float* h_weights, uint32_t n_cage_vertices) { check(nrs_edit_set_mvc(m_edit, h_weights, n_cage_vertices), "nrs_edit_set_mvc"); }
+	void update_cage(void* stream, const float* h_cage_vertices, uint32_t n_cage_vertices) {
+		check(nrs_edit_update_cage(m_edit, stream, h_cage_vertices, n_cage_vertices), "nrs_edit_update_cage");
+	}
+	void update_vertices(void* stream, const float* h_vertices, uint32_t n_vertices) {
+		check(nrs_edit_update_vertices(m_edit, stream, h_vertices, n_vertices), "nrs_edit_update_vertices");
 	}
 	nrs_edit* get() const { return m_edit; }
 
@@ -126,6 +137,27 @@ public:
 	bool m_enable_edits = true;
 	nrs_render_mode m_render_mode = NRS_RENDER_SHADE;
 	std::vector<const CageDeformation*> m_edit_operators; // NerfTracer::m_edit_operators, applied last-to-first
+
+	// Testbed state update_density_grid_nerf_operator advances: m_rng, m_nerf.density_grid_ema_step, density_grid_decay, max_cascade
+	nrs_grid_update m_density_grid_update{};
+	void seed_density_grid_update(uint32_t max_cascade, uint64_t seed = 1337, float decay = 0.95f) {
+		m_density_grid_update = nrs_grid_update{};
+		m_density_grid_update.n_uniform_samples = NRS_GRID_VOLUME * (max_cascade + 1);
+		m_density_grid_update.max_cascade = max_cascade;
+		m_density_grid_update.decay = decay;
+		nrs_rng_seed(seed, &m_density_grid_update.rng_state, &m_density_grid_update.rng_inc);
+	}
+	// void Testbed::update_density_grid_nerf_render(uint32_t n_iterations, bool reset_grid, cudaStream_t)  -- testbed_nerf.cu:3514
+	void update_density_grid_nerf_render(NerfNetwork& network, uint32_t n_iterations, bool reset_grid, void* stream) {
+		std::vector<nrs_edit*> edits;
+		if (m_enable_edits) for (const CageDeformation* op : m_edit_operators) edits.push_back(op->get());
+		for (uint32_t i = 0; i < n_iterations; ++i) {
+			m_density_grid_update.reset_grid = (reset_grid && i == 0) ? 1u : 0u;
+			check(nrs_model_update_density_grid(network.get(), edits.data(), (int)edits.size(), &m_density_grid_update, stream),
+			      "nrs_model_update_density_grid");
+		}
+		m_density_grid_update.reset_grid = 0;
+	}
 
 	// void Testbed::render_nerf(NerfNetwork<precision_t>&, CudaRenderBuffer&, const Vector2i& max_res, const Vector2f& focal_length,
 	//     const Matrix<float,3,4>& camera_matrix0, const Matrix<float,3,4>& camera_matrix1, const Vector4f& rolling_shutter,
