@@ -20,6 +20,8 @@
  *   nrs_edit_map_rays        <- EditOperator::map_rays      edit_operator.h:43, CageDeformation::map_rays  cage_deformation.cu:547
  *   nrs_edit_map_positions   <- EditOperator::map_positions edit_operator.h:51, cage_deformation.cu:624
  *   nrs_model_update_density_grid <- Testbed::update_density_grid_nerf_operator       src/testbed_nerf.cu:3533   ("next" row f2)
+ *   nrs_snapshot_open        <- Testbed::load_snapshot / load_network_config        src/testbed.cu:3054 / :152       ("next" row f3)
+ *   nrs_edits_open           <- Testbed::load_edits                                 src/testbed.cu:3205              ("next" row f3)
  *   nrs_tet_lut_build        <- TetMesh::build_tet_grid / build_original_tet_grid  tet_mesh.cu:368 / :76   (host, "next" row f1)
  *   nrs_mvc_compute / nrs_mvc_apply <- Cage::compute_mvc / interpolate_with_mvc    cage.cu:6 / :38          (host, "next" row f1)
  *   nrs_tet_local_rotations  <- TetMesh::update_local_rotations                    tet_mesh.cu:37           (host, "next" row f1)
@@ -271,6 +273,33 @@ int nrs_detile(nrs_ctx* ctx, void* stream, const nrs_render_params* params, uint
  * (t, dt) pairs.  d_t, d_dt: [n_pixels x max_samples] f32; d_count: [n_pixels] u32. */
 int nrs_trace_samples(nrs_model* model, const nrs_render_params* params, void* stream, uint32_t n_pixels,
                       const uint32_t* d_pixel_idx, uint32_t max_samples, float* d_t, float* d_dt, uint32_t* d_count);
+
+/* ---- on-disk formats either side of the path ("next" row f3; host-only, no device needed) ------------------------ */
+/* Snapshot: Testbed::load_network_config + load_snapshot (src/testbed.cu:152-184, 3054-3087).  `.msgpack` is
+ * nlohmann::json::to_msgpack of the network config with a "snapshot" object; `.ingp` is the same behind zlib (zstr).
+ * Read here: encoding / network / rgb_network / dir_encoding hyper-parameters, snapshot.nerf.aabb_scale (or
+ * .dataset.aabb_scale), snapshot.params_binary (tcnn Trainer::serialize, fp16 or float), snapshot.density_grid_binary
+ * (float [5*128^3] from save_snapshot, fp16 [(max_cascade+1)*128^3] from export_snapshot), snapshot.camera.matrix. */
+typedef struct nrs_snapshot nrs_snapshot;
+int          nrs_snapshot_open(const char* path, nrs_snapshot** out);
+void         nrs_snapshot_close(nrs_snapshot* snapshot);
+int          nrs_snapshot_model_desc(const nrs_snapshot* snapshot, nrs_model_desc* desc_out, uint32_t* aabb_scale_out);
+const void*  nrs_snapshot_params_fp16(const nrs_snapshot* snapshot, size_t* n_params_out);   /* -> nrs_model_set_params */
+const float* nrs_snapshot_density_grid(const nrs_snapshot* snapshot, size_t* n_floats_out);  /* -> nrs_model_set_density_grid */
+int          nrs_snapshot_camera(const nrs_snapshot* snapshot, float* camera_matrix12_out);   /* column-major 3x4 */
+/* Edits: Testbed::load_edits (src/testbed.cu:3205-3236): {"edit_operators": [{"type": "cage_deformation",
+ * "proxy_cage": Cage (cage.h:100-145), "interpolation_mesh": TetMesh (tet_mesh.h:136-174), ...}]}.
+ * nrs_edits_cage fills an nrs_tet_mesh for DEVICE authoring (vertices, original vertices, tets; LUT / bitfield /
+ * rotations left NULL so nrs_edit_create builds them, as the reference's JSON constructor rebuilds the tet grid,
+ * growing_selection.cu:112-115) and hands out the MVC weights and the proxy cage.  Pointers live as long as `edits`. */
+typedef struct nrs_edits nrs_edits;
+int          nrs_edits_open(const char* path, nrs_edits** out);
+void         nrs_edits_close(nrs_edits* edits);
+uint32_t     nrs_edits_count(const nrs_edits* edits);
+const char*  nrs_edits_type(const nrs_edits* edits, uint32_t i);   /* "cage_deformation", "affine_duplication", "twist" */
+int          nrs_edits_cage(const nrs_edits* edits, uint32_t i, nrs_tet_mesh* mesh_out, const float** h_mvc_weights_out,
+                            const float** h_cage_vertices_out, const float** h_cage_original_vertices_out,
+                            const uint32_t** h_cage_triangles_out, uint32_t* n_cage_vertices_out, uint32_t* n_cage_triangles_out);
 
 /* ---- host-side edit authoring ("next" row f1; CPU like the reference, no device needed) -------------- */
 typedef struct nrs_tet_lut nrs_tet_lut;

@@ -115,6 +115,8 @@ EXPORTS = [
     "nrs_edit_create", "nrs_edit_destroy", "nrs_edit_map_rays", "nrs_edit_map_positions",
     "nrs_edit_set_mvc", "nrs_edit_update_cage", "nrs_edit_update_vertices", "nrs_edit_lut_size", "nrs_edit_download",
     "nrs_render_nerf", "nrs_render_owned_tiles", "nrs_detile", "nrs_trace_samples",
+    "nrs_snapshot_open", "nrs_snapshot_close", "nrs_snapshot_model_desc", "nrs_snapshot_params_fp16", "nrs_snapshot_density_grid",
+    "nrs_snapshot_camera", "nrs_edits_open", "nrs_edits_close", "nrs_edits_count", "nrs_edits_type", "nrs_edits_cage",
     "nrs_tet_lut_build", "nrs_tet_lut_n_idx", "nrs_tet_lut_max_per_cell", "nrs_tet_lut_offsets",
     "nrs_tet_lut_idx", "nrs_tet_lut_bitfield", "nrs_tet_lut_destroy",
     "nrs_mvc_compute", "nrs_mvc_apply", "nrs_tet_local_rotations",
@@ -180,6 +182,23 @@ def load():
     lib.nrs_render_owned_tiles.restype = U32
     lib.nrs_detile.argtypes = [P, P, C.POINTER(RenderParams), U32, U32, P, U32, P]
     lib.nrs_trace_samples.argtypes = [P, C.POINTER(RenderParams), P, U32, P, U32, P, P, P]
+    lib.nrs_snapshot_open.argtypes = [C.c_char_p, C.POINTER(P)]
+    lib.nrs_snapshot_close.argtypes = [P]
+    lib.nrs_snapshot_close.restype = None
+    lib.nrs_snapshot_model_desc.argtypes = [P, C.POINTER(ModelDesc), C.POINTER(U32)]
+    lib.nrs_snapshot_params_fp16.argtypes = [P, C.POINTER(C.c_size_t)]
+    lib.nrs_snapshot_params_fp16.restype = P
+    lib.nrs_snapshot_density_grid.argtypes = [P, C.POINTER(C.c_size_t)]
+    lib.nrs_snapshot_density_grid.restype = P
+    lib.nrs_snapshot_camera.argtypes = [P, P]
+    lib.nrs_edits_open.argtypes = [C.c_char_p, C.POINTER(P)]
+    lib.nrs_edits_close.argtypes = [P]
+    lib.nrs_edits_close.restype = None
+    lib.nrs_edits_count.argtypes = [P]
+    lib.nrs_edits_count.restype = U32
+    lib.nrs_edits_type.argtypes = [P, U32]
+    lib.nrs_edits_type.restype = C.c_char_p
+    lib.nrs_edits_cage.argtypes = [P, U32, C.POINTER(TetMesh), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(U32), C.POINTER(U32)]
     lib.nrs_tet_lut_build.argtypes = [P, U32, P, U32, I, C.POINTER(P)]
     for name in ("nrs_tet_lut_n_idx", "nrs_tet_lut_max_per_cell"):
         getattr(lib, name).argtypes = [P]

@@ -18,6 +18,7 @@
 using namespace nrs;
 
 static thread_local std::string g_err;
+namespace nrs { void set_last_error(const char* msg) { g_err = msg ? msg : ""; } }
 static int fail(int code, const std::string& msg) {
 	g_err = msg;
 	return code;

@@ -126,4 +126,7 @@ uint32_t lut_big_list_capacity(size_t idx_capacity);
 int launch_local_rotations(uint32_t n_tets, const float* d_verts, const float* d_orig, const uint32_t* d_tets, float* d_out, void* stream);
 const char* cage_last_error();
 
+// the thread-local message nrs_last_error() returns (nrs_api.cpp); used by the host-only translation units
+void set_last_error(const char* msg);
+
 } // namespace nrs

@@ -1,0 +1,117 @@
+"""the snapshot (.msgpack / .ingp) and edits (.json) readers of libnrs against files written in the
+reference's schemas (Testbed::save_snapshot / export_snapshot / save_edits, src/testbed.cu:3089-3203) by the harness.
+Host-only: no GPU needed.  Arrays must come back bit-identical (fp16 grids: identical to the fp16 rounding)."""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+
+from nerfshop_amd import _abi, formats, synth
+
+
+@pytest.mark.parametrize("aabb_scale,ext", [(1, "msgpack"), (1, "ingp"), (16, "ingp"), (16, "msgpack")])
+def test_snapshot_round_trip(built, tmp_path, aabb_scale, ext):
+    desc = synth.model_desc(aabb_scale)
+    rng = np.random.default_rng(3)
+    n = _abi.load().nrs_model_n_params(C.byref(desc))
+    params = rng.integers(0, 0x7BFF, size=n, dtype=np.uint16)       # arbitrary finite fp16 bit patterns
+    grid = np.zeros(5 * 128 ** 3, np.float32)
+    used = (int(np.log2(aabb_scale)) + 1) * 128 ** 3
+    grid[:used] = rng.uniform(0, 0.2, size=used).astype(np.float32)
+    grid[:1000] = -1.0                                               # untrained cells
+    cam = synth.orbit_camera(30.0, 30.0, scale=0.33)
+    path = tmp_path / f"scene.{ext}"
+    formats.save_snapshot(path, desc, aabb_scale, params, grid, camera=cam)
+    s = formats.load_snapshot(path)
+    assert s.aabb_scale == aabb_scale
+    for f, _ in _abi.ModelDesc._fields_:
+        a, b = getattr(s.desc, f), getattr(desc, f)
+        assert (list(a) == list(b)) if hasattr(a, "__len__") else (a == b), f
+    assert np.array_equal(s.params, params)
+    if ext == "ingp":   # export_snapshot stores fp16 of the used cascades
+        assert np.array_equal(s.density_grid[:used], grid[:used].astype(np.float16).astype(np.float32))
+        assert (s.density_grid[used:] == 0).all()
+    else:
+        assert np.array_equal(s.density_grid, grid)
+    assert np.array_equal(s.camera, np.asarray(cam, np.float32).reshape(-1))
+
+
+def test_snapshot_float_params_and_errors(built, tmp_path):
+    import msgpack
+    desc = synth.model_desc(1)
+    n = _abi.load().nrs_model_n_params(C.byref(desc))
+    rng = np.random.default_rng(5)
+    pf = rng.normal(0, 0.3, size=n).astype(np.float32)
+    cfg = formats.network_config(desc, explicit_per_level_scale=True)
+    cfg["snapshot"] = {"density_grid_size": 128, "params_type": "float", "params_binary": pf.tobytes(), "n_params": int(n),
+                       "density_grid_binary": np.zeros(5 * 128 ** 3, np.float32).tobytes(), "nerf": {"aabb_scale": 1}}
+    p = tmp_path / "f.msgpack"
+    p.write_bytes(msgpack.packb(cfg, use_bin_type=True))
+    s = formats.load_snapshot(p)
+    assert np.array_equal(s.params, pf.astype(np.float16).view(np.uint16))   # Trainer::deserialize converts float -> half
+
+    # errors, with the reference's messages where it has them
+    def expect(mutate, fragment):
+        c = {k: (dict(v) if isinstance(v, dict) else v) for k, v in cfg.items()}
+        c["snapshot"] = dict(cfg["snapshot"])
+        c["snapshot"]["nerf"] = dict(cfg["snapshot"]["nerf"])
+        mutate(c)
+        q = tmp_path / "bad.msgpack"
+        q.write_bytes(msgpack.packb(c, use_bin_type=True))
+        with pytest.raises(_abi.NrsError) as ei:
+            formats.load_snapshot(q)
+        assert fragment in str(ei.value), str(ei.value)
+
+    expect(lambda c: c.pop("snapshot"), "does not contain a snapshot")
+    expect(lambda c: c["snapshot"].__setitem__("density_grid_size", 64), "Incompatible grid size")
+    expect(lambda c: c["snapshot"].__setitem__("params_binary", b"123"), "wrong size")
+    expect(lambda c: c["snapshot"]["nerf"].__setitem__("aabb_scale", 3), "power of two")
+    expect(lambda c: c["encoding"].__setitem__("n_levels", 8), "architecture")
+    trunc = tmp_path / "trunc.msgpack"
+    trunc.write_bytes(p.read_bytes()[:1000])
+    with pytest.raises(_abi.NrsError):
+        formats.load_snapshot(trunc)
+    with pytest.raises(_abi.NrsError):
+        formats.load_snapshot(tmp_path / "missing.msgpack")
+
+
+def test_edits_round_trip(scene, tmp_path):
+    e = scene.edit
+    path = tmp_path / "edits.json"
+    formats.save_edits(path, [e])
+    ops = formats.load_edits(path)
+    assert len(ops) == 1
+    c = ops[0]
+    assert np.array_equal(c.vertices, e.vertices) and np.array_equal(c.original_vertices, e.original_vertices)
+    assert np.array_equal(c.tets, e.tets)
+    assert np.array_equal(c.mvc_weights, e.mvc_weights)
+    assert np.array_equal(c.cage_deformed, e.cage_deformed) and np.array_equal(c.cage_vertices, e.cage_vertices)
+    assert np.array_equal(c.cage_triangles.reshape(-1), e.cage_triangles.reshape(-1))
+    # operators the reference's load_edits accepts but this path does not execute are reported by type
+    doc = json.loads(path.read_text())
+    doc["edit_operators"].insert(0, {"type": "affine_duplication"})
+    path.write_text(json.dumps(doc))
+    ops = formats.load_edits(path)
+    assert ops[0] == "affine_duplication" and np.array_equal(ops[1].tets, e.tets)
+    doc["edit_operators"].append({"type": "bogus"})
+    path.write_text(json.dumps(doc))
+    with pytest.raises(_abi.NrsError) as ei:
+        formats.load_edits(path)
+    assert "Invalid edit operator!" in str(ei.value)
+    path.write_text('{"edit_operators": [{"type": "cage_deformation", "proxy_cage": {"vertices": [[0, 0]]}}]}')
+    with pytest.raises(_abi.NrsError):
+        formats.load_edits(path)
+
+
+def test_json_parser_corner_cases(built, tmp_path):
+    """escapes, exponents, nesting, whitespace -- through the edits reader (the only JSON entry point)."""
+    p = tmp_path / "e.json"
+    p.write_text(' {\n "edit_\\u006fperators" : [ ] , "x": [1e-3, -2.5E+2, true, false, null, "a\\"b\\\\c\\n"] }\n')
+    assert formats.load_edits(p) == []
+    p.write_text('{"edit_operators": [}')
+    with pytest.raises(_abi.NrsError):
+        formats.load_edits(p)
+    p.write_text("[" * 100 + "]" * 100)
+    with pytest.raises(_abi.NrsError):
+        formats.load_edits(p)
