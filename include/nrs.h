@@ -17,6 +17,7 @@
  *   nrs_model_set_density_grid <- Testbed::update_density_grid_mean_and_bitfield   src/testbed_nerf.cu:3642
  *   nrs_edit_create          <- TetMesh GPU members + upload                       tet_mesh.h:80-94, tet_mesh.cu:651-667
  *   nrs_edit_update_cage / _vertices <- interpolate_with_mvc + build_tet_grid + update_local_rotations, on the device   ("next" row f1)
+ *   nrs_edit_create_affine   <- AffineDuplication ctor + update_destination         editing/affine_duplication.h:26, :77   ("next" row f4)
  *   nrs_edit_map_rays        <- EditOperator::map_rays      edit_operator.h:43, CageDeformation::map_rays  cage_deformation.cu:547
  *   nrs_edit_map_positions   <- EditOperator::map_positions edit_operator.h:51, cage_deformation.cu:624
  *   nrs_model_update_density_grid <- Testbed::update_density_grid_nerf_operator       src/testbed_nerf.cu:3533   ("next" row f2)
@@ -123,6 +124,21 @@ typedef struct nrs_tet_mesh {
 	 * by nrs_edit_update_*.  (m_correct_direction, cage_deformation.h) */
 	uint32_t        correct_direction;
 } nrs_tet_mesh;
+
+/* AffineDuplication operator (include/.../editing/affine_duplication.h:23-106): the content of an oriented selection box
+ * is shown again translated / scaled / rotated.  Fields = what the operator's JSON stores (affine_duplication.cu:356-369);
+ * of the selection AffineBoundingBox only center / scale / rot_matrix matter (warp_box and update_destination rebuild
+ * u, v, w, min, max from them, affine_bounding_box.cuh:40-101).  Matrices are Eigen column-major 3x3, world units. */
+typedef struct nrs_affine_duplication {
+	float    selection_center[3];
+	float    selection_scale[3];   /* edge lengths of the box */
+	float    selection_rot[9];
+	float    translation[3];
+	float    scale[3];
+	float    rotation[9];
+	uint32_t hide_original;        /* m_hide_original (false) */
+	uint32_t correct_dir;          /* m_correct_dir (true): rotate the view direction too */
+} nrs_affine_duplication;
 
 /* Arguments + implicit Testbed members of render_nerf (SURVEY 8b "Renderer"). */
 typedef struct nrs_render_params {
@@ -231,6 +247,9 @@ int nrs_hashgrid_encode(nrs_model* model, void* stream, uint32_t n, const float*
 
 /* ---- edit operators -------------------------------------------------------------------------------- */
 int  nrs_edit_create(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_tet_mesh* mesh, nrs_edit** out);
+/* AffineDuplication(selection_box, translation, aabb) + update_destination (affine_duplication.h:26, 77-90); the
+ * resulting nrs_edit is used exactly like a cage edit (map_rays / map_positions / render / occupancy refresh). */
+int  nrs_edit_create_affine(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_affine_duplication* op, nrs_edit** out);
 void nrs_edit_destroy(nrs_edit* edit);
 /* map_rays: in-place on d_coords [n x 7] f32, OR-accumulates into d_empty_mask [n] u8 */
 int  nrs_edit_map_rays(nrs_edit* edit, void* stream, uint32_t n, float* d_coords, uint8_t* d_empty_mask);
@@ -297,6 +316,7 @@ int          nrs_edits_open(const char* path, nrs_edits** out);
 void         nrs_edits_close(nrs_edits* edits);
 uint32_t     nrs_edits_count(const nrs_edits* edits);
 const char*  nrs_edits_type(const nrs_edits* edits, uint32_t i);   /* "cage_deformation", "affine_duplication", "twist" */
+int          nrs_edits_affine(const nrs_edits* edits, uint32_t i, nrs_affine_duplication* op_out);
 int          nrs_edits_cage(const nrs_edits* edits, uint32_t i, nrs_tet_mesh* mesh_out, const float** h_mvc_weights_out,
                             const float** h_cage_vertices_out, const float** h_cage_original_vertices_out,
                             const uint32_t** h_cage_triangles_out, uint32_t* n_cage_vertices_out, uint32_t* n_cage_triangles_out);

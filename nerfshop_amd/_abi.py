@@ -61,6 +61,19 @@ class TetMesh(C.Structure):
     ]
 
 
+class AffineDuplicationOp(C.Structure):
+    _fields_ = [
+        ("selection_center", C.c_float * 3),
+        ("selection_scale", C.c_float * 3),
+        ("selection_rot", C.c_float * 9),
+        ("translation", C.c_float * 3),
+        ("scale", C.c_float * 3),
+        ("rotation", C.c_float * 9),
+        ("hide_original", C.c_uint32),
+        ("correct_dir", C.c_uint32),
+    ]
+
+
 class RenderParams(C.Structure):
     _fields_ = [
         ("resolution", C.c_int32 * 2),
@@ -112,11 +125,11 @@ EXPORTS = [
     "nrs_model_set_params", "nrs_model_set_density_bitfield", "nrs_model_set_density_grid",
     "nrs_model_get_density_bitfield", "nrs_model_get_density_grid", "nrs_model_update_density_grid", "nrs_rng_seed",
     "nrs_network_inference", "nrs_network_density", "nrs_hashgrid_encode",
-    "nrs_edit_create", "nrs_edit_destroy", "nrs_edit_map_rays", "nrs_edit_map_positions",
+    "nrs_edit_create", "nrs_edit_create_affine", "nrs_edit_destroy", "nrs_edit_map_rays", "nrs_edit_map_positions",
     "nrs_edit_set_mvc", "nrs_edit_update_cage", "nrs_edit_update_vertices", "nrs_edit_lut_size", "nrs_edit_download",
     "nrs_render_nerf", "nrs_render_owned_tiles", "nrs_detile", "nrs_trace_samples",
     "nrs_snapshot_open", "nrs_snapshot_close", "nrs_snapshot_model_desc", "nrs_snapshot_params_fp16", "nrs_snapshot_density_grid",
-    "nrs_snapshot_camera", "nrs_edits_open", "nrs_edits_close", "nrs_edits_count", "nrs_edits_type", "nrs_edits_cage",
+    "nrs_snapshot_camera", "nrs_edits_open", "nrs_edits_close", "nrs_edits_count", "nrs_edits_type", "nrs_edits_cage", "nrs_edits_affine",
     "nrs_tet_lut_build", "nrs_tet_lut_n_idx", "nrs_tet_lut_max_per_cell", "nrs_tet_lut_offsets",
     "nrs_tet_lut_idx", "nrs_tet_lut_bitfield", "nrs_tet_lut_destroy",
     "nrs_mvc_compute", "nrs_mvc_apply", "nrs_tet_local_rotations",
@@ -168,6 +181,8 @@ def load():
     lib.nrs_network_density.argtypes = [P, P, U32, P, U32, P, U32, I]
     lib.nrs_hashgrid_encode.argtypes = [P, P, U32, P, U32, P]
     lib.nrs_edit_create.argtypes = [P, C.POINTER(ModelDesc), C.POINTER(TetMesh), C.POINTER(P)]
+    lib.nrs_edit_create_affine.argtypes = [P, C.POINTER(ModelDesc), C.POINTER(AffineDuplicationOp), C.POINTER(P)]
+    lib.nrs_edits_affine.argtypes = [P, U32, C.POINTER(AffineDuplicationOp)]
     lib.nrs_edit_destroy.argtypes = [P]
     lib.nrs_edit_destroy.restype = None
     lib.nrs_edit_map_rays.argtypes = [P, P, U32, P, P]

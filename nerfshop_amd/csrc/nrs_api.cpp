@@ -613,6 +613,63 @@ int nrs_edit_create(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_tet_mesh
 	*out = e;
 	return NRS_OK;
 }
+// AffineBoundingBox bookkeeping (affine_bounding_box.cuh:40-101) for the boxes the kernels test.  R column-major.
+namespace {
+struct HostAffineBox { float center[3], scale[3], rot[9]; };
+void affine_finish(const HostAffineBox& b, AffineBox& out) {
+	// u = rot * scale.x * e_x etc.;  min = -0.5 * rot * scale + center
+	for (int i = 0; i < 3; ++i) {
+		out.u[i] = b.rot[i] * b.scale[0];
+		out.v[i] = b.rot[3 + i] * b.scale[1];
+		out.w[i] = b.rot[6 + i] * b.scale[2];
+		out.mn[i] = (((-0.5f * b.rot[i]) * b.scale[0] + (-0.5f * b.rot[3 + i]) * b.scale[1]) + (-0.5f * b.rot[6 + i]) * b.scale[2]) + b.center[i];
+		out.center[i] = b.center[i];
+	}
+	out.uu = (out.u[0] * out.u[0] + out.u[1] * out.u[1]) + out.u[2] * out.u[2];
+	out.vv = (out.v[0] * out.v[0] + out.v[1] * out.v[1]) + out.v[2] * out.v[2];
+	out.ww = (out.w[0] * out.w[0] + out.w[1] * out.w[1]) + out.w[2] * out.w[2];
+}
+void affine_warp_box(HostAffineBox& b, const Box3& aabb) { // warp_box, :90-97
+	for (int i = 0; i < 3; ++i) {
+		const float diag = aabb.mx[i] - aabb.mn[i];
+		b.center[i] = (b.center[i] - aabb.mn[i]) / diag;
+		b.scale[i] = b.scale[i] / diag;
+	}
+}
+} // namespace
+
+int nrs_edit_create_affine(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_affine_duplication* op, nrs_edit** out) {
+	if (!ctx || !desc || !op || !out) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create_affine: NULL argument");
+	for (int i = 0; i < 3; ++i)
+		if (!(op->scale[i] != 0.f) || !(op->selection_scale[i] > 0.f)) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_create_affine: zero scale / empty selection box");
+	nrs_edit* e = new (std::nothrow) nrs_edit();
+	if (!e) return fail(NRS_ERR_STATE, "out of host memory");
+	e->ctx = ctx;
+	DeviceEdit& de = e->de;
+	de.kind = kEditAffine;
+	for (int k = 0; k < 3; ++k) { de.aabb.mn[k] = desc->aabb_min[k]; de.aabb.mx[k] = desc->aabb_max[k]; }
+	HostAffineBox sel, dst;
+	memcpy(sel.center, op->selection_center, 12); memcpy(sel.scale, op->selection_scale, 12); memcpy(sel.rot, op->selection_rot, 36);
+	// update_destination (affine_duplication.h:77-90): translate, scale_with_vector, rotate (rot_matrix = R * rot_matrix)
+	dst = sel;
+	for (int i = 0; i < 3; ++i) { dst.center[i] = dst.center[i] + op->translation[i]; dst.scale[i] = dst.scale[i] * op->scale[i]; }
+	for (int c = 0; c < 3; ++c)
+		for (int r = 0; r < 3; ++r)
+			dst.rot[3 * c + r] = (op->rotation[r] * sel.rot[3 * c] + op->rotation[3 + r] * sel.rot[3 * c + 1]) + op->rotation[6 + r] * sel.rot[3 * c + 2];
+	affine_warp_box(dst, de.aabb);
+	affine_warp_box(sel, de.aabb);
+	affine_finish(dst, de.a_dst);
+	affine_finish(sel, de.a_sel);
+	for (int i = 0; i < 3; ++i) {
+		de.a_translation[i] = op->translation[i] / (de.aabb.mx[i] - de.aabb.mn[i]); // m_warped_translation
+		de.a_scale[i] = op->scale[i];
+	}
+	memcpy(de.a_rot, op->rotation, 36);
+	de.a_hide_original = op->hide_original ? 1u : 0u;
+	de.a_correct_dir = op->correct_dir ? 1u : 0u;
+	*out = e;
+	return NRS_OK;
+}
 void nrs_edit_destroy(nrs_edit* e) {
 	if (!e) return;
 	for (void* p : e->allocs) (void)hipFree(p);
@@ -624,6 +681,7 @@ void nrs_edit_destroy(nrs_edit* e) {
 // ---- per-move updates --------------------------------------------------------------------------------------------
 int nrs_edit_set_mvc(nrs_edit* e, const float* h_weights, uint32_t n_cage_vertices) {
 	if (!e || !h_weights || n_cage_vertices == 0) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_set_mvc: bad argument");
+	if (e->de.kind != kEditCage) return fail(NRS_ERR_STATE, "nrs_edit_set_mvc: not a cage operator");
 	HIP_TRY(hipSetDevice(e->ctx->device));
 	(void)hipFree(e->d_mvc); (void)hipFree(e->d_cage);
 	e->d_mvc = nullptr; e->d_cage = nullptr; e->n_cv = 0;
@@ -646,6 +704,7 @@ int nrs_edit_update_cage(nrs_edit* e, void* stream, const float* h_cage_vertices
 }
 int nrs_edit_update_vertices(nrs_edit* e, void* stream, const float* h_vertices, uint32_t n_vertices) {
 	if (!e || !h_vertices) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_update_vertices: NULL argument");
+	if (e->de.kind != kEditCage) return fail(NRS_ERR_STATE, "nrs_edit_update_vertices: not a cage operator");
 	if (n_vertices != e->n_vertices) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_update_vertices: vertex count differs from the mesh's");
 	HIP_TRY(hipSetDevice(e->ctx->device));
 	hipStream_t s = (hipStream_t)stream;
@@ -661,6 +720,7 @@ int nrs_edit_lut_size(const nrs_edit* e, uint32_t* n_idx, uint32_t* max_per_cell
 int nrs_edit_download(nrs_edit* e, float* h_vertices, uint32_t* h_lut_offsets, uint32_t* h_lut_idx, float* h_rotations, uint8_t* h_original_bitfield,
                       float* h_bbox6) {
 	if (!e) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_download: NULL argument");
+	if (e->de.kind != kEditCage) return fail(NRS_ERR_STATE, "nrs_edit_download: not a cage operator");
 	HIP_TRY(hipSetDevice(e->ctx->device));
 	if (h_vertices) HIP_TRY(hipMemcpy(h_vertices, e->d_verts, (size_t)e->n_vertices * 12, hipMemcpyDeviceToHost));
 	if (h_lut_offsets) HIP_TRY(hipMemcpy(h_lut_offsets, e->d_lut_off, ((size_t)kGridVol * kCascades + 1) * 4, hipMemcpyDeviceToHost));

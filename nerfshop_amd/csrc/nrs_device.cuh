@@ -354,6 +354,35 @@ __device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3&
 	return empty;
 }
 
+// AffineDuplication::map_rays / map_positions (affine_duplication.cu:69-118): samples inside the warped destination box
+// are carried back into the selection box (inverse scale, inverse rotation about the destination centre, inverse
+// translation; optionally the view direction too); samples inside the selection box are emptied if hide_original.
+__device__ __forceinline__ bool affine_contains(const AffineBox& b, f3 p) {
+	const f3 q = p - mk3(b.mn[0], b.mn[1], b.mn[2]);
+	const float du = dot3(mk3(b.u[0], b.u[1], b.u[2]), q), dv = dot3(mk3(b.v[0], b.v[1], b.v[2]), q), dw = dot3(mk3(b.w[0], b.w[1], b.w[2]), q);
+	return du >= 0.f && du < b.uu && dv >= 0.f && dv < b.vv && dw >= 0.f && dw < b.ww;
+}
+__device__ __forceinline__ f3 mul_rt(const float* R, f3 q) { // R^T q, R column-major: (R^T q)_i = sum_k R(k, i) q_k
+	return {(R[0] * q.x + R[1] * q.y) + R[2] * q.z, (R[3] * q.x + R[4] * q.y) + R[5] * q.z, (R[6] * q.x + R[7] * q.y) + R[8] * q.z};
+}
+__device__ __forceinline__ bool affine_warp(const DeviceEdit& e, bool with_dir, f3& wpos, f3& wdir) {
+	if (affine_contains(e.a_dst, wpos)) {
+		const f3 c = mk3(e.a_dst.center[0], e.a_dst.center[1], e.a_dst.center[2]);
+		const f3 d = wpos - c;
+		const f3 q = {d.x / e.a_scale[0], d.y / e.a_scale[1], d.z / e.a_scale[2]};
+		f3 p = mul_rt(e.a_rot, q) + c;
+		wpos = p - mk3(e.a_translation[0], e.a_translation[1], e.a_translation[2]);
+		if (with_dir && e.a_correct_dir) wdir = warp_direction(mul_rt(e.a_rot, unwarp_direction(wdir)));
+		return false;
+	}
+	return e.a_hide_original && affine_contains(e.a_sel, wpos);
+}
+// EditOperator::map_rays / map_positions dispatch
+__device__ __forceinline__ bool edit_warp(const DeviceEdit& e, bool with_dir, f3& wpos, f3& wdir) {
+	if (e.kind == kEditAffine) return affine_warp(e, with_dir, wpos, wdir);
+	return tet_warp(e, with_dir, wpos, wdir);
+}
+
 // Membrane ("Poisson") correction inputs of one sample: compute_residual_poisson_kernel's body (cage_deformation.cu:467-507)
 // fused with the evaluate_sh9 (cn:218-245) that composite_kernel_nerf applies to its result (tn:800-805).  wpos0 is the
 // sample position BEFORE map_rays (residuals live in deformed space), dir the un-warped view direction AFTER map_rays.

@@ -344,6 +344,7 @@ struct nrs_snapshot {
 
 struct CageOperator {
 	std::string type;
+	nrs_affine_duplication affine{};
 	std::vector<float> vertices, original_vertices, mvc, cage_vertices, cage_original_vertices;
 	std::vector<uint32_t> tets, cage_indices;
 	uint32_t n_cage_vertices = 0;
@@ -508,7 +509,28 @@ int nrs_edits_open(const char* path, nrs_edits** out) {
 						}
 					}
 				}
-			} else if (c.type != "affine_duplication" && c.type != "twist") {
+			} else if (c.type == "affine_duplication") {                       // affine_duplication.h:31-40
+				auto vec3 = [](const Value& v, float* out, const char* what) {
+					if (v.kind != Value::Arr || v.a.size() != 3) throw std::runtime_error(std::string(what) + ": expected 3 numbers");
+					for (int k = 0; k < 3; ++k) out[k] = (float)v.a[k].number();
+				};
+				auto mat3 = [](const Value& v, float* out, const char* what) { // rows of 3 (Eigen to_json) -> column-major
+					if (v.kind != Value::Arr || v.a.size() != 3) throw std::runtime_error(std::string(what) + ": expected 3 rows");
+					for (int r = 0; r < 3; ++r) {
+						if (v.a[r].kind != Value::Arr || v.a[r].a.size() != 3) throw std::runtime_error(std::string(what) + ": expected 3 x 3 numbers");
+						for (int col = 0; col < 3; ++col) out[3 * col + r] = (float)v.a[r].a[col].number();
+					}
+				};
+				const Value& box = op.at("selection_box");
+				vec3(box.at("center"), c.affine.selection_center, "selection_box.center");
+				vec3(box.at("scale"), c.affine.selection_scale, "selection_box.scale");
+				mat3(box.at("rot_matrix"), c.affine.selection_rot, "selection_box.rot_matrix");
+				vec3(op.at("translation"), c.affine.translation, "translation");
+				vec3(op.at("scale"), c.affine.scale, "scale");
+				mat3(op.at("rotation_matrix"), c.affine.rotation, "rotation_matrix");
+				c.affine.hide_original = op.at("hide_original").number() != 0.0;
+				c.affine.correct_dir = op.at("correct_dir").number() != 0.0;
+			} else if (c.type != "twist") {
 				throw std::runtime_error("Invalid edit operator!");            // testbed.cu:3233
 			}
 			e->ops.push_back(std::move(c));
@@ -522,6 +544,12 @@ int nrs_edits_open(const char* path, nrs_edits** out) {
 void nrs_edits_close(nrs_edits* e) { delete e; }
 uint32_t nrs_edits_count(const nrs_edits* e) { return e ? (uint32_t)e->ops.size() : 0; }
 const char* nrs_edits_type(const nrs_edits* e, uint32_t i) { return (e && i < e->ops.size()) ? e->ops[i].type.c_str() : nullptr; }
+int nrs_edits_affine(const nrs_edits* e, uint32_t i, nrs_affine_duplication* op_out) {
+	if (!e || i >= e->ops.size() || !op_out) return fmt_fail(NRS_ERR_INVALID_ARG, "nrs_edits_affine: bad argument");
+	if (e->ops[i].type != "affine_duplication") return fmt_fail(NRS_ERR_UNSUPPORTED, "nrs_edits_affine: operator " + std::to_string(i) + " is '" + e->ops[i].type + "'");
+	*op_out = e->ops[i].affine;
+	return NRS_OK;
+}
 int nrs_edits_cage(const nrs_edits* e, uint32_t i, nrs_tet_mesh* mesh_out, const float** h_mvc_weights_out, const float** h_cage_vertices_out,
                    const float** h_cage_original_vertices_out, const uint32_t** h_cage_triangles_out, uint32_t* n_cage_vertices_out,
                    uint32_t* n_cage_triangles_out) {

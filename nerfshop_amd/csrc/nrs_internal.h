@@ -51,7 +51,16 @@ struct DeviceModel {
 	uint32_t        density_activation;
 };
 
+// AffineBoundingBox as the kernels test it (affine_bounding_box.cuh:83-88): u.(p - min) in [0, u.u) etc.
+struct AffineBox { float mn[3]; float u[3]; float v[3]; float w[3]; float uu, vv, ww; float center[3]; };
+enum EditKind : uint32_t { kEditCage = 0, kEditAffine = 1 };
+
 struct DeviceEdit {
+	uint32_t kind;             // EditKind
+	// AffineDuplication (affine_duplication.h:92-106): warped destination / selection boxes, warped translation
+	uint32_t a_hide_original, a_correct_dir, a_pad;
+	AffineBox a_dst, a_sel;
+	float a_translation[3], a_scale[3], a_rot[9];
 	Box3 aabb;                 // scene aabb
 	Box3 bbox;                 // deformed mesh, world units           (TetMesh::bbox)
 	Box3 warped_bbox;          // bbox in warped [0,1] coordinates     (TetMesh::warped_bbox)

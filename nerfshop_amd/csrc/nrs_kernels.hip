@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		bool empty = false;
 		const f3 wpos0 = wpos; // un-deformed sample position (membrane terms live in deformed space)
 		if (ops && have) { // map_rays, last-to-first (tn:2899-2902)
-			for (int ei = a.n_edits - 1; ei >= 0; --ei) empty |= tet_warp(a.edits[ei], true, wpos, wdir);
+			for (int ei = a.n_edits - 1; ei >= 0; --ei) empty |= edit_warp(a.edits[ei], true, wpos, wdir);
 		}
 		// ---- membrane correction inputs (compute_poisson_full_residuals, tn:2867-2883) + first network pass (tn:2890-2892) ----
 		float p_rgb[3] = {0.f, 0.f, 0.f}, p_out = 0.f, p_res = 0.f, sigma_old_raw = 0.f;
@@ -511,7 +511,7 @@ __global__ void map_rays_kernel(const DeviceEdit e, uint32_t n, float* __restric
 	f3 wpos = mk3(c[0], c[1], c[2]);
 	f3 wdir = with_dir ? mk3(c[4], c[5], c[6]) : mk3(0.5f, 0.5f, 0.5f);
 	const f3 p0 = wpos, d0 = wdir;
-	const bool empty = tet_warp(e, with_dir != 0, wpos, wdir);
+	const bool empty = edit_warp(e, with_dir != 0, wpos, wdir);
 	if (wpos.x != p0.x || wpos.y != p0.y || wpos.z != p0.z) { c[0] = wpos.x; c[1] = wpos.y; c[2] = wpos.z; }
 	if (with_dir && (wdir.x != d0.x || wdir.y != d0.y || wdir.z != d0.z)) { c[4] = wdir.x; c[5] = wdir.y; c[6] = wdir.z; }
 	if (empty) empty_mask[i] = 1;
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 			}
 			cell = generate_grid_sample(rng, i, uni ? a.n_uniform : a.n_nonuniform, a.step, m.aabb, a.grid, a.n_cascades, uni ? -0.01f : 0.01f, wpos);
 			f3 unused = mk3(0.5f, 0.5f, 0.5f);
-			for (int k = a.n_edits - 1; k >= 0; --k) empty |= tet_warp(a.edits[k], false, wpos, unused);
+			for (int k = a.n_edits - 1; k >= 0; --k) empty |= edit_warp(a.edits[k], false, wpos, unused);
 		}
 		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
 		const bool phave = __shfl_xor((int)have, 32, 64) != 0;

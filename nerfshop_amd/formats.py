@@ -109,6 +109,16 @@ def save_edits(path, cage_edits):
     operator (proxy_cage, interpolation_mesh; growing_selection.cu:96-115); selection bookkeeping is written empty."""
     ops = []
     for e in cage_edits:
+        if isinstance(e, _abi.AffineDuplicationOp):   # AffineDuplication::to_json, affine_duplication.cu:356-369
+            def m3(a):   # column-major 9 -> rows (Eigen to_json)
+                return [[float(a[3 * c + r]) for c in range(3)] for r in range(3)]
+            c, sc = [float(v) for v in e.selection_center], [float(v) for v in e.selection_scale]
+            box = {"min": c, "max": c, "rot_matrix": m3(e.selection_rot), "u": [1.0, 0.0, 0.0], "v": [0.0, 1.0, 0.0], "w": [0.0, 0.0, 1.0],
+                   "center": c, "scale": sc}   # min / max / u / v / w are rebuilt on load (warp_box), written as placeholders
+            ops.append({"type": "affine_duplication", "selection_box": box, "translation": [float(v) for v in e.translation],
+                        "scale": [float(v) for v in e.scale], "rotation_matrix": m3(e.rotation), "hide_original": bool(e.hide_original),
+                        "correct_dir": bool(e.correct_dir)})
+            continue
         V = e.vertices.shape[0]
         cage = {"vertices": _vec3_rows(e.cage_deformed), "indices": [int(i) for i in e.cage_triangles.reshape(-1)], "normals": [],
                 "initial_normals": [], "labels": [0] * e.cage_vertices.shape[0], "original_vertices": _vec3_rows(e.cage_vertices), "colors": [],
@@ -148,6 +158,11 @@ def load_edits(path):
     try:
         for i in range(lib.nrs_edits_count(h)):
             kind = lib.nrs_edits_type(h, i).decode()
+            if kind == "affine_duplication":
+                op = _abi.AffineDuplicationOp()
+                check(lib.nrs_edits_affine(h, i, C.byref(op)))
+                out.append(op)
+                continue
             if kind != "cage_deformation":
                 out.append(kind)
                 continue

@@ -228,6 +228,17 @@ class CageDeformation:
             pass
 
 
+class AffineDuplication(CageDeformation):
+    """AffineDuplication edit operator (editing/affine_duplication.h): shares map_rays / map_positions with the cage operator."""
+
+    def __init__(self, ctx, desc, op):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.host = op
+        self.h = C.c_void_p()
+        self.n_vertices = self.n_tets = 0
+        check(self.lib.nrs_edit_create_affine(ctx.h, C.byref(desc), C.byref(op), C.byref(self.h)))
+
+
 class RenderBuffer:
     """frame_buffer(): f32x4 premultiplied linear RGBA [H, W, 4]; depth_buffer(): f32 [H, W]; spp(): Sobol sample index."""
 

@@ -498,6 +498,30 @@ def make_cage_edit(lattice_n=10, box=((0.22, 0.60, 0.40), (0.60, 0.76, 0.60)), i
                     cage_deformed=cage_def, mvc_weights=weights, mvc_labels=labels, max_per_cell=max_per_cell)
 
 
+def make_affine_edit(box=((0.22, 0.60, 0.40), (0.60, 0.76, 0.60)), translation=(0.0, 0.12, 0.0), scale=(0.8, 0.9, 1.1), yaw_deg=25.0, box_yaw_deg=10.0,
+                     scene_scale=1.0, hide_original=False, correct_dir=True):
+    """An AffineDuplication of the solid's arm: an oriented selection box (rotated by box_yaw about y) shown again translated,
+    anisotropically scaled and rotated by yaw_deg about y.  -> _abi.AffineDuplicationOp"""
+    from ._abi import AffineDuplicationOp
+    mn, mx = np.array(box[0], np.float64), np.array(box[1], np.float64)
+    mn, mx = (mn - 0.5) * scene_scale + 0.5, (mx - 0.5) * scene_scale + 0.5
+
+    def rot_y(deg):
+        a = np.radians(deg)
+        return np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+
+    op = AffineDuplicationOp()
+    op.selection_center[:] = [float(v) for v in (0.5 * (mn + mx)).astype(np.float32)]
+    op.selection_scale[:] = [float(v) for v in (mx - mn).astype(np.float32)]
+    op.selection_rot[:] = [float(v) for v in rot_y(box_yaw_deg).T.reshape(-1)]   # column-major
+    op.translation[:] = [float(np.float32(t * scene_scale)) for t in translation]
+    op.scale[:] = [float(np.float32(v)) for v in scale]
+    op.rotation[:] = [float(v) for v in rot_y(yaw_deg).T.reshape(-1)]
+    op.hide_original = 1 if hide_original else 0
+    op.correct_dir = 1 if correct_dir else 0
+    return op
+
+
 def deformed_density_grid(grid, desc, map_positions, aabb_scale=1):
     """One-shot, noise-free update_density_grid_nerf_operator (testbed_nerf.cu:3533-3640): occupancy of the EDITED scene.
 

@@ -583,7 +583,14 @@ inline bool point_in_tet(V3 v1, V3 v2, V3 v3_, V3 v4, V3 p) { // :41-47
 	       same_side_tet(v3_, v4, v1, v2, p) && same_side_tet(v4, v1, v2, v3_, p);
 }
 
+// AffineBoundingBox after warp_box (affine_bounding_box.cuh:83-101): what translate_in_box tests
+struct ABox { V3 mn, u, v, w, center; float uu, vv, ww; };
 struct Edit {
+	int kind = 0;                               // 0 = CageDeformation, 1 = AffineDuplication
+	ABox a_dst, a_sel;                          // m_warped_destination_box, m_warped_selection_box
+	V3 a_translation, a_scale;                  // m_warped_translation, m_scale
+	float a_rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; // m_rotation_matrix, column-major
+	bool a_hide_original = false, a_correct_dir = true;
 	Box aabb;                                   // scene aabb (m_scene_aabb)
 	Box bbox, warped_bbox, orig_bbox, orig_warped_bbox; // tet_mesh.cu:12-20, tet_mesh.h:100-107
 	std::vector<V3> verts, orig;
@@ -609,8 +616,35 @@ Box bbox_of(const std::vector<V3>& v) {
 }
 Box warp_box(const Box& b, const Box& aabb) { return Box{warp_position(b.mn, aabb), warp_position(b.mx, aabb)}; } // bounding_box.cuh:272
 
+// AffineDuplication: translate_in_box / translate_in_box_pos, affine_duplication.cu:69-118
+inline bool abox_contains(const ABox& b, V3 p) { // affine_bounding_box.cuh:83-88
+	V3 q = p - b.mn;
+	float du = dot(b.u, q), dv = dot(b.v, q), dw = dot(b.w, q);
+	return du >= 0.f && du < b.uu && dv >= 0.f && dv < b.vv && dw >= 0.f && dw < b.ww;
+}
+inline V3 mul_rt(const float* R, V3 q) { // R^T q, R column-major
+	return {(R[0] * q.x + R[1] * q.y) + R[2] * q.z, (R[3] * q.x + R[4] * q.y) + R[5] * q.z, (R[6] * q.x + R[7] * q.y) + R[8] * q.z};
+}
+static void affine_map_one(const Edit& e, float* pos, float* dir /* nullable */, uint8_t* empty) {
+	V3 p = {pos[0], pos[1], pos[2]};
+	if (abox_contains(e.a_dst, p)) {
+		V3 d = p - e.a_dst.center;
+		V3 q = {d.x / e.a_scale.x, d.y / e.a_scale.y, d.z / e.a_scale.z};
+		V3 r = mul_rt(e.a_rot, q) + e.a_dst.center;
+		r = r - e.a_translation;
+		pos[0] = r.x; pos[1] = r.y; pos[2] = r.z;
+		if (dir && e.a_correct_dir) {
+			V3 wd = warp_direction(mul_rt(e.a_rot, unwarp_direction(v3(dir[0], dir[1], dir[2]))));
+			dir[0] = wd.x; dir[1] = wd.y; dir[2] = wd.z;
+		}
+	} else if (e.a_hide_original && abox_contains(e.a_sel, p)) {
+		*empty = 1;
+	}
+}
+
 // interpolate_tet, cage_deformation.cu:197-269.  coord: 7 floats, in place.  returns through *empty.
 void map_ray_one(const Edit& e, float coord[7], uint8_t* empty) {
+	if (e.kind == 1) { affine_map_one(e, coord, coord + 4, empty); return; }
 	V3 p = {coord[0], coord[1], coord[2]};
 	bool in_deformed = false;
 	if (box_contains(e.warped_bbox, p)) {
@@ -654,6 +688,7 @@ void map_ray_one(const Edit& e, float coord[7], uint8_t* empty) {
 
 // interpolate_tet_pos, cage_deformation.cu:136-192 (no direction, no copy flag)
 void map_position_one(const Edit& e, float pos[3], uint8_t* empty) {
+	if (e.kind == 1) { affine_map_one(e, pos, nullptr, empty); return; }
 	V3 p = {pos[0], pos[1], pos[2]};
 	bool in_deformed = false;
 	if (box_contains(e.warped_bbox, p)) {
@@ -1304,6 +1339,50 @@ void* orc_edit_create(const nrs_model_desc* d, const nrs_tet_mesh* mesh) {
 	e->warped_bbox = warp_box(e->bbox, e->aabb);
 	e->orig_bbox = bbox_of(e->orig);        // ctor, tet_mesh.h:100-107
 	e->orig_warped_bbox = warp_box(e->orig_bbox, e->aabb);
+	return e;
+}
+// AffineDuplication(selection_box, ...) + update_destination, affine_duplication.h:26-40, 77-90; box bookkeeping
+// affine_bounding_box.cuh:40-101.  Only center / scale / rot_matrix of the selection box enter (warp_box rebuilds the rest).
+static void abox_finish(const float center[3], const float scale[3], const float rot[9], ABox& out) {
+	float u[3], v[3], w[3], mn[3];
+	for (int i = 0; i < 3; ++i) {
+		u[i] = rot[i] * scale[0];
+		v[i] = rot[3 + i] * scale[1];
+		w[i] = rot[6 + i] * scale[2];
+		mn[i] = (((-0.5f * rot[i]) * scale[0] + (-0.5f * rot[3 + i]) * scale[1]) + (-0.5f * rot[6 + i]) * scale[2]) + center[i];
+	}
+	out.u = v3(u[0], u[1], u[2]); out.v = v3(v[0], v[1], v[2]); out.w = v3(w[0], w[1], w[2]);
+	out.mn = v3(mn[0], mn[1], mn[2]);
+	out.center = v3(center[0], center[1], center[2]);
+	out.uu = dot(out.u, out.u); out.vv = dot(out.v, out.v); out.ww = dot(out.w, out.w);
+}
+void* orc_edit_create_affine(const nrs_model_desc* d, const nrs_affine_duplication* op) {
+	Edit* e = new Edit();
+	e->kind = 1;
+	e->aabb = Box{v3(d->aabb_min[0], d->aabb_min[1], d->aabb_min[2]), v3(d->aabb_max[0], d->aabb_max[1], d->aabb_max[2])};
+	const float diag[3] = {d->aabb_max[0] - d->aabb_min[0], d->aabb_max[1] - d->aabb_min[1], d->aabb_max[2] - d->aabb_min[2]};
+	float sc[3], ss[3], dc[3], ds[3], drot[9];
+	for (int i = 0; i < 3; ++i) {
+		dc[i] = op->selection_center[i] + op->translation[i];   // translate
+		ds[i] = op->selection_scale[i] * op->scale[i];           // scale_with_vector
+	}
+	for (int c = 0; c < 3; ++c)                                   // rotate: rot_matrix = rotation * rot_matrix
+		for (int r = 0; r < 3; ++r)
+			drot[3 * c + r] = (op->rotation[r] * op->selection_rot[3 * c] + op->rotation[3 + r] * op->selection_rot[3 * c + 1]) +
+			                  op->rotation[6 + r] * op->selection_rot[3 * c + 2];
+	for (int i = 0; i < 3; ++i) {                                 // warp_box: relative_pos(center), scale / diag
+		dc[i] = (dc[i] - d->aabb_min[i]) / diag[i];
+		ds[i] = ds[i] / diag[i];
+		sc[i] = (op->selection_center[i] - d->aabb_min[i]) / diag[i];
+		ss[i] = op->selection_scale[i] / diag[i];
+	}
+	abox_finish(dc, ds, drot, e->a_dst);
+	abox_finish(sc, ss, op->selection_rot, e->a_sel);
+	e->a_translation = v3(op->translation[0] / diag[0], op->translation[1] / diag[1], op->translation[2] / diag[2]);
+	e->a_scale = v3(op->scale[0], op->scale[1], op->scale[2]);
+	memcpy(e->a_rot, op->rotation, sizeof(e->a_rot));
+	e->a_hide_original = op->hide_original != 0;
+	e->a_correct_dir = op->correct_dir != 0;
 	return e;
 }
 void orc_edit_destroy(void* e) { delete (Edit*)e; }

@@ -44,7 +44,7 @@ def load():
         "orc_model_create": (P, [P, P, C.c_size_t, P]), "orc_model_set_bitfield": (None, [P, P]), "orc_model_destroy": (None, [P]),
         "orc_hashgrid_encode": (None, [P, U32, P, U32, P]), "orc_sh4_encode": (None, [U32, P, U32, P]),
         "orc_network_inference": (None, [P, U32, P, P, U32, I]), "orc_network_density": (None, [P, U32, P, U32, P, U32, I]),
-        "orc_edit_create": (P, [P, P]), "orc_edit_destroy": (None, [P]),
+        "orc_edit_create": (P, [P, P]), "orc_edit_create_affine": (P, [P, P]), "orc_edit_destroy": (None, [P]),
         "orc_edit_map_rays": (None, [P, U32, P, P]), "orc_edit_map_positions": (None, [P, U32, P, U32, P]),
         "orc_render": (None, [P, P, P, I, P, P, P, P, I, I]), "orc_max_threads": (I, []),
         "orc_trace_samples": (None, [P, P, U32, P, U32, P, P, P]),
@@ -163,6 +163,15 @@ class Edit:
         if getattr(self, "h", None):
             self.lib.orc_edit_destroy(self.h)
             self.h = None
+
+
+class AffineEdit(Edit):
+    """AffineDuplication restated; same map_rays / map_positions interface as Edit."""
+
+    def __init__(self, desc, affine_op):
+        self.lib = load()
+        self.keepalive = affine_op
+        self.h = self.lib.orc_edit_create_affine(C.byref(desc), C.byref(affine_op))
 
 
 def tet_lut_build(vertices, tets):

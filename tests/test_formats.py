@@ -90,10 +90,10 @@ def test_edits_round_trip(scene, tmp_path):
     assert np.array_equal(c.cage_triangles.reshape(-1), e.cage_triangles.reshape(-1))
     # operators the reference's load_edits accepts but this path does not execute are reported by type
     doc = json.loads(path.read_text())
-    doc["edit_operators"].insert(0, {"type": "affine_duplication"})
+    doc["edit_operators"].insert(0, {"type": "twist"})
     path.write_text(json.dumps(doc))
     ops = formats.load_edits(path)
-    assert ops[0] == "affine_duplication" and np.array_equal(ops[1].tets, e.tets)
+    assert ops[0] == "twist" and np.array_equal(ops[1].tets, e.tets)
     doc["edit_operators"].append({"type": "bogus"})
     path.write_text(json.dumps(doc))
     with pytest.raises(_abi.NrsError) as ei:
@@ -115,3 +115,17 @@ def test_json_parser_corner_cases(built, tmp_path):
     p.write_text("[" * 100 + "]" * 100)
     with pytest.raises(_abi.NrsError):
         formats.load_edits(p)
+
+
+def test_affine_edit_round_trip(built, tmp_path):
+    op = synth.make_affine_edit(hide_original=True)
+    path = tmp_path / "affine.json"
+    formats.save_edits(path, [op])
+    got = formats.load_edits(path)
+    assert len(got) == 1
+    assert bytes(got[0]) == bytes(op)
+    doc = json.loads(path.read_text())
+    del doc["edit_operators"][0]["translation"]
+    path.write_text(json.dumps(doc))
+    with pytest.raises(_abi.NrsError):
+        formats.load_edits(path)

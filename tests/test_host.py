@@ -28,13 +28,13 @@ def test_library_exports_every_declared_symbol(built):
 def test_struct_layouts_match_header(built):
     """ctypes mirrors must have the C compiler's sizes (checked against a tiny C program's sizeof)."""
     import subprocess, tempfile
-    src = '#include <stdio.h>\n#include "nrs.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(nrs_model_desc), sizeof(nrs_tet_mesh), sizeof(nrs_render_params), sizeof(nrs_render_stats), sizeof(nrs_grid_update));return 0;}\n'
+    src = '#include <stdio.h>\n#include "nrs.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(nrs_model_desc), sizeof(nrs_tet_mesh), sizeof(nrs_render_params), sizeof(nrs_render_stats), sizeof(nrs_grid_update), sizeof(nrs_affine_duplication));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         sizes = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
     assert sizes == [C.sizeof(_abi.ModelDesc), C.sizeof(_abi.TetMesh), C.sizeof(_abi.RenderParams), C.sizeof(_abi.RenderStats),
-                     C.sizeof(_abi.GridUpdate)]
+                     C.sizeof(_abi.GridUpdate), C.sizeof(_abi.AffineDuplicationOp)]
 
 
 def test_no_gpu_is_a_loud_error(built):
