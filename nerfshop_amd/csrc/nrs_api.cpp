@@ -800,6 +800,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 			if (!edits[i]) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: NULL edit operator");
 			host_edits[i] = edits[i]->de;
 			a.any_poisson |= edits[i]->de.apply_poisson;
+			a.any_affine |= (edits[i]->de.kind == kEditAffine) ? 1u : 0u;
 		}
 		HIP_TRY(hipMemcpyAsync(ctx->d_edits, host_edits, sizeof(DeviceEdit) * n_edits, hipMemcpyHostToDevice, s));
 	}

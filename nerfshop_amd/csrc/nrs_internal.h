@@ -95,6 +95,7 @@ struct RenderArgs {
 	const DeviceEdit* edits;   // device array, applied last-to-first
 	int32_t  n_edits;
 	uint32_t any_poisson;      // some edit has apply_poisson set
+	uint32_t any_affine;       // some edit is an AffineDuplication
 	uint32_t n_packets;        // 8x8 pixel packets owned by this call
 	uint32_t tiles_x;          // image width in tiles (tiled mode) or in 32x32 super-tiles (whole-image mode)
 	uint32_t packets_per_tile_x;
