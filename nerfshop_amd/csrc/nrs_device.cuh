@@ -122,6 +122,21 @@ __device__ __forceinline__ float distance_to_next_voxel(f3 pos, f3 dir, f3 idir,
 }
 __device__ __forceinline__ float advance_to_next_voxel(float t, float cone_angle, f3 pos, f3 dir, f3 idir, uint32_t res, float inv_res) {
 	float t_target = t + distance_to_next_voxel(pos, dir, idir, res, inv_res);
+	if (cone_angle == 0.f) {
+		// constant step (aabb_scale 1): the same chain of float additions as the loop below, but the first eight are
+		// straight-line select code -- a cell diagonal is at most sqrt(3)/128 = 8 steps of sqrt(3)/1024, so the divergent
+		// loop (whose trip count is the wave's maximum) only runs for coarser cascades.
+		// t += (t < t_target) ? dt : 0 without a compare/select pair (VCC hazards): m = clamp((t_target - t) * 2^100, 0, 1)
+		// is exactly 1 or 0, and fmaf(m, dt, t) rounds t + dt exactly as the addition does (m * dt is exact).
+		t += NRS_MIN_STEP;
+		#pragma unroll
+		for (int k = 0; k < 7; ++k) {
+			const float m = __builtin_amdgcn_fmed3f((t_target - t) * 0x1p100f, 0.0f, 1.0f);
+			t = fmaf(m, NRS_MIN_STEP, t);
+		}
+		while (t < t_target) t += NRS_MIN_STEP;
+		return t;
+	}
 	do {
 		t += calc_dt(t, cone_angle);
 	} while (t < t_target);
@@ -142,16 +157,19 @@ __device__ __forceinline__ bool get_bitfield_at(uint32_t cell_idx, uint32_t leve
 __device__ __forceinline__ bool density_grid_occupied_at(f3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip) {
 	return get_bitfield_at(cascaded_grid_idx_at(pos, mip), mip, bitfield);
 }
+// min(4, max(0, frexp_exponent(maxval) + 1)) without branches: the biased exponent alone decides (sub-normal maxval
+// clamps to 0 like every maxval < 0.5), except frexpf(0) = 0 * 2^0, which the reference turns into mip 1.
 __device__ __forceinline__ int mip_from_pos(f3 pos) {
 	float maxval = fmaxf(fmaxf(fabsf(pos.x - 0.5f), fabsf(pos.y - 0.5f)), fabsf(pos.z - 0.5f));
-	int exponent = frexp_exponent(maxval);
-	return min((int)kCascades - 1, max(0, exponent + 1));
+	const uint32_t u = __float_as_uint(maxval); // maxval >= 0
+	const int mip = min((int)kCascades - 1, max(0, (int)(u >> 23) - 125));
+	return u == 0 ? 1 : mip;
 }
 __device__ __forceinline__ int mip_from_dt(float dt, f3 pos) {
 	int mip = mip_from_pos(pos);
 	dt *= 2 * kGrid;
-	if (dt < 1.f) return mip;
-	int exponent = frexp_exponent(dt);
+	// dt >= 1 is a normal number: frexp exponent = biased exponent - 126; for dt < 1 that is <= 0 <= mip, so max() keeps mip
+	const int exponent = (int)(__float_as_uint(dt) >> 23) - 126;
 	return min((int)kCascades - 1, max(exponent, mip));
 }
 __device__ __forceinline__ f3 warp_position(f3 pos, const Box3& aabb) {
