@@ -540,6 +540,13 @@ int nrs_edit_create(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_tet_mesh
 	e->n_tets = mesh->n_tets;
 	DeviceEdit& de = e->de;
 	for (int k = 0; k < 3; ++k) { de.aabb.mn[k] = desc->aabb_min[k]; de.aabb.mx[k] = desc->aabb_max[k]; }
+	de.diag_pow2 = 1;
+	for (int k = 0; k < 3; ++k) {
+		const float diag = desc->aabb_max[k] - desc->aabb_min[k];
+		int ex = 0;
+		if (std::frexp(diag, &ex) != 0.5f) de.diag_pow2 = 0;
+		de.inv_diag[k] = 1.0f / diag;
+	}
 	Box3 orig_bbox;
 	box_of(mesh->h_vertices, mesh->n_vertices, de.bbox);           // post_update_vertices, tet_mesh.cu:12-20
 	warp_box(de.bbox, de.aabb, de.warped_bbox);

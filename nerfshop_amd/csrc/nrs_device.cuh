@@ -348,7 +348,8 @@ __device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3&
 			f3 canon = bc[0] * ld3(e.orig, tv.x) + bc[1] * ld3(e.orig, tv.y);
 			canon = canon + bc[2] * ld3(e.orig, tv.z);
 			canon = canon + bc[3] * ld3(e.orig, tv.w);
-			wpos = warp_position(canon, e.aabb);
+			wpos = e.diag_pow2 ? mk3((canon.x - e.aabb.mn[0]) * e.inv_diag[0], (canon.y - e.aabb.mn[1]) * e.inv_diag[1], (canon.z - e.aabb.mn[2]) * e.inv_diag[2])
+			                   : warp_position(canon, e.aabb);
 			__builtin_amdgcn_sched_barrier(0);
 			if (with_dir && e.rot) {
 				const f3 ud = unwarp_direction(wdir);
@@ -558,8 +559,8 @@ __device__ __forceinline__ float network_to_density(float v, uint32_t act) {
 // x^2.4 as exp2(2.4 * log2 x) on the transcendental unit (v_log_f32 / v_exp_f32, ~1 ulp each): |rel. error| < 1e-5 on
 // (0.04, 1], far inside the stated colour tolerance, and ~100 instructions cheaper per channel than powf.
 __device__ __forceinline__ float srgb_to_linear(float s) {
-	if (s <= 0.04045f) return s / 12.92f;
-	return __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf((s + 0.055f) / 1.055f));
+	if (s <= 0.04045f) return s * (1.0f / 12.92f);
+	return __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf((s + 0.055f) * (1.0f / 1.055f)));
 }
 
 } // namespace nrs

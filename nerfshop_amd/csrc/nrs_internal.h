@@ -62,6 +62,8 @@ struct DeviceEdit {
 	AffineBox a_dst, a_sel;
 	float a_translation[3], a_scale[3], a_rot[9];
 	Box3 aabb;                 // scene aabb
+	float inv_diag[3];         // 1 / (aabb.max - aabb.min)
+	uint32_t diag_pow2;        // every extent a power of two: x / d == x * (1 / d) bit for bit (DeviceModel::diag_pow2)
 	Box3 bbox;                 // deformed mesh, world units           (TetMesh::bbox)
 	Box3 warped_bbox;          // bbox in warped [0,1] coordinates     (TetMesh::warped_bbox)
 	Box3 orig_warped_bbox;     // canonical mesh, warped               (TetMesh::original_warped_bbox)
