@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnrs.so")
+LIB_PATH = os.environ.get("NRS_LIB_PATH") or os.path.join(_HERE, "csrc", "libnrs.so")  # NRS_LIB_PATH: A/B builds while profiling
 
 NRS_OK = 0
 GRID_SIZE = 128
