@@ -841,6 +841,10 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 				if (c.phase_cycles[i] && i != 6) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)c.phase_cycles[i] / (double)tot);
 			fprintf(stderr, " | mean wave lifetime = %.1f%% of the longest (%.2f Mcycles)", 100.0 * ((double)tot / 4096.0) / (double)c.phase_cycles[6], (double)c.phase_cycles[6] / 1e6);
 			fprintf(stderr, "\n");
+			fprintf(stderr, "[nrs walk] fill: %llu lane iterations in %llu wave trips (%.1f lanes busy per trip); march: %llu lane iterations in %llu wave trips "
+			        "(%.1f lanes/trip), %llu of %llu rounds needed > 1 trip; live lanes per round %.1f\n",
+			        c.walk[0], c.walk[1], c.walk[1] ? (double)c.walk[0] / (double)c.walk[1] : 0.0, c.walk[2], c.walk[3],
+			        c.walk[3] ? (double)c.walk[2] / (double)c.walk[3] : 0.0, c.walk[6], c.walk[4], c.walk[4] ? (double)c.walk[5] / (double)c.walk[4] : 0.0);
 			// per-wave log: when did each wave finish (wall clock), when did it first find the frame's queue empty
 			std::vector<unsigned long long> wl(8192 * 4);
 			HIP_TRY(hipMemcpy(wl.data(), ctx->d_wave_log, wl.size() * 8, hipMemcpyDeviceToHost));

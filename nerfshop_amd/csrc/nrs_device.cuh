@@ -265,12 +265,13 @@ __device__ __forceinline__ bool ray_meets_box_ahead(const Box3& b, f3 o, f3 idir
 // executed verbatim, so the first accepted t is bit-identical -- and (ii) once the remaining ray cannot meet the box any
 // more, no further sample can ever be emitted and the walk to the far side of the render box is cut short.
 __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, const uint8_t* __restrict__ bitfield, const Box3& occ_box, f3 o, f3 d,
-                                                  f3 idir, float& t, f3& pos, float& dt) {
+                                                  f3 idir, float& t, f3& pos, float& dt, uint32_t* n_iter = nullptr) {
 	Box3 bb;
 	#pragma unroll
 	for (int i = 0; i < 3; ++i) { bb.mn[i] = p.render_aabb_min[i]; bb.mx[i] = p.render_aabb_max[i]; }
 	const float cone = p.cone_angle_constant;
 	while (1) {
+		if (n_iter) ++*n_iter; // profiling build only
 		pos = o + d * t;
 		if (!box_contains(bb, pos)) return false;
 		dt = calc_dt(t, cone);
@@ -286,12 +287,13 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 }
 
 // advance_pos_nerf, tn:557-606: jitter by one Sobol value, then skip to the first occupied cell
-__device__ __forceinline__ bool first_hit(const nrs_render_params& p, const uint8_t* __restrict__ bitfield, const Box3& occ_box, uint32_t pixel_idx, Ray& r) {
+__device__ __forceinline__ bool first_hit(const nrs_render_params& p, const uint8_t* __restrict__ bitfield, const Box3& occ_box, uint32_t pixel_idx, Ray& r,
+                                          uint32_t* n_iter = nullptr) {
 	f3 idir = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
 	float dt = calc_dt(r.t, p.cone_angle_constant);
 	r.t += ld_random_val(p.spp_index, pixel_idx * 786433u) * dt;
 	f3 pos;
-	return march_to_occupied(p, bitfield, occ_box, r.o, r.d, idir, r.t, pos, dt);
+	return march_to_occupied(p, bitfield, occ_box, r.o, r.d, idir, r.t, pos, dt, n_iter);
 }
 
 // ---- tet warp: selection_utils.h:10-47, cage_deformation.cu:136-269 -----------------------------------------------

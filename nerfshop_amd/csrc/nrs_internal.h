@@ -90,6 +90,9 @@ struct RenderCounters {    // zeroed before every launch
 	uint32_t n_rays_hit;
 	uint32_t pad;
 	unsigned long long phase_cycles[8]; // NRS_DEBUG & 4: per-phase wave cycles (profiling build of the kernel only)
+	// NRS_DEBUG & 4: voxel-walk statistics. [0]/[1] fill: lane iterations / wave trips (= max over lanes per call);
+	// [2]/[3] the same for the per-sample march; [4] sample rounds, [5] live lanes summed over rounds, [6] march calls with > 1 trip
+	unsigned long long walk[8];
 };
 
 struct RenderArgs {

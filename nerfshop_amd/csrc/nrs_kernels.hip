@@ -117,6 +117,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	uint32_t st_samples = 0, st_alive = 0, st_hit = 0;
 	unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
 	unsigned long long pf_rounds = 0, pf_packets = 0, pf_tq = 0, pf_rounds_q = 0;
+	unsigned long long pf_walk[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // see RenderCounters::walk
 	const unsigned long long pf_wall0 = PROF ? wall_clock64() : 0ull; // 100 MHz, identical on every XCD (s_memtime is the per-XCD shader clock)
 	int ph_cur = 0;
 
@@ -148,7 +149,13 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				a.depth[oi] = 1e10f; // tn:2586
 				if (a.steps) a.steps[oi] = 0;
 				alive = r.alive;
-				if (alive) alive = first_hit(p, m.bitfield, m.occ_box, x + (uint32_t)p.resolution[0] * y, r);
+				uint32_t it_fill = 0;
+				if (alive) alive = first_hit(p, m.bitfield, m.occ_box, x + (uint32_t)p.resolution[0] * y, r, PROF ? &it_fill : nullptr);
+				if (PROF) {
+					uint32_t mx = it_fill;
+					for (int sh = 32; sh > 0; sh >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, sh, 64));
+					pf_walk[0] += it_fill; pf_walk[1] += (lane == 0) ? mx : 0u;
+				}
 				t0 = r.t;
 			}
 			const unsigned long long am = __ballot(alive);
@@ -260,6 +267,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 
 		NRS_PHASE(5); // composite + march + shade
 		// ---- composite_kernel_nerf body (tn:750-955, Shade mode) + next-sample march ----
+		uint32_t it_march = 0;
+		if (PROF) { pf_walk[4] += (lane == 0) ? 1u : 0u; pf_walk[5] += have ? 1u : 0u; }
 		if (have) {
 			const f3 cpos = unwarp_position(wpos, m.aabb);
 			const float T = 1.f - ca;
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			} else {
 				t += dt;
 				f3 npos; float ndt;
-				done = !march_to_occupied(p, m.bitfield, m.occ_box, o, d, idir, t, npos, ndt);
+				done = !march_to_occupied(p, m.bitfield, m.occ_box, o, d, idir, t, npos, ndt, PROF ? &it_march : nullptr);
 			}
 			if (done) {
 				if (shade && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
@@ -327,9 +336,15 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				have = false;
 			}
 		}
+		if (PROF) {
+			uint32_t mx = it_march;
+			for (int sh = 32; sh > 0; sh >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, sh, 64));
+			pf_walk[2] += it_march; pf_walk[3] += (lane == 0) ? mx : 0u; pf_walk[6] += (lane == 0 && mx > 1) ? 1u : 0u;
+		}
 	}
 
 	if (PROF) {
+		for (int i = 0; i < 8; ++i) if (pf_walk[i]) atomicAdd(&a.counters->walk[i], pf_walk[i]);
 		NRS_PHASE(7);
 		if (lane == 0) {
 			unsigned long long life = 0;
