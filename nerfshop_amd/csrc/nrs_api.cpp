@@ -58,6 +58,7 @@ struct nrs_model {
 	uint32_t* d_grid = nullptr;
 	uint16_t* d_wfrag = nullptr;
 	uint8_t* d_bitfield = nullptr;
+	OccAccel accel_any{}, accel_exact{}; // marching shortcuts for general step parameters / for cone_angle == 0 && min_mip == 0
 	float* d_density_grid = nullptr;   // m_nerf.density_grid [5*128^3], kept for the occupancy refresh
 	uint32_t* d_density_tmp = nullptr; // density_grid_tmp (float bits), allocated on first refresh
 	bool have_params = false, have_bitfield = false;
@@ -178,13 +179,26 @@ static uint32_t compact3(uint32_t x) {
 	x = (x | (x >> 16)) & 0x0000ffffu;
 	return x;
 }
-static void occupied_bounds(const uint8_t* bitfield, Box3& out) {
+// exact_mip: the caller renders with cone_angle == 0 and min_mip == 0, so the cascade tested at a position is
+// mip_from_pos(pos) and nothing else: a cell of cascade L >= 1 can only ever be consulted from the shell
+// 2^(L-2) <= max|pos - 0.5| (cn:163-168); cells that lie entirely inside that shell's hole are ignored.  This is what keeps
+// the OR-pooled coarse cascades of an aabb_scale-1 scene from blowing the box (and the mask below) up to their resolution.
+static bool cell_block_relevant(uint32_t level, const uint32_t c[3], bool exact_mip, float margin) {
+	if (!exact_mip || level == 0) return true;
+	const float s = std::ldexp(1.0f, (int)level);
+	float far = 0.f;
+	for (int k = 0; k < 3; ++k) {
+		const float a = ((float)c[k] / (float)kGrid - 0.5f) * s - margin, b = ((float)(c[k] + 2u) / (float)kGrid - 0.5f) * s + margin; // pos - 0.5
+		far = std::fmax(far, std::fmax(std::fabs(a), std::fabs(b)));
+	}
+	return far >= std::ldexp(1.0f, (int)level - 2);
+}
+static void occupied_bounds(const uint8_t* bitfield, bool exact_mip, Box3& out) {
 	const float inf = std::numeric_limits<float>::infinity();
 	for (int k = 0; k < 3; ++k) { out.mn[k] = inf; out.mx[k] = -inf; }
 	for (uint32_t level = 0; level < kCascades; ++level) {
-		uint32_t lo[3] = {kGrid, kGrid, kGrid}, hi[3] = {0, 0, 0};
-		bool any = false;
 		const uint8_t* b = bitfield + (size_t)level * kGridVol / 8;
+		const float s = std::ldexp(1.0f, (int)level), margin = s / (float)kGrid / 16.f;
 		for (uint32_t byte = 0; byte < kGridVol / 8; ++byte) {
 			if ((byte & 7u) == 0) { // most of the field is empty: skip 8 bytes (64 cells) at a time
 				uint64_t w;
@@ -192,20 +206,60 @@ static void occupied_bounds(const uint8_t* bitfield, Box3& out) {
 				if (!w) { byte += 7; continue; }
 			}
 			if (!b[byte]) continue;
-			any = true;
 			// the 8 cells of a byte are one 2x2x2 Morton block: bounds of the block are exact enough (<= 1 cell slack)
 			const uint32_t m = byte * 8;
 			const uint32_t c[3] = {compact3(m), compact3(m >> 1), compact3(m >> 2)};
-			for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], c[k]); hi[k] = std::max(hi[k], c[k] + 2u); }
-		}
-		if (!any) continue;
-		const float s = std::ldexp(1.0f, (int)level), margin = s / (float)kGrid / 16.f;
-		for (int k = 0; k < 3; ++k) {
-			out.mn[k] = std::fmin(out.mn[k], ((float)lo[k] / (float)kGrid - 0.5f) * s + 0.5f - margin);
-			out.mx[k] = std::fmax(out.mx[k], ((float)hi[k] / (float)kGrid - 0.5f) * s + 0.5f + margin);
+			if (!cell_block_relevant(level, c, exact_mip, margin)) continue;
+			for (int k = 0; k < 3; ++k) {
+				out.mn[k] = std::fmin(out.mn[k], ((float)c[k] / (float)kGrid - 0.5f) * s + 0.5f - margin);
+				out.mx[k] = std::fmax(out.mx[k], ((float)(c[k] + 2u) / (float)kGrid - 0.5f) * s + 0.5f + margin);
+			}
 		}
 	}
 }
+
+// The look-ahead mask over occ_box (OccAccel::mask): every relevant occupied 2x2x2 Morton block of every cascade marks the
+// coarse blocks its (inflated) extent overlaps.
+static void occupied_accel(const uint8_t* bitfield, bool exact_mip, OccAccel& acc) {
+	occupied_bounds(bitfield, exact_mip, acc.box);
+	memset(acc.mask, 0, sizeof(acc.mask));
+	for (int k = 0; k < 3; ++k) { acc.cell[k] = 1.f; acc.inv_cell[k] = 1.f; }
+	if (!(acc.box.mn[0] <= acc.box.mx[0])) return; // nothing occupied
+	for (int k = 0; k < 3; ++k) {
+		acc.cell[k] = (acc.box.mx[k] - acc.box.mn[k]) / (float)kCoarse;
+		acc.inv_cell[k] = 1.0f / acc.cell[k];
+	}
+	for (uint32_t level = 0; level < kCascades; ++level) {
+		const uint8_t* b = bitfield + (size_t)level * kGridVol / 8;
+		const float s = std::ldexp(1.0f, (int)level), margin = s / (float)kGrid / 16.f;
+		for (uint32_t byte = 0; byte < kGridVol / 8; ++byte) {
+			if ((byte & 7u) == 0) {
+				uint64_t w;
+				memcpy(&w, b + byte, 8);
+				if (!w) { byte += 7; continue; }
+			}
+			if (!b[byte]) continue;
+			const uint32_t m = byte * 8;
+			const uint32_t c[3] = {compact3(m), compact3(m >> 1), compact3(m >> 2)};
+			if (!cell_block_relevant(level, c, exact_mip, margin)) continue;
+			int lo[3], hi[3];
+			for (int k = 0; k < 3; ++k) {
+				const float wmin = ((float)c[k] / (float)kGrid - 0.5f) * s + 0.5f - margin;
+				const float wmax = ((float)(c[k] + 2u) / (float)kGrid - 0.5f) * s + 0.5f + margin;
+				lo[k] = std::min((int)kCoarse - 1, std::max(0, (int)std::floor((wmin - acc.box.mn[k]) * acc.inv_cell[k])));
+				hi[k] = std::min((int)kCoarse - 1, std::max(0, (int)std::floor((wmax - acc.box.mn[k]) * acc.inv_cell[k])));
+			}
+			for (int z = lo[2]; z <= hi[2]; ++z)
+				for (int y = lo[1]; y <= hi[1]; ++y)
+					for (int x = lo[0]; x <= hi[0]; ++x) {
+						const uint32_t idx = ((uint32_t)z * kCoarse + (uint32_t)y) * kCoarse + (uint32_t)x;
+						acc.mask[idx >> 5] |= 1u << (idx & 31);
+					}
+		}
+	}
+}
+// DeviceModel as one render / trace launch sees it: the marching accelerator that matches the launch's step parameters
+static DeviceModel model_for_launch(const nrs_model* m, const nrs_render_params& p);
 
 template <typename T>
 static int upload(nrs_edit* e, const T* h, size_t count, const T** d_out) {
@@ -215,6 +269,12 @@ static int upload(nrs_edit* e, const T* h, size_t count, const T** d_out) {
 	if (count) HIP_TRY(hipMemcpy(d, h, count * sizeof(T), hipMemcpyHostToDevice));
 	*d_out = (const T*)d;
 	return NRS_OK;
+}
+
+static DeviceModel model_for_launch(const nrs_model* m, const nrs_render_params& p) {
+	DeviceModel dm = m->dm;
+	dm.occ = (p.cone_angle_constant == 0.f && p.min_mip == 0) ? m->accel_exact : m->accel_any;
+	return dm;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -344,7 +404,8 @@ int nrs_model_set_density_bitfield(nrs_model* m, const uint8_t* h_bitfield, size
 	if (n_bytes != NRS_BITFIELD_BYTES) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_density_bitfield: expected 5*128^3/8 bytes");
 	HIP_TRY(hipSetDevice(m->ctx->device));
 	HIP_TRY(hipMemcpy(m->d_bitfield, h_bitfield, n_bytes, hipMemcpyHostToDevice));
-	occupied_bounds(h_bitfield, m->dm.occ_box);
+	occupied_accel(h_bitfield, false, m->accel_any);
+	occupied_accel(h_bitfield, true, m->accel_exact);
 	m->have_bitfield = true;
 	return NRS_OK;
 }
@@ -356,7 +417,8 @@ static int refresh_bitfield(nrs_model* m, void* stream) {
 	std::vector<uint8_t> host_bits(NRS_BITFIELD_BYTES);
 	HIP_TRY(hipMemcpyAsync(host_bits.data(), m->d_bitfield, NRS_BITFIELD_BYTES, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
-	occupied_bounds(host_bits.data(), m->dm.occ_box);
+	occupied_accel(host_bits.data(), false, m->accel_any);
+	occupied_accel(host_bits.data(), true, m->accel_exact);
 	m->have_bitfield = true;
 	return NRS_OK;
 }
@@ -824,7 +886,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	a.wave_log = (a.dbg & 4u) ? ctx->d_wave_log : nullptr;
 	if (a.wave_log) HIP_TRY(hipMemsetAsync(ctx->d_wave_log, 0, 8192 * 4 * 8, s));
 	HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(RenderCounters), s));
-	NRS_TRY(launch_render(m->dm, a, ctx->n_cus, s));
+	NRS_TRY(launch_render(model_for_launch(m, *p), a, ctx->n_cus, s));
 	if (h_stats) {
 		RenderCounters c;
 		HIP_TRY(hipMemcpyAsync(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost, s));
@@ -889,7 +951,7 @@ int nrs_trace_samples(nrs_model* m, const nrs_render_params* p, void* stream, ui
 	if (!m || !p || !d_pixel_idx || !d_t || !d_dt || !d_count) return fail(NRS_ERR_INVALID_ARG, "nrs_trace_samples: NULL argument");
 	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_trace_samples: occupancy not set");
 	HIP_TRY(hipSetDevice(m->ctx->device));
-	NRS_TRY(launch_trace_samples(m->dm, *p, n_pixels, d_pixel_idx, max_samples, d_t, d_dt, d_count, stream));
+	NRS_TRY(launch_trace_samples(model_for_launch(m, *p), *p, n_pixels, d_pixel_idx, max_samples, d_t, d_dt, d_count, stream));
 	return NRS_OK;
 }
 

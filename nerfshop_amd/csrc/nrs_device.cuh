@@ -257,19 +257,68 @@ __device__ __forceinline__ bool ray_meets_box_ahead(const Box3& b, f3 o, f3 idir
 	return tnear <= tfar;
 }
 
+// Marching shortcut 2 (result-preserving).  kCoarse^3 blocks over occ_box carry "some occupied cell (any cascade,
+// inflated like occ_box) overlaps this block".  coarse_safe_until walks the blocks along o + d*s, s >= t (Amanatides-Woo,
+// <= 3 * kCoarse - 2 steps) and returns the parameter up to which the ray provably meets no occupied cell:
+//   < 0       nothing ahead at all: no further sample can be emitted, the caller retires the ray at once;
+//   otherwise the entry into the first marked block, minus a margin that dwarfs the walk's float error.
+// `mask` is the LDS copy of DeviceModel::coarse_mask.
+__device__ __forceinline__ float coarse_safe_until(const DeviceModel& m, const uint32_t* __restrict__ mask, f3 o, f3 d, f3 idir, float t) {
+	const Box3& b = m.occ.box;
+	const float ax = (b.mn[0] - o.x) * idir.x, bx = (b.mx[0] - o.x) * idir.x;
+	const float ay = (b.mn[1] - o.y) * idir.y, by = (b.mx[1] - o.y) * idir.y;
+	const float az = (b.mn[2] - o.z) * idir.z, bz = (b.mx[2] - o.z) * idir.z;
+	const float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), t));
+	const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+	if (!(tnear <= tfar)) return -1.f;
+	const f3 p = o + d * tnear;
+	const float hi = (float)(kCoarse - 1);
+	int cx = (int)__builtin_amdgcn_fmed3f((p.x - b.mn[0]) * m.occ.inv_cell[0], 0.f, hi);
+	int cy = (int)__builtin_amdgcn_fmed3f((p.y - b.mn[1]) * m.occ.inv_cell[1], 0.f, hi);
+	int cz = (int)__builtin_amdgcn_fmed3f((p.z - b.mn[2]) * m.occ.inv_cell[2], 0.f, hi);
+	const int sx = d.x >= 0.f ? 1 : -1, sy = d.y >= 0.f ? 1 : -1, sz = d.z >= 0.f ? 1 : -1;
+	const float inf = __builtin_huge_valf();
+	float tmx = d.x != 0.f ? ((b.mn[0] + (float)(cx + (sx > 0 ? 1 : 0)) * m.occ.cell[0]) - o.x) * idir.x : inf;
+	float tmy = d.y != 0.f ? ((b.mn[1] + (float)(cy + (sy > 0 ? 1 : 0)) * m.occ.cell[1]) - o.y) * idir.y : inf;
+	float tmz = d.z != 0.f ? ((b.mn[2] + (float)(cz + (sz > 0 ? 1 : 0)) * m.occ.cell[2]) - o.z) * idir.z : inf;
+	const float tdx = fabsf(m.occ.cell[0] * idir.x), tdy = fabsf(m.occ.cell[1] * idir.y), tdz = fabsf(m.occ.cell[2] * idir.z);
+	float t_enter = tnear; // parameter at which the current block was entered
+	#pragma unroll 1
+	for (int it = 0; it < (int)(3 * kCoarse); ++it) {
+		const uint32_t idx = ((uint32_t)cz * kCoarse + (uint32_t)cy) * kCoarse + (uint32_t)cx;
+		if ((mask[idx >> 5] >> (idx & 31)) & 1u) return fmaxf(t_enter - 1e-4f, 0.f);
+		const bool step_x = tmx <= tmy && tmx <= tmz, step_y = !step_x && tmy <= tmz, step_z = !step_x && !step_y;
+		t_enter = step_x ? tmx : (step_y ? tmy : tmz);
+		cx += step_x ? sx : 0; cy += step_y ? sy : 0; cz += step_z ? sz : 0;
+		tmx += step_x ? tdx : 0.f; tmy += step_y ? tdy : 0.f; tmz += step_z ? tdz : 0.f;
+		if ((uint32_t)(cx | cy | cz) > kCoarse - 1) return -1.f; // left the box through an empty block (negative indices have high bits set)
+	}
+	return 0.f; // unreachable (a ray crosses at most 3 * kCoarse - 2 blocks); "nothing is known" keeps the plain walk
+}
+
 // The inner loop shared by advance_pos_nerf (tn:589-603) and generate_next_nerf_network_inputs (tn:668-692):
 // advance t until the ray sits in an occupied cell (returns true; pos/dt valid) or leaves the render box (false).
 //
-// occ_box bounds all occupied cells of all cascades (inflated).  Outside it every occupancy test of the reference is
-// false, so (i) the bitfield lookup is skipped -- the DDA recurrence that decides WHICH t values get tested is still
-// executed verbatim, so the first accepted t is bit-identical -- and (ii) once the remaining ray cannot meet the box any
-// more, no further sample can ever be emitted and the walk to the far side of the render box is cut short.
-__device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, const uint8_t* __restrict__ bitfield, const Box3& occ_box, f3 o, f3 d,
+// Shortcut 1: occ_box bounds all occupied cells of all cascades (inflated).  Outside it every occupancy test of the
+// reference is false, so (i) the bitfield lookup is skipped -- the DDA recurrence that decides WHICH t values get tested is
+// still executed verbatim, so the first accepted t is bit-identical -- and (ii) once the remaining ray cannot meet the box
+// any more, no further sample can ever be emitted and the walk to the far side of the render box is cut short.
+//
+// Shortcut 2: when the cell the ray stands in is empty, the coarse mask is consulted ONCE (coarse_safe_until).  Rays with
+// nothing ahead are retired.  For the others the stretch up to t_safe is walked by the LEAN loop below: the same float
+// operations on t in the same order (position, cascade, distance to the voxel border, the chain of step additions) but
+// none of the tests whose outcome is known there -- inside the render box (t_safe is clipped to it), cell empty.  The
+// lean loop hands over BEFORE a step could land beyond t_safe; the full loop then re-enters at a t it would have reached
+// itself, so the (t, dt) stream stays bit-identical (tests/test_gpu_parity.py compares it against the oracle).
+__device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, const DeviceModel& m, const uint32_t* __restrict__ coarse_mask, f3 o, f3 d,
                                                   f3 idir, float& t, f3& pos, float& dt, uint32_t* n_iter = nullptr) {
+	const uint8_t* __restrict__ bitfield = m.bitfield;
+	const Box3& occ_box = m.occ.box;
 	Box3 bb;
 	#pragma unroll
 	for (int i = 0; i < 3; ++i) { bb.mn[i] = p.render_aabb_min[i]; bb.mx[i] = p.render_aabb_max[i]; }
 	const float cone = p.cone_angle_constant;
+	bool looked_ahead = false;
 	while (1) {
 		if (n_iter) ++*n_iter; // profiling build only
 		pos = o + d * t;
@@ -281,19 +330,43 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 		} else if (!ray_meets_box_ahead(occ_box, o, idir, t)) {
 			return false;
 		}
+		if (!looked_ahead) {
+			looked_ahead = true;
+			float t_safe = coarse_safe_until(m, coarse_mask, o, d, idir, t);
+			if (t_safe < 0.f) return false;
+			{ // clip to the exit of the render box: the lean loop carries no containment test
+				const float ax = (bb.mn[0] - o.x) * idir.x, bx = (bb.mx[0] - o.x) * idir.x;
+				const float ay = (bb.mn[1] - o.y) * idir.y, by = (bb.mx[1] - o.y) * idir.y;
+				const float az = (bb.mn[2] - o.z) * idir.z, bz = (bb.mx[2] - o.z) * idir.z;
+				t_safe = fminf(t_safe, fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) - 1e-4f);
+			}
+			// lean walk: every position it stands on has parameter < t_safe
+			while (1) {
+				const uint32_t lres = kGrid >> mip;
+				const float linv = ldexpf(1.0f, (int)mip - 7);
+				// one step past the border is the farthest the next position can be (first lattice point >= the border)
+				const float border = t + distance_to_next_voxel(pos, d, idir, lres, linv);
+				if (!(border + calc_dt(border, cone) < t_safe)) break;
+				t = advance_to_next_voxel(t, cone, pos, d, idir, lres, linv);
+				if (n_iter) ++*n_iter;
+				pos = o + d * t;
+				dt = calc_dt(t, cone);
+				mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
+			}
+		}
 		uint32_t res = kGrid >> mip;
 		t = advance_to_next_voxel(t, cone, pos, d, idir, res, ldexpf(1.0f, (int)mip - 7));
 	}
 }
 
 // advance_pos_nerf, tn:557-606: jitter by one Sobol value, then skip to the first occupied cell
-__device__ __forceinline__ bool first_hit(const nrs_render_params& p, const uint8_t* __restrict__ bitfield, const Box3& occ_box, uint32_t pixel_idx, Ray& r,
+__device__ __forceinline__ bool first_hit(const nrs_render_params& p, const DeviceModel& m, const uint32_t* __restrict__ coarse_mask, uint32_t pixel_idx, Ray& r,
                                           uint32_t* n_iter = nullptr) {
 	f3 idir = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
 	float dt = calc_dt(r.t, p.cone_angle_constant);
 	r.t += ld_random_val(p.spp_index, pixel_idx * 786433u) * dt;
 	f3 pos;
-	return march_to_occupied(p, bitfield, occ_box, r.o, r.d, idir, r.t, pos, dt, n_iter);
+	return march_to_occupied(p, m, coarse_mask, r.o, r.d, idir, r.t, pos, dt, n_iter);
 }
 
 // ---- tet warp: selection_utils.h:10-47, cage_deformation.cu:136-269 -----------------------------------------------

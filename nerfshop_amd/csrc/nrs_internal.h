@@ -11,6 +11,8 @@ constexpr uint32_t kGrid = 128;                  // NERF_GRIDSIZE
 constexpr uint32_t kCascades = 5;                // NERF_CASCADES
 constexpr uint32_t kGridVol = kGrid * kGrid * kGrid;
 constexpr uint32_t kLevels = 16;
+constexpr uint32_t kCoarse = 16;                // blocks per axis of the occupancy look-ahead mask
+constexpr uint32_t kCoarseWords = kCoarse * kCoarse * kCoarse / 32;
 // Packets (8x8 pixels) a wave claims from the frame's work queue at a time; in whole-image mode they form one
 // kRunSide x kRunSide block of packets (Morton order).  Larger runs = more coherent gathers but coarser load balance.
 constexpr uint32_t kPacketRun = 1;
@@ -38,6 +40,15 @@ constexpr uint32_t kWfragBytes = kNumFrags * kFragBytes; // 24 KiB
 
 struct Box3 { float mn[3]; float mx[3]; };
 
+// Result-preserving marching accelerator derived from the occupancy bitfield on the host:
+//   box   world-space bounds of every occupied cell that can be consulted, slightly inflated (shortcut 1)
+//   mask  kCoarse^3 bits over box: bit (z*16 + y)*16 + x set iff such a cell (inflated alike) overlaps that block (shortcut 2)
+struct OccAccel {
+	Box3 box;
+	float cell[3], inv_cell[3];
+	uint32_t mask[kCoarseWords];
+};
+
 struct DeviceModel {
 	const uint32_t* grid;      // fp16x2 entries
 	const uint16_t* wfrag;     // kWfragBytes
@@ -46,7 +57,7 @@ struct DeviceModel {
 	Box3            aabb;      // train aabb (m_aabb)
 	float           inv_diag[3]; // 1 / (aabb.max - aabb.min), exact when diag_pow2
 	uint32_t        diag_pow2; // every aabb extent is a power of two (always so for NGP scene boxes): x / d == x * (1/d) bit for bit
-	Box3            occ_box;   // world-space bounds of every occupied cell of every cascade, slightly inflated (marching shortcut)
+	OccAccel        occ;       // marching shortcuts (filled per launch, see model_for_launch in nrs_api.cpp)
 	uint32_t        rgb_activation;
 	uint32_t        density_activation;
 };

@@ -37,6 +37,7 @@ struct RenderSmem {
 	ModelLds ml;
 	FeatLds fl[WAVES];
 	uint4 ring[WAVES][kRing]; // {x | y << 16, t bits, output index, -}
+	uint32_t coarse[kCoarseWords]; // DeviceModel::coarse_mask (marching shortcut 2)
 };
 
 // packet -> pixel of this lane.  Packets are 8x8 pixel blocks.
@@ -86,7 +87,8 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE>
 __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceModel m, const RenderArgs a) {
 	__shared__ RenderSmem<WAVES> sm;
-	stage_model_to_lds(m, sm.ml, a.dbg);
+	if (threadIdx.x < kCoarseWords) sm.coarse[threadIdx.x] = m.occ.mask[threadIdx.x];
+	stage_model_to_lds(m, sm.ml, a.dbg); // (ends with the barrier that also publishes sm.coarse)
 
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				if (a.steps) a.steps[oi] = 0;
 				alive = r.alive;
 				uint32_t it_fill = 0;
-				if (alive) alive = first_hit(p, m.bitfield, m.occ_box, x + (uint32_t)p.resolution[0] * y, r, PROF ? &it_fill : nullptr);
+				if (alive) alive = first_hit(p, m, sm.coarse, x + (uint32_t)p.resolution[0] * y, r, PROF ? &it_fill : nullptr);
 				if (PROF) {
 					uint32_t mx = it_fill;
 					for (int sh = 32; sh > 0; sh >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, sh, 64));
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			} else {
 				t += dt;
 				f3 npos; float ndt;
-				done = !march_to_occupied(p, m.bitfield, m.occ_box, o, d, idir, t, npos, ndt, PROF ? &it_march : nullptr);
+				done = !march_to_occupied(p, m, sm.coarse, o, d, idir, t, npos, ndt, PROF ? &it_march : nullptr);
 			}
 			if (done) {
 				if (shade && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
@@ -404,6 +406,9 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 // ---- trace_samples ------------------------------------------------------------------------------------------------
 __global__ void trace_samples_kernel(const DeviceModel m, const nrs_render_params p, uint32_t n_pixels, const uint32_t* __restrict__ pixel_idx,
                                      uint32_t max_samples, float* __restrict__ t_out, float* __restrict__ dt_out, uint32_t* __restrict__ count_out) {
+	__shared__ uint32_t coarse[kCoarseWords];
+	if (threadIdx.x < kCoarseWords) coarse[threadIdx.x] = m.occ.mask[threadIdx.x];
+	__syncthreads();
 	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k >= n_pixels) return;
 	float off_x, off_y;
@@ -411,12 +416,12 @@ __global__ void trace_samples_kernel(const DeviceModel m, const nrs_render_param
 	const uint32_t idx = pixel_idx[k], W = (uint32_t)p.resolution[0];
 	Ray r = init_ray(p, idx % W, idx / W, off_x, off_y);
 	uint32_t cnt = 0;
-	if (r.alive && first_hit(p, m.bitfield, m.occ_box, idx, r)) {
+	if (r.alive && first_hit(p, m, coarse, idx, r)) {
 		const f3 idir = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
 		float t = r.t;
 		while (cnt < max_samples) {
 			f3 pos; float dt;
-			if (!march_to_occupied(p, m.bitfield, m.occ_box, r.o, r.d, idir, t, pos, dt)) break;
+			if (!march_to_occupied(p, m, coarse, r.o, r.d, idir, t, pos, dt)) break;
 			t_out[(size_t)k * max_samples + cnt] = t;
 			dt_out[(size_t)k * max_samples + cnt] = dt;
 			++cnt;
