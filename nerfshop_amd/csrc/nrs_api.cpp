@@ -75,6 +75,7 @@ struct nrs_edit {
 	uint32_t* d_lut_idx = nullptr;     // == de.lut_idx
 	size_t lut_idx_cap = 0;            // entries allocated
 	float* d_rot = nullptr;            // == de.rot when rotations are on
+	float* d_planes = nullptr;         // == de.planes, [T x 32] one 128-byte record per tet (tet_planes_kernel), follows the deformed vertices
 	uint32_t* d_counts = nullptr;      // [5*128^3], all zero between builds
 	uint32_t* d_tile_sums = nullptr;
 	uint32_t* d_scratch = nullptr;     // [0..5] bbox (float bits), [6] total entries, [7] max tets per cell, [8] long-list counter
@@ -572,6 +573,7 @@ static int rebuild_after_vertices(nrs_edit* e, hipStream_t s) {
 	CAGE_TRY(launch_bbox(e->n_vertices, e->d_verts, (float*)e->d_scratch, s));
 	NRS_TRY(build_lut_on_device(e, e->d_verts, nullptr, s));
 	if (e->d_rot) CAGE_TRY(launch_local_rotations(e->n_tets, e->d_verts, e->de.orig, e->de.tets, e->d_rot, s));
+	CAGE_TRY(launch_tet_planes(e->n_tets, e->d_verts, e->de.tets, e->d_planes, s));
 	uint32_t host[8];
 	HIP_TRY(hipMemcpyAsync(host, e->d_scratch, sizeof(host), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
@@ -624,8 +626,10 @@ int nrs_edit_create(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_tet_mesh
 	chk(dev_alloc((void**)&e->d_lut_off, (n_cells + 1) * 4));
 	if (s == NRS_OK && hipMemcpy(e->d_verts, mesh->h_vertices, 12 * (size_t)mesh->n_vertices, hipMemcpyHostToDevice) != hipSuccess)
 		s = fail(NRS_ERR_HIP, "nrs_edit_create: vertex upload failed");
+	chk(dev_alloc((void**)&e->d_planes, 128 * (size_t)mesh->n_tets));
 	de.verts = e->d_verts;
 	de.lut_off = e->d_lut_off;
+	de.planes = e->d_planes;
 	const bool want_rot = mesh->h_local_rotations != nullptr || mesh->correct_direction != 0;
 	if (want_rot) {
 		chk(dev_alloc((void**)&e->d_rot, 36 * (size_t)mesh->n_tets));
@@ -665,6 +669,11 @@ int nrs_edit_create(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_tet_mesh
 		e->lut_idx_cap = n_idx;
 		e->lut_n_idx = n_idx;
 		de.lut_idx = e->d_lut_idx;
+		{
+			int st = launch_tet_planes(e->n_tets, e->d_verts, de.tets, e->d_planes, nullptr);
+			if (st != NRS_OK) return bail((g_err = cage_last_error(), st));
+			if (hipDeviceSynchronize() != hipSuccess) return bail(fail(NRS_ERR_HIP, "nrs_edit_create: tet_planes_kernel failed"));
+		}
 		if (mesh->h_local_rotations) {
 			he = hipMemcpy(e->d_rot, mesh->h_local_rotations, 36 * (size_t)mesh->n_tets, hipMemcpyHostToDevice);
 			if (he != hipSuccess) return bail(fail_hip(he, "nrs_edit_create: rotation upload"));
@@ -742,7 +751,7 @@ int nrs_edit_create_affine(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_a
 void nrs_edit_destroy(nrs_edit* e) {
 	if (!e) return;
 	for (void* p : e->allocs) (void)hipFree(p);
-	(void)hipFree(e->d_verts); (void)hipFree(e->d_lut_off); (void)hipFree(e->d_lut_idx); (void)hipFree(e->d_rot);
+	(void)hipFree(e->d_verts); (void)hipFree(e->d_lut_off); (void)hipFree(e->d_lut_idx); (void)hipFree(e->d_rot); (void)hipFree(e->d_planes);
 	(void)hipFree(e->d_big_cells); (void)hipFree(e->d_counts); (void)hipFree(e->d_tile_sums); (void)hipFree(e->d_scratch); (void)hipFree(e->d_mvc); (void)hipFree(e->d_cage);
 	delete e;
 }

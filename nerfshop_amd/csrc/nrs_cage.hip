@@ -363,6 +363,28 @@ __global__ void local_rotations_kernel(uint32_t n_tets, const float* __restrict_
 	for (int k = 0; k < 9; ++k) out[9 * (size_t)i + k] = (float)R[k];
 }
 
+// ---- per-tet face planes for point_in_tet_planes (nrs_device.cuh): the tet-only half of same_side_tet, selection_utils.h:33-39 ----
+__global__ void tet_planes_kernel(uint32_t n_tets, const float* __restrict__ verts, const uint32_t* __restrict__ tets, float* __restrict__ planes) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_tets) return;
+	const uint4 tv = reinterpret_cast<const uint4*>(tets)[i];
+	const f3 v[4] = {ld3(verts, tv.x), ld3(verts, tv.y), ld3(verts, tv.z), ld3(verts, tv.w)};
+	float out[32];
+	uint32_t signs = 0;
+	for (int f = 0; f < 4; ++f) { // point_in_tet's calls: (v1,v2,v3,v4), (v2,v3,v4,v1), (v3,v4,v1,v2), (v4,v1,v2,v3)
+		const f3 v1 = v[f], v2 = v[(f + 1) & 3], v3 = v[(f + 2) & 3], v4 = v[(f + 3) & 3];
+		const f3 normal = cross3(v2 - v1, v3 - v1);
+		const float dotV4 = dot3(normal, v4 - v1);
+		out[3 * f] = v1.x; out[3 * f + 1] = v1.y; out[3 * f + 2] = v1.z;
+		out[12 + 3 * f] = normal.x; out[12 + 3 * f + 1] = normal.y; out[12 + 3 * f + 2] = normal.z;
+		signs |= (__float_as_uint(dotV4) >> 31) << f;
+	}
+	out[24] = __uint_as_float(signs);
+	for (int k = 25; k < 32; ++k) out[k] = 0.f;
+	float4* dst = reinterpret_cast<float4*>(planes) + 8 * (size_t)i;
+	for (int q = 0; q < 8; ++q) dst[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+}
+
 // ---- launchers ----------------------------------------------------------------------------------------------------------------
 int launch_mvc_apply(uint32_t n_points, uint32_t n_cv, const float* d_weights, const float* d_cage, float* d_points, void* stream) {
 	hipLaunchKernelGGL(mvc_apply_kernel, dim3((n_points + 127) / 128), dim3(128), 0, (hipStream_t)stream, n_points, n_cv, d_weights, d_cage, d_points);
@@ -402,6 +424,11 @@ int launch_lut_fill(uint32_t n_tets, const float* d_verts, const uint32_t* d_tet
 	return NRS_OK;
 }
 uint32_t lut_big_list_capacity(size_t idx_capacity) { return (uint32_t)(idx_capacity / kSmallList + 1); }
+int launch_tet_planes(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, float* d_planes, void* stream) {
+	hipLaunchKernelGGL(tet_planes_kernel, dim3((n_tets + 127) / 128), dim3(128), 0, (hipStream_t)stream, n_tets, d_verts, d_tets, d_planes);
+	NRS_CAGE_CHECK("tet_planes_kernel launch");
+	return NRS_OK;
+}
 int launch_local_rotations(uint32_t n_tets, const float* d_verts, const float* d_orig, const uint32_t* d_tets, float* d_out, void* stream) {
 	hipLaunchKernelGGL(local_rotations_kernel, dim3((n_tets + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_tets, d_verts, d_orig, d_tets, d_out);
 	NRS_CAGE_CHECK("local_rotations_kernel launch");

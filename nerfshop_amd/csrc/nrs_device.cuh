@@ -392,6 +392,37 @@ __device__ __forceinline__ void bary_tet(f3 a, f3 b, f3 c, f3 d, f3 p, float out
 }
 __device__ __forceinline__ f3 ld3(const float* __restrict__ a, uint32_t i) { return {a[3 * i], a[3 * i + 1], a[3 * i + 2]}; }
 
+// point_in_tet with the per-tet part of same_side_tet hoisted out of the sample loop, and the tet's own vertices stored next to
+// it: tet_planes_kernel writes one 128-byte record per tet -- vertices v_0..v_3 (12 floats), normal_f = cross(v_{f+1} - v_f,
+// v_{f+2} - v_f) for f = 0..3 (12 floats), the four bits signbit(dot(normal_f, v_{f+3} - v_f)) -- the very floats same_side_tet
+// computes, so dot(normal_f, p - v_f) and the sign comparison are bit-identical to the direct evaluation.  One cache line per
+// candidate instead of the tets[] -> vertices[] chain, and a quarter of the arithmetic.
+__device__ __forceinline__ bool point_in_tet_rec(const float* __restrict__ recs, uint32_t t, f3 p) {
+	const float4* q = reinterpret_cast<const float4*>(recs) + 8 * (size_t)t;
+	const float4 v0 = q[0], v1 = q[1], v2 = q[2], n0 = q[3], n1 = q[4], n2 = q[5], sg = q[6];
+	const float d0 = dot3(mk3(n0.x, n0.y, n0.z), p - mk3(v0.x, v0.y, v0.z));
+	const float d1 = dot3(mk3(n0.w, n1.x, n1.y), p - mk3(v0.w, v1.x, v1.y));
+	const float d2 = dot3(mk3(n1.z, n1.w, n2.x), p - mk3(v1.z, v1.w, v2.x));
+	const float d3 = dot3(mk3(n2.y, n2.z, n2.w), p - mk3(v2.y, v2.z, v2.w));
+	const uint32_t got = (__float_as_uint(d0) >> 31) | ((__float_as_uint(d1) >> 31) << 1) | ((__float_as_uint(d2) >> 31) << 2) | ((__float_as_uint(d3) >> 31) << 3);
+	return got == __float_as_uint(sg.x);
+}
+// first tet of the cell's list that contains p (0xffffffff: none); the next candidate's id is fetched while the current one is tested
+__device__ __forceinline__ uint32_t scan_cell_for_tet(const DeviceEdit& e, uint32_t cell, f3 p) {
+	const uint32_t j0 = e.lut_off[cell], j1 = e.lut_off[cell + 1];
+	uint32_t found = 0xffffffffu;
+	if (j0 < j1) {
+		uint32_t t = e.lut_idx[j0];
+		#pragma unroll 1
+		for (uint32_t j = j0; j < j1; ++j) {
+			const uint32_t t_next = e.lut_idx[min(j + 1, j1 - 1)];
+			if (point_in_tet_rec(e.planes, t, p)) { found = t; break; }
+			t = t_next;
+		}
+	}
+	return found;
+}
+
 // interpolate_tet (with_dir, honours copy) / interpolate_tet_pos (!with_dir, ignores copy).  pos/dir are the warped
 // [0,1] values of the NerfCoordinate; returns true if the sample must be treated as empty space.
 // Two phases on purpose: the LUT scan only decides WHICH tet contains the sample; the barycentric map-back reloads that
@@ -402,15 +433,7 @@ __device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3&
 		const f3 u = unwarp_position(wpos, e.aabb);
 		const int level = mip_from_pos(u);
 		const uint32_t cell = (uint32_t)level * kGridVol + cascaded_grid_idx_at(u, (uint32_t)level);
-		const uint32_t j0 = e.lut_off[cell], j1 = e.lut_off[cell + 1];
-		uint32_t found = 0xffffffffu;
-		#pragma unroll 1
-		for (uint32_t j = j0; j < j1; ++j) {
-			const uint32_t t = e.lut_idx[j];
-			const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[t];
-			const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), d = ld3(e.verts, tv.w);
-			if (point_in_tet(a, b, c, d, u)) { found = t; break; }
-		}
+		const uint32_t found = scan_cell_for_tet(e, cell, u);
 		__builtin_amdgcn_sched_barrier(0);
 		if (found != 0xffffffffu) {
 			const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[found];
@@ -487,15 +510,7 @@ __device__ __forceinline__ void poisson_residual_rgb(const DeviceEdit& e, f3 wpo
 	if (!box_contains(e.bbox, pos)) return;
 	const int level = mip_from_pos(pos);
 	const uint32_t cell = (uint32_t)level * kGridVol + cascaded_grid_idx_at(pos, (uint32_t)level);
-	const uint32_t j0 = e.lut_off[cell], j1 = e.lut_off[cell + 1];
-	uint32_t found = 0xffffffffu;
-	#pragma unroll 1
-	for (uint32_t j = j0; j < j1; ++j) {
-		const uint32_t t = e.lut_idx[j];
-		const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[t];
-		const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), dd = ld3(e.verts, tv.w);
-		if (point_in_tet(a, b, c, dd, pos)) { found = t; break; }
-	}
+	const uint32_t found = scan_cell_for_tet(e, cell, pos);
 	if (found == 0xffffffffu) return;
 	const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[found];
 	float bc[4];
@@ -598,20 +613,14 @@ __device__ __forceinline__ bool poisson_residual_density(const DeviceEdit& e, f3
 	if (!box_contains(e.bbox, pos)) return false;
 	const int level = mip_from_pos(pos);
 	const uint32_t cell = (uint32_t)level * kGridVol + cascaded_grid_idx_at(pos, (uint32_t)level);
-	const uint32_t j0 = e.lut_off[cell], j1 = e.lut_off[cell + 1];
-	#pragma unroll 1
-	for (uint32_t j = j0; j < j1; ++j) {
-		const uint32_t t = e.lut_idx[j];
-		const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[t];
-		const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), d = ld3(e.verts, tv.w);
-		if (point_in_tet(a, b, c, d, pos)) {
-			float bc[4];
-			bary_tet(a, b, c, d, pos, bc);
-			residual = ((bc[0] * e.res_density[tv.x] + bc[1] * e.res_density[tv.y]) + bc[2] * e.res_density[tv.z]) + bc[3] * e.res_density[tv.w];
-			return true;
-		}
-	}
-	return false;
+	const uint32_t t = scan_cell_for_tet(e, cell, pos);
+	if (t == 0xffffffffu) return false;
+	const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[t];
+	const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), d = ld3(e.verts, tv.w);
+	float bc[4];
+	bary_tet(a, b, c, d, pos, bc);
+	residual = ((bc[0] * e.res_density[tv.x] + bc[1] * e.res_density[tv.y]) + bc[2] * e.res_density[tv.z]) + bc[3] * e.res_density[tv.w];
+	return true;
 }
 
 // ---- activations (cn:38-66) and shade (common_device.cuh:31-37) ---------------------------------------------------

@@ -84,6 +84,7 @@ struct DeviceEdit {
 	const float*    verts;
 	const float*    orig;
 	const float*    rot;           // nullable
+	const float*    planes;        // [T x 32] one 128-byte record per tet: its 4 vertices, the 4 face normals exactly as same_side_tet forms them, the 4 sign bits of dotV4 (tet_planes_kernel)
 	const uint8_t*  orig_bitfield;
 	const float*    shs;           // nullable unless apply_poisson
 	const float*    out_density;
@@ -149,6 +150,7 @@ int launch_lut_count_scan(uint32_t n_tets, const float* d_verts, const uint32_t*
 int launch_lut_fill(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, const uint32_t* d_offsets, uint32_t* d_idx,
                     uint8_t* d_bitfield, uint32_t* d_scratch_u32, uint32_t* d_big_cells, void* stream);
 uint32_t lut_big_list_capacity(size_t idx_capacity);
+int launch_tet_planes(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, float* d_planes, void* stream);
 int launch_local_rotations(uint32_t n_tets, const float* d_verts, const float* d_orig, const uint32_t* d_tets, float* d_out, void* stream);
 const char* cage_last_error();
 
