@@ -58,6 +58,7 @@ struct nrs_model {
 	uint32_t* d_grid = nullptr;
 	uint16_t* d_wfrag = nullptr;
 	uint8_t* d_bitfield = nullptr;
+	uint32_t* d_accel_masks = nullptr;   // 2 x kCoarseWords: accel_any.mask | accel_exact.mask
 	OccAccel accel_any{}, accel_exact{}; // marching shortcuts for general step parameters / for cone_angle == 0 && min_mip == 0
 	float* d_density_grid = nullptr;   // m_nerf.density_grid [5*128^3], kept for the occupancy refresh
 	uint32_t* d_density_tmp = nullptr; // density_grid_tmp (float bits), allocated on first refresh
@@ -221,9 +222,9 @@ static void occupied_bounds(const uint8_t* bitfield, bool exact_mip, Box3& out) 
 
 // The look-ahead mask over occ_box (OccAccel::mask): every relevant occupied 2x2x2 Morton block of every cascade marks the
 // coarse blocks its (inflated) extent overlaps.
-static void occupied_accel(const uint8_t* bitfield, bool exact_mip, OccAccel& acc) {
+static void occupied_accel(const uint8_t* bitfield, bool exact_mip, OccAccel& acc, uint32_t* host_mask) {
 	occupied_bounds(bitfield, exact_mip, acc.box);
-	memset(acc.mask, 0, sizeof(acc.mask));
+	memset(host_mask, 0, kCoarseWords * 4);
 	for (int k = 0; k < 3; ++k) { acc.cell[k] = 1.f; acc.inv_cell[k] = 1.f; }
 	if (!(acc.box.mn[0] <= acc.box.mx[0])) return; // nothing occupied
 	for (int k = 0; k < 3; ++k) {
@@ -254,7 +255,7 @@ static void occupied_accel(const uint8_t* bitfield, bool exact_mip, OccAccel& ac
 				for (int y = lo[1]; y <= hi[1]; ++y)
 					for (int x = lo[0]; x <= hi[0]; ++x) {
 						const uint32_t idx = ((uint32_t)z * kCoarse + (uint32_t)y) * kCoarse + (uint32_t)x;
-						acc.mask[idx >> 5] |= 1u << (idx & 31);
+						host_mask[idx >> 5] |= 1u << (idx & 31);
 					}
 		}
 	}
@@ -272,6 +273,16 @@ static int upload(nrs_edit* e, const T* h, size_t count, const T** d_out) {
 	return NRS_OK;
 }
 
+// both flavours of the marching accelerator from a host copy of the bitfield; masks go to the model's device buffers
+static int refresh_accel(nrs_model* m, const uint8_t* h_bitfield) {
+	std::vector<uint32_t> mask(2 * kCoarseWords);
+	occupied_accel(h_bitfield, false, m->accel_any, mask.data());
+	occupied_accel(h_bitfield, true, m->accel_exact, mask.data() + kCoarseWords);
+	HIP_TRY(hipMemcpy(m->d_accel_masks, mask.data(), mask.size() * 4, hipMemcpyHostToDevice));
+	m->accel_any.mask = m->d_accel_masks;
+	m->accel_exact.mask = m->d_accel_masks + kCoarseWords;
+	return NRS_OK;
+}
 static DeviceModel model_for_launch(const nrs_model* m, const nrs_render_params& p) {
 	DeviceModel dm = m->dm;
 	dm.occ = (p.cone_angle_constant == 0.f && p.min_mip == 0) ? m->accel_exact : m->accel_any;
@@ -366,6 +377,8 @@ int nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out) 
 	HIP_TRY(hipMalloc((void**)&m->d_grid, (size_t)m->total_entries * 4));
 	HIP_TRY(hipMalloc((void**)&m->d_wfrag, kWfragBytes));
 	HIP_TRY(hipMalloc((void**)&m->d_bitfield, NRS_BITFIELD_BYTES));
+	HIP_TRY(hipMalloc((void**)&m->d_accel_masks, 2 * kCoarseWords * 4));
+	HIP_TRY(hipMemset(m->d_accel_masks, 0, 2 * kCoarseWords * 4));
 	HIP_TRY(hipMalloc((void**)&m->d_density_grid, (size_t)kGridVol * kCascades * 4));
 	HIP_TRY(hipMemset(m->d_density_grid, 0, (size_t)kGridVol * kCascades * 4));
 	m->dm.grid = m->d_grid;
@@ -379,6 +392,7 @@ void nrs_model_destroy(nrs_model* m) {
 	(void)hipFree(m->d_grid);
 	(void)hipFree(m->d_wfrag);
 	(void)hipFree(m->d_bitfield);
+	(void)hipFree(m->d_accel_masks);
 	(void)hipFree(m->d_density_grid);
 	(void)hipFree(m->d_density_tmp);
 	delete m;
@@ -405,8 +419,7 @@ int nrs_model_set_density_bitfield(nrs_model* m, const uint8_t* h_bitfield, size
 	if (n_bytes != NRS_BITFIELD_BYTES) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_density_bitfield: expected 5*128^3/8 bytes");
 	HIP_TRY(hipSetDevice(m->ctx->device));
 	HIP_TRY(hipMemcpy(m->d_bitfield, h_bitfield, n_bytes, hipMemcpyHostToDevice));
-	occupied_accel(h_bitfield, false, m->accel_any);
-	occupied_accel(h_bitfield, true, m->accel_exact);
+	NRS_TRY(refresh_accel(m, h_bitfield));
 	m->have_bitfield = true;
 	return NRS_OK;
 }
@@ -418,8 +431,7 @@ static int refresh_bitfield(nrs_model* m, void* stream) {
 	std::vector<uint8_t> host_bits(NRS_BITFIELD_BYTES);
 	HIP_TRY(hipMemcpyAsync(host_bits.data(), m->d_bitfield, NRS_BITFIELD_BYTES, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
-	occupied_accel(host_bits.data(), false, m->accel_any);
-	occupied_accel(host_bits.data(), true, m->accel_exact);
+	NRS_TRY(refresh_accel(m, host_bits.data()));
 	m->have_bitfield = true;
 	return NRS_OK;
 }

@@ -11,8 +11,9 @@ constexpr uint32_t kGrid = 128;                  // NERF_GRIDSIZE
 constexpr uint32_t kCascades = 5;                // NERF_CASCADES
 constexpr uint32_t kGridVol = kGrid * kGrid * kGrid;
 constexpr uint32_t kLevels = 16;
-constexpr uint32_t kCoarse = 16;                // blocks per axis of the occupancy look-ahead mask
+constexpr uint32_t kCoarse = 32;                // blocks per axis of the occupancy look-ahead mask
 constexpr uint32_t kCoarseWords = kCoarse * kCoarse * kCoarse / 32;
+static_assert((kCoarse & (kCoarse - 1)) == 0, "the block walk's bounds test (cx | cy | cz) needs a power of two");
 // Packets (8x8 pixels) a wave claims from the frame's work queue at a time; in whole-image mode they form one
 // kRunSide x kRunSide block of packets (Morton order).  Larger runs = more coherent gathers but coarser load balance.
 constexpr uint32_t kPacketRun = 1;
@@ -42,11 +43,11 @@ struct Box3 { float mn[3]; float mx[3]; };
 
 // Result-preserving marching accelerator derived from the occupancy bitfield on the host:
 //   box   world-space bounds of every occupied cell that can be consulted, slightly inflated (shortcut 1)
-//   mask  kCoarse^3 bits over box: bit (z*16 + y)*16 + x set iff such a cell (inflated alike) overlaps that block (shortcut 2)
+//   mask  kCoarse^3 bits over box: bit (z*kCoarse + y)*kCoarse + x set iff such a cell (inflated alike) overlaps that block (shortcut 2)
 struct OccAccel {
 	Box3 box;
 	float cell[3], inv_cell[3];
-	uint32_t mask[kCoarseWords];
+	const uint32_t* mask; // device, kCoarseWords words (staged into LDS by the kernels)
 };
 
 struct DeviceModel {

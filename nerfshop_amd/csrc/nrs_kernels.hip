@@ -87,7 +87,7 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE>
 __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceModel m, const RenderArgs a) {
 	__shared__ RenderSmem<WAVES> sm;
-	if (threadIdx.x < kCoarseWords) sm.coarse[threadIdx.x] = m.occ.mask[threadIdx.x];
+	for (uint32_t i = threadIdx.x; i < kCoarseWords; i += blockDim.x) sm.coarse[i] = m.occ.mask[i];
 	stage_model_to_lds(m, sm.ml, a.dbg); // (ends with the barrier that also publishes sm.coarse)
 
 	const int lane = threadIdx.x & 63;
@@ -407,7 +407,7 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 __global__ void trace_samples_kernel(const DeviceModel m, const nrs_render_params p, uint32_t n_pixels, const uint32_t* __restrict__ pixel_idx,
                                      uint32_t max_samples, float* __restrict__ t_out, float* __restrict__ dt_out, uint32_t* __restrict__ count_out) {
 	__shared__ uint32_t coarse[kCoarseWords];
-	if (threadIdx.x < kCoarseWords) coarse[threadIdx.x] = m.occ.mask[threadIdx.x];
+	for (uint32_t i = threadIdx.x; i < kCoarseWords; i += blockDim.x) coarse[i] = m.occ.mask[i];
 	__syncthreads();
 	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k >= n_pixels) return;
