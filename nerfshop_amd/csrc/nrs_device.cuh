@@ -100,7 +100,8 @@ __device__ __forceinline__ void ld_random_pixel_offset(uint32_t spp, float& ox, 
 
 // ---- step / grid math (cn:80-177) -------------------------------------------------------------------------------
 __device__ __forceinline__ float clampf_(float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); }
-__device__ __forceinline__ float calc_dt(float t, float cone_angle) { return clampf_(t * cone_angle, NRS_MIN_STEP, NRS_MAX_STEP); }
+// clamp(t * cone, MIN, MAX) as one v_med3_f32: the median of (v, lo, hi) is the clamp for every non-NaN v (t * cone >= 0)
+__device__ __forceinline__ float calc_dt(float t, float cone_angle) { return __builtin_amdgcn_fmed3f(t * cone_angle, NRS_MIN_STEP, NRS_MAX_STEP); }
 __device__ __forceinline__ float signf_(float x) { return copysignf(1.0f, x); }
 
 // frexpf's exponent: x = m * 2^e, 0.5 <= |m| < 1; 0 for x == 0
