@@ -283,10 +283,11 @@ int nrs_render_nerf(nrs_model* model, const nrs_render_params* params, nrs_edit*
                     float* d_frame, float* d_depth, uint32_t* d_steps, void* stream, nrs_render_stats* h_stats);
 /* number of tiles this rank owns / pixels of the compact buffer for given params (host-only) */
 uint32_t nrs_render_owned_tiles(const nrs_render_params* params);
-/* scatter compact tile buffers of all ranks (concatenated rank-major, as all_gather delivers them)
- * back into a full W x H image.  n_ranks * tiles_per_rank_padded tiles are read. */
+/* scatter compact tile buffers of all ranks (rank-major, as a gather delivers them) back into a full W x H image.
+ * Rank r's tiles start at d_tiles + r * rank_stride_floats (0 = densely packed: tiles_per_rank_padded * tile^2 * channels);
+ * a stride lets frame and depth share one gathered buffer [rank][frame block | depth block] -> one collective per frame. */
 int nrs_detile(nrs_ctx* ctx, void* stream, const nrs_render_params* params, uint32_t n_ranks,
-               uint32_t tiles_per_rank_padded, const float* d_tiles, uint32_t channels, float* d_image);
+               uint32_t tiles_per_rank_padded, const float* d_tiles, uint32_t channels, size_t rank_stride_floats, float* d_image);
 /* Test hook for bit-exact ray/sample indexing: for each listed pixel, march exactly as the renderer does
  * (init -> jitter -> first hit -> successive samples) ignoring compositing, and emit up to max_samples
  * (t, dt) pairs.  d_t, d_dt: [n_pixels x max_samples] f32; d_count: [n_pixels] u32. */

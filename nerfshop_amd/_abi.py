@@ -195,7 +195,7 @@ def load():
     lib.nrs_render_nerf.argtypes = [P, C.POINTER(RenderParams), C.POINTER(P), I, P, P, P, P, C.POINTER(RenderStats)]
     lib.nrs_render_owned_tiles.argtypes = [C.POINTER(RenderParams)]
     lib.nrs_render_owned_tiles.restype = U32
-    lib.nrs_detile.argtypes = [P, P, C.POINTER(RenderParams), U32, U32, P, U32, P]
+    lib.nrs_detile.argtypes = [P, P, C.POINTER(RenderParams), U32, U32, P, U32, C.c_size_t, P]
     lib.nrs_trace_samples.argtypes = [P, C.POINTER(RenderParams), P, U32, P, U32, P, P, P]
     lib.nrs_snapshot_open.argtypes = [C.c_char_p, C.POINTER(P)]
     lib.nrs_snapshot_close.argtypes = [P]

@@ -959,11 +959,14 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 }
 
 int nrs_detile(nrs_ctx* ctx, void* stream, const nrs_render_params* p, uint32_t n_ranks, uint32_t tiles_per_rank_padded, const float* d_tiles,
-               uint32_t channels, float* d_image) {
+               uint32_t channels, size_t rank_stride_floats, float* d_image) {
 	if (!ctx || !p || !d_tiles || !d_image) return fail(NRS_ERR_INVALID_ARG, "nrs_detile: NULL argument");
 	if (p->tile_size == 0 || p->tile_size % 8 || n_ranks == 0 || channels == 0) return fail(NRS_ERR_INVALID_ARG, "nrs_detile: bad tiling");
+	const size_t dense = (size_t)tiles_per_rank_padded * p->tile_size * p->tile_size * channels;
+	if (rank_stride_floats == 0) rank_stride_floats = dense;
+	if (rank_stride_floats < dense) return fail(NRS_ERR_INVALID_ARG, "nrs_detile: rank stride smaller than one rank's tiles");
 	HIP_TRY(hipSetDevice(ctx->device));
-	NRS_TRY(launch_detile(*p, n_ranks, tiles_per_rank_padded, d_tiles, channels, d_image, stream));
+	NRS_TRY(launch_detile(*p, n_ranks, rank_stride_floats, d_tiles, channels, d_image, stream));
 	return NRS_OK;
 }
 

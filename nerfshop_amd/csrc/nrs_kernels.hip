@@ -733,24 +733,24 @@ int launch_grid_update(const DeviceModel& m, const DeviceEdit* d_edits, int n_ed
 }
 
 // ---- multi-GPU de-tiling ---------------------------------------------------------------------------------------------------
-__global__ void detile_kernel(int W, int H, uint32_t tile, uint32_t tiles_x, uint32_t n_ranks, uint32_t tiles_per_rank_padded,
-                              const float* __restrict__ tiles, uint32_t channels, float* __restrict__ image) {
+__global__ void detile_kernel(int W, int H, uint32_t tile, uint32_t tiles_x, uint32_t n_ranks, size_t rank_stride, const float* __restrict__ tiles,
+                              uint32_t channels, float* __restrict__ image) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= (uint32_t)(W * H)) return;
 	const uint32_t x = i % (uint32_t)W, y = i / (uint32_t)W;
 	const uint32_t T = (y / tile) * tiles_x + (x / tile);
 	const uint32_t r = T % n_ranks, k = T / n_ranks;
-	const size_t src = (((size_t)r * tiles_per_rank_padded + k) * tile + (y % tile)) * tile + (x % tile);
-	for (uint32_t c = 0; c < channels; ++c) image[(size_t)i * channels + c] = tiles[src * channels + c];
+	const size_t src = (size_t)r * rank_stride + ((((size_t)k * tile + (y % tile)) * tile + (x % tile))) * channels;
+	for (uint32_t c = 0; c < channels; ++c) image[(size_t)i * channels + c] = tiles[src + c];
 }
 
-int launch_detile(const nrs_render_params& p, uint32_t n_ranks, uint32_t tiles_per_rank_padded, const float* d_tiles, uint32_t channels,
+int launch_detile(const nrs_render_params& p, uint32_t n_ranks, size_t rank_stride_floats, const float* d_tiles, uint32_t channels,
                   float* d_image, void* stream) {
 	const int W = p.resolution[0], H = p.resolution[1];
 	const uint32_t tiles_x = ((uint32_t)W + p.tile_size - 1) / p.tile_size;
 	const uint32_t n = (uint32_t)(W * H);
-	hipLaunchKernelGGL(detile_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, H, p.tile_size, tiles_x, n_ranks,
-	                   tiles_per_rank_padded, d_tiles, channels, d_image);
+	hipLaunchKernelGGL(detile_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, H, p.tile_size, tiles_x, n_ranks, rank_stride_floats,
+	                   d_tiles, channels, d_image);
 	NRS_LAUNCH_CHECK("detile_kernel launch");
 	return NRS_OK;
 }

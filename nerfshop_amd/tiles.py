@@ -42,13 +42,15 @@ class TileSharder:
         self.device = torch.device(device)
         self.tiles_x, self.tiles_y, self.total, self.per_rank = tile_counts(width, height, tile, world)
         self.padded = max(self.per_rank)  # equal-sized contributions: one collective, no ragged sends
-        self.local_frame = torch.zeros((self.padded, tile, tile, 4), dtype=torch.float32, device=self.device)
-        self.local_depth = torch.zeros((self.padded, tile, tile), dtype=torch.float32, device=self.device)
+        # frame and depth of a rank live in ONE buffer [frame block | depth block] so that a single gather moves both
+        n_px = self.padded * tile * tile
+        self.local = torch.zeros(n_px * 5, dtype=torch.float32, device=self.device)
+        self.local_frame = self.local[: n_px * 4].view(self.padded, tile, tile, 4)
+        self.local_depth = self.local[n_px * 4:].view(self.padded, tile, tile)
         if rank == 0:
-            self.all_frame = torch.zeros((world, self.padded, tile, tile, 4), dtype=torch.float32, device=self.device)
-            self.all_depth = torch.zeros((world, self.padded, tile, tile), dtype=torch.float32, device=self.device)
+            self.all = torch.zeros((world, n_px * 5), dtype=torch.float32, device=self.device)
         else:
-            self.all_frame = self.all_depth = None
+            self.all = None
         self._index = None
 
     def fill(self, p):
@@ -57,28 +59,27 @@ class TileSharder:
         return p
 
     def clear(self):
-        self.local_frame.zero_()
-        self.local_depth.zero_()
+        self.local.zero_()
 
     def gather(self, ctx, p, frame, depth):
-        """One gather per buffer to rank 0, then de-tile there.  `frame` [H, W, 4] / `depth` [H, W] are written on rank 0."""
+        """One gather to rank 0, then de-tile there.  `frame` [H, W, 4] / `depth` [H, W] are written on rank 0."""
         if self.world > 1:
-            fl = list(self.all_frame.unbind(0)) if self.rank == 0 else None
-            dl = list(self.all_depth.unbind(0)) if self.rank == 0 else None
-            dist.gather(self.local_frame, fl, dst=0)
-            dist.gather(self.local_depth, dl, dst=0)
+            dist.gather(self.local, list(self.all.unbind(0)) if self.rank == 0 else None, dst=0)
         elif self.rank == 0:
-            self.all_frame[0].copy_(self.local_frame)
-            self.all_depth[0].copy_(self.local_depth)
+            self.all[0].copy_(self.local)
         if self.rank != 0:
             return
+        n_px = self.padded * self.tile * self.tile
         if self.device.type == "cuda":
+            # the gathered buffer is [rank][frame block | depth block]: de-tile each block with its rank stride
             lib = _abi.load()
             s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            _abi.check(lib.nrs_detile(ctx.h, s, C.byref(p), self.world, self.padded, self.all_frame.data_ptr(), 4, frame.data_ptr()))
-            _abi.check(lib.nrs_detile(ctx.h, s, C.byref(p), self.world, self.padded, self.all_depth.data_ptr(), 1, depth.data_ptr()))
+            _abi.check(lib.nrs_detile(ctx.h, s, C.byref(p), self.world, self.padded, self.all.data_ptr(), 4, n_px * 5, frame.data_ptr()))
+            _abi.check(lib.nrs_detile(ctx.h, s, C.byref(p), self.world, self.padded, self.all.data_ptr() + n_px * 16, 1, n_px * 5, depth.data_ptr()))
         else:
             if self._index is None:
                 self._index = detile_index(self.width, self.height, self.tile, self.world, self.padded)
-            frame.view(-1, 4).copy_(self.all_frame.view(-1, 4)[self._index])
-            depth.view(-1).copy_(self.all_depth.view(-1)[self._index])
+            all_frame = self.all[:, : n_px * 4].reshape(-1, 4)
+            all_depth = self.all[:, n_px * 4:].reshape(-1)
+            frame.view(-1, 4).copy_(all_frame[self._index])
+            depth.view(-1).copy_(all_depth[self._index])

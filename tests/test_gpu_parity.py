@@ -258,12 +258,54 @@ def test_tiled_render_matches_whole(rig):
     image = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
     dimage = torch.zeros((H, W), dtype=torch.float32, device="cuda:0")
     from nerfshop_amd._abi import check
-    check(lib.nrs_detile(rig.ctx.h, None, C.byref(p), n_ranks, pad, tiles.data_ptr(), 4, image.data_ptr()))
-    check(lib.nrs_detile(rig.ctx.h, None, C.byref(p), n_ranks, pad, dtiles.data_ptr(), 1, dimage.data_ptr()))
+    check(lib.nrs_detile(rig.ctx.h, None, C.byref(p), n_ranks, pad, tiles.data_ptr(), 4, 0, image.data_ptr()))
+    check(lib.nrs_detile(rig.ctx.h, None, C.byref(p), n_ranks, pad, dtiles.data_ptr(), 1, 0, dimage.data_ptr()))
     torch.cuda.synchronize()
     assert total == whole_stats.n_samples
     assert np.array_equal(image.cpu().numpy(), whole)
     assert np.array_equal(dimage.cpu().numpy(), whole_depth)
+
+
+def test_tile_sharder_fused_buffer_on_device(rig):
+    """bench.py's N > 1 data path minus the collective: every rank renders into its [frame block | depth block] buffer
+    (tiles.TileSharder), the blocks are laid out rank-major as one gather delivers them, and the strided nrs_detile
+    reproduces the un-tiled frame bit for bit."""
+    import ctypes as C
+    from nerfshop_amd import tiles
+    from nerfshop_amd._abi import check
+    rig.use_edit(False)
+    torch = rig.torch
+    W, H, tile, world = 200, 120, 32, 3
+    p = rig.scene.params_for(W, H, 30.0)
+    whole, whole_depth, _, _ = rig.render(p, want_steps=False)
+    shards = [tiles.TileSharder(W, H, tile, r, world, "cuda:0") for r in range(world)]
+    for sh in shards:
+        sh.fill(p)
+        sh.clear()
+        rig.testbed.render_with_params(rig.net, p, sh.local_frame, sh.local_depth, None, None)
+    root = shards[0]
+    for r, sh in enumerate(shards):
+        root.all[r].copy_(sh.local)          # what dist.gather does
+    n_px = root.padded * tile * tile
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    depth = torch.zeros((H, W), dtype=torch.float32, device="cuda:0")
+    lib = rig.ctx.lib
+    root.fill(p)
+    check(lib.nrs_detile(rig.ctx.h, None, C.byref(p), world, root.padded, root.all.data_ptr(), 4, n_px * 5, frame.data_ptr()))
+    check(lib.nrs_detile(rig.ctx.h, None, C.byref(p), world, root.padded, root.all.data_ptr() + n_px * 16, 1, n_px * 5, depth.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), whole)
+    assert np.array_equal(depth.cpu().numpy(), whole_depth)
+    # world == 1 goes through the same code (bench.py --gpus 1 does not shard, this keeps the path honest)
+    one = tiles.TileSharder(W, H, tile, 0, 1, "cuda:0")
+    one.fill(p)
+    one.clear()
+    rig.testbed.render_with_params(rig.net, p, one.local_frame, one.local_depth, None, None)
+    frame.zero_(); depth.zero_()
+    one.gather(rig.ctx, p, frame, depth)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), whole)
+    assert np.array_equal(depth.cpu().numpy(), whole_depth)
 
 
 def test_density_grid_to_bitfield_device(rig):
