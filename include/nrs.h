@@ -71,7 +71,6 @@ typedef enum nrs_render_mode {
 /* GPUMatrixDynamic<T>::layout() of the network output: planes = row-major [16 x n_el]
  * (renderer, density-grid update), interleaved = column-major, 16 halfs per sample (selection, Poisson). */
 typedef enum nrs_layout { NRS_PLANES = 0, NRS_INTERLEAVED = 1 } nrs_layout;
-typedef enum nrs_schedule { NRS_SCHEDULE_AUTO = 0, NRS_SCHEDULE_ONE_LANE_PER_RAY = 1, NRS_SCHEDULE_TWO_LANES_PER_RAY = 2 } nrs_schedule;
 
 /* Network hyper-parameters: configs/nerf/base.json:23-58 + src/testbed.cu:2257-2333. */
 typedef struct nrs_model_desc {
@@ -169,10 +168,6 @@ typedef struct nrs_render_params {
 	uint32_t tile_size;           /* multiple of 8, or 0 */
 	uint32_t tile_first;
 	uint32_t tile_stride;
-	/* How rays are laid onto lanes (results are identical; no reference counterpart): AUTO picks two lanes per ray when the
-	 * call has little work for the machine (one rank's tiles of a frame shared by several GPUs), where one ray's latency,
-	 * not throughput, sets the frame time. */
-	uint32_t schedule;            /* nrs_schedule */
 } nrs_render_params;
 
 typedef struct nrs_render_stats {

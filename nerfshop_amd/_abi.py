@@ -19,7 +19,6 @@ N_LUT_CELLS = GRID_VOLUME * GRID_CASCADES
 ACT_NONE, ACT_RELU, ACT_LOGISTIC, ACT_EXPONENTIAL = 0, 1, 2, 3
 RENDER_SHADE, RENDER_COST = 1, 8
 LAYOUT_PLANES, LAYOUT_INTERLEAVED = 0, 1
-SCHEDULE_AUTO, SCHEDULE_ONE_LANE_PER_RAY, SCHEDULE_TWO_LANES_PER_RAY = 0, 1, 2
 
 
 class ModelDesc(C.Structure):
@@ -98,7 +97,6 @@ class RenderParams(C.Structure):
         ("tile_size", C.c_uint32),
         ("tile_first", C.c_uint32),
         ("tile_stride", C.c_uint32),
-        ("schedule", C.c_uint32),
     ]
 
 

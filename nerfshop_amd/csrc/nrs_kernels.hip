@@ -84,11 +84,7 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 // the common path pays neither its registers nor its code.
 // AFFINE compiles in the AffineDuplication operator (edit_warp's second kind): frames whose operators are all cage
 // deformations -- the common case and the benchmark -- run the instantiation without it (2 % faster: 122 vs 128 VGPRs).
-// TEAM: two lanes per ray.  Lanes 0..31 own the rays; each round the owner also finds its ray's NEXT sample (the march it would do
-// after compositing anyway) and hands it to lane + 32, the wave evaluates both, and the owner composites them in order (the
-// second is dropped if the first saturated the ray).  Same samples, same arithmetic, half the sequential rounds per ray: for
-// launches with little work per GPU (multi-GPU tiles), where the frame time is one ray's latency rather than throughput.
-template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, bool TEAM>
+template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE>
 __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceModel m, const RenderArgs a) {
 	__shared__ RenderSmem<WAVES> sm;
 	for (uint32_t i = threadIdx.x; i < kCoarseWords; i += blockDim.x) sm.coarse[i] = m.occ.mask[i];
@@ -129,7 +125,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 
 	for (;;) {
 		NRS_PHASE(0); // fill
-		const unsigned long long free_mask = TEAM ? (__ballot(!have) & 0xffffffffull) : __ballot(!have); // TEAM: only lanes 0..31 own rays
+		const unsigned long long free_mask = __ballot(!have);
 		const uint32_t nfree = (uint32_t)__popcll(free_mask);
 
 		// ---- fill the ring with rays that found an occupied cell (init_rays + advance_pos_nerf) ----
@@ -179,7 +175,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		if (nfree && ring_count) {
 			const uint32_t take = min(nfree, ring_count);
 			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
-			if (!have && rank < take && (!TEAM || lane < 32)) {
+			if (!have && rank < take) {
 				const uint4 e = ring[(ring_head + rank) & (kRing - 1)];
 				const uint32_t x = e.x & 0xffffu, y = e.x >> 16;
 				ray_origin_dir(p, x, y, off_x, off_y, o, d); // same arithmetic as at enqueue time -> same bits
@@ -203,29 +199,15 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		NRS_PHASE(2); // sample set-up + cage warp
 		if (PROF) ++pf_rounds;
 		// ---- one sample per live ray: generate_next_nerf_network_inputs body (tn:668-692) ----
-		f3 pos = o + d * t;
-		float dt = calc_dt(t, p.cone_angle_constant);
-		f3 sdir = d;
-		bool shave = have;       // this lane carries a sample this round (== have unless TEAM)
-		float tB = 0.f, dtB = 0.f;
-		bool okB = false;
-		if (TEAM) {
-			f3 posB = mk3(0.f, 0.f, 0.f);
-			if (have) { // the owner's second sample: exactly the march the sequential schedule performs after compositing the first
-				tB = t + dt;
-				okB = march_to_occupied(p, m, sm.coarse, o, d, idir, tB, posB, dtB);
-			}
-			const f3 xp = mk3(xchg32(posB.x), xchg32(posB.y), xchg32(posB.z)), xd = mk3(xchg32(d.x), xchg32(d.y), xchg32(d.z));
-			const float xdt = xchg32(dtB);
-			const bool xok = __shfl_xor((int)okB, 32, 64) != 0;
-			if (g == 1) { pos = xp; dt = xdt; sdir = xd; shave = xok; }
-		}
+		const f3 pos = o + d * t;
+		const float dt = calc_dt(t, p.cone_angle_constant);
 		f3 wpos = m.diag_pow2 ? mk3((pos.x - m.aabb.mn[0]) * m.inv_diag[0], (pos.y - m.aabb.mn[1]) * m.inv_diag[1], (pos.z - m.aabb.mn[2]) * m.inv_diag[2])
 		                      : warp_position(pos, m.aabb);
-		f3 wdir = warp_direction(sdir);
+		f3 wdir = warp_direction(d);
+		const float wdt = warp_dt(dt);
 		bool empty = false;
 		const f3 wpos0 = wpos; // un-deformed sample position (membrane terms live in deformed space)
-		if (ops && shave) { // map_rays, last-to-first (tn:2899-2902)
+		if (ops && have) { // map_rays, last-to-first (tn:2899-2902)
 			for (int ei = a.n_edits - 1; ei >= 0; --ei) empty |= AFFINE ? edit_warp(a.edits[ei], true, wpos, wdir) : tet_warp(a.edits[ei], true, wpos, wdir);
 		}
 		// ---- membrane correction inputs (compute_poisson_full_residuals, tn:2867-2883) + first network pass (tn:2890-2892) ----
@@ -259,14 +241,13 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		// ---- gather: own sample (block g) and the partner lane's sample (block 1-g), levels 2*it+g ----
 		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
 		const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
-		const bool phave = __shfl_xor((int)shave, 32, 64) != 0;
-		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, shave, ppos, phave);
+		const bool phave = __shfl_xor((int)have, 32, 64) != 0;
+		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, have, ppos, phave);
 		NRS_PHASE(4); // SH + MLP
 		const half8 sh_own = encode_sh4(g, wdir), sh_par = encode_sh4(g, pdir);
 
 		// ---- fused MLPs on MFMA, one 32-sample block at a time ----
 		uint32_t res_d = 0, res_rg = 0, res_b = 0;
-		uint32_t resB_d = 0, resB_rg = 0, resB_b = 0; // TEAM: the second sample's outputs, kept on the owner lane
 		#pragma unroll 1
 		for (int b = 0; b < 2; ++b) {
 			const int sel = (b != g) ? 1 : 0;
@@ -279,13 +260,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			const u32x4 dd = __builtin_bit_cast(u32x4, dout), rr = __builtin_bit_cast(u32x4, rout);
 			// rows 0..2 of a block sit in its lanes 0..31; block 1's samples belong to the rays of lanes 32..63
 			uint32_t vd = dd[0], vrg = rr[0], vb = rr[1];
-			if (TEAM) { // both blocks' rows 0..2 sit in lanes 0..31 = the owners
-				if (b == 0) { res_d = vd; res_rg = vrg; res_b = vb; }
-				else { resB_d = vd; resB_rg = vrg; resB_b = vb; }
-			} else {
-				if (b == 1) { vd = xchg32u(vd); vrg = xchg32u(vrg); vb = xchg32u(vb); }
-				if (g == b) { res_d = vd; res_rg = vrg; res_b = vb; }
-			}
+			if (b == 1) { vd = xchg32u(vd); vrg = xchg32u(vrg); vb = xchg32u(vb); }
+			if (g == b) { res_d = vd; res_rg = vrg; res_b = vb; }
 		}
 		const half2v hd = __builtin_bit_cast(half2v, res_d), hrg = __builtin_bit_cast(half2v, res_rg), hb = __builtin_bit_cast(half2v, res_b);
 		const float sigma_raw = (float)hd[0];
@@ -295,78 +271,48 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		// ---- composite_kernel_nerf body (tn:750-955, Shade mode) + next-sample march ----
 		uint32_t it_march = 0;
 		if (PROF) { pf_walk[4] += (lane == 0) ? 1u : 0u; pf_walk[5] += have ? 1u : 0u; }
-		// what the owner needs from the lane that carried its second sample (cross-lane reads must run with every lane active)
-		float depth_cand = 0.f, depthB = 0.f;
-		bool emptyB = false;
-		if (TEAM) {
-			depth_cand = dot3(cam_fwd, unwarp_position(wpos, m.aabb) - cam_o);
-			depthB = xchg32(depth_cand);
-			emptyB = __shfl_xor((int)empty, 32, 64) != 0;
-		}
 		if (have) {
-			// one sample into the ray's accumulators (composite_kernel_nerf's loop body); returns true when the ray saturated
-			auto composite = [&](float s_raw, float r_raw, float g_raw, float b_raw, float step, bool is_empty, float depth_of_sample) -> bool {
-				const float T = 1.f - ca;
-				const float cdt = unwarp_dt(warp_dt(step));
-				const float sigma = network_to_density(s_raw, m.density_activation);
-				float alpha = 1.f - __expf(-sigma * cdt);
-				if (POISSON && has_res) { // tn:770-780
-					const float targetval = network_to_density(sigma_old_raw, m.density_activation);
-					const float val = p.poisson_target ? fminf(fmaxf(targetval, sigma), sigma + p_res) : sigma + p_res;
-					alpha = 1.f - __expf(-(val) * cdt);
-				}
-				if (is_empty) alpha = 0.0f;
-				const float weight = alpha * T;
-				const float sr = network_to_rgb(r_raw, m.rgb_activation), sg = network_to_rgb(g_raw, m.rgb_activation), sb = network_to_rgb(b_raw, m.rgb_activation);
-				if (POISSON && has_res) { // tn:796-805, 939-943
-					const float alpha_N = 1.f - __expf(-sigma * cdt);
-					const float alpha_R = 1.f - __expf(-p_out * cdt);
-					const float w_N = alpha_N / (alpha_N + alpha_R), w_R = alpha_R / (alpha_N + alpha_R);
-					cr += weight * (w_N * sr + w_R * p_rgb[0]);
-					cg += weight * (w_N * sg + w_R * p_rgb[1]);
-					cb += weight * (w_N * sb + w_R * p_rgb[2]);
-				} else {
-					cr += sr * weight;
-					cg += sg * weight;
-					cb += sb * weight;
-				}
-				ca += weight;
-				if (weight > max_weight) {
-					max_weight = weight;
-					ray_depth = TEAM ? depth_of_sample : dot3(cam_fwd, unwarp_position(wpos, m.aabb) - cam_o);
-				}
-				++n_steps;
-				++st_samples;
-				if (ca > (1.0f - p.min_transmittance)) {
-					// rgba /= alpha (tn:951-953): one v_rcp (1 ulp) + three multiplies instead of four IEEE divisions -- this block runs
-					// nearly every round (some lane of the wave saturates), and the colour tolerance (tests) is 5 orders of magnitude wider
-					const float inv_a = __builtin_amdgcn_rcpf(ca);
-					cr *= inv_a; cg *= inv_a; cb *= inv_a; ca = 1.0f;
-					return true;
-				}
-				return false;
-			};
+			const f3 cpos = unwarp_position(wpos, m.aabb);
+			const float T = 1.f - ca;
+			const float cdt = unwarp_dt(wdt);
+			const float sigma = network_to_density(sigma_raw, m.density_activation);
+			float alpha = 1.f - __expf(-sigma * cdt);
+			if (POISSON && has_res) { // tn:770-780
+				const float targetval = network_to_density(sigma_old_raw, m.density_activation);
+				const float val = p.poisson_target ? fminf(fmaxf(targetval, sigma), sigma + p_res) : sigma + p_res;
+				alpha = 1.f - __expf(-(val) * cdt);
+			}
+			if (empty) alpha = 0.0f;
+			const float weight = alpha * T;
+			const float sr = network_to_rgb(raw_r, m.rgb_activation), sg = network_to_rgb(raw_g, m.rgb_activation), sb = network_to_rgb(raw_b, m.rgb_activation);
+			if (POISSON && has_res) { // tn:796-805, 939-943
+				const float alpha_N = 1.f - __expf(-sigma * cdt);
+				const float alpha_R = 1.f - __expf(-p_out * cdt);
+				const float w_N = alpha_N / (alpha_N + alpha_R), w_R = alpha_R / (alpha_N + alpha_R);
+				cr += weight * (w_N * sr + w_R * p_rgb[0]);
+				cg += weight * (w_N * sg + w_R * p_rgb[1]);
+				cb += weight * (w_N * sb + w_R * p_rgb[2]);
+			} else {
+				cr += sr * weight;
+				cg += sg * weight;
+				cb += sb * weight;
+			}
+			ca += weight;
+			if (weight > max_weight) {
+				max_weight = weight;
+				ray_depth = dot3(cam_fwd, cpos - cam_o);
+			}
+			++n_steps;
+			++st_samples;
 			bool done = false, shade = true;
-			if (composite(sigma_raw, raw_r, raw_g, raw_b, dt, empty, depth_cand)) {
+			if (ca > (1.0f - p.min_transmittance)) {
+				// rgba /= alpha (tn:951-953): one v_rcp (1 ulp) + three multiplies instead of four IEEE divisions -- this block runs
+				// nearly every round (some lane of the wave saturates), and the colour tolerance (tests) is 5 orders of magnitude wider
+				const float inv_a = __builtin_amdgcn_rcpf(ca);
+				cr *= inv_a; cg *= inv_a; cb *= inv_a; ca = 1.0f;
 				done = true;
 			} else if (n_steps >= a.max_steps) {
 				done = true; shade = false; // MARCH_ITER exhausted: the reference never compacts such a ray into the hit list
-			} else if (TEAM) {
-				if (!okB) {
-					done = true; // the march after the first sample left the render box
-				} else {
-					const half2v hdB = __builtin_bit_cast(half2v, resB_d), hrgB = __builtin_bit_cast(half2v, resB_rg), hbB = __builtin_bit_cast(half2v, resB_b);
-					t = tB;
-					if (composite((float)hdB[0], (float)hrgB[0], (float)hrgB[1], (float)hbB[0], dtB, emptyB, depthB)) {
-						done = true;
-					} else if (n_steps >= a.max_steps) {
-						done = true; shade = false;
-					} else {
-						t += dtB;
-						f3 npos; float ndt;
-						done = !march_to_occupied(p, m, sm.coarse, o, d, idir, t, npos, ndt, PROF ? &it_march : nullptr);
-					}
-				}
 			} else {
 				t += dt;
 				f3 npos; float ndt;
@@ -422,17 +368,17 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	atomicAdd(&a.counters->n_rays_hit, st_hit);
 }
 
-template <int WAVES, int OCC, bool PROF = false, bool POISSON = false, bool AFFINE = false, bool TEAM = false>
+template <int WAVES, int OCC, bool PROF = false, bool POISSON = false, bool AFFINE = false>
 static int launch_render_cfg(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream) {
 	int blocks_per_cu = 0;
-	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC, PROF, POISSON, AFFINE, TEAM>, 64 * WAVES, 0);
+	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC, PROF, POISSON, AFFINE>, 64 * WAVES, 0);
 	if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(render_kernel)");
 	if (blocks_per_cu < 1) blocks_per_cu = 1;
 	uint32_t grid = (uint32_t)(n_cus * blocks_per_cu);
 	const uint32_t max_useful = (a.n_packets + WAVES - 1) / WAVES; // at least one packet per wave
 	if (grid > max_useful) grid = max_useful;
 	if (grid == 0) return NRS_OK;
-	hipLaunchKernelGGL((render_kernel<WAVES, OCC, PROF, POISSON, AFFINE, TEAM>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
+	hipLaunchKernelGGL((render_kernel<WAVES, OCC, PROF, POISSON, AFFINE>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
 	NRS_LAUNCH_CHECK("render_kernel launch");
 	return NRS_OK;
 }
@@ -446,12 +392,6 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 	}();
 	hipStream_t s = (hipStream_t)stream;
 	if (a.any_poisson) return launch_render_cfg<8, 2, false, true, true>(m, a, n_cus, s);
-	// little work for the machine (one rank's tiles of a frame shared by several GPUs): two lanes per ray.  The threshold is in
-	// packets per resident wave (16 waves/CU); NRS_TEAM_PACKETS overrides it (0 = never) for the scaling measurements.
-	static const int team_ppw = []() { const char* e = getenv("NRS_TEAM_PACKETS"); return e ? atoi(e) : 3; }();
-	const bool team = a.p.schedule == NRS_SCHEDULE_TWO_LANES_PER_RAY ||
-	                  (a.p.schedule == NRS_SCHEDULE_AUTO && a.n_packets < (uint32_t)team_ppw * (uint32_t)n_cus * 16u);
-	if (team && !a.any_affine && !(a.dbg & 4u) && cfg == 0) return launch_render_cfg<8, 3, false, false, false, true>(m, a, n_cus, s);
 	if (a.any_affine) return launch_render_cfg<8, 3, false, false, true>(m, a, n_cus, s);
 	if (a.dbg & 4u) return launch_render_cfg<8, 4, true>(m, a, n_cus, s);
 	// <8, 3>: __launch_bounds__(512, 3) lets the register allocator aim at 168 VGPRs; it settles at 128 (still 4 waves/SIMD,

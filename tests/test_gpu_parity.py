@@ -146,12 +146,10 @@ def _compare_frames(frame, depth, steps, ref_frame, ref_depth, ref_steps):
     assert (depth[miss] == 1e10).all() and (ref_depth[miss] == 1e10).all()
 
 
-@pytest.mark.parametrize("schedule", [1, 2])   # one lane per ray / two lanes per ray (nrs_schedule); AUTO would pick 2 at this size
 @pytest.mark.parametrize("az,snap", [(30.0, True), (200.0, False)])
-def test_render_no_edit(rig, az, snap, schedule):
+def test_render_no_edit(rig, az, snap):
     rig.use_edit(False)
     p = rig.scene.params_for(256, 144, az, snap=snap, spp_index=0 if snap else 5)
-    p.schedule = schedule
     frame, depth, steps, stats = rig.render(p)
     ref_frame, ref_depth, ref_steps, ref_stats = rig.scene.oracle_model.render(p)
     assert ref_stats.n_hit > 1000
@@ -161,12 +159,10 @@ def test_render_no_edit(rig, az, snap, schedule):
     assert abs(int(stats.n_rays_hit) - int(ref_stats.n_hit)) <= 2
 
 
-@pytest.mark.parametrize("schedule", [1, 2])
-def test_render_with_cage_edit(rig, schedule):
+def test_render_with_cage_edit(rig):
     rig.use_edit(True)
     try:
         p = rig.scene.params_for(256, 144, 60.0)
-        p.schedule = schedule
         frame, depth, steps, stats = rig.render(p)
         ref_frame, ref_depth, ref_steps, ref_stats = rig.scene.oracle_model.render(p, [rig.scene.oracle_edit])
         _compare_frames(frame, depth, steps, ref_frame, ref_depth, ref_steps)
@@ -268,26 +264,6 @@ def test_tiled_render_matches_whole(rig):
     assert total == whole_stats.n_samples
     assert np.array_equal(image.cpu().numpy(), whole)
     assert np.array_equal(dimage.cpu().numpy(), whole_depth)
-
-
-@pytest.mark.parametrize("with_edit", [False, True])
-def test_schedules_are_bit_identical(rig, with_edit):
-    """One lane per ray and two lanes per ray evaluate the same samples with the same arithmetic: identical frames, depths and
-    per-pixel sample counts (the second sample of a round is dropped exactly when the first saturated the ray)."""
-    rig.use_edit(with_edit)
-    try:
-        out = []
-        for schedule in (1, 2):
-            p = rig.scene.params_for(320, 200, 75.0, snap=False, spp_index=3)
-            p.schedule = schedule
-            frame, depth, steps, stats = rig.render(p)
-            out.append((frame, depth, steps, int(stats.n_samples), int(stats.n_rays_hit)))
-        assert out[0][3] == out[1][3] and out[0][4] == out[1][4] and out[0][3] > 100000
-        assert np.array_equal(out[0][2], out[1][2])
-        assert np.array_equal(out[0][0], out[1][0])
-        assert np.array_equal(out[0][1], out[1][1])
-    finally:
-        rig.use_edit(False)
 
 
 def test_tile_sharder_fused_buffer_on_device(rig):
