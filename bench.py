@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary no-edit measurement")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = default: 1 frame at a time on one GPU, 2 (double-buffered streams) on several")
     args = ap.parse_args()
 
     import torch
@@ -133,9 +134,18 @@ def main():
     tb = scene["tb"]
     W, H = args.width, args.height
 
-    sharder = tiles.TileSharder(W, H, TILE, rank, world, dev) if world > 1 else None
-    frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
-    depth = torch.zeros((H, W), dtype=torch.float32, device=dev)
+    # N > 1: frames are double-buffered over two HIP streams (two tile buffers, two output images), so that the last
+    # generation of rays of frame k -- one ray's latency, during which the GPU drains -- overlaps the start of frame k + 1 and
+    # the RCCL gather of frame k hides behind rendering.  One rank's share of a 1080p frame is latency-bound, not
+    # throughput-bound.  N = 1 renders strictly one frame at a time: per-launch durations stay clean for the roofline.
+    n_buf = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world > 1 else 1)
+    tiled = world > 1 or n_buf > 1
+    sharders = [tiles.TileSharder(W, H, TILE, rank, world, dev) for _ in range(n_buf)] if tiled else None
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_buf)] if tiled else None
+    frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(n_buf)]
+    depths = [torch.zeros((H, W), dtype=torch.float32, device=dev) for _ in range(n_buf)]
+    frame, depth = frames[0], depths[0]
+    sharder = sharders[0] if sharders else None
 
     def make_params(step, apply_ops=True):
         p = synth.render_params(W, H, camera_for(step, synth, scene["aabb_scale"]), aabb_scale=scene["aabb_scale"], apply_operators=apply_ops)
@@ -156,13 +166,16 @@ def main():
             if timed_idx is not None:
                 ev1[timed_idx].record()
         else:
-            sharder.clear()
-            if timed_idx is not None:
-                ev0[timed_idx].record()
-            st = tb.render_with_params(tb.nerf_network, p, sharder.local_frame, sharder.local_depth, None, None, want_stats=want_stats)
-            if timed_idx is not None:
-                ev1[timed_idx].record()
-            sharder.gather(ctx, p, frame, depth)  # RCCL gather to rank 0 + de-tile
+            b = step % n_buf
+            sh, stream = sharders[b], streams[b]
+            with torch.cuda.stream(stream):
+                sh.clear()
+                if timed_idx is not None:
+                    ev0[timed_idx].record(stream)
+                st = tb.render_with_params(tb.nerf_network, p, sh.local_frame, sh.local_depth, None, stream, want_stats=want_stats)
+                if timed_idx is not None:
+                    ev1[timed_idx].record(stream)
+                sh.gather(ctx, p, frames[b], depths[b])  # RCCL gather to rank 0 + de-tile, ordered after this stream's render
         return st
 
     def sync_all():
@@ -236,7 +249,8 @@ def main():
                                     "lego": "lego-like snapshot 1920x1080, no edits (BASELINE configs[1])",
                                     "garden_cage": "garden-style aabb_scale 16 1920x1080, one cage edit (BASELINE configs[3])"}[args.workload],
                        "resolution": [W, H], "samples_per_frame": int(total_samples / args.steps),
-                       "sharding": f"{TILE}x{TILE} image tiles round-robin over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else "")},
+                       "sharding": f"{TILE}x{TILE} image tiles round-robin over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "frames_in_flight": n_buf},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic(args.workload) if world == 1 else None, "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 3),
                          "algorithmic_bytes_per_launch": int(per_launch_samples * BYTES_PER_SAMPLE),

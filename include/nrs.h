@@ -33,7 +33,8 @@
  * thread-local message.  All buffers named d_* are DEVICE pointers owned by the caller; h_* are HOST
  * pointers.  `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous
  * on `stream` unless stated; the caller synchronises (the reference does the same, src/testbed.cu:2843).
- * A context is not thread-safe; use one per host thread / GPU.  No torch / C++ types cross this boundary.
+ * A context is not thread-safe; use one per host thread / GPU.  Render calls issued back to back on DIFFERENT streams may
+ * overlap on the device (double-buffered frames; up to 8 in flight per context).  No torch / C++ types cross this boundary.
  */
 #ifndef NRS_H
 #define NRS_H

@@ -43,8 +43,12 @@ struct nrs_ctx {
 	int n_cus = 0;
 	size_t hbm_bytes = 0;
 	char name[256] = {0};
-	RenderCounters* d_counters = nullptr;
-	DeviceEdit* d_edits = nullptr; // scratch array for render calls
+	// per-launch scratch comes from small rings so that render calls issued back to back on DIFFERENT streams (double-buffered
+	// frames) do not share a packet counter or an operator table: slot = launch number % kInFlight
+	static constexpr int kInFlight = 8;
+	RenderCounters* d_counters = nullptr;   // [kInFlight]
+	DeviceEdit* d_edits = nullptr;          // [kInFlight][kMaxEdits]
+	uint32_t launch_serial = 0;
 	float* d_mean = nullptr;
 	unsigned long long* d_wave_log = nullptr; // profiling only (NRS_DEBUG & 4)
 	static constexpr int kMaxEdits = 32;
@@ -310,8 +314,8 @@ int nrs_ctx_create(int device, nrs_ctx** out) {
 	c->n_cus = prop.multiProcessorCount;
 	c->hbm_bytes = prop.totalGlobalMem;
 	snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
-	HIP_TRY(hipMalloc((void**)&c->d_counters, sizeof(RenderCounters)));
-	HIP_TRY(hipMalloc((void**)&c->d_edits, sizeof(DeviceEdit) * nrs_ctx::kMaxEdits));
+	HIP_TRY(hipMalloc((void**)&c->d_counters, sizeof(RenderCounters) * nrs_ctx::kInFlight));
+	HIP_TRY(hipMalloc((void**)&c->d_edits, sizeof(DeviceEdit) * nrs_ctx::kMaxEdits * nrs_ctx::kInFlight));
 	HIP_TRY(hipMalloc((void**)&c->d_mean, 8 + 256 * 8)); // mean + partial sums (launch_grid_to_bitfield)
 	HIP_TRY(hipMalloc((void**)&c->d_wave_log, 8192 * 4 * 8));
 	*out = c;
@@ -876,6 +880,9 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	nrs_ctx* ctx = m->ctx;
 	HIP_TRY(hipSetDevice(ctx->device));
 	hipStream_t s = (hipStream_t)stream;
+	const uint32_t slot = ctx->launch_serial++ % (uint32_t)nrs_ctx::kInFlight;
+	RenderCounters* d_counters_slot = ctx->d_counters + slot;
+	DeviceEdit* d_edits_slot = ctx->d_edits + (size_t)slot * nrs_ctx::kMaxEdits;
 
 	RenderArgs a{};
 	a.p = *p;
@@ -892,9 +899,9 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 			a.any_poisson |= edits[i]->de.apply_poisson;
 			a.any_affine |= (edits[i]->de.kind == kEditAffine) ? 1u : 0u;
 		}
-		HIP_TRY(hipMemcpyAsync(ctx->d_edits, host_edits, sizeof(DeviceEdit) * n_edits, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(d_edits_slot, host_edits, sizeof(DeviceEdit) * n_edits, hipMemcpyHostToDevice, s));
 	}
-	a.edits = ctx->d_edits;
+	a.edits = d_edits_slot;
 	a.max_steps = p->max_march_steps ? p->max_march_steps : 10000u; // MARCH_ITER, testbed_nerf.cu:56
 	{
 		static const uint32_t dbg = []() { const char* e = getenv("NRS_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
@@ -903,14 +910,14 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	a.frame = d_frame;
 	a.depth = d_depth;
 	a.steps = d_steps;
-	a.counters = ctx->d_counters;
+	a.counters = d_counters_slot;
 	a.wave_log = (a.dbg & 4u) ? ctx->d_wave_log : nullptr;
 	if (a.wave_log) HIP_TRY(hipMemsetAsync(ctx->d_wave_log, 0, 8192 * 4 * 8, s));
-	HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(RenderCounters), s));
+	HIP_TRY(hipMemsetAsync(d_counters_slot, 0, sizeof(RenderCounters), s));
 	NRS_TRY(launch_render(model_for_launch(m, *p), a, ctx->n_cus, s));
 	if (h_stats) {
 		RenderCounters c;
-		HIP_TRY(hipMemcpyAsync(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemcpyAsync(&c, d_counters_slot, sizeof(c), hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		h_stats->n_samples = c.n_samples;
 		h_stats->n_rays_alive = c.n_rays_alive;

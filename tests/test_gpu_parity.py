@@ -308,6 +308,33 @@ def test_tile_sharder_fused_buffer_on_device(rig):
     assert np.array_equal(depth.cpu().numpy(), whole_depth)
 
 
+def test_concurrent_launches_on_two_streams(rig):
+    """Double-buffered frames: render calls issued back to back on different streams run concurrently (each has its own packet
+    counter and operator table, nrs_ctx::kInFlight) and produce exactly the frames of one-at-a-time rendering."""
+    rig.use_edit(True)
+    torch = rig.torch
+    try:
+        views = [rig.scene.params_for(320, 200, az) for az in (10.0, 100.0, 190.0, 280.0)]
+        ref = [rig.render(p, want_steps=False)[0] for p in views]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        frames = [torch.zeros((200, 320, 4), dtype=torch.float32, device="cuda:0") for _ in views]
+        depths = [torch.zeros((200, 320), dtype=torch.float32, device="cuda:0") for _ in views]
+        torch.cuda.synchronize()
+        for rep in range(3):
+            for f in frames:
+                f.zero_()
+            torch.cuda.synchronize()
+            for i, p in enumerate(views):
+                st = streams[i % 2]
+                with torch.cuda.stream(st):
+                    rig.testbed.render_with_params(rig.net, p, frames[i], depths[i], None, st)
+            torch.cuda.synchronize()
+            for i in range(len(views)):
+                assert np.array_equal(frames[i].cpu().numpy(), ref[i]), (rep, i)
+    finally:
+        rig.use_edit(False)
+
+
 def test_density_grid_to_bitfield_device(rig):
     """nrs_model_set_density_grid == update_density_grid_mean_and_bitfield: bit-exact vs the oracle."""
     from oracle import oracle as orc
