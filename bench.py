@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary no-edit measurement")
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = default: 1 frame at a time on one GPU, 2 (double-buffered streams) on several")
+    ap.add_argument("--frames-in-flight", type=int, default=1, help="frames rendered concurrently (double-buffered streams when > 1)")
     args = ap.parse_args()
 
     import torch
@@ -134,23 +134,26 @@ def main():
     tb = scene["tb"]
     W, H = args.width, args.height
 
-    # N > 1: frames are double-buffered over two HIP streams (two tile buffers, two output images), so that the last
-    # generation of rays of frame k -- one ray's latency, during which the GPU drains -- overlaps the start of frame k + 1 and
-    # the RCCL gather of frame k hides behind rendering.  One rank's share of a 1080p frame is latency-bound, not
-    # throughput-bound.  N = 1 renders strictly one frame at a time: per-launch durations stay clean for the roofline.
-    n_buf = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world > 1 else 1)
+    # Frames are rendered strictly one at a time by default (frames_in_flight = 1, at every N): per-launch durations stay clean
+    # for the roofline and the per-N values compare like with like.  The secondary "pipelined" measurement below double-buffers
+    # frames over two HIP streams (two tile buffers, two output images): the last generation of rays of frame k -- one ray's
+    # latency, during which the GPU drains -- then overlaps the start of frame k + 1, and the RCCL gather hides behind rendering.
+    n_buf = max(1, args.frames_in_flight)
     tiled = world > 1 or n_buf > 1
-    sharders = [tiles.TileSharder(W, H, TILE, rank, world, dev) for _ in range(n_buf)] if tiled else None
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_buf)] if tiled else None
-    frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(n_buf)]
-    depths = [torch.zeros((H, W), dtype=torch.float32, device=dev) for _ in range(n_buf)]
+    max_buf = max(n_buf, 1 if args.no_extra else 2)
+    all_sharders = [tiles.TileSharder(W, H, TILE, rank, world, dev) for _ in range(max_buf)]
+    all_streams = [torch.cuda.Stream(device=dev) for _ in range(max_buf)]
+    frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(max_buf)]
+    depths = [torch.zeros((H, W), dtype=torch.float32, device=dev) for _ in range(max_buf)]
     frame, depth = frames[0], depths[0]
-    sharder = sharders[0] if sharders else None
+    sharders = all_sharders if tiled else None
+    streams = all_streams if tiled else None
+    sharder = all_sharders[0] if tiled else None
 
-    def make_params(step, apply_ops=True):
+    def make_params(step, apply_ops=True, force_tiled=False):
         p = synth.render_params(W, H, camera_for(step, synth, scene["aabb_scale"]), aabb_scale=scene["aabb_scale"], apply_operators=apply_ops)
-        if sharder is not None:
-            sharder.fill(p)
+        if sharder is not None or force_tiled:
+            all_sharders[0].fill(p)
         return p
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -224,6 +227,28 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         extra["noedit"] = {"msamples_per_s": round(ns / dt / 1e6, 2), "fps": round(8 / dt, 2)}
+
+    if not args.no_extra:
+        # secondary: the same frames with two in flight (all ranks take part; `value` stays the one-at-a-time figure)
+        def pipelined_step(step):
+            b = step % 2
+            p = make_params(step, force_tiled=True)
+            with torch.cuda.stream(all_streams[b]):
+                all_sharders[b].clear()
+                tb.render_with_params(tb.nerf_network, p, all_sharders[b].local_frame, all_sharders[b].local_depth, None, all_streams[b])
+                all_sharders[b].gather(ctx, p, frames[b], depths[b])
+        for s in range(4):
+            pipelined_step(s)
+        sync_all()
+        t1 = time.perf_counter()
+        for s in range(args.steps):
+            pipelined_step(s)
+        sync_all()
+        dtp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(dtp, op=dist.ReduceOp.MAX)
+        extra["pipelined"] = {"frames_in_flight": 2, "msamples_per_s": round(total_samples / float(dtp[0]) / 1e6, 2),
+                              "fps": round(args.steps / float(dtp[0]), 2)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
