@@ -101,6 +101,70 @@ def test_trace_samples_bit_exact(rig, az):
     assert np.array_equal(dt.cpu().numpy().view(np.uint32), dt_ref.view(np.uint32))
 
 
+def _trace_equal(rig, scene, p, n_pixels, max_samples):
+    torch = rig.torch
+    idx = np.arange(n_pixels, dtype=np.uint32)
+    t_ref, dt_ref, c_ref = scene.oracle_model.trace_samples(p, idx, max_samples)
+    t, dt, c = rig.testbed.trace_samples(p, torch.from_numpy(idx.astype(np.int32)).cuda(), max_samples)
+    assert np.array_equal(c.cpu().numpy().astype(np.uint32), c_ref)
+    assert np.array_equal(t.cpu().numpy().view(np.uint32), t_ref.view(np.uint32))
+    assert np.array_equal(dt.cpu().numpy().view(np.uint32), dt_ref.view(np.uint32))
+    return c_ref
+
+
+def test_trace_samples_bit_exact_at_1080p(rig):
+    """BASELINE's full size: all 2 073 600 rays of a 1920x1080 view, first 12 samples each.  This is the regression net of the
+    marching accelerator (occupied box, coarse mask look-ahead, lean walk, exact-mip bounds): any ray retired early, any
+    lattice point skipped or any hand-over at the wrong step changes a count or a bit."""
+    rig.use_edit(True)   # the edited occupancy: the arm is in a different place than in the plain scene
+    try:
+        p = rig.scene.params_for(1920, 1080, 75.0, snap=False, spp_index=2)
+        c = _trace_equal(rig, rig.scene, p, 1920 * 1080, 12)
+        assert (c > 0).sum() > 500000 and (c == 0).sum() > 500000
+    finally:
+        rig.use_edit(False)
+
+
+@pytest.mark.parametrize("case", ["cropped_render_box", "min_mip_1", "camera_inside", "single_cell", "empty"])
+def test_trace_samples_accelerator_corner_cases(rig, case):
+    """The shortcuts must hand over correctly when the render box is smaller than the occupied box, fall back to the general
+    bounds when min_mip != 0, cope with an origin inside the occupied region, a one-cell scene and an empty one."""
+    scene = rig.scene
+    rig.use_edit(False)
+    W, H = 480, 270
+    p = scene.params_for(W, H, 140.0, snap=False, spp_index=7)
+    bits = scene.bitfield
+    try:
+        if case == "cropped_render_box":
+            p.render_aabb_min[:] = [0.30, 0.25, 0.35]
+            p.render_aabb_max[:] = [0.70, 0.55, 0.62]
+        elif case == "min_mip_1":
+            p.min_mip = 1
+        elif case == "camera_inside":
+            cam = np.array(p.camera_matrix1[:], np.float32)
+            cam[9:12] = [0.5, 0.5, 0.5]
+            p.camera_matrix0[:] = [float(v) for v in cam]
+            p.camera_matrix1[:] = [float(v) for v in cam]
+        elif case == "single_cell":
+            bits = np.zeros_like(scene.bitfield)
+            from nerfshop_amd import synth
+            m = int(synth.morton3d(np.array([70], np.uint32), np.array([60], np.uint32), np.array([66], np.uint32))[0])
+            bits[m // 8] = 1 << (m % 8)
+        elif case == "empty":
+            bits = np.zeros_like(scene.bitfield)
+        rig.net.set_density_bitfield(bits)
+        scene.oracle_model.set_bitfield(bits)
+        c = _trace_equal(rig, scene, p, W * H, 24)
+        if case == "empty":
+            assert c.max() == 0
+        elif case == "single_cell":
+            assert 0 < (c > 0).sum() < 2000
+        else:
+            assert (c > 0).sum() > 5000
+    finally:
+        rig.use_edit(False)
+
+
 def test_map_rays_bit_exact(rig):
     torch = rig.torch
     e = rig.scene.edit
