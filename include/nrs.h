@@ -13,6 +13,7 @@
  *                               + shade_kernel_nerf                    src/testbed_nerf.cu:2448
  *   nrs_network_inference    <- NerfNetwork<T>::inference_mixed_precision   include/.../nerf_network_full.h:62
  *   nrs_network_density      <- NerfNetwork<T>::density                     include/.../nerf_network_full.h:223
+ *   nrs_density_on_grid / nrs_rgba_on_grid <- Testbed::get_density_on_grid / get_rgba_on_grid   src/testbed_nerf.cu:4538 / :4588  ("next" row f4)
  *   nrs_model_set_params     <- NerfNetwork<T>::set_params                  include/.../nerf_network_full.h:316
  *   nrs_model_set_density_grid <- Testbed::update_density_grid_mean_and_bitfield   src/testbed_nerf.cu:3642
  *   nrs_edit_create          <- TetMesh GPU members + upload                       tet_mesh.h:80-94, tet_mesh.cu:651-667
@@ -242,6 +243,17 @@ int nrs_network_inference(nrs_model* model, void* stream, uint32_t n, const floa
  * (nerf_network_full.h:231-236).  Output = the density MLP's 16 outputs (c 0 = density raw). */
 int nrs_network_density(nrs_model* model, void* stream, uint32_t n, const float* d_in, uint32_t ld_in,
                         void* d_out_fp16, uint32_t ld_out, int layout);
+/* The network on a regular grid ("next" row f4: the marching-cubes / volume-export callers of the operator).
+ * nrs_density_on_grid <- Testbed::get_density_on_grid (src/testbed_nerf.cu:4538): point (x,y,z) of the res3d grid sits at
+ *   aabb_min + (x/rx, y/ry, z/rz) * (aabb_max - aabb_min); d_out[x + y*rx + z*rx*ry] = raw density (fp16 network output as float),
+ *   or -10000 where the resident density grid is below NERF_MIN_OPTICAL_THICKNESS at that position (mask_with_density_grid != 0,
+ *   grid_samples_half_to_float :464).
+ * nrs_rgba_on_grid <- Testbed::get_rgba_on_grid (:4588): the grid spans the render box, every point is seen from ray_dir;
+ *   d_out_rgba[i] = (rgb * a, a), a = clamp(1 - exp(-density / 100), 0, 1)  (compute_nerf_density :624). */
+int nrs_density_on_grid(nrs_model* model, void* stream, const uint32_t res3d[3], const float aabb_min[3], const float aabb_max[3],
+                        int mask_with_density_grid, float* d_out);
+int nrs_rgba_on_grid(nrs_model* model, void* stream, const uint32_t res3d[3], const float render_aabb_min[3],
+                     const float render_aabb_max[3], const float ray_dir[3], float* d_out_rgba);
 /* hash-grid encoding alone (test hook; tcnn Encoding::inference_mixed_precision): d_out [n x 32] fp16 */
 int nrs_hashgrid_encode(nrs_model* model, void* stream, uint32_t n, const float* d_in, uint32_t ld_in,
                         void* d_out_fp16);

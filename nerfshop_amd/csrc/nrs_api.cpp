@@ -533,6 +533,25 @@ int nrs_network_density(nrs_model* m, void* stream, uint32_t n, const float* d_i
 	NRS_TRY(launch_network(m->dm, 1, n, d_in, ld_in, d_out, ld_out, layout, m->ctx->n_cus, stream));
 	return NRS_OK;
 }
+int nrs_density_on_grid(nrs_model* m, void* stream, const uint32_t res3d[3], const float aabb_min[3], const float aabb_max[3], int mask_with_density_grid,
+                        float* d_out) {
+	if (!m || !res3d || !aabb_min || !aabb_max || !d_out) return fail(NRS_ERR_INVALID_ARG, "nrs_density_on_grid: NULL argument");
+	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_density_on_grid: parameters not set (nrs_model_set_params)");
+	if ((uint64_t)res3d[0] * res3d[1] * res3d[2] > 0x7fffffffull) return fail(NRS_ERR_INVALID_ARG, "nrs_density_on_grid: more than 2^31 grid points");
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	NRS_TRY(launch_grid_eval(m->dm, 0, res3d, aabb_min, aabb_max, nullptr, mask_with_density_grid ? m->d_density_grid : nullptr, d_out, m->ctx->n_cus, stream));
+	return NRS_OK;
+}
+int nrs_rgba_on_grid(nrs_model* m, void* stream, const uint32_t res3d[3], const float render_aabb_min[3], const float render_aabb_max[3],
+                     const float ray_dir[3], float* d_out_rgba) {
+	if (!m || !res3d || !render_aabb_min || !render_aabb_max || !ray_dir || !d_out_rgba) return fail(NRS_ERR_INVALID_ARG, "nrs_rgba_on_grid: NULL argument");
+	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_rgba_on_grid: parameters not set (nrs_model_set_params)");
+	if ((uint64_t)res3d[0] * res3d[1] * res3d[2] > 0x7fffffffull) return fail(NRS_ERR_INVALID_ARG, "nrs_rgba_on_grid: more than 2^31 grid points");
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	const float dir01[3] = {(ray_dir[0] + 1.0f) * 0.5f, (ray_dir[1] + 1.0f) * 0.5f, (ray_dir[2] + 1.0f) * 0.5f}; // warp_direction, not normalised (tn:430)
+	NRS_TRY(launch_grid_eval(m->dm, 1, res3d, render_aabb_min, render_aabb_max, dir01, nullptr, d_out_rgba, m->ctx->n_cus, stream));
+	return NRS_OK;
+}
 int nrs_hashgrid_encode(nrs_model* m, void* stream, uint32_t n, const float* d_in, uint32_t ld_in, void* d_out) {
 	int s = check_net(m, d_in, d_out, "nrs_hashgrid_encode");
 	if (s != NRS_OK) return s;

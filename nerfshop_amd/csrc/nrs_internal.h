@@ -133,6 +133,8 @@ int launch_trace_samples(const DeviceModel& m, const nrs_render_params& p, uint3
 // mode 0: full inference (16 channels, c3 = density), 1: density MLP outputs, 2: hash-grid features [n x 32]
 int launch_network(const DeviceModel& m, int mode, uint32_t n, const float* d_in, uint32_t ld_in, void* d_out, uint32_t ld_out,
                    int layout, int n_cus, void* stream);
+int launch_grid_eval(const DeviceModel& m, int mode, const uint32_t res[3], const float box_mn[3], const float box_mx[3], const float dir01[3],
+                     const float* d_density_grid, float* d_out, int n_cus, void* stream);
 int launch_map_rays(const DeviceEdit& e, uint32_t n, float* d_coords, uint32_t ld, int with_dir, uint8_t* d_empty, void* stream);
 int launch_grid_to_bitfield(const float* d_grid, uint8_t* d_bitfield, float* d_scratch_mean, void* stream);
 // one iteration of update_density_grid_nerf_operator up to (not including) mean/bitfield; d_grid_tmp must be zeroed

@@ -530,6 +530,97 @@ int launch_network(const DeviceModel& m, int mode, uint32_t n, const float* d_in
 	return NRS_OK;
 }
 
+// ---- the network on a regular grid: Testbed::get_density_on_grid (tn:4538) / get_rgba_on_grid (tn:4588) ------------------------
+// MODE 0: raw density (row 0 of the density MLP) per grid point, -10000 where the density grid says "empty" (grid_samples_half_to_float,
+//         tn:464-481); MODE 1: premultiplied rgba for a fixed view direction (compute_nerf_density, tn:624-635).  The reference
+//         materialises the position array and runs the network in 2^20-point batches; here a lane generates its own point.
+struct GridEvalArgs {
+	uint32_t res[3];
+	float box_mn[3], box_mx[3];  // the box the grid spans (world units)
+	float dir01[3];              // MODE 1: warp_direction(ray_dir)
+	const float* density_grid;   // MODE 0: nullable
+	float* out;                  // MODE 0: float [n]; MODE 1: float4 [n]
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void grid_eval_kernel(const DeviceModel m, const GridEvalArgs a) {
+	__shared__ NetSmem sm;
+	stage_model_to_lds(m, sm.ml);
+	const int lane = threadIdx.x & 63;
+	const int g = lane >> 5, j = lane & 31;
+	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count);
+	const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+	const uint32_t n = a.res[0] * a.res[1] * a.res[2];
+	const uint32_t n_tiles = (n + 63) / 64;
+	const f3 wdir = mk3(a.dir01[0], a.dir01[1], a.dir01[2]);
+	for (uint32_t tile = wave_global; tile < n_tiles; tile += n_waves) {
+		const uint32_t s = tile * 64 + lane;
+		const bool have = s < n;
+		f3 pos = mk3(0, 0, 0), wpos = mk3(0, 0, 0);
+		if (have) { // generate_grid_samples_nerf_uniform(_dir), tn:406-431
+			const uint32_t x = s % a.res[0], y = (s / a.res[0]) % a.res[1], z = s / (a.res[0] * a.res[1]);
+			pos = mk3((float)x * (1.f / (float)a.res[0]), (float)y * (1.f / (float)a.res[1]), (float)z * (1.f / (float)a.res[2]));
+			pos = mk3(pos.x * (a.box_mx[0] - a.box_mn[0]) + a.box_mn[0], pos.y * (a.box_mx[1] - a.box_mn[1]) + a.box_mn[1],
+			          pos.z * (a.box_mx[2] - a.box_mn[2]) + a.box_mn[2]);
+			wpos = warp_position(pos, m.aabb);
+		}
+		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
+		const bool phave = __shfl_xor((int)have, 32, 64) != 0;
+		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, have, ppos, phave);
+		half8 sh;
+		if (MODE == 1) sh = encode_sh4(g, wdir);
+		uint32_t res_d = 0, res_rg = 0, res_b = 0;
+		#pragma unroll 1
+		for (int b = 0; b < 2; ++b) {
+			const int sel = (b != g) ? 1 : 0;
+			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
+			const half8 dout = density_mlp(sm.ml.w, lane, x0, x1);
+			half8 rout = dout;
+			if (MODE == 1) rout = rgb_mlp(sm.ml.w, lane, dout, sh);
+			const u32x4 dd = __builtin_bit_cast(u32x4, dout), rr = __builtin_bit_cast(u32x4, rout);
+			uint32_t vd = dd[0], vrg = rr[0], vb = rr[1]; // rows 0..2 of a block sit in lanes 0..31
+			if (b == 1) { vd = xchg32u(vd); vrg = xchg32u(vrg); vb = xchg32u(vb); }
+			if (g == b) { res_d = vd; res_rg = vrg; res_b = vb; }
+		}
+		if (!have) continue;
+		const float sigma_raw = (float)__builtin_bit_cast(half2v, res_d)[0];
+		if (MODE == 0) {
+			float v = sigma_raw;
+			if (a.density_grid) {
+				const f3 upos = unwarp_position(wpos, m.aabb);
+				const uint32_t mip = (uint32_t)mip_from_pos(upos);
+				if (a.density_grid[cascaded_grid_idx_at(upos, mip) + mip * kGridVol] < 0.01f) v = -10000.f; // NERF_MIN_OPTICAL_THICKNESS
+			}
+			a.out[s] = v;
+		} else {
+			const half2v hrg = __builtin_bit_cast(half2v, res_rg), hb = __builtin_bit_cast(half2v, res_b);
+			const float alpha = clampf_(1.f - __expf(-network_to_density(sigma_raw, m.density_activation) / 100.0f), 0.0f, 1.0f);
+			reinterpret_cast<float4*>(a.out)[s] = make_float4(network_to_rgb((float)hrg[0], m.rgb_activation) * alpha, network_to_rgb((float)hrg[1], m.rgb_activation) * alpha,
+			                                                   network_to_rgb((float)hb[0], m.rgb_activation) * alpha, alpha);
+		}
+	}
+	(void)j;
+}
+
+int launch_grid_eval(const DeviceModel& m, int mode, const uint32_t res[3], const float box_mn[3], const float box_mx[3], const float dir01[3],
+                     const float* d_density_grid, float* d_out, int n_cus, void* stream) {
+	GridEvalArgs a{};
+	for (int k = 0; k < 3; ++k) { a.res[k] = res[k]; a.box_mn[k] = box_mn[k]; a.box_mx[k] = box_mx[k]; a.dir01[k] = dir01 ? dir01[k] : 0.5f; }
+	a.density_grid = d_density_grid;
+	a.out = d_out;
+	const uint32_t n = res[0] * res[1] * res[2];
+	if (n == 0) return NRS_OK;
+	const uint32_t n_tiles = (n + 63) / 64;
+	uint32_t grid = (n_tiles + 3) / 4;
+	const uint32_t cap = (uint32_t)n_cus * 8;
+	if (grid > cap) grid = cap;
+	if (mode == 0) hipLaunchKernelGGL(grid_eval_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m, a);
+	else hipLaunchKernelGGL(grid_eval_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m, a);
+	NRS_LAUNCH_CHECK("grid_eval_kernel launch");
+	return NRS_OK;
+}
+
 // ---- EditOperator::map_rays / map_positions on caller batches --------------------------------------------------------------
 __global__ void map_rays_kernel(const DeviceEdit e, uint32_t n, float* __restrict__ coords, uint32_t ld, int with_dir, uint8_t* __restrict__ empty_mask) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

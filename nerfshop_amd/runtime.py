@@ -332,6 +332,23 @@ class Testbed:
         self.last_stats = stats
         return stats
 
+    def get_density_on_grid(self, res3d, aabb_min, aabb_max, mask_with_density_grid=True, stream=None):
+        """Testbed::get_density_on_grid(res3d, aabb) (testbed_nerf.cu:4538) -> float32 CUDA tensor [rz, ry, rx]"""
+        res = (C.c_uint32 * 3)(*[int(v) for v in res3d])
+        mn, mx = (C.c_float * 3)(*aabb_min), (C.c_float * 3)(*aabb_max)
+        out = torch.zeros((int(res3d[2]), int(res3d[1]), int(res3d[0])), dtype=torch.float32, device=f"cuda:{self.ctx.device}")
+        check(self.lib.nrs_density_on_grid(self.nerf_network.h, _stream_handle(stream), C.byref(res), C.byref(mn), C.byref(mx),
+                                           1 if mask_with_density_grid else 0, out.data_ptr()))
+        return out
+
+    def get_rgba_on_grid(self, res3d, ray_dir, stream=None):
+        """Testbed::get_rgba_on_grid(res3d, ray_dir) (testbed_nerf.cu:4588) over m_render_aabb -> float32 CUDA tensor [rz, ry, rx, 4]"""
+        res = (C.c_uint32 * 3)(*[int(v) for v in res3d])
+        mn, mx, rd = (C.c_float * 3)(*self.render_aabb[0]), (C.c_float * 3)(*self.render_aabb[1]), (C.c_float * 3)(*ray_dir)
+        out = torch.zeros((int(res3d[2]), int(res3d[1]), int(res3d[0]), 4), dtype=torch.float32, device=f"cuda:{self.ctx.device}")
+        check(self.lib.nrs_rgba_on_grid(self.nerf_network.h, _stream_handle(stream), C.byref(res), C.byref(mn), C.byref(mx), C.byref(rd), out.data_ptr()))
+        return out
+
     def new_grid_update(self, max_cascade=0, seed=1337, decay=0.95):
         """The Testbed members update_density_grid_nerf_operator reads: m_rng = default_rng_t{m_seed} (testbed.cu:2220),
         density_grid_ema_step = 0, density_grid_decay = 0.95 (testbed.h:604), sized as update_density_grid_nerf_render does."""

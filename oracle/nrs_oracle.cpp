@@ -1313,6 +1313,52 @@ void orc_network_density(void* model, uint32_t n, const float* in, uint32_t ld_i
 	}
 }
 
+// Testbed::get_density_on_grid (tn:4538-4586): generate_grid_samples_nerf_uniform (tn:406-417) -> density() -> grid_samples_half_to_float
+// (tn:464-481).  density_grid: float [5*128^3] or NULL (no masking).
+void orc_density_on_grid(void* model, const uint32_t* res, const float* box_mn, const float* box_mx, const float* density_grid, float* out) {
+	const Model& m = *(Model*)model;
+	const int64_t n = (int64_t)res[0] * res[1] * res[2];
+#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < n; ++i) {
+		const uint32_t x = (uint32_t)(i % res[0]), y = (uint32_t)((i / res[0]) % res[1]), z = (uint32_t)(i / ((int64_t)res[0] * res[1]));
+		V3 pos = {(float)x * (1.f / (float)res[0]), (float)y * (1.f / (float)res[1]), (float)z * (1.f / (float)res[2])};
+		pos = {pos.x * (box_mx[0] - box_mn[0]) + box_mn[0], pos.y * (box_mx[1] - box_mn[1]) + box_mn[1], pos.z * (box_mx[2] - box_mn[2]) + box_mn[2]};
+		const V3 w = warp_position(pos, m.aabb);
+		const float p[3] = {w.x, w.y, w.z};
+		uint16_t feat[32], o[16];
+		hashgrid_encode_one(m, p, feat);
+		density_mlp_one(m, feat, o);
+		float v = h2f(o[0]);
+		if (density_grid) {
+			const V3 up = unwarp_position(w, m.aabb);
+			const uint32_t mip = (uint32_t)mip_from_pos(up);
+			if (density_grid[cascaded_grid_idx_at(up, mip) + (size_t)mip * GRIDVOL] < 0.01f) v = -10000.f;
+		}
+		out[i] = v;
+	}
+}
+// Testbed::get_rgba_on_grid (tn:4588-4611): generate_grid_samples_nerf_uniform_dir (tn:419-431) -> inference() -> compute_nerf_density (tn:624-635)
+void orc_rgba_on_grid(void* model, const uint32_t* res, const float* box_mn, const float* box_mx, const float* ray_dir, float* out4) {
+	const Model& m = *(Model*)model;
+	const int64_t n = (int64_t)res[0] * res[1] * res[2];
+	const V3 wd = warp_direction(v3(ray_dir[0], ray_dir[1], ray_dir[2]));
+#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < n; ++i) {
+		const uint32_t x = (uint32_t)(i % res[0]), y = (uint32_t)((i / res[0]) % res[1]), z = (uint32_t)(i / ((int64_t)res[0] * res[1]));
+		V3 pos = {(float)x * (1.f / (float)res[0]), (float)y * (1.f / (float)res[1]), (float)z * (1.f / (float)res[2])};
+		pos = {pos.x * (box_mx[0] - box_mn[0]) + box_mn[0], pos.y * (box_mx[1] - box_mn[1]) + box_mn[1], pos.z * (box_mx[2] - box_mn[2]) + box_mn[2]};
+		const V3 w = warp_position(pos, m.aabb);
+		const float in7[7] = {w.x, w.y, w.z, warp_dt(MIN_STEP), wd.x, wd.y, wd.z};
+		uint16_t o[16];
+		network_inference_one(m, in7, o);
+		const float a = clampf(1.f - expf(-network_to_density(h2f(o[3]), m.desc.density_activation) / 100.0f), 0.0f, 1.0f);
+		out4[4 * i] = network_to_rgb(h2f(o[0]), m.desc.rgb_activation) * a;
+		out4[4 * i + 1] = network_to_rgb(h2f(o[1]), m.desc.rgb_activation) * a;
+		out4[4 * i + 2] = network_to_rgb(h2f(o[2]), m.desc.rgb_activation) * a;
+		out4[4 * i + 3] = a;
+	}
+}
+
 void* orc_edit_create(const nrs_model_desc* d, const nrs_tet_mesh* mesh) {
 	Edit* e = new Edit();
 	e->aabb = Box{v3(d->aabb_min[0], d->aabb_min[1], d->aabb_min[2]), v3(d->aabb_max[0], d->aabb_max[1], d->aabb_max[2])};

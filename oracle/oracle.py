@@ -56,6 +56,7 @@ def load():
         "orc_pcg32_seed": (None, [C.c_uint64, P, P]), "orc_pcg32_next_uint": (U32, [P, C.c_uint64]),
         "orc_pcg32_next_float": (F, [P, C.c_uint64]), "orc_pcg32_advance": (None, [P, C.c_uint64, C.c_uint64]),
         "orc_update_density_grid": (None, [P, P, I, P, P, P]),
+        "orc_density_on_grid": (None, [P, P, P, P, P, P]), "orc_rgba_on_grid": (None, [P, P, P, P, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -114,6 +115,21 @@ class Model:
         self.lib.orc_update_density_grid(self.h, arr, len(edits), grid.ctypes.data, bits.ctypes.data, C.byref(update))
         self.set_bitfield(bits)
         return bits
+
+    def density_on_grid(self, res3d, box_min, box_max, density_grid=None):
+        res = (C.c_uint32 * 3)(*res3d)
+        mn, mx = (C.c_float * 3)(*box_min), (C.c_float * 3)(*box_max)
+        out = np.zeros(int(res3d[0]) * int(res3d[1]) * int(res3d[2]), np.float32)
+        g = np.ascontiguousarray(density_grid, np.float32) if density_grid is not None else None
+        self.lib.orc_density_on_grid(self.h, res, mn, mx, g.ctypes.data if g is not None else None, out.ctypes.data)
+        return out
+
+    def rgba_on_grid(self, res3d, box_min, box_max, ray_dir):
+        res = (C.c_uint32 * 3)(*res3d)
+        mn, mx, rd = (C.c_float * 3)(*box_min), (C.c_float * 3)(*box_max), (C.c_float * 3)(*ray_dir)
+        out = np.zeros((int(res3d[0]) * int(res3d[1]) * int(res3d[2]), 4), np.float32)
+        self.lib.orc_rgba_on_grid(self.h, res, mn, mx, rd, out.ctypes.data)
+        return out
 
     def trace_samples(self, params, pixel_idx, max_samples):
         pixel_idx = np.ascontiguousarray(pixel_idx, np.uint32)

@@ -174,3 +174,32 @@ def test_grid_refresh_errors(rig_shaped):
     u.max_cascade = 5
     with pytest.raises(NrsError):
         tb.update_density_grid_nerf_operator(u)
+
+
+def test_density_and_rgba_on_grid(rig_shaped):
+    """Testbed::get_density_on_grid / get_rgba_on_grid (testbed_nerf.cu:4538 / :4588) against the oracle: the grid point
+    positions are integer / order-controlled fp32 (so the density-grid mask is bit-exact: the same cells become -10000); the
+    network values carry the network tolerance (<= 2 fp16 ulps of the raw outputs)."""
+    rig, scene = rig_shaped, rig_shaped.scene
+    tb = rig.testbed
+    grid = scene.grid
+    rig.net.set_density_grid(grid)
+    try:
+        res = (48, 40, 33)   # ragged on purpose (not multiples of 64)
+        mn, mx = (0.1, 0.15, 0.2), (0.9, 0.8, 0.85)
+        got = tb.get_density_on_grid(res, mn, mx).cpu().numpy().reshape(-1)
+        ref = scene.oracle_model.density_on_grid(res, mn, mx, grid)
+        assert np.array_equal(got == -10000.0, ref == -10000.0)
+        live = ref != -10000.0
+        assert 1000 < live.sum() < live.size
+        ulp = np.maximum(np.abs(ref[live]), 2.0 ** -14) * 2.0 ** -10
+        assert (np.abs(got[live] - ref[live]) <= 2 * ulp).all()
+        assert (got[live] == ref[live]).mean() > 0.97
+        unmasked = tb.get_density_on_grid(res, mn, mx, mask_with_density_grid=False).cpu().numpy().reshape(-1)
+        assert (unmasked != -10000.0).all() and np.array_equal(unmasked[live], got[live])
+        rgba = tb.get_rgba_on_grid((32, 32, 32), (0.3, -0.5, 0.8)).cpu().numpy().reshape(-1, 4)
+        ref_rgba = scene.oracle_model.rgba_on_grid((32, 32, 32), tb.render_aabb[0], tb.render_aabb[1], (0.3, -0.5, 0.8))
+        assert np.abs(rgba - ref_rgba).max() < 4e-3
+        assert rgba[:, 3].max() > 0.5 and rgba[:, 3].min() < 1e-3      # solid inside, (almost) nothing outside
+    finally:
+        rig.use_edit(False)
