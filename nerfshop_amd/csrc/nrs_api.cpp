@@ -314,10 +314,14 @@ int nrs_ctx_create(int device, nrs_ctx** out) {
 	c->n_cus = prop.multiProcessorCount;
 	c->hbm_bytes = prop.totalGlobalMem;
 	snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
-	HIP_TRY(hipMalloc((void**)&c->d_counters, sizeof(RenderCounters) * nrs_ctx::kInFlight));
-	HIP_TRY(hipMalloc((void**)&c->d_edits, sizeof(DeviceEdit) * nrs_ctx::kMaxEdits * nrs_ctx::kInFlight));
-	HIP_TRY(hipMalloc((void**)&c->d_mean, 8 + 256 * 8)); // mean + partial sums (launch_grid_to_bitfield)
-	HIP_TRY(hipMalloc((void**)&c->d_wave_log, 8192 * 4 * 8));
+	hipError_t he = hipMalloc((void**)&c->d_counters, sizeof(RenderCounters) * nrs_ctx::kInFlight);
+	if (he == hipSuccess) he = hipMalloc((void**)&c->d_edits, sizeof(DeviceEdit) * nrs_ctx::kMaxEdits * nrs_ctx::kInFlight);
+	if (he == hipSuccess) he = hipMalloc((void**)&c->d_mean, 8 + 256 * 8); // mean + partial sums (launch_grid_to_bitfield)
+	if (he == hipSuccess) he = hipMalloc((void**)&c->d_wave_log, 8192 * 4 * 8);
+	if (he != hipSuccess) {
+		nrs_ctx_destroy(c);
+		return fail_hip(he, "nrs_ctx_create: hipMalloc");
+	}
 	*out = c;
 	return NRS_OK;
 }
@@ -378,13 +382,17 @@ int nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out) 
 	}
 	m->dm.rgb_activation = desc->rgb_activation;
 	m->dm.density_activation = desc->density_activation;
-	HIP_TRY(hipMalloc((void**)&m->d_grid, (size_t)m->total_entries * 4));
-	HIP_TRY(hipMalloc((void**)&m->d_wfrag, kWfragBytes));
-	HIP_TRY(hipMalloc((void**)&m->d_bitfield, NRS_BITFIELD_BYTES));
-	HIP_TRY(hipMalloc((void**)&m->d_accel_masks, 2 * kCoarseWords * 4));
-	HIP_TRY(hipMemset(m->d_accel_masks, 0, 2 * kCoarseWords * 4));
-	HIP_TRY(hipMalloc((void**)&m->d_density_grid, (size_t)kGridVol * kCascades * 4));
-	HIP_TRY(hipMemset(m->d_density_grid, 0, (size_t)kGridVol * kCascades * 4));
+	hipError_t he = hipMalloc((void**)&m->d_grid, (size_t)m->total_entries * 4);
+	if (he == hipSuccess) he = hipMalloc((void**)&m->d_wfrag, kWfragBytes);
+	if (he == hipSuccess) he = hipMalloc((void**)&m->d_bitfield, NRS_BITFIELD_BYTES);
+	if (he == hipSuccess) he = hipMalloc((void**)&m->d_accel_masks, 2 * kCoarseWords * 4);
+	if (he == hipSuccess) he = hipMemset(m->d_accel_masks, 0, 2 * kCoarseWords * 4);
+	if (he == hipSuccess) he = hipMalloc((void**)&m->d_density_grid, (size_t)kGridVol * kCascades * 4);
+	if (he == hipSuccess) he = hipMemset(m->d_density_grid, 0, (size_t)kGridVol * kCascades * 4);
+	if (he != hipSuccess) {
+		nrs_model_destroy(m);
+		return fail_hip(he, "nrs_model_create: device allocation");
+	}
 	m->dm.grid = m->d_grid;
 	m->dm.wfrag = m->d_wfrag;
 	m->dm.bitfield = m->d_bitfield;
