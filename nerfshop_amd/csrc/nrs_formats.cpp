@@ -275,6 +275,7 @@ std::string maybe_inflate(const std::string& in) {
 		rc = inflate(&zs, Z_NO_FLUSH);
 		if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); throw std::runtime_error("zlib: corrupt stream"); }
 		out.append(buf.data(), buf.size() - zs.avail_out);
+		if (out.size() > (size_t)8 << 30) { inflateEnd(&zs); throw std::runtime_error("zlib: stream inflates to more than 8 GiB"); }
 	}
 	inflateEnd(&zs);
 	if (rc != Z_STREAM_END) throw std::runtime_error("zlib: truncated stream");

@@ -129,3 +129,54 @@ def test_affine_edit_round_trip(built, tmp_path):
     path.write_text(json.dumps(doc))
     with pytest.raises(_abi.NrsError):
         formats.load_edits(path)
+
+
+def test_readers_survive_corrupt_input(built, tmp_path):
+    """The readers parse files from disk: truncations and random byte flips must end in NrsError (or a clean load), never in a crash."""
+    import msgpack
+    import zlib
+    desc = synth.model_desc(1)
+    cfg = formats.network_config(desc)
+    cfg["snapshot"] = {"density_grid_size": 128, "params_type": "__half", "params_binary": b"\x00" * 64, "n_params": 32,
+                       "density_grid_binary": b"\x00" * 128, "nerf": {"aabb_scale": 1, "rgb": {"rays_per_batch": 4096}},
+                       "camera": {"matrix": [[1.0, 0.0, 0.0, 0.5], [0.0, 1.0, 0.0, 0.5], [0.0, 0.0, 1.0, 0.5]]}}
+    blob = msgpack.packb(cfg, use_bin_type=True)
+    rng = np.random.default_rng(11)
+    path = tmp_path / "fuzz.msgpack"
+    n_err = 0
+    variants = [blob[:k] for k in range(0, len(blob), 7)]
+    for _ in range(300):
+        b = bytearray(blob)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        variants.append(bytes(b))
+    variants.append(b"\xdd\xff\xff\xff\xff")                 # array32 announcing 4 G elements
+    variants.append(b"\xc6\xff\xff\xff\xff" + b"x" * 10)      # bin32 longer than the file
+    variants.append(b"\x91" * 200)                               # nesting bomb
+    variants.append(zlib.compress(blob)[:-5])                     # truncated zlib stream
+    variants.append(b"\x78\x9c" + b"\x00" * 50)                 # zlib header, garbage body
+    for v in variants:
+        path.write_bytes(v)
+        try:
+            formats.load_snapshot(path)
+        except _abi.NrsError:
+            n_err += 1
+    assert n_err >= len(variants) - 5      # (the params blob is deliberately the wrong size: essentially everything must be refused)
+    jpath = tmp_path / "fuzz.json"
+    good = json.dumps({"edit_operators": [{"type": "affine_duplication", "selection_box": {"center": [0, 0, 0], "scale": [1, 1, 1],
+                       "rot_matrix": [[1, 0, 0], [0, 1, 0], [0, 0, 1]]}, "translation": [0, 0, 0], "scale": [1, 1, 1],
+                       "rotation_matrix": [[1, 0, 0], [0, 1, 0], [0, 0, 1]], "hide_original": False, "correct_dir": True}]})
+    jpath.write_text(good)
+    assert len(formats.load_edits(jpath)) == 1
+    for k in range(0, len(good), 3):
+        jpath.write_text(good[:k])
+        with pytest.raises(_abi.NrsError):
+            formats.load_edits(jpath)
+    for _ in range(200):
+        b = bytearray(good.encode())
+        b[int(rng.integers(0, len(b)))] = int(rng.integers(32, 127))
+        jpath.write_bytes(bytes(b))
+        try:
+            formats.load_edits(jpath)
+        except _abi.NrsError:
+            pass
