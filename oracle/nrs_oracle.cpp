@@ -9,7 +9,10 @@
  * PARITY UNPINNED: the reference ships no tests, golden vectors, fixtures or snapshots for this path
  * (SURVEY.md F3, 8c), its hash-grid / fully-fused-MLP / SH arithmetic lives in tiny-cuda-nn, an EMPTY,
  * un-pinned submodule (fork gitlab.inria.fr/cjambon/tcnn-pyngp, branch pyngp-api, .gitmodules:16-19), and
- * the reference cannot be compiled here (needs nvcc, Eigen, tcnn, GLFW...).  What IS pinned: the Sobol
+ * the reference cannot be compiled here (needs nvcc, Eigen, tcnn, GLFW...).  What IS pinned: the mean-value-coordinate
+ * routine -- the one piece of the reference that compiles from its own sources (editing/tools/mvc.h -> oracle/_ref/libref_mvc.so,
+ * oracle/ref_mvc.cpp; mvc_compute below reproduces its weights bit for bit on tests/golden/ref_mvc_golden.npz) --, pcg32 against
+ * the PCG library's published demo vector, the Sobol
  * direction numbers / scramble (tests/golden/sobol_golden.json is generated from the reference's own
  * table in include/neural-graphics-primitives/random_val.cuh by tests/golden/make_sobol_golden.py) and
  * hand-derived known-answer values for the in-tree formulas.  The tcnn parts restate upstream

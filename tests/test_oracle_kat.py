@@ -296,3 +296,27 @@ def test_occupancy_refresh_oracle_properties(built):
     assert gained.sum() > 500 and lost.sum() > 500
     assert (gained & ~moved_ref).sum() < 0.1 * gained.sum()            # new cells lie where the analytic deformed solid is
     sc.oracle_model.set_bitfield(sc.bitfield)
+
+
+def test_mvc_pinned_to_the_reference_code(built):
+    """The one piece of the reference that compiles from its own sources here: MVC3D::computeCoordinatesCustomCode
+    (include/neural-graphics-primitives/editing/tools/mvc.h), built as oracle/_ref/libref_mvc.so (oracle/ref_mvc.cpp) and run
+    on the test cage by tests/golden/make_ref_mvc_golden.py.  Oracle and product reproduce its weights (550 points incl. cage
+    vertices, points on cage faces, points outside the cage) and its success labels."""
+    import os
+    from nerfshop_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = np.load(os.path.join(root, "tests", "golden", "ref_mvc_golden.npz"))
+    for name, fn in (("oracle", orc.mvc_compute), ("product", synth.mvc_weights)):
+        w, labels = fn(g["cage_vertices"], g["cage_triangles"], g["points"])
+        assert np.array_equal(labels, g["labels"]), name
+        assert np.abs(w - g["weights"]).max() <= 1e-6, (name, np.abs(w - g["weights"]).max())
+    assert sorted(np.bincount(g["labels"]).tolist()) == [3, 547]
+    ref_lib = os.path.join(root, "oracle", "_ref", "libref_mvc.so")
+    if os.path.exists(ref_lib):   # this container: the fixture is what the reference code produces today
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("make_ref_mvc_golden", os.path.join(root, "tests", "golden", "make_ref_mvc_golden.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        w, labels = mod.ref_mvc(g["cage_vertices"], g["cage_triangles"], g["points"])
+        assert np.array_equal(w, g["weights"]) and np.array_equal(labels, g["labels"])
