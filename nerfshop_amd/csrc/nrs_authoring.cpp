@@ -6,7 +6,7 @@
 //   nrs_tet_lut_build        TetMesh::build_tet_grid / build_original_tet_grid   src/editing/datastructures/tet_mesh.cu:368 / :76
 //   nrs_mvc_compute / apply  Cage::compute_mvc / interpolate_with_mvc            src/editing/datastructures/cage.cu:6 / :38,
 //                            MVC3D::computeCoordinatesCustomCode                 include/.../editing/tools/mvc.h:125-188
-//   nrs_tet_local_rotations  TetMesh::update_local_rotations                     tet_mesh.cu:37-74
+//   nrs_tet_local_rotations  TetMesh::update_local_rotations (svd3.h numerics)    tet_mesh.cu:37-74, nrs_svd3.h
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "nrs_internal.h"
+#include "nrs_svd3.h"
 
 using namespace nrs;
 
@@ -276,58 +277,14 @@ int nrs_mvc_apply(const float* h_weights, const float* h_cage_vertices, uint32_t
 	return NRS_OK;
 }
 
-// Polar rotation of a 3x3 correlation matrix by Higham's scaled Newton iteration on the polar factor (double).
-// For C = U S V^T the orthogonal polar factor is U V^T -- exactly the R the reference forms from its approximate SVD
-// (tet_mesh.cu:66-70); degenerate (rank-deficient) C falls back to the identity.
-static void polar_rotation(const double C[9], double R[9]) {
-	double X[9];
-	memcpy(X, C, sizeof(X));
-	auto det3 = [](const double* m) {
-		return m[0] * (m[4] * m[8] - m[7] * m[5]) - m[3] * (m[1] * m[8] - m[7] * m[2]) + m[6] * (m[1] * m[5] - m[4] * m[2]);
-	};
-	for (int it = 0; it < 100; ++it) {
-		const double d = det3(X);
-		if (std::fabs(d) < 1e-300) { // singular: no unique rotation
-			for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
-			return;
-		}
-		double inv_t[9]; // inverse transpose = cofactor / det (column-major indices m[3*col + row])
-		inv_t[0] = (X[4] * X[8] - X[7] * X[5]) / d; inv_t[3] = (X[7] * X[2] - X[1] * X[8]) / d; inv_t[6] = (X[1] * X[5] - X[4] * X[2]) / d;
-		inv_t[1] = (X[6] * X[5] - X[3] * X[8]) / d; inv_t[4] = (X[0] * X[8] - X[6] * X[2]) / d; inv_t[7] = (X[3] * X[2] - X[0] * X[5]) / d;
-		inv_t[2] = (X[3] * X[7] - X[6] * X[4]) / d; inv_t[5] = (X[6] * X[1] - X[0] * X[7]) / d; inv_t[8] = (X[0] * X[4] - X[3] * X[1]) / d;
-		double nx = 0, ni = 0;
-		for (int i = 0; i < 9; ++i) { nx += X[i] * X[i]; ni += inv_t[i] * inv_t[i]; }
-		const double gamma = std::sqrt(std::sqrt(ni / nx));
-		double diff = 0;
-		for (int i = 0; i < 9; ++i) {
-			const double nv = 0.5 * (gamma * X[i] + inv_t[i] / gamma);
-			diff = std::max(diff, std::fabs(nv - X[i]));
-			X[i] = nv;
-		}
-		if (diff < 1e-14) break;
-	}
-	memcpy(R, X, sizeof(X));
-}
-
+// TetMesh::update_local_rotations (tet_mesh.cu:37-74) with the reference's approximate SVD, see nrs_svd3.h
 int nrs_tet_local_rotations(const float* h_vertices, const float* h_original_vertices, const uint32_t* h_tets, uint32_t n_tets, float* h_out) {
 	if (!h_vertices || !h_original_vertices || !h_tets || !h_out) return NRS_ERR_INVALID_ARG;
-	const P3* def = reinterpret_cast<const P3*>(h_vertices);
-	const P3* org = reinterpret_cast<const P3*>(h_original_vertices);
 	for (uint32_t i = 0; i < n_tets; ++i) {
-		P3 c0 = {0, 0, 0}, c1 = {0, 0, 0};
-		for (int j = 0; j < 4; ++j) { c0 = add(c0, org[h_tets[4 * i + j]]); c1 = add(c1, def[h_tets[4 * i + j]]); }
-		c0 = {c0.x / 4.f, c0.y / 4.f, c0.z / 4.f};
-		c1 = {c1.x / 4.f, c1.y / 4.f, c1.z / 4.f};
-		double C[9] = {0};
-		for (int j = 0; j < 4; ++j) {
-			const P3 a = sub(org[h_tets[4 * i + j]], c0), b = sub(def[h_tets[4 * i + j]], c1);
-			const float av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
-			for (int r = 0; r < 3; ++r)
-				for (int c = 0; c < 3; ++c) C[3 * c + r] += (double)(av[r] * bv[c]);
-		}
-		double R[9];
-		polar_rotation(C, R);
-		for (int k = 0; k < 9; ++k) h_out[9 * (size_t)i + k] = (float)R[k];
+		float o[4][3], d[4][3];
+		for (int j = 0; j < 4; ++j)
+			for (int k = 0; k < 3; ++k) { o[j][k] = h_original_vertices[3 * h_tets[4 * i + j] + k]; d[j][k] = h_vertices[3 * h_tets[4 * i + j] + k]; }
+		svd3::tet_rotation(o, d, h_out + 9 * (size_t)i);
 	}
 	return NRS_OK;
 }

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include "nrs_internal.h"
 #include "nrs_device.cuh"
+#include "nrs_svd3.h"
 
 namespace nrs {
 
@@ -313,54 +314,19 @@ __global__ __launch_bounds__(1024) void lut_sort_big_kernel(const uint32_t* __re
 	}
 }
 
-// ---- TetMesh::update_local_rotations (tet_mesh.cu:37-74): R = polar factor of sum (orig - c0)(def - c1)^T ---------------------
-// Higham's scaled Newton iteration in double, the same sequence of operations as nrs_authoring.cpp's polar_rotation.
-__device__ void polar_rotation(const double C[9], double R[9]) {
-	double X[9];
-	for (int i = 0; i < 9; ++i) X[i] = C[i];
-	for (int it = 0; it < 100; ++it) {
-		const double d = X[0] * (X[4] * X[8] - X[7] * X[5]) - X[3] * (X[1] * X[8] - X[7] * X[2]) + X[6] * (X[1] * X[5] - X[4] * X[2]);
-		if (fabs(d) < 1e-300) {
-			for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
-			return;
-		}
-		double inv_t[9];
-		inv_t[0] = (X[4] * X[8] - X[7] * X[5]) / d; inv_t[3] = (X[7] * X[2] - X[1] * X[8]) / d; inv_t[6] = (X[1] * X[5] - X[4] * X[2]) / d;
-		inv_t[1] = (X[6] * X[5] - X[3] * X[8]) / d; inv_t[4] = (X[0] * X[8] - X[6] * X[2]) / d; inv_t[7] = (X[3] * X[2] - X[0] * X[5]) / d;
-		inv_t[2] = (X[3] * X[7] - X[6] * X[4]) / d; inv_t[5] = (X[6] * X[1] - X[0] * X[7]) / d; inv_t[8] = (X[0] * X[4] - X[3] * X[1]) / d;
-		double nx = 0, ni = 0;
-		for (int i = 0; i < 9; ++i) { nx += X[i] * X[i]; ni += inv_t[i] * inv_t[i]; }
-		const double gamma = sqrt(sqrt(ni / nx));
-		double diff = 0;
-		for (int i = 0; i < 9; ++i) {
-			const double nv = 0.5 * (gamma * X[i] + inv_t[i] / gamma);
-			diff = fmax(diff, fabs(nv - X[i]));
-			X[i] = nv;
-		}
-		if (diff < 1e-14) break;
-	}
-	for (int i = 0; i < 9; ++i) R[i] = X[i];
-}
+// ---- TetMesh::update_local_rotations (tet_mesh.cu:37-74): R = U V^T from the reference's approximate SVD (nrs_svd3.h) -------------
 __global__ void local_rotations_kernel(uint32_t n_tets, const float* __restrict__ def, const float* __restrict__ org,
                                        const uint32_t* __restrict__ tets, float* __restrict__ out) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_tets) return;
 	const uint4 tv = reinterpret_cast<const uint4*>(tets)[i];
 	const uint32_t id[4] = {tv.x, tv.y, tv.z, tv.w};
-	f3 c0 = mk3(0, 0, 0), c1 = mk3(0, 0, 0);
-	for (int j = 0; j < 4; ++j) { c0 = c0 + ld3(org, id[j]); c1 = c1 + ld3(def, id[j]); }
-	c0 = {c0.x / 4.f, c0.y / 4.f, c0.z / 4.f};
-	c1 = {c1.x / 4.f, c1.y / 4.f, c1.z / 4.f};
-	double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-	for (int j = 0; j < 4; ++j) {
-		const f3 a = ld3(org, id[j]) - c0, b = ld3(def, id[j]) - c1;
-		const float av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
-		for (int r = 0; r < 3; ++r)
-			for (int c = 0; c < 3; ++c) C[3 * c + r] += (double)(av[r] * bv[c]);
-	}
-	double R[9];
-	polar_rotation(C, R);
-	for (int k = 0; k < 9; ++k) out[9 * (size_t)i + k] = (float)R[k];
+	float o[4][3], d[4][3];
+	for (int j = 0; j < 4; ++j)
+		for (int k = 0; k < 3; ++k) { o[j][k] = org[3 * id[j] + k]; d[j][k] = def[3 * id[j] + k]; }
+	float R[9];
+	svd3::tet_rotation(o, d, R);
+	for (int k = 0; k < 9; ++k) out[9 * (size_t)i + k] = R[k];
 }
 
 // ---- per-tet face planes for point_in_tet_planes (nrs_device.cuh): the tet-only half of same_side_tet, selection_utils.h:33-39 ----

@@ -11,7 +11,8 @@
  * un-pinned submodule (fork gitlab.inria.fr/cjambon/tcnn-pyngp, branch pyngp-api, .gitmodules:16-19), and
  * the reference cannot be compiled here (needs nvcc, Eigen, tcnn, GLFW...).  What IS pinned: the mean-value-coordinate
  * routine -- the one piece of the reference that compiles from its own sources (editing/tools/mvc.h -> oracle/_ref/libref_mvc.so,
- * oracle/ref_mvc.cpp; mvc_compute below reproduces its weights bit for bit on tests/golden/ref_mvc_golden.npz) --, pcg32 against
+ * oracle/ref_mvc.cpp; mvc_compute below reproduces its weights bit for bit on tests/golden/ref_mvc_golden.npz) -- and the 3x3 SVD
+ * behind the per-tet rotations (editing/tools/svd3.h -> oracle/_ref/libref_svd.so; tests/golden/ref_rotations_golden.npz) --, pcg32 against
  * the PCG library's published demo vector, the Sobol
  * direction numbers / scramble (tests/golden/sobol_golden.json is generated from the reference's own
  * table in include/neural-graphics-primitives/random_val.cuh by tests/golden/make_sobol_golden.py) and
@@ -1165,45 +1166,121 @@ bool mvc_one(V3 eta, const uint32_t* tris, uint32_t n_tris, const V3* cv, uint32
 	return false;
 }
 
-// 3x3 SVD via one-sided Jacobi in double (the reference uses the approximate McAdams SVD, svd3.h:405-420;
-// R is compared with tolerance 1e-4).  A = U S V^T, column-major 3x3 arrays.
-void svd3(const double A[9], double U[9], double S[3], double V[9]) {
-	double B[9];
-	memcpy(B, A, sizeof(B)); // columns of B get orthogonalised: B = A V
-	for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
-	for (int sweep = 0; sweep < 60; ++sweep) {
-		double off = 0.0;
-		for (int p = 0; p < 2; ++p)
-			for (int q = p + 1; q < 3; ++q) {
-				double alpha = 0, beta = 0, gamma = 0;
-				for (int k = 0; k < 3; ++k) { alpha += B[3 * p + k] * B[3 * p + k]; beta += B[3 * q + k] * B[3 * q + k]; gamma += B[3 * p + k] * B[3 * q + k]; }
-				off = std::max(off, fabs(gamma) / (sqrt(alpha * beta) + 1e-300));
-				if (fabs(gamma) < 1e-300) continue;
-				double zeta = (beta - alpha) / (2.0 * gamma);
-				double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-				double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
-				for (int k = 0; k < 3; ++k) {
-					double bp = B[3 * p + k], bq = B[3 * q + k];
-					B[3 * p + k] = cs * bp - sn * bq; B[3 * q + k] = sn * bp + cs * bq;
-					double vp = V[3 * p + k], vq = V[3 * q + k];
-					V[3 * p + k] = cs * vp - sn * vq; V[3 * q + k] = sn * vp + cs * vq;
-				}
-			}
-		if (off < 1e-15) break;
+// The reference's 3x3 SVD (svd3.h: McAdams/Selle/Tamstorf/Teran/Sifakis TR1690, implementation by E. Jang), restated in
+// fp32 with its operation order: four cyclic Jacobi sweeps with approximate Givens rotations on A^T A (quaternion
+// accumulation), column sort with sign flips, QR by three Givens rotations.  Inexact by design: U V^T is up to 1.3e-2 away
+// from the exact polar factor on ordinary tets, which is why it is restated rather than replaced.  Pinned bit for bit by
+// tests/golden/ref_rotations_golden.npz (the reference header itself, oracle/ref_svd.cpp).  Matrices are row-major [r][c].
+struct Quat { float x, y, z, w; };
+inline float ref_rsqrt(float x) { return 1.0f / sqrtf(x); }            // rsqrt(float) of nvcc's host math
+inline float ref_rsqrt1(float x) {                                    // svd3.h:54-63
+	float xhalf = 0.5f * x;
+	int32_t i = (int32_t)f2u(x);
+	i = 0x5f37599e - (i >> 1);
+	x = u2f((uint32_t)i);
+	x = x * (1.5f - xhalf * x * x);
+	x = x * (1.5f - xhalf * x * x);
+	return x;
+}
+// jacobiConjugation (svd3.h:165-213) for the pivot whose quaternion component is `zc` (and x/y components xc/yc);
+// sym = {s11, s21, s22, s31, s32, s33}
+inline void jacobi_conjugation(int xc, int yc, int zc, float sym[6], float q[4]) {
+	float s11 = sym[0], s21 = sym[1], s22 = sym[2], s31 = sym[3], s32 = sym[4], s33 = sym[5];
+	float ch = 2 * (s11 - s22);                                        // approximateGivensQuaternion, :147-163
+	float sh = s21;
+	bool b = 5.828427124 * sh * sh < ch * ch;
+	float w = ref_rsqrt(ch * ch + sh * sh);
+	ch = b ? w * ch : (float)0.923879532;
+	sh = b ? w * sh : (float)0.3826834323;
+	float scale = ch * ch + sh * sh;
+	float a = (ch * ch - sh * sh) / scale;
+	float bb = (2 * sh * ch) / scale;
+	float o11 = a * (a * s11 + bb * s21) + bb * (a * s21 + bb * s22);
+	float o21 = a * (-bb * s11 + a * s21) + bb * (-bb * s21 + a * s22);
+	float o22 = -bb * (-bb * s11 + a * s21) + a * (-bb * s21 + a * s22);
+	float o31 = a * s31 + bb * s32;
+	float o32 = -bb * s31 + a * s32;
+	float o33 = s33;
+	float tmp0 = q[0] * sh, tmp1 = q[1] * sh, tmp2 = q[2] * sh;
+	float tmp[3] = {tmp0, tmp1, tmp2};
+	sh *= q[3];
+	q[0] *= ch; q[1] *= ch; q[2] *= ch; q[3] *= ch;
+	q[zc] += sh;
+	q[3] -= tmp[zc];
+	q[xc] += tmp[yc];
+	q[yc] -= tmp[xc];
+	sym[0] = o22; sym[1] = o32; sym[2] = o33; sym[3] = o21; sym[4] = o31; sym[5] = o11; // re-arranged for the next pivot
+}
+inline void qr_givens_quaternion(float a1, float a2, float& ch, float& sh) { // svd3.h:270-285
+	float epsilon = (float)1e-6;
+	float sq = a1 * a1 + a2 * a2;
+	float rho = sq * ref_rsqrt1(sq);
+	sh = rho > epsilon ? a2 : 0;
+	ch = fabsf(a1) + fmaxf(rho, epsilon);
+	if (a1 < 0) std::swap(sh, ch);
+	float w = ref_rsqrt(ch * ch + sh * sh);
+	ch *= w;
+	sh *= w;
+}
+// U, V of svd(A) (svd3.h:355-403)
+void ref_svd_uv(const float A[3][3], float U[3][3], float V[3][3]) {
+	float sym[6] = {
+		A[0][0] * A[0][0] + A[1][0] * A[1][0] + A[2][0] * A[2][0],   // (A^T A)11
+		A[0][1] * A[0][0] + A[1][1] * A[1][0] + A[2][1] * A[2][0],   // 21
+		A[0][1] * A[0][1] + A[1][1] * A[1][1] + A[2][1] * A[2][1],   // 22
+		A[0][2] * A[0][0] + A[1][2] * A[1][0] + A[2][2] * A[2][0],   // 31
+		A[0][2] * A[0][1] + A[1][2] * A[1][1] + A[2][2] * A[2][1],   // 32
+		A[0][2] * A[0][2] + A[1][2] * A[1][2] + A[2][2] * A[2][2]};  // 33
+	float q[4] = {0, 0, 0, 1};
+	for (int i = 0; i < 4; ++i) {
+		jacobi_conjugation(0, 1, 2, sym, q);
+		jacobi_conjugation(1, 2, 0, sym, q);
+		jacobi_conjugation(2, 0, 1, sym, q);
 	}
-	for (int j = 0; j < 3; ++j) {
-		double n = sqrt(B[3 * j] * B[3 * j] + B[3 * j + 1] * B[3 * j + 1] + B[3 * j + 2] * B[3 * j + 2]);
-		S[j] = n;
-		for (int k = 0; k < 3; ++k) U[3 * j + k] = n > 1e-300 ? B[3 * j + k] / n : 0.0;
+	{ // quatToMat3, :121-145
+		float w = q[3], x = q[0], y = q[1], z = q[2];
+		float qxx = x * x, qyy = y * y, qzz = z * z, qxz = x * z, qxy = x * y, qyz = y * z, qwx = w * x, qwy = w * y, qwz = w * z;
+		V[0][0] = 1 - 2 * (qyy + qzz); V[0][1] = 2 * (qxy - qwz); V[0][2] = 2 * (qxz + qwy);
+		V[1][0] = 2 * (qxy + qwz); V[1][1] = 1 - 2 * (qxx + qzz); V[1][2] = 2 * (qyz - qwx);
+		V[2][0] = 2 * (qxz - qwy); V[2][1] = 2 * (qyz + qwx); V[2][2] = 1 - 2 * (qxx + qyy);
 	}
-	// complete U to an orthonormal basis if a singular value vanished (flat tets): use cross products
-	for (int j = 0; j < 3; ++j)
-		if (S[j] <= 1e-300) {
-			int a = (j + 1) % 3, b = (j + 2) % 3;
-			U[3 * j + 0] = U[3 * a + 1] * U[3 * b + 2] - U[3 * a + 2] * U[3 * b + 1];
-			U[3 * j + 1] = U[3 * a + 2] * U[3 * b + 0] - U[3 * a + 0] * U[3 * b + 2];
-			U[3 * j + 2] = U[3 * a + 0] * U[3 * b + 1] - U[3 * a + 1] * U[3 * b + 0];
+	float B[3][3];
+	for (int r = 0; r < 3; ++r)
+		for (int c = 0; c < 3; ++c) B[r][c] = A[r][0] * V[0][c] + A[r][1] * V[1][c] + A[r][2] * V[2][c];
+	auto rho_of = [&](int c) { return B[0][c] * B[0][c] + B[1][c] * B[1][c] + B[2][c] * B[2][c]; };
+	auto neg_swap = [&](bool c, int i, int j) {                        // condNegSwap on columns i, j of B and V, :78-84
+		for (int r = 0; r < 3; ++r) {
+			float zb = -B[r][i]; B[r][i] = c ? B[r][j] : B[r][i]; B[r][j] = c ? zb : B[r][j];
+			float zv = -V[r][i]; V[r][i] = c ? V[r][j] : V[r][i]; V[r][j] = c ? zv : V[r][j];
 		}
+	};
+	float rho1 = rho_of(0), rho2 = rho_of(1), rho3 = rho_of(2);
+	bool c = rho1 < rho2;
+	neg_swap(c, 0, 1);
+	if (c) std::swap(rho1, rho2);
+	c = rho1 < rho3;
+	neg_swap(c, 0, 2);
+	if (c) std::swap(rho1, rho3);
+	c = rho2 < rho3;
+	neg_swap(c, 1, 2);
+	float ch1, sh1, ch2, sh2, ch3, sh3, R[3][3];
+	qr_givens_quaternion(B[0][0], B[1][0], ch1, sh1);
+	float a = 1 - 2 * sh1 * sh1, b = 2 * ch1 * sh1;
+	for (int k = 0; k < 3; ++k) { R[0][k] = a * B[0][k] + b * B[1][k]; R[1][k] = -b * B[0][k] + a * B[1][k]; R[2][k] = B[2][k]; }
+	qr_givens_quaternion(R[0][0], R[2][0], ch2, sh2);
+	a = 1 - 2 * sh2 * sh2; b = 2 * ch2 * sh2;
+	for (int k = 0; k < 3; ++k) { B[0][k] = a * R[0][k] + b * R[2][k]; B[1][k] = R[1][k]; B[2][k] = -b * R[0][k] + a * R[2][k]; }
+	qr_givens_quaternion(B[1][1], B[2][1], ch3, sh3);
+	float sh12 = sh1 * sh1, sh22 = sh2 * sh2, sh32 = sh3 * sh3;        // Q = Q1 Q2 Q3, :336-352
+	U[0][0] = (-1 + 2 * sh12) * (-1 + 2 * sh22);
+	U[0][1] = 4 * ch2 * ch3 * (-1 + 2 * sh12) * sh2 * sh3 + 2 * ch1 * sh1 * (-1 + 2 * sh32);
+	U[0][2] = 4 * ch1 * ch3 * sh1 * sh3 - 2 * ch2 * (-1 + 2 * sh12) * sh2 * (-1 + 2 * sh32);
+	U[1][0] = 2 * ch1 * sh1 * (1 - 2 * sh22);
+	U[1][1] = -8 * ch1 * ch2 * ch3 * sh1 * sh2 * sh3 + (-1 + 2 * sh12) * (-1 + 2 * sh32);
+	U[1][2] = -2 * ch3 * sh3 + 4 * sh1 * (ch3 * sh1 * sh3 + ch1 * ch2 * sh2 * (-1 + 2 * sh32));
+	U[2][0] = 2 * ch2 * sh2;
+	U[2][1] = 2 * ch3 * (1 - 2 * sh22) * sh3;
+	U[2][2] = (-1 + 2 * sh22) * (-1 + 2 * sh32);
 }
 
 } // namespace
@@ -1552,19 +1629,19 @@ void orc_tet_local_rotations(const float* verts, const float* orig, const uint32
 			dc = dc + v3(verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]);
 		}
 		cc = v3(cc.x / 4.f, cc.y / 4.f, cc.z / 4.f); dc = v3(dc.x / 4.f, dc.y / 4.f, dc.z / 4.f);
-		double C[9] = {0};
+		float A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 		for (int j = 0; j < 4; ++j) {
 			uint32_t v = tets[4 * i + j];
 			V3 a = v3(orig[3 * v], orig[3 * v + 1], orig[3 * v + 2]) - cc, b = v3(verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]) - dc;
 			float av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
-			for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) C[3 * c + r] += (double)(av[r] * bv[c]); // (orig-c)(def-c)^T
+			for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[r][c] += av[r] * bv[c]; // corr_mat += (orig - c)(def - c)^T, fp32 like Eigen::Matrix3f
 		}
-		double U[9], S[3], V[9];
-		svd3(C, U, S, V);
-		for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { // R = U V^T
-			double s = 0;
-			for (int k = 0; k < 3; ++k) s += U[3 * k + r] * V[3 * k + c];
-			out[9 * (size_t)i + 3 * c + r] = (float)s;
+		float U[3][3], V[3][3];
+		ref_svd_uv(A, U, V);                                          // svd_eigen, svd3.h:405-420
+		for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {     // R = U V^T, column-major out
+			float s = 0.f;
+			for (int k = 0; k < 3; ++k) s += U[r][k] * V[c][k];
+			out[9 * (size_t)i + 3 * c + r] = s;
 		}
 	}
 }

@@ -3,8 +3,8 @@ TetMesh::post_update_vertices (tet_mesh.cu:12), build_tet_grid (:368), update_lo
 nrs_edit_create(device authoring) / nrs_edit_update_cage / nrs_edit_update_vertices, against the oracle's builders.
 
 Bars: vertices after the MVC apply, the bounding box, the CSR offsets, the per-cell tet lists (ascending) and the touched-cell
-bitfield are BIT-EXACT (integer work + order-controlled fp32 tests).  Rotations: 1e-4 against the oracle's Jacobi SVD (a
-different algorithm) and bit-exact against libnrs's own host routine (same double-precision iteration).
+bitfield are BIT-EXACT (integer work + order-controlled fp32 tests).  Rotations: bit-exact too -- device, host and oracle restate the reference's
+approximate fp32 SVD (editing/tools/svd3.h) step by step, pinned by tests/golden/ref_rotations_golden.npz.
 """
 import numpy as np
 import pytest
@@ -28,7 +28,7 @@ def _check_tables(op, scene, verts, orig_bits_expected=None):
     r_host = synth.local_rotations(verts, e.original_vertices, e.tets)
     assert np.array_equal(got["rotations"].reshape(-1), r_host.reshape(-1)), np.abs(got["rotations"].reshape(-1) - r_host.reshape(-1)).max()
     r_orc = orc.local_rotations(verts, e.original_vertices, e.tets)
-    assert np.abs(got["rotations"] - r_orc.reshape(-1, 9)).max() < 1e-4
+    assert np.array_equal(got["rotations"].reshape(-1), r_orc.reshape(-1))   # device == oracle == the reference's svd3.h (test_oracle_kat)
     return got
 
 

@@ -108,7 +108,7 @@ def test_mvc_and_rotations_match_oracle(scene):
     assert np.array_equal(orc.mvc_apply(e.mvc_weights, e.cage_deformed), e.vertices)   # same float summation order
     assert (e.mvc_weights > -1e-6).all()        # points strictly inside a convex cage: non-negative coordinates
     r_orc = orc.local_rotations(e.vertices, e.original_vertices, e.tets)
-    assert np.abs(r_orc - e.local_rotations).max() < 1e-4   # SURVEY App. A #14 tolerance (different SVD / polar algorithms)
+    assert np.array_equal(r_orc.reshape(-1), e.local_rotations.reshape(-1))   # both restate the reference's fp32 SVD step by step
     R = e.local_rotations.reshape(-1, 3, 3)
     assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-5   # orthonormal
     # a rigidly rotated tet mesh recovers the inverse rotation (deformed -> canonical)
@@ -116,7 +116,7 @@ def test_mvc_and_rotations_match_oracle(scene):
     Q = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], np.float32)
     rot_v = (e.original_vertices - 0.5) @ Q.T + 0.5
     Rr = synth.local_rotations(rot_v.astype(np.float32), e.original_vertices, e.tets[:50]).reshape(-1, 3, 3).transpose(0, 2, 1)  # col-major -> row
-    assert np.abs(Rr - Q.T).max() < 1e-4
+    assert np.abs(Rr - Q.T).max() < 2e-2   # the reference's SVD is approximate (4 Jacobi sweeps): see test_oracle_kat
 
 
 def test_cage_edit_geometry(scene):

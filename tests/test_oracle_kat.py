@@ -320,3 +320,33 @@ def test_mvc_pinned_to_the_reference_code(built):
         spec.loader.exec_module(mod)
         w, labels = mod.ref_mvc(g["cage_vertices"], g["cage_triangles"], g["points"])
         assert np.array_equal(w, g["weights"]) and np.array_equal(labels, g["labels"])
+
+
+def test_local_rotations_pinned_to_the_reference_code(built):
+    """TetMesh::update_local_rotations uses the approximate McAdams SVD of editing/tools/svd3.h; oracle/ref_svd.cpp compiles that
+    header in place and tests/golden/make_ref_rotations_golden.py records its R = U V^T for 2592 tets (a mild and a harsh
+    deformation).  The oracle's restatement and the product's (host here, device in tests/test_gpu_cage_update.py) match bit for bit."""
+    import os
+    from nerfshop_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = np.load(os.path.join(root, "tests", "golden", "ref_rotations_golden.npz"))
+    want = g["rotations"].view(np.uint32)
+    r_orc = orc.local_rotations(g["vertices"], g["original_vertices"], g["tets"]).reshape(-1, 9)
+    r_lib = synth.local_rotations(g["vertices"], g["original_vertices"], g["tets"]).reshape(-1, 9)
+    assert np.array_equal(r_orc.view(np.uint32), want)
+    assert np.array_equal(r_lib.view(np.uint32), want)
+    # the procedure is approximate by design: close to, but not, the exact polar rotation
+    v = g["vertices"][g["tets"]].astype(np.float64)
+    o = g["original_vertices"][g["tets"]].astype(np.float64)
+    A = np.einsum("nji,njk->nik", o - o.mean(1, keepdims=True), v - v.mean(1, keepdims=True))
+    U, _, Vt = np.linalg.svd(A)
+    exact = (U @ Vt).transpose(0, 2, 1).reshape(-1, 9)      # column-major like the fixture
+    err = np.abs(exact - g["rotations"]).max(1)
+    assert np.median(err) < 1e-5 and 1e-3 < err.max() < 5e-2
+    ref_lib = os.path.join(root, "oracle", "_ref", "libref_svd.so")
+    if os.path.exists(ref_lib):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("make_ref_rotations_golden", os.path.join(root, "tests", "golden", "make_ref_rotations_golden.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        assert np.array_equal(mod.ref_rotations(g["vertices"], g["original_vertices"], g["tets"]).view(np.uint32), want)
