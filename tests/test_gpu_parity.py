@@ -474,6 +474,24 @@ def test_render_1080p_properties(rig):
         rig.use_edit(False)
 
 
+def test_render_is_deterministic(rig):
+    """The persistent kernel hands packets out through an atomic queue and refills lanes in place, so WHICH wave renders a ray
+    changes from run to run; every pixel must not.  30 runs of a 720p view (with the cage edit), all bit-identical."""
+    rig.use_edit(True)
+    try:
+        p = rig.scene.params_for(1280, 720, 110.0, snap=False, spp_index=9)
+        first = None
+        for i in range(30):
+            frame, depth, steps, stats = rig.render(p)
+            if first is None:
+                first = (frame, depth, steps, int(stats.n_samples))
+                continue
+            assert int(stats.n_samples) == first[3]
+            assert np.array_equal(steps, first[2]) and np.array_equal(frame, first[0]) and np.array_equal(depth, first[1]), i
+    finally:
+        rig.use_edit(False)
+
+
 def test_errors_are_loud(rig):
     import ctypes as C
     from nerfshop_amd import runtime, synth
