@@ -275,7 +275,8 @@ def main():
                                     "garden_cage": "garden-style aabb_scale 16 1920x1080, one cage edit (BASELINE configs[3])"}[args.workload],
                        "resolution": [W, H], "samples_per_frame": int(total_samples / args.steps),
                        "sharding": f"{TILE}x{TILE} image tiles round-robin over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else ""),
-                       "frames_in_flight": n_buf},
+                       "frames_in_flight": n_buf,
+                       "cell_records": "levels 0..%d, %.1f GB (nrs_model_set_cell_cache default)" % (tb.nerf_network.cell_cache()[1] - 1, tb.nerf_network.cell_cache()[0] / 1e9)},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic(args.workload) if world == 1 else None, "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 3),
                          "algorithmic_bytes_per_launch": int(per_launch_samples * BYTES_PER_SAMPLE),

@@ -214,6 +214,15 @@ int    nrs_model_level_table(const nrs_model_desc* desc, float* scale, uint32_t*
 /* fp16 parameter blob in tiny-cuda-nn order: density MLP | rgb MLP | hash grid (nerf_network_full.h:316-349).
  * h_params is a HOST pointer (what Trainer::deserialize hands over); synchronous. */
 int    nrs_model_set_params(nrs_model* model, const void* h_params_fp16, size_t n_params);
+/* Cell-record cache (no counterpart in the reference: a memory-for-bandwidth trade the 288 GB of HBM allow).  For the
+ * coarsest levels that fit `max_bytes` (an even number of them), every grid cell gets a 32-byte record holding its 8
+ * corner entries, fetched with the level's own index function (tiny-cuda-nn grid.h:76-95), so that a sample reads two
+ * 16-byte loads from one cache line instead of hashing eight corners and gathering them from four lines.  Results are
+ * bit-identical with or without the cache.  The records are rebuilt inside every nrs_model_set_params (a few ms per
+ * 10 GB); callers that change parameters every frame (training) pass 0.  Levels 0..11 of base.json's table take
+ * 9.3 GB, 0..13 take 64 GB.  Synchronises the device.  max_bytes = 0 drops the cache. */
+int    nrs_model_set_cell_cache(nrs_model* model, size_t max_bytes);
+size_t nrs_model_cell_cache_bytes(const nrs_model* model, uint32_t* n_levels_out);
 /* occupancy: either the ready-made bitfield (NRS_BITFIELD_BYTES, Morton order, mips pooled) ... */
 int    nrs_model_set_density_bitfield(nrs_model* model, const uint8_t* h_bitfield, size_t n_bytes);
 /* ... or the float density grid [5*128^3]; thresholded with min(0.01, mean) and OR-pooled on the device

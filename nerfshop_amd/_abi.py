@@ -122,7 +122,7 @@ EXPORTS = [
     "nrs_last_error", "nrs_abi_version",
     "nrs_ctx_create", "nrs_ctx_destroy", "nrs_ctx_device_info",
     "nrs_model_create", "nrs_model_destroy", "nrs_model_n_params", "nrs_model_level_table",
-    "nrs_model_set_params", "nrs_model_set_density_bitfield", "nrs_model_set_density_grid",
+    "nrs_model_set_params", "nrs_model_set_cell_cache", "nrs_model_cell_cache_bytes", "nrs_model_set_density_bitfield", "nrs_model_set_density_grid",
     "nrs_model_get_density_bitfield", "nrs_model_get_density_grid", "nrs_model_update_density_grid", "nrs_rng_seed",
     "nrs_network_inference", "nrs_network_density", "nrs_hashgrid_encode", "nrs_density_on_grid", "nrs_rgba_on_grid",
     "nrs_edit_create", "nrs_edit_create_affine", "nrs_edit_destroy", "nrs_edit_map_rays", "nrs_edit_map_positions",
@@ -170,6 +170,9 @@ def load():
     lib.nrs_model_n_params.restype = C.c_size_t
     lib.nrs_model_level_table.argtypes = [C.POINTER(ModelDesc), P, P, P, P, P]
     lib.nrs_model_set_params.argtypes = [P, P, C.c_size_t]
+    lib.nrs_model_set_cell_cache.argtypes = [P, C.c_size_t]
+    lib.nrs_model_cell_cache_bytes.argtypes = [P, P]
+    lib.nrs_model_cell_cache_bytes.restype = C.c_size_t
     lib.nrs_model_set_density_bitfield.argtypes = [P, P, C.c_size_t]
     lib.nrs_model_set_density_grid.argtypes = [P, P, C.c_size_t]
     lib.nrs_model_get_density_bitfield.argtypes = [P, P, C.c_size_t]

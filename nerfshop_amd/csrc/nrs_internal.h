@@ -21,7 +21,7 @@ constexpr uint32_t kRunSide = 1;  // sqrt(kPacketRun)
 constexpr uint32_t kDensityW = 64 * 32 + 16 * 64;           // density MLP params (base.json:30-36)
 constexpr uint32_t kRgbW = 64 * 32 + 64 * 64 + 16 * 64;     // rgb MLP params (base.json:52-58)
 
-// One hash-grid level as the kernels consume it (staged in LDS, 32 B).
+// One hash-grid level as the kernels consume it (staged in LDS, 48 B).
 struct LevelParams {
 	float    scale;       // exp2(l*log2(b))*Nmin - 1
 	uint32_t resolution;  // ceil(scale) + 1
@@ -30,6 +30,10 @@ struct LevelParams {
 	uint32_t count;       // entries in the level
 	uint32_t hashed;      // 1: spatial hash (count is a power of two), 0: dense x + y*res + z*res^2
 	uint32_t mask;        // count - 1 when hashed
+	uint32_t cached;      // 1: the level has cell records (DeviceModel::records), see nrs_model_set_cell_cache
+	uint32_t rec_first;   // record number of cell (0, 0, 0)
+	uint32_t rec_res;     // cells per side with a record (= resolution: every cell a position in [0,1]^3 can fall into)
+	uint32_t rec_res2;    // rec_res^2
 	uint32_t pad;
 };
 
@@ -54,6 +58,7 @@ struct DeviceModel {
 	const uint32_t* grid;      // fp16x2 entries
 	const uint16_t* wfrag;     // kWfragBytes
 	const uint8_t*  bitfield;  // NRS_BITFIELD_BYTES
+	const void*     records;   // cell records of the cached levels: 2 x uint4 = the cell's 8 corner entries, x fastest
 	LevelParams     levels[kLevels];
 	Box3            aabb;      // train aabb (m_aabb)
 	float           inv_diag[3]; // 1 / (aabb.max - aabb.min), exact when diag_pow2
@@ -133,6 +138,7 @@ int launch_trace_samples(const DeviceModel& m, const nrs_render_params& p, uint3
 // mode 0: full inference (16 channels, c3 = density), 1: density MLP outputs, 2: hash-grid features [n x 32]
 int launch_network(const DeviceModel& m, int mode, uint32_t n, const float* d_in, uint32_t ld_in, void* d_out, uint32_t ld_out,
                    int layout, int n_cus, void* stream);
+int launch_cell_records(const DeviceModel& m, uint32_t n_levels, void* d_records, void* stream);
 int launch_grid_eval(const DeviceModel& m, int mode, const uint32_t res[3], const float box_mn[3], const float box_mx[3], const float dir01[3],
                      const float* d_density_grid, float* d_out, int n_cus, void* stream);
 int launch_map_rays(const DeviceEdit& e, uint32_t n, float* d_coords, uint32_t ld, int with_dir, uint8_t* d_empty, void* stream);

@@ -11,6 +11,7 @@
 //   grid -> bitfield     update_density_grid_mean_and_bitfield.
 //   detile_kernel        multi-GPU tile scatter.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include "nrs_internal.h"
 #include "nrs_device.cuh"
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	const int g = lane >> 5;
 	uint4* ring = sm.ring[wave];
 	FeatLds& fl = sm.fl[wave];
-	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count);
+	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count, (const uint4*)m.records);
 	const nrs_render_params& p = a.p;
 	const bool ops = p.apply_operators && a.n_edits > 0;
 	const f3 cam_fwd = mk3(p.camera_matrix1[6], p.camera_matrix1[7], p.camera_matrix1[8]);
@@ -454,6 +455,37 @@ struct NetSmem {
 };
 
 // MODE 0: inference_mixed_precision (16 channels, c3 = density raw), 1: density(), 2: hash-grid features [n x 32]
+// ---------------------------------------------------------------------------------------------------------------
+// Cell records (nrs_model_set_cell_cache): for every cell of a level, its 8 corner entries in corner order (x fastest),
+// fetched with the level's own index function (grid.h:76-95 as restated in level_eval_slow) -- so a record gather returns
+// exactly what the eight hashed / dense gathers would.  One thread per cell, 32 B written per thread, coalesced.
+__global__ __launch_bounds__(256) void cell_records_kernel(const uint32_t* __restrict__ grid, const LevelParams lp, uint4* __restrict__ out) {
+	const uint32_t n = lp.rec_res * lp.rec_res2;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+		const uint32_t gx = i % lp.rec_res, gy = (i / lp.rec_res) % lp.rec_res, gz = i / lp.rec_res2;
+		uint32_t v[8];
+		#pragma unroll
+		for (int c = 0; c < 8; ++c) {
+			const uint32_t cx = gx + (c & 1), cy = gy + ((c >> 1) & 1), cz = gz + ((c >> 2) & 1);
+			uint32_t index = lp.hashed ? ((cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u)) : (cx + cy * lp.resolution + cz * lp.res2);
+			index %= lp.count;
+			v[c] = grid[lp.offset + index];
+		}
+		uint4* o = out + 2 * ((size_t)lp.rec_first + i);
+		o[0] = make_uint4(v[0], v[1], v[2], v[3]);
+		o[1] = make_uint4(v[4], v[5], v[6], v[7]);
+	}
+}
+int launch_cell_records(const DeviceModel& m, uint32_t n_levels, void* d_records, void* stream) {
+	for (uint32_t l = 0; l < n_levels; ++l) {
+		const LevelParams& lp = m.levels[l];
+		const uint64_t n = (uint64_t)lp.rec_res * lp.rec_res2;
+		const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 1u << 20);
+		hipLaunchKernelGGL(cell_records_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m.grid, lp, (uint4*)d_records);
+	}
+	return hipGetLastError() == hipSuccess ? NRS_OK : NRS_ERR_HIP;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void network_kernel(const DeviceModel m, uint32_t n, const float* __restrict__ in, uint32_t ld_in,
                                                       _Float16* __restrict__ out, uint32_t ld_out, int layout) {
@@ -462,7 +494,7 @@ __global__ __launch_bounds__(256) void network_kernel(const DeviceModel m, uint3
 	const int lane = threadIdx.x & 63;
 	const int g = lane >> 5, j = lane & 31;
 	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count);
+	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count, (const uint4*)m.records);
 	const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
 	const uint32_t n_tiles = (n + 63) / 64;
@@ -555,7 +587,7 @@ __global__ __launch_bounds__(256) void grid_eval_kernel(const DeviceModel m, con
 	const int lane = threadIdx.x & 63;
 	const int g = lane >> 5, j = lane & 31;
 	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count);
+	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count, (const uint4*)m.records);
 	const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
 	const uint32_t n = a.res[0] * a.res[1] * a.res[2];
@@ -732,7 +764,7 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 	const int lane = threadIdx.x & 63;
 	const int g = lane >> 5;
 	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count);
+	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count, (const uint4*)m.records);
 	const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
 	uint64_t lane_mult, lane_plus;

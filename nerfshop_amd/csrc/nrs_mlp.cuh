@@ -37,14 +37,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define NRS_FRAG_R2(mb, ks) (12 + (mb) * 4 + (ks))
 #define NRS_FRAG_R3(ks) (20 + (ks))
 
-enum { KIND_DENSE = 0, KIND_HASHED = 1, KIND_MIXED = 2 };
+enum { KIND_DENSE = 0, KIND_HASHED = 1, KIND_MIXED = 2, KIND_RECORD = 3 };
 
 // Per-block model state in LDS: weight fragments, level table (index 2*it+g), kind of each level pair.
 struct ModelLds {
 	half8 w[kNumFrags * 64];
 	LevelParams levels[kLevels];
 	uint32_t kinds[8];
-	uint32_t pad[8];
+	uint32_t kinds_native[8]; // the kinds without the cell records (samples outside [0,1]^3 take these)
 };
 // Per-wave feature slab: feat[it][sel][lane], sel 0 = the lane's own sample, 1 = its partner's (lane ^ 32) sample.
 struct FeatLds { uint32_t feat[8][2][64]; };
@@ -60,16 +60,20 @@ __device__ __forceinline__ void stage_model_to_lds(const DeviceModel& m, ModelLd
 	}
 	if (threadIdx.x < 8) {
 		const uint32_t h0 = (dbg & 1u) ? 1u : m.levels[2 * threadIdx.x].hashed, h1 = (dbg & 1u) ? 1u : m.levels[2 * threadIdx.x + 1].hashed;
-		s.kinds[threadIdx.x] = (h0 && h1) ? KIND_HASHED : ((!h0 && !h1) ? KIND_DENSE : KIND_MIXED);
+		const bool rec = !(dbg & 1u) && m.levels[2 * threadIdx.x].cached && m.levels[2 * threadIdx.x + 1].cached;
+		const uint32_t native = (h0 && h1) ? KIND_HASHED : ((!h0 && !h1) ? KIND_DENSE : KIND_MIXED);
+		s.kinds[threadIdx.x] = rec ? KIND_RECORD : native;
+		s.kinds_native[threadIdx.x] = native;
 	}
 	__syncthreads();
 }
 
 // The table is read through a buffer descriptor: one 32-bit offset per gather instead of 64-bit pointer arithmetic.
-struct GridView { __amdgpu_buffer_rsrc_t rsrc; };
-__device__ __forceinline__ GridView make_grid_view(const uint32_t* grid, uint32_t n_entries) {
+struct GridView { __amdgpu_buffer_rsrc_t rsrc; const uint4* records; };
+__device__ __forceinline__ GridView make_grid_view(const uint32_t* grid, uint32_t n_entries, const uint4* records = nullptr) {
 	GridView v;
 	v.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)grid, 0, (int)(n_entries * 4u), 0x00020000);
+	v.records = records;
 	return v;
 }
 __device__ __forceinline__ uint32_t grid_load(const GridView& v, uint32_t entry) {
@@ -155,6 +159,20 @@ __device__ __forceinline__ void issue_gathers(const GridView& gv, const LevelPar
 		}
 	}
 }
+// Cached level: the 8 corner entries of the sample's cell sit in one 32-byte record (written by cell_records_kernel with
+// the level's own index function, so the values are the ones the hashed / dense gather would fetch): two 16-byte loads
+// and one address instead of eight gathers and eight hashes, and one cache line instead of four.
+// Every cell a position in [0,1]^3 falls into has a record: floor(scale * p + 0.5) <= ceil(scale) = resolution - 1.
+__device__ __forceinline__ bool outside_unit_cube(f3 p) {
+	return !(p.x >= 0.f && p.x <= 1.f && p.y >= 0.f && p.y <= 1.f && p.z >= 0.f && p.z <= 1.f);
+}
+__device__ __forceinline__ void issue_record_loads(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t v[8]) {
+	const uint32_t rec = lp.rec_first + c.gx + c.gy * lp.rec_res + c.gz * lp.rec_res2;
+	const uint4* p = gv.records + 2 * (size_t)rec;
+	const uint4 lo = p[0], hi = p[1];
+	v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+	v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+}
 // Trilinear interpolation in the oracle's order (corner 0..7, x fastest; weight = (wx' * wy') * wz') -> packed fp16 pair.
 __device__ __forceinline__ uint32_t interpolate(const CellCoords& c, const uint32_t v[8]) {
 	const float ux = 1.0f - c.wx, uy = 1.0f - c.wy, uz = 1.0f - c.wz;
@@ -189,13 +207,16 @@ __device__ __forceinline__ void level_eval_pair(const GridView& gv, const LevelP
 	const f3 zero = mk3(0.f, 0.f, 0.f);
 	const CellCoords ca = cell_coords(lp, actA ? posA : zero), cb = cell_coords(lp, actB ? posB : zero);
 	const bool lane_hashed = (KIND == KIND_HASHED) || (KIND == KIND_MIXED && lp.hashed);
-	const bool slowA = !lane_hashed && dense_needs_slow(lp, ca), slowB = !lane_hashed && dense_needs_slow(lp, cb);
-	if (KIND != KIND_HASHED && __builtin_expect(__any(slowA || slowB), 0)) { // exact tcnn wrap for samples outside [0,1)^3: rare
+	const bool slowA = KIND != KIND_RECORD && !lane_hashed && dense_needs_slow(lp, ca), slowB = KIND != KIND_RECORD && !lane_hashed && dense_needs_slow(lp, cb);
+	if (KIND != KIND_HASHED && KIND != KIND_RECORD && __builtin_expect(__any(slowA || slowB), 0)) { // exact tcnn wrap for samples outside [0,1)^3: rare
 		fa = level_eval_exact(gv, lp, ca);
 		fb = level_eval_exact(gv, lp, cb);
 	} else {
 		uint32_t va[8], vb[8];
-		if (KIND == KIND_HASHED) {
+		if (KIND == KIND_RECORD) {
+			issue_record_loads(gv, lp, ca, va);
+			issue_record_loads(gv, lp, cb, vb);
+		} else if (KIND == KIND_HASHED) {
 			issue_gathers<true>(gv, lp, ca, va);
 			issue_gathers<true>(gv, lp, cb, vb);
 		} else if (KIND == KIND_DENSE) {
@@ -217,12 +238,16 @@ __device__ __forceinline__ void level_eval_pair(const GridView& gv, const LevelP
 
 // All 8 level pairs of two positions (own sample A, partner's sample B) -> the wave's feature slab.
 __device__ __forceinline__ void encode_to_lds(const GridView& gv, const ModelLds& ml, FeatLds& fl, int lane, int g, f3 posA, bool actA, f3 posB, bool actB) {
+	// the records cover [0,1]^3; a wave with a sample outside it (a warped sample of an edit, rarely) gathers the native way
+	const bool outside = __any((actA && outside_unit_cube(posA)) || (actB && outside_unit_cube(posB)));
+	const uint32_t* kinds = outside ? ml.kinds_native : ml.kinds;
 	#pragma unroll 1
 	for (int it = 0; it < 8; ++it) {
 		const LevelParams lp = ml.levels[2 * it + g];
-		const uint32_t kind = __builtin_amdgcn_readfirstlane(ml.kinds[it]);
+		const uint32_t kind = __builtin_amdgcn_readfirstlane(kinds[it]);
 		uint32_t fa, fb;
-		if (kind == KIND_HASHED) level_eval_pair<KIND_HASHED>(gv, lp, posA, actA, posB, actB, fa, fb);
+		if (kind == KIND_RECORD) level_eval_pair<KIND_RECORD>(gv, lp, posA, actA, posB, actB, fa, fb);
+		else if (kind == KIND_HASHED) level_eval_pair<KIND_HASHED>(gv, lp, posA, actA, posB, actB, fa, fb);
 		else if (kind == KIND_DENSE) level_eval_pair<KIND_DENSE>(gv, lp, posA, actA, posB, actB, fa, fb);
 		else level_eval_pair<KIND_MIXED>(gv, lp, posA, actA, posB, actB, fa, fb);
 		fl.feat[it][0][lane] = fa;

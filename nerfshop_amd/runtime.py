@@ -89,6 +89,16 @@ class NerfNetwork:
             raise NrsError("set_params expects fp16 parameters (numpy float16 or their uint16 bits)")
         check(self.lib.nrs_model_set_params(self.h, p.ctypes.data, p.size))
 
+    def set_cell_cache(self, max_bytes):
+        """Budget of the cell-record cache (nrs_model_set_cell_cache): 0 drops it; results do not depend on it."""
+        check(self.lib.nrs_model_set_cell_cache(self.h, int(max_bytes)))
+
+    def cell_cache(self):
+        """(bytes held by the cell records, number of levels they cover)"""
+        n = C.c_uint32()
+        b = self.lib.nrs_model_cell_cache_bytes(self.h, C.byref(n))
+        return int(b), int(n.value)
+
     def set_density_bitfield(self, bitfield_u8):
         b = np.ascontiguousarray(bitfield_u8, np.uint8)
         check(self.lib.nrs_model_set_density_bitfield(self.h, b.ctypes.data, b.size))

@@ -1,0 +1,132 @@
+"""The cell-record cache (nrs_model_set_cell_cache) is a layout of the same numbers: everything that reads the hash grid
+must return the same bits with the records, without them, and with any number of cached levels -- inside the unit cube,
+on its faces and outside it (where the kernels gather the native way)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from nerfshop_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+
+def _level_cells(desc):
+    res = (C.c_uint32 * 16)()
+    _abi.check(_abi.load().nrs_model_level_table(C.byref(desc), None, res, None, None, None))
+    return [int(r) ** 3 for r in res]
+
+
+def _encode(rig, coords):
+    torch = rig.torch
+    out = torch.zeros((coords.shape[0], 32), dtype=torch.float16, device="cuda:0")
+    rig.net.hashgrid_encode(None, torch.from_numpy(coords).cuda(), out)
+    return out.cpu().numpy().view(np.uint16)
+
+
+def _coords(n, seed, lo, hi):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(lo, hi, size=(n, 7)).astype(np.float32)
+    c[:, 3:] = 0.5
+    return c
+
+
+def test_plan_follows_the_budget(rig):
+    cells = _level_cells(rig.scene.desc)
+    default_bytes, default_levels = rig.net.cell_cache()
+    try:
+        assert default_levels == 12 and default_bytes == 32 * sum(cells[:12])   # 9.3 GB: levels 0..11 of base.json's table
+        for budget, want in [(0, 0), (31, 0), (32 * sum(cells[:2]) - 1, 0), (32 * sum(cells[:2]), 2), (32 * sum(cells[:5]), 4),
+                             (32 * sum(cells[:8]) + 5, 8)]:
+            rig.net.set_cell_cache(budget)
+            assert rig.net.cell_cache() == (32 * sum(cells[:want]), want), budget
+    finally:
+        rig.net.set_cell_cache(10 << 30)
+    assert rig.net.cell_cache() == (default_bytes, default_levels)
+
+
+def test_features_identical_with_and_without_records(rig):
+    inside = _coords(50000, 5, 0.0, 1.0)
+    inside[:8, :3] = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], np.float32)   # corners of the cube
+    inside[8:2008, :3] = np.round(inside[8:2008, :3] * 64) / 64                                          # cell boundaries of many levels
+    around = _coords(50000, 6, -0.75, 1.75)        # most samples outside the cube: waves fall back to the native gathers
+    around[::7, :3] = _coords(50000, 8, 0.0, 1.0)[::7, :3]
+    far = _coords(4096, 7, -300.0, 300.0)
+    ref_in = rig.scene.oracle_model.hashgrid_encode(inside[:3000])
+    ref_out = rig.scene.oracle_model.hashgrid_encode(around[:3000])
+    try:
+        got = {}
+        for budget in (10 << 30, 0, 300 << 20, 3 << 30):
+            rig.net.set_cell_cache(budget)
+            got[budget] = [_encode(rig, c) for c in (inside, around, far)]
+            assert np.array_equal(got[budget][0][:3000], ref_in) and np.array_equal(got[budget][1][:3000], ref_out), rig.net.cell_cache()
+        for budget, arrays in got.items():
+            for a, b in zip(arrays, got[0]):
+                assert np.array_equal(a, b), f"features differ between a {budget}-byte cache and none"
+    finally:
+        rig.net.set_cell_cache(10 << 30)
+
+
+def test_frames_identical_with_and_without_records(rig):
+    rig.use_edit(True)
+    try:
+        p = rig.scene.params_for(512, 288, 60.0)
+        frames = {}
+        for budget in (10 << 30, 0, 1 << 30):
+            rig.net.set_cell_cache(budget)
+            frames[budget] = rig.render(p)
+        ref = frames[0]
+        assert ref[3].n_samples > 100000
+        for budget, (frame, depth, steps, stats) in frames.items():
+            assert np.array_equal(frame.view(np.uint32), ref[0].view(np.uint32)), budget
+            assert np.array_equal(depth.view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(steps, ref[2])
+            assert stats.n_samples == ref[3].n_samples
+    finally:
+        rig.net.set_cell_cache(10 << 30)
+        rig.use_edit(False)
+
+
+def test_records_follow_set_params(rig):
+    """nrs_model_set_params rebuilds the records: new parameters must show up through the cached levels at once."""
+    c = _coords(20000, 9, 0.0, 1.0)
+    before = _encode(rig, c)
+    rng = np.random.default_rng(10)
+    other = rig.scene.params.copy()
+    n_net = other.size - 2 * sum(_level_entries(rig.scene.desc))
+    grid = rng.uniform(-0.3, 0.3, size=other.size - n_net).astype(np.float16)
+    other[n_net:] = grid.view(np.uint16)
+    try:
+        rig.net.set_params(other)
+        with_records = _encode(rig, c)
+        rig.net.set_cell_cache(0)
+        without = _encode(rig, c)
+        assert np.array_equal(with_records, without)
+        assert (with_records != before).mean() > 0.5
+    finally:
+        rig.net.set_cell_cache(10 << 30)
+        rig.net.set_params(rig.scene.params)
+    assert np.array_equal(_encode(rig, c), before)
+
+
+def _level_entries(desc):
+    cnt = (C.c_uint32 * 16)()
+    _abi.check(_abi.load().nrs_model_level_table(C.byref(desc), None, None, None, cnt, None))
+    return [int(v) for v in cnt]
+
+
+def test_occupancy_refresh_identical_with_and_without_records(rig_shaped):
+    """The density-grid refresh evaluates the network through the same gathers."""
+    rig = rig_shaped
+    grids = []
+    try:
+        for budget in (10 << 30, 0):
+            rig.net.set_cell_cache(budget)
+            rig.net.set_density_grid(rig.scene.grid)
+            u = rig.testbed.new_grid_update(max_cascade=0, seed=1337)
+            rig.testbed.update_density_grid_nerf_render(2, True, u)
+            rig.torch.cuda.synchronize()
+            grids.append(rig.net.get_density_grid().copy())
+        assert np.array_equal(grids[0].view(np.uint32), grids[1].view(np.uint32))
+    finally:
+        rig.net.set_cell_cache(10 << 30)
+        rig.net.set_density_bitfield(rig.scene.bitfield)
