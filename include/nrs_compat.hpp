@@ -64,6 +64,8 @@ public:
 	// set_params(params, inference_params, ...) of the reference takes device pointers into the trainer's blob; here the fp16
 	// blob (density MLP | rgb MLP | hash grid, nerf_network_full.h:316-349) is handed over from the host once.
 	void set_params(const void* h_params_fp16, size_t n) { check(nrs_model_set_params(m_model, h_params_fp16, n), "nrs_model_set_params"); }
+	// budget of the cell-record cache (no counterpart in the reference; results do not depend on it), 0 = off
+	void set_cell_cache(size_t max_bytes) { check(nrs_model_set_cell_cache(m_model, max_bytes), "nrs_model_set_cell_cache"); }
 
 	void inference_mixed_precision(void* stream, const InputMatrix& input, OutputMatrix& output, bool /*use_inference_params*/ = true) {
 		if (input.rows != NRS_NETWORK_INPUT_FLOATS) throw std::runtime_error("NerfNetwork::inference_mixed_precision: input must have 7 rows");
