@@ -120,7 +120,7 @@ class GridUpdate(C.Structure):
 # every symbol include/nrs.h declares; tests check the library exports exactly these
 EXPORTS = [
     "nrs_last_error", "nrs_abi_version",
-    "nrs_ctx_create", "nrs_ctx_destroy", "nrs_ctx_device_info",
+    "nrs_ctx_create", "nrs_ctx_destroy", "nrs_ctx_device_info", "nrs_ctx_set_lane_teams",
     "nrs_model_create", "nrs_model_destroy", "nrs_model_n_params", "nrs_model_level_table",
     "nrs_model_set_params", "nrs_model_set_cell_cache", "nrs_model_cell_cache_bytes", "nrs_model_set_density_bitfield", "nrs_model_set_density_grid",
     "nrs_model_get_density_bitfield", "nrs_model_get_density_grid", "nrs_model_update_density_grid", "nrs_rng_seed",
@@ -164,6 +164,7 @@ def load():
     lib.nrs_ctx_destroy.restype = None
     lib.nrs_ctx_device_info.argtypes = [P, C.c_char_p, C.c_size_t, C.POINTER(I), C.POINTER(C.c_size_t)]
     lib.nrs_model_create.argtypes = [P, C.POINTER(ModelDesc), C.POINTER(P)]
+    lib.nrs_ctx_set_lane_teams.argtypes = [P, C.c_int]
     lib.nrs_model_destroy.argtypes = [P]
     lib.nrs_model_destroy.restype = None
     lib.nrs_model_n_params.argtypes = [C.POINTER(ModelDesc)]

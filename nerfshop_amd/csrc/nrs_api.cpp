@@ -39,6 +39,7 @@ static int fail_hip(hipError_t e, const char* what) {
 	} while (0)
 
 struct nrs_ctx {
+	int lane_teams = 0; // nrs_ctx_set_lane_teams: 0 = automatic, 1 / 2 / 4 = lanes per ray for every render launch
 	int device = 0;
 	int n_cus = 0;
 	size_t hbm_bytes = 0;
@@ -51,6 +52,8 @@ struct nrs_ctx {
 	uint32_t launch_serial = 0;
 	float* d_mean = nullptr;
 	unsigned long long* d_wave_log = nullptr; // profiling only (NRS_DEBUG & 4)
+	unsigned long long* h_feedback = nullptr; // pinned, device-visible: written by the last workgroup of a render launch
+	unsigned long long* d_feedback = nullptr; // its device address
 	static constexpr int kMaxEdits = 32;
 };
 
@@ -331,6 +334,14 @@ int nrs_ctx_create(int device, nrs_ctx** out) {
 		nrs_ctx_destroy(c);
 		return fail_hip(he, "nrs_ctx_create: hipMalloc");
 	}
+	// one device-visible host word for the launch feedback (lane-team sizing); optional: without it the estimate stays at its default
+	if (hipHostMalloc((void**)&c->h_feedback, 8, hipHostMallocMapped) == hipSuccess) {
+		*c->h_feedback = 0ull;
+		if (hipHostGetDevicePointer((void**)&c->d_feedback, c->h_feedback, 0) != hipSuccess) c->d_feedback = nullptr;
+	} else {
+		(void)hipGetLastError();
+		c->h_feedback = nullptr;
+	}
 	*out = c;
 	return NRS_OK;
 }
@@ -340,7 +351,14 @@ void nrs_ctx_destroy(nrs_ctx* c) {
 	(void)hipFree(c->d_edits);
 	(void)hipFree(c->d_mean);
 	(void)hipFree(c->d_wave_log);
+	if (c->h_feedback) (void)hipHostFree(c->h_feedback);
 	delete c;
+}
+int nrs_ctx_set_lane_teams(nrs_ctx* ctx, int lanes_per_ray) {
+	if (!ctx || !(lanes_per_ray == 0 || lanes_per_ray == 1 || lanes_per_ray == 2 || lanes_per_ray == 4))
+		return fail(NRS_ERR_INVALID_ARG, "nrs_ctx_set_lane_teams: lanes_per_ray must be 0 (automatic), 1, 2 or 4");
+	ctx->lane_teams = lanes_per_ray;
+	return NRS_OK;
 }
 int nrs_ctx_device_info(const nrs_ctx* c, char* name_out, size_t name_len, int* n_cus, size_t* hbm_bytes) {
 	if (!c) return fail(NRS_ERR_INVALID_ARG, "ctx is NULL");
@@ -944,14 +962,15 @@ int nrs_edit_map_positions(nrs_edit* e, void* stream, uint32_t n, float* d_pos, 
 }
 
 // ---- renderer --------------------------------------------------------------------------------------------------------
-static int tile_geometry(const nrs_render_params& p, uint32_t& tiles_x, uint32_t& owned, uint32_t& n_packets, uint32_t& ppt_x) {
+static int tile_geometry(const nrs_render_params& p, uint32_t team, uint32_t& tiles_x, uint32_t& owned, uint32_t& n_packets, uint32_t& ppt_x) {
 	const uint32_t W = (uint32_t)p.resolution[0], H = (uint32_t)p.resolution[1];
+	const uint32_t pw = team >= 16 ? 2u : (team >= 4 ? 4u : 8u), ph = 64u / team / pw; // packet_pixel<TEAM>()
 	if (p.tile_size == 0) {
-		const uint32_t side = 8 * kRunSide; // super-tiles of kPacketRun packets (Morton order inside), see packet_pixel()
-		tiles_x = (W + side - 1) / side;
+		const uint32_t side_x = pw * kRunSide, side_y = ph * kRunSide; // super-tiles of kPacketRun packets (Morton order inside)
+		tiles_x = (W + side_x - 1) / side_x;
 		owned = 1;
 		ppt_x = 0;
-		n_packets = tiles_x * ((H + side - 1) / side) * kPacketRun;
+		n_packets = tiles_x * ((H + side_y - 1) / side_y) * kPacketRun;
 		return NRS_OK;
 	}
 	if (p.tile_size % 8) return fail(NRS_ERR_INVALID_ARG, "tile_size must be a multiple of 8");
@@ -959,14 +978,14 @@ static int tile_geometry(const nrs_render_params& p, uint32_t& tiles_x, uint32_t
 	const uint32_t tiles_y = (H + p.tile_size - 1) / p.tile_size, total = tiles_x * tiles_y;
 	const uint32_t stride = p.tile_stride ? p.tile_stride : 1;
 	owned = p.tile_first < total ? (total - p.tile_first + stride - 1) / stride : 0;
-	ppt_x = p.tile_size / 8;
-	n_packets = owned * ppt_x * ppt_x;
+	ppt_x = p.tile_size / pw;
+	n_packets = owned * ppt_x * (p.tile_size / ph);
 	return NRS_OK;
 }
 uint32_t nrs_render_owned_tiles(const nrs_render_params* p) {
 	if (!p || p->resolution[0] <= 0 || p->resolution[1] <= 0) return 0;
 	uint32_t tx, owned, np, ppt;
-	if (tile_geometry(*p, tx, owned, np, ppt) != NRS_OK) return 0;
+	if (tile_geometry(*p, 1, tx, owned, np, ppt) != NRS_OK) return 0;
 	return owned;
 }
 
@@ -991,7 +1010,8 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	RenderArgs a{};
 	a.p = *p;
 	uint32_t owned_tiles = 0;
-	int st = tile_geometry(*p, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x);
+	a.team = 1;
+	int st = tile_geometry(*p, 1, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x);
 	if (st != NRS_OK) return st;
 	a.n_edits = n_edits;
 	a.any_poisson = 0;
@@ -1006,6 +1026,30 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		HIP_TRY(hipMemcpyAsync(d_edits_slot, host_edits, sizeof(DeviceEdit) * n_edits, hipMemcpyHostToDevice, s));
 	}
 	a.edits = d_edits_slot;
+	{ // lane teams (render_kernel's TEAM) when the launch cannot fill the GPU with one ray per lane.  Rays per lane is
+	  // estimated from the share of pixels that became rays in the last finished launch (written by its last workgroup;
+	  // 0.25 until one has finished).  Measured on 1080p lego (0.22 of the pixels hit), frame shares 1/1 .. 1/8, ms per
+	  // launch with 1 / 2 / 4 lanes per ray: 3.09 2.89 3.31 | 2.07 1.78 1.95 | 1.56 1.25 1.21 | 1.19 0.93 0.88; 8 and 16
+	  // lanes lose everywhere (1.07, 1.72 at 1/8); 2560x1440: 4.31 4.52 5.64; aabb-16 1080p (every pixel hits): 9.64 9.76 10.9
+		static const int env_forced = []() { const char* e = getenv("NRS_TEAM"); return e ? atoi(e) : 0; }();
+		const int forced = ctx->lane_teams ? ctx->lane_teams : env_forced;
+		const unsigned long long fb = ctx->h_feedback ? __atomic_load_n(ctx->h_feedback, __ATOMIC_RELAXED) : 0ull;
+		const double hit_share = (fb >> 32) ? (double)(uint32_t)fb / (double)(fb >> 32) : 0.25;
+		a.pixels_owned = a.n_packets * 64u;
+		const double rays_per_lane = hit_share * (double)a.pixels_owned / (64.0 * 16.0 * (double)ctx->n_cus);
+		uint32_t team = rays_per_lane <= 0.55 ? 4u : (rays_per_lane <= 4.5 ? 2u : 1u);
+		// the fill runs once per pixel and lane of a team: keep it to ~8 passes over the GPU (an all-miss 1080p frame is 8)
+		while (team > 1 && (double)team * (double)a.pixels_owned > 8.5 * 64.0 * 16.0 * (double)ctx->n_cus) team >>= 1;
+		if (forced == 1 || forced == 2 || forced == 4) team = (uint32_t)forced;
+		if (a.any_poisson || a.any_affine) team = 1; // (those instantiations are built for one lane per ray)
+		static const bool log_teams = getenv("NRS_TEAM_LOG") != nullptr;
+		if (log_teams) fprintf(stderr, "[nrs team] pixels=%u hit_share=%.3f rays/lane=%.3f team=%u\n", a.pixels_owned, hit_share, rays_per_lane, team);
+		if (team > 1) {
+			a.team = team;
+			NRS_TRY(tile_geometry(*p, team, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x));
+		}
+		a.feedback = ctx->d_feedback;
+	}
 	a.max_steps = p->max_march_steps ? p->max_march_steps : 10000u; // MARCH_ITER, testbed_nerf.cu:56
 	{
 		static const uint32_t dbg = []() { const char* e = getenv("NRS_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();

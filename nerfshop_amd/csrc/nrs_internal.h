@@ -106,7 +106,7 @@ struct RenderCounters {    // zeroed before every launch
 	uint32_t next_packet;
 	uint32_t n_rays_alive;
 	uint32_t n_rays_hit;
-	uint32_t pad;
+	uint32_t blocks_done; // workgroups that have flushed their statistics (the last one reports to RenderArgs::feedback)
 	unsigned long long phase_cycles[8]; // NRS_DEBUG & 4: per-phase wave cycles (profiling build of the kernel only)
 	// NRS_DEBUG & 4: voxel-walk statistics. [0]/[1] fill: lane iterations / wave trips (= max over lanes per call);
 	// [2]/[3] the same for the per-sample march; [4] sample rounds, [5] live lanes summed over rounds, [6] march calls with > 1 trip
@@ -119,9 +119,12 @@ struct RenderArgs {
 	int32_t  n_edits;
 	uint32_t any_poisson;      // some edit has apply_poisson set
 	uint32_t any_affine;       // some edit is an AffineDuplication
-	uint32_t n_packets;        // 8x8 pixel packets owned by this call
-	uint32_t tiles_x;          // image width in tiles (tiled mode) or in 32x32 super-tiles (whole-image mode)
+	uint32_t n_packets;        // pixel packets owned by this call (8x8 pixels; 8x4 / 4x4 with lane teams of 2 / 4)
+	uint32_t tiles_x;          // image width in tiles (tiled mode) or in packets (whole-image mode)
 	uint32_t packets_per_tile_x;
+	uint32_t pixels_owned;     // pixels this launch covers (for the feedback word)
+	unsigned long long* feedback; // host-mapped: rays that found an occupied cell | pixels_owned << 32, written by the last workgroup
+	uint32_t team;             // lanes per ray: 1, or 2 / 4 for launches with too few rays to fill the GPU (render_kernel's TEAM)
 	uint32_t max_steps;
 	uint32_t dbg;              // NRS_DEBUG ablation bits (profiling only; 0 in production): 1 = all gathers hit entry 0, 2 = skip the MLPs
 	float*    frame;           // f32x4

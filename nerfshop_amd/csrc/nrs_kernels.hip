@@ -46,28 +46,70 @@ struct RenderSmem {
 	FeatLds fl[WAVES];
 	uint4 ring[WAVES][kRing]; // {x | y << 16, t bits, output index, -}
 	uint32_t coarse[kCoarseWords]; // DeviceModel::coarse_mask (marching shortcut 2)
+	unsigned long long queue;       // the workgroup's chunk of the frame's packet queue: next packet | end << 32 (claim_packet)
+	unsigned long long sum_samples; // statistics of the workgroup's waves, flushed by the last one to finish
+	uint32_t sum_alive, sum_hit, n_finished;
 };
 
-// packet -> pixel of this lane.  Packets are 8x8 pixel blocks.
+// The frame's work queue is one device-wide counter.  Device-scope atomics on one address serialise across the 8 XCDs at
+// ~18 ns each (an all-miss 1080p frame, 32 400 packets, took 0.57 ms for that reason alone), so the waves of a workgroup
+// share a chunk of kQueueChunk packets held in LDS and only the wave that finds the chunk used up goes to the global
+// counter.  State word: low half = next packet of the chunk, high half = its end; bit 31 of the low half = queue dry.
+constexpr uint32_t kQueueChunk = 8;
+constexpr uint32_t kNoPacket = 0xffffffffu;
+__device__ __forceinline__ uint32_t claim_packet(unsigned long long* state, uint32_t* global_next, uint32_t n_packets, int lane) {
+	uint32_t result = kNoPacket;
+	if (lane == 0) {
+		for (;;) {
+			const unsigned long long old = atomicAdd(state, 1ull);
+			const uint32_t cur = (uint32_t)old, end = (uint32_t)(old >> 32);
+			if (cur & 0x80000000u) break; // dry
+			if (cur < end) { result = cur; break; }
+			if (cur == end) { // the first wave past the end fetches the next chunk (and takes its first packet)
+				const uint32_t base = atomicAdd(global_next, kQueueChunk);
+				if (base >= n_packets) {
+					atomicExch(state, 0x80000000ull);
+				} else {
+					const uint32_t e = min(base + kQueueChunk, n_packets);
+					atomicExch(state, ((unsigned long long)e << 32) | (unsigned long long)(base + 1u));
+					result = base;
+				}
+				break;
+			}
+			for (;;) { // another wave is fetching: wait for the new chunk (its end differs: the global counter only grows)
+				const unsigned long long s = __atomic_load_n(state, __ATOMIC_RELAXED);
+				if ((uint32_t)(s >> 32) != end || ((uint32_t)s & 0x80000000u)) break;
+				__builtin_amdgcn_s_sleep(2);
+			}
+		}
+	}
+	return (uint32_t)__builtin_amdgcn_readfirstlane((int)result);
+}
+
+// packet -> pixel of this lane.  Packets are 8x8 pixel blocks; with lane teams (TEAM lanes per ray) a packet is the 64 / TEAM
+// pixels of an 8x4 / 4x4 block and the TEAM lanes of a team stand on the same pixel.
+template <int TEAM>
 __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, int lane, uint32_t& x, uint32_t& y, uint32_t& out_idx) {
+	constexpr uint32_t PW = TEAM >= 16 ? 2u : (TEAM >= 4 ? 4u : 8u), PH = 64u / TEAM / PW; // 8x8, 8x4, 4x4, 4x2, 2x2
 	const uint32_t W = (uint32_t)a.p.resolution[0], H = (uint32_t)a.p.resolution[1];
-	const uint32_t lx = lane & 7, ly = lane >> 3;
+	const uint32_t idx = (uint32_t)lane / TEAM;
+	const uint32_t lx = idx % PW, ly = idx / PW;
 	if (a.p.tile_size == 0) {
 		// whole image: super-tiles of kPacketRun packets in Morton order, so that the run of packets a wave claims (and with
 		// it the rays it marches together) stays spatially compact -> fewer distinct cache lines per gather
 		const uint32_t tile = pk / kPacketRun, sub = pk % kPacketRun;
 		const uint32_t bx = (tile % a.tiles_x) * kRunSide + ((sub & 1u) | ((sub >> 1) & 2u));
 		const uint32_t by = (tile / a.tiles_x) * kRunSide + (((sub >> 1) & 1u) | ((sub >> 2) & 2u));
-		x = bx * 8 + lx;
-		y = by * 8 + ly;
+		x = bx * PW + lx;
+		y = by * PH + ly;
 		out_idx = x + W * y;
 	} else {
-		const uint32_t ppt = a.packets_per_tile_x * a.packets_per_tile_x;
+		const uint32_t ppt = a.packets_per_tile_x * (a.p.tile_size / PH);
 		const uint32_t k = pk / ppt, b = pk % ppt;
 		const uint32_t stride = a.p.tile_stride ? a.p.tile_stride : 1;
 		const uint32_t T = a.p.tile_first + k * stride;
 		const uint32_t Tx = T % a.tiles_x, Ty = T / a.tiles_x;
-		const uint32_t tx = (b % a.packets_per_tile_x) * 8 + lx, ty = (b / a.packets_per_tile_x) * 8 + ly;
+		const uint32_t tx = (b % a.packets_per_tile_x) * PW + lx, ty = (b / a.packets_per_tile_x) * PH + ly;
 		x = Tx * a.p.tile_size + tx;
 		y = Ty * a.p.tile_size + ty;
 		out_idx = (k * a.p.tile_size + ty) * a.p.tile_size + tx;
@@ -92,15 +134,25 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 // the common path pays neither its registers nor its code.
 // AFFINE compiles in the AffineDuplication operator (edit_warp's second kind): frames whose operators are all cage
 // deformations -- the common case and the benchmark -- run the instantiation without it (2 % faster: 122 vs 128 VGPRs).
-template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE>
+// TEAM = lanes per ray (1, 2, 4) -- *lane teams* for launches with too few rays to fill the GPU (one GPU's tiles of a frame
+// sharded over 4-8 GPUs).  A ray needs one round per sample and a round is a latency chain, so such a launch takes one
+// ray's life (~30 rounds) however few rays it has.  With TEAM lanes per ray, lane k of a team stands k samples ahead of
+// lane 0 (same marching arithmetic, same t values), all evaluate their sample in the same round, then every lane of the
+// team composites the TEAM samples in order (identical float operations => identical accumulators in every lane, the
+// result of the sequential loop bit for bit) and walks TEAM samples on.  Samples past the one that saturates the ray are
+// discarded, as the reference discards the rest of a batch (tn:951-960).  The fill works on 64 / TEAM pixels per packet.
+template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM>
 __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceModel m, const RenderArgs a) {
 	__shared__ RenderSmem<WAVES> sm;
 	for (uint32_t i = threadIdx.x; i < kCoarseWords; i += blockDim.x) sm.coarse[i] = m.occ.mask[i];
-	stage_model_to_lds(m, sm.ml, a.dbg); // (ends with the barrier that also publishes sm.coarse)
+	if (threadIdx.x == 0) { sm.queue = 0ull; sm.sum_samples = 0ull; sm.sum_alive = 0u; sm.sum_hit = 0u; sm.n_finished = 0u; }
+	stage_model_to_lds(m, sm.ml, a.dbg); // (ends with the barrier that also publishes sm.coarse and the words above)
 
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int g = lane >> 5;
+	const int tk = lane & (TEAM - 1), team_base = lane & ~(TEAM - 1); // position in the lane team, its first lane
+	constexpr uint32_t kRaysPerWave = 64 / TEAM;
 	uint4* ring = sm.ring[wave];
 	FeatLds& fl = sm.fl[wave];
 	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count, (const uint4*)m.records);
@@ -114,6 +166,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 
 	// ---- per-lane ray state (registers) ----
 	bool have = false;
+	bool valid = true; // TEAM > 1: this lane's sample exists (the ray has not left the render box before it)
 	f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), idir = mk3(0, 0, 0);
 	float t = 0.f;
 	float cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f; // accumulated premultiplied colour / alpha
@@ -121,7 +174,6 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	uint32_t out_idx = 0, n_steps = 0;
 	// ---- wave-uniform queue state ----
 	uint32_t ring_head = 0, ring_count = 0;
-	uint32_t run_next = 0, run_left = 0;
 	bool more = true;
 	// ---- statistics ----
 	uint32_t st_samples = 0, st_alive = 0, st_hit = 0;
@@ -139,25 +191,19 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		// ---- fill the ring with rays that found an occupied cell (init_rays + advance_pos_nerf) ----
 		// (Measured: moving this into its own lean kernel does not pay -- the DDA's dependent bitfield loads overlap with
 		// other waves' gather/MLP work here for free, while a separate launch adds ~1 ms of serial time at 1080p.)
-		while (more && ring_count < nfree && nfree >= kRefillWhenIdle) {
-			if (run_left == 0) { // claim a run of kPacketRun neighbouring packets
-				uint32_t base = 0;
-				if (lane == 0) base = atomicAdd(&a.counters->next_packet, kPacketRun);
-				run_next = __builtin_amdgcn_readfirstlane(base);
-				run_left = kPacketRun;
-			}
-			const uint32_t pk = run_next;
-			if (pk >= a.n_packets) { more = false; if (PROF) { pf_tq = wall_clock64() - pf_wall0; pf_rounds_q = pf_rounds; } break; }
+		while (more && ring_count < (TEAM > 1 ? kRaysPerWave : nfree) && nfree >= kRefillWhenIdle) {
+			const uint32_t pk = claim_packet(&sm.queue, &a.counters->next_packet, a.n_packets, lane);
+			if (pk == kNoPacket) { more = false; if (PROF) { pf_tq = wall_clock64() - pf_wall0; pf_rounds_q = pf_rounds; } break; }
 			if (PROF) ++pf_packets;
-			++run_next;
-			--run_left;
 			uint32_t x, y, oi;
 			bool alive = false;
 			float t0 = 0.f;
-			if (packet_pixel(a, pk, lane, x, y, oi)) {
+			if (packet_pixel<TEAM>(a, pk, lane, x, y, oi)) {
 				Ray r = init_ray(p, x, y, off_x, off_y);
-				a.depth[oi] = 1e10f; // tn:2586
-				if (a.steps) a.steps[oi] = 0;
+				if (tk == 0) {
+					a.depth[oi] = 1e10f; // tn:2586
+					if (a.steps) a.steps[oi] = 0;
+				}
 				alive = r.alive;
 				uint32_t it_fill = 0;
 				if (alive) alive = first_hit(p, m, sm.coarse, x + (uint32_t)p.resolution[0] * y, r, PROF ? &it_fill : nullptr);
@@ -168,6 +214,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				}
 				t0 = r.t;
 			}
+			if (TEAM > 1) alive = alive && tk == 0; // the lanes of a team found the same ray: one ring entry
 			const unsigned long long am = __ballot(alive);
 			if (alive) {
 				const uint32_t slot = ring_head + ring_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
@@ -181,8 +228,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 
 		// ---- hand pending rays to idle lanes ----
 		if (nfree >= kRefillWhenIdle && ring_count) {
-			const uint32_t take = min(nfree, ring_count);
-			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
+			const uint32_t take = min(TEAM > 1 ? kRaysPerWave : nfree, ring_count);
+			const uint32_t rank = TEAM > 1 ? (uint32_t)lane / TEAM // (all 64 lanes are idle: kRefillWhenIdle)
+			                               : __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
 			if (!have && rank < take) {
 				const uint4 e = ring[(ring_head + rank) & (kRing - 1)];
 				const uint32_t x = e.x & 0xffffu, y = e.x >> 16;
@@ -193,6 +241,14 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				cr = cg = cb = ca = 0.f;
 				ray_depth = 0.f; max_weight = 0.f; n_steps = 0;
 				have = true;
+				if (TEAM > 1) { // lane k of the team walks k samples ahead
+					valid = true;
+					for (int j = 0; j < tk && valid; ++j) {
+						t += calc_dt(t, p.cone_angle_constant);
+						f3 npos; float ndt;
+						valid = march_to_occupied(p, m, sm.coarse, o, d, idir, t, npos, ndt, nullptr);
+					}
+				}
 			}
 			ring_head += take;
 			ring_count -= take;
@@ -215,7 +271,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		const float wdt = warp_dt(dt);
 		bool empty = false;
 		const f3 wpos0 = wpos; // un-deformed sample position (membrane terms live in deformed space)
-		if (ops && have) { // map_rays, last-to-first (tn:2899-2902)
+		const bool act = TEAM > 1 ? (have && valid) : have; // this lane evaluates a sample in this round
+		if (ops && act) { // map_rays, last-to-first (tn:2899-2902)
 			for (int ei = a.n_edits - 1; ei >= 0; --ei) empty |= AFFINE ? edit_warp(a.edits[ei], true, wpos, wdir) : tet_warp(a.edits[ei], true, wpos, wdir);
 		}
 		// ---- membrane correction inputs (compute_poisson_full_residuals, tn:2867-2883) + first network pass (tn:2890-2892) ----
@@ -249,10 +306,11 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		// ---- gather: own sample (block g) and the partner lane's sample (block 1-g), levels 2*it+g ----
 		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
 		const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
-		const bool phave = __shfl_xor((int)have, 32, 64) != 0;
-		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, have, ppos, phave);
+		const bool phave = __shfl_xor((int)act, 32, 64) != 0;
+		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, act, ppos, phave);
 		NRS_PHASE(4); // SH + MLP
-		const half8 sh_own = encode_sh4(g, wdir), sh_par = encode_sh4(g, pdir);
+		half8 sh_own, sh_par;
+		encode_sh4_2(g, wdir, pdir, sh_own, sh_par);
 
 		// ---- fused MLPs on MFMA, one 32-sample block at a time ----
 		uint32_t res_d = 0, res_rg = 0, res_b = 0;
@@ -279,6 +337,81 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		// ---- composite_kernel_nerf body (tn:750-955, Shade mode) + next-sample march ----
 		uint32_t it_march = 0;
 		if (PROF) { pf_walk[4] += (lane == 0) ? 1u : 0u; pf_walk[5] += have ? 1u : 0u; }
+		if constexpr (TEAM > 1) {
+			// this lane's sample, reduced to what compositing needs
+			float s_alpha = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f, s_depth = 0.f;
+			if (act) {
+				const f3 cpos = unwarp_position(wpos, m.aabb);
+				const float sigma = network_to_density(sigma_raw, m.density_activation);
+				s_alpha = 1.f - __expf(-sigma * unwarp_dt(wdt));
+				if (empty) s_alpha = 0.0f;
+				s_r = network_to_rgb(raw_r, m.rgb_activation); s_g = network_to_rgb(raw_g, m.rgb_activation); s_b = network_to_rgb(raw_b, m.rgb_activation);
+				s_depth = dot3(cam_fwd, cpos - cam_o);
+			}
+			// every lane of the team composites the team's samples in marching order (composite_kernel_nerf, tn:750-955)
+			bool done = false, shade = true;
+			#pragma unroll
+			for (int k = 0; k < TEAM; ++k) {
+				const int src = team_base + k;
+				const bool v_k = __shfl((int)act, src, 64) != 0;
+				const float al = __shfl(s_alpha, src, 64), kr = __shfl(s_r, src, 64), kg = __shfl(s_g, src, 64), kb = __shfl(s_b, src, 64);
+				const float kdepth = __shfl(s_depth, src, 64);
+				if (have && !done) {
+					if (!v_k) {
+						done = true; // the walk after the previous sample left the render box
+					} else {
+						const float weight = al * (1.f - ca);
+						cr += kr * weight;
+						cg += kg * weight;
+						cb += kb * weight;
+						ca += weight;
+						if (weight > max_weight) {
+							max_weight = weight;
+							ray_depth = kdepth;
+						}
+						++n_steps;
+						if (tk == 0) ++st_samples;
+						if (ca > (1.0f - p.min_transmittance)) {
+							const float inv_a = __builtin_amdgcn_rcpf(ca);
+							cr *= inv_a; cg *= inv_a; cb *= inv_a; ca = 1.0f;
+							done = true;
+						} else if (n_steps >= a.max_steps) {
+							done = true; shade = false;
+						}
+					}
+				}
+			}
+			if (have && !done) { // on to this lane's next sample, TEAM samples ahead
+				for (int j = 0; j < TEAM && valid; ++j) {
+					t += calc_dt(t, p.cone_angle_constant);
+					f3 npos; float ndt;
+					valid = march_to_occupied(p, m, sm.coarse, o, d, idir, t, npos, ndt, nullptr);
+				}
+			}
+			const bool lead_valid = __shfl((int)valid, team_base, 64) != 0;
+			if (have && !done && !lead_valid) done = true; // no further sample: the ray is finished now rather than a round later
+			if (have && done) {
+				if (tk == 0) {
+					if (shade && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
+						float tr = cr, tg = cg, tb = cb, ta = ca;
+						if (p.render_mode == NRS_RENDER_COST) {
+							const float col = (float)n_steps / 128;
+							tr = tg = tb = col; ta = 1.0f;
+						} else if (!p.linear_colors) {
+							tr = srgb_to_linear(tr); tg = srgb_to_linear(tg); tb = srgb_to_linear(tb);
+						}
+						float4* fb = reinterpret_cast<float4*>(a.frame) + out_idx;
+						const float4 prev = *fb;
+						const float om = 1.0f - ta;
+						*fb = make_float4(tr + prev.x * om, tg + prev.y * om, tb + prev.z * om, ta + prev.w * om);
+						if (ta > 0.2f) a.depth[out_idx] = ray_depth;
+						++st_hit;
+					}
+					if (a.steps) a.steps[out_idx] = n_steps;
+				}
+				have = false;
+			}
+		} else
 		if (have) {
 			const f3 cpos = unwarp_position(wpos, m.aabb);
 			const float T = 1.f - ca;
@@ -371,22 +504,37 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			}
 		}
 	}
-	atomicAdd(&a.counters->n_samples, (unsigned long long)st_samples);
-	atomicAdd(&a.counters->n_rays_alive, st_alive);
-	atomicAdd(&a.counters->n_rays_hit, st_hit);
+	// statistics: per workgroup in LDS, one set of device atomics from the last wave to finish (see claim_packet for why)
+	atomicAdd(&sm.sum_samples, (unsigned long long)st_samples);
+	atomicAdd(&sm.sum_alive, st_alive);
+	atomicAdd(&sm.sum_hit, st_hit);
+	__builtin_amdgcn_wave_barrier();
+	if (lane == 0 && atomicAdd(&sm.n_finished, 1u) == (uint32_t)WAVES - 1u) {
+		atomicAdd(&a.counters->n_samples, __atomic_load_n(&sm.sum_samples, __ATOMIC_RELAXED));
+		atomicAdd(&a.counters->n_rays_hit, __atomic_load_n(&sm.sum_hit, __ATOMIC_RELAXED));
+		// the last workgroup of the launch tells the host which share of the pixels became rays: the next launch sizes its
+		// lane teams with it (nrs_render_nerf).  A heuristic input only -- results do not depend on the team size.  The
+		// returned value orders this workgroup's count before its "done" mark (no fence: a device-scope fence writes the
+		// L2 back, 0.15 ms per launch when 512 workgroups do it over a freshly written frame).
+		const uint32_t before = atomicAdd(&a.counters->n_rays_alive, __atomic_load_n(&sm.sum_alive, __ATOMIC_RELAXED));
+		uint32_t one = 1u;
+		asm volatile("" : "+v"(one) : "v"(before)); // the increment below waits for the count above to have returned
+		if (atomicAdd(&a.counters->blocks_done, one) == gridDim.x - 1u && a.feedback)
+			*a.feedback = (unsigned long long)atomicAdd(&a.counters->n_rays_alive, 0u) | ((unsigned long long)a.pixels_owned << 32);
+	}
 }
 
-template <int WAVES, int OCC, bool PROF = false, bool POISSON = false, bool AFFINE = false>
+template <int WAVES, int OCC, bool PROF = false, bool POISSON = false, bool AFFINE = false, int TEAM = 1>
 static int launch_render_cfg(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream) {
 	int blocks_per_cu = 0;
-	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC, PROF, POISSON, AFFINE>, 64 * WAVES, 0);
+	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC, PROF, POISSON, AFFINE, TEAM>, 64 * WAVES, 0);
 	if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(render_kernel)");
 	if (blocks_per_cu < 1) blocks_per_cu = 1;
 	uint32_t grid = (uint32_t)(n_cus * blocks_per_cu);
 	const uint32_t max_useful = (a.n_packets + WAVES - 1) / WAVES; // at least one packet per wave
 	if (grid > max_useful) grid = max_useful;
 	if (grid == 0) return NRS_OK;
-	hipLaunchKernelGGL((render_kernel<WAVES, OCC, PROF, POISSON, AFFINE>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
+	hipLaunchKernelGGL((render_kernel<WAVES, OCC, PROF, POISSON, AFFINE, TEAM>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
 	NRS_LAUNCH_CHECK("render_kernel launch");
 	return NRS_OK;
 }
@@ -402,6 +550,8 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 	if (a.any_poisson) return launch_render_cfg<8, 2, false, true, true>(m, a, n_cus, s);
 	if (a.any_affine) return launch_render_cfg<8, 3, false, false, true>(m, a, n_cus, s);
 	if (a.dbg & 4u) return launch_render_cfg<8, 4, true>(m, a, n_cus, s);
+	if (a.team == 2) return launch_render_cfg<8, 3, false, false, false, 2>(m, a, n_cus, s);
+	if (a.team == 4) return launch_render_cfg<8, 3, false, false, false, 4>(m, a, n_cus, s);
 	// <8, 3>: __launch_bounds__(512, 3) lets the register allocator aim at 168 VGPRs; it settles at 128 (still 4 waves/SIMD,
 	// the LDS allows 2 workgroups per CU) with a schedule that measures 3-5 % faster than the <8, 4> one (122 VGPRs).
 	switch (cfg) {

@@ -131,6 +131,7 @@ __device__ __forceinline__ CellCoords cell_coords(const LevelParams& lp, f3 pos)
 	c.wx = px - fx; c.wy = py - fy; c.wz = pz - fz;
 	return c;
 }
+typedef float f2 __attribute__((ext_vector_type(2)));
 // dense fast path precondition: no index of the cell reaches `count`, so no wrap and x-neighbours are adjacent entries
 __device__ __forceinline__ bool dense_needs_slow(const LevelParams& lp, const CellCoords& c) {
 	return c.gx >= lp.resolution || c.gy >= lp.resolution || c.gz >= lp.resolution ||
@@ -293,6 +294,36 @@ __device__ __forceinline__ half8 encode_sh4(int g, f3 dir01) {
 	#pragma unroll
 	for (int e = 0; e < 8; ++e) r[e] = (_Float16)o[e];
 	return r;
+}
+
+// The same for two directions (the lane's own sample and its partner's) in packed fp32: every product and sum is the scalar
+// one (+1.7 % on the bench).  The same treatment of the trilinear weights measured -11 %, of the cell coordinates 0.
+__device__ __forceinline__ void encode_sh4_2(int g, f3 dirA, f3 dirB, half8& outA, half8& outB) {
+	const f2 two = {2.f, 2.f}, one = {1.f, 1.f};
+	const f2 x = (f2){dirA.x, dirB.x} * two - one, y = (f2){dirA.y, dirB.y} * two - one, z = (f2){dirA.z, dirB.z} * two - one;
+	const f2 xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+	f2 o[8];
+	if (g == 0) {
+		o[0] = (f2){0.28209479177387814f, 0.28209479177387814f};
+		o[1] = -0.48860251190291987f * y;
+		o[2] = 0.48860251190291987f * z;
+		o[3] = -0.48860251190291987f * x;
+		o[4] = 1.0925484305920792f * xy;
+		o[5] = -1.0925484305920792f * yz;
+		o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+		o[7] = -1.0925484305920792f * xz;
+	} else {
+		o[0] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+		o[1] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+		o[2] = 2.8906114426405538f * xy * z;
+		o[3] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+		o[4] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+		o[5] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+		o[6] = 1.4453057213202769f * z * (x2 - y2);
+		o[7] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+	}
+	#pragma unroll
+	for (int e = 0; e < 8; ++e) { outA[e] = (_Float16)o[e].x; outB[e] = (_Float16)o[e].y; }
 }
 
 // ReLU + fp16 rounding of 8 accumulator rows.  max(round(x), 0) == round(max(x, 0)); done on packed halfs.

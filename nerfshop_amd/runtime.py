@@ -47,6 +47,10 @@ class Context:
         check(self.lib.nrs_ctx_device_info(self.h, name, 256, C.byref(ncu), C.byref(hbm)))
         self.device_name, self.n_cus, self.hbm_bytes = name.value.decode(), ncu.value, hbm.value
 
+    def set_lane_teams(self, lanes_per_ray):
+        """0 = automatic (default), 1 / 2 / 4 = lanes of a wavefront per ray in render launches (nrs_ctx_set_lane_teams)."""
+        check(self.lib.nrs_ctx_set_lane_teams(self.h, int(lanes_per_ray)))
+
     def close(self):
         if self.h:
             self.lib.nrs_ctx_destroy(self.h)
