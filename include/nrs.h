@@ -203,10 +203,11 @@ int         nrs_abi_version(void);
 int  nrs_ctx_create(int device, nrs_ctx** out);
 void nrs_ctx_destroy(nrs_ctx* ctx);
 int  nrs_ctx_device_info(const nrs_ctx* ctx, char* name_out, size_t name_len, int* n_cus, size_t* hbm_bytes);
-/* Lane teams: how many lanes of a wavefront share one ray in nrs_render_nerf.  0 (default) = automatic: 1 for launches
- * that fill the GPU, 2 or 4 when a launch owns so few pixels (one GPU's tiles of a frame sharded over 4-8 GPUs, small
- * viewports) that its duration would otherwise be one ray's latency chain; 1 / 2 / 4 force it.  Pixel values, depth,
- * step counts and statistics do not depend on it (tests/test_gpu_lane_teams.py). */
+/* Lane teams: how many lanes of a wavefront share one ray in nrs_render_nerf.  0 (default) = automatic: 2 or 4 when a
+ * launch owns so few pixels (one GPU's tiles of a frame sharded over 4-8 GPUs, small viewports) that its duration would
+ * otherwise be one ray's latency chain; one lane per ray for launches that fill the GPU, with teams only for the last
+ * eighth of the frame's work queue ("hybrid", whole-image mode).  1 / 2 / 4 force a size for every ray, -1 forces the
+ * hybrid schedule.  Pixel values, depth, step counts and statistics do not depend on it (tests/test_gpu_lane_teams.py). */
 int  nrs_ctx_set_lane_teams(nrs_ctx* ctx, int lanes_per_ray);
 
 int    nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out);

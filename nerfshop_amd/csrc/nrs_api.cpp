@@ -355,8 +355,8 @@ void nrs_ctx_destroy(nrs_ctx* c) {
 	delete c;
 }
 int nrs_ctx_set_lane_teams(nrs_ctx* ctx, int lanes_per_ray) {
-	if (!ctx || !(lanes_per_ray == 0 || lanes_per_ray == 1 || lanes_per_ray == 2 || lanes_per_ray == 4))
-		return fail(NRS_ERR_INVALID_ARG, "nrs_ctx_set_lane_teams: lanes_per_ray must be 0 (automatic), 1, 2 or 4");
+	if (!ctx || !(lanes_per_ray == -1 || lanes_per_ray == 0 || lanes_per_ray == 1 || lanes_per_ray == 2 || lanes_per_ray == 4))
+		return fail(NRS_ERR_INVALID_ARG, "nrs_ctx_set_lane_teams: lanes_per_ray must be 0 (automatic), 1, 2, 4 or -1 (hybrid)");
 	ctx->lane_teams = lanes_per_ray;
 	return NRS_OK;
 }
@@ -1026,11 +1026,16 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		HIP_TRY(hipMemcpyAsync(d_edits_slot, host_edits, sizeof(DeviceEdit) * n_edits, hipMemcpyHostToDevice, s));
 	}
 	a.edits = d_edits_slot;
+	{
+		static const uint32_t dbg = []() { const char* e = getenv("NRS_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
+		a.dbg = dbg;
+	}
 	{ // lane teams (render_kernel's TEAM) when the launch cannot fill the GPU with one ray per lane.  Rays per lane is
 	  // estimated from the share of pixels that became rays in the last finished launch (written by its last workgroup;
 	  // 0.25 until one has finished).  Measured on 1080p lego (0.22 of the pixels hit), frame shares 1/1 .. 1/8, ms per
 	  // launch with 1 / 2 / 4 lanes per ray: 3.09 2.89 3.31 | 2.07 1.78 1.95 | 1.56 1.25 1.21 | 1.19 0.93 0.88; 8 and 16
 	  // lanes lose everywhere (1.07, 1.72 at 1/8); 2560x1440: 4.31 4.52 5.64; aabb-16 1080p (every pixel hits): 9.64 9.76 10.9
+		static const bool hybrid_on = []() { const char* e = getenv("NRS_HYBRID"); return !e || atoi(e) != 0; }();
 		static const int env_forced = []() { const char* e = getenv("NRS_TEAM"); return e ? atoi(e) : 0; }();
 		const int forced = ctx->lane_teams ? ctx->lane_teams : env_forced;
 		const unsigned long long fb = ctx->h_feedback ? __atomic_load_n(ctx->h_feedback, __ATOMIC_RELAXED) : 0ull;
@@ -1041,20 +1046,25 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		// the fill runs once per pixel and lane of a team: keep it to ~8 passes over the GPU (an all-miss 1080p frame is 8)
 		while (team > 1 && (double)team * (double)a.pixels_owned > 8.5 * 64.0 * 16.0 * (double)ctx->n_cus) team >>= 1;
 		if (forced == 1 || forced == 2 || forced == 4) team = (uint32_t)forced;
+		if (forced == -1) team = 1;
 		if (a.any_poisson || a.any_affine) team = 1; // (those instantiations are built for one lane per ray)
 		static const bool log_teams = getenv("NRS_TEAM_LOG") != nullptr;
 		if (log_teams) fprintf(stderr, "[nrs team] pixels=%u hit_share=%.3f rays/lane=%.3f team=%u\n", a.pixels_owned, hit_share, rays_per_lane, team);
 		if (team > 1) {
 			a.team = team;
 			NRS_TRY(tile_geometry(*p, team, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x));
+		} else if (p->tile_size == 0 && !a.any_poisson && !a.any_affine && !(a.dbg & 4u) && (forced == -1 || (!forced && hybrid_on))) {
+			// hybrid: every 8th packet row leaves the 8x8 list and joins the end of the queue as 4x4 tail packets (packet_pixel_bulk/_tail)
+			const uint32_t rows = ((uint32_t)p->resolution[1] + 7u) / 8u, tail_rows = rows / 8u;
+			if (tail_rows) {
+				a.team = 0;
+				a.p_big = (rows - tail_rows) * a.tiles_x;
+				a.n_packets = a.p_big + tail_rows * a.tiles_x * 4u;
+			}
 		}
 		a.feedback = ctx->d_feedback;
 	}
 	a.max_steps = p->max_march_steps ? p->max_march_steps : 10000u; // MARCH_ITER, testbed_nerf.cu:56
-	{
-		static const uint32_t dbg = []() { const char* e = getenv("NRS_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
-		a.dbg = dbg;
-	}
 	a.frame = d_frame;
 	a.depth = d_depth;
 	a.steps = d_steps;

@@ -134,6 +134,28 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 // the common path pays neither its registers nor its code.
 // AFFINE compiles in the AffineDuplication operator (edit_warp's second kind): frames whose operators are all cage
 // deformations -- the common case and the benchmark -- run the instantiation without it (2 % faster: 122 vs 128 VGPRs).
+// Hybrid launches (TEAM == 0, whole-image mode): every 8th packet row of the image is taken out of the 8x8 packet list and
+// appended to the queue as 4x4 packets ("tail" packets, a uniform 1/8 sample of the picture, so about 1/8 of the rays
+// whatever the scene).  Waves that reach them switch to lane teams: the last rays of a frame then take a quarter of a
+// ray's life while the waves still on their last 64-ray generation finish (see render_kernel).
+__device__ __forceinline__ bool packet_pixel_bulk(const RenderArgs& a, uint32_t pk, int lane, uint32_t& x, uint32_t& y, uint32_t& out_idx) {
+	const uint32_t W = (uint32_t)a.p.resolution[0], H = (uint32_t)a.p.resolution[1];
+	const uint32_t rb = pk / a.tiles_x, col = pk % a.tiles_x, row = rb + rb / 7u; // rows 7, 15, ... are tail rows
+	x = col * 8u + ((uint32_t)lane & 7u);
+	y = row * 8u + ((uint32_t)lane >> 3);
+	out_idx = x + W * y;
+	return x < W && y < H;
+}
+__device__ __forceinline__ bool packet_pixel_tail(const RenderArgs& a, uint32_t q, int lane, uint32_t& x, uint32_t& y, uint32_t& out_idx) {
+	const uint32_t W = (uint32_t)a.p.resolution[0], H = (uint32_t)a.p.resolution[1];
+	const uint32_t per_row = a.tiles_x * 4u, trow = q / per_row, s = q % per_row, sy = s / (a.tiles_x * 2u), sx = s % (a.tiles_x * 2u);
+	const uint32_t idx = (uint32_t)lane >> 2; // 4 lanes per pixel, as in packet_pixel<4>
+	x = sx * 4u + (idx & 3u);
+	y = (trow * 8u + 7u) * 8u + sy * 4u + (idx >> 2);
+	out_idx = x + W * y;
+	return x < W && y < H;
+}
+
 // TEAM = lanes per ray (1, 2, 4) -- *lane teams* for launches with too few rays to fill the GPU (one GPU's tiles of a frame
 // sharded over 4-8 GPUs).  A ray needs one round per sample and a round is a latency chain, so such a launch takes one
 // ray's life (~30 rounds) however few rays it has.  With TEAM lanes per ray, lane k of a team stands k samples ahead of
@@ -151,8 +173,10 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int g = lane >> 5;
-	const int tk = lane & (TEAM - 1), team_base = lane & ~(TEAM - 1); // position in the lane team, its first lane
-	constexpr uint32_t kRaysPerWave = 64 / TEAM;
+	// lanes per ray of the current generation: TEAM, or chosen per generation in hybrid launches (TEAM == 0)
+	uint32_t gen_t = TEAM ? (uint32_t)TEAM : 1u;
+	int tk = lane & (int)(gen_t - 1u), team_base = lane & ~(int)(gen_t - 1u); // position in the lane team, its first lane
+	bool tail_seen = false; // TEAM == 0: this wave has reached the queue's tail packets
 	uint4* ring = sm.ring[wave];
 	FeatLds& fl = sm.fl[wave];
 	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count, (const uint4*)m.records);
@@ -191,16 +215,25 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		// ---- fill the ring with rays that found an occupied cell (init_rays + advance_pos_nerf) ----
 		// (Measured: moving this into its own lean kernel does not pay -- the DDA's dependent bitfield loads overlap with
 		// other waves' gather/MLP work here for free, while a separate launch adds ~1 ms of serial time at 1080p.)
-		while (more && ring_count < (TEAM > 1 ? kRaysPerWave : nfree) && nfree >= kRefillWhenIdle) {
+		while (more && ring_count < (TEAM > 1 ? 64u / gen_t : (TEAM == 0 && tail_seen ? 16u : nfree)) && nfree >= kRefillWhenIdle) {
 			const uint32_t pk = claim_packet(&sm.queue, &a.counters->next_packet, a.n_packets, lane);
 			if (pk == kNoPacket) { more = false; if (PROF) { pf_tq = wall_clock64() - pf_wall0; pf_rounds_q = pf_rounds; } break; }
 			if (PROF) ++pf_packets;
 			uint32_t x, y, oi;
 			bool alive = false;
 			float t0 = 0.f;
-			if (packet_pixel<TEAM>(a, pk, lane, x, y, oi)) {
+			bool small = TEAM > 1, inside;
+			if (TEAM == 0 && a.p_big) {
+				small = pk >= a.p_big;
+				tail_seen = tail_seen || small;
+				inside = small ? packet_pixel_tail(a, pk - a.p_big, lane, x, y, oi) : packet_pixel_bulk(a, pk, lane, x, y, oi);
+			} else {
+				inside = packet_pixel<(TEAM ? TEAM : 1)>(a, pk, lane, x, y, oi);
+			}
+			const bool first_of_team = TEAM == 0 ? (!small || (lane & 3) == 0) : tk == 0;
+			if (inside) {
 				Ray r = init_ray(p, x, y, off_x, off_y);
-				if (tk == 0) {
+				if (first_of_team) {
 					a.depth[oi] = 1e10f; // tn:2586
 					if (a.steps) a.steps[oi] = 0;
 				}
@@ -214,7 +247,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				}
 				t0 = r.t;
 			}
-			if (TEAM > 1) alive = alive && tk == 0; // the lanes of a team found the same ray: one ring entry
+			if (TEAM != 1) alive = alive && first_of_team; // the lanes of a team found the same ray: one ring entry
 			const unsigned long long am = __ballot(alive);
 			if (alive) {
 				const uint32_t slot = ring_head + ring_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
@@ -228,9 +261,14 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 
 		// ---- hand pending rays to idle lanes ----
 		if (nfree >= kRefillWhenIdle && ring_count) {
-			const uint32_t take = min(TEAM > 1 ? kRaysPerWave : nfree, ring_count);
-			const uint32_t rank = TEAM > 1 ? (uint32_t)lane / TEAM // (all 64 lanes are idle: kRefillWhenIdle)
-			                               : __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
+			if (TEAM == 0) { // hybrid: full generations until the tail packets, then as many lanes per ray as the pending rays allow
+				gen_t = tail_seen ? (ring_count > 32u ? 1u : (ring_count > 16u ? 2u : 4u)) : 1u;
+				tk = lane & (int)(gen_t - 1u);
+				team_base = lane & ~(int)(gen_t - 1u);
+			}
+			const uint32_t take = min(TEAM != 1 ? 64u / gen_t : nfree, ring_count);
+			const uint32_t rank = TEAM != 1 ? (uint32_t)lane / gen_t // (all 64 lanes are idle: kRefillWhenIdle)
+			                                : __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
 			if (!have && rank < take) {
 				const uint4 e = ring[(ring_head + rank) & (kRing - 1)];
 				const uint32_t x = e.x & 0xffffu, y = e.x >> 16;
@@ -241,7 +279,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				cr = cg = cb = ca = 0.f;
 				ray_depth = 0.f; max_weight = 0.f; n_steps = 0;
 				have = true;
-				if (TEAM > 1) { // lane k of the team walks k samples ahead
+				if (TEAM != 1) { // lane k of the team walks k samples ahead
 					valid = true;
 					for (int j = 0; j < tk && valid; ++j) {
 						t += calc_dt(t, p.cone_angle_constant);
@@ -271,7 +309,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		const float wdt = warp_dt(dt);
 		bool empty = false;
 		const f3 wpos0 = wpos; // un-deformed sample position (membrane terms live in deformed space)
-		const bool act = TEAM > 1 ? (have && valid) : have; // this lane evaluates a sample in this round
+		const bool act = TEAM != 1 ? (have && valid) : have; // this lane evaluates a sample in this round
 		if (ops && act) { // map_rays, last-to-first (tn:2899-2902)
 			for (int ei = a.n_edits - 1; ei >= 0; --ei) empty |= AFFINE ? edit_warp(a.edits[ei], true, wpos, wdir) : tet_warp(a.edits[ei], true, wpos, wdir);
 		}
@@ -337,7 +375,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		// ---- composite_kernel_nerf body (tn:750-955, Shade mode) + next-sample march ----
 		uint32_t it_march = 0;
 		if (PROF) { pf_walk[4] += (lane == 0) ? 1u : 0u; pf_walk[5] += have ? 1u : 0u; }
-		if constexpr (TEAM > 1) {
+		bool team_round = false;
+		if constexpr (TEAM != 1) team_round = gen_t > 1u;
+		if (TEAM != 1 && team_round) {
 			// this lane's sample, reduced to what compositing needs
 			float s_alpha = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f, s_depth = 0.f;
 			if (act) {
@@ -351,7 +391,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			// every lane of the team composites the team's samples in marching order (composite_kernel_nerf, tn:750-955)
 			bool done = false, shade = true;
 			#pragma unroll
-			for (int k = 0; k < TEAM; ++k) {
+			for (int k = 0; k < (TEAM ? TEAM : 4); ++k) {
+				if (TEAM == 0 && k >= (int)gen_t) break;
 				const int src = team_base + k;
 				const bool v_k = __shfl((int)act, src, 64) != 0;
 				const float al = __shfl(s_alpha, src, 64), kr = __shfl(s_r, src, 64), kg = __shfl(s_g, src, 64), kb = __shfl(s_b, src, 64);
@@ -382,7 +423,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				}
 			}
 			if (have && !done) { // on to this lane's next sample, TEAM samples ahead
-				for (int j = 0; j < TEAM && valid; ++j) {
+				for (int j = 0; j < (int)gen_t && valid; ++j) {
 					t += calc_dt(t, p.cone_angle_constant);
 					f3 npos; float ndt;
 					valid = march_to_occupied(p, m, sm.coarse, o, d, idir, t, npos, ndt, nullptr);
@@ -412,7 +453,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				have = false;
 			}
 		} else
-		if (have) {
+		if (have) { // one lane per ray
 			const f3 cpos = unwarp_position(wpos, m.aabb);
 			const float T = 1.f - ca;
 			const float cdt = unwarp_dt(wdt);
@@ -550,6 +591,7 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 	if (a.any_poisson) return launch_render_cfg<8, 2, false, true, true>(m, a, n_cus, s);
 	if (a.any_affine) return launch_render_cfg<8, 3, false, false, true>(m, a, n_cus, s);
 	if (a.dbg & 4u) return launch_render_cfg<8, 4, true>(m, a, n_cus, s);
+	if (a.team == 0) return launch_render_cfg<8, 3, false, false, false, 0>(m, a, n_cus, s);
 	if (a.team == 2) return launch_render_cfg<8, 3, false, false, false, 2>(m, a, n_cus, s);
 	if (a.team == 4) return launch_render_cfg<8, 3, false, false, false, 4>(m, a, n_cus, s);
 	// <8, 3>: __launch_bounds__(512, 3) lets the register allocator aim at 168 VGPRs; it settles at 128 (still 4 waves/SIMD,

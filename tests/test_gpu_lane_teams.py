@@ -18,7 +18,7 @@ def _params(rig, w, h, az, **fields):
 def _render_all(rig, p):
     out = {}
     try:
-        for team in (1, 2, 4, 0):
+        for team in (1, 2, 4, -1, 0):
             rig.ctx.set_lane_teams(team)
             out[team] = rig.render(p)
     finally:
@@ -96,6 +96,24 @@ def test_teams_aabb16(rig16):
         _assert_same(_render_all(rig16, p), "aabb 16, cone stepping")
     finally:
         rig16.use_edit(False)
+
+
+def test_hybrid_at_1080p(rig):
+    """the schedule bench.py runs: full generations, lane teams for the tail rows of the queue (every 8th packet row)"""
+    rig.use_edit(True)
+    try:
+        p = rig.scene.params_for(1920, 1080, 75.0)
+        out = {}
+        try:
+            for team in (1, -1, 0):
+                rig.ctx.set_lane_teams(team)
+                out[team] = rig.render(p)
+        finally:
+            rig.ctx.set_lane_teams(0)
+        _assert_same(out, "1080p hybrid")
+        assert out[1][3].n_samples > 10_000_000
+    finally:
+        rig.use_edit(False)
 
 
 def test_bad_team_size_is_refused(rig):
