@@ -269,6 +269,20 @@ int nrs_density_on_grid(nrs_model* model, void* stream, const uint32_t res3d[3],
                         int mask_with_density_grid, float* d_out);
 int nrs_rgba_on_grid(nrs_model* model, void* stream, const uint32_t res3d[3], const float render_aabb_min[3],
                      const float render_aabb_max[3], const float ray_dir[3], float* d_out_rgba);
+/* Selection tool, first step ("next" row f4) <- GrowingSelection::project_selection_pixels (growing_selection.cu:1832-2035:
+ * shoot_selection_rays_kernel :1673 + NerfNetwork::density + composite_shot_rays :1768), one launch.  For every scribbled
+ * pixel (x, y of `params`' resolution; camera = params->camera_matrix1, focal_length, screen_center, cone_angle_constant)
+ * a ray is stepped through the occupied cells of the model's train box (pixel_to_ray with spp 0, direction not
+ * normalised, up to NERF_STEPS = 1024 samples) while the density composites; the first sample reached with
+ * transmittance <= threshold (the reference's 0.1) gives d_positions[i] (world space) and d_cells[i] =
+ * mip * 128^3 + morton(cell); d_found[i] = 0 and position = aabb_min - 1 when the ray never gets there. */
+int nrs_project_selection_pixels(nrs_model* model, void* stream, const nrs_render_params* params, const int32_t* d_pixels_xy,
+                                 uint32_t n_pixels, float transmittance_threshold, float* d_positions, uint32_t* d_cells, uint8_t* d_found);
+/* host-only bookkeeping that follows (:1964-2021): automatic growing level = highest cascade found, cells below it lifted
+ * to it (get_upper_cell_idx, selection_utils.cu:36), duplicates dropped; outputs in pixel order, sized n. */
+uint32_t nrs_upper_cell_idx(uint32_t cell_idx, uint32_t target_level);
+int nrs_selection_cells(const float* h_positions, const uint32_t* h_cells, const uint8_t* h_found, uint32_t n, int automatic_max_level,
+                        uint32_t* growing_level_inout, uint32_t* out_cells, float* out_positions, uint32_t* n_out);
 /* hash-grid encoding alone (test hook; tcnn Encoding::inference_mixed_precision): d_out [n x 32] fp16 */
 int nrs_hashgrid_encode(nrs_model* model, void* stream, uint32_t n, const float* d_in, uint32_t ld_in,
                         void* d_out_fp16);

@@ -655,6 +655,17 @@ int nrs_rgba_on_grid(nrs_model* m, void* stream, const uint32_t res3d[3], const 
 	NRS_TRY(launch_grid_eval(m->dm, 1, res3d, render_aabb_min, render_aabb_max, dir01, nullptr, d_out_rgba, m->ctx->n_cus, stream));
 	return NRS_OK;
 }
+int nrs_project_selection_pixels(nrs_model* m, void* stream, const nrs_render_params* p, const int32_t* d_pixels_xy, uint32_t n_pixels,
+                                 float transmittance_threshold, float* d_positions, uint32_t* d_cells, uint8_t* d_found) {
+	if (!m || !p || (n_pixels && (!d_pixels_xy || !d_positions || !d_cells || !d_found)))
+		return fail(NRS_ERR_INVALID_ARG, "nrs_project_selection_pixels: NULL argument");
+	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_project_selection_pixels: parameters not set (nrs_model_set_params)");
+	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_project_selection_pixels: occupancy not set (nrs_model_set_density_bitfield/_grid)");
+	if (p->resolution[0] <= 0 || p->resolution[1] <= 0) return fail(NRS_ERR_INVALID_ARG, "nrs_project_selection_pixels: empty resolution");
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	NRS_TRY(launch_selection_rays(m->dm, *p, d_pixels_xy, n_pixels, transmittance_threshold, d_positions, d_cells, d_found, stream));
+	return NRS_OK;
+}
 int nrs_hashgrid_encode(nrs_model* m, void* stream, uint32_t n, const float* d_in, uint32_t ld_in, void* d_out) {
 	int s = check_net(m, d_in, d_out, "nrs_hashgrid_encode");
 	if (s != NRS_OK) return s;

@@ -290,3 +290,54 @@ int nrs_tet_local_rotations(const float* h_vertices, const float* h_original_ver
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Selection bookkeeping after nrs_project_selection_pixels (host; growing_selection.cu:1964-2021, selection_utils.cu:36-48)
+static uint32_t morton_part(uint32_t x) { // tcnn morton3D's expand_bits
+	x = (x * 0x00010001u) & 0xFF0000FFu;
+	x = (x * 0x00000101u) & 0x0F00F00Fu;
+	x = (x * 0x00000011u) & 0xC30C30C3u;
+	x = (x * 0x00000005u) & 0x49249249u;
+	return x;
+}
+static uint32_t morton_compact(uint32_t x) { // tcnn morton3D_invert
+	x = x & 0x49249249u;
+	x = (x | (x >> 2)) & 0xc30c30c3u;
+	x = (x | (x >> 4)) & 0x0f00f00fu;
+	x = (x | (x >> 8)) & 0xff0000ffu;
+	x = (x | (x >> 16)) & 0x0000ffffu;
+	return x;
+}
+extern "C" uint32_t nrs_upper_cell_idx(uint32_t cell_idx, uint32_t target_level) {
+	const uint32_t vol = 128u * 128u * 128u;
+	const uint32_t level = cell_idx / vol, pos = cell_idx % vol;
+	uint32_t x = morton_compact(pos), y = morton_compact(pos >> 1), z = morton_compact(pos >> 2);
+	for (uint32_t i = level; i < target_level; ++i) { x = x / 2 + 32; y = y / 2 + 32; z = z / 2 + 32; }
+	return target_level * vol + (morton_part(x) | (morton_part(y) << 1) | (morton_part(z) << 2));
+}
+extern "C" int nrs_selection_cells(const float* h_positions, const uint32_t* h_cells, const uint8_t* h_found, uint32_t n, int automatic_max_level,
+                                   uint32_t* growing_level, uint32_t* out_cells, float* out_positions, uint32_t* n_out) {
+	if (!growing_level || !n_out || (n && (!h_positions || !h_cells || !h_found || !out_cells || !out_positions))) return NRS_ERR_INVALID_ARG;
+	const uint32_t vol = 128u * 128u * 128u;
+	if (automatic_max_level) { // :1964-1976
+		*growing_level = 0;
+		for (uint32_t i = 0; i < n; ++i)
+			if (h_found[i] && h_cells[i] / vol > *growing_level) *growing_level = h_cells[i] / vol;
+	}
+	std::vector<uint32_t> seen;
+	uint32_t k = 0;
+	for (uint32_t i = 0; i < n; ++i) { // :1983-2021, in pixel order (the reference iterates in the order its atomics compacted the rays)
+		if (!h_found[i]) continue;
+		uint32_t cell = h_cells[i];
+		const uint32_t level = cell / vol;
+		if (level > *growing_level) continue;
+		if (level < *growing_level) cell = nrs_upper_cell_idx(cell, *growing_level);
+		if (std::find(seen.begin(), seen.end(), cell) != seen.end()) continue;
+		seen.push_back(cell);
+		out_cells[k] = cell;
+		for (int c = 0; c < 3; ++c) out_positions[3 * k + c] = h_positions[3 * i + c];
+		++k;
+	}
+	*n_out = k;
+	return NRS_OK;
+}

@@ -142,6 +142,8 @@ int launch_trace_samples(const DeviceModel& m, const nrs_render_params& p, uint3
 // mode 0: full inference (16 channels, c3 = density), 1: density MLP outputs, 2: hash-grid features [n x 32]
 int launch_network(const DeviceModel& m, int mode, uint32_t n, const float* d_in, uint32_t ld_in, void* d_out, uint32_t ld_out,
                    int layout, int n_cus, void* stream);
+int launch_selection_rays(const DeviceModel& m, const nrs_render_params& p, const int32_t* d_pixels, uint32_t n, float threshold,
+                          float* d_positions, uint32_t* d_cells, uint8_t* d_found, void* stream);
 int launch_cell_records(const DeviceModel& m, uint32_t n_levels, void* d_records, void* stream);
 int launch_grid_eval(const DeviceModel& m, int mode, const uint32_t res[3], const float box_mn[3], const float box_mx[3], const float dir01[3],
                      const float* d_density_grid, float* d_out, int n_cus, void* stream);

@@ -646,7 +646,111 @@ struct NetSmem {
 	FeatLds fl[4];
 };
 
-// MODE 0: inference_mixed_precision (16 channels, c3 = density raw), 1: density(), 2: hash-grid features [n x 32]
+// ---- selection rays ------------------------------------------------------------------------------------------------
+// GrowingSelection::project_selection_pixels (growing_selection.cu:1832-2035) in one launch: shoot_selection_rays_kernel
+// (:1673; the ray of pixel_to_ray with spp 0, direction NOT normalised, start at max(t_enter, 0), up to NERF_STEPS samples
+// on occupied cells, no min_mip) -> NerfNetwork::density -> composite_shot_rays (:1768; the first sample REACHED with
+// T <= threshold is the answer: its position after the warp / unwarp round trip and its occupancy cell).  The reference
+// writes every sample, runs the network on all of them and then composites; here a lane owns a ray, the wave evaluates one
+// sample per ray and round, and a ray stops at its answer -- the samples behind it are never needed.
+constexpr uint32_t kNerfSteps = 1024; // NERF_STEPS, common_nerf.h:20
+struct SelectionArgs {
+	nrs_render_params p;
+	const int32_t* pixels; // [n][2]
+	uint32_t n;
+	float threshold;
+	float* positions;      // [n][3]
+	uint32_t* cells;       // [n]
+	uint8_t* found;        // [n]
+};
+__global__ __launch_bounds__(256) void selection_rays_kernel(const DeviceModel m, const SelectionArgs a) {
+	__shared__ NetSmem sm;
+	stage_model_to_lds(m, sm.ml);
+	const int lane = threadIdx.x & 63;
+	const int g = lane >> 5;
+	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count, (const uint4*)m.records);
+	const nrs_render_params& p = a.p;
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	bool have = i < a.n;
+	f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), idir = mk3(0, 0, 0);
+	float t = 0.f, T = 1.f;
+	uint32_t j = 0;
+	if (have) {
+		float off_x, off_y;
+		ld_random_pixel_offset(0u, off_x, off_y);
+		const float W = (float)p.resolution[0], H = (float)p.resolution[1];
+		const float uvx = ((float)a.pixels[2 * i] + off_x) / W, uvy = ((float)a.pixels[2 * i + 1] + off_y) / H;
+		const f3 dir = {(uvx - p.screen_center[0]) * W / p.focal_length[0], (uvy - p.screen_center[1]) * H / p.focal_length[1], 1.0f};
+		const float* cam = p.camera_matrix1;
+		d = mk3((cam[0] * dir.x + cam[3] * dir.y) + cam[6] * dir.z, (cam[1] * dir.x + cam[4] * dir.y) + cam[7] * dir.z,
+		        (cam[2] * dir.x + cam[5] * dir.y) + cam[8] * dir.z);
+		o = mk3(cam[9], cam[10], cam[11]);
+		idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+		float tmin;
+		ray_intersect(m.aabb.mn, m.aabb.mx, o, d, tmin);
+		t = fmaxf(tmin, 0.0f);
+		a.found[i] = 0;
+		a.cells[i] = 0;
+		a.positions[3 * i] = m.aabb.mn[0] - 1.f; a.positions[3 * i + 1] = m.aabb.mn[1] - 1.f; a.positions[3 * i + 2] = m.aabb.mn[2] - 1.f; // :1826
+	}
+	while (__any(have)) {
+		// next sample of the ray (the walk of :1716-1727 / :1754-1765)
+		f3 pos = mk3(0, 0, 0);
+		float dt = 0.f;
+		if (have) {
+			bool at_sample = false;
+			while (j < kNerfSteps) {
+				pos = o + d * t;
+				if (!box_contains(m.aabb, pos)) break;
+				dt = calc_dt(t, p.cone_angle_constant);
+				const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
+				if (density_grid_occupied_at(pos, m.bitfield, mip)) { at_sample = true; break; }
+				t = advance_to_next_voxel(t, p.cone_angle_constant, pos, d, idir, kGrid >> mip, 1.0f / (float)(kGrid >> mip));
+			}
+			if (!at_sample) have = false; // no further sample: transmittance never fell to the threshold (positions stays at the marker)
+		}
+		const f3 wpos = have ? warp_position(pos, m.aabb) : mk3(0, 0, 0);
+		if (have && T <= a.threshold) { // :1802-1809
+			const f3 up = unwarp_position(wpos, m.aabb);
+			a.positions[3 * i] = up.x; a.positions[3 * i + 1] = up.y; a.positions[3 * i + 2] = up.z;
+			const uint32_t level = (uint32_t)mip_from_pos(up);
+			a.cells[i] = level * kGridVol + cascaded_grid_idx_at(up, level);
+			a.found[i] = 1;
+			have = false;
+		}
+		if (!__any(have)) break;
+		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
+		const bool phave = __shfl_xor((int)have, 32, 64) != 0;
+		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, have, ppos, phave);
+		uint32_t res_d = 0;
+		#pragma unroll 1
+		for (int b = 0; b < 2; ++b) {
+			const int sel = (b != g) ? 1 : 0;
+			const half8 dout = density_mlp(sm.ml.w, lane, load_features(fl, lane, sel, 0), load_features(fl, lane, sel, 1));
+			uint32_t vd = __builtin_bit_cast(u32x4, dout)[0];
+			if (b == 1) vd = xchg32u(vd);
+			if (g == b) res_d = vd;
+		}
+		if (have) {
+			const float density = network_to_density((float)__builtin_bit_cast(half2v, res_d)[0], m.density_activation);
+			const float alpha = 1.f - __expf(-density * unwarp_dt(warp_dt(dt))); // (the reference reads dt back from the NerfCoordinate)
+			T *= (1.f - alpha);
+			++j;
+			t += dt;
+		}
+	}
+}
+int launch_selection_rays(const DeviceModel& m, const nrs_render_params& p, const int32_t* d_pixels, uint32_t n, float threshold,
+                          float* d_positions, uint32_t* d_cells, uint8_t* d_found, void* stream) {
+	if (n == 0) return NRS_OK;
+	SelectionArgs a{};
+	a.p = p; a.pixels = d_pixels; a.n = n; a.threshold = threshold; a.positions = d_positions; a.cells = d_cells; a.found = d_found;
+	hipLaunchKernelGGL(selection_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, m, a);
+	NRS_LAUNCH_CHECK("selection_rays_kernel launch");
+	return NRS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Cell records (nrs_model_set_cell_cache): for every cell of a level, its 8 corner entries in corner order (x fastest),
 // fetched with the level's own index function (grid.h:76-95 as restated in level_eval_slow) -- so a record gather returns
@@ -678,6 +782,7 @@ int launch_cell_records(const DeviceModel& m, uint32_t n_levels, void* d_records
 	return hipGetLastError() == hipSuccess ? NRS_OK : NRS_ERR_HIP;
 }
 
+// MODE 0: inference_mixed_precision (16 channels, c3 = density raw), 1: density(), 2: hash-grid features [n x 32]
 template <int MODE>
 __global__ __launch_bounds__(256) void network_kernel(const DeviceModel m, uint32_t n, const float* __restrict__ in, uint32_t ld_in,
                                                       _Float16* __restrict__ out, uint32_t ld_out, int layout) {

@@ -355,6 +355,28 @@ class Testbed:
                                            1 if mask_with_density_grid else 0, out.data_ptr()))
         return out
 
+    def project_selection_pixels(self, params, pixels_xy, transmittance_threshold=0.1, automatic_max_level=True, growing_level=0, stream=None):
+        """GrowingSelection::project_selection_pixels (growing_selection.cu:1832): scribbled pixels -> surface points and the
+        occupancy cells they fall into.  Returns (positions [n, 3], cells [n], found [n]) per pixel plus the de-duplicated
+        (cells, positions, growing_level) the region growing starts from."""
+        px = torch.as_tensor(np.ascontiguousarray(pixels_xy, np.int32).reshape(-1, 2), device=f"cuda:{self.ctx.device}")
+        n = px.shape[0]
+        pos = torch.zeros((n, 3), dtype=torch.float32, device=px.device)
+        cells = torch.zeros((n,), dtype=torch.int32, device=px.device)
+        found = torch.zeros((n,), dtype=torch.uint8, device=px.device)
+        check(self.lib.nrs_project_selection_pixels(self.nerf_network.h, _stream_handle(stream), C.byref(params), px.data_ptr(), n,
+                                                    float(transmittance_threshold), pos.data_ptr(), cells.data_ptr(), found.data_ptr()))
+        if stream is not None:
+            stream.synchronize()
+        else:
+            torch.cuda.synchronize()
+        h_pos, h_cells, h_found = pos.cpu().numpy(), cells.cpu().numpy().view(np.uint32), found.cpu().numpy()
+        level = C.c_uint32(int(growing_level))
+        out_cells, out_pos, n_out = np.zeros(n, np.uint32), np.zeros((n, 3), np.float32), C.c_uint32()
+        check(self.lib.nrs_selection_cells(h_pos.ctypes.data, h_cells.ctypes.data, h_found.ctypes.data, n, 1 if automatic_max_level else 0,
+                                           C.byref(level), out_cells.ctypes.data, out_pos.ctypes.data, C.byref(n_out)))
+        return (h_pos, h_cells, h_found), (out_cells[: n_out.value], out_pos[: n_out.value], level.value)
+
     def get_rgba_on_grid(self, res3d, ray_dir, stream=None):
         """Testbed::get_rgba_on_grid(res3d, ray_dir) (testbed_nerf.cu:4588) over m_render_aabb -> float32 CUDA tensor [rz, ry, rx, 4]"""
         res = (C.c_uint32 * 3)(*[int(v) for v in res3d])

@@ -1417,6 +1417,71 @@ void orc_density_on_grid(void* model, const uint32_t* res, const float* box_mn, 
 		out[i] = v;
 	}
 }
+// GrowingSelection::project_selection_pixels (growing_selection.cu:1832-2035), in the reference's three steps:
+// shoot_selection_rays_kernel (:1673-1766) writes every sample of every ray, NerfNetwork::density runs on all of them,
+// composite_shot_rays (:1768-1829) walks each ray's samples.  Per-pixel outputs (the reference compacts in atomic order).
+// A ray whose transmittance falls to the threshold only behind its LAST sample leaves the reference's output slot unwritten
+// (uninitialised workspace); it is reported as not found here, as in the product.
+void orc_project_selection_pixels(void* model, const nrs_render_params* p, const int32_t* pixels, uint32_t n, float threshold, float* positions,
+                                  uint32_t* cells, uint8_t* found) {
+	const Model& m = *(Model*)model;
+	const uint8_t* grid = m.bitfield.data();
+	float offset[2];
+	ld_random_pixel_offset(0, offset);
+#pragma omp parallel for schedule(dynamic, 16)
+	for (int64_t i = 0; i < (int64_t)n; ++i) {
+		// pixel_to_ray(0, pixel, ...), common_device.cuh:259-284; NOT normalised here
+		const float W = (float)p->resolution[0], H = (float)p->resolution[1];
+		const float uvx = ((float)pixels[2 * i] + offset[0]) / W, uvy = ((float)pixels[2 * i + 1] + offset[1]) / H;
+		const V3 dir = {(uvx - p->screen_center[0]) * W / p->focal_length[0], (uvy - p->screen_center[1]) * H / p->focal_length[1], 1.0f};
+		const float* cam = p->camera_matrix1;
+		const V3 c0 = cam_col(cam, 0), c1 = cam_col(cam, 1), c2 = cam_col(cam, 2);
+		const V3 d = {(c0.x * dir.x + c1.x * dir.y) + c2.x * dir.z, (c0.y * dir.x + c1.y * dir.y) + c2.y * dir.z, (c0.z * dir.x + c1.z * dir.y) + c2.z * dir.z};
+		const V3 o = cam_col(cam, 3);
+		const V3 idir = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+		float tmin, tmax;
+		ray_intersect(m.aabb, o, d, tmin, tmax);
+		const float startt = fmaxf(tmin, 0.0f);
+		// the samples (second pass of the kernel; the first only counts them)
+		std::vector<V3> wpos;
+		std::vector<float> wdt;
+		float t = startt;
+		V3 pos;
+		while (box_contains(m.aabb, pos = o + d * t) && wpos.size() < 1024) {
+			const float dt = calc_dt(t, p->cone_angle_constant);
+			const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
+			if (density_grid_occupied_at(pos, grid, mip)) {
+				wpos.push_back(warp_position(pos, m.aabb));
+				wdt.push_back(warp_dt(dt));
+				t += dt;
+			} else {
+				t = advance_to_next_voxel(t, p->cone_angle_constant, pos, d, idir, GRID >> mip);
+			}
+		}
+		found[i] = 0;
+		cells[i] = 0;
+		positions[3 * i] = m.aabb.mn.x - 1.f; positions[3 * i + 1] = m.aabb.mn.y - 1.f; positions[3 * i + 2] = m.aabb.mn.z - 1.f;
+		// composite_shot_rays
+		float T = 1.f;
+		for (size_t c = 0; c < wpos.size(); ++c) {
+			if (T <= threshold) {
+				const V3 up = unwarp_position(wpos[c], m.aabb);
+				positions[3 * i] = up.x; positions[3 * i + 1] = up.y; positions[3 * i + 2] = up.z;
+				const uint32_t level = (uint32_t)mip_from_pos(up);
+				cells[i] = level * GRIDVOL + cascaded_grid_idx_at(up, level);
+				found[i] = 1;
+				break;
+			}
+			const float in[3] = {wpos[c].x, wpos[c].y, wpos[c].z};
+			uint16_t feat[32], out[16];
+			hashgrid_encode_one(m, in, feat);
+			density_mlp_one(m, feat, out);
+			const float density = network_to_density(h2f(out[0]), m.desc.density_activation);
+			const float alpha = 1.f - expf(-density * unwarp_dt(wdt[c]));
+			T *= (1.f - alpha);
+		}
+	}
+}
 // Testbed::get_rgba_on_grid (tn:4588-4611): generate_grid_samples_nerf_uniform_dir (tn:419-431) -> inference() -> compute_nerf_density (tn:624-635)
 void orc_rgba_on_grid(void* model, const uint32_t* res, const float* box_mn, const float* box_mx, const float* ray_dir, float* out4) {
 	const Model& m = *(Model*)model;

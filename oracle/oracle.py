@@ -57,6 +57,7 @@ def load():
         "orc_pcg32_next_float": (F, [P, C.c_uint64]), "orc_pcg32_advance": (None, [P, C.c_uint64, C.c_uint64]),
         "orc_update_density_grid": (None, [P, P, I, P, P, P]),
         "orc_density_on_grid": (None, [P, P, P, P, P, P]), "orc_rgba_on_grid": (None, [P, P, P, P, P, P]),
+        "orc_project_selection_pixels": (None, [P, P, P, U32, F, P, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -123,6 +124,14 @@ class Model:
         g = np.ascontiguousarray(density_grid, np.float32) if density_grid is not None else None
         self.lib.orc_density_on_grid(self.h, res, mn, mx, g.ctypes.data if g is not None else None, out.ctypes.data)
         return out
+
+    def project_selection_pixels(self, params, pixels_xy, threshold=0.1):
+        px = np.ascontiguousarray(pixels_xy, np.int32).reshape(-1, 2)
+        n = px.shape[0]
+        pos, cells, found = np.zeros((n, 3), np.float32), np.zeros(n, np.uint32), np.zeros(n, np.uint8)
+        self.lib.orc_project_selection_pixels(self.h, C.byref(params), px.ctypes.data, n, C.c_float(threshold), pos.ctypes.data,
+                                              cells.ctypes.data, found.ctypes.data)
+        return pos, cells, found
 
     def rgba_on_grid(self, res3d, box_min, box_max, ray_dir):
         res = (C.c_uint32 * 3)(*res3d)
