@@ -283,6 +283,18 @@ int nrs_project_selection_pixels(nrs_model* model, void* stream, const nrs_rende
 uint32_t nrs_upper_cell_idx(uint32_t cell_idx, uint32_t target_level);
 int nrs_selection_cells(const float* h_positions, const uint32_t* h_cells, const uint8_t* h_found, uint32_t n, int automatic_max_level,
                         uint32_t* growing_level_inout, uint32_t* out_cells, float* out_positions, uint32_t* n_out);
+/* Membrane ("Poisson") boundary values of a proxy cage ("next" row f4) <- GrowingSelection::compute_poisson_boundary
+ * (growing_selection.cu:2220-2348): for every cage vertex, sh_width^2 directions on the sphere (stratified in (u, v) with one
+ * jitter pair per sample -- the reference draws them with std::rand(); here the caller supplies them, [n_verts * sh_width^2][2]
+ * in [0, 1]), the full network at the vertex seen from those directions, then the vertex's density (its first sample; zeroed
+ * where the occupancy is empty when is_inside, filter_empty :2200) and the SH9 fit of the colours (project_sh9, times
+ * 4 pi / n).  h_sh_out: [n_verts][27], SH9RGB column-major (coefficient k of colour c at 9 c + k) -- what the render path's
+ * membrane correction consumes.  Host pointers, synchronous, like the reference.  nrs_poisson_sample_coords is the host half
+ * on its own (the [n][7] network inputs), exported for tests. */
+int  nrs_poisson_boundary(nrs_model* model, const float* h_vertices, uint32_t n_verts, uint32_t sh_width, uint32_t hemisphere_width,
+                          const float* h_jitter, int is_inside, float* h_density_out, float* h_sh_out);
+void nrs_poisson_sample_coords(const float* vertices, uint32_t n_verts, uint32_t sh_width, uint32_t hemisphere_width, const float* jitter,
+                               const float aabb_min[3], const float aabb_max[3], float* coords7_out);
 /* hash-grid encoding alone (test hook; tcnn Encoding::inference_mixed_precision): d_out [n x 32] fp16 */
 int nrs_hashgrid_encode(nrs_model* model, void* stream, uint32_t n, const float* d_in, uint32_t ld_in,
                         void* d_out_fp16);

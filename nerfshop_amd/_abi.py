@@ -125,7 +125,7 @@ EXPORTS = [
     "nrs_model_set_params", "nrs_model_set_cell_cache", "nrs_model_cell_cache_bytes", "nrs_model_set_density_bitfield", "nrs_model_set_density_grid",
     "nrs_model_get_density_bitfield", "nrs_model_get_density_grid", "nrs_model_update_density_grid", "nrs_rng_seed",
     "nrs_network_inference", "nrs_network_density", "nrs_hashgrid_encode", "nrs_density_on_grid", "nrs_rgba_on_grid",
-    "nrs_project_selection_pixels", "nrs_upper_cell_idx", "nrs_selection_cells",
+    "nrs_poisson_boundary", "nrs_poisson_sample_coords", "nrs_project_selection_pixels", "nrs_upper_cell_idx", "nrs_selection_cells",
     "nrs_edit_create", "nrs_edit_create_affine", "nrs_edit_destroy", "nrs_edit_map_rays", "nrs_edit_map_positions",
     "nrs_edit_set_mvc", "nrs_edit_update_cage", "nrs_edit_update_vertices", "nrs_edit_lut_size", "nrs_edit_download",
     "nrs_render_nerf", "nrs_render_owned_tiles", "nrs_detile", "nrs_trace_samples",
@@ -173,6 +173,9 @@ def load():
     lib.nrs_model_level_table.argtypes = [C.POINTER(ModelDesc), P, P, P, P, P]
     lib.nrs_model_set_params.argtypes = [P, P, C.c_size_t]
     lib.nrs_project_selection_pixels.argtypes = [P, P, C.POINTER(RenderParams), P, C.c_uint32, C.c_float, P, P, P]
+    lib.nrs_poisson_boundary.argtypes = [P, P, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_int, P, P]
+    lib.nrs_poisson_sample_coords.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, P, P, P, P]
+    lib.nrs_poisson_sample_coords.restype = None
     lib.nrs_upper_cell_idx.argtypes = [C.c_uint32, C.c_uint32]
     lib.nrs_upper_cell_idx.restype = C.c_uint32
     lib.nrs_selection_cells.argtypes = [P, P, P, C.c_uint32, C.c_int, P, P, P, P]

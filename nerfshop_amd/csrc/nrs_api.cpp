@@ -666,6 +666,56 @@ int nrs_project_selection_pixels(nrs_model* m, void* stream, const nrs_render_pa
 	NRS_TRY(launch_selection_rays(m->dm, *p, d_pixels_xy, n_pixels, transmittance_threshold, d_positions, d_cells, d_found, stream));
 	return NRS_OK;
 }
+// Sampling directions of compute_poisson_boundary (growing_selection.cu:2241-2261), on the host with the host's libm as the
+// reference does; jitter = the two (float)std::rand() / RAND_MAX draws per sample, supplied by the caller.
+void nrs_poisson_sample_coords(const float* vertices, uint32_t n_verts, uint32_t sh_width, uint32_t hemisphere_width, const float* jitter,
+                               const float aabb_min[3], const float aabb_max[3], float* coords7) {
+	const uint32_t n_sh = sh_width * sh_width;
+	for (uint32_t k = 0; k < n_verts; ++k)
+		for (uint32_t i = 0; i < sh_width; ++i)
+			for (uint32_t j = 0; j < sh_width; ++j) {
+				const size_t s = (size_t)n_sh * k + (size_t)i * sh_width + j;
+				const float u = ((float)i + jitter[2 * s]) / (float)(int)hemisphere_width;
+				const float v = ((float)j + jitter[2 * s + 1]) / (float)(int)hemisphere_width;
+				const float theta = (float)(2.f * M_PI * v);
+				const float phi = acosf(2.f * u - 1.f);
+				const float x = cosf(theta) * sinf(phi), y = sinf(theta) * sinf(phi), z = cosf(phi);
+				float* c = coords7 + s * 7;
+				for (int a = 0; a < 3; ++a) c[a] = (vertices[3 * k + a] - aabb_min[a]) / (aabb_max[a] - aabb_min[a]); // warp_position
+				c[3] = 0.f;
+				c[4] = (x + 1.f) * 0.5f; c[5] = (y + 1.f) * 0.5f; c[6] = (z + 1.f) * 0.5f; // warp_direction
+			}
+}
+int nrs_poisson_boundary(nrs_model* m, const float* h_vertices, uint32_t n_verts, uint32_t sh_width, uint32_t hemisphere_width, const float* h_jitter,
+                         int is_inside, float* h_density_out, float* h_sh_out) {
+	if (!m || (n_verts && (!h_vertices || !h_jitter || !h_density_out || !h_sh_out))) return fail(NRS_ERR_INVALID_ARG, "nrs_poisson_boundary: NULL argument");
+	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_poisson_boundary: parameters not set (nrs_model_set_params)");
+	if (is_inside && !m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_poisson_boundary: occupancy not set (nrs_model_set_density_bitfield/_grid)");
+	if (sh_width == 0 || sh_width > 64 || hemisphere_width == 0) return fail(NRS_ERR_INVALID_ARG, "nrs_poisson_boundary: sampling widths out of range (1..64)");
+	if (n_verts == 0) return NRS_OK;
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	const uint32_t n_sh = sh_width * sh_width;
+	const size_t n = (size_t)n_verts * n_sh;
+	if (n > 0x7fffffffull) return fail(NRS_ERR_INVALID_ARG, "nrs_poisson_boundary: too many samples");
+	std::vector<float> coords(n * 7);
+	nrs_poisson_sample_coords(h_vertices, n_verts, sh_width, hemisphere_width, h_jitter, m->dm.aabb.mn, m->dm.aabb.mx, coords.data());
+	float *d_coords = nullptr, *d_density = nullptr, *d_sh = nullptr;
+	void* d_net = nullptr;
+	hipError_t he = hipMalloc((void**)&d_coords, n * 7 * 4);
+	if (he == hipSuccess) he = hipMalloc(&d_net, n * 16 * 2);
+	if (he == hipSuccess) he = hipMalloc((void**)&d_density, (size_t)n_verts * 4);
+	if (he == hipSuccess) he = hipMalloc((void**)&d_sh, (size_t)n_verts * 27 * 4);
+	int rc = NRS_OK;
+	if (he != hipSuccess) rc = fail_hip(he, "nrs_poisson_boundary: device allocation");
+	if (rc == NRS_OK && hipMemcpy(d_coords, coords.data(), n * 7 * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fail(NRS_ERR_HIP, "nrs_poisson_boundary: upload");
+	if (rc == NRS_OK) rc = launch_network(m->dm, 0, (uint32_t)n, d_coords, NRS_NETWORK_INPUT_FLOATS, d_net, 16, NRS_INTERLEAVED, m->ctx->n_cus, nullptr);
+	if (rc == NRS_OK) rc = launch_poisson_fit(m->dm, n_verts, n_sh, d_coords, d_net, is_inside, (float)(4 * M_PI / n_sh), d_density, d_sh, nullptr);
+	if (rc == NRS_OK && (hipMemcpy(h_density_out, d_density, (size_t)n_verts * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+	                     hipMemcpy(h_sh_out, d_sh, (size_t)n_verts * 27 * 4, hipMemcpyDeviceToHost) != hipSuccess))
+		rc = fail(NRS_ERR_HIP, "nrs_poisson_boundary: download");
+	(void)hipFree(d_coords); (void)hipFree(d_net); (void)hipFree(d_density); (void)hipFree(d_sh);
+	return rc;
+}
 int nrs_hashgrid_encode(nrs_model* m, void* stream, uint32_t n, const float* d_in, uint32_t ld_in, void* d_out) {
 	int s = check_net(m, d_in, d_out, "nrs_hashgrid_encode");
 	if (s != NRS_OK) return s;

@@ -144,6 +144,8 @@ int launch_network(const DeviceModel& m, int mode, uint32_t n, const float* d_in
                    int layout, int n_cus, void* stream);
 int launch_selection_rays(const DeviceModel& m, const nrs_render_params& p, const int32_t* d_pixels, uint32_t n, float threshold,
                           float* d_positions, uint32_t* d_cells, uint8_t* d_found, void* stream);
+int launch_poisson_fit(const DeviceModel& m, uint32_t n_verts, uint32_t n_sh, const float* d_coords, const void* d_net, int is_inside, float scale,
+                       float* d_density, float* d_sh, void* stream);
 int launch_cell_records(const DeviceModel& m, uint32_t n_levels, void* d_records, void* stream);
 int launch_grid_eval(const DeviceModel& m, int mode, const uint32_t res[3], const float box_mn[3], const float box_mx[3], const float dir01[3],
                      const float* d_density_grid, float* d_out, int n_cus, void* stream);

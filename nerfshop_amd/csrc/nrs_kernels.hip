@@ -751,6 +751,56 @@ int launch_selection_rays(const DeviceModel& m, const nrs_render_params& p, cons
 	return NRS_OK;
 }
 
+// ---- membrane boundary values -------------------------------------------------------------------------------------
+// The device half of GrowingSelection::compute_poisson_boundary (growing_selection.cu:2220-2348) after the network has run on
+// the n_sh samples of every cage vertex: activate_network_output (:2182), filter_empty (:2200, is_inside only), the vertex's
+// density (its first sample) and the SH9 fit (project_sh9 summed in sample order, times 4 pi / n_sh; sh_utils.cu:30-69).
+// One 64-thread workgroup per vertex; thread c < 27 owns coefficient (k = c % 9, colour = c / 9) and sums it sequentially.
+__global__ __launch_bounds__(64) void poisson_fit_kernel(const DeviceModel m, uint32_t n_sh, const float* __restrict__ coords /* [n][7] */,
+                                                         const _Float16* __restrict__ net /* [n][16] */, int is_inside, float scale,
+                                                         float* __restrict__ density_out, float* __restrict__ sh_out /* [n_verts][27] */) {
+	const uint32_t v = blockIdx.x, c = threadIdx.x;
+	const size_t base = (size_t)v * n_sh;
+	if (c == 0) {
+		float density = network_to_density((float)net[base * 16 + 3], m.density_activation);
+		if (is_inside) {
+			const f3 pos = unwarp_position(mk3(coords[base * 7], coords[base * 7 + 1], coords[base * 7 + 2]), m.aabb);
+			if (!density_grid_occupied_at(pos, m.bitfield, (uint32_t)mip_from_pos(pos))) density = 0.0f;
+		}
+		density_out[v] = density;
+	}
+	if (c >= 27) return;
+	const uint32_t kk = c % 9, col = c / 9;
+	float acc = 0.f;
+	for (uint32_t i = 0; i < n_sh; ++i) {
+		const float* co = coords + (base + i) * 7;
+		const f3 d = unwarp_direction(mk3(co[4], co[5], co[6]));
+		const float rgb = network_to_rgb((float)net[(base + i) * 16 + col], m.rgb_activation);
+		const float x = d.x, y = d.y, z = d.z;
+		float term;
+		switch (kk) { // prefilter.c's constants, rounded to float as the reference's `float c = 0.282095;` does
+			case 0: term = rgb * 0.282095f; break;
+			case 1: term = rgb * (0.488603f * y); break;
+			case 2: term = rgb * (0.488603f * z); break;
+			case 3: term = rgb * (0.488603f * x); break;
+			case 4: term = rgb * (1.092548f * x * y); break;
+			case 5: term = rgb * (1.092548f * y * z); break;
+			case 7: term = rgb * (1.092548f * x * z); break;
+			case 6: term = rgb * (0.315392f * (3 * z * z - 1)); break;
+			default: term = rgb * (0.546274f * (x * x - y * y)); break;
+		}
+		acc += term; // (times domega = 1.0f: exact)
+	}
+	sh_out[(size_t)v * 27 + c] = acc * scale;
+}
+int launch_poisson_fit(const DeviceModel& m, uint32_t n_verts, uint32_t n_sh, const float* d_coords, const void* d_net, int is_inside, float scale,
+                       float* d_density, float* d_sh, void* stream) {
+	if (n_verts == 0) return NRS_OK;
+	hipLaunchKernelGGL(poisson_fit_kernel, dim3(n_verts), dim3(64), 0, (hipStream_t)stream, m, n_sh, d_coords, (const _Float16*)d_net, is_inside, scale, d_density, d_sh);
+	NRS_LAUNCH_CHECK("poisson_fit_kernel launch");
+	return NRS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Cell records (nrs_model_set_cell_cache): for every cell of a level, its 8 corner entries in corner order (x fastest),
 // fetched with the level's own index function (grid.h:76-95 as restated in level_eval_slow) -- so a record gather returns

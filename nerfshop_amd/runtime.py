@@ -377,6 +377,19 @@ class Testbed:
                                            C.byref(level), out_cells.ctypes.data, out_pos.ctypes.data, C.byref(n_out)))
         return (h_pos, h_cells, h_found), (out_cells[: n_out.value], out_pos[: n_out.value], level.value)
 
+    def compute_poisson_boundary(self, vertices, is_inside, jitter, sh_sampling_width=10, hemisphere_width=10):
+        """GrowingSelection::compute_poisson_boundary (growing_selection.cu:2220): per cage vertex the density and the SH9 fit of
+        the colours around it.  jitter: [n_verts * w * w, 2] in [0, 1] (the reference's std::rand() draws).  -> (density [n], sh [n, 27])"""
+        v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+        jt = np.ascontiguousarray(jitter, np.float32)
+        n = v.shape[0]
+        if jt.size != n * sh_sampling_width * sh_sampling_width * 2:
+            raise NrsError("compute_poisson_boundary: jitter must hold two draws per sample")
+        density, sh = np.zeros(n, np.float32), np.zeros((n, 27), np.float32)
+        check(self.lib.nrs_poisson_boundary(self.nerf_network.h, v.ctypes.data, n, int(sh_sampling_width), int(hemisphere_width), jt.ctypes.data,
+                                            1 if is_inside else 0, density.ctypes.data, sh.ctypes.data))
+        return density, sh
+
     def get_rgba_on_grid(self, res3d, ray_dir, stream=None):
         """Testbed::get_rgba_on_grid(res3d, ray_dir) (testbed_nerf.cu:4588) over m_render_aabb -> float32 CUDA tensor [rz, ry, rx, 4]"""
         res = (C.c_uint32 * 3)(*[int(v) for v in res3d])

@@ -1482,6 +1482,55 @@ void orc_project_selection_pixels(void* model, const nrs_render_params* p, const
 		}
 	}
 }
+// GrowingSelection::compute_poisson_boundary (growing_selection.cu:2220-2348); jitter = the (float)std::rand() / RAND_MAX draws.
+void orc_poisson_boundary(void* model, const float* vertices, uint32_t n_verts, uint32_t sh_width, uint32_t hemisphere_width, const float* jitter,
+                          int is_inside, float* density_out, float* sh_out, float* coords_out /* nullable [n][7] */) {
+	const Model& m = *(Model*)model;
+	const uint32_t n_sh = sh_width * sh_width;
+#pragma omp parallel for schedule(dynamic, 4)
+	for (int64_t k = 0; k < (int64_t)n_verts; ++k) {
+		float sh[27] = {0};
+		for (uint32_t i = 0; i < sh_width; ++i)
+			for (uint32_t j = 0; j < sh_width; ++j) {
+				const size_t s = (size_t)n_sh * k + (size_t)i * sh_width + j;
+				float u = ((float)i + jitter[2 * s]) / (float)(int)hemisphere_width;
+				float v = ((float)j + jitter[2 * s + 1]) / (float)(int)hemisphere_width;
+				float theta = (float)(2.f * M_PI * v);
+				float phi = acosf(2.f * u - 1.f);
+				const V3 dir = {cosf(theta) * sinf(phi), sinf(theta) * sinf(phi), cosf(phi)};
+				const V3 wp = warp_position(v3(vertices[3 * k], vertices[3 * k + 1], vertices[3 * k + 2]), m.aabb);
+				const V3 wd = {(dir.x + 1.f) * 0.5f, (dir.y + 1.f) * 0.5f, (dir.z + 1.f) * 0.5f};
+				const float in[7] = {wp.x, wp.y, wp.z, 0.f, wd.x, wd.y, wd.z};
+				if (coords_out) memcpy(coords_out + s * 7, in, sizeof(in));
+				uint16_t out[16];
+				network_inference_one(m, in, out);
+				const float rgb[3] = {network_to_rgb(h2f(out[0]), m.desc.rgb_activation), network_to_rgb(h2f(out[1]), m.desc.rgb_activation),
+				                      network_to_rgb(h2f(out[2]), m.desc.rgb_activation)};
+				if (i == 0 && j == 0) { // target_density[k] = density_host[k * n_sh_samples]
+					float density = network_to_density(h2f(out[3]), m.desc.density_activation);
+					if (is_inside) {
+						const V3 pos = unwarp_position(wp, m.aabb);
+						if (!density_grid_occupied_at(pos, m.bitfield.data(), (uint32_t)mip_from_pos(pos))) density = 0.0f;
+					}
+					density_out[k] = density;
+				}
+				// project_sh9(unwarp_direction(dir), rgb), sh_utils.cu:30-69
+				const V3 d = unwarp_direction(wd);
+				const float x = d.x, y = d.y, z = d.z;
+				for (int col = 0; col < 3; ++col) {
+					float* c9 = sh + 9 * col;
+					float c;
+					c = 0.282095; c9[0] += rgb[col] * c * 1.0f;
+					c = 0.488603; c9[1] += rgb[col] * (c * y) * 1.0f; c9[2] += rgb[col] * (c * z) * 1.0f; c9[3] += rgb[col] * (c * x) * 1.0f;
+					c = 1.092548; c9[4] += rgb[col] * (c * x * y) * 1.0f; c9[5] += rgb[col] * (c * y * z) * 1.0f; c9[7] += rgb[col] * (c * x * z) * 1.0f;
+					c = 0.315392; c9[6] += rgb[col] * (c * (3 * z * z - 1)) * 1.0f;
+					c = 0.546274; c9[8] += rgb[col] * (c * (x * x - y * y)) * 1.0f;
+				}
+			}
+		const float scale = (float)(4 * M_PI / (n_sh));
+		for (int c = 0; c < 27; ++c) sh_out[27 * k + c] = sh[c] * scale;
+	}
+}
 // Testbed::get_rgba_on_grid (tn:4588-4611): generate_grid_samples_nerf_uniform_dir (tn:419-431) -> inference() -> compute_nerf_density (tn:624-635)
 void orc_rgba_on_grid(void* model, const uint32_t* res, const float* box_mn, const float* box_mx, const float* ray_dir, float* out4) {
 	const Model& m = *(Model*)model;

@@ -58,6 +58,7 @@ def load():
         "orc_update_density_grid": (None, [P, P, I, P, P, P]),
         "orc_density_on_grid": (None, [P, P, P, P, P, P]), "orc_rgba_on_grid": (None, [P, P, P, P, P, P]),
         "orc_project_selection_pixels": (None, [P, P, P, U32, F, P, P, P]),
+        "orc_poisson_boundary": (None, [P, P, U32, U32, U32, P, I, P, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -124,6 +125,15 @@ class Model:
         g = np.ascontiguousarray(density_grid, np.float32) if density_grid is not None else None
         self.lib.orc_density_on_grid(self.h, res, mn, mx, g.ctypes.data if g is not None else None, out.ctypes.data)
         return out
+
+    def poisson_boundary(self, vertices, sh_width, hemisphere_width, jitter, is_inside):
+        v = _f32(vertices).reshape(-1, 3)
+        jt = _f32(jitter)
+        n = v.shape[0]
+        density, sh, coords = np.zeros(n, np.float32), np.zeros((n, 27), np.float32), np.zeros((n * sh_width * sh_width, 7), np.float32)
+        self.lib.orc_poisson_boundary(self.h, v.ctypes.data, n, sh_width, hemisphere_width, jt.ctypes.data, 1 if is_inside else 0,
+                                      density.ctypes.data, sh.ctypes.data, coords.ctypes.data)
+        return density, sh, coords
 
     def project_selection_pixels(self, params, pixels_xy, threshold=0.1):
         px = np.ascontiguousarray(pixels_xy, np.int32).reshape(-1, 2)
