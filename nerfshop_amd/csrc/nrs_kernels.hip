@@ -44,7 +44,7 @@ template <int WAVES>
 struct RenderSmem {
 	ModelLds ml;
 	FeatLds fl[WAVES];
-	uint4 ring[WAVES][kRing]; // {x | y << 16, t bits, output index, -}
+	uint2 ring[WAVES][kRing]; // {x | y << 16, t bits}; the output index follows from the pixel (pixel_out_idx)
 	uint32_t coarse[kCoarseWords]; // DeviceModel::coarse_mask (marching shortcut 2)
 	unsigned long long queue;       // the workgroup's chunk of the frame's packet queue: next packet | end << 32 (claim_packet)
 	unsigned long long sum_samples; // statistics of the workgroup's waves, flushed by the last one to finish
@@ -134,6 +134,15 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 // the common path pays neither its registers nor its code.
 // AFFINE compiles in the AffineDuplication operator (edit_warp's second kind): frames whose operators are all cage
 // deformations -- the common case and the benchmark -- run the instantiation without it (2 % faster: 122 vs 128 VGPRs).
+// where pixel (x, y) of this launch lands in the caller's buffers: packet_pixel's out_idx from the pixel alone
+__device__ __forceinline__ uint32_t pixel_out_idx(const RenderArgs& a, uint32_t x, uint32_t y) {
+	if (a.p.tile_size == 0) return x + (uint32_t)a.p.resolution[0] * y;
+	const uint32_t ts = a.p.tile_size, Tx = x / ts, Ty = y / ts, T = Ty * a.tiles_x + Tx;
+	const uint32_t stride = a.p.tile_stride ? a.p.tile_stride : 1;
+	const uint32_t k = (T - a.p.tile_first) / stride;
+	return (k * ts + (y - Ty * ts)) * ts + (x - Tx * ts);
+}
+
 // Hybrid launches (TEAM == 0, whole-image mode): every 8th packet row of the image is taken out of the 8x8 packet list and
 // appended to the queue as 4x4 packets ("tail" packets, a uniform 1/8 sample of the picture, so about 1/8 of the rays
 // whatever the scene).  Waves that reach them switch to lane teams: the last rays of a frame then take a quarter of a
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	uint32_t gen_t = TEAM ? (uint32_t)TEAM : 1u;
 	int tk = lane & (int)(gen_t - 1u), team_base = lane & ~(int)(gen_t - 1u); // position in the lane team, its first lane
 	bool tail_seen = false; // TEAM == 0: this wave has reached the queue's tail packets
-	uint4* ring = sm.ring[wave];
+	uint2* ring = sm.ring[wave];
 	FeatLds& fl = sm.fl[wave];
 	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count, (const uint4*)m.records);
 	const nrs_render_params& p = a.p;
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			const unsigned long long am = __ballot(alive);
 			if (alive) {
 				const uint32_t slot = ring_head + ring_count + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-				ring[slot & (kRing - 1)] = make_uint4(x | (y << 16), __float_as_uint(t0), oi, 0u);
+				ring[slot & (kRing - 1)] = make_uint2(x | (y << 16), __float_as_uint(t0));
 				++st_alive;
 			}
 			ring_count += (uint32_t)__popcll(am);
@@ -270,12 +279,12 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			const uint32_t rank = TEAM != 1 ? (uint32_t)lane / gen_t // (all 64 lanes are idle: kRefillWhenIdle)
 			                                : __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
 			if (!have && rank < take) {
-				const uint4 e = ring[(ring_head + rank) & (kRing - 1)];
+				const uint2 e = ring[(ring_head + rank) & (kRing - 1)];
 				const uint32_t x = e.x & 0xffffu, y = e.x >> 16;
 				ray_origin_dir(p, x, y, off_x, off_y, o, d); // same arithmetic as at enqueue time -> same bits
 				idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 				t = __uint_as_float(e.y);
-				out_idx = e.z;
+				out_idx = pixel_out_idx(a, x, y);
 				cr = cg = cb = ca = 0.f;
 				ray_depth = 0.f; max_weight = 0.f; n_steps = 0;
 				have = true;
