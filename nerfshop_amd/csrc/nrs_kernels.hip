@@ -5,7 +5,12 @@
 //                        the reference's per-iteration launch train + host syncs: no NerfPayload / network
 //                        input / network output arrays exist in HBM; the only traffic is the hash-table gather, the
 //                        occupancy bitfield, the cage tables and one float4 per hit pixel.
+//                        Template parameter TEAM: 1 lane per ray, 2 / 4 lanes per ray (lane teams, for launches that cannot
+//                        fill the GPU), or 0 = hybrid (teams only for the tail of the frame's queue).
 //   network_kernel       NerfNetwork::inference_mixed_precision / density / hash-grid encode on caller batches.
+//   cell_records_kernel  the cell-record cache of the coarse hash-grid levels (nrs_model_set_cell_cache).
+//   grid_eval_kernel     get_density_on_grid / get_rgba_on_grid; grid_refresh / grid_ema: the occupancy refresh.
+//   selection_rays_kernel, poisson_fit_kernel   the selection tool's ray shooting, the membrane boundary fit.
 //   map_rays_kernel      EditOperator::map_rays / map_positions on caller batches.
 //   trace_samples_kernel test hook: the (t, dt) stream of listed pixels.
 //   grid -> bitfield     update_density_grid_mean_and_bitfield.
