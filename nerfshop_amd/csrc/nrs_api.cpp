@@ -1115,8 +1115,11 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 			a.team = team;
 			NRS_TRY(tile_geometry(*p, team, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x));
 		} else if (p->tile_size == 0 && !a.any_poisson && !a.any_affine && !(a.dbg & 4u) && (forced == -1 || (!forced && hybrid_on))) {
-			// hybrid: every 8th packet row leaves the 8x8 list and joins the end of the queue as 4x4 tail packets (packet_pixel_bulk/_tail)
-			const uint32_t rows = ((uint32_t)p->resolution[1] + 7u) / 8u, tail_rows = rows / 8u;
+			// hybrid: every 3rd packet row leaves the 8x8 list and joins the end of the queue as 4x4 tail packets (packet_pixel_bulk/_tail);
+			// measured on 1080p lego + cage, every 2nd / 3rd / 4th / 6th / 8th / 16th row: 8.88 / 8.89 / 8.79 / 8.75 / 8.65 / 8.65 Gsamples/s
+			static const uint32_t tail_every = []() { const char* e = getenv("NRS_TAIL_EVERY"); return e && atoi(e) >= 2 ? (uint32_t)atoi(e) : 3u; }();
+			const uint32_t rows = ((uint32_t)p->resolution[1] + 7u) / 8u, tail_rows = rows / tail_every;
+			a.tail_every = tail_every;
 			if (tail_rows) {
 				a.team = 0;
 				a.p_big = (rows - tail_rows) * a.tiles_x;

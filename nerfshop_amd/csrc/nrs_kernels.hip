@@ -148,13 +148,13 @@ __device__ __forceinline__ uint32_t pixel_out_idx(const RenderArgs& a, uint32_t 
 	return (k * ts + (y - Ty * ts)) * ts + (x - Tx * ts);
 }
 
-// Hybrid launches (TEAM == 0, whole-image mode): every 8th packet row of the image is taken out of the 8x8 packet list and
-// appended to the queue as 4x4 packets ("tail" packets, a uniform 1/8 sample of the picture, so about 1/8 of the rays
+// Hybrid launches (TEAM == 0, whole-image mode): every tail_every-th (3rd) packet row of the image is taken out of the 8x8 packet
+// list and appended to the queue as 4x4 packets ("tail" packets, a uniform sample of the picture, so the same share of the rays
 // whatever the scene).  Waves that reach them switch to lane teams: the last rays of a frame then take a quarter of a
 // ray's life while the waves still on their last 64-ray generation finish (see render_kernel).
 __device__ __forceinline__ bool packet_pixel_bulk(const RenderArgs& a, uint32_t pk, int lane, uint32_t& x, uint32_t& y, uint32_t& out_idx) {
 	const uint32_t W = (uint32_t)a.p.resolution[0], H = (uint32_t)a.p.resolution[1];
-	const uint32_t rb = pk / a.tiles_x, col = pk % a.tiles_x, row = rb + rb / 7u; // rows 7, 15, ... are tail rows
+	const uint32_t rb = pk / a.tiles_x, col = pk % a.tiles_x, row = rb + rb / (a.tail_every - 1u); // every tail_every-th row is a tail row
 	x = col * 8u + ((uint32_t)lane & 7u);
 	y = row * 8u + ((uint32_t)lane >> 3);
 	out_idx = x + W * y;
@@ -165,7 +165,7 @@ __device__ __forceinline__ bool packet_pixel_tail(const RenderArgs& a, uint32_t 
 	const uint32_t per_row = a.tiles_x * 4u, trow = q / per_row, s = q % per_row, sy = s / (a.tiles_x * 2u), sx = s % (a.tiles_x * 2u);
 	const uint32_t idx = (uint32_t)lane >> 2; // 4 lanes per pixel, as in packet_pixel<4>
 	x = sx * 4u + (idx & 3u);
-	y = (trow * 8u + 7u) * 8u + sy * 4u + (idx >> 2);
+	y = (trow * a.tail_every + a.tail_every - 1u) * 8u + sy * 4u + (idx >> 2);
 	out_idx = x + W * y;
 	return x < W && y < H;
 }
