@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		// ---- fill the ring with rays that found an occupied cell (init_rays + advance_pos_nerf) ----
 		// (Measured: moving this into its own lean kernel does not pay -- the DDA's dependent bitfield loads overlap with
 		// other waves' gather/MLP work here for free, while a separate launch adds ~1 ms of serial time at 1080p.)
-		while (more && ring_count < (TEAM > 1 ? 64u / gen_t : (TEAM == 0 && tail_seen ? 16u : nfree)) && nfree >= kRefillWhenIdle) {
+		while (more && ring_count < (TEAM > 1 ? 64u / gen_t : (TEAM == 0 && tail_seen ? a.tail_target : nfree)) && nfree >= kRefillWhenIdle) {
 			const uint32_t pk = claim_packet(&sm.queue, &a.counters->next_packet, a.n_packets, lane);
 			if (pk == kNoPacket) { more = false; if (PROF) { pf_tq = wall_clock64() - pf_wall0; pf_rounds_q = pf_rounds; } break; }
 			if (PROF) ++pf_packets;
