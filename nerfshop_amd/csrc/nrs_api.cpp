@@ -54,6 +54,8 @@ struct nrs_ctx {
 	unsigned long long* d_wave_log = nullptr; // profiling only (NRS_DEBUG & 4)
 	unsigned long long* h_feedback = nullptr; // pinned, device-visible: written by the last workgroup of a render launch
 	unsigned long long* d_feedback = nullptr; // its device address
+	std::vector<DeviceEdit> edits_shadow = std::vector<DeviceEdit>((size_t)kInFlight * 32); // what each slot of d_edits holds
+	int shadow_n[kInFlight] = {-1, -1, -1, -1, -1, -1, -1, -1};
 	static constexpr int kMaxEdits = 32;
 };
 
@@ -599,6 +601,7 @@ int nrs_model_update_density_grid(nrs_model* m, nrs_edit* const* edits, int n_ed
 		}
 		HIP_TRY(hipMemcpyAsync(ctx->d_edits, host_edits, sizeof(DeviceEdit) * n_edits, hipMemcpyHostToDevice, s));
 		HIP_TRY(hipStreamSynchronize(s)); // host_edits is a stack array
+		ctx->shadow_n[0] = -1; // (slot 0 of the render launches' operator tables was overwritten)
 	}
 	if (u->reset_grid) HIP_TRY(hipMemsetAsync(m->d_density_grid, 0, grid_bytes, s));
 	HIP_TRY(hipMemsetAsync(m->d_density_tmp, 0, grid_bytes, s));
@@ -1084,7 +1087,13 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 			a.any_poisson |= edits[i]->de.apply_poisson;
 			a.any_affine |= (edits[i]->de.kind == kEditAffine) ? 1u : 0u;
 		}
-		HIP_TRY(hipMemcpyAsync(d_edits_slot, host_edits, sizeof(DeviceEdit) * n_edits, hipMemcpyHostToDevice, s));
+		// the operator table of a slot is re-sent only when it changed (a viewer renders many frames per gizmo move)
+		DeviceEdit* shadow = ctx->edits_shadow.data() + (size_t)slot * nrs_ctx::kMaxEdits;
+		if (ctx->shadow_n[slot] != n_edits || memcmp(shadow, host_edits, sizeof(DeviceEdit) * n_edits) != 0) {
+			HIP_TRY(hipMemcpyAsync(d_edits_slot, host_edits, sizeof(DeviceEdit) * n_edits, hipMemcpyHostToDevice, s));
+			memcpy(shadow, host_edits, sizeof(DeviceEdit) * n_edits);
+			ctx->shadow_n[slot] = n_edits;
+		}
 	}
 	a.edits = d_edits_slot;
 	{
