@@ -14,6 +14,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "nrs_internal.h"
@@ -324,7 +325,7 @@ extern "C" int nrs_selection_cells(const float* h_positions, const uint32_t* h_c
 		for (uint32_t i = 0; i < n; ++i)
 			if (h_found[i] && h_cells[i] / vol > *growing_level) *growing_level = h_cells[i] / vol;
 	}
-	std::vector<uint32_t> seen;
+	std::unordered_set<uint32_t> seen;
 	uint32_t k = 0;
 	for (uint32_t i = 0; i < n; ++i) { // :1983-2021, in pixel order (the reference iterates in the order its atomics compacted the rays)
 		if (!h_found[i]) continue;
@@ -332,8 +333,7 @@ extern "C" int nrs_selection_cells(const float* h_positions, const uint32_t* h_c
 		const uint32_t level = cell / vol;
 		if (level > *growing_level) continue;
 		if (level < *growing_level) cell = nrs_upper_cell_idx(cell, *growing_level);
-		if (std::find(seen.begin(), seen.end(), cell) != seen.end()) continue;
-		seen.push_back(cell);
+		if (!seen.insert(cell).second) continue;
 		out_cells[k] = cell;
 		for (int c = 0; c < 3; ++c) out_positions[3 * k + c] = h_positions[3 * i + c];
 		++k;

@@ -1,6 +1,8 @@
 """Timings of the SURVEY 8(f) "next" rows on the device, with the CPU path beside them (one JSON line each):
   cage_move        nrs_edit_update_cage  (MVC apply + bbox + cell->tet LUT + rotations)   vs  libnrs's threaded host builder
   occupancy_refresh nrs_model_update_density_grid (128^3 * (max_cascade+1) samples)        vs  the oracle (OpenMP) on the host
+  selection_rays   nrs_project_selection_pixels (scribble pixels -> surface points)         vs  the oracle's three-step restatement
+  poisson_boundary nrs_poisson_boundary (cage vertices x 100 directions -> density + SH9)   vs  the oracle
 Run on the GPU box:  python profiles/bench_next_rows.py [--lattice 10 20] [--reps 20]
 """
 import argparse
@@ -82,6 +84,47 @@ def main():
         print(json.dumps({"row": "occupancy_refresh", "aabb_scale": aabb_scale, "samples": n, "gpu_ms_per_iteration": round(gpu_ms, 3),
                           "gpu_msamples_per_s": round(n / gpu_ms / 1e3, 1), "cpu_oracle_ms_per_iteration": cpu_ms and round(cpu_ms, 1),
                           "cpu_threads": orc.load().orc_max_threads()}))
+
+    # ---- selection rays / membrane boundary ----
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest
+    scene = conftest.Scene(aabb_scale=1, with_edit=False)
+    tb = runtime.Testbed(ctx, scene.desc, 1)
+    tb.nerf_network.set_params(scene.params)
+    tb.nerf_network.set_density_bitfield(scene.bitfield)
+    for n_px in (3000, 100000):
+        w, h = 1920, 1080
+        p = scene.params_for(w, h, 50.0)
+        rng = np.random.default_rng(1)
+        px = np.stack([rng.integers(w // 4, 3 * w // 4, n_px), rng.integers(h // 4, 3 * h // 4, n_px)], 1).astype(np.int32)
+        tb.project_selection_pixels(p, px)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            (pos, cells, found), _sel = tb.project_selection_pixels(p, px)
+        gpu_ms = (time.perf_counter() - t0) * 1e3 / 5
+        cpu_ms = None
+        if not a.no_cpu:
+            t0 = time.perf_counter()
+            scene.oracle_model.project_selection_pixels(p, px)
+            cpu_ms = (time.perf_counter() - t0) * 1e3
+        print(json.dumps({"row": "selection_rays", "pixels": n_px, "found": int(found.sum()), "gpu_ms_end_to_end": round(gpu_ms, 3),
+                          "cpu_ms": None if cpu_ms is None else round(cpu_ms, 1), "cpu_threads": orc.max_threads() if hasattr(orc, "max_threads") else None}), flush=True)
+    for n_v in (300, 3000):
+        rng = np.random.default_rng(2)
+        v = rng.uniform(0.3, 0.7, size=(n_v, 3)).astype(np.float32)
+        jitter = rng.uniform(0, 1, size=(n_v * 100, 2)).astype(np.float32)
+        tb.compute_poisson_boundary(v, True, jitter)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            tb.compute_poisson_boundary(v, True, jitter)
+        gpu_ms = (time.perf_counter() - t0) * 1e3 / 5
+        cpu_ms = None
+        if not a.no_cpu:
+            t0 = time.perf_counter()
+            scene.oracle_model.poisson_boundary(v, 10, 10, jitter, True)
+            cpu_ms = (time.perf_counter() - t0) * 1e3
+        print(json.dumps({"row": "poisson_boundary", "vertices": n_v, "samples": n_v * 100, "gpu_ms_end_to_end": round(gpu_ms, 3),
+                          "cpu_ms": None if cpu_ms is None else round(cpu_ms, 1)}), flush=True)
 
 
 if __name__ == "__main__":
