@@ -1110,7 +1110,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		const int forced = ctx->lane_teams ? ctx->lane_teams : env_forced;
 		const unsigned long long fb = ctx->h_feedback ? __atomic_load_n(ctx->h_feedback, __ATOMIC_RELAXED) : 0ull;
 		const double hit_share = (fb >> 32) ? (double)(uint32_t)fb / (double)(fb >> 32) : 0.25;
-		a.pixels_owned = a.n_packets * 64u;
+		a.pixels_owned = (uint32_t)std::min<uint64_t>((uint64_t)a.n_packets * 64ull, 0xffffffffull);
 		const double rays_per_lane = hit_share * (double)a.pixels_owned / (64.0 * 16.0 * (double)ctx->n_cus);
 		uint32_t team = rays_per_lane <= 0.55 ? 4u : (rays_per_lane <= 4.5 ? 2u : 1u);
 		// the fill runs once per pixel and lane of a team: keep it to ~8 passes over the GPU (an all-miss 1080p frame is 8)
