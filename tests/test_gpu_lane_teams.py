@@ -116,6 +116,18 @@ def test_hybrid_at_1080p(rig):
         rig.use_edit(False)
 
 
+@pytest.mark.parametrize("size", [(8, 8), (9, 25), (64, 24), (173, 131), (7, 3), (331, 47)])
+def test_odd_resolutions(rig, size):
+    """packet geometry of every schedule at sizes that are not multiples of the packet shapes (8x8, 8x4, 4x4; tail rows of the hybrid)"""
+    rig.use_edit(False)
+    p = rig.scene.params_for(size[0], size[1], 35.0)
+    out = _render_all(rig, p)
+    ref = out[1]
+    for team, (frame, depth, steps, stats) in out.items():
+        assert np.array_equal(frame.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(depth.view(np.uint32), ref[1].view(np.uint32)), (size, team)
+        assert np.array_equal(steps, ref[2]) and stats.n_samples == ref[3].n_samples and stats.n_rays_alive == ref[3].n_rays_alive, (size, team)
+
+
 def test_bad_team_size_is_refused(rig):
     from nerfshop_amd import _abi
     with pytest.raises(_abi.NrsError):
