@@ -207,7 +207,7 @@ int  nrs_ctx_device_info(const nrs_ctx* ctx, char* name_out, size_t name_len, in
  * launch owns so few pixels (one GPU's tiles of a frame sharded over 4-8 GPUs, small viewports) that its duration would
  * otherwise be one ray's latency chain; one lane per ray for launches that fill the GPU, with teams only for the last
  * third of the frame's work queue ("hybrid", whole-image mode).  1 / 2 / 4 force a size for every ray, -1 forces the
- * hybrid schedule.  Pixel values, depth, step counts and statistics do not depend on it (tests/test_gpu_lane_teams.py). */
+ * hybrid schedule, -2 the small-launch schedule (4x4-pixel packets, team size chosen per generation).  Pixel values, depth, step counts and statistics do not depend on it (tests/test_gpu_lane_teams.py). */
 int  nrs_ctx_set_lane_teams(nrs_ctx* ctx, int lanes_per_ray);
 
 int    nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out);

@@ -237,7 +237,11 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			bool alive = false;
 			float t0 = 0.f;
 			bool small = TEAM > 1, inside;
-			if (TEAM == 0 && a.p_big) {
+			if (TEAM == 0 && a.all_tail) { // a launch of 4x4 packets only (few rays for the GPU): every generation sizes its teams
+				small = true;
+				tail_seen = true;
+				inside = packet_pixel<4>(a, pk, lane, x, y, oi);
+			} else if (TEAM == 0 && a.p_big) {
 				small = pk >= a.p_big;
 				tail_seen = tail_seen || small;
 				inside = small ? packet_pixel_tail(a, pk - a.p_big, lane, x, y, oi) : packet_pixel_bulk(a, pk, lane, x, y, oi);

@@ -18,7 +18,7 @@ def _params(rig, w, h, az, **fields):
 def _render_all(rig, p):
     out = {}
     try:
-        for team in (1, 2, 4, -1, 0):
+        for team in (1, 2, 4, -1, -2, 0):
             rig.ctx.set_lane_teams(team)
             out[team] = rig.render(p)
     finally:
@@ -69,7 +69,7 @@ def test_teams_on_tiles(rig):
             torch = rig.torch
             got = {}
             try:
-                for team in (1, 2, 4):
+                for team in (1, 2, 4, -2, 0):
                     rig.ctx.set_lane_teams(team)
                     from nerfshop_amd import _abi
                     import ctypes as C
@@ -82,7 +82,7 @@ def test_teams_on_tiles(rig):
             finally:
                 rig.ctx.set_lane_teams(0)
             assert got[1][2] > 0
-            for team in (2, 4):
+            for team in (2, 4, -2, 0):
                 assert np.array_equal(got[team][0].view(np.uint32), got[1][0].view(np.uint32)), (first, stride, team)
                 assert np.array_equal(got[team][1].view(np.uint32), got[1][1].view(np.uint32)) and got[team][2] == got[1][2]
     finally:
