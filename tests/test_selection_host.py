@@ -41,3 +41,24 @@ def test_selection_cells_lifts_to_the_highest_cascade(built):
     _abi.check(lib.nrs_selection_cells(pos.ctypes.data, cells.ctypes.data, found.ctypes.data, 5, 0, C.byref(level), out_c.ctypes.data,
                                        out_p.ctypes.data, C.byref(n_out)))
     assert n_out.value == 3 and out_c[:3].tolist() == [m(10, 20, 30), m(11, 21, 31), m(100, 100, 100)]
+
+
+def test_poisson_sample_coords_match_oracle(scene):
+    """host half of nrs_poisson_boundary (growing_selection.cu:2241-2261): the network inputs, bit for bit the oracle's"""
+    import ctypes as C
+    n, w = 50, 10
+    rng = np.random.default_rng(12)
+    v = rng.uniform(0.1, 0.9, size=(n, 3)).astype(np.float32)
+    jitter = rng.uniform(0, 1, size=(n * w * w, 2)).astype(np.float32)
+    coords = np.zeros((n * w * w, 7), np.float32)
+    mn, mx = (C.c_float * 3)(*scene.desc.aabb_min), (C.c_float * 3)(*scene.desc.aabb_max)
+    _abi.load().nrs_poisson_sample_coords(v.ctypes.data, n, w, w, jitter.ctypes.data, mn, mx, coords.ctypes.data)
+    _, _, ref = scene.oracle_model.poisson_boundary(v, w, w, jitter, False)
+    assert np.array_equal(coords.view(np.uint32), ref.view(np.uint32))
+    d = coords[:, 4:7] * 2 - 1
+    assert np.abs(np.linalg.norm(d, axis=1) - 1).max() < 1e-5
+    # stratification: cell (i, j) of the 10 x 10 grid in (u, v) holds exactly one sample per vertex
+    u = (d[:, 2] + 1) / 2                     # z = cos(phi) = 2u - 1
+    th = np.mod(np.arctan2(d[:, 1], d[:, 0]), 2 * np.pi) / (2 * np.pi)
+    cells = (np.minimum((u * w).astype(int), w - 1) * w + np.minimum((th * w).astype(int), w - 1)).reshape(n, w * w)
+    assert (np.sort(cells, axis=1) == np.arange(w * w)).mean() > 0.97   # (rounding at cell borders aside)
