@@ -1030,11 +1030,10 @@ static int tile_geometry(const nrs_render_params& p, uint32_t team, uint32_t& ti
 	const uint32_t W = (uint32_t)p.resolution[0], H = (uint32_t)p.resolution[1];
 	const uint32_t pw = team >= 16 ? 2u : (team >= 4 ? 4u : 8u), ph = 64u / team / pw; // packet_pixel<TEAM>()
 	if (p.tile_size == 0) {
-		const uint32_t side_x = pw * kRunSide, side_y = ph * kRunSide; // super-tiles of kPacketRun packets (Morton order inside)
-		tiles_x = (W + side_x - 1) / side_x;
+		tiles_x = (W + pw - 1) / pw; // packets per image row
 		owned = 1;
 		ppt_x = 0;
-		n_packets = tiles_x * ((H + side_y - 1) / side_y) * kPacketRun;
+		n_packets = tiles_x * ((H + ph - 1) / ph);
 		return NRS_OK;
 	}
 	if (p.tile_size % 8) return fail(NRS_ERR_INVALID_ARG, "tile_size must be a multiple of 8");

@@ -14,10 +14,6 @@ constexpr uint32_t kLevels = 16;
 constexpr uint32_t kCoarse = 32;                // blocks per axis of the occupancy look-ahead mask
 constexpr uint32_t kCoarseWords = kCoarse * kCoarse * kCoarse / 32;
 static_assert((kCoarse & (kCoarse - 1)) == 0, "the block walk's bounds test (cx | cy | cz) needs a power of two");
-// Packets (8x8 pixels) a wave claims from the frame's work queue at a time; in whole-image mode they form one
-// kRunSide x kRunSide block of packets (Morton order).  Larger runs = more coherent gathers but coarser load balance.
-constexpr uint32_t kPacketRun = 1;
-constexpr uint32_t kRunSide = 1;  // sqrt(kPacketRun)
 constexpr uint32_t kDensityW = 64 * 32 + 16 * 64;           // density MLP params (base.json:30-36)
 constexpr uint32_t kRgbW = 64 * 32 + 64 * 64 + 16 * 64;     // rgb MLP params (base.json:52-58)
 

@@ -100,11 +100,9 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 	const uint32_t idx = (uint32_t)lane / TEAM;
 	const uint32_t lx = idx % PW, ly = idx / PW;
 	if (a.p.tile_size == 0) {
-		// whole image: super-tiles of kPacketRun packets in Morton order, so that the run of packets a wave claims (and with
-		// it the rays it marches together) stays spatially compact -> fewer distinct cache lines per gather
-		const uint32_t tile = pk / kPacketRun, sub = pk % kPacketRun;
-		const uint32_t bx = (tile % a.tiles_x) * kRunSide + ((sub & 1u) | ((sub >> 1) & 2u));
-		const uint32_t by = (tile / a.tiles_x) * kRunSide + (((sub >> 1) & 1u) | ((sub >> 2) & 2u));
+		// whole image: packets in row-major order (runs of neighbouring packets per claim were measured and lose: a wave's
+		// unstarted packets are invisible to idle waves)
+		const uint32_t bx = pk % a.tiles_x, by = pk / a.tiles_x;
 		x = bx * PW + lx;
 		y = by * PH + ly;
 		out_idx = x + W * y;
