@@ -60,6 +60,15 @@ def test_teams_with_low_opacity_and_step_cap(rig):
             assert stats.n_samples == ref[3].n_samples, (cap, team)
 
 
+def test_teams_in_cost_mode_and_with_jittered_pixels(rig):
+    """ERenderMode::Cost (step counts as colour) and a non-zero spp index (Sobol pixel offsets, accumulation into the frame)"""
+    from nerfshop_amd import _abi
+    p = _params(rig, 256, 144, 70.0, render_mode=_abi.RENDER_COST)
+    _assert_same(_render_all(rig, p), "cost mode")
+    p = _params(rig, 256, 144, 70.0, spp_index=5, snap_to_pixel_centers=0)
+    _assert_same(_render_all(rig, p), "spp 5, jittered")
+
+
 def test_teams_on_tiles(rig):
     """one rank's tiles of a sharded frame (the case lane teams exist for), against the same tiles with one lane per ray"""
     rig.use_edit(True)
