@@ -311,6 +311,12 @@ __device__ __forceinline__ float coarse_safe_until(const DeviceModel& m, const u
 // none of the tests whose outcome is known there -- inside the render box (t_safe is clipped to it), cell empty.  The
 // lean loop hands over BEFORE a step could land beyond t_safe; the full loop then re-enters at a t it would have reached
 // itself, so the (t, dt) stream stays bit-identical (tests/test_gpu_parity.py compares it against the oracle).
+// The look-ahead of shortcut 2 is repeated every kLookEvery empty cells of a walk, not only at its first: a ray that leaves
+// the object through blocks that are marked (they touch the surface) but empty along its path used to walk on, cell by cell
+// with a full test each, until it left the occupied bounds; a few cells on, nothing is marked ahead any more and it can be
+// retired at once (or lean-walked to the next marked block).  Measured (Gsamples/s, lego + cage edit; ms for a 64x40-pixel
+// frame): once per walk 9.0 / 0.84, every 3rd cell 9.43 / 0.58, 6th 9.92 / 0.56, 10th 9.80 / 0.55, 16th 9.82 / 0.58, 32nd 9.54 / 0.65.
+constexpr int kLookEvery = 6;
 __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, const DeviceModel& m, const uint32_t* __restrict__ coarse_mask, f3 o, f3 d,
                                                   f3 idir, float& t, f3& pos, float& dt, uint32_t* n_iter = nullptr) {
 	const uint8_t* __restrict__ bitfield = m.bitfield;
@@ -319,7 +325,7 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 	#pragma unroll
 	for (int i = 0; i < 3; ++i) { bb.mn[i] = p.render_aabb_min[i]; bb.mx[i] = p.render_aabb_max[i]; }
 	const float cone = p.cone_angle_constant;
-	bool looked_ahead = false;
+	int until_look = 0; // trips until the next look-ahead
 	while (1) {
 		if (n_iter) ++*n_iter; // profiling build only
 		pos = o + d * t;
@@ -331,8 +337,8 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 		} else if (!ray_meets_box_ahead(occ_box, o, idir, t)) {
 			return false;
 		}
-		if (!looked_ahead) {
-			looked_ahead = true;
+		if (until_look-- == 0) {
+			until_look = kLookEvery;
 			float t_safe = coarse_safe_until(m, coarse_mask, o, d, idir, t);
 			if (t_safe < 0.f) return false;
 			{ // clip to the exit of the render box: the lean loop carries no containment test
