@@ -902,12 +902,13 @@ void affine_finish(const HostAffineBox& b, AffineBox& out) {
 		out.u[i] = b.rot[i] * b.scale[0];
 		out.v[i] = b.rot[3 + i] * b.scale[1];
 		out.w[i] = b.rot[6 + i] * b.scale[2];
-		out.mn[i] = (((-0.5f * b.rot[i]) * b.scale[0] + (-0.5f * b.rot[3 + i]) * b.scale[1]) + (-0.5f * b.rot[6 + i]) * b.scale[2]) + b.center[i];
+		// Eigen's 3-term reduction order x0 + (x1 + x2) in every small product / dot (Redux.h complete unrolling; see nrs_device.cuh)
+		out.mn[i] = ((-0.5f * b.rot[i]) * b.scale[0] + ((-0.5f * b.rot[3 + i]) * b.scale[1] + (-0.5f * b.rot[6 + i]) * b.scale[2])) + b.center[i];
 		out.center[i] = b.center[i];
 	}
-	out.uu = (out.u[0] * out.u[0] + out.u[1] * out.u[1]) + out.u[2] * out.u[2];
-	out.vv = (out.v[0] * out.v[0] + out.v[1] * out.v[1]) + out.v[2] * out.v[2];
-	out.ww = (out.w[0] * out.w[0] + out.w[1] * out.w[1]) + out.w[2] * out.w[2];
+	out.uu = out.u[0] * out.u[0] + (out.u[1] * out.u[1] + out.u[2] * out.u[2]);
+	out.vv = out.v[0] * out.v[0] + (out.v[1] * out.v[1] + out.v[2] * out.v[2]);
+	out.ww = out.w[0] * out.w[0] + (out.w[1] * out.w[1] + out.w[2] * out.w[2]);
 }
 void affine_warp_box(HostAffineBox& b, const Box3& aabb) { // warp_box, :90-97
 	for (int i = 0; i < 3; ++i) {
@@ -935,7 +936,7 @@ int nrs_edit_create_affine(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_a
 	for (int i = 0; i < 3; ++i) { dst.center[i] = dst.center[i] + op->translation[i]; dst.scale[i] = dst.scale[i] * op->scale[i]; }
 	for (int c = 0; c < 3; ++c)
 		for (int r = 0; r < 3; ++r)
-			dst.rot[3 * c + r] = (op->rotation[r] * sel.rot[3 * c] + op->rotation[3 + r] * sel.rot[3 * c + 1]) + op->rotation[6 + r] * sel.rot[3 * c + 2];
+			dst.rot[3 * c + r] = op->rotation[r] * sel.rot[3 * c] + (op->rotation[3 + r] * sel.rot[3 * c + 1] + op->rotation[6 + r] * sel.rot[3 * c + 2]);
 	affine_warp_box(dst, de.aabb);
 	affine_warp_box(sel, de.aabb);
 	affine_finish(dst, de.a_dst);

@@ -28,7 +28,8 @@ struct P3 { float x, y, z; };
 inline P3 sub(P3 a, P3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline P3 add(P3 a, P3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 inline P3 mul(P3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-inline float dotp(P3 a, P3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// Eigen's 3-term reduction order (Eigen/src/Core/Redux.h, complete unrolling: x0 + (x1 + x2)); see nrs_device.cuh
+inline float dotp(P3 a, P3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
 inline P3 crossp(P3 a, P3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline float at(const P3& p, int i) { return i == 0 ? p.x : (i == 1 ? p.y : p.z); }
 
@@ -235,24 +236,26 @@ int nrs_mvc_compute(const float* h_cage_vertices, uint32_t n_cv, const uint32_t*
 					len[i] = std::sqrt(dotp(q, q));
 					theta[i] = (float)(2.0 * std::asin((double)len[i] / 2.0));
 				}
-				const float h = (float)((double)(theta[0] + theta[1] + theta[2]) / 2.0);
+				// Overloads as the reference's translation units resolve them: unqualified sin(float) / fabs(float) are the FLOAT functions
+				// (<math.h> and CUDA's global float overloads are in scope), asin(l / 2.0) and sqrt(std::max<double>(..)) take doubles;
+				// pinned by mvc.h compiled with Eigen::Vector3f points (tests/golden/ref_mvc_golden.npz).
+				const float h = (float)((double)((theta[0] + theta[1]) + theta[2]) / 2.0);
 				if (M_PI - (double)h < (double)eps) { // eta lies on the triangle: 2-D barycentric
-					for (int i = 0; i < 3; ++i) w[i] = (float)(std::sin((double)theta[i]) * (double)len[(i + 2) % 3] * (double)len[(i + 1) % 3]);
-					const float sw = w[0] + w[1] + w[2];
+					for (int i = 0; i < 3; ++i) w[i] = (sinf(theta[i]) * len[(i + 2) % 3]) * len[(i + 1) % 3];
+					const float sw = (w[0] + w[1]) + w[2];
 					std::fill(w_out, w_out + n_cv, 0.f);
 					for (int i = 0; i < 3; ++i) w_out[id[i]] = w[i] / sw;
 					early = true;
 					break;
 				}
 				for (int i = 0; i < 3; ++i)
-					c[i] = (float)((2.0 * std::sin((double)h) * std::sin((double)(h - theta[i]))) /
-					               (std::sin((double)theta[(i + 1) % 3]) * std::sin((double)theta[(i + 2) % 3])) - 1.0);
+					c[i] = (float)((((2.0 * (double)sinf(h)) * (double)sinf(h - theta[i])) / (double)(sinf(theta[(i + 1) % 3]) * sinf(theta[(i + 2) % 3]))) - 1.0);
 				const float sgn = ((double)dotp(crossp(unit[id[0]], unit[id[1]]), unit[id[2]]) < 0.0) ? -1.f : 1.f;
 				for (int i = 0; i < 3; ++i) s[i] = (float)((double)sgn * std::sqrt(std::max(0.0, 1.0 - (double)(c[i] * c[i]))));
-				if (std::fabs(s[0]) < eps || std::fabs(s[1]) < eps || std::fabs(s[2]) < eps) continue; // coplanar, outside the triangle
+				if (fabsf(s[0]) < eps || fabsf(s[1]) < eps || fabsf(s[2]) < eps) continue; // coplanar, outside the triangle
 				for (int i = 0; i < 3; ++i)
-					w[i] = (float)(((double)(theta[i] - c[(i + 1) % 3] * theta[(i + 2) % 3] - c[(i + 2) % 3] * theta[(i + 1) % 3])) /
-					               (2.0 * (double)dist[id[i]] * std::sin((double)theta[(i + 1) % 3]) * (double)s[(i + 2) % 3]));
+					w[i] = (float)(((double)((theta[i] - c[(i + 1) % 3] * theta[(i + 2) % 3]) - c[(i + 2) % 3] * theta[(i + 1) % 3])) /
+					               (((2.0 * (double)dist[id[i]]) * (double)sinf(theta[(i + 1) % 3])) * (double)s[(i + 2) % 3]));
 				sum += (w[0] + w[1] + w[2]);
 				acc[id[0]] += w[0]; acc[id[1]] += w[1]; acc[id[2]] += w[2];
 			}

@@ -16,7 +16,15 @@ __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b
 __device__ __forceinline__ f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 __device__ __forceinline__ f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
-__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// Eigen evaluates fixed-size reductions (dot, squaredNorm, the inner sums of small matrix products) with its complete unroller
+// (Eigen/src/Core/Redux.h, redux_novec_unroller: split at len / 2), so a 3-term sum is x0 + (x1 + x2), not (x0 + x1) + x2.
+// The reference's own sources compiled against that model pin this (oracle/ref_render.cpp, tests/test_ref_pin.py).
+__device__ __forceinline__ float sum3(float a, float b, float c) { return a + (b + c); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return sum3(a.x * b.x, a.y * b.y, a.z * b.z); }
+// M * v, M column-major 3x3 (Eigen's coefficient-based product: every row in the reduction order above)
+__device__ __forceinline__ f3 mat3_mul(const float* M, f3 v) {
+	return {sum3(M[0] * v.x, M[3] * v.y, M[6] * v.z), sum3(M[1] * v.x, M[4] * v.y, M[7] * v.z), sum3(M[2] * v.x, M[5] * v.y, M[8] * v.z)};
+}
 __device__ __forceinline__ f3 cross3(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 
 __device__ __forceinline__ bool box_contains(const Box3& b, f3 p) { // BoundingBox::contains, bounding_box.cuh:243
@@ -227,9 +235,7 @@ __device__ __forceinline__ void ray_origin_dir(const nrs_render_params& p, uint3
 	float uvx = ((float)x + off_x) / W;
 	float uvy = ((float)y + off_y) / H;
 	f3 dir = {(uvx - p.screen_center[0]) * W / p.focal_length[0], (uvy - p.screen_center[1]) * H / p.focal_length[1], 1.0f};
-	d = {(cam[0] * dir.x + cam[3] * dir.y) + cam[6] * dir.z,
-	     (cam[1] * dir.x + cam[4] * dir.y) + cam[7] * dir.z,
-	     (cam[2] * dir.x + cam[5] * dir.y) + cam[8] * dir.z};
+	d = mat3_mul(cam, dir); // camera_matrix.block<3, 3>(0, 0) * dir, common_device.cuh:279
 	o = {cam[9], cam[10], cam[11]};
 	float n = sqrtf(dot3(d, d));
 	d = {d.x / n, d.y / n, d.z / n};
@@ -459,8 +465,7 @@ __device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3&
 			if (with_dir && e.rot) {
 				const f3 ud = unwarp_direction(wdir);
 				const float* R = e.rot + 9 * (size_t)found;
-				const f3 rd = {(R[0] * ud.x + R[3] * ud.y) + R[6] * ud.z, (R[1] * ud.x + R[4] * ud.y) + R[7] * ud.z,
-				               (R[2] * ud.x + R[5] * ud.y) + R[8] * ud.z};
+				const f3 rd = mat3_mul(R, ud);
 				wdir = warp_direction(rd);
 			}
 			in_deformed = true;
@@ -487,7 +492,7 @@ __device__ __forceinline__ bool affine_contains(const AffineBox& b, f3 p) {
 	return du >= 0.f && du < b.uu && dv >= 0.f && dv < b.vv && dw >= 0.f && dw < b.ww;
 }
 __device__ __forceinline__ f3 mul_rt(const float* R, f3 q) { // R^T q, R column-major: (R^T q)_i = sum_k R(k, i) q_k
-	return {(R[0] * q.x + R[1] * q.y) + R[2] * q.z, (R[3] * q.x + R[4] * q.y) + R[5] * q.z, (R[6] * q.x + R[7] * q.y) + R[8] * q.z};
+	return {sum3(R[0] * q.x, R[1] * q.y, R[2] * q.z), sum3(R[3] * q.x, R[4] * q.y, R[5] * q.z), sum3(R[6] * q.x, R[7] * q.y, R[8] * q.z)};
 }
 __device__ __forceinline__ bool affine_warp(const DeviceEdit& e, bool with_dir, f3& wpos, f3& wdir) {
 	if (affine_contains(e.a_dst, wpos)) {
@@ -546,13 +551,11 @@ __device__ __forceinline__ void poisson_residual_rgb(const DeviceEdit& e, f3 wpo
 	const float* s3 = e.shs + 27 * (size_t)tv.w;
 	#pragma unroll
 	for (int c = 0; c < 3; ++c) {
-		float s = 0.f;
+		float q[9];
 		#pragma unroll
-		for (int k = 0; k < 9; ++k) {
-			const float sh = ((bc[0] * s0[9 * c + k] + bc[1] * s1[9 * c + k]) + bc[2] * s2[9 * c + k]) + bc[3] * s3[9 * c + k];
-			s += pSH[k] * sh;
-		}
-		rgb[c] = s;
+		for (int k = 0; k < 9; ++k) q[k] = pSH[k] * (((bc[0] * s0[9 * c + k] + bc[1] * s1[9 * c + k]) + bc[2] * s2[9 * c + k]) + bc[3] * s3[9 * c + k]);
+		// pSH.dot(sh.block<9, 1>(0, c)): Eigen's unrolled 9-term reduction, 4 | 5 -> (2|2) | (2|(1|2))
+		rgb[c] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + (q[7] + q[8])));
 	}
 	const float lo = ((bc[0] * e.out_density[tv.x] + bc[1] * e.out_density[tv.y]) + bc[2] * e.out_density[tv.z]) + bc[3] * e.out_density[tv.w];
 	const float lr = ((bc[0] * e.res_density[tv.x] + bc[1] * e.res_density[tv.y]) + bc[2] * e.res_density[tv.z]) + bc[3] * e.res_density[tv.w];

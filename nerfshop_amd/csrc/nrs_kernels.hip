@@ -699,8 +699,7 @@ __global__ __launch_bounds__(256) void selection_rays_kernel(const DeviceModel m
 		const float uvx = ((float)a.pixels[2 * i] + off_x) / W, uvy = ((float)a.pixels[2 * i + 1] + off_y) / H;
 		const f3 dir = {(uvx - p.screen_center[0]) * W / p.focal_length[0], (uvy - p.screen_center[1]) * H / p.focal_length[1], 1.0f};
 		const float* cam = p.camera_matrix1;
-		d = mk3((cam[0] * dir.x + cam[3] * dir.y) + cam[6] * dir.z, (cam[1] * dir.x + cam[4] * dir.y) + cam[7] * dir.z,
-		        (cam[2] * dir.x + cam[5] * dir.y) + cam[8] * dir.z);
+		d = mat3_mul(cam, dir);
 		o = mk3(cam[9], cam[10], cam[11]);
 		idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 		float tmin;

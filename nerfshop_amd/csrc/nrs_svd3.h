@@ -158,9 +158,7 @@ NRS_HD void tet_rotation(const float org[4][3], const float def[4][3], float out
 	svd_uv(A, U, V);
 	for (int r = 0; r < 3; ++r)
 		for (int c = 0; c < 3; ++c) {
-			float s = 0.f;
-			for (int k = 0; k < 3; ++k) s += U.a[r][k] * V.a[c][k];
-			out9[3 * c + r] = s;
+			out9[3 * c + r] = U.a[r][0] * V.a[c][0] + (U.a[r][1] * V.a[c][1] + U.a[r][2] * V.a[c][2]); // Eigen's 3-term reduction: x0 + (x1 + x2)
 		}
 }
 

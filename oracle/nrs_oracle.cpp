@@ -95,7 +95,15 @@ inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 inline V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
-inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// Eigen evaluates fixed-size reductions (dot, squaredNorm, the inner sums of small matrix products) with its complete unroller,
+// Eigen/src/Core/Redux.h redux_novec_unroller: the range is split at len/2, so a 3-term sum is x0 + (x1 + x2) -- NOT (x0 + x1) + x2.
+// Pinned by the reference's own code compiled against oracle/ref_stubs/Eigen (tests/test_ref_pin.py).
+inline float sum3(float a, float b, float c) { return a + (b + c); }
+inline float dot(V3 a, V3 b) { return sum3(a.x * b.x, a.y * b.y, a.z * b.z); }
+// M * v for a column-major 3x3 (Eigen's coefficient-based product: row . v with the reduction order above)
+inline V3 mat3_mul(const float* M, V3 v) {
+	return {sum3(M[0] * v.x, M[3] * v.y, M[6] * v.z), sum3(M[1] * v.x, M[4] * v.y, M[7] * v.z), sum3(M[2] * v.x, M[5] * v.y, M[8] * v.z)};
+}
 inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline float comp(const V3& a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
@@ -330,10 +338,7 @@ inline void init_ray(const nrs_render_params& p, uint32_t x, uint32_t y, Payload
 	float uvy = ((float)y + offset[1]) / (float)H;
 	V3 dir = {(uvx - p.screen_center[0]) * (float)W / p.focal_length[0],
 	          (uvy - p.screen_center[1]) * (float)H / p.focal_length[1], 1.0f};
-	V3 c0 = cam_col(cam, 0), c1 = cam_col(cam, 1), c2 = cam_col(cam, 2);
-	V3 d = {(c0.x * dir.x + c1.x * dir.y) + c2.x * dir.z,
-	        (c0.y * dir.x + c1.y * dir.y) + c2.y * dir.z,
-	        (c0.z * dir.x + c1.z * dir.y) + c2.z * dir.z};
+	V3 d = mat3_mul(cam, dir); // camera_matrix.block<3, 3>(0, 0) * dir, common_device.cuh:279
 	V3 o = cam_col(cam, 3);
 
 	payload.max_weight = 0.0f; // tn:2573
@@ -627,7 +632,7 @@ inline bool abox_contains(const ABox& b, V3 p) { // affine_bounding_box.cuh:83-8
 	return du >= 0.f && du < b.uu && dv >= 0.f && dv < b.vv && dw >= 0.f && dw < b.ww;
 }
 inline V3 mul_rt(const float* R, V3 q) { // R^T q, R column-major
-	return {(R[0] * q.x + R[1] * q.y) + R[2] * q.z, (R[3] * q.x + R[4] * q.y) + R[5] * q.z, (R[6] * q.x + R[7] * q.y) + R[8] * q.z};
+	return {sum3(R[0] * q.x, R[1] * q.y, R[2] * q.z), sum3(R[3] * q.x, R[4] * q.y, R[5] * q.z), sum3(R[6] * q.x, R[7] * q.y, R[8] * q.z)};
 }
 static void affine_map_one(const Edit& e, float* pos, float* dir /* nullable */, uint8_t* empty) {
 	V3 p = {pos[0], pos[1], pos[2]};
@@ -668,9 +673,7 @@ void map_ray_one(const Edit& e, float coord[7], uint8_t* empty) {
 				if (!e.rot.empty()) {
 					V3 ud = unwarp_direction(v3(coord[4], coord[5], coord[6]));
 					const float* R = &e.rot[9 * (size_t)t]; // column-major
-					V3 rd = {(R[0] * ud.x + R[3] * ud.y) + R[6] * ud.z,
-					         (R[1] * ud.x + R[4] * ud.y) + R[7] * ud.z,
-					         (R[2] * ud.x + R[5] * ud.y) + R[8] * ud.z};
+					V3 rd = mat3_mul(R, ud);
 					V3 wd = warp_direction(rd);
 					coord[4] = wd.x; coord[5] = wd.y; coord[6] = wd.z;
 				}
@@ -765,10 +768,9 @@ void evaluate_sh9(const float sh[27], V3 dir, float rgb[3]) {
 	fS1 = dir.x * fS0 + dir.y * fC0;
 	fTmpC = 0.5462742152960395f;
 	pSH[8] = fTmpC * fC1; pSH[4] = fTmpC * fS1;
-	for (int c = 0; c < 3; ++c) {
-		float s = 0.f;
-		for (int k = 0; k < 9; ++k) s += pSH[k] * sh[9 * c + k];
-		rgb[c] = s;
+	for (int c = 0; c < 3; ++c) { // pSH.dot(sh.block<9, 1>(0, c)): 9 terms in Eigen's unrolled reduction order (Redux.h), 4 | 5 -> 2|2 | 2|(1|2)
+		const float* q = sh + 9 * c;
+		rgb[c] = ((pSH[0] * q[0] + pSH[1] * q[1]) + (pSH[2] * q[2] + pSH[3] * q[3])) + ((pSH[4] * q[4] + pSH[5] * q[5]) + (pSH[6] * q[6] + (pSH[7] * q[7] + pSH[8] * q[8])));
 	}
 }
 
@@ -1142,23 +1144,26 @@ bool mvc_one(V3 eta, const uint32_t* tris, uint32_t n_tris, const V3* cv, uint32
 	for (uint32_t t = 0; t < n_tris; ++t) {
 		for (int i = 0; i < 3; ++i) vid[i] = tris[3 * t + i];
 		for (int i = 0; i < 3; ++i) { V3 q = u[vid[(i + 1) % 3]] - u[vid[(i + 2) % 3]]; l[i] = sqrtf(dot(q, q)); }
+		// Overloads as the reference's translation units resolve them (unqualified sin / fabs with <math.h> and CUDA's global float
+		// overloads in scope): sin(float) is the FLOAT function; asin(l / 2.0) and sqrt(std::max<double>(..)) take doubles.  Pinned by
+		// mvc.h itself compiled with Eigen::Vector3f points (oracle/ref_render.cpp: ref_mvc_compute; tests/test_ref_pin.py).
 		for (int i = 0; i < 3; ++i) theta[i] = (T)(2.0 * asin((double)l[i] / 2.0));
-		T h = (T)(((double)(theta[0] + theta[1] + theta[2])) / 2.0);
+		T h = (T)(((double)((theta[0] + theta[1]) + theta[2])) / 2.0);
 		if (M_PI - (double)h < (double)epsilon) {
-			for (int i = 0; i < 3; ++i) w[i] = (T)(sin((double)theta[i]) * (double)l[(i + 2) % 3] * (double)l[(i + 1) % 3]);
-			sumWeights = w[0] + w[1] + w[2];
+			for (int i = 0; i < 3; ++i) w[i] = (sinf(theta[i]) * l[(i + 2) % 3]) * l[(i + 1) % 3];
+			sumWeights = (w[0] + w[1]) + w[2];
 			weights[vid[0]] = w[0] / sumWeights; weights[vid[1]] = w[1] / sumWeights; weights[vid[2]] = w[2] / sumWeights;
 			return true;
 		}
 		for (int i = 0; i < 3; ++i)
-			c[i] = (T)((2.0 * sin((double)h) * sin((double)(h - theta[i]))) / (sin((double)theta[(i + 1) % 3]) * sin((double)theta[(i + 2) % 3])) - 1.0);
+			c[i] = (T)((((2.0 * (double)sinf(h)) * (double)sinf(h - theta[i])) / (double)(sinf(theta[(i + 1) % 3]) * sinf(theta[(i + 2) % 3]))) - 1.0);
 		T sign_basis = 1;
 		if ((double)dot(cross(u[vid[0]], u[vid[1]]), u[vid[2]]) < 0.0) sign_basis = -1;
 		for (int i = 0; i < 3; ++i) s[i] = (T)((double)sign_basis * sqrt(std::max<double>(0.0, 1.0 - (double)(c[i] * c[i]))));
-		if (fabs(s[0]) < epsilon || fabs(s[1]) < epsilon || fabs(s[2]) < epsilon) continue;
+		if (fabsf(s[0]) < epsilon || fabsf(s[1]) < epsilon || fabsf(s[2]) < epsilon) continue;
 		for (int i = 0; i < 3; ++i)
-			w[i] = (T)(((double)(theta[i] - c[(i + 1) % 3] * theta[(i + 2) % 3] - c[(i + 2) % 3] * theta[(i + 1) % 3])) /
-			           (2.0 * (double)d[vid[i]] * sin((double)theta[(i + 1) % 3]) * (double)s[(i + 2) % 3]));
+			w[i] = (T)(((double)((theta[i] - c[(i + 1) % 3] * theta[(i + 2) % 3]) - c[(i + 2) % 3] * theta[(i + 1) % 3])) /
+			           (((2.0 * (double)d[vid[i]]) * (double)sinf(theta[(i + 1) % 3])) * (double)s[(i + 2) % 3]));
 		sumWeights += (w[0] + w[1] + w[2]);
 		w_weights[vid[0]] += w[0]; w_weights[vid[1]] += w[1]; w_weights[vid[2]] += w[2];
 	}
@@ -1435,8 +1440,7 @@ void orc_project_selection_pixels(void* model, const nrs_render_params* p, const
 		const float uvx = ((float)pixels[2 * i] + offset[0]) / W, uvy = ((float)pixels[2 * i + 1] + offset[1]) / H;
 		const V3 dir = {(uvx - p->screen_center[0]) * W / p->focal_length[0], (uvy - p->screen_center[1]) * H / p->focal_length[1], 1.0f};
 		const float* cam = p->camera_matrix1;
-		const V3 c0 = cam_col(cam, 0), c1 = cam_col(cam, 1), c2 = cam_col(cam, 2);
-		const V3 d = {(c0.x * dir.x + c1.x * dir.y) + c2.x * dir.z, (c0.y * dir.x + c1.y * dir.y) + c2.y * dir.z, (c0.z * dir.x + c1.z * dir.y) + c2.z * dir.z};
+		const V3 d = mat3_mul(cam, dir);
 		const V3 o = cam_col(cam, 3);
 		const V3 idir = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
 		float tmin, tmax;
@@ -1589,7 +1593,7 @@ static void abox_finish(const float center[3], const float scale[3], const float
 		u[i] = rot[i] * scale[0];
 		v[i] = rot[3 + i] * scale[1];
 		w[i] = rot[6 + i] * scale[2];
-		mn[i] = (((-0.5f * rot[i]) * scale[0] + (-0.5f * rot[3 + i]) * scale[1]) + (-0.5f * rot[6 + i]) * scale[2]) + center[i];
+		mn[i] = sum3((-0.5f * rot[i]) * scale[0], (-0.5f * rot[3 + i]) * scale[1], (-0.5f * rot[6 + i]) * scale[2]) + center[i];
 	}
 	out.u = v3(u[0], u[1], u[2]); out.v = v3(v[0], v[1], v[2]); out.w = v3(w[0], w[1], w[2]);
 	out.mn = v3(mn[0], mn[1], mn[2]);
@@ -1608,8 +1612,7 @@ void* orc_edit_create_affine(const nrs_model_desc* d, const nrs_affine_duplicati
 	}
 	for (int c = 0; c < 3; ++c)                                   // rotate: rot_matrix = rotation * rot_matrix
 		for (int r = 0; r < 3; ++r)
-			drot[3 * c + r] = (op->rotation[r] * op->selection_rot[3 * c] + op->rotation[3 + r] * op->selection_rot[3 * c + 1]) +
-			                  op->rotation[6 + r] * op->selection_rot[3 * c + 2];
+			drot[3 * c + r] = sum3(op->rotation[r] * op->selection_rot[3 * c], op->rotation[3 + r] * op->selection_rot[3 * c + 1], op->rotation[6 + r] * op->selection_rot[3 * c + 2]);
 	for (int i = 0; i < 3; ++i) {                                 // warp_box: relative_pos(center), scale / diag
 		dc[i] = (dc[i] - d->aabb_min[i]) / diag[i];
 		ds[i] = ds[i] / diag[i];
@@ -1753,9 +1756,7 @@ void orc_tet_local_rotations(const float* verts, const float* orig, const uint32
 		float U[3][3], V[3][3];
 		ref_svd_uv(A, U, V);                                          // svd_eigen, svd3.h:405-420
 		for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {     // R = U V^T, column-major out
-			float s = 0.f;
-			for (int k = 0; k < 3; ++k) s += U[r][k] * V[c][k];
-			out[9 * (size_t)i + 3 * c + r] = s;
+			out[9 * (size_t)i + 3 * c + r] = sum3(U[r][0] * V[c][0], U[r][1] * V[c][1], U[r][2] * V[c][2]); // Eigen's 3-term reduction order
 		}
 	}
 }
@@ -1938,6 +1939,144 @@ float orc_density_grid_threshold(const float* grid) {
 	double mean = 0.0;
 	for (uint32_t i = 0; i < GRIDVOL; ++i) mean += (double)(fmaxf(grid[i], 0.f) / (float)GRIDVOL);
 	return std::min(0.01f, (float)mean);
+}
+
+// ---- array probes with the signatures of oracle/ref_render.cpp's ref_* probes (tests/test_ref_pin.py drives both with one code path) --------
+void orc_p_bary_tet(uint32_t n, const float* abcd12, const float* p3, float* out4) {
+	for (uint32_t i = 0; i < n; ++i) orc_bary_tet(abcd12 + 12 * (size_t)i, p3 + 3 * (size_t)i, out4 + 4 * (size_t)i);
+}
+void orc_p_point_in_tet(uint32_t n, const float* abcd12, const float* p3, uint8_t* out) {
+	for (uint32_t i = 0; i < n; ++i) out[i] = (uint8_t)orc_point_in_tet(abcd12 + 12 * (size_t)i, p3 + 3 * (size_t)i);
+}
+void orc_p_ld_random_val(uint32_t n, const uint32_t* index, const uint32_t* seed, float* out) {
+	for (uint32_t i = 0; i < n; ++i) out[i] = ld_random_val(index[i], seed[i]);
+}
+void orc_p_ld_random_pixel_offset(uint32_t n, const uint32_t* spp, float* out2) {
+	for (uint32_t i = 0; i < n; ++i) ld_random_pixel_offset(spp[i], out2 + 2 * (size_t)i);
+}
+void orc_p_sobol(uint32_t n, const uint32_t* index, uint32_t dim, uint32_t* out) {
+	for (uint32_t i = 0; i < n; ++i) out[i] = sobol(index[i], dim);
+}
+void orc_p_ray_intersect(uint32_t n, const float* box6, const float* o3, const float* d3, float* out2, uint8_t* contains_o) {
+	for (uint32_t i = 0; i < n; ++i) {
+		const float* q = box6 + 6 * (size_t)i;
+		Box b{v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5])};
+		V3 o = v3(o3[3 * (size_t)i], o3[3 * (size_t)i + 1], o3[3 * (size_t)i + 2]);
+		ray_intersect(b, o, v3(d3[3 * (size_t)i], d3[3 * (size_t)i + 1], d3[3 * (size_t)i + 2]), out2[2 * (size_t)i], out2[2 * (size_t)i + 1]);
+		contains_o[i] = box_contains(b, o) ? 1 : 0;
+	}
+}
+void orc_p_box_intersects_triangle(uint32_t n, const float* box6, const float* tri9, uint8_t* out) {
+	for (uint32_t i = 0; i < n; ++i) out[i] = (uint8_t)orc_box_intersects_triangle(box6 + 6 * (size_t)i, tri9 + 9 * (size_t)i);
+}
+void orc_p_grid_math(uint32_t n, const float* pos3, const float* dir3, const float* t, const float* cone, const uint32_t* mip, float* calc_dt_out, int32_t* mip_from_pos_out,
+                     int32_t* mip_from_dt_out, uint32_t* cell_idx_out, float* dist_out, float* advance_out) {
+	for (uint32_t i = 0; i < n; ++i) {
+		const V3 pos = v3(pos3[3 * (size_t)i], pos3[3 * (size_t)i + 1], pos3[3 * (size_t)i + 2]), dir = v3(dir3[3 * (size_t)i], dir3[3 * (size_t)i + 1], dir3[3 * (size_t)i + 2]);
+		const V3 idir = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+		const float dt = calc_dt(t[i], cone[i]);
+		calc_dt_out[i] = dt;
+		mip_from_pos_out[i] = mip_from_pos(pos);
+		mip_from_dt_out[i] = mip_from_dt(dt, pos);
+		cell_idx_out[i] = cascaded_grid_idx_at(pos, mip[i]);
+		const uint32_t res = GRID >> mip[i];
+		dist_out[i] = distance_to_next_voxel(pos, dir, idir, res);
+		advance_out[i] = advance_to_next_voxel(t[i], cone[i], pos, dir, idir, res);
+	}
+}
+void orc_p_warp(uint32_t n, const float* box6, const float* pos3, const float* dt, float* warp_pos3, float* unwarp_pos3, float* warp_dir3, float* unwarp_dir3, float* warp_dt_out,
+                float* unwarp_dt_out) {
+	const Box b{v3(box6[0], box6[1], box6[2]), v3(box6[3], box6[4], box6[5])};
+	for (uint32_t i = 0; i < n; ++i) {
+		const V3 p = v3(pos3[3 * (size_t)i], pos3[3 * (size_t)i + 1], pos3[3 * (size_t)i + 2]);
+		const V3 a = warp_position(p, b), u = unwarp_position(p, b), wd = warp_direction(p), ud = unwarp_direction(p);
+		const V3 r[4] = {a, u, wd, ud};
+		float* outs[4] = {warp_pos3, unwarp_pos3, warp_dir3, unwarp_dir3};
+		for (int k = 0; k < 4; ++k) { outs[k][3 * (size_t)i] = r[k].x; outs[k][3 * (size_t)i + 1] = r[k].y; outs[k][3 * (size_t)i + 2] = r[k].z; }
+		warp_dt_out[i] = warp_dt(dt[i]);
+		unwarp_dt_out[i] = unwarp_dt(dt[i]);
+	}
+}
+void orc_p_evaluate_sh9(uint32_t n, const float* sh27, const float* dir3, float* rgb3) {
+	for (uint32_t i = 0; i < n; ++i) orc_evaluate_sh9(sh27 + 27 * (size_t)i, dir3 + 3 * (size_t)i, rgb3 + 3 * (size_t)i);
+}
+void orc_p_activations(uint32_t n, const float* x, float* srgb_to_linear_out, float* rgb_logistic, float* rgb_exp, float* density_exp) {
+	for (uint32_t i = 0; i < n; ++i) {
+		srgb_to_linear_out[i] = srgb_to_linear(x[i]);
+		rgb_logistic[i] = network_to_rgb(x[i], NRS_ACT_LOGISTIC);
+		rgb_exp[i] = network_to_rgb(x[i], NRS_ACT_EXPONENTIAL);
+		density_exp[i] = network_to_density(x[i], NRS_ACT_EXPONENTIAL);
+	}
+}
+// pixel_to_ray (common_device.cuh:245-295; camera_matrix1, no distortion, no DoF): the un-normalised direction
+void orc_p_pixel_to_ray(uint32_t n, const int32_t* pixel2, const nrs_render_params* p, float* origin3, float* dir3) {
+	const uint32_t W = (uint32_t)p->resolution[0], H = (uint32_t)p->resolution[1];
+	float offset[2];
+	ld_random_pixel_offset(p->snap_to_pixel_centers ? 0 : p->spp_index, offset);
+	for (uint32_t i = 0; i < n; ++i) {
+		float uvx = ((float)pixel2[2 * (size_t)i] + offset[0]) / (float)W, uvy = ((float)pixel2[2 * (size_t)i + 1] + offset[1]) / (float)H;
+		V3 dir = {(uvx - p->screen_center[0]) * (float)W / p->focal_length[0], (uvy - p->screen_center[1]) * (float)H / p->focal_length[1], 1.0f};
+		V3 d = mat3_mul(p->camera_matrix1, dir), o = cam_col(p->camera_matrix1, 3);
+		origin3[3 * (size_t)i] = o.x; origin3[3 * (size_t)i + 1] = o.y; origin3[3 * (size_t)i + 2] = o.z;
+		dir3[3 * (size_t)i] = d.x; dir3[3 * (size_t)i + 1] = d.y; dir3[3 * (size_t)i + 2] = d.z;
+	}
+}
+void orc_p_cell_functions(uint32_t n, const uint32_t* xyz_level4, const float* pos3, float* cell_pos3, int32_t* cell_at_pos3) {
+	for (uint32_t i = 0; i < n; ++i) {
+		const uint32_t* q = xyz_level4 + 4 * (size_t)i;
+		V3 c = get_cell_pos(q[0], q[1], q[2], q[3]);
+		cell_pos3[3 * (size_t)i] = c.x; cell_pos3[3 * (size_t)i + 1] = c.y; cell_pos3[3 * (size_t)i + 2] = c.z;
+		int a[3];
+		get_cell_at_pos(v3(pos3[3 * (size_t)i], pos3[3 * (size_t)i + 1], pos3[3 * (size_t)i + 2]), q[3], a);
+		for (int k = 0; k < 3; ++k) cell_at_pos3[3 * (size_t)i + k] = a[k];
+	}
+}
+// per listed pixel: the network-input records (warped position, warped dt, warped direction) of every generated sample and payload.t after it
+void orc_p_trace_coords(const nrs_model_desc* desc, const nrs_render_params* p, const uint8_t* grid, uint32_t n_pixels, const uint32_t* pixel_idx, uint32_t max_samples,
+                        float* coords_out, float* t_after_out, uint32_t* count_out, float* origin_dir_t0_out) {
+	const uint32_t W = (uint32_t)p->resolution[0];
+	const Box render_aabb{v3(p->render_aabb_min[0], p->render_aabb_min[1], p->render_aabb_min[2]), v3(p->render_aabb_max[0], p->render_aabb_max[1], p->render_aabb_max[2])};
+	const Box train_aabb{v3(desc->aabb_min[0], desc->aabb_min[1], desc->aabb_min[2]), v3(desc->aabb_max[0], desc->aabb_max[1], desc->aabb_max[2])};
+#pragma omp parallel for schedule(dynamic, 64)
+	for (int64_t k = 0; k < (int64_t)n_pixels; ++k) {
+		uint32_t idx = pixel_idx[k];
+		Payload pl;
+		memset(&pl, 0, sizeof(pl));
+		float d0;
+		init_ray(*p, idx % W, idx / W, pl, d0);
+		advance_pos(*p, grid, pl, idx);
+		if (origin_dir_t0_out) {
+			float* o = origin_dir_t0_out + 7 * (size_t)k;
+			o[0] = pl.origin.x; o[1] = pl.origin.y; o[2] = pl.origin.z; o[3] = pl.dir.x; o[4] = pl.dir.y; o[5] = pl.dir.z; o[6] = pl.t;
+		}
+		uint32_t cnt = 0;
+		if (pl.alive) {
+			V3 origin = pl.origin, dir = pl.dir;
+			V3 idir = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+			float t = pl.t;
+			while (cnt < max_samples) {
+				V3 pos;
+				float dt = 0.f;
+				bool exited = false;
+				while (1) {
+					pos = origin + dir * t;
+					if (!box_contains(render_aabb, pos)) { exited = true; break; }
+					dt = calc_dt(t, p->cone_angle_constant);
+					uint32_t mip = std::max(p->min_mip, (uint32_t)mip_from_dt(dt, pos));
+					if (density_grid_occupied_at(pos, grid, mip)) break;
+					t = advance_to_next_voxel(t, p->cone_angle_constant, pos, dir, idir, GRID >> mip);
+				}
+				if (exited) break;
+				float* c = coords_out + ((size_t)k * max_samples + cnt) * 7;
+				V3 wp = warp_position(pos, train_aabb), wd = warp_direction(dir);
+				c[0] = wp.x; c[1] = wp.y; c[2] = wp.z; c[3] = warp_dt(dt); c[4] = wd.x; c[5] = wd.y; c[6] = wd.z;
+				t += dt;
+				t_after_out[(size_t)k * max_samples + cnt] = t;
+				++cnt;
+			}
+		}
+		count_out[k] = cnt;
+	}
 }
 
 } // extern "C"

@@ -1,13 +1,12 @@
 """Golden vectors from the REFERENCE's own code: MVC3D::computeCoordinatesCustomCode of
-/root/reference/include/neural-graphics-primitives/editing/tools/mvc.h, compiled as oracle/_ref/libref_mvc.so by
-oracle/Makefile (only possible where /root/reference is mounted).  Run from the repo root:
+/root/reference/include/neural-graphics-primitives/editing/tools/mvc.h instantiated with point_t = Eigen::Vector3f (growing_selection.h:90),
+compiled into oracle/_ref/libref_render.so by oracle/Makefile (only possible where /root/reference is mounted).  Run from the repo root:
 
     python tests/golden/make_ref_mvc_golden.py
 
 Writes tests/golden/ref_mvc_golden.npz: the cage, the query points and the reference's weights / labels.  The points are
 the tet-lattice vertices of the test edit plus the special cases of the routine: a cage vertex (early exit), points on
 cage faces (the 2-D barycentric branch), points outside the cage, random interior points."""
-import ctypes as C
 import os
 import sys
 
@@ -18,16 +17,8 @@ sys.path.insert(0, ROOT)
 
 
 def ref_mvc(cage_v, cage_t, points):
-    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_mvc.so"))
-    lib.ref_mvc_compute.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-    lib.ref_mvc_compute.restype = None
-    cv = np.ascontiguousarray(cage_v, np.float32)
-    ct = np.ascontiguousarray(cage_t, np.uint32)
-    pts = np.ascontiguousarray(points, np.float32)
-    w = np.zeros((pts.shape[0], cv.shape[0]), np.float32)
-    labels = np.zeros(pts.shape[0], np.uint8)
-    lib.ref_mvc_compute(cv.ctypes.data, cv.shape[0], ct.ctypes.data, ct.shape[0], pts.ctypes.data, pts.shape[0], w.ctypes.data, labels.ctypes.data)
-    return w, labels
+    from oracle import ref
+    return ref.mvc_compute(cage_v, cage_t, points)
 
 
 def inputs():

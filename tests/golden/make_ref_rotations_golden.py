@@ -1,8 +1,7 @@
-"""Golden vectors from the REFERENCE's own 3x3 SVD: include/neural-graphics-primitives/editing/tools/svd3.h compiled as
-oracle/_ref/libref_svd.so (oracle/ref_svd.cpp wraps it in the loop of TetMesh::update_local_rotations, tet_mesh.cu:37-74).
+"""Golden vectors from the REFERENCE's own per-tet rotations: the loop of TetMesh::update_local_rotations (tet_mesh.cu:49-70) and
+include/neural-graphics-primitives/editing/tools/svd3.h (svd_eigen), compiled into oracle/_ref/libref_render.so (oracle/ref_render.cpp).
 Run from the repo root where /root/reference is mounted:   python tests/golden/make_ref_rotations_golden.py
 Writes tests/golden/ref_rotations_golden.npz: deformed / canonical vertices, tets, and the per-tet R = U V^T."""
-import ctypes as C
 import os
 import sys
 
@@ -13,13 +12,8 @@ sys.path.insert(0, ROOT)
 
 
 def ref_rotations(vertices, original, tets):
-    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_svd.so"))
-    lib.ref_local_rotations.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
-    lib.ref_local_rotations.restype = None
-    v, o, t = (np.ascontiguousarray(vertices, np.float32), np.ascontiguousarray(original, np.float32), np.ascontiguousarray(tets, np.uint32))
-    out = np.zeros((t.shape[0], 9), np.float32)
-    lib.ref_local_rotations(v.ctypes.data, o.ctypes.data, t.ctypes.data, t.shape[0], out.ctypes.data)
-    return out
+    from oracle import ref
+    return ref.local_rotations(vertices, original, tets)
 
 
 if __name__ == "__main__":
