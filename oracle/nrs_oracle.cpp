@@ -2079,4 +2079,15 @@ void orc_p_trace_coords(const nrs_model_desc* desc, const nrs_render_params* p, 
 	}
 }
 
+// compute_residual_poisson_kernel on a caller batch (one sample per call site; outputs pre-zeroed like the tracer's memsets, tn:2866-2869)
+void orc_p_poisson_residuals(void* edit, uint32_t n, const float* coords7, float* sh27, float* out_density, float* res_density) {
+	const Edit& e = *(Edit*)edit;
+#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < (int64_t)n; ++i) {
+		memset(sh27 + 27 * (size_t)i, 0, 108);
+		out_density[i] = 0.f; res_density[i] = 0.f;
+		if (e.apply_poisson) poisson_residual_one(e, coords7 + 7 * (size_t)i, sh27 + 27 * (size_t)i, out_density + i, res_density + i);
+	}
+}
+
 } // extern "C"

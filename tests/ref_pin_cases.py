@@ -1,0 +1,354 @@
+"""Inputs and cases of the reference pin (tests/test_ref_pin.py, tests/golden/make_ref_pin_golden.py).
+
+Every case is evaluated twice with the same seeded inputs: by the REFERENCE's own code compiled as host code (oracle/_ref/libref_render.so,
+which="ref"; only where /root/reference is mounted) and by the oracle's restatement (which="orc").  The generator stores the reference's
+outputs (small arrays whole, 10^5-input probes as SHA-256 of the output bytes plus their first rows) in tests/golden/ref_pin_golden.npz, so
+the GPU box -- where the reference does not exist -- still checks the oracle against the reference's code.
+"""
+import hashlib
+
+import numpy as np
+
+N = 100_000
+
+
+def _rng(tag):
+    return np.random.Generator(np.random.PCG64([1337, sum(ord(c) * (i + 1) for i, c in enumerate(tag))]))
+
+
+def sha(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode() + str(a.shape).encode())
+        h.update(a.tobytes())
+    return np.frombuffer(h.digest(), np.uint8).copy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# element-wise probes of the header / common_nerf.cu functions
+# ---------------------------------------------------------------------------------------------------------------------------------
+def run_probes(which):
+    """-> {name: [output arrays]} for 10^5 seeded inputs per function.  which = "ref" | "orc"."""
+    from oracle import ref
+    out = {}
+    r = _rng("tets")
+    abcd = r.uniform(0, 1, (N, 12)).astype(np.float32)
+    p = r.uniform(0, 1, (N, 3)).astype(np.float32)
+    w = r.dirichlet(np.ones(4), N).astype(np.float32)
+    p[:N // 2] = (abcd[:N // 2].reshape(-1, 4, 3) * w[:N // 2, :, None]).sum(1)  # half the points inside their tet
+    p[N // 2:N // 2 + 4000] = abcd[N // 2:N // 2 + 4000, :3]                     # on a vertex
+    out["bary_tet"] = [ref.bary_tet(abcd, p, which)]                               # selection_utils.h:14-31
+    out["point_in_tet"] = [ref.point_in_tet(abcd, p, which)]                       # selection_utils.h:33-47
+
+    r = _rng("sobol")
+    idx = r.integers(0, 2 ** 32, N, dtype=np.uint64).astype(np.uint32)
+    idx[:4096] = np.arange(4096)
+    seed = r.integers(0, 2 ** 32, N, dtype=np.uint64).astype(np.uint32)
+    seed[:4096] = (np.arange(4096) * 786433).astype(np.uint32)
+    out["ld_random_val"] = [ref.ld_random_val(idx, seed, which)]                   # random_val.cuh:284-288
+    out["ld_random_pixel_offset"] = [ref.ld_random_pixel_offset(idx, which)]       # random_val.cuh:317-322
+    out["sobol"] = [ref.sobol(idx, 0, which), ref.sobol(idx, 1, which)]            # random_val.cuh:159-216 (dims 0, 1: the ones the path uses)
+
+    r = _rng("box")
+    box = np.concatenate([r.uniform(-1, 0.4, (N, 3)), r.uniform(0.6, 2, (N, 3))], 1).astype(np.float32)
+    o = r.uniform(-3, 3, (N, 3)).astype(np.float32)
+    d = r.normal(size=(N, 3)).astype(np.float32)
+    d[::7, 0] = 0.0; d[::11, 1] = 0.0; d[::13, 2] = -0.0                            # axis-parallel rays: divisions by +-0
+    a, inside = ref.ray_intersect(box, o, d, which)                                # bounding_box.cuh:180-238, :243-248
+    out["ray_intersect"] = [a, inside]
+    lo = r.uniform(0, 1, (N, 3)).astype(np.float32)
+    box2 = np.concatenate([lo, lo + r.uniform(0.01, 0.5, (N, 3)).astype(np.float32)], 1)
+    tri = r.uniform(-1, 2, (N, 9)).astype(np.float32)
+    tri[:N // 2] = (box2[:N // 2, None, :3] + r.normal(scale=0.3, size=(N // 2, 3, 3))).reshape(-1, 9).astype(np.float32)
+    out["box_intersects_triangle"] = [ref.box_intersects_triangle(box2, tri, which)]  # bounding_box.cuh:126-178, triangle.cuh:39
+
+    r = _rng("grid")
+    mip = r.integers(0, 5, N).astype(np.uint32)
+    pos = (0.5 + (r.uniform(0, 1, (N, 3)) - 0.5) * (2.0 ** mip)[:, None] * 0.999).astype(np.float32)  # inside cascade `mip`
+    dg = r.normal(size=(N, 3))
+    dg = np.where(np.abs(dg) < 1e-2, 0.1, dg)
+    dg = (dg / np.linalg.norm(dg, axis=1, keepdims=True)).astype(np.float32)
+    t = r.uniform(0, 20, N).astype(np.float32)
+    cone = np.where(r.uniform(size=N) < 0.5, 0.0, 1.0 / 256.0).astype(np.float32)
+    g = ref.grid_math(pos, dg, t, cone, mip, which)                                # common_nerf.cu:89-177
+    out["grid_math"] = [g[k] for k in ("calc_dt", "mip_from_pos", "mip_from_dt", "cell_idx", "distance_to_next_voxel", "advance_to_next_voxel")]
+    bx = np.array([-7.5] * 3 + [8.5] * 3, np.float32)
+    dt = r.uniform(0, 0.3, N).astype(np.float32)
+    wv = ref.warp(bx, pos, dt, which)                                              # common_nerf.cu:5-36
+    out["warp"] = [wv[k] for k in ("warp_position", "unwarp_position", "warp_direction", "unwarp_direction", "warp_dt", "unwarp_dt")]
+    q = np.concatenate([r.integers(0, 128, (N, 3)), mip[:, None]], 1).astype(np.uint32)
+    cp, ca = ref.cell_functions(q, pos, which)                                     # selection_utils.cu:65-83
+    out["cell_functions"] = [cp, ca]
+
+    r = _rng("sh")
+    shc = r.normal(size=(N, 27)).astype(np.float32)
+    dn = r.normal(size=(N, 3))
+    dn = (dn / np.linalg.norm(dn, axis=1, keepdims=True)).astype(np.float32)
+    out["evaluate_sh9"] = [ref.evaluate_sh9(shc, dn, which)]                       # common_nerf.cu:218-245
+    x = r.uniform(-12, 12, N).astype(np.float32)
+    x[:2000] = np.linspace(0, 1, 2000)
+    av = ref.activations(x, which)                                                 # common_device.cuh:31-37, common_nerf.cu:38-66 (libm exp on the host)
+    out["activations"] = [av[k] for k in ("srgb_to_linear", "rgb_logistic", "rgb_exponential", "density_exponential")]
+    return out
+
+
+def pixel_to_ray_case(scene, which):
+    """pixel_to_ray (common_device.cuh:245-295) for every pixel of two views, snapped and jittered."""
+    from oracle import ref
+    outs = []
+    for az, snap, spp in ((30.0, 1, 0), (200.0, 0, 7)):
+        p = scene.params_for(160, 90, az)
+        p.snap_to_pixel_centers, p.spp_index = snap, spp
+        ys, xs = np.mgrid[0:90, 0:160]
+        px = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
+        o, d = ref.pixel_to_ray(px, p, which)
+        outs += [o, d]
+    return outs
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# whole frames: Testbed::render_nerf with the reference's kernels (network = the oracle's, tcnn is outside the reference checkout)
+# ---------------------------------------------------------------------------------------------------------------------------------
+FRAME_CASES = [
+    # name, scene key, (W, H, azimuth), params overrides, edit kind
+    ("lego_noedit", "lego", (64, 36, 30.0), {}, None),
+    ("lego_edit", "lego", (64, 36, 60.0), {}, "cage"),
+    ("lego_edit_jitter", "lego", (64, 36, 100.0), {"snap_to_pixel_centers": 0, "spp_index": 5}, "cage"),
+    ("lego_edit_cost", "lego", (64, 36, 200.0), {"render_mode": 8}, "cage"),
+    ("lego_edit_linear", "lego", (64, 36, 250.0), {"linear_colors": 1}, "cage"),
+    ("lego_membrane", "lego", (64, 36, 60.0), {}, "membrane"),
+    ("lego_membrane_target", "lego", (64, 36, 60.0), {"poisson_target": 1}, "membrane"),
+    ("lego_over_background", "lego", (64, 36, 30.0), {"_background": 0.25}, "cage"),
+    ("aabb16_edit", "aabb16", (64, 36, 30.0), {}, "cage"),
+    ("aabb16_edit_jitter", "aabb16", (64, 36, 120.0), {"snap_to_pixel_centers": 0, "spp_index": 3}, "cage"),
+]
+
+
+class Scenes:
+    """the conftest.Scene objects the cases use, built on demand"""
+
+    def __init__(self):
+        self._s = {}
+
+    def get(self, key):
+        if key not in self._s:
+            from conftest import Scene
+            self._s[key] = Scene(aabb_scale=1, with_edit=True, lattice_n=6) if key == "lego" else Scene(aabb_scale=16, with_edit=True, lattice_n=5)
+        return self._s[key]
+
+
+def _case_setup(scenes, case):
+    from oracle import oracle as orc
+    name, key, (W, H, az), over, kind = case
+    sc = scenes.get(key)
+    p = sc.params_for(W, H, az)
+    background = None
+    for k, v in over.items():
+        if k == "_background":
+            background = v
+        else:
+            setattr(p, k, v)
+    edit = None
+    if kind == "cage":
+        edit = sc.edit
+    elif kind == "membrane":
+        edit = sc.edit.with_membrane(residual_amplitude=0.8)
+    p.apply_operators = 1 if edit is not None else 0
+    bitfield = sc.edited_bitfield if edit is not None else sc.bitfield
+    frame0 = np.full((H, W, 4), background, np.float32) if background is not None else None
+    return sc, p, edit, bitfield, frame0
+
+
+def render_case(scenes, case, which):
+    """-> frame, depth, steps, (n_hit, composited, generated)"""
+    from oracle import oracle as orc
+    from oracle import ref
+    sc, p, edit, bitfield, frame0 = _case_setup(scenes, case)
+    sc.oracle_model.set_bitfield(bitfield)
+    if which == "ref":
+        meshes = [edit.tet_mesh_struct()] if edit is not None else []
+        f, d, s, st = ref.render_frame(sc.desc, p, bitfield, meshes, sc.oracle_model, frame=frame0)
+    else:
+        edits = [orc.Edit(sc.desc, edit.tet_mesh_struct(), keepalive=edit)] if edit is not None else []
+        W, H = p.resolution[0], p.resolution[1]
+        if frame0 is not None:  # orc.Model.render allocates a cleared frame: render, then composite over the background as shade_kernel_nerf does
+            import ctypes as C
+            lib = orc.load()
+            f, d, s = frame0.copy(), np.zeros((H, W), np.float32), np.zeros((H, W), np.uint32)
+            st = orc.OrcRenderStats()
+            arr = (C.c_void_p * max(len(edits), 1))(*[e.h for e in edits])
+            lib.orc_render(sc.oracle_model.h, C.byref(p), arr, len(edits), f.ctypes.data, d.ctypes.data, s.ctypes.data, C.byref(st), 0, 0)
+        else:
+            f, d, s, st = sc.oracle_model.render(p, edits)
+    return f, d, s, np.array([st.n_hit, st.composited, st.generated], np.uint64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# sample streams: per pixel the network-input records of every generated sample (init_rays -> advance_pos -> generate_next...)
+# ---------------------------------------------------------------------------------------------------------------------------------
+STREAM_CASES = [
+    ("lego", (96, 54, 30.0), {}),
+    ("lego", (96, 54, 140.0), {"snap_to_pixel_centers": 0, "spp_index": 9}),
+    ("lego", (96, 54, 300.0), {"min_mip": 1}),
+    ("aabb16", (96, 54, 30.0), {}),
+    ("aabb16", (96, 54, 210.0), {"snap_to_pixel_centers": 0, "spp_index": 2}),
+]
+
+
+def stream_case(scenes, case, which):
+    from oracle import ref
+    key, (W, H, az), over = case
+    sc = scenes.get(key)
+    p = sc.params_for(W, H, az)
+    for k, v in over.items():
+        setattr(p, k, v)
+    px = np.arange(W * H, dtype=np.uint32)
+    coords, t_after, cnt, odt = ref.trace_coords(sc.desc, p, sc.edited_bitfield, px, 160, which)
+    return coords, t_after, cnt, odt
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# edit operators on caller batches, LUT builder, rotations, MVC
+# ---------------------------------------------------------------------------------------------------------------------------------
+def edit_coords(sc, n, seed):
+    """samples concentrated in the deformed and canonical boxes of the scene's cage edit, warped to [0,1]^3 of the scene box"""
+    r = np.random.default_rng(seed)
+    e = sc.edit
+    lo = np.minimum(e.vertices.min(0), e.original_vertices.min(0)) - 0.05
+    hi = np.maximum(e.vertices.max(0), e.original_vertices.max(0)) + 0.05
+    pos = r.uniform(lo, hi, size=(n, 3))
+    mn, mx = np.array(sc.desc.aabb_min[:]), np.array(sc.desc.aabb_max[:])
+    c = np.zeros((n, 7), np.float32)
+    c[:, :3] = ((pos - mn) / (mx - mn)).astype(np.float32)
+    c[:, 3] = r.uniform(0, 1, n)
+    d = r.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    c[:, 4:] = ((d + 1) * 0.5).astype(np.float32)
+    return c
+
+
+def operator_cases(scenes, which):
+    """-> {name: [arrays]}: map_rays / map_positions / membrane residuals of the cage edits, AffineDuplication, on 10^5 samples"""
+    from oracle import oracle as orc
+    from oracle import ref
+    out = {}
+    for key in ("lego", "aabb16"):
+        sc = scenes.get(key)
+        c = edit_coords(sc, N, 11)
+        for copy in (0, 1):
+            e = sc.edit
+            mesh = e.tet_mesh_struct()
+            mesh.copy = copy
+            if which == "ref":
+                rc, re = ref.edit_map_rays(sc.desc, mesh, c)
+                rp, rpe = ref.edit_map_positions(sc.desc, mesh, np.ascontiguousarray(c[:, :3]))
+            else:
+                o = orc.Edit(sc.desc, mesh, keepalive=e)
+                rc, re = o.map_rays(c)
+                rp, rpe = o.map_positions(np.ascontiguousarray(c[:, :3]))
+            out[f"{key}_map_rays_copy{copy}"] = [rc, re]
+            out[f"{key}_map_positions_copy{copy}"] = [rp, rpe]
+        em = sc.edit.with_membrane(residual_amplitude=0.8)
+        mesh = em.tet_mesh_struct()
+        if which == "ref":
+            sh, od, rd = ref.edit_poisson_residuals(sc.desc, mesh, c)
+        else:
+            sh, od, rd = orc_poisson_residuals(sc.desc, mesh, em, c)
+        out[f"{key}_poisson_residuals"] = [sh, od, rd]
+    # AffineDuplication with a general rotation (all three Euler angles) of operator and selection box
+    from nerfshop_amd import synth
+    sc = scenes.get("lego")
+    for hide, cd in ((0, 1), (1, 1), (1, 0)):
+        op = synth.make_affine_edit(hide_original=bool(hide), correct_dir=bool(cd))
+        op.rotation[:] = [float(v) for v in _euler(0.3, -0.5, 0.2).T.reshape(-1)]
+        op.selection_rot[:] = [float(v) for v in _euler(-0.1, 0.25, 0.4).T.reshape(-1)]
+        r = np.random.default_rng(5)
+        c = r.uniform(0, 1, size=(N, 7)).astype(np.float32)
+        sel = np.array(op.selection_center[:], np.float32)
+        ext = np.array(op.selection_scale[:], np.float32)
+        c[:N // 3, :3] = sel + r.uniform(-0.75, 0.75, size=(N // 3, 3)).astype(np.float32) * ext
+        c[N // 3:2 * (N // 3), :3] = sel + np.array(op.translation[:], np.float32) + r.uniform(-0.9, 0.9, size=(N // 3, 3)).astype(np.float32) * ext
+        if which == "ref":
+            rc, re = ref.affine_map_rays(sc.desc, op, c)
+            rp, rpe = ref.affine_map_positions(sc.desc, op, np.ascontiguousarray(c[:, :3]))
+        else:
+            o = orc.AffineEdit(sc.desc, op)
+            rc, re = o.map_rays(c)
+            rp, rpe = o.map_positions(np.ascontiguousarray(c[:, :3]))
+        out[f"affine_map_rays_hide{hide}_dir{cd}"] = [rc, re]
+        out[f"affine_map_positions_hide{hide}_dir{cd}"] = [rp, rpe]
+    return out
+
+
+def _euler(a, b, c):
+    ca, sa, cb, sb, cc, sc_ = np.cos(a), np.sin(a), np.cos(b), np.sin(b), np.cos(c), np.sin(c)
+    rx = np.array([[1, 0, 0], [0, ca, -sa], [0, sa, ca]])
+    ry = np.array([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]])
+    rz = np.array([[cc, -sc_, 0], [sc_, cc, 0], [0, 0, 1]])
+    return (rz @ ry @ rx).astype(np.float32)
+
+
+def orc_poisson_residuals(desc, mesh, keepalive, coords7):
+    """compute_residual_poisson_kernel through the oracle (one sample per call site, as ref_edit_poisson_residuals)"""
+    import ctypes as C
+    from oracle import oracle as orc
+    lib = orc.load()
+    e = orc.Edit(desc, mesh, keepalive=keepalive)
+    c = np.ascontiguousarray(coords7, np.float32)
+    n = c.shape[0]
+    sh, od, rd = np.zeros((n, 27), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    lib.orc_p_poisson_residuals.restype = None
+    lib.orc_p_poisson_residuals(C.c_void_p(e.h), C.c_uint32(n), C.c_void_p(c.ctypes.data), C.c_void_p(sh.ctypes.data), C.c_void_p(od.ctypes.data), C.c_void_p(rd.ctypes.data))
+    return sh, od, rd
+
+
+def authoring_cases(scenes, which):
+    """-> {name: [arrays]}: TetMesh::build_tet_grid tables, update_local_rotations, Cage::compute_mvc / interpolate_with_mvc"""
+    from oracle import oracle as orc
+    from oracle import ref
+    import importlib.util
+    import os
+    out = {}
+    for key in ("lego", "aabb16"):
+        e = scenes.get(key).edit
+        if which == "ref":
+            off, idx, bf, mx = ref.build_tet_grid(e.vertices, e.original_vertices, e.tets)
+            rot = ref.local_rotations(e.vertices, e.original_vertices, e.tets)
+        else:
+            off, idx, _, mx = orc.tet_lut_build(e.vertices, e.tets)
+            _, _, bf, _ = orc.tet_lut_build(e.original_vertices, e.tets)
+            rot = orc.local_rotations(e.vertices, e.original_vertices, e.tets)
+        out[f"{key}_tet_grid"] = [off, idx, bf, np.array([mx], np.uint32)]
+        out[f"{key}_local_rotations"] = [rot]
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_ref_mvc_golden", os.path.join(here, "golden", "make_ref_mvc_golden.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    cv, ct, pts = g.inputs()
+    if which == "ref":
+        w, lab = ref.mvc_compute(cv, ct, pts)
+        moved = ref.mvc_apply(w, cv * np.float32(1.07) + np.float32(0.013))
+    else:
+        w, lab = orc.mvc_compute(cv, ct, pts)
+        moved = orc.mvc_apply(w, cv * np.float32(1.07) + np.float32(0.013))
+    out["mvc"] = [w, lab, moved]
+    return out
+
+
+def bitfield_case(scenes, which):
+    """grid_to_bitfield + bitfield_max_pool (testbed_nerf.cu:514-555) on the scenes' density grids with the reference's threshold rule"""
+    from oracle import oracle as orc
+    from oracle import ref
+    outs = []
+    for key in ("lego", "aabb16"):
+        sc = scenes.get(key)
+        grid = np.ascontiguousarray(sc.edited_grid, np.float32)
+        if which == "ref":
+            # update_density_grid_mean_and_bitfield (:3642-3651): mean over the FIRST cascade of max(v, 0) / 128^3, summed by reduce_sum
+            # (a tcnn reduction, order unspecified) -- here in double, like the oracle
+            mean = float(np.sum(np.maximum(grid[:128 ** 3], 0).astype(np.float32) / np.float32(128 ** 3), dtype=np.float64))
+            outs.append(ref.grid_to_bitfield(grid, np.float32(mean)))
+        else:
+            outs.append(orc.density_grid_to_bitfield(grid))
+    return outs

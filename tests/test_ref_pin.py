@@ -1,0 +1,141 @@
+"""The oracle pinned to the REFERENCE'S OWN CODE (VERDICT r1 "next round" #1).
+
+oracle/_ref/libref_render.so is the reference's render path compiled as host code: its headers on the path (common_device.cuh,
+bounding_box.cuh, triangle.cuh, random_val.cuh, nerf.h, editing/tools/selection_utils.h, mvc.h, svd3.h) and src/common_nerf.cu whole, and
+the kernels cut out of src/testbed_nerf.cu (:557-606, :637-696, :698-979, :2448-2616 ...), src/editing/cage_deformation.cu (:136-269, :341-541),
+src/editing/datastructures/tet_mesh.cu (:49-70, :407-468, :585-641), src/editing/affine_duplication.cu (:69-118) by oracle/ref_extract.py --
+against a stand-in for the EMPTY Eigen / tiny-cuda-nn submodules (oracle/ref_stubs; the stand-in's evaluation-order model is stated there).
+
+Two layers:
+  * `*_golden`: the oracle against tests/golden/ref_pin_golden.npz (made from that library by tests/golden/make_ref_pin_golden.py).
+    Runs everywhere, also on the GPU box where /root/reference does not exist.
+  * `*_live`: the oracle against the library itself, array by array with counts of differing elements (only where it is built).
+Bar: bit-exact, 10^5 seeded inputs per function, whole frames (RGBA, depth, per-pixel sample counts) and whole sample streams for the
+lego-like and the aabb-16 scene.  What stays unpinned is tiny-cuda-nn (hash grid, MLPs, SH encoding, pcg32): the frames use the oracle's
+network on both sides.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import ref_pin_cases as cases
+from oracle import ref
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "ref_pin_golden.npz")
+live = pytest.mark.skipif(not ref.available(), reason="oracle/_ref/libref_render.so needs /root/reference (build: make -C oracle)")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN)
+
+
+@pytest.fixture(scope="module")
+def scenes(built):
+    return cases.Scenes()
+
+
+def _check_hashed(golden, prefix, results):
+    bad = []
+    for name, arrays in results.items():
+        if not np.array_equal(cases.sha(*arrays), golden[f"{prefix}/{name}/sha"]):
+            heads = [int((np.ascontiguousarray(a)[:64].view(np.uint8) != golden[f"{prefix}/{name}/head{k}"].view(np.uint8)).sum()) for k, a in enumerate(arrays)]
+            bad.append((name, heads))
+    assert not bad, f"oracle differs from the reference's code (name, differing bytes in the first 64 rows of each output): {bad}"
+
+
+def _check_live(a, b):
+    bad = {}
+    for name in a:
+        for k, (x, y) in enumerate(zip(a[name], b[name])):
+            x, y = np.ascontiguousarray(x), np.ascontiguousarray(y)
+            assert x.shape == y.shape and x.dtype == y.dtype, (name, k, x.shape, y.shape)
+            n = int((x.reshape(x.shape[0], -1).view(np.uint8) != y.reshape(y.shape[0], -1).view(np.uint8)).any(axis=1).sum())
+            if n:
+                bad[f"{name}[{k}]"] = n
+    assert not bad, f"rows that differ between the reference's code and the oracle: {bad}"
+
+
+# ---- header / common_nerf.cu functions, 10^5 inputs each ---------------------------------------------------------------------
+def test_functions_golden(built, golden):
+    _check_hashed(golden, "probe", cases.run_probes("orc"))
+
+
+def test_pixel_to_ray_golden(scenes, golden):
+    _check_hashed(golden, "probe", {"pixel_to_ray": cases.pixel_to_ray_case(scenes.get("lego"), "orc")})
+
+
+@live
+def test_functions_live(built):
+    _check_live(cases.run_probes("ref"), cases.run_probes("orc"))
+
+
+# ---- edit operators on caller batches: interpolate_tet(_pos), compute_residual_poisson_kernel, translate_in_box(_pos) ---------------
+def test_operators_golden(scenes, golden):
+    _check_hashed(golden, "op", cases.operator_cases(scenes, "orc"))
+
+
+@live
+def test_operators_live(scenes):
+    a, b = cases.operator_cases(scenes, "ref"), cases.operator_cases(scenes, "orc")
+    _check_live(a, b)
+    # the cases must exercise the branches: samples mapped back, samples masked, membrane terms present
+    for key in ("lego", "aabb16"):
+        c = cases.edit_coords(scenes.get(key), cases.N, 11)
+        moved = (a[f"{key}_map_rays_copy0"][0][:, :3] != c[:, :3]).any(axis=1)
+        assert moved.sum() > 5000 and a[f"{key}_map_rays_copy0"][1].sum() > 500 and a[f"{key}_map_rays_copy1"][1].sum() == 0
+        assert (a[f"{key}_poisson_residuals"][1] > 1e-9).sum() > 2000
+
+
+# ---- build_tet_grid, update_local_rotations, compute_mvc / interpolate_with_mvc, grid_to_bitfield + bitfield_max_pool -------------
+def test_authoring_golden(scenes, golden):
+    _check_hashed(golden, "authoring", cases.authoring_cases(scenes, "orc"))
+    _check_hashed(golden, "bitfield", {"grids": cases.bitfield_case(scenes, "orc")})
+
+
+@live
+def test_authoring_live(scenes):
+    _check_live(cases.authoring_cases(scenes, "ref"), cases.authoring_cases(scenes, "orc"))
+    _check_live({"grids": cases.bitfield_case(scenes, "ref")}, {"grids": cases.bitfield_case(scenes, "orc")})
+
+
+# ---- whole frames: init_rays -> advance_pos -> [compact -> generate inputs -> residuals -> map_rays -> network -> composite]* -> shade ----
+@pytest.mark.parametrize("case", cases.FRAME_CASES, ids=[c[0] for c in cases.FRAME_CASES])
+def test_frame_golden(scenes, golden, case):
+    f, d, s, st = cases.render_case(scenes, case, "orc")
+    g = lambda k: golden[f"frame/{case[0]}/{k}"]
+    assert np.array_equal(st, g("stats")), (st, g("stats"))
+    assert np.array_equal(s, g("steps").astype(np.uint32))
+    assert np.array_equal(f.view(np.uint32), g("frame").view(np.uint32)), int((f.view(np.uint32) != g("frame").view(np.uint32)).sum())
+    assert np.array_equal(d.view(np.uint32), g("depth").view(np.uint32))
+    assert st[0] > 500 and (f[..., 3] > 0).sum() > 500  # not an empty picture
+
+
+@live
+@pytest.mark.parametrize("case", [cases.FRAME_CASES[1], cases.FRAME_CASES[5], cases.FRAME_CASES[8]], ids=lambda c: c[0])
+def test_frame_live_larger(scenes, case):
+    """the same pipeline at 160x90 (not stored): frame, depth, per-pixel sample counts and the trace() statistics bit for bit"""
+    big = (case[0], case[1], (160, 90, case[2][2] + 17.0), case[3], case[4])
+    fr, dr, sr, str_ = cases.render_case(scenes, big, "ref")
+    fo, do, so, sto = cases.render_case(scenes, big, "orc")
+    assert np.array_equal(str_, sto)
+    assert np.array_equal(sr, so)
+    assert np.array_equal(fr.view(np.uint32), fo.view(np.uint32)) and np.array_equal(dr.view(np.uint32), do.view(np.uint32))
+
+
+# ---- whole sample streams of every pixel of a view (lego and aabb 16; snapped, jittered, min_mip) ---------------------------------
+@pytest.mark.parametrize("k", range(len(cases.STREAM_CASES)))
+def test_stream_golden(scenes, golden, k):
+    coords, t_after, cnt, odt = cases.stream_case(scenes, cases.STREAM_CASES[k], "orc")
+    assert np.array_equal(cnt, golden[f"stream/{k}/count"].astype(np.uint32))
+    assert np.array_equal(cases.sha(coords, t_after, cnt, odt), golden[f"stream/{k}/sha"])
+    assert cnt.sum() > 100000 and cnt.max() > 60
+
+
+@live
+@pytest.mark.parametrize("k", [0, 3])
+def test_stream_live(scenes, k):
+    a, b = cases.stream_case(scenes, cases.STREAM_CASES[k], "ref"), cases.stream_case(scenes, cases.STREAM_CASES[k], "orc")
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
