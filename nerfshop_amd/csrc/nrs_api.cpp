@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -48,8 +49,14 @@ struct nrs_ctx {
 	// frames) do not share a packet counter or an operator table: slot = launch number % kInFlight
 	static constexpr int kInFlight = 8;
 	RenderCounters* d_counters = nullptr;   // [kInFlight]
-	DeviceEdit* d_edits = nullptr;          // [kInFlight][kMaxEdits]
-	uint32_t launch_serial = 0;
+	DeviceEdit* d_edits = nullptr;          // [kInFlight + 1][kMaxEdits]; the last table belongs to the occupancy refresh
+	std::atomic<uint32_t> launch_serial{0};
+	// A slot is reused every kInFlight launches, possibly from ANOTHER stream: the launch that used it last records slot_done, and a
+	// launch on a different stream makes its stream wait on that event before it clears the counters / re-sends the operator table
+	// (same-stream reuse is ordered by the stream itself).
+	hipEvent_t slot_done[kInFlight] = {};
+	hipStream_t slot_stream[kInFlight] = {};
+	bool slot_used[kInFlight] = {};
 	float* d_mean = nullptr;
 	unsigned long long* d_wave_log = nullptr; // profiling only (NRS_DEBUG & 4)
 	unsigned long long* h_feedback = nullptr; // pinned, device-visible: written by the last workgroup of a render launch
@@ -104,6 +111,19 @@ struct nrs_edit {
 	uint32_t lut_n_idx = 0, lut_max_per_cell = 0;
 };
 
+// Marching parameters every ray-marching entry point hands to the kernels: min_mip indexes the 5-cascade bitfield (min_mip > 4 reads past
+// it and makes kGrid >> mip zero, i.e. a voxel walk without progress), a negative / non-finite cone angle breaks calc_dt's clamp, a
+// non-positive resolution divides by zero on the device.
+static int check_march_params(const nrs_render_params& p, const char* who) {
+	if (p.resolution[0] <= 0 || p.resolution[1] <= 0 || p.resolution[0] > 65535 || p.resolution[1] > 65535)
+		return fail(NRS_ERR_INVALID_ARG, std::string(who) + ": resolution out of range (1..65535)");
+	if (p.min_mip > kCascades - 1) return fail(NRS_ERR_INVALID_ARG, std::string(who) + ": min_mip > 4 (the occupancy grid has 5 cascades)");
+	if (!(p.cone_angle_constant >= 0.f) || !std::isfinite(p.cone_angle_constant)) return fail(NRS_ERR_INVALID_ARG, std::string(who) + ": cone_angle_constant must be finite and >= 0");
+	if (!(p.min_transmittance >= 0.f && p.min_transmittance <= 1.f)) return fail(NRS_ERR_INVALID_ARG, std::string(who) + ": min_transmittance outside [0, 1]");
+	for (int i = 0; i < 3; ++i)
+		if (!std::isfinite(p.render_aabb_min[i]) || !std::isfinite(p.render_aabb_max[i])) return fail(NRS_ERR_INVALID_ARG, std::string(who) + ": render box is not finite");
+	return NRS_OK;
+}
 // ---------------------------------------------------------------------------------------------------------------
 static bool desc_supported(const nrs_model_desc& d) {
 	return d.n_levels == 16 && d.n_features_per_level == 2 && d.n_neurons == 64 && d.density_hidden_layers == 1 &&
@@ -112,15 +132,17 @@ static bool desc_supported(const nrs_model_desc& d) {
 }
 
 // tcnn GridEncoding level geometry: scale = exp2(l*log2(b))*Nmin - 1, res = ceil(scale)+1,
-// entries = min(align8(res^3), 2^log2_T).  Evaluated in double on the host, rounded to float once.
+// entries = min(align8(res^3), 2^log2_T).  tiny-cuda-nn evaluates the scale in FLOAT -- exp2f(level * log2f(per_level_scale)) *
+// base_resolution - 1.0f, in the encoding's constructor and again in kernel_grid -- so it is float here too: evaluated in double it can
+// land one ulp away, and next to an integer that changes ceil(scale) + 1 and every later level offset (a real checkpoint would be
+// mis-addressed).  Host libm stands in for the device's exp2f (<= 2 ulp on NVIDIA hardware: that last bit is outside anyone's control).
 static uint32_t make_levels(const nrs_model_desc& d, LevelParams* lv) {
 	uint32_t off = 0;
-	const double l2 = std::log2((double)d.per_level_scale);
+	const float l2 = log2f(d.per_level_scale);
 	for (uint32_t l = 0; l < d.n_levels; ++l) {
 		LevelParams& p = lv[l];
-		const double s = std::exp2((double)l * l2) * (double)d.base_resolution - 1.0;
-		p.scale = (float)s;
-		p.resolution = (uint32_t)std::ceil((double)p.scale) + 1u;
+		p.scale = exp2f((float)l * l2) * (float)d.base_resolution - 1.0f;
+		p.resolution = (uint32_t)ceilf(p.scale) + 1u;
 		p.res2 = p.resolution * p.resolution;
 		uint64_t n = (uint64_t)p.resolution * p.resolution * p.resolution;
 		n = (n + 7ull) / 8ull * 8ull;
@@ -329,7 +351,8 @@ int nrs_ctx_create(int device, nrs_ctx** out) {
 	c->hbm_bytes = prop.totalGlobalMem;
 	snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
 	hipError_t he = hipMalloc((void**)&c->d_counters, sizeof(RenderCounters) * nrs_ctx::kInFlight);
-	if (he == hipSuccess) he = hipMalloc((void**)&c->d_edits, sizeof(DeviceEdit) * nrs_ctx::kMaxEdits * nrs_ctx::kInFlight);
+	if (he == hipSuccess) he = hipMalloc((void**)&c->d_edits, sizeof(DeviceEdit) * nrs_ctx::kMaxEdits * (nrs_ctx::kInFlight + 1));
+	for (int i = 0; i < nrs_ctx::kInFlight && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming);
 	if (he == hipSuccess) he = hipMalloc((void**)&c->d_mean, 8 + 256 * 8); // mean + partial sums (launch_grid_to_bitfield)
 	if (he == hipSuccess) he = hipMalloc((void**)&c->d_wave_log, 8192 * 4 * 8);
 	if (he != hipSuccess) {
@@ -351,6 +374,8 @@ void nrs_ctx_destroy(nrs_ctx* c) {
 	if (!c) return;
 	(void)hipFree(c->d_counters);
 	(void)hipFree(c->d_edits);
+	for (int i = 0; i < nrs_ctx::kInFlight; ++i)
+		if (c->slot_done[i]) (void)hipEventDestroy(c->slot_done[i]);
 	(void)hipFree(c->d_mean);
 	(void)hipFree(c->d_wave_log);
 	if (c->h_feedback) (void)hipHostFree(c->h_feedback);
@@ -593,20 +618,20 @@ int nrs_model_update_density_grid(nrs_model* m, nrs_edit* const* edits, int n_ed
 	hipStream_t s = (hipStream_t)stream;
 	const size_t grid_bytes = (size_t)kGridVol * kCascades * 4;
 	if (!m->d_density_tmp) HIP_TRY(hipMalloc((void**)&m->d_density_tmp, grid_bytes));
+	DeviceEdit* d_refresh_edits = ctx->d_edits + (size_t)nrs_ctx::kInFlight * nrs_ctx::kMaxEdits; // the refresh's own operator table
 	if (n_edits > 0) {
 		DeviceEdit host_edits[nrs_ctx::kMaxEdits];
 		for (int i = 0; i < n_edits; ++i) {
 			if (!edits[i]) return fail(NRS_ERR_INVALID_ARG, "nrs_model_update_density_grid: NULL edit operator");
 			host_edits[i] = edits[i]->de;
 		}
-		HIP_TRY(hipMemcpyAsync(ctx->d_edits, host_edits, sizeof(DeviceEdit) * n_edits, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(d_refresh_edits, host_edits, sizeof(DeviceEdit) * n_edits, hipMemcpyHostToDevice, s));
 		HIP_TRY(hipStreamSynchronize(s)); // host_edits is a stack array
-		ctx->shadow_n[0] = -1; // (slot 0 of the render launches' operator tables was overwritten)
 	}
 	if (u->reset_grid) HIP_TRY(hipMemsetAsync(m->d_density_grid, 0, grid_bytes, s));
 	HIP_TRY(hipMemsetAsync(m->d_density_tmp, 0, grid_bytes, s));
 	const uint64_t rng_nonuniform = pcg_advance(u->rng_state, u->rng_inc, 1ull << 32); // m_rng.advance() between the two draws
-	NRS_TRY(launch_grid_update(m->dm, ctx->d_edits, n_edits, *u, rng_nonuniform, m->d_density_grid, m->d_density_tmp, ctx->n_cus, stream));
+	NRS_TRY(launch_grid_update(m->dm, d_refresh_edits, n_edits, *u, rng_nonuniform, m->d_density_grid, m->d_density_tmp, ctx->n_cus, stream));
 	u->rng_state = pcg_advance(u->rng_state, u->rng_inc, 2ull << 32);
 	u->ema_step += 1;
 	return refresh_bitfield(m, stream);
@@ -628,6 +653,7 @@ int nrs_network_inference(nrs_model* m, void* stream, uint32_t n, const float* d
 	int s = check_net(m, d_in, d_out, "nrs_network_inference");
 	if (s != NRS_OK) return s;
 	if (layout == NRS_PLANES && ld_out < n) return fail(NRS_ERR_INVALID_ARG, "nrs_network_inference: ld_out < n");
+	HIP_TRY(hipSetDevice(m->ctx->device));
 	NRS_TRY(launch_network(m->dm, 0, n, d_in, NRS_NETWORK_INPUT_FLOATS, d_out, ld_out, layout, m->ctx->n_cus, stream));
 	return NRS_OK;
 }
@@ -636,6 +662,7 @@ int nrs_network_density(nrs_model* m, void* stream, uint32_t n, const float* d_i
 	if (s != NRS_OK) return s;
 	if (ld_in < 3) return fail(NRS_ERR_INVALID_ARG, "nrs_network_density: ld_in < 3");
 	if (layout == NRS_PLANES && ld_out < n) return fail(NRS_ERR_INVALID_ARG, "nrs_network_density: ld_out < n");
+	HIP_TRY(hipSetDevice(m->ctx->device));
 	NRS_TRY(launch_network(m->dm, 1, n, d_in, ld_in, d_out, ld_out, layout, m->ctx->n_cus, stream));
 	return NRS_OK;
 }
@@ -664,7 +691,7 @@ int nrs_project_selection_pixels(nrs_model* m, void* stream, const nrs_render_pa
 		return fail(NRS_ERR_INVALID_ARG, "nrs_project_selection_pixels: NULL argument");
 	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_project_selection_pixels: parameters not set (nrs_model_set_params)");
 	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_project_selection_pixels: occupancy not set (nrs_model_set_density_bitfield/_grid)");
-	if (p->resolution[0] <= 0 || p->resolution[1] <= 0) return fail(NRS_ERR_INVALID_ARG, "nrs_project_selection_pixels: empty resolution");
+	{ const int pc = check_march_params(*p, "nrs_project_selection_pixels"); if (pc != NRS_OK) return pc; }
 	HIP_TRY(hipSetDevice(m->ctx->device));
 	NRS_TRY(launch_selection_rays(m->dm, *p, d_pixels_xy, n_pixels, transmittance_threshold, d_positions, d_cells, d_found, stream));
 	return NRS_OK;
@@ -711,8 +738,10 @@ int nrs_poisson_boundary(nrs_model* m, const float* h_vertices, uint32_t n_verts
 	int rc = NRS_OK;
 	if (he != hipSuccess) rc = fail_hip(he, "nrs_poisson_boundary: device allocation");
 	if (rc == NRS_OK && hipMemcpy(d_coords, coords.data(), n * 7 * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fail(NRS_ERR_HIP, "nrs_poisson_boundary: upload");
-	if (rc == NRS_OK) rc = launch_network(m->dm, 0, (uint32_t)n, d_coords, NRS_NETWORK_INPUT_FLOATS, d_net, 16, NRS_INTERLEAVED, m->ctx->n_cus, nullptr);
-	if (rc == NRS_OK) rc = launch_poisson_fit(m->dm, n_verts, n_sh, d_coords, d_net, is_inside, (float)(4 * M_PI / n_sh), d_density, d_sh, nullptr);
+	if (rc == NRS_OK && (rc = launch_network(m->dm, 0, (uint32_t)n, d_coords, NRS_NETWORK_INPUT_FLOATS, d_net, 16, NRS_INTERLEAVED, m->ctx->n_cus, nullptr)) != NRS_OK)
+		g_err = launch_last_error();
+	if (rc == NRS_OK && (rc = launch_poisson_fit(m->dm, n_verts, n_sh, d_coords, d_net, is_inside, (float)(4 * M_PI / n_sh), d_density, d_sh, nullptr)) != NRS_OK)
+		g_err = launch_last_error();
 	if (rc == NRS_OK && (hipMemcpy(h_density_out, d_density, (size_t)n_verts * 4, hipMemcpyDeviceToHost) != hipSuccess ||
 	                     hipMemcpy(h_sh_out, d_sh, (size_t)n_verts * 27 * 4, hipMemcpyDeviceToHost) != hipSuccess))
 		rc = fail(NRS_ERR_HIP, "nrs_poisson_boundary: download");
@@ -723,6 +752,7 @@ int nrs_hashgrid_encode(nrs_model* m, void* stream, uint32_t n, const float* d_i
 	int s = check_net(m, d_in, d_out, "nrs_hashgrid_encode");
 	if (s != NRS_OK) return s;
 	if (ld_in < 3) return fail(NRS_ERR_INVALID_ARG, "nrs_hashgrid_encode: ld_in < 3");
+	HIP_TRY(hipSetDevice(m->ctx->device));
 	NRS_TRY(launch_network(m->dm, 2, n, d_in, ld_in, d_out, 0, NRS_INTERLEAVED, m->ctx->n_cus, stream));
 	return NRS_OK;
 }
@@ -1016,12 +1046,14 @@ int nrs_edit_download(nrs_edit* e, float* h_vertices, uint32_t* h_lut_offsets, u
 }
 int nrs_edit_map_rays(nrs_edit* e, void* stream, uint32_t n, float* d_coords, uint8_t* d_empty_mask) {
 	if (!e || !d_coords || !d_empty_mask) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_map_rays: NULL argument");
+	HIP_TRY(hipSetDevice(e->ctx->device));
 	NRS_TRY(launch_map_rays(e->de, n, d_coords, NRS_NETWORK_INPUT_FLOATS, 1, d_empty_mask, stream));
 	return NRS_OK;
 }
 int nrs_edit_map_positions(nrs_edit* e, void* stream, uint32_t n, float* d_pos, uint32_t ld, uint8_t* d_empty_mask) {
 	if (!e || !d_pos || !d_empty_mask) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_map_positions: NULL argument");
 	if (ld < 3) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_map_positions: ld < 3");
+	HIP_TRY(hipSetDevice(e->ctx->device));
 	NRS_TRY(launch_map_rays(e->de, n, d_pos, ld, 0, d_empty_mask, stream));
 	return NRS_OK;
 }
@@ -1058,8 +1090,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	if (!m || !p || !d_frame || !d_depth) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: NULL argument");
 	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_render_nerf: parameters not set (nrs_model_set_params)");
 	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_render_nerf: occupancy not set (nrs_model_set_density_bitfield/_grid)");
-	if (p->resolution[0] <= 0 || p->resolution[1] <= 0 || p->resolution[0] > 65535 || p->resolution[1] > 65535)
-		return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: resolution out of range (1..65535)");
+	{ const int pc = check_march_params(*p, "nrs_render_nerf"); if (pc != NRS_OK) return pc; }
 	if (p->render_mode != NRS_RENDER_SHADE && p->render_mode != NRS_RENDER_COST)
 		return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: only render modes Shade and Cost are implemented (debug visualisations are out of scope)");
 	if (n_edits < 0 || n_edits > nrs_ctx::kMaxEdits) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: too many edit operators");
@@ -1067,7 +1098,8 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	nrs_ctx* ctx = m->ctx;
 	HIP_TRY(hipSetDevice(ctx->device));
 	hipStream_t s = (hipStream_t)stream;
-	const uint32_t slot = ctx->launch_serial++ % (uint32_t)nrs_ctx::kInFlight;
+	const uint32_t slot = ctx->launch_serial.fetch_add(1u) % (uint32_t)nrs_ctx::kInFlight;
+	if (ctx->slot_used[slot] && ctx->slot_stream[slot] != s) HIP_TRY(hipStreamWaitEvent(s, ctx->slot_done[slot], 0));
 	RenderCounters* d_counters_slot = ctx->d_counters + slot;
 	DeviceEdit* d_edits_slot = ctx->d_edits + (size_t)slot * nrs_ctx::kMaxEdits;
 
@@ -1156,6 +1188,9 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	if (a.wave_log) HIP_TRY(hipMemsetAsync(ctx->d_wave_log, 0, 8192 * 4 * 8, s));
 	HIP_TRY(hipMemsetAsync(d_counters_slot, 0, sizeof(RenderCounters), s));
 	NRS_TRY(launch_render(model_for_launch(m, *p), a, ctx->n_cus, s));
+	HIP_TRY(hipEventRecord(ctx->slot_done[slot], s));
+	ctx->slot_stream[slot] = s;
+	ctx->slot_used[slot] = true;
 	if (h_stats) {
 		RenderCounters c;
 		HIP_TRY(hipMemcpyAsync(&c, d_counters_slot, sizeof(c), hipMemcpyDeviceToHost, s));
@@ -1222,6 +1257,7 @@ int nrs_trace_samples(nrs_model* m, const nrs_render_params* p, void* stream, ui
                       float* d_t, float* d_dt, uint32_t* d_count) {
 	if (!m || !p || !d_pixel_idx || !d_t || !d_dt || !d_count) return fail(NRS_ERR_INVALID_ARG, "nrs_trace_samples: NULL argument");
 	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_trace_samples: occupancy not set");
+	{ const int pc = check_march_params(*p, "nrs_trace_samples"); if (pc != NRS_OK) return pc; }
 	HIP_TRY(hipSetDevice(m->ctx->device));
 	NRS_TRY(launch_trace_samples(model_for_launch(m, *p), *p, n_pixels, d_pixel_idx, max_samples, d_t, d_dt, d_count, stream));
 	return NRS_OK;

@@ -383,23 +383,30 @@ int nrs_snapshot_open(const char* path, nrs_snapshot** out) {
 		const Value* dir = root.find("dir_encoding");
 		if (!rgb || !dir) throw std::runtime_error("snapshot without dir_encoding / rgb_network (NerfNetworkNoDir) is not supported");
 		nrs_model_desc& d = s->desc;
-		d.n_features_per_level = (uint32_t)enc.number_or("n_features_per_level", 2);
+		// every hyper-parameter is validated BEFORE it is used in arithmetic (a crafted file must be refused, not divide by zero or shift by 200)
+		auto bounded = [](double v, double lo, double hi, const char* what) -> uint32_t {
+			if (!(v >= lo && v <= hi) || v != std::floor(v)) throw std::runtime_error(std::string("snapshot: ") + what + " out of range");
+			return (uint32_t)v;
+		};
+		d.n_features_per_level = bounded(enc.number_or("n_features_per_level", 2), 2, 2, "encoding.n_features_per_level (only 2 is supported)");
 		const double n_features = enc.number_or("n_features", 0);
+		if (!(n_features >= 0 && n_features <= 4096)) throw std::runtime_error("snapshot: encoding.n_features out of range");
 		d.n_levels = n_features > 0 ? (uint32_t)n_features / d.n_features_per_level : (uint32_t)enc.number_or("n_levels", 16);
-		d.log2_hashmap_size = (uint32_t)enc.number_or("log2_hashmap_size", 15);
-		d.base_resolution = (uint32_t)enc.number_or("base_resolution", 0);
+		d.log2_hashmap_size = bounded(enc.number_or("log2_hashmap_size", 15), 8, 24, "encoding.log2_hashmap_size");
+		d.base_resolution = bounded(enc.number_or("base_resolution", 0), 0, 65536, "encoding.base_resolution");
 		if (!d.base_resolution) d.base_resolution = 1u << (d.log2_hashmap_size / 3);
 		float pls = (float)enc.number_or("per_level_scale", 0.0);
 		if (pls <= 0.0f && d.n_levels > 1) pls = std::exp(std::log(2048.0f * (float)as / (float)d.base_resolution) / (float)(d.n_levels - 1));
 		d.per_level_scale = pls;
-		d.n_neurons = (uint32_t)net.number_or("n_neurons", 64);
-		d.density_hidden_layers = (uint32_t)net.number_or("n_hidden_layers", 1);
+		if (!std::isfinite(pls) || pls <= 0.0f) throw std::runtime_error("snapshot: encoding.per_level_scale out of range");
+		d.n_neurons = bounded(net.number_or("n_neurons", 64), 1, 4096, "network.n_neurons");
+		d.density_hidden_layers = bounded(net.number_or("n_hidden_layers", 1), 0, 64, "network.n_hidden_layers");
 		d.density_output_dims = 16; // nerf_network_full.h:47-49
-		d.rgb_hidden_layers = (uint32_t)rgb->number_or("n_hidden_layers", 2);
+		d.rgb_hidden_layers = bounded(rgb->number_or("n_hidden_layers", 2), 0, 64, "rgb_network.n_hidden_layers");
 		if ((uint32_t)rgb->number_or("n_neurons", 64) != d.n_neurons) throw std::runtime_error("density / rgb networks of different widths are not supported");
 		d.sh_degree = 4;
 		if (const Value* nested = dir->find("nested"))
-			if (nested->kind == Value::Arr && !nested->a.empty()) d.sh_degree = (uint32_t)nested->a[0].number_or("degree", 4);
+			if (nested->kind == Value::Arr && !nested->a.empty()) d.sh_degree = bounded(nested->a[0].number_or("degree", 4), 0, 16, "dir_encoding.degree");
 		d.rgb_activation = NRS_ACT_LOGISTIC;      // testbed.h:636-637 defaults; snapshots do not store them
 		d.density_activation = NRS_ACT_EXPONENTIAL;
 		const float half = 0.5f * (float)std::min<uint32_t>(1u << (kCascades - 1), as); // m_aabb, testbed_nerf.cu:3410-3411

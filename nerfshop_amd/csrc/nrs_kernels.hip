@@ -176,7 +176,19 @@ __device__ __forceinline__ bool packet_pixel_tail(const RenderArgs& a, uint32_t 
 // result of the sequential loop bit for bit) and walks TEAM samples on.  Samples past the one that saturates the ray are
 // discarded, as the reference discards the rest of a batch (tn:951-960).  The fill works on 64 / TEAM pixels per packet.
 template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM>
-__global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceModel m, const RenderArgs a) {
+__global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceModel m_arg, const RenderArgs a_arg) {
+	// The two argument structs (~1.3 KB of wave-uniform values) live in the kernel-argument segment and are read with scalar loads.
+	// Left alone, the compiler hoists every such load out of the frame loop and then spills ~150 scalar registers into VGPR lanes
+	// (v_writelane / v_readlane: VALU slots in the round loop, 3 VGPRs).  NRS_FRESH_ARGS re-derives the two references from an
+	// offset the compiler cannot see through (always 0), so the loads of a phase stay inside that phase: short-lived SGPRs, re-read
+	// from the scalar cache on use.
+	#define NRS_FRESH_ARGS(m, a)                                                                          \
+		uint32_t zofs_##m = 0;                                                                            \
+		asm volatile("" : "+s"(zofs_##m));                                                                \
+		const DeviceModel& m = *reinterpret_cast<const DeviceModel*>(reinterpret_cast<const char*>(&m_arg) + zofs_##m); \
+		const RenderArgs& a = *reinterpret_cast<const RenderArgs*>(reinterpret_cast<const char*>(&a_arg) + zofs_##m);
+	const DeviceModel& m = m_arg;
+	const RenderArgs& a = a_arg;
 	__shared__ RenderSmem<WAVES> sm;
 	for (uint32_t i = threadIdx.x; i < kCoarseWords; i += blockDim.x) sm.coarse[i] = m.occ.mask[i];
 	if (threadIdx.x == 0) { sm.queue = 0ull; sm.sum_samples = 0ull; sm.sum_alive = 0u; sm.sum_hit = 0u; sm.n_finished = 0u; }
@@ -220,6 +232,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	int ph_cur = 0;
 
 	for (;;) {
+		NRS_FRESH_ARGS(m1, a1);
+		const nrs_render_params& p1 = a1.p;
 		NRS_PHASE(0); // fill
 		const unsigned long long free_mask = __ballot(!have);
 		const uint32_t nfree = (uint32_t)__popcll(free_mask);
@@ -227,35 +241,35 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		// ---- fill the ring with rays that found an occupied cell (init_rays + advance_pos_nerf) ----
 		// (Measured: moving this into its own lean kernel does not pay -- the DDA's dependent bitfield loads overlap with
 		// other waves' gather/MLP work here for free, while a separate launch adds ~1 ms of serial time at 1080p.)
-		while (more && ring_count < (TEAM > 1 ? 64u / gen_t : (TEAM == 0 && tail_seen ? a.tail_target : nfree)) && nfree >= kRefillWhenIdle) {
-			const uint32_t pk = claim_packet(&sm.queue, &a.counters->next_packet, a.n_packets, lane);
+		while (more && ring_count < (TEAM > 1 ? 64u / gen_t : (TEAM == 0 && tail_seen ? a1.tail_target : nfree)) && nfree >= kRefillWhenIdle) {
+			const uint32_t pk = claim_packet(&sm.queue, &a1.counters->next_packet, a1.n_packets, lane);
 			if (pk == kNoPacket) { more = false; if (PROF) { pf_tq = wall_clock64() - pf_wall0; pf_rounds_q = pf_rounds; } break; }
 			if (PROF) ++pf_packets;
 			uint32_t x, y, oi;
 			bool alive = false;
 			float t0 = 0.f;
 			bool small = TEAM > 1, inside;
-			if (TEAM == 0 && a.all_tail) { // a launch of 4x4 packets only (few rays for the GPU): every generation sizes its teams
+			if (TEAM == 0 && a1.all_tail) { // a launch of 4x4 packets only (few rays for the GPU): every generation sizes its teams
 				small = true;
 				tail_seen = true;
-				inside = packet_pixel<4>(a, pk, lane, x, y, oi);
-			} else if (TEAM == 0 && a.p_big) {
-				small = pk >= a.p_big;
+				inside = packet_pixel<4>(a1, pk, lane, x, y, oi);
+			} else if (TEAM == 0 && a1.p_big) {
+				small = pk >= a1.p_big;
 				tail_seen = tail_seen || small;
-				inside = small ? packet_pixel_tail(a, pk - a.p_big, lane, x, y, oi) : packet_pixel_bulk(a, pk, lane, x, y, oi);
+				inside = small ? packet_pixel_tail(a1, pk - a1.p_big, lane, x, y, oi) : packet_pixel_bulk(a1, pk, lane, x, y, oi);
 			} else {
-				inside = packet_pixel<(TEAM ? TEAM : 1)>(a, pk, lane, x, y, oi);
+				inside = packet_pixel<(TEAM ? TEAM : 1)>(a1, pk, lane, x, y, oi);
 			}
 			const bool first_of_team = TEAM == 0 ? (!small || (lane & 3) == 0) : tk == 0;
 			if (inside) {
-				Ray r = init_ray(p, x, y, off_x, off_y);
+				Ray r = init_ray(p1, x, y, off_x, off_y);
 				if (first_of_team) {
-					a.depth[oi] = 1e10f; // tn:2586
-					if (a.steps) a.steps[oi] = 0;
+					a1.depth[oi] = 1e10f; // tn:2586
+					if (a1.steps) a1.steps[oi] = 0;
 				}
 				alive = r.alive;
 				uint32_t it_fill = 0;
-				if (alive) alive = first_hit(p, m, sm.coarse, x + (uint32_t)p.resolution[0] * y, r, PROF ? &it_fill : nullptr);
+				if (alive) alive = first_hit(p1, m1, sm.coarse, x + (uint32_t)p1.resolution[0] * y, r, PROF ? &it_fill : nullptr);
 				if (PROF) {
 					uint32_t mx = it_fill;
 					for (int sh = 32; sh > 0; sh >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, sh, 64));
@@ -288,19 +302,19 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			if (!have && rank < take) {
 				const uint2 e = ring[(ring_head + rank) & (kRing - 1)];
 				const uint32_t x = e.x & 0xffffu, y = e.x >> 16;
-				ray_origin_dir(p, x, y, off_x, off_y, o, d); // same arithmetic as at enqueue time -> same bits
+				ray_origin_dir(p1, x, y, off_x, off_y, o, d); // same arithmetic as at enqueue time -> same bits
 				idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 				t = __uint_as_float(e.y);
-				out_idx = pixel_out_idx(a, x, y);
+				out_idx = pixel_out_idx(a1, x, y);
 				cr = cg = cb = ca = 0.f;
 				ray_depth = 0.f; max_weight = 0.f; n_steps = 0;
 				have = true;
 				if (TEAM != 1) { // lane k of the team walks k samples ahead
 					valid = true;
 					for (int j = 0; j < tk && valid; ++j) {
-						t += calc_dt(t, p.cone_angle_constant);
+						t += calc_dt(t, p1.cone_angle_constant);
 						f3 npos; float ndt;
-						valid = march_to_occupied(p, m, sm.coarse, o, d, idir, t, npos, ndt, nullptr);
+						valid = march_to_occupied(p1, m1, sm.coarse, o, d, idir, t, npos, ndt, nullptr);
 					}
 				}
 			}
@@ -314,20 +328,22 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			continue;
 		}
 
+		NRS_FRESH_ARGS(m2, a2);
+		const nrs_render_params& p2 = a2.p;
 		NRS_PHASE(2); // sample set-up + cage warp
 		if (PROF) ++pf_rounds;
 		// ---- one sample per live ray: generate_next_nerf_network_inputs body (tn:668-692) ----
 		const f3 pos = o + d * t;
-		const float dt = calc_dt(t, p.cone_angle_constant);
-		f3 wpos = m.diag_pow2 ? mk3((pos.x - m.aabb.mn[0]) * m.inv_diag[0], (pos.y - m.aabb.mn[1]) * m.inv_diag[1], (pos.z - m.aabb.mn[2]) * m.inv_diag[2])
-		                      : warp_position(pos, m.aabb);
+		const float dt = calc_dt(t, p2.cone_angle_constant);
+		f3 wpos = m2.diag_pow2 ? mk3((pos.x - m2.aabb.mn[0]) * m2.inv_diag[0], (pos.y - m2.aabb.mn[1]) * m2.inv_diag[1], (pos.z - m2.aabb.mn[2]) * m2.inv_diag[2])
+		                      : warp_position(pos, m2.aabb);
 		f3 wdir = warp_direction(d);
 		const float wdt = warp_dt(dt);
 		bool empty = false;
 		const f3 wpos0 = wpos; // un-deformed sample position (membrane terms live in deformed space)
 		const bool act = TEAM != 1 ? (have && valid) : have; // this lane evaluates a sample in this round
 		if (ops && act) { // map_rays, last-to-first (tn:2899-2902)
-			for (int ei = a.n_edits - 1; ei >= 0; --ei) empty |= AFFINE ? edit_warp(a.edits[ei], true, wpos, wdir) : tet_warp(a.edits[ei], true, wpos, wdir);
+			for (int ei = a2.n_edits - 1; ei >= 0; --ei) empty |= AFFINE ? edit_warp(a2.edits[ei], true, wpos, wdir) : tet_warp(a2.edits[ei], true, wpos, wdir);
 		}
 		// ---- membrane correction inputs (compute_poisson_full_residuals, tn:2867-2883) + first network pass (tn:2890-2892) ----
 		float p_rgb[3] = {0.f, 0.f, 0.f}, p_out = 0.f, p_res = 0.f, sigma_old_raw = 0.f;
@@ -335,14 +351,12 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		if (POISSON) {
 			if (ops && have) {
 				const f3 udir = unwarp_direction(wdir);
-				for (int ei = a.n_edits - 1; ei >= 0; --ei)
-					if (a.edits[ei].apply_poisson) poisson_residual_rgb(a.edits[ei], wpos0, udir, p_rgb, p_out, p_res);
+				for (int ei = a2.n_edits - 1; ei >= 0; --ei)
+					if (a2.edits[ei].apply_poisson) poisson_residual_rgb(a2.edits[ei], wpos0, udir, p_rgb, p_out, p_res);
 			}
 			has_res = have && p_out > 1e-9f;
 			if (__any(has_res)) { // the reference evaluates the un-deformed network everywhere; only these samples consume it (tn:770-773)
-				const f3 ppos0 = mk3(xchg32(wpos0.x), xchg32(wpos0.y), xchg32(wpos0.z));
-				const bool phas = __shfl_xor((int)has_res, 32, 64) != 0;
-				encode_to_lds(gv, sm.ml, fl, lane, g, wpos0, has_res, ppos0, phas);
+				encode_to_lds(gv, m2.levels, sm.ml, fl, lane, g, wpos0, has_res);
 				uint32_t old_d = 0;
 				#pragma unroll 1
 				for (int b = 0; b < 2; ++b) {
@@ -358,11 +372,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 
 		NRS_PHASE(3); // gather
 		// ---- gather: own sample (block g) and the partner lane's sample (block 1-g), levels 2*it+g ----
-		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
-		const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
-		const bool phave = __shfl_xor((int)act, 32, 64) != 0;
-		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, act, ppos, phave);
+		encode_to_lds(gv, m2.levels, sm.ml, fl, lane, g, wpos, act);
 		NRS_PHASE(4); // SH + MLP
+		const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
 		half8 sh_own, sh_par;
 		encode_sh4_2(g, wdir, pdir, sh_own, sh_par);
 
@@ -373,7 +385,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			const int sel = (b != g) ? 1 : 0;
 			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
 			half8 dout = x0, rout = x1;
-			if (!(a.dbg & 2u)) {
+			if (!(a2.dbg & 2u)) {
 				dout = density_mlp(sm.ml.w, lane, x0, x1);
 				rout = rgb_mlp(sm.ml.w, lane, dout, sel ? sh_par : sh_own);
 			}
@@ -387,6 +399,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		const float sigma_raw = (float)hd[0];
 		const float raw_r = (float)hrg[0], raw_g = (float)hrg[1], raw_b = (float)hb[0];
 
+		NRS_FRESH_ARGS(m3, a3);
+		const nrs_render_params& p3 = a3.p;
 		NRS_PHASE(5); // composite + march + shade
 		// ---- composite_kernel_nerf body (tn:750-955, Shade mode) + next-sample march ----
 		uint32_t it_march = 0;
@@ -397,11 +411,11 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			// this lane's sample, reduced to what compositing needs
 			float s_alpha = 0.f, s_r = 0.f, s_g = 0.f, s_b = 0.f, s_depth = 0.f;
 			if (act) {
-				const f3 cpos = unwarp_position(wpos, m.aabb);
-				const float sigma = network_to_density(sigma_raw, m.density_activation);
+				const f3 cpos = unwarp_position(wpos, m3.aabb);
+				const float sigma = network_to_density(sigma_raw, m3.density_activation);
 				s_alpha = 1.f - __expf(-sigma * unwarp_dt(wdt));
 				if (empty) s_alpha = 0.0f;
-				s_r = network_to_rgb(raw_r, m.rgb_activation); s_g = network_to_rgb(raw_g, m.rgb_activation); s_b = network_to_rgb(raw_b, m.rgb_activation);
+				s_r = network_to_rgb(raw_r, m3.rgb_activation); s_g = network_to_rgb(raw_g, m3.rgb_activation); s_b = network_to_rgb(raw_b, m3.rgb_activation);
 				s_depth = dot3(cam_fwd, cpos - cam_o);
 			}
 			// every lane of the team composites the team's samples in marching order (composite_kernel_nerf, tn:750-955)
@@ -428,11 +442,11 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 						}
 						++n_steps;
 						if (tk == 0) ++st_samples;
-						if (ca > (1.0f - p.min_transmittance)) {
+						if (ca > (1.0f - p3.min_transmittance)) {
 							const float inv_a = __builtin_amdgcn_rcpf(ca);
 							cr *= inv_a; cg *= inv_a; cb *= inv_a; ca = 1.0f;
 							done = true;
-						} else if (n_steps >= a.max_steps) {
+						} else if (n_steps >= a3.max_steps) {
 							done = true; shade = false;
 						}
 					}
@@ -440,9 +454,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			}
 			if (have && !done) { // on to this lane's next sample, TEAM samples ahead
 				for (int j = 0; j < (int)gen_t && valid; ++j) {
-					t += calc_dt(t, p.cone_angle_constant);
+					t += calc_dt(t, p3.cone_angle_constant);
 					f3 npos; float ndt;
-					valid = march_to_occupied(p, m, sm.coarse, o, d, idir, t, npos, ndt, nullptr);
+					valid = march_to_occupied(p3, m3, sm.coarse, o, d, idir, t, npos, ndt, nullptr);
 				}
 			}
 			const bool lead_valid = __shfl((int)valid, team_base, 64) != 0;
@@ -451,38 +465,38 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				if (tk == 0) {
 					if (shade && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
 						float tr = cr, tg = cg, tb = cb, ta = ca;
-						if (p.render_mode == NRS_RENDER_COST) {
+						if (p3.render_mode == NRS_RENDER_COST) {
 							const float col = (float)n_steps / 128;
 							tr = tg = tb = col; ta = 1.0f;
-						} else if (!p.linear_colors) {
+						} else if (!p3.linear_colors) {
 							tr = srgb_to_linear(tr); tg = srgb_to_linear(tg); tb = srgb_to_linear(tb);
 						}
-						float4* fb = reinterpret_cast<float4*>(a.frame) + out_idx;
+						float4* fb = reinterpret_cast<float4*>(a3.frame) + out_idx;
 						const float4 prev = *fb;
 						const float om = 1.0f - ta;
 						*fb = make_float4(tr + prev.x * om, tg + prev.y * om, tb + prev.z * om, ta + prev.w * om);
-						if (ta > 0.2f) a.depth[out_idx] = ray_depth;
+						if (ta > 0.2f) a3.depth[out_idx] = ray_depth;
 						++st_hit;
 					}
-					if (a.steps) a.steps[out_idx] = n_steps;
+					if (a3.steps) a3.steps[out_idx] = n_steps;
 				}
 				have = false;
 			}
 		} else
 		if (have) { // one lane per ray
-			const f3 cpos = unwarp_position(wpos, m.aabb);
+			const f3 cpos = unwarp_position(wpos, m3.aabb);
 			const float T = 1.f - ca;
 			const float cdt = unwarp_dt(wdt);
-			const float sigma = network_to_density(sigma_raw, m.density_activation);
+			const float sigma = network_to_density(sigma_raw, m3.density_activation);
 			float alpha = 1.f - __expf(-sigma * cdt);
 			if (POISSON && has_res) { // tn:770-780
-				const float targetval = network_to_density(sigma_old_raw, m.density_activation);
-				const float val = p.poisson_target ? fminf(fmaxf(targetval, sigma), sigma + p_res) : sigma + p_res;
+				const float targetval = network_to_density(sigma_old_raw, m3.density_activation);
+				const float val = p3.poisson_target ? fminf(fmaxf(targetval, sigma), sigma + p_res) : sigma + p_res;
 				alpha = 1.f - __expf(-(val) * cdt);
 			}
 			if (empty) alpha = 0.0f;
 			const float weight = alpha * T;
-			const float sr = network_to_rgb(raw_r, m.rgb_activation), sg = network_to_rgb(raw_g, m.rgb_activation), sb = network_to_rgb(raw_b, m.rgb_activation);
+			const float sr = network_to_rgb(raw_r, m3.rgb_activation), sg = network_to_rgb(raw_g, m3.rgb_activation), sb = network_to_rgb(raw_b, m3.rgb_activation);
 			if (POISSON && has_res) { // tn:796-805, 939-943
 				const float alpha_N = 1.f - __expf(-sigma * cdt);
 				const float alpha_R = 1.f - __expf(-p_out * cdt);
@@ -503,36 +517,36 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			++n_steps;
 			++st_samples;
 			bool done = false, shade = true;
-			if (ca > (1.0f - p.min_transmittance)) {
+			if (ca > (1.0f - p3.min_transmittance)) {
 				// rgba /= alpha (tn:951-953): one v_rcp (1 ulp) + three multiplies instead of four IEEE divisions -- this block runs
 				// nearly every round (some lane of the wave saturates), and the colour tolerance (tests) is 5 orders of magnitude wider
 				const float inv_a = __builtin_amdgcn_rcpf(ca);
 				cr *= inv_a; cg *= inv_a; cb *= inv_a; ca = 1.0f;
 				done = true;
-			} else if (n_steps >= a.max_steps) {
+			} else if (n_steps >= a3.max_steps) {
 				done = true; shade = false; // MARCH_ITER exhausted: the reference never compacts such a ray into the hit list
 			} else {
 				t += dt;
 				f3 npos; float ndt;
-				done = !march_to_occupied(p, m, sm.coarse, o, d, idir, t, npos, ndt, PROF ? &it_march : nullptr);
+				done = !march_to_occupied(p3, m3, sm.coarse, o, d, idir, t, npos, ndt, PROF ? &it_march : nullptr);
 			}
 			if (done) {
 				if (shade && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
 					float tr = cr, tg = cg, tb = cb, ta = ca;
-					if (p.render_mode == NRS_RENDER_COST) {
+					if (p3.render_mode == NRS_RENDER_COST) {
 						const float col = (float)n_steps / 128;
 						tr = tg = tb = col; ta = 1.0f;
-					} else if (!p.linear_colors) {
+					} else if (!p3.linear_colors) {
 						tr = srgb_to_linear(tr); tg = srgb_to_linear(tg); tb = srgb_to_linear(tb);
 					}
-					float4* fb = reinterpret_cast<float4*>(a.frame) + out_idx;
+					float4* fb = reinterpret_cast<float4*>(a3.frame) + out_idx;
 					const float4 prev = *fb;
 					const float om = 1.0f - ta;
 					*fb = make_float4(tr + prev.x * om, tg + prev.y * om, tb + prev.z * om, ta + prev.w * om);
-					if (ta > 0.2f) a.depth[out_idx] = ray_depth;
+					if (ta > 0.2f) a3.depth[out_idx] = ray_depth;
 					++st_hit;
 				}
-				if (a.steps) a.steps[out_idx] = n_steps;
+				if (a3.steps) a3.steps[out_idx] = n_steps;
 				have = false;
 			}
 		}
@@ -605,17 +619,17 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 	}();
 	hipStream_t s = (hipStream_t)stream;
 	if (a.any_poisson) return launch_render_cfg<8, 2, false, true, true>(m, a, n_cus, s);
-	if (a.any_affine) return launch_render_cfg<8, 3, false, false, true>(m, a, n_cus, s);
+	if (a.any_affine) return launch_render_cfg<8, 4, false, false, true>(m, a, n_cus, s);
 	if (a.dbg & 4u) return launch_render_cfg<8, 4, true>(m, a, n_cus, s);
-	if (a.team == 0) return launch_render_cfg<8, 3, false, false, false, 0>(m, a, n_cus, s);
-	if (a.team == 2) return launch_render_cfg<8, 3, false, false, false, 2>(m, a, n_cus, s);
-	if (a.team == 4) return launch_render_cfg<8, 3, false, false, false, 4>(m, a, n_cus, s);
+	if (a.team == 0) return cfg == 105 ? launch_render_cfg<10, 5, false, false, false, 0>(m, a, n_cus, s) : launch_render_cfg<8, 4, false, false, false, 0>(m, a, n_cus, s);
+	if (a.team == 2) return launch_render_cfg<8, 4, false, false, false, 2>(m, a, n_cus, s);
+	if (a.team == 4) return launch_render_cfg<8, 4, false, false, false, 4>(m, a, n_cus, s);
 	// <8, 3>: __launch_bounds__(512, 3) lets the register allocator aim at 168 VGPRs; it settles at 128 (still 4 waves/SIMD,
 	// the LDS allows 2 workgroups per CU) with a schedule that measures 3-5 % faster than the <8, 4> one (122 VGPRs).
 	switch (cfg) {
 		case 42: return launch_render_cfg<4, 2>(m, a, n_cus, s);
-		case 84: return launch_render_cfg<8, 4>(m, a, n_cus, s);
-		default: return launch_render_cfg<8, 3>(m, a, n_cus, s);
+		case 83: return launch_render_cfg<8, 3>(m, a, n_cus, s);
+		default: return launch_render_cfg<8, 4>(m, a, n_cus, s);
 	}
 }
 
@@ -735,9 +749,7 @@ __global__ __launch_bounds__(256) void selection_rays_kernel(const DeviceModel m
 			have = false;
 		}
 		if (!__any(have)) break;
-		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
-		const bool phave = __shfl_xor((int)have, 32, 64) != 0;
-		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, have, ppos, phave);
+		encode_to_lds(gv, m.levels, sm.ml, fl, lane, g, wpos, have);
 		uint32_t res_d = 0;
 		#pragma unroll 1
 		for (int b = 0; b < 2; ++b) {
@@ -869,9 +881,7 @@ __global__ __launch_bounds__(256) void network_kernel(const DeviceModel m, uint3
 			wpos = mk3(c[0], c[1], c[2]);
 			if (MODE == 0) wdir = mk3(c[4], c[5], c[6]);
 		}
-		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
-		const bool phave = __shfl_xor((int)have, 32, 64) != 0;
-		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, have, ppos, phave);
+		encode_to_lds(gv, m.levels, sm.ml, fl, lane, g, wpos, have);
 
 		if (MODE == 2) {
 			#pragma unroll 1
@@ -966,9 +976,7 @@ __global__ __launch_bounds__(256) void grid_eval_kernel(const DeviceModel m, con
 			          pos.z * (a.box_mx[2] - a.box_mn[2]) + a.box_mn[2]);
 			wpos = warp_position(pos, m.aabb);
 		}
-		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
-		const bool phave = __shfl_xor((int)have, 32, 64) != 0;
-		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, have, ppos, phave);
+		encode_to_lds(gv, m.levels, sm.ml, fl, lane, g, wpos, have);
 		half8 sh;
 		if (MODE == 1) sh = encode_sh4(g, wdir);
 		uint32_t res_d = 0, res_rg = 0, res_b = 0;
@@ -1159,9 +1167,7 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 			f3 unused = mk3(0.5f, 0.5f, 0.5f);
 			for (int k = a.n_edits - 1; k >= 0; --k) empty |= edit_warp(a.edits[k], false, wpos, unused);
 		}
-		const f3 ppos = mk3(xchg32(wpos.x), xchg32(wpos.y), xchg32(wpos.z));
-		const bool phave = __shfl_xor((int)have, 32, 64) != 0;
-		encode_to_lds(gv, sm.ml, fl, lane, g, wpos, have, ppos, phave);
+		encode_to_lds(gv, m.levels, sm.ml, fl, lane, g, wpos, have);
 		_Float16 raw_b[2];
 		#pragma unroll 1
 		for (int b = 0; b < 2; ++b) {

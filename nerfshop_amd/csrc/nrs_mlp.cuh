@@ -3,10 +3,10 @@
 // Replaces tiny-cuda-nn's kernel_grid + 2x kernel_mlp_fused + SH encoding + extract_density with one
 // on-chip pipeline.  A wave owns 64 samples, processed as two 32-sample MFMA column blocks:
 //
-//   block b holds the samples of lanes 32b..32b+31.  Lane l = (j = l & 31, g = l >> 5) works for sample j of each
-//   block and owns, of that sample, the hash-grid levels L(g, it) = 2*it + g (it = 0..7) -- the two lane halves split
-//   the 16 levels even/odd, so both halves of an iteration are of the same kind (dense / hashed) except for at most one
-//   mixed pair -- and the SH coefficients 8g..8g+7.
+//   block b holds the samples of lanes 32b..32b+31.  Every lane gathers the 16 hash-grid levels of its OWN sample, two levels per
+//   iteration (level parameters wave-uniform, in scalar registers), and writes them into the per-wave LDS slab in the order the
+//   MFMA B operands want: lane l = (j = l & 31, g = l >> 5) supplies, for sample j of each block, the levels 2*it + g (it = 0..7)
+//   and the SH coefficients 8g..8g+7.
 //
 // Every layer is computed transposed, H^T[unit][sample] = W[unit][k] * X^T[k][sample], with
 // v_mfma_f32_32x32x16_f16: A = a 32x16 weight tile (LDS, pre-arranged on the host), B = 16 x 32 samples.  The D tile of
@@ -39,12 +39,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 enum { KIND_DENSE = 0, KIND_HASHED = 1, KIND_MIXED = 2, KIND_RECORD = 3 };
 
-// Per-block model state in LDS: weight fragments, level table (index 2*it+g), kind of each level pair.
+// Per-block model state in LDS: weight fragments, kind of each level pair (the level table itself is read with scalar loads).
 struct ModelLds {
 	half8 w[kNumFrags * 64];
-	LevelParams levels[kLevels];
-	uint32_t kinds[8];
+	uint32_t kinds[8];        // kind of the level pair (2 it, 2 it + 1): both records / both hashed / both dense, else KIND_MIXED
 	uint32_t kinds_native[8]; // the kinds without the cell records (samples outside [0,1]^3 take these)
+	uint32_t one_line;        // NRS_DEBUG & 1
 };
 // Per-wave feature slab: feat[it][sel][lane], sel 0 = the lane's own sample, 1 = its partner's (lane ^ 32) sample.
 struct FeatLds { uint32_t feat[8][2][64]; };
@@ -53,18 +53,14 @@ __device__ __forceinline__ void stage_model_to_lds(const DeviceModel& m, ModelLd
 	const uint4* src = reinterpret_cast<const uint4*>(m.wfrag);
 	uint4* dst = reinterpret_cast<uint4*>(s.w);
 	for (uint32_t i = threadIdx.x; i < kWfragBytes / 16; i += blockDim.x) dst[i] = src[i];
-	if (threadIdx.x < kLevels) {
-		LevelParams lp = m.levels[threadIdx.x];
-		if (dbg & 1u) { lp.hashed = 1; lp.mask = 31; lp.offset = 0; lp.count = 32; } // profiling: every gather of a wave hits one 128-byte line
-		s.levels[threadIdx.x] = lp;
-	}
 	if (threadIdx.x < 8) {
 		const uint32_t h0 = (dbg & 1u) ? 1u : m.levels[2 * threadIdx.x].hashed, h1 = (dbg & 1u) ? 1u : m.levels[2 * threadIdx.x + 1].hashed;
-		const bool rec = !(dbg & 1u) && m.levels[2 * threadIdx.x].cached && m.levels[2 * threadIdx.x + 1].cached;
+		const bool c0 = !(dbg & 1u) && m.levels[2 * threadIdx.x].cached, c1 = !(dbg & 1u) && m.levels[2 * threadIdx.x + 1].cached;
 		const uint32_t native = (h0 && h1) ? KIND_HASHED : ((!h0 && !h1) ? KIND_DENSE : KIND_MIXED);
-		s.kinds[threadIdx.x] = rec ? KIND_RECORD : native;
+		s.kinds[threadIdx.x] = (c0 && c1) ? KIND_RECORD : ((c0 || c1) ? KIND_MIXED : native);
 		s.kinds_native[threadIdx.x] = native;
 	}
+	if (threadIdx.x == 0) s.one_line = dbg & 1u;
 	__syncthreads();
 }
 
@@ -199,60 +195,86 @@ __device__ __forceinline__ uint32_t level_eval_exact(const GridView& gv, const L
 	return __builtin_bit_cast(uint32_t, r);
 }
 
-// One level of TWO samples (the lane's own, A, and its partner's, B).  All gathers of both samples are issued before the
-// first is consumed: a round is a chain of dependent memory round trips, and when few waves are left on a CU (the end of a
-// frame) its latency, not its throughput, sets the frame time.  Idle lanes gather for position 0 (one shared cache line)
-// so that the code stays branch-free; their result is zeroed.
+// Issue the loads of one sample at one level of kind KIND (the level parameters are wave-uniform: scalar registers).
 template <int KIND>
-__device__ __forceinline__ void level_eval_pair(const GridView& gv, const LevelParams& lp, f3 posA, bool actA, f3 posB, bool actB, uint32_t& fa, uint32_t& fb) {
-	const f3 zero = mk3(0.f, 0.f, 0.f);
-	const CellCoords ca = cell_coords(lp, actA ? posA : zero), cb = cell_coords(lp, actB ? posB : zero);
-	const bool lane_hashed = (KIND == KIND_HASHED) || (KIND == KIND_MIXED && lp.hashed);
-	const bool slowA = KIND != KIND_RECORD && !lane_hashed && dense_needs_slow(lp, ca), slowB = KIND != KIND_RECORD && !lane_hashed && dense_needs_slow(lp, cb);
-	if (KIND != KIND_HASHED && KIND != KIND_RECORD && __builtin_expect(__any(slowA || slowB), 0)) { // exact tcnn wrap for samples outside [0,1)^3: rare
-		fa = level_eval_exact(gv, lp, ca);
-		fb = level_eval_exact(gv, lp, cb);
+__device__ __forceinline__ void issue_level(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t v[8]) {
+	if (KIND == KIND_RECORD) issue_record_loads(gv, lp, c, v);
+	else if (KIND == KIND_HASHED) issue_gathers<true>(gv, lp, c, v);
+	else issue_gathers<false>(gv, lp, c, v);
+}
+__device__ __forceinline__ uint32_t zero_if(bool cond, uint32_t v) { return cond ? 0u : v; }
+
+// TWO levels (an even one and the odd one after it) of ONE sample, both of kind KIND.  All loads of both levels are issued before the
+// first is consumed: a round is a chain of dependent memory round trips, and when few waves are left on a CU (the end of a frame)
+// its latency, not its throughput, sets the frame time.  Idle lanes gather for position 0 (one shared cache line) so that the code
+// stays branch-free; their result is zeroed.
+template <int KIND>
+__device__ __forceinline__ void level_eval_two(const GridView& gv, const LevelParams& lp0, const LevelParams& lp1, f3 pos, bool act, uint32_t& f0, uint32_t& f1) {
+	const f3 q = act ? pos : mk3(0.f, 0.f, 0.f);
+	const CellCoords c0 = cell_coords(lp0, q), c1 = cell_coords(lp1, q);
+	if (KIND == KIND_DENSE && __builtin_expect(__any(dense_needs_slow(lp0, c0) || dense_needs_slow(lp1, c1)), 0)) { // exact tcnn wrap for samples outside [0,1)^3: rare
+		f0 = level_eval_exact(gv, lp0, c0);
+		f1 = level_eval_exact(gv, lp1, c1);
 	} else {
-		uint32_t va[8], vb[8];
-		if (KIND == KIND_RECORD) {
-			issue_record_loads(gv, lp, ca, va);
-			issue_record_loads(gv, lp, cb, vb);
-		} else if (KIND == KIND_HASHED) {
-			issue_gathers<true>(gv, lp, ca, va);
-			issue_gathers<true>(gv, lp, cb, vb);
-		} else if (KIND == KIND_DENSE) {
-			issue_gathers<false>(gv, lp, ca, va);
-			issue_gathers<false>(gv, lp, cb, vb);
-		} else if (lane_hashed) { // mixed pair: the two lane halves are of different kinds
-			issue_gathers<true>(gv, lp, ca, va);
-			issue_gathers<true>(gv, lp, cb, vb);
-		} else {
-			issue_gathers<false>(gv, lp, ca, va);
-			issue_gathers<false>(gv, lp, cb, vb);
-		}
-		fa = interpolate(ca, va);
-		fb = interpolate(cb, vb);
+		uint32_t v0[8], v1[8];
+		issue_level<KIND>(gv, lp0, c0, v0);
+		issue_level<KIND>(gv, lp1, c1, v1);
+		f0 = interpolate(c0, v0);
+		f1 = interpolate(c1, v1);
 	}
-	if (!actA) fa = 0u;
-	if (!actB) fb = 0u;
+	f0 = zero_if(!act, f0);
+	f1 = zero_if(!act, f1);
+}
+// One level of one sample, kind decided at run time (wave-uniform): the pairs whose two levels are of different kinds (the one
+// dense | hashed pair of a model without cell records, a records | no-records boundary at an odd level) come here, level after level.
+__device__ __forceinline__ uint32_t level_eval_one(const GridView& gv, const LevelParams& lp, bool use_record, f3 pos, bool act) {
+	const f3 q = act ? pos : mk3(0.f, 0.f, 0.f);
+	const CellCoords c = cell_coords(lp, q);
+	uint32_t f;
+	uint32_t v[8];
+	if (use_record) {
+		issue_level<KIND_RECORD>(gv, lp, c, v);
+		f = interpolate(c, v);
+	} else if (lp.hashed) {
+		issue_level<KIND_HASHED>(gv, lp, c, v);
+		f = interpolate(c, v);
+	} else if (__builtin_expect(__any(dense_needs_slow(lp, c)), 0)) {
+		f = level_eval_exact(gv, lp, c);
+	} else {
+		issue_level<KIND_DENSE>(gv, lp, c, v);
+		f = interpolate(c, v);
+	}
+	return zero_if(!act, f);
 }
 
-// All 8 level pairs of two positions (own sample A, partner's sample B) -> the wave's feature slab.
-__device__ __forceinline__ void encode_to_lds(const GridView& gv, const ModelLds& ml, FeatLds& fl, int lane, int g, f3 posA, bool actA, f3 posB, bool actB) {
+// All 16 levels of the lane's OWN sample -> the wave's feature slab, two levels (2 it, 2 it + 1) per iteration.
+// A lane used to gather half the levels of its own sample and half the levels of its partner's (lane ^ 32), which made the level a
+// per-lane quantity: twelve VGPRs of level parameters read from LDS per iteration, the partner's position held in registers, a
+// fourth "mixed" kind.  Now every lane of the wave works on the same two levels, so their parameters are wave-uniform -- scalar
+// loads straight from the kernel's argument segment (`lv` = DeviceModel::levels), no VGPR, no LDS read -- and the values are the
+// same bits as before: the arithmetic per (sample, level) did not change.  The slab layout the MLP reads is unchanged too:
+// feat[it][0][l] = level 2 it + g(l) of lane l's sample, feat[it][1][l] = the same level of lane (l ^ 32)'s sample; so the level
+// of the lane's own parity goes to [0][lane] and the other one to [1][lane ^ 32] (a conflict-free permutation of the banks).
+__device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelParams* __restrict__ lv, const ModelLds& ml, FeatLds& fl, int lane, int g, f3 pos, bool act) {
 	// the records cover [0,1]^3; a wave with a sample outside it (a warped sample of an edit, rarely) gathers the native way
-	const bool outside = __any((actA && outside_unit_cube(posA)) || (actB && outside_unit_cube(posB)));
+	const bool outside = __any(act && outside_unit_cube(pos));
 	const uint32_t* kinds = outside ? ml.kinds_native : ml.kinds;
+	const bool one_line = __builtin_amdgcn_readfirstlane(ml.one_line) != 0u; // profiling (NRS_DEBUG & 1): every gather of a wave hits one 128-byte line
 	#pragma unroll 1
 	for (int it = 0; it < 8; ++it) {
-		const LevelParams lp = ml.levels[2 * it + g];
+		LevelParams lp0 = lv[2 * it], lp1 = lv[2 * it + 1];
+		if (one_line) { lp0.hashed = lp1.hashed = 1u; lp0.mask = lp1.mask = 31u; lp0.offset = lp1.offset = 0u; lp0.count = lp1.count = 32u; }
 		const uint32_t kind = __builtin_amdgcn_readfirstlane(kinds[it]);
-		uint32_t fa, fb;
-		if (kind == KIND_RECORD) level_eval_pair<KIND_RECORD>(gv, lp, posA, actA, posB, actB, fa, fb);
-		else if (kind == KIND_HASHED) level_eval_pair<KIND_HASHED>(gv, lp, posA, actA, posB, actB, fa, fb);
-		else if (kind == KIND_DENSE) level_eval_pair<KIND_DENSE>(gv, lp, posA, actA, posB, actB, fa, fb);
-		else level_eval_pair<KIND_MIXED>(gv, lp, posA, actA, posB, actB, fa, fb);
-		fl.feat[it][0][lane] = fa;
-		fl.feat[it][1][lane] = fb;
+		uint32_t f0, f1;
+		if (kind == KIND_RECORD) level_eval_two<KIND_RECORD>(gv, lp0, lp1, pos, act, f0, f1);
+		else if (kind == KIND_HASHED) level_eval_two<KIND_HASHED>(gv, lp0, lp1, pos, act, f0, f1);
+		else if (kind == KIND_DENSE) level_eval_two<KIND_DENSE>(gv, lp0, lp1, pos, act, f0, f1);
+		else {
+			f0 = level_eval_one(gv, lp0, !outside && !one_line && lp0.cached, pos, act);
+			f1 = level_eval_one(gv, lp1, !outside && !one_line && lp1.cached, pos, act);
+		}
+		fl.feat[it][0][lane] = g ? f1 : f0;
+		fl.feat[it][1][lane ^ 32] = g ? f0 : f1;
 	}
 }
 

@@ -402,14 +402,13 @@ bool desc_supported(const nrs_model_desc& d) {
 
 void make_level_table(const nrs_model_desc& d, LevelTable& lt) {
 	// tcnn GridEncoding ctor: scale = exp2(l*log2(pls))*base - 1; res = ceil(scale)+1;
-	// params_in_level = min(align8(res^3), 2^log2_T).  Scales are evaluated in double on the HOST and
-	// rounded to float once (our choice: keeps device exp2f out of the indexing path).
+	// params_in_level = min(align8(res^3), 2^log2_T).  tcnn evaluates the scale in FLOAT (exp2f(level * log2f(pls)) * base - 1.0f, in the
+	// encoding's constructor and in kernel_grid); so do we, with the host libm (upstream NVlabs/tiny-cuda-nn grid.h as recalled, App. B).
 	uint32_t off = 0;
-	const double l2 = std::log2((double)d.per_level_scale);
+	const float l2 = log2f(d.per_level_scale);
 	for (uint32_t l = 0; l < d.n_levels; ++l) {
-		double s = std::exp2((double)l * l2) * (double)d.base_resolution - 1.0;
-		lt.scale[l] = (float)s;
-		uint32_t res = (uint32_t)std::ceil((double)lt.scale[l]) + 1u;
+		lt.scale[l] = exp2f((float)l * l2) * (float)d.base_resolution - 1.0f;
+		uint32_t res = (uint32_t)ceilf(lt.scale[l]) + 1u;
 		lt.resolution[l] = res;
 		uint64_t n = (uint64_t)res * res * res;
 		uint64_t cap = 1ull << d.log2_hashmap_size;

@@ -155,6 +155,17 @@ def test_readers_survive_corrupt_input(built, tmp_path):
     variants.append(b"\x91" * 200)                               # nesting bomb
     variants.append(zlib.compress(blob)[:-5])                     # truncated zlib stream
     variants.append(b"\x78\x9c" + b"\x00" * 50)                 # zlib header, garbage body
+    # hyper-parameters that would divide by zero / shift out of range if used unchecked: must be refused, not crash the process
+    for key, val in (("n_features_per_level", 0), ("log2_hashmap_size", 200), ("log2_hashmap_size", -3), ("base_resolution", 1e12), ("n_features", 1e300),
+                     ("per_level_scale", float("nan"))):
+        bad = json.loads(json.dumps(formats.network_config(desc)))
+        bad["encoding"][key] = val
+        if key == "n_features_per_level":
+            bad["encoding"]["n_features"] = 32
+        bad["snapshot"] = cfg["snapshot"]
+        path.write_bytes(msgpack.packb(bad, use_bin_type=True))
+        with pytest.raises(_abi.NrsError):
+            formats.load_snapshot(path)
     for v in variants:
         path.write_bytes(v)
         try:

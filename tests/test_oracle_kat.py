@@ -190,6 +190,40 @@ def test_hashgrid_level_table_and_lookup(scene):
         assert f[1] == grid[2 * idx + 1]
 
 
+def test_level_scale_is_evaluated_in_float(built):
+    """tiny-cuda-nn evaluates the level scale in FLOAT -- exp2f(level * log2f(per_level_scale)) * base_resolution - 1.0f --
+    and ceil(scale) + 1 decides every later level offset, so one ulp next to an integer silently mis-addresses a checkpoint.  Oracle and
+    product follow the float formula; checked here against the host libm's exp2f / log2f called through ctypes (numpy's float32 exp2 is its own
+    SIMD routine and differs from libm in the last bit) over a sweep of per_level_scale values
+    (aabb scales 1..128, base resolutions 16 / 32 and values chosen so that scales land on or next to integers)."""
+    from nerfshop_amd import synth
+    lib = orc.load()
+    libm = C.CDLL("libm.so.6")
+    libm.exp2f.restype = libm.log2f.restype = C.c_float
+    libm.exp2f.argtypes = libm.log2f.argtypes = [C.c_float]
+    n_doubles_differ = 0
+    sweep = [synth.per_level_scale(a, b) for a in (1, 2, 4, 8, 16, 32, 64, 128) for b in (16, 32)] + [1.25, 1.5, 2.0, 1.3819128, 1.4472692, 1.38191288] + \
+            [float(np.float32(v)) for v in np.linspace(1.26, 2.0, 75)]
+    for base in (16, 32):
+        for pls in sweep:
+            d = synth.model_desc(1)
+            d.per_level_scale, d.base_resolution = pls, base
+            lt = synth.level_table(d)
+            scale = np.zeros(16, np.float32)
+            res, off, cnt, hashed = (np.zeros(16, np.uint32) for _ in range(4))
+            assert lib.orc_model_level_table(C.byref(d), scale.ctypes.data, res.ctypes.data, off.ctypes.data, cnt.ctypes.data, hashed.ctypes.data) == 0
+            lvl = np.arange(16, dtype=np.float32)
+            l2 = np.float32(libm.log2f(C.c_float(d.per_level_scale)))
+            want = np.array([np.float32(libm.exp2f(C.c_float(np.float32(l) * l2))) * np.float32(base) - np.float32(1.0) for l in lvl], np.float32)
+            want_res = np.ceil(want).astype(np.uint32) + 1
+            assert np.array_equal(scale.view(np.uint32), want.view(np.uint32)) and np.array_equal(lt["scale"].view(np.uint32), want.view(np.uint32)), (pls, base)
+            assert np.array_equal(res, want_res) and np.array_equal(lt["resolution"], want_res)
+            assert np.array_equal(off, lt["offset"]) and np.array_equal(cnt, lt["count"]) and np.array_equal(hashed, lt["hashed"])
+            in_double = (np.exp2(lvl.astype(np.float64) * np.log2(np.float64(np.float32(d.per_level_scale)))) * base - 1.0).astype(np.float32)
+            n_doubles_differ += int((in_double.view(np.uint32) != want.view(np.uint32)).sum())
+    assert n_doubles_differ > 50  # the sweep does contain levels where double evaluation lands on another float
+
+
 def test_network_oracle_against_numpy(scene):
     """The C++ oracle's MLP wiring against an independent numpy evaluation (float64 accumulate, fp16 rounding points)."""
     rng = np.random.default_rng(1)
