@@ -34,9 +34,14 @@ TILE = 64
 
 def build_scene(workload, rt, synth, ctx, torch):
     aabb_scale = 16 if workload.startswith("garden") else 1
-    with_edit = workload.endswith("cage")
+    with_edit = "cage" in workload
     desc = synth.model_desc(aabb_scale)
-    params = synth.make_params(desc, sigma_raw=synth.default_sigma_raw(aabb_scale))
+    if workload.endswith("varied"):
+        # non-uniform opacity: geometry inside the network (shaped) and a strong density noise, so that per-sample alpha -- and with
+        # it the number of samples a ray needs -- varies widely, as in a trained snapshot
+        params = synth.make_params(desc, sigma_raw=synth.default_sigma_raw(aabb_scale), shaped=True, density_noise=1.5, aabb_scale=aabb_scale)
+    else:
+        params = synth.make_params(desc, sigma_raw=synth.default_sigma_raw(aabb_scale))
     grid = synth.density_grid(aabb_scale)
     tb = rt.Testbed(ctx, desc, aabb_scale)
     tb.nerf_network.set_params(params)
@@ -63,41 +68,52 @@ def camera_for(step, synth, aabb_scale):
     return synth.orbit_camera(45.0 * (step % 8) + 30.0, 30.0, scale=scale)
 
 
-def cpu_baseline(scene, synth, width, height, n_frames=8):
-    """The oracle (our CPU restatement; the reference has no CPU path and cannot be built here) on a bounded sample:
-    the bench's 8 views at 1/16 of the pixels (480x270), all host cores (~10-20 s of CPU work)."""
+def cpu_baseline(synth):
+    """BASELINE config #1 (SURVEY 8d "Config 1"): one 256x256 frame of the lego-like scene, NO edits, on the host CPU, best of 5, all cores;
+    plus a single-thread figure on a bounded 64x64 view of the same camera (a whole 256x256 frame takes ~100 s on one thread).
+    The CPU path is the ORACLE (our restatement, pinned to the reference's compiled code): a checker -- software fp16, exact double
+    accumulation, the reference's global compaction loop -- not a tuned CPU renderer; the reference itself has no CPU path."""
     from oracle import oracle as orc
-    desc, params = scene["desc"], scene["params"]
-    bitfield = scene["tb"].nerf_network.get_density_bitfield()
-    model = orc.Model(desc, params, bitfield)
-    edits = []
-    if scene["edit"] is not None:
-        edits = [orc.Edit(desc, scene["edit"].tet_mesh_struct(), keepalive=scene["edit"])]
-    w, h = width // 4, height // 4
-    cores = orc.load().orc_max_threads()
-    total, t_total = 0, 0.0
-    for f in range(n_frames):
-        p = synth.render_params(w, h, camera_for(f, synth, scene["aabb_scale"]), aabb_scale=scene["aabb_scale"])
+    desc = synth.model_desc(1)
+    params = synth.make_params(desc, sigma_raw=synth.default_sigma_raw(1))
+    model = orc.Model(desc, params, synth.grid_to_bitfield(synth.density_grid(1)))
+    cores = int(orc.load().orc_max_threads())
+    cam = synth.orbit_camera(30.0, 30.0, scale=0.33)
+    p = synth.render_params(256, 256, cam, aabb_scale=1, apply_operators=False)
+    best, samples = None, 0
+    for _ in range(5):
         t0 = time.perf_counter()
-        _, _, _, st = model.render(p, edits)
-        t_total += time.perf_counter() - t0
-        total += st.composited
-    return {"value": round(total / t_total / 1e6, 4), "unit": "Msamples/s", "cores": int(cores), "kind": "port",
-            "sample": f"the {n_frames} bench views of the same workload at {w}x{h} (1/16 of the pixels each), {total} samples, {t_total:.1f} s",
-            "fps_equiv_1080p": round(1.0 / (t_total / n_frames * 16.0), 4)}
+        _, _, _, st = model.render(p, [])
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        samples = int(st.composited)
+    p1 = synth.render_params(64, 64, cam, aabb_scale=1, apply_operators=False)
+    t0 = time.perf_counter()
+    _, _, _, st1 = model.render(p1, [], n_threads=1)
+    dt1 = time.perf_counter() - t0
+    orc.load().orc_render  # (thread count is restored by the next call's n_threads = 0 -> OpenMP default)
+    return {"value": round(samples / best / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "note": "checker-grade oracle (software fp16, double accumulation), not a tuned CPU renderer",
+            "sample": f"BASELINE config #1: one 256x256 frame, no edits, best of 5: {samples} samples in {best * 1e3:.0f} ms ({1.0 / best:.2f} FPS)",
+            "ms_per_frame_256": round(best * 1e3, 1),
+            "one_thread": {"value": round(int(st1.composited) / dt1 / 1e6, 5), "unit": "Msamples/s", "sample": f"64x64 view of the same camera, {int(st1.composited)} samples in {dt1:.1f} s"}}
+
+
+TRAFFIC_FILE = "profiles/r02_traffic.json"
 
 
 def measured_traffic(workload):
     """HBM bytes per render_kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
-    MI355X_MICROARCH.md prescribes).  PMC counters cannot be sampled from inside this process, so the number comes from
-    profiles/r01_traffic.json (same workload, same kernel); null for the other workloads."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    MI355X_MICROARCH.md prescribes).  PMC counters cannot be sampled from inside this process, so this is a RECORDED number from
+    TRAFFIC_FILE (same workload, same kernel; `traffic_source` in the line says so); null for the other workloads."""
+    path = os.path.join(ROOT, TRAFFIC_FILE)
     if workload != "lego_cage" or not os.path.exists(path):
-        return None
+        return None, None
     try:
-        return int(json.load(open(path))["traffic_bytes_per_launch"])
+        j = json.load(open(path))
+        return int(j["traffic_bytes_per_launch"]), f"recorded: {TRAFFIC_FILE} ({j.get('source', 'rocprofv3 --pmc passes')}), not measured by this run"
     except Exception:
-        return None
+        return None, None
 
 
 def main():
@@ -105,7 +121,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage"])
+    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage", "lego_cage_varied"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -140,7 +156,7 @@ def main():
     # latency, during which the GPU drains -- then overlaps the start of frame k + 1, and the RCCL gather hides behind rendering.
     n_buf = max(1, args.frames_in_flight)
     tiled = world > 1 or n_buf > 1
-    max_buf = max(n_buf, 1 if args.no_extra else 2)
+    max_buf = max(n_buf, 1 if args.no_extra else 4)
     all_sharders = [tiles.TileSharder(W, H, TILE, rank, world, dev) for _ in range(max_buf)]
     all_streams = [torch.cuda.Stream(device=dev) for _ in range(max_buf)]
     frames = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(max_buf)]
@@ -229,32 +245,62 @@ def main():
         extra["noedit"] = {"msamples_per_s": round(ns / dt / 1e6, 2), "fps": round(8 / dt, 2)}
 
     if not args.no_extra:
-        # secondary: the same frames with two in flight (all ranks take part; `value` stays the one-at-a-time figure)
-        def pipelined_step(step):
-            b = step % 2
+        # secondary: the same frames with 2 and with 4 in flight (all ranks take part; `value` stays the one-at-a-time figure).  The drain of
+        # frame k -- one ray's latency, during which a GPU that owns only 1/N of the picture runs nearly empty -- overlaps frames k+1..;
+        # a viewer that accepts that latency (or an offline render) gets this rate, DESIGN 5.
+        def pipelined_step(step, k):
+            b = step % k
             p = make_params(step, force_tiled=True)
             with torch.cuda.stream(all_streams[b]):
                 all_sharders[b].clear()
                 tb.render_with_params(tb.nerf_network, p, all_sharders[b].local_frame, all_sharders[b].local_depth, None, all_streams[b])
                 all_sharders[b].gather(ctx, p, frames[b], depths[b])
-        for s in range(4):
-            pipelined_step(s)
-        sync_all()
-        t1 = time.perf_counter()
-        for s in range(args.steps):
-            pipelined_step(s)
-        sync_all()
-        dtp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(dtp, op=dist.ReduceOp.MAX)
-        extra["pipelined"] = {"frames_in_flight": 2, "msamples_per_s": round(total_samples / float(dtp[0]) / 1e6, 2),
-                              "fps": round(args.steps / float(dtp[0]), 2)}
+        for k in (2, 4):
+            for s in range(2 * k):
+                pipelined_step(s, k)
+            sync_all()
+            t1 = time.perf_counter()
+            for s in range(args.steps):
+                pipelined_step(s, k)
+            sync_all()
+            dtp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(dtp, op=dist.ReduceOp.MAX)
+            rec = {"frames_in_flight": k, "msamples_per_s": round(total_samples / float(dtp[0]) / 1e6, 2), "fps": round(args.steps / float(dtp[0]), 2)}
+            extra["pipelined" if k == 2 else "pipelined4"] = rec
+
+    if rank == 0 and world == 1 and not args.no_extra and args.workload == "lego_cage":
+        # secondary workloads, one frame at a time like `value`: BASELINE configs[3] (garden-style: aabb_scale 16, cone stepping, 5 cascades, one
+        # cage edit) and the lego-like scene with non-uniform opacity (a wide distribution of ray lengths, as a trained snapshot has)
+        for name in ("garden_cage", "lego_cage_varied"):
+            sc2 = build_scene(name, rt, synth, ctx, torch)
+            tb2 = sc2["tb"]
+
+            def step2(step, want_stats=False):
+                p2 = synth.render_params(W, H, camera_for(step, synth, sc2["aabb_scale"]), aabb_scale=sc2["aabb_scale"], apply_operators=True)
+                frame.zero_()
+                return tb2.render_with_params(tb2.nerf_network, p2, frame, depth, None, None, want_stats=want_stats)
+            ns = sum(int(step2(s2, want_stats=True).n_samples) for s2 in range(8))
+            rays = int(step2(0, want_stats=True).n_rays_alive)
+            for s2 in range(2):
+                step2(s2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s2 in range(8):
+                step2(s2)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            extra[name] = {"msamples_per_s": round(ns / dt / 1e6, 2), "fps": round(8 / dt, 2), "samples_per_frame": ns // 8, "rays_view0": rays,
+                           "roofline_frac": round(ns / dt * BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4)}
+            del sc2, tb2
+            torch.cuda.empty_cache()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_samples / elapsed / 1e6
         # roofline of the dominant kernel (render_kernel): algorithmic bytes per launch / mean launch duration (HIP events)
         per_launch_samples = total_samples / args.steps / world
+        traffic, traffic_source = measured_traffic(args.workload)
         ach = per_launch_samples * BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": "render_msamples_per_s_1080p",
@@ -272,19 +318,21 @@ def main():
             "data": "synthetic",
             "config": {"workload": {"lego_cage": "lego-like snapshot 1920x1080, one cage edit (BASELINE configs[2]/[4])",
                                     "lego": "lego-like snapshot 1920x1080, no edits (BASELINE configs[1])",
-                                    "garden_cage": "garden-style aabb_scale 16 1920x1080, one cage edit (BASELINE configs[3])"}[args.workload],
+                                    "garden_cage": "garden-style aabb_scale 16 1920x1080, one cage edit (BASELINE configs[3])",
+                                    "lego_cage_varied": "lego-like snapshot with non-uniform opacity (geometry in the network, density noise 1.5) 1920x1080, one cage edit"}[args.workload],
                        "resolution": [W, H], "samples_per_frame": int(total_samples / args.steps),
                        "sharding": f"{TILE}x{TILE} image tiles round-robin over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else ""),
                        "frames_in_flight": n_buf,
                        "cell_records": "levels 0..%d, %.1f GB (nrs_model_set_cell_cache default)" % (tb.nerf_network.cell_cache()[1] - 1, tb.nerf_network.cell_cache()[0] / 1e9)},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(args.workload) if world == 1 else None, "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 3),
+                         "traffic": traffic if world == 1 else None, "traffic_source": traffic_source if world == 1 else None,
+                         "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 3),
                          "algorithmic_bytes_per_launch": int(per_launch_samples * BYTES_PER_SAMPLE),
                          "mfma_tflops": round(per_launch_samples * FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12, 2)},
         }
         line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scene, synth, W, H)
+            line["cpu_baseline"] = cpu_baseline(synth)
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -209,13 +209,15 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	const f3 cam_fwd = mk3(p.camera_matrix1[6], p.camera_matrix1[7], p.camera_matrix1[8]);
 	const f3 cam_o = mk3(p.camera_matrix1[9], p.camera_matrix1[10], p.camera_matrix1[11]);
 
-	float off_x, off_y;
+	float off_x, off_y; // wave-uniform: kept in scalar registers
 	ld_random_pixel_offset(p.snap_to_pixel_centers ? 0u : p.spp_index, off_x, off_y);
+	off_x = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(off_x)));
+	off_y = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(off_y)));
 
 	// ---- per-lane ray state (registers) ----
 	bool have = false;
 	bool valid = true; // TEAM > 1: this lane's sample exists (the ray has not left the render box before it)
-	f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), idir = mk3(0, 0, 0);
+	f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
 	float t = 0.f;
 	float cr = 0.f, cg = 0.f, cb = 0.f, ca = 0.f; // accumulated premultiplied colour / alpha
 	float ray_depth = 0.f, max_weight = 0.f;
@@ -303,7 +305,6 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				const uint2 e = ring[(ring_head + rank) & (kRing - 1)];
 				const uint32_t x = e.x & 0xffffu, y = e.x >> 16;
 				ray_origin_dir(p1, x, y, off_x, off_y, o, d); // same arithmetic as at enqueue time -> same bits
-				idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 				t = __uint_as_float(e.y);
 				out_idx = pixel_out_idx(a1, x, y);
 				cr = cg = cb = ca = 0.f;
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				have = true;
 				if (TEAM != 1) { // lane k of the team walks k samples ahead
 					valid = true;
+					const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 					for (int j = 0; j < tk && valid; ++j) {
 						t += calc_dt(t, p1.cone_angle_constant);
 						f3 npos; float ndt;
@@ -453,6 +455,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 				}
 			}
 			if (have && !done) { // on to this lane's next sample, TEAM samples ahead
+				const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 				for (int j = 0; j < (int)gen_t && valid; ++j) {
 					t += calc_dt(t, p3.cone_angle_constant);
 					f3 npos; float ndt;
@@ -528,6 +531,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			} else {
 				t += dt;
 				f3 npos; float ndt;
+				const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // recomputed (IEEE, same bits) rather than held across the round
 				done = !march_to_occupied(p3, m3, sm.coarse, o, d, idir, t, npos, ndt, PROF ? &it_march : nullptr);
 			}
 			if (done) {
