@@ -60,6 +60,11 @@ def build_scene(workload, rt, synth, ctx, torch):
 
         grid = synth.deformed_density_grid(grid, desc, map_positions, aabb_scale)
     tb.nerf_network.set_density_grid(grid)  # threshold + mip pooling on the device
+    if aabb_scale > 1 and os.environ.get("NRS_SPARSE_GB", "64") != "0":
+        # aabb-16 scenes: the dense cell records end at level 7 (7.3 GB); levels 8.. get occupancy-sparse brick records wherever lookups can
+        # happen: the occupancy of the edited scene OR the un-edited one (the cage carries samples back to canonical space)
+        mask = synth.grid_to_bitfield(grid) | synth.grid_to_bitfield(synth.density_grid(aabb_scale))
+        tb.nerf_network.set_sparse_cell_cache(mask, int(float(os.environ.get("NRS_SPARSE_GB", "64")) * (1 << 30)))
     return dict(desc=desc, params=params, grid=grid, edit=edit, tb=tb, aabb_scale=aabb_scale)
 
 
@@ -121,7 +126,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage", "lego_cage_varied"])
+    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage", "garden", "lego_cage_varied"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -291,7 +296,8 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             extra[name] = {"msamples_per_s": round(ns / dt / 1e6, 2), "fps": round(8 / dt, 2), "samples_per_frame": ns // 8, "rays_view0": rays,
-                           "roofline_frac": round(ns / dt * BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4)}
+                           "roofline_frac": round(ns / dt * BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4),
+                           "cell_records_gb": round((tb2.nerf_network.cell_cache()[0] + tb2.nerf_network.sparse_cell_cache()[0]) / 1e9, 1)}
             del sc2, tb2
             torch.cuda.empty_cache()
 
@@ -319,11 +325,14 @@ def main():
             "config": {"workload": {"lego_cage": "lego-like snapshot 1920x1080, one cage edit (BASELINE configs[2]/[4])",
                                     "lego": "lego-like snapshot 1920x1080, no edits (BASELINE configs[1])",
                                     "garden_cage": "garden-style aabb_scale 16 1920x1080, one cage edit (BASELINE configs[3])",
+                                    "garden": "garden-style aabb_scale 16 1920x1080, no edits",
                                     "lego_cage_varied": "lego-like snapshot with non-uniform opacity (geometry in the network, density noise 1.5) 1920x1080, one cage edit"}[args.workload],
                        "resolution": [W, H], "samples_per_frame": int(total_samples / args.steps),
                        "sharding": f"{TILE}x{TILE} image tiles round-robin over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else ""),
                        "frames_in_flight": n_buf,
-                       "cell_records": "levels 0..%d, %.1f GB (nrs_model_set_cell_cache default)" % (tb.nerf_network.cell_cache()[1] - 1, tb.nerf_network.cell_cache()[0] / 1e9)},
+                       "cell_records": "levels 0..%d, %.1f GB (nrs_model_set_cell_cache default)" % (tb.nerf_network.cell_cache()[1] - 1, tb.nerf_network.cell_cache()[0] / 1e9) +
+                                       ("; sparse brick records for levels %d..%d, %.1f GB" % (tb.nerf_network.sparse_cell_cache()[1], sum(tb.nerf_network.sparse_cell_cache()[1:]) - 1,
+                                                                                               tb.nerf_network.sparse_cell_cache()[0] / 1e9) if tb.nerf_network.sparse_cell_cache()[2] else "")},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": traffic if world == 1 else None, "traffic_source": traffic_source if world == 1 else None,
                          "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 3),

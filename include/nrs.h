@@ -229,6 +229,15 @@ int    nrs_model_set_params(nrs_model* model, const void* h_params_fp16, size_t 
  * 9.3 GB, 0..13 take 64 GB.  Synchronises the device.  max_bytes = 0 drops the cache. */
 int    nrs_model_set_cell_cache(nrs_model* model, size_t max_bytes);
 size_t nrs_model_cell_cache_bytes(const nrs_model* model, uint32_t* n_levels_out);
+/* Sparse cell records for levels the dense cache cannot hold (aabb_scale-16 scenes: the fine levels of a 16^3-unit box).  The cells of
+ * a level are grouped in 8 x 8 x 8 bricks (16 KiB of records); a brick is allocated if it touches a cell marked in h_mask_bitfield (the
+ * density-bitfield layout, NRS_BITFIELD_BYTES): pass the occupancy of every place hash-grid lookups can happen -- the current occupancy,
+ * OR-ed with the un-edited one when edit operators carry samples back to canonical space.  A sample whose brick has no records gathers the
+ * hashed way, so results never depend on the mask, only speed does.  Levels are taken in pairs after the dense ones while brick tables +
+ * records fit max_bytes.  Kept current by nrs_model_set_params; dropped by nrs_model_set_cell_cache (set the dense budget first).
+ * h_mask_bitfield == NULL or max_bytes == 0 drops them.  Synchronises the device. */
+int    nrs_model_set_sparse_cell_cache(nrs_model* model, const uint8_t* h_mask_bitfield, size_t max_bytes);
+size_t nrs_model_sparse_cell_cache_bytes(const nrs_model* model, uint32_t* first_level_out, uint32_t* n_levels_out);
 /* occupancy: either the ready-made bitfield (NRS_BITFIELD_BYTES, Morton order, mips pooled) ... */
 int    nrs_model_set_density_bitfield(nrs_model* model, const uint8_t* h_bitfield, size_t n_bytes);
 /* ... or the float density grid [5*128^3]; thresholded with min(0.01, mean) and OR-pooled on the device

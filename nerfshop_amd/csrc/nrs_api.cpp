@@ -87,6 +87,13 @@ struct nrs_model {
 	uint4* d_records = nullptr;
 	size_t records_bytes = 0, cell_cache_budget = 0;
 	uint32_t cached_levels = 0;
+	// sparse brick records of the levels after them (nrs_model_set_sparse_cell_cache)
+	uint32_t* d_bricks = nullptr;   // brick tables of the sparse levels, concatenated
+	uint32_t* d_slots = nullptr;    // brick number of every allocated brick, per level (slot_first[l] .. +slot_count[l])
+	uint4* d_records2 = nullptr;
+	size_t sparse_bytes = 0;        // tables + slots + records
+	uint32_t sparse_first = 0, sparse_levels = 0;
+	uint32_t slot_first[kLevels] = {}, slot_count[kLevels] = {};
 };
 
 struct nrs_edit {
@@ -152,7 +159,7 @@ static uint32_t make_levels(const nrs_model_desc& d, LevelParams* lv) {
 		p.hashed = p.count < stride ? 1u : 0u;
 		p.mask = p.hashed ? p.count - 1u : 0u;
 		p.offset = off;
-		p.pad = 0;
+		p.tab_first = 0;
 		p.cached = p.rec_first = p.rec_res = p.rec_res2 = 0;
 		off += p.count;
 	}
@@ -468,8 +475,12 @@ void nrs_model_destroy(nrs_model* m) {
 	(void)hipFree(m->d_density_grid);
 	(void)hipFree(m->d_density_tmp);
 	(void)hipFree(m->d_records);
+	(void)hipFree(m->d_bricks);
+	(void)hipFree(m->d_slots);
+	(void)hipFree(m->d_records2);
 	delete m;
 }
+static void drop_sparse_cell_cache(nrs_model* m);
 // Cell-record cache: plan (how many levels fit the budget), allocate, build.  Levels are cached from the coarsest up, an
 // even number of them (the kernels evaluate levels in pairs), and their records share one allocation.
 static uint32_t plan_cell_cache(const LevelParams* lv, size_t budget, LevelParams* out, size_t* bytes) {
@@ -494,15 +505,107 @@ static uint32_t plan_cell_cache(const LevelParams* lv, size_t budget, LevelParam
 	return n;
 }
 static int rebuild_cell_cache(nrs_model* m) {
-	if (!m->cached_levels || !m->have_params) return NRS_OK;
-	NRS_TRY(launch_cell_records(m->dm, m->cached_levels, m->d_records, nullptr));
+	if (!m->have_params) return NRS_OK;
+	if (m->cached_levels) NRS_TRY(launch_cell_records(m->dm, m->cached_levels, m->d_records, nullptr));
+	for (uint32_t l = m->sparse_first; l < m->sparse_first + m->sparse_levels; ++l)
+		NRS_TRY(launch_brick_fill(m->dm, m->dm.levels[l], m->d_slots + m->slot_first[l], m->slot_count[l], m->d_records2, nullptr));
 	HIP_TRY(hipStreamSynchronize(nullptr));
 	return NRS_OK;
+}
+static void drop_sparse_cell_cache(nrs_model* m) {
+	(void)hipFree(m->d_bricks); (void)hipFree(m->d_slots); (void)hipFree(m->d_records2);
+	m->d_bricks = nullptr; m->d_slots = nullptr; m->d_records2 = nullptr;
+	m->sparse_bytes = 0; m->sparse_first = m->sparse_levels = 0;
+	for (uint32_t l = 0; l < kLevels; ++l)
+		if (m->dm.levels[l].cached == 2u) { m->dm.levels[l].cached = 0; m->dm.levels[l].rec_first = m->dm.levels[l].rec_res = m->dm.levels[l].rec_res2 = m->dm.levels[l].tab_first = 0; }
+	m->dm.records2 = nullptr; m->dm.bricks = nullptr;
+}
+// Sparse brick records for the levels after the dense ones, in pairs, while tables + records fit the budget.
+int nrs_model_set_sparse_cell_cache(nrs_model* m, const uint8_t* h_mask_bitfield, size_t max_bytes) {
+	if (!m) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_sparse_cell_cache: NULL model");
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	HIP_TRY(hipDeviceSynchronize()); // launches in flight may still read the old records
+	drop_sparse_cell_cache(m);
+	if (!h_mask_bitfield || !max_bytes) return NRS_OK;
+	const uint32_t first = m->cached_levels;
+	uint8_t* d_mask = nullptr;
+	uint32_t* d_counter = nullptr;
+	uint32_t* d_tmp_table = nullptr;
+	auto cleanup = [&]() { (void)hipFree(d_mask); (void)hipFree(d_counter); (void)hipFree(d_tmp_table); d_mask = nullptr; d_counter = nullptr; d_tmp_table = nullptr; };
+	auto bail = [&](int rc) { cleanup(); drop_sparse_cell_cache(m); return rc; };
+	hipError_t he = hipMalloc((void**)&d_mask, NRS_BITFIELD_BYTES);
+	if (he == hipSuccess) he = hipMemcpy(d_mask, h_mask_bitfield, NRS_BITFIELD_BYTES, hipMemcpyHostToDevice);
+	if (he == hipSuccess) he = hipMalloc((void**)&d_counter, 4 * kLevels);
+	if (he == hipSuccess) he = hipMemset(d_counter, 0, 4 * kLevels);
+	if (he != hipSuccess) { (void)hipGetLastError(); return bail(fail(NRS_ERR_HIP, "nrs_model_set_sparse_cell_cache: out of device memory")); }
+	// pass A: level by level, mark into a scratch table to COUNT the bricks the mask asks for (the set is deterministic, only the slot order is
+	// not); accept level pairs while tables + slot lists + records fit the budget
+	LevelParams lv[kLevels];
+	uint32_t counts[kLevels] = {}, nbs[kLevels] = {};
+	uint64_t used = 0, table_total = 0, bricks_total = 0;
+	uint32_t n_ok = 0;
+	for (uint32_t l = first; l + 1 < kLevels; l += 2) {
+		uint64_t pair_bytes = 0, pair_tables = 0, pair_bricks = 0;
+		bool ok = true;
+		for (uint32_t k = l; k < l + 2 && ok; ++k) {
+			const uint32_t nb = (m->dm.levels[k].resolution + kBrick - 1) / kBrick;
+			const uint64_t entries = (uint64_t)nb * nb * nb;
+			if (entries * 4ull > max_bytes - std::min<uint64_t>(max_bytes, used + pair_bytes) || table_total + pair_tables + entries >= (1ull << 32)) { ok = false; break; }
+			if (hipMalloc((void**)&d_tmp_table, entries * 4ull) != hipSuccess || hipMemset(d_tmp_table, 0, entries * 4ull) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+			lv[k] = m->dm.levels[k];
+			lv[k].rec_res = nb; lv[k].rec_res2 = nb * nb; lv[k].tab_first = 0; lv[k].rec_first = 0;
+			const int rc = launch_brick_mark(m->dm, lv[k], d_mask, d_tmp_table, d_counter + k, nullptr, 0, nullptr);
+			if (rc != NRS_OK) { g_err = launch_last_error(); return bail(rc); }
+			if (hipMemcpy(&counts[k], d_counter + k, 4, hipMemcpyDeviceToHost) != hipSuccess) return bail(fail(NRS_ERR_HIP, "nrs_model_set_sparse_cell_cache: read-back"));
+			(void)hipFree(d_tmp_table); d_tmp_table = nullptr;
+			nbs[k] = nb;
+			pair_tables += entries; pair_bricks += counts[k];
+			pair_bytes += entries * 4ull + (uint64_t)counts[k] * ((uint64_t)kBrickCells * 32ull + 4ull);
+			if (getenv("NRS_SPARSE_LOG"))
+				fprintf(stderr, "[nrs sparse] level %u: res %u, %u^3 bricks (table %.1f MB), %u bricks marked = %.2f GB of records\n", k, m->dm.levels[k].resolution, nb, entries * 4e-6,
+				        counts[k], counts[k] * 16384e-9);
+		}
+		if (!ok || used + pair_bytes > max_bytes || (bricks_total + pair_bricks) * kBrickCells >= (1ull << 32)) break;
+		used += pair_bytes; table_total += pair_tables; bricks_total += pair_bricks;
+		n_ok += 2;
+	}
+	if (!n_ok || !bricks_total) { cleanup(); drop_sparse_cell_cache(m); return NRS_OK; }
+	// pass B: the real tables, slot lists and records of the accepted levels
+	he = hipMalloc((void**)&m->d_bricks, table_total * 4ull);
+	if (he == hipSuccess) he = hipMemset(m->d_bricks, 0, table_total * 4ull);
+	if (he == hipSuccess) he = hipMalloc((void**)&m->d_slots, bricks_total * 4ull);
+	if (he == hipSuccess) he = hipMalloc((void**)&m->d_records2, bricks_total * kBrickCells * 32ull);
+	if (he == hipSuccess) he = hipMemset(d_counter, 0, 4 * kLevels);
+	if (he != hipSuccess) { (void)hipGetLastError(); return bail(fail(NRS_ERR_HIP, "nrs_model_set_sparse_cell_cache: out of device memory (records)")); }
+	uint64_t tab = 0, slot0 = 0;
+	for (uint32_t l = first; l < first + n_ok; ++l) {
+		lv[l].tab_first = (uint32_t)tab;
+		lv[l].rec_first = (uint32_t)(slot0 * kBrickCells);
+		const int rc = launch_brick_mark(m->dm, lv[l], d_mask, m->d_bricks + tab, d_counter + l, m->d_slots + slot0, counts[l], nullptr);
+		if (rc != NRS_OK) { g_err = launch_last_error(); return bail(rc); }
+		m->slot_first[l] = (uint32_t)slot0; m->slot_count[l] = counts[l];
+		lv[l].cached = 2u;
+		m->dm.levels[l] = lv[l];
+		tab += (uint64_t)nbs[l] * nbs[l] * nbs[l];
+		slot0 += counts[l];
+	}
+	m->sparse_first = first; m->sparse_levels = n_ok;
+	m->sparse_bytes = (size_t)used;
+	m->dm.records2 = m->d_records2; m->dm.bricks = m->d_bricks;
+	cleanup();
+	return rebuild_cell_cache(m);
+}
+size_t nrs_model_sparse_cell_cache_bytes(const nrs_model* m, uint32_t* first_level, uint32_t* n_levels) {
+	if (!m) return 0;
+	if (first_level) *first_level = m->sparse_first;
+	if (n_levels) *n_levels = m->sparse_levels;
+	return m->sparse_bytes;
 }
 int nrs_model_set_cell_cache(nrs_model* m, size_t max_bytes) {
 	if (!m) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_cell_cache: NULL model");
 	HIP_TRY(hipSetDevice(m->ctx->device));
 	HIP_TRY(hipDeviceSynchronize()); // launches in flight may still read the old records
+	drop_sparse_cell_cache(m); // they start where the dense levels end: set them again afterwards
 	LevelParams lv[kLevels];
 	size_t bytes = 0;
 	const uint32_t n = plan_cell_cache(m->dm.levels, max_bytes, lv, &bytes);

@@ -26,11 +26,12 @@ struct LevelParams {
 	uint32_t count;       // entries in the level
 	uint32_t hashed;      // 1: spatial hash (count is a power of two), 0: dense x + y*res + z*res^2
 	uint32_t mask;        // count - 1 when hashed
-	uint32_t cached;      // 1: the level has cell records (DeviceModel::records), see nrs_model_set_cell_cache
-	uint32_t rec_first;   // record number of cell (0, 0, 0)
-	uint32_t rec_res;     // cells per side with a record (= resolution: every cell a position in [0,1]^3 can fall into)
+	uint32_t cached;      // 1: the level has dense cell records (DeviceModel::records, nrs_model_set_cell_cache); 2: sparse brick records
+	                      //    (DeviceModel::records2 + bricks, nrs_model_set_sparse_cell_cache)
+	uint32_t rec_first;   // record number of cell (0, 0, 0) [dense] / of the level's first brick [sparse]
+	uint32_t rec_res;     // dense: cells per side with a record (= resolution: every cell a position in [0,1]^3 can fall into); sparse: bricks per side
 	uint32_t rec_res2;    // rec_res^2
-	uint32_t pad;
+	uint32_t tab_first;   // sparse: first entry of the level's brick table in DeviceModel::bricks
 };
 
 // MFMA A-operand image of the five weight matrices: kNumFrags fragments of 64 lanes x 8 halfs (1 KiB each).
@@ -55,6 +56,8 @@ struct DeviceModel {
 	const uint16_t* wfrag;     // kWfragBytes
 	const uint8_t*  bitfield;  // NRS_BITFIELD_BYTES
 	const void*     records;   // cell records of the cached levels: 2 x uint4 = the cell's 8 corner entries, x fastest
+	const void*     records2;  // sparse levels: records of the allocated bricks, 512 records (8 x 8 x 8 cells, x fastest) per brick
+	const uint32_t* bricks;    // sparse levels: brick tables, entry = brick slot + 1, or 0 = no records here (hashed gathers instead)
 	LevelParams     levels[kLevels];
 	Box3            aabb;      // train aabb (m_aabb)
 	float           inv_diag[3]; // 1 / (aabb.max - aabb.min), exact when diag_pow2
@@ -146,6 +149,9 @@ int launch_selection_rays(const DeviceModel& m, const nrs_render_params& p, cons
 int launch_poisson_fit(const DeviceModel& m, uint32_t n_verts, uint32_t n_sh, const float* d_coords, const void* d_net, int is_inside, float scale,
                        float* d_density, float* d_sh, void* stream);
 int launch_cell_records(const DeviceModel& m, uint32_t n_levels, void* d_records, void* stream);
+constexpr uint32_t kBrick = 8, kBrickCells = kBrick * kBrick * kBrick; // sparse cell records: 8^3 cells = 16 KiB of records per brick
+int launch_brick_mark(const DeviceModel& m, const LevelParams& lp, const uint8_t* d_mask, uint32_t* d_table, uint32_t* d_counter, uint32_t* d_slots, uint32_t capacity, void* stream);
+int launch_brick_fill(const DeviceModel& m, const LevelParams& lp, const uint32_t* d_slots, uint32_t n_bricks, void* d_records2, void* stream);
 int launch_grid_eval(const DeviceModel& m, int mode, const uint32_t res[3], const float box_mn[3], const float box_mx[3], const float dir01[3],
                      const float* d_density_grid, float* d_out, int n_cus, void* stream);
 int launch_map_rays(const DeviceEdit& e, uint32_t n, float* d_coords, uint32_t ld, int with_dir, uint8_t* d_empty, void* stream);

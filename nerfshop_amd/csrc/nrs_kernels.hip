@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	bool tail_seen = false; // TEAM == 0: this wave has reached the queue's tail packets
 	uint2* ring = sm.ring[wave];
 	FeatLds& fl = sm.fl[wave];
-	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count, (const uint4*)m.records);
+	const GridView gv = make_grid_view(m);
 	const nrs_render_params& p = a.p;
 	const bool ops = p.apply_operators && a.n_edits > 0;
 	const f3 cam_fwd = mk3(p.camera_matrix1[6], p.camera_matrix1[7], p.camera_matrix1[8]);
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256) void selection_rays_kernel(const DeviceModel m
 	const int lane = threadIdx.x & 63;
 	const int g = lane >> 5;
 	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count, (const uint4*)m.records);
+	const GridView gv = make_grid_view(m);
 	const nrs_render_params& p = a.p;
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	bool have = i < a.n;
@@ -863,6 +863,76 @@ int launch_cell_records(const DeviceModel& m, uint32_t n_levels, void* d_records
 	return hipGetLastError() == hipSuccess ? NRS_OK : NRS_ERR_HIP;
 }
 
+// ---- sparse cell records (nrs_model_set_sparse_cell_cache) -------------------------------------------------------------------------
+// brick_mark_kernel: one thread per cell of the 5-cascade mask (density-bitfield layout).  A marked cell allocates every 8^3-cell
+// brick of the level that its box touches (one cell of margin: samples sit anywhere inside the density cell, borders included).
+// Slots are handed out in arrival order; the records do not depend on it.
+__global__ __launch_bounds__(256) void brick_mark_kernel(const LevelParams lp, const Box3 aabb, const uint8_t* __restrict__ mask, uint32_t* __restrict__ table,
+                                                         uint32_t* __restrict__ counter, uint32_t* __restrict__ slots, uint32_t capacity) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= kGridVol * kCascades) return;
+	if (!((mask[i >> 3] >> (i & 7u)) & 1u)) return;
+	const uint32_t level = i / kGridVol, idx = i % kGridVol;
+	const float s = ldexpf(1.0f, (int)level);
+	const uint32_t cx = morton3D_invert(idx), cy = morton3D_invert(idx >> 1), cz = morton3D_invert(idx >> 2);
+	const float c[3] = {(float)cx, (float)cy, (float)cz};
+	int lo[3], hi[3];
+	for (int k = 0; k < 3; ++k) {
+		const float w0 = ((c[k] / (float)kGrid - 0.5f) * s + 0.5f - aabb.mn[k]) / (aabb.mx[k] - aabb.mn[k]);
+		const float w1 = (((c[k] + 1.0f) / (float)kGrid - 0.5f) * s + 0.5f - aabb.mn[k]) / (aabb.mx[k] - aabb.mn[k]);
+		if (w1 < 0.f || w0 > 1.f) return; // outside the scene box: no lookups there (records cover [0,1]^3)
+		const int g0 = (int)floorf(fmaf(lp.scale, fmaxf(w0, 0.f), 0.5f)) - 1, g1 = (int)floorf(fmaf(lp.scale, fminf(w1, 1.f), 0.5f)) + 1;
+		lo[k] = max(g0, 0) >> 3;
+		hi[k] = min(g1, (int)lp.resolution - 1) >> 3;
+	}
+	for (int bz = lo[2]; bz <= hi[2]; ++bz)
+		for (int by = lo[1]; by <= hi[1]; ++by)
+			for (int bx = lo[0]; bx <= hi[0]; ++bx) {
+				const uint32_t b = (uint32_t)bz * lp.rec_res2 + (uint32_t)by * lp.rec_res + (uint32_t)bx;
+				if (table[b] != 0u) continue;
+				if (atomicCAS(&table[b], 0u, 0xffffffffu) == 0u) {
+					const uint32_t slot = atomicAdd(counter, 1u);
+					if (slot < capacity) slots[slot] = b;
+					__atomic_store_n(&table[b], slot + 1u, __ATOMIC_RELAXED);
+				}
+			}
+}
+// brick_fill_kernel: one thread per record of an allocated brick: the cell's 8 corner entries, fetched with the level's own index
+// function exactly as cell_records_kernel does.
+__global__ __launch_bounds__(256) void brick_fill_kernel(const uint32_t* __restrict__ grid, const LevelParams lp, const uint32_t* __restrict__ slots, uint32_t n_bricks,
+                                                         uint4* __restrict__ out) {
+	const uint64_t n = (uint64_t)n_bricks * kBrickCells;
+	for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+		const uint32_t b = slots[i >> 9], within = (uint32_t)i & 511u;
+		const uint32_t bx = b % lp.rec_res, by = (b / lp.rec_res) % lp.rec_res, bz = b / lp.rec_res2;
+		const uint32_t gx = bx * 8u + (within & 7u), gy = by * 8u + ((within >> 3) & 7u), gz = bz * 8u + (within >> 6);
+		uint32_t v[8];
+		#pragma unroll
+		for (int c = 0; c < 8; ++c) {
+			const uint32_t cx = gx + (c & 1), cy = gy + ((c >> 1) & 1), cz = gz + ((c >> 2) & 1);
+			uint32_t index = lp.hashed ? ((cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u)) : (cx + cy * lp.resolution + cz * lp.res2);
+			index %= lp.count;
+			v[c] = grid[lp.offset + index];
+		}
+		uint4* o = out + 2 * ((size_t)lp.rec_first + i);
+		o[0] = make_uint4(v[0], v[1], v[2], v[3]);
+		o[1] = make_uint4(v[4], v[5], v[6], v[7]);
+	}
+}
+int launch_brick_mark(const DeviceModel& m, const LevelParams& lp, const uint8_t* d_mask, uint32_t* d_table, uint32_t* d_counter, uint32_t* d_slots, uint32_t capacity, void* stream) {
+	hipLaunchKernelGGL(brick_mark_kernel, dim3((kGridVol * kCascades + 255) / 256), dim3(256), 0, (hipStream_t)stream, lp, m.aabb, d_mask, d_table, d_counter, d_slots, capacity);
+	NRS_LAUNCH_CHECK("brick_mark_kernel launch");
+	return NRS_OK;
+}
+int launch_brick_fill(const DeviceModel& m, const LevelParams& lp, const uint32_t* d_slots, uint32_t n_bricks, void* d_records2, void* stream) {
+	if (!n_bricks) return NRS_OK;
+	const uint64_t n = (uint64_t)n_bricks * kBrickCells;
+	const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 1u << 20);
+	hipLaunchKernelGGL(brick_fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m.grid, lp, d_slots, n_bricks, (uint4*)d_records2);
+	NRS_LAUNCH_CHECK("brick_fill_kernel launch");
+	return NRS_OK;
+}
+
 // MODE 0: inference_mixed_precision (16 channels, c3 = density raw), 1: density(), 2: hash-grid features [n x 32]
 template <int MODE>
 __global__ __launch_bounds__(256) void network_kernel(const DeviceModel m, uint32_t n, const float* __restrict__ in, uint32_t ld_in,
@@ -872,7 +942,7 @@ __global__ __launch_bounds__(256) void network_kernel(const DeviceModel m, uint3
 	const int lane = threadIdx.x & 63;
 	const int g = lane >> 5, j = lane & 31;
 	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count, (const uint4*)m.records);
+	const GridView gv = make_grid_view(m);
 	const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
 	const uint32_t n_tiles = (n + 63) / 64;
@@ -963,7 +1033,7 @@ __global__ __launch_bounds__(256) void grid_eval_kernel(const DeviceModel m, con
 	const int lane = threadIdx.x & 63;
 	const int g = lane >> 5, j = lane & 31;
 	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count, (const uint4*)m.records);
+	const GridView gv = make_grid_view(m);
 	const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
 	const uint32_t n = a.res[0] * a.res[1] * a.res[2];
@@ -1138,7 +1208,7 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 	const int lane = threadIdx.x & 63;
 	const int g = lane >> 5;
 	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-	const GridView gv = make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count, (const uint4*)m.records);
+	const GridView gv = make_grid_view(m);
 	const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
 	uint64_t lane_mult, lane_plus;

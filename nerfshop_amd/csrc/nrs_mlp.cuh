@@ -37,7 +37,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define NRS_FRAG_R2(mb, ks) (12 + (mb) * 4 + (ks))
 #define NRS_FRAG_R3(ks) (20 + (ks))
 
-enum { KIND_DENSE = 0, KIND_HASHED = 1, KIND_MIXED = 2, KIND_RECORD = 3 };
+enum { KIND_DENSE = 0, KIND_HASHED = 1, KIND_MIXED = 2, KIND_RECORD = 3, KIND_SPARSE = 4 };
 
 // Per-block model state in LDS: weight fragments, kind of each level pair (the level table itself is read with scalar loads).
 struct ModelLds {
@@ -55,9 +55,9 @@ __device__ __forceinline__ void stage_model_to_lds(const DeviceModel& m, ModelLd
 	for (uint32_t i = threadIdx.x; i < kWfragBytes / 16; i += blockDim.x) dst[i] = src[i];
 	if (threadIdx.x < 8) {
 		const uint32_t h0 = (dbg & 1u) ? 1u : m.levels[2 * threadIdx.x].hashed, h1 = (dbg & 1u) ? 1u : m.levels[2 * threadIdx.x + 1].hashed;
-		const bool c0 = !(dbg & 1u) && m.levels[2 * threadIdx.x].cached, c1 = !(dbg & 1u) && m.levels[2 * threadIdx.x + 1].cached;
+		const uint32_t c0 = (dbg & 1u) ? 0u : m.levels[2 * threadIdx.x].cached, c1 = (dbg & 1u) ? 0u : m.levels[2 * threadIdx.x + 1].cached;
 		const uint32_t native = (h0 && h1) ? KIND_HASHED : ((!h0 && !h1) ? KIND_DENSE : KIND_MIXED);
-		s.kinds[threadIdx.x] = (c0 && c1) ? KIND_RECORD : ((c0 || c1) ? KIND_MIXED : native);
+		s.kinds[threadIdx.x] = (c0 == 1u && c1 == 1u) ? KIND_RECORD : ((c0 == 2u && c1 == 2u) ? KIND_SPARSE : ((c0 == 1u || c1 == 1u) ? KIND_MIXED : native));
 		s.kinds_native[threadIdx.x] = native;
 	}
 	if (threadIdx.x == 0) s.one_line = dbg & 1u;
@@ -65,12 +65,18 @@ __device__ __forceinline__ void stage_model_to_lds(const DeviceModel& m, ModelLd
 }
 
 // The table is read through a buffer descriptor: one 32-bit offset per gather instead of 64-bit pointer arithmetic.
-struct GridView { __amdgpu_buffer_rsrc_t rsrc; const uint4* records; };
-__device__ __forceinline__ GridView make_grid_view(const uint32_t* grid, uint32_t n_entries, const uint4* records = nullptr) {
+struct GridView { __amdgpu_buffer_rsrc_t rsrc; const uint4* records; const uint4* records2; const uint32_t* bricks; };
+__device__ __forceinline__ GridView make_grid_view(const uint32_t* grid, uint32_t n_entries, const uint4* records = nullptr, const uint4* records2 = nullptr,
+                                                   const uint32_t* bricks = nullptr) {
 	GridView v;
 	v.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)grid, 0, (int)(n_entries * 4u), 0x00020000);
 	v.records = records;
+	v.records2 = records2;
+	v.bricks = bricks;
 	return v;
+}
+__device__ __forceinline__ GridView make_grid_view(const DeviceModel& m) {
+	return make_grid_view(m.grid, m.levels[kLevels - 1].offset + m.levels[kLevels - 1].count, (const uint4*)m.records, (const uint4*)m.records2, m.bricks);
 }
 __device__ __forceinline__ uint32_t grid_load(const GridView& v, uint32_t entry) {
 	return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(v.rsrc, (int)(entry * 4u), 0, 0);
@@ -195,6 +201,19 @@ __device__ __forceinline__ uint32_t level_eval_exact(const GridView& gv, const L
 	return __builtin_bit_cast(uint32_t, r);
 }
 
+// Sparse level (nrs_model_set_sparse_cell_cache): the level's cells are grouped in 8 x 8 x 8 bricks; a table says which bricks carry
+// records (slot + 1) and which do not (0).  One table load (neighbouring samples share its lines), then the record as in a dense level.
+__device__ __forceinline__ uint32_t brick_entry(const GridView& gv, const LevelParams& lp, const CellCoords& c) {
+	return gv.bricks[lp.tab_first + (c.gz >> 3) * lp.rec_res2 + (c.gy >> 3) * lp.rec_res + (c.gx >> 3)];
+}
+__device__ __forceinline__ void issue_brick_record_loads(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t brick, uint32_t v[8]) {
+	const uint32_t rec = lp.rec_first + (brick - 1u) * 512u + (((c.gz & 7u) << 6) | ((c.gy & 7u) << 3) | (c.gx & 7u));
+	const uint4* p = gv.records2 + 2 * (size_t)rec;
+	const uint4 lo = p[0], hi = p[1]; // (streaming these with non-temporal loads was measured: no gain on the aabb-16 scene)
+	v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+	v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+}
+
 // Issue the loads of one sample at one level of kind KIND (the level parameters are wave-uniform: scalar registers).
 template <int KIND>
 __device__ __forceinline__ void issue_level(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t v[8]) {
@@ -212,6 +231,21 @@ template <int KIND>
 __device__ __forceinline__ void level_eval_two(const GridView& gv, const LevelParams& lp0, const LevelParams& lp1, f3 pos, bool act, uint32_t& f0, uint32_t& f1) {
 	const f3 q = act ? pos : mk3(0.f, 0.f, 0.f);
 	const CellCoords c0 = cell_coords(lp0, q), c1 = cell_coords(lp1, q);
+	if (KIND == KIND_SPARSE) {
+		uint32_t b0 = brick_entry(gv, lp0, c0), b1 = brick_entry(gv, lp1, c1);
+		if (!act) { b0 = 1u; b1 = 1u; } // idle lanes read the level's first record
+		uint32_t v0[8], v1[8];
+		if (__builtin_expect(__all(b0 != 0u && b1 != 0u), 1)) {
+			issue_brick_record_loads(gv, lp0, c0, b0, v0);
+			issue_brick_record_loads(gv, lp1, c1, b1, v1);
+		} else { // some lane stands where the mask promised no lookups: that lane gathers the hashed way (same values)
+			if (b0) issue_brick_record_loads(gv, lp0, c0, b0, v0); else issue_gathers<true>(gv, lp0, c0, v0);
+			if (b1) issue_brick_record_loads(gv, lp1, c1, b1, v1); else issue_gathers<true>(gv, lp1, c1, v1);
+		}
+		f0 = zero_if(!act, interpolate(c0, v0));
+		f1 = zero_if(!act, interpolate(c1, v1));
+		return;
+	}
 	if (KIND == KIND_DENSE && __builtin_expect(__any(dense_needs_slow(lp0, c0) || dense_needs_slow(lp1, c1)), 0)) { // exact tcnn wrap for samples outside [0,1)^3: rare
 		f0 = level_eval_exact(gv, lp0, c0);
 		f1 = level_eval_exact(gv, lp1, c1);
@@ -269,9 +303,10 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 		if (kind == KIND_RECORD) level_eval_two<KIND_RECORD>(gv, lp0, lp1, pos, act, f0, f1);
 		else if (kind == KIND_HASHED) level_eval_two<KIND_HASHED>(gv, lp0, lp1, pos, act, f0, f1);
 		else if (kind == KIND_DENSE) level_eval_two<KIND_DENSE>(gv, lp0, lp1, pos, act, f0, f1);
+		else if (kind == KIND_SPARSE) level_eval_two<KIND_SPARSE>(gv, lp0, lp1, pos, act, f0, f1);
 		else {
-			f0 = level_eval_one(gv, lp0, !outside && !one_line && lp0.cached, pos, act);
-			f1 = level_eval_one(gv, lp1, !outside && !one_line && lp1.cached, pos, act);
+			f0 = level_eval_one(gv, lp0, !outside && !one_line && lp0.cached == 1u, pos, act);
+			f1 = level_eval_one(gv, lp1, !outside && !one_line && lp1.cached == 1u, pos, act);
 		}
 		fl.feat[it][0][lane] = g ? f1 : f0;
 		fl.feat[it][1][lane ^ 32] = g ? f0 : f1;

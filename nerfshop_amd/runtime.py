@@ -103,6 +103,21 @@ class NerfNetwork:
         b = self.lib.nrs_model_cell_cache_bytes(self.h, C.byref(n))
         return int(b), int(n.value)
 
+    def set_sparse_cell_cache(self, mask_bitfield_u8, max_bytes):
+        """Sparse brick records for the levels after the dense ones (nrs_model_set_sparse_cell_cache); mask = density-bitfield layout."""
+        if mask_bitfield_u8 is None:
+            check(self.lib.nrs_model_set_sparse_cell_cache(self.h, None, 0))
+            return
+        b = np.ascontiguousarray(mask_bitfield_u8, np.uint8)
+        assert b.size == _abi.BITFIELD_BYTES
+        check(self.lib.nrs_model_set_sparse_cell_cache(self.h, b.ctypes.data, int(max_bytes)))
+
+    def sparse_cell_cache(self):
+        """(bytes held by brick tables + records, first sparse level, number of sparse levels)"""
+        f, n = C.c_uint32(), C.c_uint32()
+        b = self.lib.nrs_model_sparse_cell_cache_bytes(self.h, C.byref(f), C.byref(n))
+        return int(b), int(f.value), int(n.value)
+
     def set_density_bitfield(self, bitfield_u8):
         b = np.ascontiguousarray(bitfield_u8, np.uint8)
         check(self.lib.nrs_model_set_density_bitfield(self.h, b.ctypes.data, b.size))

@@ -130,3 +130,71 @@ def test_occupancy_refresh_identical_with_and_without_records(rig_shaped):
     finally:
         rig.net.set_cell_cache(10 << 30)
         rig.net.set_density_bitfield(rig.scene.bitfield)
+
+
+def _samples_in_mask(scene, mask, n_per_cascade, seed):
+    """warped positions inside marked cells of every cascade of `mask` (density-bitfield layout)"""
+    from nerfshop_amd import synth
+    bits = np.unpackbits(mask, bitorder="little").reshape(5, -1)
+    rng = np.random.default_rng(seed)
+    x, y, z = synth._cell_coords()
+    mn = np.array(scene.desc.aabb_min[:])
+    ext = np.array(scene.desc.aabb_max[:]) - mn
+    out = []
+    for lvl in range(5):
+        idx = np.nonzero(bits[lvl])[0]
+        if idx.size == 0:
+            continue
+        pick = rng.choice(idx, n_per_cascade)
+        p = (np.stack([x[pick], y[pick], z[pick]], 1) + rng.uniform(0, 1, (n_per_cascade, 3))) / 128.0
+        p = (p - 0.5) * 2.0 ** lvl + 0.5
+        w = (p - mn) / ext
+        out.append(w[((w >= 0) & (w <= 1)).all(1)])
+    return np.concatenate(out).astype(np.float32)
+
+
+def test_sparse_brick_records_are_a_layout_of_the_same_numbers(rig16):
+    """nrs_model_set_sparse_cell_cache (aabb-16 scenes: the levels after the dense records get occupancy-sparse 8^3-cell bricks of records):
+    features, frames, depth, steps and statistics are identical bit for bit with the sparse records, without them, with a partial budget, and
+    with a mask that does NOT cover the samples (those lanes fall back to the hashed gathers)."""
+    rig, scene = rig16, rig16.scene
+    mask = scene.bitfield | scene.edited_bitfield
+    c = _coords(150000, 21, 0.0, 1.0)
+    inside = _samples_in_mask(scene, mask, 20000, 3)
+    c[:inside.shape[0], :3] = inside
+    c[-8:, :3] = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], np.float32)
+    rig.use_edit(True)
+    try:
+        rig.net.set_sparse_cell_cache(None, 0)
+        assert rig.net.sparse_cell_cache() == (0, 0, 0)
+        base = _encode(rig, c)
+        assert np.array_equal(base[:3000], scene.oracle_model.hashgrid_encode(c[:3000]))
+        p = scene.params_for(384, 216, 60.0)
+        ref = rig.render(p)
+        assert ref[3].n_samples > 100000
+        dense_levels = rig.net.cell_cache()[1]
+        wrong_mask = np.zeros_like(mask)
+        wrong_mask[:1000] = 0xff  # a few cells near one corner of cascade 0: almost no sample has records
+        for m, budget, want_levels in ((mask, 4 << 30, 2), (mask, 80 << 30, 4), (wrong_mask, 4 << 30, None), (mask, 1 << 20, 0)):
+            rig.net.set_sparse_cell_cache(m, budget)
+            nbytes, first, n = rig.net.sparse_cell_cache()
+            if want_levels is not None:
+                assert n == want_levels and (first == dense_levels or n == 0) and nbytes <= budget, (nbytes, first, n)
+            assert np.array_equal(_encode(rig, c), base), (budget, n)
+            frame, depth, steps, stats = rig.render(p)
+            assert np.array_equal(frame.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(depth.view(np.uint32), ref[1].view(np.uint32))
+            assert np.array_equal(steps, ref[2]) and stats.n_samples == ref[3].n_samples
+        # the records follow the parameters, and the dense budget drops the sparse levels (they start where the dense ones end)
+        rig.net.set_sparse_cell_cache(mask, 4 << 30)
+        other = scene.params.copy()
+        n_net = other.size - 2 * sum(_level_entries(scene.desc))
+        other[n_net:] = np.random.default_rng(4).uniform(-0.3, 0.3, size=other.size - n_net).astype(np.float16).view(np.uint16)
+        rig.net.set_params(other)
+        with_sparse = _encode(rig, c)
+        rig.net.set_cell_cache(0)
+        assert rig.net.sparse_cell_cache() == (0, 0, 0)
+        assert np.array_equal(_encode(rig, c), with_sparse) and (with_sparse != base).mean() > 0.5
+    finally:
+        rig.net.set_cell_cache(10 << 30)
+        rig.net.set_params(scene.params)
+        rig.use_edit(False)
