@@ -328,7 +328,7 @@ def main():
                                     "garden": "garden-style aabb_scale 16 1920x1080, no edits",
                                     "lego_cage_varied": "lego-like snapshot with non-uniform opacity (geometry in the network, density noise 1.5) 1920x1080, one cage edit"}[args.workload],
                        "resolution": [W, H], "samples_per_frame": int(total_samples / args.steps),
-                       "sharding": f"{TILE}x{TILE} image tiles round-robin over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "sharding": f"{TILE}x{TILE} image tiles round-robin over {world} GPU(s)" + (f", gather to rank 0 by {all_sharders[0].gather_impl}" if world > 1 else ""),
                        "frames_in_flight": n_buf,
                        "cell_records": "levels 0..%d, %.1f GB (nrs_model_set_cell_cache default)" % (tb.nerf_network.cell_cache()[1] - 1, tb.nerf_network.cell_cache()[0] / 1e9) +
                                        ("; sparse brick records for levels %d..%d, %.1f GB" % (tb.nerf_network.sparse_cell_cache()[1], sum(tb.nerf_network.sparse_cell_cache()[1:]) - 1,

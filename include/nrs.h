@@ -74,6 +74,17 @@ typedef enum nrs_render_mode {
  * (renderer, density-grid update), interleaved = column-major, 16 halfs per sample (selection, Poisson). */
 typedef enum nrs_layout { NRS_PLANES = 0, NRS_INTERLEAVED = 1 } nrs_layout;
 
+/* The two roundings of tiny-cuda-nn that cannot be read off the reference checkout (its tiny-cuda-nn submodule is empty and un-pinned), switchable
+ * per model (nrs_model_set_numerics).  Defaults are the wider ones.
+ *   grid: FP32    = the trilinear sum of a level runs in fp32 (one fmaf per corner, corners 0..7) and is rounded to fp16 once;
+ *         NETWORK = kernel_grid as recalled from NVlabs/tiny-cuda-nn of 2022: per corner `result[f] += (T)(weight * (float)value[f])`, T = __half
+ *                   -- the fp32 product is rounded to fp16 and accumulated in fp16.
+ *   mlp:  FP32    = fp16 x fp16 products accumulated in fp32 (MFMA accumulators), one rounding per layer output;
+ *         FP16    = FullyFusedMLP's wmma fragments carry fp16 accumulators: modelled as one fp16 rounding of the running sum after every 16-wide
+ *                   k block (how a tensor core sums inside a block is unspecified: a model of it, within tolerance of any implementation). */
+typedef enum nrs_grid_acc { NRS_GRID_ACC_FP32 = 0, NRS_GRID_ACC_NETWORK = 1 } nrs_grid_acc;
+typedef enum nrs_mlp_acc { NRS_MLP_ACC_FP32 = 0, NRS_MLP_ACC_FP16 = 1 } nrs_mlp_acc;
+
 /* Network hyper-parameters: configs/nerf/base.json:23-58 + src/testbed.cu:2257-2333. */
 typedef struct nrs_model_desc {
 	uint32_t n_levels;             /* 16 */
@@ -220,6 +231,9 @@ int    nrs_model_level_table(const nrs_model_desc* desc, float* scale, uint32_t*
 /* fp16 parameter blob in tiny-cuda-nn order: density MLP | rgb MLP | hash grid (nerf_network_full.h:316-349).
  * h_params is a HOST pointer (what Trainer::deserialize hands over); synchronous. */
 int    nrs_model_set_params(nrs_model* model, const void* h_params_fp16, size_t n_params);
+/* nrs_grid_acc / nrs_mlp_acc above.  Applies to every entry point that evaluates the network.  The render kernel runs the non-default modes
+ * with one lane per ray and without the membrane / AffineDuplication instantiations (NRS_ERR_UNSUPPORTED for those combinations). */
+int    nrs_model_set_numerics(nrs_model* model, uint32_t grid_acc, uint32_t mlp_acc);
 /* Cell-record cache (no counterpart in the reference: a memory-for-bandwidth trade the 288 GB of HBM allow).  For the
  * coarsest levels that fit `max_bytes` (an even number of them), every grid cell gets a 32-byte record holding its 8
  * corner entries, fetched with the level's own index function (tiny-cuda-nn grid.h:76-95), so that a sample reads two
@@ -256,6 +270,20 @@ int    nrs_model_get_density_grid(nrs_model* model, float* h_grid_out, size_t n_
 int    nrs_model_update_density_grid(nrs_model* model, nrs_edit* const* edits, int n_edits, nrs_grid_update* u, void* stream);
 /* tcnn::pcg32(seed) -- Testbed seeds m_rng = default_rng_t{m_seed = 1337} (src/testbed.cu:2220). host-only */
 void   nrs_rng_seed(uint64_t seed, uint64_t* state_out, uint64_t* inc_out);
+
+/* ---- multi-GPU: one exchange step per frame (the reference is single-GPU, README.md:423-425) --------------------------- */
+/* The frame is cut into tile_size x tile_size tiles dealt round-robin to the ranks (nrs_render_params.tile_*); every rank renders into a compact
+ * buffer [tiles_padded * tile^2 * 4 floats of frame | tiles_padded * tile^2 floats of depth]; nrs_gather_tiles moves them to the root with
+ * ncclGroupStart / ncclSend / ncclRecv x (N - 1) / ncclGroupEnd (RCCL point-to-point over xGMI) on `stream` and de-tiles there.
+ * RCCL is dlopen'ed on first use (no link-time dependency).  Bootstrap as with NCCL: rank 0 makes a 128-byte id, the application distributes
+ * it (its own channel), every rank creates the communicator with it (collective call). */
+typedef struct nrs_comm nrs_comm;
+int  nrs_comm_unique_id(uint8_t* out128);
+int  nrs_comm_create(int device, int rank, int n_ranks, const uint8_t* unique_id128, nrs_comm** out);
+void nrs_comm_destroy(nrs_comm* comm);
+/* d_local: this rank's buffer.  Root only: d_recv = n_ranks such buffers (rank-major); d_image [H*W*4] / d_depth [H*W] may be NULL. */
+int  nrs_gather_tiles(nrs_ctx* ctx, nrs_comm* comm, int root, const nrs_render_params* p, uint32_t tiles_per_rank_padded, const float* d_local,
+                      float* d_recv, float* d_image, float* d_depth, void* stream);
 
 /* ---- NerfNetwork operator -------------------------------------------------------------------------- */
 /* d_in: [n x 7] f32 (column-major 7 x n in tcnn terms).  d_out: fp16, n_el = n_padded samples wide:

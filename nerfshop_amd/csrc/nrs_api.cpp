@@ -651,6 +651,12 @@ int nrs_model_set_params(nrs_model* m, const void* h_params_fp16, size_t n_param
 	m->have_params = true;
 	return rebuild_cell_cache(m);
 }
+int nrs_model_set_numerics(nrs_model* m, uint32_t grid_acc, uint32_t mlp_acc) {
+	if (!m) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_numerics: NULL model");
+	if (grid_acc > NRS_GRID_ACC_NETWORK || mlp_acc > NRS_MLP_ACC_FP16) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_numerics: unknown mode");
+	m->dm.numerics = (grid_acc == NRS_GRID_ACC_NETWORK ? 1u : 0u) | (mlp_acc == NRS_MLP_ACC_FP16 ? 2u : 0u);
+	return NRS_OK;
+}
 int nrs_model_set_density_bitfield(nrs_model* m, const uint8_t* h_bitfield, size_t n_bytes) {
 	if (!m || !h_bitfield) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_density_bitfield: NULL argument");
 	if (n_bytes != NRS_BITFIELD_BYTES) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_density_bitfield: expected 5*128^3/8 bytes");
@@ -734,6 +740,7 @@ int nrs_model_update_density_grid(nrs_model* m, nrs_edit* const* edits, int n_ed
 	if (u->reset_grid) HIP_TRY(hipMemsetAsync(m->d_density_grid, 0, grid_bytes, s));
 	HIP_TRY(hipMemsetAsync(m->d_density_tmp, 0, grid_bytes, s));
 	const uint64_t rng_nonuniform = pcg_advance(u->rng_state, u->rng_inc, 1ull << 32); // m_rng.advance() between the two draws
+	if (m->dm.numerics) return fail(NRS_ERR_UNSUPPORTED, "nrs_model_update_density_grid: only the default numerics are built for this entry point (nrs_model_set_numerics)");
 	NRS_TRY(launch_grid_update(m->dm, d_refresh_edits, n_edits, *u, rng_nonuniform, m->d_density_grid, m->d_density_tmp, ctx->n_cus, stream));
 	u->rng_state = pcg_advance(u->rng_state, u->rng_inc, 2ull << 32);
 	u->ema_step += 1;
@@ -775,6 +782,7 @@ int nrs_density_on_grid(nrs_model* m, void* stream, const uint32_t res3d[3], con
 	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_density_on_grid: parameters not set (nrs_model_set_params)");
 	if ((uint64_t)res3d[0] * res3d[1] * res3d[2] > 0x7fffffffull) return fail(NRS_ERR_INVALID_ARG, "nrs_density_on_grid: more than 2^31 grid points");
 	HIP_TRY(hipSetDevice(m->ctx->device));
+	if (m->dm.numerics) return fail(NRS_ERR_UNSUPPORTED, "nrs_density_on_grid: only the default numerics are built for this entry point (nrs_model_set_numerics)");
 	NRS_TRY(launch_grid_eval(m->dm, 0, res3d, aabb_min, aabb_max, nullptr, mask_with_density_grid ? m->d_density_grid : nullptr, d_out, m->ctx->n_cus, stream));
 	return NRS_OK;
 }
@@ -785,6 +793,7 @@ int nrs_rgba_on_grid(nrs_model* m, void* stream, const uint32_t res3d[3], const 
 	if ((uint64_t)res3d[0] * res3d[1] * res3d[2] > 0x7fffffffull) return fail(NRS_ERR_INVALID_ARG, "nrs_rgba_on_grid: more than 2^31 grid points");
 	HIP_TRY(hipSetDevice(m->ctx->device));
 	const float dir01[3] = {(ray_dir[0] + 1.0f) * 0.5f, (ray_dir[1] + 1.0f) * 0.5f, (ray_dir[2] + 1.0f) * 0.5f}; // warp_direction, not normalised (tn:430)
+	if (m->dm.numerics) return fail(NRS_ERR_UNSUPPORTED, "nrs_rgba_on_grid: only the default numerics are built for this entry point (nrs_model_set_numerics)");
 	NRS_TRY(launch_grid_eval(m->dm, 1, res3d, render_aabb_min, render_aabb_max, dir01, nullptr, d_out_rgba, m->ctx->n_cus, stream));
 	return NRS_OK;
 }
@@ -796,6 +805,7 @@ int nrs_project_selection_pixels(nrs_model* m, void* stream, const nrs_render_pa
 	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_project_selection_pixels: occupancy not set (nrs_model_set_density_bitfield/_grid)");
 	{ const int pc = check_march_params(*p, "nrs_project_selection_pixels"); if (pc != NRS_OK) return pc; }
 	HIP_TRY(hipSetDevice(m->ctx->device));
+	if (m->dm.numerics) return fail(NRS_ERR_UNSUPPORTED, "nrs_project_selection_pixels: only the default numerics are built for this entry point (nrs_model_set_numerics)");
 	NRS_TRY(launch_selection_rays(m->dm, *p, d_pixels_xy, n_pixels, transmittance_threshold, d_positions, d_cells, d_found, stream));
 	return NRS_OK;
 }
@@ -1197,6 +1207,10 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	if (p->render_mode != NRS_RENDER_SHADE && p->render_mode != NRS_RENDER_COST)
 		return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: only render modes Shade and Cost are implemented (debug visualisations are out of scope)");
 	if (n_edits < 0 || n_edits > nrs_ctx::kMaxEdits) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: too many edit operators");
+	if (m->dm.numerics)
+		for (int i = 0; i < n_edits; ++i)
+			if (edits && edits[i] && p->apply_operators && (edits[i]->de.apply_poisson || edits[i]->de.kind == kEditAffine))
+				return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: the non-default numerics (nrs_model_set_numerics) are built for cage edits without membrane correction only");
 	if (n_edits > 0 && !edits) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: edits is NULL");
 	nrs_ctx* ctx = m->ctx;
 	HIP_TRY(hipSetDevice(ctx->device));

@@ -65,6 +65,7 @@ struct DeviceModel {
 	OccAccel        occ;       // marching shortcuts (filled per launch, see model_for_launch in nrs_api.cpp)
 	uint32_t        rgb_activation;
 	uint32_t        density_activation;
+	uint32_t        numerics;  // bit 0: nrs_grid_acc NETWORK, bit 1: nrs_mlp_acc FP16 (nrs_model_set_numerics); 0 = the default roundings
 };
 
 // AffineBoundingBox as the kernels test it (affine_bounding_box.cuh:83-88): u.(p - min) in [0, u.u) etc.

@@ -175,7 +175,8 @@ __device__ __forceinline__ bool packet_pixel_tail(const RenderArgs& a, uint32_t 
 // team composites the TEAM samples in order (identical float operations => identical accumulators in every lane, the
 // result of the sequential loop bit for bit) and walks TEAM samples on.  Samples past the one that saturates the ray are
 // discarded, as the reference discards the rest of a batch (tn:951-960).  The fill works on 64 / TEAM pixels per packet.
-template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM>
+// NUM: the non-default tiny-cuda-nn roundings (DeviceModel::numerics: bit 0 grid accumulation in network precision, bit 1 fp16 MLP accumulators)
+template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0>
 __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceModel m_arg, const RenderArgs a_arg) {
 	// The two argument structs (~1.3 KB of wave-uniform values) live in the kernel-argument segment and are read with scalar loads.
 	// Left alone, the compiler hoists every such load out of the frame loop and then spills ~150 scalar registers into VGPR lanes
@@ -358,12 +359,12 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			}
 			has_res = have && p_out > 1e-9f;
 			if (__any(has_res)) { // the reference evaluates the un-deformed network everywhere; only these samples consume it (tn:770-773)
-				encode_to_lds(gv, m2.levels, sm.ml, fl, lane, g, wpos0, has_res);
+				encode_to_lds<(NUM & 1) != 0>(gv, m2.levels, sm.ml, fl, lane, g, wpos0, has_res);
 				uint32_t old_d = 0;
 				#pragma unroll 1
 				for (int b = 0; b < 2; ++b) {
 					const int sel = (b != g) ? 1 : 0;
-					const half8 dout = density_mlp(sm.ml.w, lane, load_features(fl, lane, sel, 0), load_features(fl, lane, sel, 1));
+					const half8 dout = density_mlp<(NUM & 2) != 0>(sm.ml.w, lane, load_features(fl, lane, sel, 0), load_features(fl, lane, sel, 1));
 					uint32_t vd = __builtin_bit_cast(u32x4, dout)[0];
 					if (b == 1) vd = xchg32u(vd);
 					if (g == b) old_d = vd;
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 
 		NRS_PHASE(3); // gather
 		// ---- gather: own sample (block g) and the partner lane's sample (block 1-g), levels 2*it+g ----
-		encode_to_lds(gv, m2.levels, sm.ml, fl, lane, g, wpos, act);
+		encode_to_lds<(NUM & 1) != 0>(gv, m2.levels, sm.ml, fl, lane, g, wpos, act);
 		NRS_PHASE(4); // SH + MLP
 		const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
 		half8 sh_own, sh_par;
@@ -388,8 +389,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
 			half8 dout = x0, rout = x1;
 			if (!(a2.dbg & 2u)) {
-				dout = density_mlp(sm.ml.w, lane, x0, x1);
-				rout = rgb_mlp(sm.ml.w, lane, dout, sel ? sh_par : sh_own);
+				dout = density_mlp<(NUM & 2) != 0>(sm.ml.w, lane, x0, x1);
+				rout = rgb_mlp<(NUM & 2) != 0>(sm.ml.w, lane, dout, sel ? sh_par : sh_own);
 			}
 			const u32x4 dd = __builtin_bit_cast(u32x4, dout), rr = __builtin_bit_cast(u32x4, rout);
 			// rows 0..2 of a block sit in its lanes 0..31; block 1's samples belong to the rays of lanes 32..63
@@ -599,17 +600,17 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	}
 }
 
-template <int WAVES, int OCC, bool PROF = false, bool POISSON = false, bool AFFINE = false, int TEAM = 1>
+template <int WAVES, int OCC, bool PROF = false, bool POISSON = false, bool AFFINE = false, int TEAM = 1, int NUM = 0>
 static int launch_render_cfg(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream) {
 	int blocks_per_cu = 0;
-	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC, PROF, POISSON, AFFINE, TEAM>, 64 * WAVES, 0);
+	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC, PROF, POISSON, AFFINE, TEAM, NUM>, 64 * WAVES, 0);
 	if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(render_kernel)");
 	if (blocks_per_cu < 1) blocks_per_cu = 1;
 	uint32_t grid = (uint32_t)(n_cus * blocks_per_cu);
 	const uint32_t max_useful = (a.n_packets + WAVES - 1) / WAVES; // at least one packet per wave
 	if (grid > max_useful) grid = max_useful;
 	if (grid == 0) return NRS_OK;
-	hipLaunchKernelGGL((render_kernel<WAVES, OCC, PROF, POISSON, AFFINE, TEAM>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
+	hipLaunchKernelGGL((render_kernel<WAVES, OCC, PROF, POISSON, AFFINE, TEAM, NUM>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
 	NRS_LAUNCH_CHECK("render_kernel launch");
 	return NRS_OK;
 }
@@ -622,6 +623,13 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 		return e ? atoi(e) : 0;
 	}();
 	hipStream_t s = (hipStream_t)stream;
+	if (m.numerics) { // non-default tiny-cuda-nn roundings: one lane per ray, cage edits only (checked by nrs_render_nerf)
+		switch (m.numerics & 3u) {
+			case 1: return launch_render_cfg<8, 3, false, false, false, 1, 1>(m, a, n_cus, s);
+			case 2: return launch_render_cfg<8, 3, false, false, false, 1, 2>(m, a, n_cus, s);
+			default: return launch_render_cfg<8, 3, false, false, false, 1, 3>(m, a, n_cus, s);
+		}
+	}
 	if (a.any_poisson) return launch_render_cfg<8, 2, false, true, true>(m, a, n_cus, s);
 	if (a.any_affine) return launch_render_cfg<8, 4, false, false, true>(m, a, n_cus, s);
 	if (a.dbg & 4u) return launch_render_cfg<8, 4, true>(m, a, n_cus, s);
@@ -934,7 +942,7 @@ int launch_brick_fill(const DeviceModel& m, const LevelParams& lp, const uint32_
 }
 
 // MODE 0: inference_mixed_precision (16 channels, c3 = density raw), 1: density(), 2: hash-grid features [n x 32]
-template <int MODE>
+template <int MODE, int NUM = 0>
 __global__ __launch_bounds__(256) void network_kernel(const DeviceModel m, uint32_t n, const float* __restrict__ in, uint32_t ld_in,
                                                       _Float16* __restrict__ out, uint32_t ld_out, int layout) {
 	__shared__ NetSmem sm;
@@ -955,7 +963,7 @@ __global__ __launch_bounds__(256) void network_kernel(const DeviceModel m, uint3
 			wpos = mk3(c[0], c[1], c[2]);
 			if (MODE == 0) wdir = mk3(c[4], c[5], c[6]);
 		}
-		encode_to_lds(gv, m.levels, sm.ml, fl, lane, g, wpos, have);
+		encode_to_lds<(NUM & 1) != 0>(gv, m.levels, sm.ml, fl, lane, g, wpos, have);
 
 		if (MODE == 2) {
 			#pragma unroll 1
@@ -981,9 +989,9 @@ __global__ __launch_bounds__(256) void network_kernel(const DeviceModel m, uint3
 		for (int b = 0; b < 2; ++b) {
 			const int sel = (b != g) ? 1 : 0;
 			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
-			const half8 dout = density_mlp(sm.ml.w, lane, x0, x1);
+			const half8 dout = density_mlp<(NUM & 2) != 0>(sm.ml.w, lane, x0, x1);
 			half8 rout = dout;
-			if (MODE == 0) rout = rgb_mlp(sm.ml.w, lane, dout, sel ? sh_par : sh_own);
+			if (MODE == 0) rout = rgb_mlp<(NUM & 2) != 0>(sm.ml.w, lane, dout, sel ? sh_par : sh_own);
 			const uint32_t sb = tile * 64 + 32 * b + j;
 			if (sb < n) {
 				#pragma unroll
@@ -1008,9 +1016,19 @@ int launch_network(const DeviceModel& m, int mode, uint32_t n, const float* d_in
 	if (grid > cap) grid = cap;
 	hipStream_t s = (hipStream_t)stream;
 	_Float16* out = (_Float16*)d_out;
-	if (mode == 0) hipLaunchKernelGGL(network_kernel<0>, dim3(grid), dim3(256), 0, s, m, n, d_in, ld_in, out, ld_out, layout);
-	else if (mode == 1) hipLaunchKernelGGL(network_kernel<1>, dim3(grid), dim3(256), 0, s, m, n, d_in, ld_in, out, ld_out, layout);
-	else hipLaunchKernelGGL(network_kernel<2>, dim3(grid), dim3(256), 0, s, m, n, d_in, ld_in, out, ld_out, layout);
+#define NRS_NET_LAUNCH(MODE, NUM) hipLaunchKernelGGL((network_kernel<MODE, NUM>), dim3(grid), dim3(256), 0, s, m, n, d_in, ld_in, out, ld_out, layout)
+#define NRS_NET_MODE(MODE)                                      \
+	switch (m.numerics & 3u) {                                  \
+		case 0: NRS_NET_LAUNCH(MODE, 0); break;                 \
+		case 1: NRS_NET_LAUNCH(MODE, 1); break;                 \
+		case 2: NRS_NET_LAUNCH(MODE, 2); break;                 \
+		default: NRS_NET_LAUNCH(MODE, 3); break;                \
+	}
+	if (mode == 0) { NRS_NET_MODE(0) }
+	else if (mode == 1) { NRS_NET_MODE(1) }
+	else { NRS_NET_MODE(2) }
+#undef NRS_NET_MODE
+#undef NRS_NET_LAUNCH
 	NRS_LAUNCH_CHECK("network_kernel launch");
 	return NRS_OK;
 }

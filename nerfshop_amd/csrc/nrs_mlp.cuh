@@ -98,9 +98,11 @@ __device__ __forceinline__ float fma_mix_hi(float w, uint32_t entry, float acc) 
 }
 
 // Exact tcnn index for any position (also far outside [0,1]^3): the rarely taken out-of-line path.
+template <bool NETACC = false>
 __device__ __forceinline__ void level_eval_slow(const GridView gv, const LevelParams lp, uint32_t gx, uint32_t gy, uint32_t gz,
                                                           float wx, float wy, float wz, float* out0, float* out1) {
 	float acc0 = 0.f, acc1 = 0.f;
+	_Float16 h0 = (_Float16)0.f, h1 = (_Float16)0.f;
 	#pragma unroll 1
 	for (int c = 0; c < 8; ++c) {
 		const uint32_t cx = gx + (c & 1), cy = gy + ((c >> 1) & 1), cz = gz + ((c >> 2) & 1);
@@ -111,11 +113,16 @@ __device__ __forceinline__ void level_eval_slow(const GridView gv, const LevelPa
 		weight *= (c & 2) ? wy : 1.0f - wy;
 		weight *= (c & 4) ? wz : 1.0f - wz;
 		const half2v hv = __builtin_bit_cast(half2v, grid_load(gv, lp.offset + index));
-		acc0 = fmaf(weight, (float)hv[0], acc0);
-		acc1 = fmaf(weight, (float)hv[1], acc1);
+		if (NETACC) {
+			h0 = h0 + (_Float16)(weight * (float)hv[0]);
+			h1 = h1 + (_Float16)(weight * (float)hv[1]);
+		} else {
+			acc0 = fmaf(weight, (float)hv[0], acc0);
+			acc1 = fmaf(weight, (float)hv[1], acc1);
+		}
 	}
-	*out0 = acc0;
-	*out1 = acc1;
+	*out0 = NETACC ? (float)h0 : acc0;
+	*out1 = NETACC ? (float)h1 : acc1;
 }
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -177,9 +184,22 @@ __device__ __forceinline__ void issue_record_loads(const GridView& gv, const Lev
 	v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
 }
 // Trilinear interpolation in the oracle's order (corner 0..7, x fastest; weight = (wx' * wy') * wz') -> packed fp16 pair.
+// NETACC (nrs_grid_acc NETWORK): tiny-cuda-nn's kernel_grid as recalled -- every corner's fp32 product is rounded to fp16 and added in fp16.
+template <bool NETACC = false>
 __device__ __forceinline__ uint32_t interpolate(const CellCoords& c, const uint32_t v[8]) {
 	const float ux = 1.0f - c.wx, uy = 1.0f - c.wy, uz = 1.0f - c.wz;
 	const float wxy[4] = {ux * uy, c.wx * uy, ux * c.wy, c.wx * c.wy};
+	if (NETACC) {
+		half2v r = {(_Float16)0.f, (_Float16)0.f};
+		#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const float weight = wxy[k & 3] * ((k & 4) ? c.wz : uz);
+			const half2v hv = __builtin_bit_cast(half2v, v[k]);
+			r[0] = r[0] + (_Float16)(weight * (float)hv[0]);
+			r[1] = r[1] + (_Float16)(weight * (float)hv[1]);
+		}
+		return __builtin_bit_cast(uint32_t, r);
+	}
 	float acc0 = 0.f, acc1 = 0.f;
 	#pragma unroll
 	for (int k = 0; k < 8; ++k) {
@@ -192,9 +212,10 @@ __device__ __forceinline__ uint32_t interpolate(const CellCoords& c, const uint3
 	r[1] = (_Float16)acc1;
 	return __builtin_bit_cast(uint32_t, r);
 }
+template <bool NETACC = false>
 __device__ __forceinline__ uint32_t level_eval_exact(const GridView& gv, const LevelParams& lp, const CellCoords& c) {
 	float a0, a1;
-	level_eval_slow(gv, lp, c.gx, c.gy, c.gz, c.wx, c.wy, c.wz, &a0, &a1);
+	level_eval_slow<NETACC>(gv, lp, c.gx, c.gy, c.gz, c.wx, c.wy, c.wz, &a0, &a1);
 	half2v r;
 	r[0] = (_Float16)a0;
 	r[1] = (_Float16)a1;
@@ -227,7 +248,7 @@ __device__ __forceinline__ uint32_t zero_if(bool cond, uint32_t v) { return cond
 // first is consumed: a round is a chain of dependent memory round trips, and when few waves are left on a CU (the end of a frame)
 // its latency, not its throughput, sets the frame time.  Idle lanes gather for position 0 (one shared cache line) so that the code
 // stays branch-free; their result is zeroed.
-template <int KIND>
+template <int KIND, bool NETACC = false>
 __device__ __forceinline__ void level_eval_two(const GridView& gv, const LevelParams& lp0, const LevelParams& lp1, f3 pos, bool act, uint32_t& f0, uint32_t& f1) {
 	const f3 q = act ? pos : mk3(0.f, 0.f, 0.f);
 	const CellCoords c0 = cell_coords(lp0, q), c1 = cell_coords(lp1, q);
@@ -242,25 +263,26 @@ __device__ __forceinline__ void level_eval_two(const GridView& gv, const LevelPa
 			if (b0) issue_brick_record_loads(gv, lp0, c0, b0, v0); else issue_gathers<true>(gv, lp0, c0, v0);
 			if (b1) issue_brick_record_loads(gv, lp1, c1, b1, v1); else issue_gathers<true>(gv, lp1, c1, v1);
 		}
-		f0 = zero_if(!act, interpolate(c0, v0));
-		f1 = zero_if(!act, interpolate(c1, v1));
+		f0 = zero_if(!act, interpolate<NETACC>(c0, v0));
+		f1 = zero_if(!act, interpolate<NETACC>(c1, v1));
 		return;
 	}
 	if (KIND == KIND_DENSE && __builtin_expect(__any(dense_needs_slow(lp0, c0) || dense_needs_slow(lp1, c1)), 0)) { // exact tcnn wrap for samples outside [0,1)^3: rare
-		f0 = level_eval_exact(gv, lp0, c0);
-		f1 = level_eval_exact(gv, lp1, c1);
+		f0 = level_eval_exact<NETACC>(gv, lp0, c0);
+		f1 = level_eval_exact<NETACC>(gv, lp1, c1);
 	} else {
 		uint32_t v0[8], v1[8];
 		issue_level<KIND>(gv, lp0, c0, v0);
 		issue_level<KIND>(gv, lp1, c1, v1);
-		f0 = interpolate(c0, v0);
-		f1 = interpolate(c1, v1);
+		f0 = interpolate<NETACC>(c0, v0);
+		f1 = interpolate<NETACC>(c1, v1);
 	}
 	f0 = zero_if(!act, f0);
 	f1 = zero_if(!act, f1);
 }
 // One level of one sample, kind decided at run time (wave-uniform): the pairs whose two levels are of different kinds (the one
 // dense | hashed pair of a model without cell records, a records | no-records boundary at an odd level) come here, level after level.
+template <bool NETACC = false>
 __device__ __forceinline__ uint32_t level_eval_one(const GridView& gv, const LevelParams& lp, bool use_record, f3 pos, bool act) {
 	const f3 q = act ? pos : mk3(0.f, 0.f, 0.f);
 	const CellCoords c = cell_coords(lp, q);
@@ -268,15 +290,15 @@ __device__ __forceinline__ uint32_t level_eval_one(const GridView& gv, const Lev
 	uint32_t v[8];
 	if (use_record) {
 		issue_level<KIND_RECORD>(gv, lp, c, v);
-		f = interpolate(c, v);
+		f = interpolate<NETACC>(c, v);
 	} else if (lp.hashed) {
 		issue_level<KIND_HASHED>(gv, lp, c, v);
-		f = interpolate(c, v);
+		f = interpolate<NETACC>(c, v);
 	} else if (__builtin_expect(__any(dense_needs_slow(lp, c)), 0)) {
-		f = level_eval_exact(gv, lp, c);
+		f = level_eval_exact<NETACC>(gv, lp, c);
 	} else {
 		issue_level<KIND_DENSE>(gv, lp, c, v);
-		f = interpolate(c, v);
+		f = interpolate<NETACC>(c, v);
 	}
 	return zero_if(!act, f);
 }
@@ -289,6 +311,7 @@ __device__ __forceinline__ uint32_t level_eval_one(const GridView& gv, const Lev
 // same bits as before: the arithmetic per (sample, level) did not change.  The slab layout the MLP reads is unchanged too:
 // feat[it][0][l] = level 2 it + g(l) of lane l's sample, feat[it][1][l] = the same level of lane (l ^ 32)'s sample; so the level
 // of the lane's own parity goes to [0][lane] and the other one to [1][lane ^ 32] (a conflict-free permutation of the banks).
+template <bool NETACC = false>
 __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelParams* __restrict__ lv, const ModelLds& ml, FeatLds& fl, int lane, int g, f3 pos, bool act) {
 	// the records cover [0,1]^3; a wave with a sample outside it (a warped sample of an edit, rarely) gathers the native way
 	const bool outside = __any(act && outside_unit_cube(pos));
@@ -300,13 +323,13 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 		if (one_line) { lp0.hashed = lp1.hashed = 1u; lp0.mask = lp1.mask = 31u; lp0.offset = lp1.offset = 0u; lp0.count = lp1.count = 32u; }
 		const uint32_t kind = __builtin_amdgcn_readfirstlane(kinds[it]);
 		uint32_t f0, f1;
-		if (kind == KIND_RECORD) level_eval_two<KIND_RECORD>(gv, lp0, lp1, pos, act, f0, f1);
-		else if (kind == KIND_HASHED) level_eval_two<KIND_HASHED>(gv, lp0, lp1, pos, act, f0, f1);
-		else if (kind == KIND_DENSE) level_eval_two<KIND_DENSE>(gv, lp0, lp1, pos, act, f0, f1);
-		else if (kind == KIND_SPARSE) level_eval_two<KIND_SPARSE>(gv, lp0, lp1, pos, act, f0, f1);
+		if (kind == KIND_RECORD) level_eval_two<KIND_RECORD, NETACC>(gv, lp0, lp1, pos, act, f0, f1);
+		else if (kind == KIND_HASHED) level_eval_two<KIND_HASHED, NETACC>(gv, lp0, lp1, pos, act, f0, f1);
+		else if (kind == KIND_DENSE) level_eval_two<KIND_DENSE, NETACC>(gv, lp0, lp1, pos, act, f0, f1);
+		else if (kind == KIND_SPARSE) level_eval_two<KIND_SPARSE, NETACC>(gv, lp0, lp1, pos, act, f0, f1);
 		else {
-			f0 = level_eval_one(gv, lp0, !outside && !one_line && lp0.cached == 1u, pos, act);
-			f1 = level_eval_one(gv, lp1, !outside && !one_line && lp1.cached == 1u, pos, act);
+			f0 = level_eval_one<NETACC>(gv, lp0, !outside && !one_line && lp0.cached == 1u, pos, act);
+			f1 = level_eval_one<NETACC>(gv, lp1, !outside && !one_line && lp1.cached == 1u, pos, act);
 		}
 		fl.feat[it][0][lane] = g ? f1 : f0;
 		fl.feat[it][1][lane ^ 32] = g ? f0 : f1;
@@ -405,64 +428,76 @@ __device__ __forceinline__ floatx16 zero16() {
 }
 
 #define NRS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+// ACC16 (nrs_mlp_acc FP16): the running sums are rounded to fp16 after every 16-wide k step, the model of tiny-cuda-nn's fp16 accumulator fragments
+template <bool ACC16>
+__device__ __forceinline__ floatx16 mfma_step(half8 a, half8 b, floatx16 c) {
+	floatx16 d = NRS_MFMA(a, b, c);
+	if (ACC16) {
+		#pragma unroll
+		for (int i = 0; i < 16; ++i) d[i] = (float)(_Float16)d[i];
+	}
+	return d;
+}
 // Scheduling fence between MLP stages: without it hipcc hoists all 24 weight-fragment LDS reads (96 VGPRs) to the top of
 // the MLP, which costs a wave of occupancy.  The gather, not the MLP, is the phase that needs the latency hiding.
 #define NRS_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // Density MLP 32 -> 64 (ReLU) -> 16 for one 32-sample block.  x0/x1: features (k-steps 0/1).
 // Returns the fp16-rounded outputs as the next B operand: element e of lane (j, g) = output row (e&3) + 8*(e>>2) + 4g.
+template <bool ACC16 = false>
 __device__ __forceinline__ half8 density_mlp(const half8* lds_w, int lane, half8 x0, half8 x1) {
 	// hidden rows 0..31 then 32..63, each reduced to its two packed B operands before the next accumulator is started
 	floatx16 h = zero16();
-	h = NRS_MFMA(lds_w[NRS_FRAG_D1(0, 0) * 64 + lane], x0, h);
-	h = NRS_MFMA(lds_w[NRS_FRAG_D1(0, 1) * 64 + lane], x1, h);
+	h = mfma_step<ACC16>(lds_w[NRS_FRAG_D1(0, 0) * 64 + lane], x0, h);
+	h = mfma_step<ACC16>(lds_w[NRS_FRAG_D1(0, 1) * 64 + lane], x1, h);
 	const half8 p0 = relu_pack(h, 0), p1 = relu_pack(h, 8);
 	NRS_STAGE_FENCE();
 	h = zero16();
-	h = NRS_MFMA(lds_w[NRS_FRAG_D1(1, 0) * 64 + lane], x0, h);
-	h = NRS_MFMA(lds_w[NRS_FRAG_D1(1, 1) * 64 + lane], x1, h);
+	h = mfma_step<ACC16>(lds_w[NRS_FRAG_D1(1, 0) * 64 + lane], x0, h);
+	h = mfma_step<ACC16>(lds_w[NRS_FRAG_D1(1, 1) * 64 + lane], x1, h);
 	const half8 p2 = relu_pack(h, 0), p3 = relu_pack(h, 8);
 	NRS_STAGE_FENCE();
 	floatx16 o = zero16();
-	o = NRS_MFMA(lds_w[NRS_FRAG_D2(0) * 64 + lane], p0, o);
-	o = NRS_MFMA(lds_w[NRS_FRAG_D2(1) * 64 + lane], p1, o);
-	o = NRS_MFMA(lds_w[NRS_FRAG_D2(2) * 64 + lane], p2, o);
-	o = NRS_MFMA(lds_w[NRS_FRAG_D2(3) * 64 + lane], p3, o);
+	o = mfma_step<ACC16>(lds_w[NRS_FRAG_D2(0) * 64 + lane], p0, o);
+	o = mfma_step<ACC16>(lds_w[NRS_FRAG_D2(1) * 64 + lane], p1, o);
+	o = mfma_step<ACC16>(lds_w[NRS_FRAG_D2(2) * 64 + lane], p2, o);
+	o = mfma_step<ACC16>(lds_w[NRS_FRAG_D2(3) * 64 + lane], p3, o);
 	NRS_STAGE_FENCE();
 	return pack(o, 0);
 }
 
 // RGB MLP [density out 16 | SH 16] -> 64 -> 64 -> 16 (3 used) for one block.  Same output row map.
+template <bool ACC16 = false>
 __device__ __forceinline__ half8 rgb_mlp(const half8* lds_w, int lane, half8 din, half8 sh) {
 	floatx16 a = zero16();
-	a = NRS_MFMA(lds_w[NRS_FRAG_R1(0, 0) * 64 + lane], din, a);
-	a = NRS_MFMA(lds_w[NRS_FRAG_R1(0, 1) * 64 + lane], sh, a);
+	a = mfma_step<ACC16>(lds_w[NRS_FRAG_R1(0, 0) * 64 + lane], din, a);
+	a = mfma_step<ACC16>(lds_w[NRS_FRAG_R1(0, 1) * 64 + lane], sh, a);
 	const half8 b0 = relu_pack(a, 0), b1 = relu_pack(a, 8);
 	NRS_STAGE_FENCE();
 	a = zero16();
-	a = NRS_MFMA(lds_w[NRS_FRAG_R1(1, 0) * 64 + lane], din, a);
-	a = NRS_MFMA(lds_w[NRS_FRAG_R1(1, 1) * 64 + lane], sh, a);
+	a = mfma_step<ACC16>(lds_w[NRS_FRAG_R1(1, 0) * 64 + lane], din, a);
+	a = mfma_step<ACC16>(lds_w[NRS_FRAG_R1(1, 1) * 64 + lane], sh, a);
 	const half8 b2 = relu_pack(a, 0), b3 = relu_pack(a, 8);
 	NRS_STAGE_FENCE();
 	floatx16 c = zero16();
-	c = NRS_MFMA(lds_w[NRS_FRAG_R2(0, 0) * 64 + lane], b0, c);
-	c = NRS_MFMA(lds_w[NRS_FRAG_R2(0, 1) * 64 + lane], b1, c);
-	c = NRS_MFMA(lds_w[NRS_FRAG_R2(0, 2) * 64 + lane], b2, c);
-	c = NRS_MFMA(lds_w[NRS_FRAG_R2(0, 3) * 64 + lane], b3, c);
+	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(0, 0) * 64 + lane], b0, c);
+	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(0, 1) * 64 + lane], b1, c);
+	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(0, 2) * 64 + lane], b2, c);
+	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(0, 3) * 64 + lane], b3, c);
 	const half8 q0 = relu_pack(c, 0), q1 = relu_pack(c, 8);
 	NRS_STAGE_FENCE();
 	c = zero16();
-	c = NRS_MFMA(lds_w[NRS_FRAG_R2(1, 0) * 64 + lane], b0, c);
-	c = NRS_MFMA(lds_w[NRS_FRAG_R2(1, 1) * 64 + lane], b1, c);
-	c = NRS_MFMA(lds_w[NRS_FRAG_R2(1, 2) * 64 + lane], b2, c);
-	c = NRS_MFMA(lds_w[NRS_FRAG_R2(1, 3) * 64 + lane], b3, c);
+	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(1, 0) * 64 + lane], b0, c);
+	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(1, 1) * 64 + lane], b1, c);
+	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(1, 2) * 64 + lane], b2, c);
+	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(1, 3) * 64 + lane], b3, c);
 	const half8 q2 = relu_pack(c, 0), q3 = relu_pack(c, 8);
 	NRS_STAGE_FENCE();
 	floatx16 o = zero16();
-	o = NRS_MFMA(lds_w[NRS_FRAG_R3(0) * 64 + lane], q0, o);
-	o = NRS_MFMA(lds_w[NRS_FRAG_R3(1) * 64 + lane], q1, o);
-	o = NRS_MFMA(lds_w[NRS_FRAG_R3(2) * 64 + lane], q2, o);
-	o = NRS_MFMA(lds_w[NRS_FRAG_R3(3) * 64 + lane], q3, o);
+	o = mfma_step<ACC16>(lds_w[NRS_FRAG_R3(0) * 64 + lane], q0, o);
+	o = mfma_step<ACC16>(lds_w[NRS_FRAG_R3(1) * 64 + lane], q1, o);
+	o = mfma_step<ACC16>(lds_w[NRS_FRAG_R3(2) * 64 + lane], q2, o);
+	o = mfma_step<ACC16>(lds_w[NRS_FRAG_R3(3) * 64 + lane], q3, o);
 	NRS_STAGE_FENCE();
 	return pack(o, 0);
 }

@@ -93,6 +93,11 @@ class NerfNetwork:
             raise NrsError("set_params expects fp16 parameters (numpy float16 or their uint16 bits)")
         check(self.lib.nrs_model_set_params(self.h, p.ctypes.data, p.size))
 
+    def set_numerics(self, grid_acc=0, mlp_acc=0):
+        """tiny-cuda-nn's two unpinned roundings (nrs_model_set_numerics): grid_acc 0 = fp32 sum rounded once, 1 = per-corner fp16 accumulation;
+        mlp_acc 0 = fp32 accumulators, 1 = fp16 rounding of the running sum every 16-wide k step."""
+        check(self.lib.nrs_model_set_numerics(self.h, int(grid_acc), int(mlp_acc)))
+
     def set_cell_cache(self, max_bytes):
         """Budget of the cell-record cache (nrs_model_set_cell_cache): 0 drops it; results do not depend on it."""
         check(self.lib.nrs_model_set_cell_cache(self.h, int(max_bytes)))

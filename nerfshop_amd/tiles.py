@@ -3,9 +3,11 @@
 Rays are independent, so the only exchange step is the final gather of the rendered tiles.  The image is cut into
 tile x tile pixel tiles in row-major tile order and dealt round-robin: rank r owns tiles r, r + N, r + 2N, ...
 (lego rays are spatially clustered; an interleave balances the load where contiguous strips would not).  Each rank
-renders its tiles into a COMPACT buffer [tiles_per_rank, tile, tile, C] (nrs_render_params.tile_*), one
-torch.distributed gather (RCCL over xGMI on GPUs, gloo in the CPU tests) collects them on rank 0, and nrs_detile
-scatters them back into the W x H image.  The model (~26 MB) is replicated; nothing else is exchanged per frame.
+renders its tiles into a COMPACT buffer [tiles_per_rank, tile, tile, C] (nrs_render_params.tile_*); ONE exchange step
+collects them on rank 0 and nrs_detile scatters them back into the W x H image.  On GPUs the exchange is libnrs's own
+nrs_gather_tiles (host C++: ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on RCCL over xGMI, include/nrs.h) on a
+communicator bootstrapped through one torch.distributed broadcast of the 128-byte id; on CPU (the gloo tests) it is a
+torch.distributed gather.  The model (~26 MB) is replicated; nothing else is exchanged per frame.
 """
 import ctypes as C
 
@@ -34,6 +36,28 @@ def detile_index(width, height, tile, world, padded):
     return (((r * padded + k) * tile + (y % tile)) * tile + (x % tile)).reshape(-1)
 
 
+_COMM = {}  # (device index, world) -> nrs_comm handle: one RCCL communicator per process, shared by every TileSharder
+
+
+def _nrs_comm(device, rank, world):
+    """libnrs's RCCL communicator for this process (created on first use: rank 0 makes the id, torch.distributed broadcasts it)."""
+    key = (device.index or 0, world)
+    if key not in _COMM:
+        lib = _abi.load()
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            _abi.check(lib.nrs_comm_unique_id(buf))
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        ident = ident.to(device)
+        dist.broadcast(ident, src=0)
+        raw = bytes(ident.cpu().tolist())
+        h = C.c_void_p()
+        _abi.check(lib.nrs_comm_create(device.index or 0, rank, world, raw, C.byref(h)))
+        _COMM[key] = h
+    return _COMM[key]
+
+
 class TileSharder:
     def __init__(self, width, height, tile, rank, world, device):
         if tile % 8:
@@ -52,6 +76,17 @@ class TileSharder:
         else:
             self.all = None
         self._index = None
+        # GPUs: the C-ABI gather (RCCL inside libnrs).  NRS_GATHER=torch keeps torch.distributed.gather (also the fallback if RCCL cannot be loaded).
+        import os
+        self.gather_impl = "torch.distributed"
+        self.comm = None
+        if self.device.type == "cuda" and world > 1 and os.environ.get("NRS_GATHER", "nrs") != "torch":
+            try:
+                self.comm = _nrs_comm(self.device, rank, world)
+                self.gather_impl = "nrs_gather_tiles (RCCL send/recv, C-ABI)"
+            except _abi.NrsError as e:
+                import sys
+                print(f"[nerfshop_amd.tiles] nrs_comm_create failed ({e}); falling back to torch.distributed.gather", file=sys.stderr)
 
     def fill(self, p):
         """Write the sharding fields of an nrs_render_params."""
@@ -63,6 +98,13 @@ class TileSharder:
 
     def gather(self, ctx, p, frame, depth):
         """One gather to rank 0, then de-tile there.  `frame` [H, W, 4] / `depth` [H, W] are written on rank 0."""
+        if self.comm is not None:
+            lib = _abi.load()
+            s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            root = self.rank == 0
+            _abi.check(lib.nrs_gather_tiles(ctx.h, self.comm, 0, C.byref(p), self.padded, self.local.data_ptr(), self.all.data_ptr() if root else None,
+                                            frame.data_ptr() if root else None, depth.data_ptr() if root else None, s))
+            return
         if self.world > 1:
             dist.gather(self.local, list(self.all.unbind(0)) if self.rank == 0 else None, dst=0)
         elif self.rank == 0:

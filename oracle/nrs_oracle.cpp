@@ -428,8 +428,28 @@ void make_level_table(const nrs_model_desc& d, LevelTable& lt) {
 constexpr uint32_t N_DENSITY_W = 64 * 32 + 16 * 64;           // 3072
 constexpr uint32_t N_RGB_W = 64 * 32 + 64 * 64 + 16 * 64;     // 7168
 
+// one correctly rounded double -> binary16 conversion: the double is first brought to float with round-to-odd (so that the float -> half
+// rounding cannot double-round); hadd = one binary16 addition (the exact sum of two halfs fits a double)
+static uint16_t d2h(double d) {
+	float f = (float)d;
+	if ((double)f == d) return f2h(f);
+	float other = ((double)f < d) ? nextafterf(f, INFINITY) : nextafterf(f, -INFINITY);
+	return f2h((f2u(f) & 1u) ? f : other);
+}
+static uint16_t hadd(uint16_t a, uint16_t b) { return d2h((double)h2f(a) + (double)h2f(b)); }
+
 struct Model {
 	nrs_model_desc desc;
+	// The two places where tiny-cuda-nn's rounding cannot be read off the reference checkout (the submodule is empty), switchable
+	// (nrs_model_set_numerics / orc_model_set_numerics):
+	//   grid_acc: NRS_GRID_ACC_FP32 (default): the trilinear sum runs in fp32 (fmaf per corner) and is rounded to fp16 once;
+	//             NRS_GRID_ACC_NETWORK: kernel_grid as we recall it from NVlabs/tiny-cuda-nn of 2022 (grid.h): per corner
+	//             `result[f] += (T)(weight * (float)value[f])` with T = __half -- the fp32 product is rounded to fp16 and ADDED in fp16.
+	//   mlp_acc:  NRS_MLP_ACC_FP32 (default): exact products, one rounding per output (what fp32 accumulators give up to their own rounding);
+	//             NRS_MLP_ACC_FP16: the fully fused MLP's wmma fragments have fp16 accumulators: modelled as ONE fp16 rounding of the running
+	//             sum after every 16-wide k block (acc = fp16(acc + exact sum of 16 products)); how a tensor core sums inside a block is not
+	//             specified by NVIDIA, so this is a model of it, not a pin.
+	uint32_t grid_acc = 0, mlp_acc = 0;
 	LevelTable lt;
 	Box aabb;
 	std::vector<uint16_t> params; // tcnn order: density | rgb | grid
@@ -464,6 +484,7 @@ void hashgrid_encode_one(const Model& m, const float pos[3], uint16_t out[32]) {
 			w[d] = p[d] - fl;
 		}
 		float acc0 = 0.f, acc1 = 0.f;
+		uint16_t hacc0 = 0, hacc1 = 0;
 		for (uint32_t c = 0; c < 8; ++c) {
 			float weight = 1.0f;
 			uint32_t gl[3];
@@ -472,11 +493,16 @@ void hashgrid_encode_one(const Model& m, const float pos[3], uint16_t out[32]) {
 				else { weight *= w[d]; gl[d] = g[d] + 1u; }
 			}
 			uint32_t e = m.lt.offset[l] + grid_index(m.lt, l, gl[0], gl[1], gl[2]);
-			acc0 = fmaf(weight, h2f(grid[2 * (size_t)e + 0]), acc0);
-			acc1 = fmaf(weight, h2f(grid[2 * (size_t)e + 1]), acc1);
+			if (m.grid_acc == NRS_GRID_ACC_NETWORK) { // result[f] += (T)(weight * data), T = __half
+				hacc0 = hadd(hacc0, f2h(weight * h2f(grid[2 * (size_t)e + 0])));
+				hacc1 = hadd(hacc1, f2h(weight * h2f(grid[2 * (size_t)e + 1])));
+			} else {
+				acc0 = fmaf(weight, h2f(grid[2 * (size_t)e + 0]), acc0);
+				acc1 = fmaf(weight, h2f(grid[2 * (size_t)e + 1]), acc1);
+			}
 		}
-		out[2 * l + 0] = f2h(acc0);
-		out[2 * l + 1] = f2h(acc1);
+		out[2 * l + 0] = m.grid_acc == NRS_GRID_ACC_NETWORK ? hacc0 : f2h(acc0);
+		out[2 * l + 1] = m.grid_acc == NRS_GRID_ACC_NETWORK ? hacc1 : f2h(acc1);
 	}
 }
 
@@ -505,12 +531,23 @@ void sh4_encode_one(const float dir01[3], uint16_t out[16]) {
 }
 
 // out[j] = act( sum_k W[j*n_in + k] * in[k] ), fp16 in/out, exact accumulation
-inline void dense_layer(const float* W, uint32_t n_out, uint32_t n_in, const uint16_t* in, uint16_t* out, bool relu) {
+inline void dense_layer(const float* W, uint32_t n_out, uint32_t n_in, const uint16_t* in, uint16_t* out, bool relu, uint32_t mlp_acc = 0) {
 	float inf[64];
 	for (uint32_t k = 0; k < n_in; ++k) inf[k] = h2f(in[k]);
 	for (uint32_t j = 0; j < n_out; ++j) {
-		double acc = 0.0;
 		const float* w = W + (size_t)j * n_in;
+		if (mlp_acc == NRS_MLP_ACC_FP16) { // fp16 accumulator fragments: one rounding of the running sum per 16-wide k block
+			uint16_t hacc = 0;
+			for (uint32_t kb = 0; kb < n_in; kb += 16) {
+				double blk = (double)h2f(hacc);
+				for (uint32_t k = kb; k < kb + 16; ++k) blk += (double)w[k] * (double)inf[k];
+				hacc = d2h(blk);
+			}
+			if (relu && !(h2f(hacc) > 0.f)) hacc = 0;
+			out[j] = hacc;
+			continue;
+		}
+		double acc = 0.0;
 		for (uint32_t k = 0; k < n_in; ++k) acc += (double)w[k] * (double)inf[k];
 		float r = (float)acc;
 		if (relu && !(r > 0.f)) r = 0.f;
@@ -523,8 +560,8 @@ void density_mlp_one(const Model& m, const uint16_t feat[32], uint16_t out[16]) 
 	const float* W1 = m.wf.data();
 	const float* W2 = W1 + 64 * 32;
 	uint16_t h[64];
-	dense_layer(W1, 64, 32, feat, h, true);
-	dense_layer(W2, 16, 64, h, out, false);
+	dense_layer(W1, 64, 32, feat, h, true, m.mlp_acc);
+	dense_layer(W2, 16, 64, h, out, false, m.mlp_acc);
 }
 // rgb MLP 32->64->64->16 (base.json:52-58); input = [density out 16 | SH 16] (nerf_network_full.h:65-87)
 void rgb_mlp_one(const Model& m, const uint16_t in32[32], uint16_t out[16]) {
@@ -532,9 +569,9 @@ void rgb_mlp_one(const Model& m, const uint16_t in32[32], uint16_t out[16]) {
 	const float* W2 = W1 + 64 * 32;
 	const float* W3 = W2 + 64 * 64;
 	uint16_t h1[64], h2[64];
-	dense_layer(W1, 64, 32, in32, h1, true);
-	dense_layer(W2, 64, 64, h1, h2, true);
-	dense_layer(W3, 16, 64, h2, out, false);
+	dense_layer(W1, 64, 32, in32, h1, true, m.mlp_acc);
+	dense_layer(W2, 64, 64, h1, h2, true, m.mlp_acc);
+	dense_layer(W3, 16, 64, h2, out, false, m.mlp_acc);
 }
 // NerfNetworkFull::inference_mixed_precision_impl, nerf_network_full.h:62-96.  coord: 7 floats. out16: channels
 // 0..2 rgb raw, 3 = density raw (extract_density :89-95), 4..15 rgb-net padding outputs.
@@ -1362,6 +1399,7 @@ void* orc_model_create(const nrs_model_desc* d, const uint16_t* params, size_t n
 }
 void orc_model_set_bitfield(void* model, const uint8_t* bitfield) { ((Model*)model)->bitfield.assign(bitfield, bitfield + NRS_BITFIELD_BYTES); }
 void orc_model_destroy(void* model) { delete (Model*)model; }
+void orc_model_set_numerics(void* model, uint32_t grid_acc, uint32_t mlp_acc) { ((Model*)model)->grid_acc = grid_acc; ((Model*)model)->mlp_acc = mlp_acc; }
 
 // out: [n x 32] fp16 interleaved
 void orc_hashgrid_encode(void* model, uint32_t n, const float* in, uint32_t ld_in, uint16_t* out) {
@@ -1827,13 +1865,6 @@ void orc_pcg32_advance(uint64_t* state, uint64_t inc, uint64_t delta) { Pcg32 r{
 
 // __hadd: the exact sum of two halfs rounded ONCE to half.  The sum is exact in double; it is brought to float with
 // round-to-odd (sticky bit) so that the final round-to-nearest-even to 11 bits cannot double-round.
-static uint16_t hadd(uint16_t a, uint16_t b) {
-	double d = (double)h2f(a) + (double)h2f(b);
-	float f = (float)d;
-	if ((double)f == d) return f2h(f);
-	float other = ((double)f < d) ? nextafterf(f, INFINITY) : nextafterf(f, -INFINITY);
-	return f2h((f2u(f) & 1u) ? f : other);
-}
 
 // generate_grid_samples_nerf_nonuniform, cn:179-208.  Returns the cell index; pos_out = warped position.
 static uint32_t generate_grid_sample(Pcg32 rng, uint32_t i, uint32_t n_elements, uint32_t step, const Box& aabb, const float* grid_in,

@@ -84,6 +84,10 @@ class Model:
         if not self.h:
             raise ValueError("oracle: unsupported model description or wrong parameter count")
 
+    def set_numerics(self, grid_acc=0, mlp_acc=0):
+        self.lib.orc_model_set_numerics.restype = None
+        self.lib.orc_model_set_numerics(C.c_void_p(self.h), C.c_uint32(grid_acc), C.c_uint32(mlp_acc))
+
     def set_bitfield(self, bitfield):
         bf = np.ascontiguousarray(bitfield, np.uint8)
         self.lib.orc_model_set_bitfield(self.h, bf.ctypes.data)
