@@ -14,13 +14,14 @@
  *   nrs_network_inference    <- NerfNetwork<T>::inference_mixed_precision   include/.../nerf_network_full.h:62
  *   nrs_network_density      <- NerfNetwork<T>::density                     include/.../nerf_network_full.h:223
  *   nrs_density_on_grid / nrs_rgba_on_grid <- Testbed::get_density_on_grid / get_rgba_on_grid   src/testbed_nerf.cu:4538 / :4588  ("next" row f4)
- *   nrs_model_set_params     <- NerfNetwork<T>::set_params                  include/.../nerf_network_full.h:316
+ *   nrs_model_set_params / _device <- NerfNetwork<T>::set_params            include/.../nerf_network_full.h:316 (host blob / device pointers)
  *   nrs_model_set_density_grid <- Testbed::update_density_grid_mean_and_bitfield   src/testbed_nerf.cu:3642
  *   nrs_edit_create          <- TetMesh GPU members + upload                       tet_mesh.h:80-94, tet_mesh.cu:651-667
  *   nrs_edit_update_cage / _vertices <- interpolate_with_mvc + build_tet_grid + update_local_rotations, on the device   ("next" row f1)
  *   nrs_edit_create_affine   <- AffineDuplication ctor + update_destination         editing/affine_duplication.h:26, :77   ("next" row f4)
  *   nrs_edit_map_rays        <- EditOperator::map_rays      edit_operator.h:43, CageDeformation::map_rays  cage_deformation.cu:547
  *   nrs_edit_map_positions   <- EditOperator::map_positions edit_operator.h:51, cage_deformation.cu:624
+ *   nrs_edit_poisson_interpolate <- GrowingSelection::interpolate_poisson_boundary  src/editing/tools/growing_selection.cu:2350
  *   nrs_model_update_density_grid <- Testbed::update_density_grid_nerf_operator       src/testbed_nerf.cu:3533   ("next" row f2)
  *   nrs_snapshot_open        <- Testbed::load_snapshot / load_network_config        src/testbed.cu:3054 / :152       ("next" row f3)
  *   nrs_edits_open           <- Testbed::load_edits                                 src/testbed.cu:3205              ("next" row f3)
@@ -231,6 +232,10 @@ int    nrs_model_level_table(const nrs_model_desc* desc, float* scale, uint32_t*
 /* fp16 parameter blob in tiny-cuda-nn order: density MLP | rgb MLP | hash grid (nerf_network_full.h:316-349).
  * h_params is a HOST pointer (what Trainer::deserialize hands over); synchronous. */
 int    nrs_model_set_params(nrs_model* model, const void* h_params_fp16, size_t n_params);
+/* The same from a DEVICE pointer, as NerfNetworkFull::set_params receives it (nerf_network_full.h:316-349: pointers into the trainer's blob):
+ * the hash grid is copied device-to-device on `stream`, only the 20 KB of MLP weights visit the host (they are re-arranged into MFMA
+ * fragments).  Copy semantics: call again after every optimiser step.  Synchronises `stream`. */
+int    nrs_model_set_params_device(nrs_model* model, const void* d_params_fp16, size_t n_params, void* stream);
 /* nrs_grid_acc / nrs_mlp_acc above.  Applies to every entry point that evaluates the network.  The render kernel runs the non-default modes
  * with one lane per ray and without the membrane / AffineDuplication instantiations (NRS_ERR_UNSUPPORTED for those combinations). */
 int    nrs_model_set_numerics(nrs_model* model, uint32_t grid_acc, uint32_t mlp_acc);
@@ -359,6 +364,14 @@ int  nrs_edit_set_mvc(nrs_edit* edit, const float* h_weights, uint32_t n_cage_ve
 int  nrs_edit_update_cage(nrs_edit* edit, void* stream, const float* h_cage_vertices, uint32_t n_cage_vertices);
 int  nrs_edit_update_vertices(nrs_edit* edit, void* stream, const float* h_vertices, uint32_t n_vertices);
 int  nrs_edit_lut_size(const nrs_edit* edit, uint32_t* n_idx_out, uint32_t* max_per_cell_out);
+/* GrowingSelection::interpolate_poisson_boundary (src/editing/tools/growing_selection.cu:2350-2395): the link between nrs_poisson_boundary
+ * (membrane terms per CAGE vertex, inside and outside) and the renderer's membrane path (terms per TET vertex): boundary_shs, outside density and
+ * residual density of every tet vertex as gamma-weighted sums over the cage vertices.  h_gamma = TetMesh::gamma_coordinates [V x n_cage_vertices]
+ * (= compute_mvc of the canonical vertices with mvc_gamma); NULL: the weights given to nrs_edit_set_mvc (mvc_gamma = 1, the default).
+ * The operator then applies the membrane correction (apply_poisson, residual_amplitude) in every later render.  Synchronises `stream`. */
+int  nrs_edit_poisson_interpolate(nrs_edit* edit, void* stream, const float* h_gamma, uint32_t n_cage_vertices, const float* h_inside_density,
+                                  const float* h_outside_density, const float* h_inside_shs, const float* h_outside_shs, float residual_amplitude);
+int  nrs_edit_download_poisson(nrs_edit* edit, float* h_boundary_shs, float* h_outside_density, float* h_residual_density);
 /* read the device-side tables back (tests / inspection); any pointer may be NULL.  h_lut_idx holds n_idx entries,
  * h_bbox6 = min xyz, max xyz of the deformed mesh. */
 int  nrs_edit_download(nrs_edit* edit, float* h_vertices, uint32_t* h_lut_offsets, uint32_t* h_lut_idx, float* h_rotations,

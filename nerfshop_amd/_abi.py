@@ -119,10 +119,10 @@ class GridUpdate(C.Structure):
 
 # every symbol include/nrs.h declares; tests check the library exports exactly these
 EXPORTS = [
-    "nrs_last_error", "nrs_abi_version", "nrs_comm_unique_id", "nrs_comm_create", "nrs_comm_destroy", "nrs_gather_tiles",
+    "nrs_last_error", "nrs_abi_version", "nrs_edit_poisson_interpolate", "nrs_edit_download_poisson", "nrs_comm_unique_id", "nrs_comm_create", "nrs_comm_destroy", "nrs_gather_tiles",
     "nrs_ctx_create", "nrs_ctx_destroy", "nrs_ctx_device_info", "nrs_ctx_set_lane_teams",
     "nrs_model_create", "nrs_model_destroy", "nrs_model_n_params", "nrs_model_level_table",
-    "nrs_model_set_params", "nrs_model_set_numerics", "nrs_model_set_cell_cache", "nrs_model_cell_cache_bytes", "nrs_model_set_sparse_cell_cache", "nrs_model_sparse_cell_cache_bytes", "nrs_model_set_density_bitfield", "nrs_model_set_density_grid",
+    "nrs_model_set_params", "nrs_model_set_params_device", "nrs_model_set_numerics", "nrs_model_set_cell_cache", "nrs_model_cell_cache_bytes", "nrs_model_set_sparse_cell_cache", "nrs_model_sparse_cell_cache_bytes", "nrs_model_set_density_bitfield", "nrs_model_set_density_grid",
     "nrs_model_get_density_bitfield", "nrs_model_get_density_grid", "nrs_model_update_density_grid", "nrs_rng_seed",
     "nrs_network_inference", "nrs_network_density", "nrs_hashgrid_encode", "nrs_density_on_grid", "nrs_rgba_on_grid",
     "nrs_poisson_boundary", "nrs_poisson_sample_coords", "nrs_project_selection_pixels", "nrs_upper_cell_idx", "nrs_selection_cells",
@@ -183,6 +183,9 @@ def load():
     lib.nrs_model_cell_cache_bytes.argtypes = [P, P]
     lib.nrs_model_cell_cache_bytes.restype = C.c_size_t
     lib.nrs_model_set_numerics.argtypes = [P, C.c_uint32, C.c_uint32]
+    lib.nrs_model_set_params_device.argtypes = [P, P, C.c_size_t, P]
+    lib.nrs_edit_poisson_interpolate.argtypes = [P, P, P, C.c_uint32, P, P, P, P, C.c_float]
+    lib.nrs_edit_download_poisson.argtypes = [P, P, P, P]
     lib.nrs_comm_unique_id.argtypes = [P]
     lib.nrs_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, P, P]
     lib.nrs_comm_destroy.argtypes = [P]

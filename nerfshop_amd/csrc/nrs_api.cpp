@@ -651,6 +651,31 @@ int nrs_model_set_params(nrs_model* m, const void* h_params_fp16, size_t n_param
 	m->have_params = true;
 	return rebuild_cell_cache(m);
 }
+// NerfNetworkFull::set_params hands over DEVICE pointers into the trainer's parameter blob (nerf_network_full.h:316-349): the same for a caller
+// whose parameters already live on the device (a viewer that trains while it renders, src/testbed.cu:2502).  The hash grid (24-27 MB) is copied
+// device-to-device on `stream` (~10 us); only the 20 KB of MLP weights visit the host, to be re-arranged into MFMA fragments.  Copy semantics:
+// call it again after every optimiser step (the reference's renderer reads the blob in place; our weight fragments are a transformed copy).
+int nrs_model_set_params_device(nrs_model* m, const void* d_params_fp16, size_t n_params, void* stream) {
+	if (!m || !d_params_fp16) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_params_device: NULL argument");
+	const size_t expect = (size_t)kDensityW + kRgbW + (size_t)m->total_entries * 2;
+	if (n_params != expect) {
+		char buf[160];
+		snprintf(buf, sizeof(buf), "nrs_model_set_params_device: got %zu params, the description implies %zu", n_params, expect);
+		return fail(NRS_ERR_INVALID_ARG, buf);
+	}
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	hipStream_t s = (hipStream_t)stream;
+	const uint16_t* d = (const uint16_t*)d_params_fp16;
+	std::vector<uint16_t> w(kDensityW + kRgbW), frag(kWfragBytes / 2);
+	HIP_TRY(hipMemcpyAsync(w.data(), d, w.size() * 2, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(m->d_grid, d + kDensityW + kRgbW, (size_t)m->total_entries * 4, hipMemcpyDeviceToDevice, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	make_weight_fragments(w.data(), frag.data());
+	HIP_TRY(hipMemcpyAsync(m->d_wfrag, frag.data(), kWfragBytes, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipStreamSynchronize(s)); // frag is a local
+	m->have_params = true;
+	return rebuild_cell_cache(m);
+}
 int nrs_model_set_numerics(nrs_model* m, uint32_t grid_acc, uint32_t mlp_acc) {
 	if (!m) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_numerics: NULL model");
 	if (grid_acc > NRS_GRID_ACC_NETWORK || mlp_acc > NRS_MLP_ACC_FP16) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_numerics: unknown mode");
@@ -1125,6 +1150,64 @@ int nrs_edit_update_cage(nrs_edit* e, void* stream, const float* h_cage_vertices
 	HIP_TRY(hipMemcpyAsync(e->d_cage, h_cage_vertices, (size_t)n_cage_vertices * 12, hipMemcpyHostToDevice, s));
 	CAGE_TRY(launch_mvc_apply(e->n_vertices, e->n_cv, e->d_mvc, e->d_cage, e->d_verts, s));
 	return rebuild_after_vertices(e, s);
+}
+// GrowingSelection::interpolate_poisson_boundary (growing_selection.cu:2350-2395): the link between nrs_poisson_boundary (per CAGE vertex) and the
+// render kernel's membrane path (per TET vertex).  The per-cage-vertex factors are prepared here with the host libm's expf (the reference does this
+// on the host: std::exp(float)); the V_tet x V_cage weighted sums run on the device in the reference's order.
+int nrs_edit_poisson_interpolate(nrs_edit* e, void* stream, const float* h_gamma, uint32_t n_cage_vertices, const float* h_inside_density, const float* h_outside_density,
+                                 const float* h_inside_shs, const float* h_outside_shs, float residual_amplitude) {
+	if (!e || !h_inside_density || !h_outside_density || !h_inside_shs || !h_outside_shs || n_cage_vertices == 0) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_poisson_interpolate: bad argument");
+	if (e->de.kind != kEditCage) return fail(NRS_ERR_STATE, "nrs_edit_poisson_interpolate: not a cage operator");
+	if (!h_gamma && (!e->d_mvc || e->n_cv != n_cage_vertices))
+		return fail(NRS_ERR_STATE, "nrs_edit_poisson_interpolate: no gamma coordinates given and the operator holds no MVC weights for this cage (nrs_edit_set_mvc)");
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	hipStream_t s = (hipStream_t)stream;
+	const float min_step = 1.73205080757f / 1024; // MIN_CONE_STEPSIZE(), common_nerf.h:31
+	std::vector<float> per_cage((size_t)n_cage_vertices * 30);
+	for (uint32_t j = 0; j < n_cage_vertices; ++j) {
+		const float alpha_out = 1 - expf(-h_outside_density[j] * min_step), alpha_in = 1 - expf(-h_inside_density[j] * min_step);
+		const float w_outside = 1.f, w_inside = std::min(alpha_in / alpha_out, 1.f);
+		float* c = per_cage.data() + 30 * (size_t)j;
+		c[0] = alpha_out;
+		c[1] = h_outside_density[j];
+		c[2] = h_outside_density[j] - h_inside_density[j];
+		for (int k = 0; k < 27; ++k) c[3 + k] = w_outside * h_outside_shs[27 * (size_t)j + k] - w_inside * h_inside_shs[27 * (size_t)j + k];
+	}
+	float *d_per_cage = nullptr, *d_gamma = nullptr;
+	HIP_TRY(hipMalloc((void**)&d_per_cage, per_cage.size() * 4));
+	auto bail = [&](int rc) { (void)hipFree(d_per_cage); (void)hipFree(d_gamma); return rc; };
+	if (hipMemcpyAsync(d_per_cage, per_cage.data(), per_cage.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) return bail(fail(NRS_ERR_HIP, "nrs_edit_poisson_interpolate: upload"));
+	if (h_gamma) {
+		if (hipMalloc((void**)&d_gamma, (size_t)e->n_vertices * n_cage_vertices * 4) != hipSuccess ||
+		    hipMemcpyAsync(d_gamma, h_gamma, (size_t)e->n_vertices * n_cage_vertices * 4, hipMemcpyHostToDevice, s) != hipSuccess)
+			return bail(fail(NRS_ERR_HIP, "nrs_edit_poisson_interpolate: upload of the gamma coordinates"));
+	}
+	if (!e->de.shs) { // the operator was created without membrane arrays: they are the operator's from now on
+		void* d[3] = {nullptr, nullptr, nullptr};
+		const size_t sizes[3] = {27 * (size_t)e->n_vertices * 4, (size_t)e->n_vertices * 4, (size_t)e->n_vertices * 4};
+		for (int k = 0; k < 3; ++k) {
+			if (hipMalloc(&d[k], std::max<size_t>(sizes[k], 16)) != hipSuccess) return bail(fail(NRS_ERR_HIP, "nrs_edit_poisson_interpolate: device allocation"));
+			e->allocs.push_back(d[k]);
+		}
+		e->de.shs = (const float*)d[0]; e->de.out_density = (const float*)d[1]; e->de.res_density = (const float*)d[2];
+	}
+	const int rc = launch_poisson_interpolate(e->n_vertices, n_cage_vertices, h_gamma ? d_gamma : e->d_mvc, d_per_cage, (float*)e->de.shs, (float*)e->de.out_density,
+	                                          (float*)e->de.res_density, s);
+	if (rc != NRS_OK) { g_err = cage_last_error(); return bail(rc); }
+	if (hipStreamSynchronize(s) != hipSuccess) return bail(fail(NRS_ERR_HIP, "nrs_edit_poisson_interpolate: synchronise")); // the staging buffers are freed below
+	e->de.apply_poisson = 1u;
+	e->de.residual_amplitude = residual_amplitude;
+	return bail(NRS_OK);
+}
+// the per-tet-vertex membrane terms an operator holds ([V*27], [V], [V]); any pointer may be NULL
+int nrs_edit_download_poisson(nrs_edit* e, float* h_boundary_shs, float* h_outside_density, float* h_residual_density) {
+	if (!e) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_download_poisson: NULL argument");
+	if (!e->de.shs) return fail(NRS_ERR_STATE, "nrs_edit_download_poisson: the operator holds no membrane terms");
+	HIP_TRY(hipSetDevice(e->ctx->device));
+	if (h_boundary_shs) HIP_TRY(hipMemcpy(h_boundary_shs, e->de.shs, 27 * (size_t)e->n_vertices * 4, hipMemcpyDeviceToHost));
+	if (h_outside_density) HIP_TRY(hipMemcpy(h_outside_density, e->de.out_density, (size_t)e->n_vertices * 4, hipMemcpyDeviceToHost));
+	if (h_residual_density) HIP_TRY(hipMemcpy(h_residual_density, e->de.res_density, (size_t)e->n_vertices * 4, hipMemcpyDeviceToHost));
+	return NRS_OK;
 }
 int nrs_edit_update_vertices(nrs_edit* e, void* stream, const float* h_vertices, uint32_t n_vertices) {
 	if (!e || !h_vertices) return fail(NRS_ERR_INVALID_ARG, "nrs_edit_update_vertices: NULL argument");

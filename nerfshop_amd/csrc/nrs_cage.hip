@@ -48,6 +48,34 @@ __global__ void mvc_apply_kernel(uint32_t n_points, uint32_t n_cv, const float* 
 	points[3 * i] = p.x; points[3 * i + 1] = p.y; points[3 * i + 2] = p.z;
 }
 
+// ---- GrowingSelection::interpolate_poisson_boundary (growing_selection.cu:2350-2395): cage-vertex membrane terms -> tet vertices ---------------
+// thread per tet vertex; cage vertices in ascending order => the reference's float sums.  per_cage = [n_cv x 30]: alpha_out, outside density,
+// outside - inside density, 27 x sh_diff (prepared on the host with the host libm's expf, as the reference computes them).
+__global__ void poisson_interpolate_kernel(uint32_t n_points, uint32_t n_cv, const float* __restrict__ gamma, const float* __restrict__ per_cage,
+                                           float* __restrict__ shs, float* __restrict__ out_density, float* __restrict__ res_density) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_points) return;
+	float sh[27];
+	#pragma unroll
+	for (int k = 0; k < 27; ++k) sh[k] = 0.f;
+	float wsum = 0.f, od = 0.f, rd = 0.f;
+	const float* g = gamma + (size_t)i * n_cv;
+	for (uint32_t j = 0; j < n_cv; ++j) {
+		const float* c = per_cage + 30 * (size_t)j;
+		const float ga = g[j] * c[0];
+		wsum += ga;
+		#pragma unroll
+		for (int k = 0; k < 27; ++k) sh[k] += ga * c[3 + k];
+		od += g[j] * c[1];
+		rd += g[j] * c[2];
+	}
+	const float denom = (float)((double)wsum + 1e-6);
+	#pragma unroll
+	for (int k = 0; k < 27; ++k) shs[27 * (size_t)i + k] = sh[k] / denom;
+	out_density[i] = od;
+	res_density[i] = fmaxf(rd, 0.f);
+}
+
 // ---- bbox of the vertices (min/max are order-independent => exact) -> out[0..2] = min, out[3..5] = max ----------------------
 __global__ void bbox_kernel(uint32_t n, const float* __restrict__ v, float* __restrict__ out) {
 	__shared__ float lo[3][256], hi[3][256];
@@ -355,6 +383,11 @@ __global__ void tet_planes_kernel(uint32_t n_tets, const float* __restrict__ ver
 int launch_mvc_apply(uint32_t n_points, uint32_t n_cv, const float* d_weights, const float* d_cage, float* d_points, void* stream) {
 	hipLaunchKernelGGL(mvc_apply_kernel, dim3((n_points + 127) / 128), dim3(128), 0, (hipStream_t)stream, n_points, n_cv, d_weights, d_cage, d_points);
 	NRS_CAGE_CHECK("mvc_apply_kernel launch");
+	return NRS_OK;
+}
+int launch_poisson_interpolate(uint32_t n_points, uint32_t n_cv, const float* d_gamma, const float* d_per_cage, float* d_shs, float* d_out_density, float* d_res_density, void* stream) {
+	hipLaunchKernelGGL(poisson_interpolate_kernel, dim3((n_points + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_points, n_cv, d_gamma, d_per_cage, d_shs, d_out_density, d_res_density);
+	NRS_CAGE_CHECK("poisson_interpolate_kernel launch");
 	return NRS_OK;
 }
 int launch_bbox(uint32_t n, const float* d_verts, float* d_out6, void* stream) {

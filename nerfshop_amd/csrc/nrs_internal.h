@@ -168,6 +168,7 @@ const char* launch_last_error();
 constexpr uint32_t kLutScanTiles = kGridVol * kCascades / 4096;
 int launch_mvc_apply(uint32_t n_points, uint32_t n_cv, const float* d_weights, const float* d_cage, float* d_points, void* stream);
 int launch_bbox(uint32_t n, const float* d_verts, float* d_out6, void* stream);
+int launch_poisson_interpolate(uint32_t n_points, uint32_t n_cv, const float* d_gamma, const float* d_per_cage, float* d_shs, float* d_out_density, float* d_res_density, void* stream);
 int launch_lut_count_scan(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, uint32_t* d_tile_sums,
                           uint32_t* d_offsets, uint32_t* d_total, void* stream);
 int launch_lut_fill(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, const uint32_t* d_offsets, uint32_t* d_idx,

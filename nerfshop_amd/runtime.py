@@ -93,6 +93,13 @@ class NerfNetwork:
             raise NrsError("set_params expects fp16 parameters (numpy float16 or their uint16 bits)")
         check(self.lib.nrs_model_set_params(self.h, p.ctypes.data, p.size))
 
+    def set_params_device(self, params_fp16_cuda, stream=None):
+        """NerfNetwork::set_params with device pointers: a CUDA tensor of fp16 (or the same bits as int16/uint16) in tcnn order."""
+        t = params_fp16_cuda
+        if not t.is_cuda or t.element_size() != 2 or not t.is_contiguous():
+            raise NrsError("set_params_device expects a contiguous 2-byte CUDA tensor")
+        check(self.lib.nrs_model_set_params_device(self.h, t.data_ptr(), t.numel(), _stream_handle(stream)))
+
     def set_numerics(self, grid_acc=0, mlp_acc=0):
         """tiny-cuda-nn's two unpinned roundings (nrs_model_set_numerics): grid_acc 0 = fp32 sum rounded once, 1 = per-corner fp16 accumulation;
         mlp_acc 0 = fp32 accumulators, 1 = fp16 rounding of the running sum every 16-wide k step."""
@@ -217,6 +224,19 @@ class CageDeformation:
     def update_vertices(self, stream, vertices):
         v = np.ascontiguousarray(vertices, np.float32)
         check(self.lib.nrs_edit_update_vertices(self.h, _stream_handle(stream), v.ctypes.data, v.shape[0]))
+
+    def poisson_interpolate(self, stream, inside_density, outside_density, inside_shs, outside_shs, residual_amplitude=1.0, gamma=None):
+        """GrowingSelection::interpolate_poisson_boundary: per-cage-vertex membrane terms -> the operator's per-tet-vertex ones (on the device)."""
+        i_d, o_d = np.ascontiguousarray(inside_density, np.float32), np.ascontiguousarray(outside_density, np.float32)
+        i_s, o_s = np.ascontiguousarray(inside_shs, np.float32).reshape(-1, 27), np.ascontiguousarray(outside_shs, np.float32).reshape(-1, 27)
+        g = np.ascontiguousarray(gamma, np.float32) if gamma is not None else None
+        check(self.lib.nrs_edit_poisson_interpolate(self.h, _stream_handle(stream), g.ctypes.data if g is not None else None, i_d.size, i_d.ctypes.data, o_d.ctypes.data,
+                                                    i_s.ctypes.data, o_s.ctypes.data, float(residual_amplitude)))
+
+    def download_poisson(self, n_vertices):
+        sh, od, rd = np.zeros((n_vertices, 27), np.float32), np.zeros(n_vertices, np.float32), np.zeros(n_vertices, np.float32)
+        check(self.lib.nrs_edit_download_poisson(self.h, sh.ctypes.data, od.ctypes.data, rd.ctypes.data))
+        return sh, od, rd
 
     def lut_size(self):
         n, m = C.c_uint32(), C.c_uint32()

@@ -2120,4 +2120,32 @@ void orc_p_poisson_residuals(void* edit, uint32_t n, const float* coords7, float
 	}
 }
 
+// GrowingSelection::interpolate_poisson_boundary, growing_selection.cu:2350-2395: the MVC-weighted (gamma_coordinates) transfer of the cage
+// vertices' inside / outside membrane terms (compute_poisson_boundary) to the tet vertices.  Host code in the reference: std::exp(float) is
+// the host libm's expf; `boundary_shs /= sh_weights_sum + 1e-6` adds in double and divides by the sum rounded to float (Eigen converts the
+// scalar to the matrix' scalar type).  Pinned by the reference's own loop (oracle/ref_render.cpp: ref_poisson_interpolate).
+void orc_poisson_interpolate(const float* gamma, uint32_t n_tet_vertices, uint32_t n_cage_vertices, const float* inside_density, const float* outside_density,
+                             const float* inside_shs27, const float* outside_shs27, float* boundary_shs27_out, float* outside_density_out, float* residual_density_out) {
+	for (uint32_t i = 0; i < n_tet_vertices; ++i) {
+		float sh[27] = {0}, sh_weights_sum = 0.f, od = 0.f, rd = 0.f;
+		for (uint32_t j = 0; j < n_cage_vertices; ++j) {
+			const float g = gamma[(size_t)i * n_cage_vertices + j];
+			const float alpha_out = 1 - expf(-outside_density[j] * MIN_STEP);
+			const float alpha_in = 1 - expf(-inside_density[j] * MIN_STEP);
+			const float w_outside = 1.f, w_inside = std::min(alpha_in / alpha_out, 1.f);
+			sh_weights_sum += g * alpha_out;
+			for (int k = 0; k < 27; ++k) {
+				const float sh_diff = w_outside * outside_shs27[27 * (size_t)j + k] - w_inside * inside_shs27[27 * (size_t)j + k];
+				sh[k] += (g * alpha_out) * sh_diff;
+			}
+			od += g * outside_density[j];
+			rd += g * (outside_density[j] - inside_density[j]);
+		}
+		const float denom = (float)((double)sh_weights_sum + 1e-6);
+		for (int k = 0; k < 27; ++k) boundary_shs27_out[27 * (size_t)i + k] = sh[k] / denom;
+		outside_density_out[i] = od;
+		residual_density_out[i] = std::max(rd, 0.f);
+	}
+}
+
 } // extern "C"

@@ -245,6 +245,19 @@ def mvc_apply(weights, cage_v):
     return out
 
 
+def poisson_interpolate(gamma, inside_density, outside_density, inside_shs, outside_shs):
+    """GrowingSelection::interpolate_poisson_boundary restated (per-cage-vertex membrane terms -> per-tet-vertex)."""
+    lib = load()
+    g = _f32(gamma)
+    i_d, o_d, i_s, o_s = _f32(inside_density), _f32(outside_density), _f32(inside_shs).reshape(-1, 27), _f32(outside_shs).reshape(-1, 27)
+    n = g.shape[0]
+    sh, od, rd = np.zeros((n, 27), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    lib.orc_poisson_interpolate.restype = None
+    lib.orc_poisson_interpolate(C.c_void_p(g.ctypes.data), C.c_uint32(n), C.c_uint32(g.shape[1]), C.c_void_p(i_d.ctypes.data), C.c_void_p(o_d.ctypes.data),
+                                C.c_void_p(i_s.ctypes.data), C.c_void_p(o_s.ctypes.data), C.c_void_p(sh.ctypes.data), C.c_void_p(od.ctypes.data), C.c_void_p(rd.ctypes.data))
+    return sh, od, rd
+
+
 def local_rotations(vertices, original, tets):
     lib = load()
     v, o, t = _f32(vertices), _f32(original), np.ascontiguousarray(tets, np.uint32)

@@ -31,7 +31,7 @@ def load():
         _lib = C.CDLL(LIB_PATH)
         for fn in ("ref_render_frame", "ref_trace_coords", "ref_edit_map_rays", "ref_edit_map_positions", "ref_edit_poisson_residuals", "ref_build_tet_grid",
                    "ref_grid_to_bitfield", "ref_bary_tet", "ref_point_in_tet", "ref_ld_random_val", "ref_ld_random_pixel_offset", "ref_sobol", "ref_ray_intersect",
-                   "ref_box_intersects_triangle", "ref_grid_math", "ref_warp", "ref_evaluate_sh9", "ref_activations", "ref_pixel_to_ray", "ref_cell_functions", "ref_local_rotations", "ref_mvc_compute", "ref_mvc_apply"):
+                   "ref_box_intersects_triangle", "ref_grid_math", "ref_warp", "ref_evaluate_sh9", "ref_activations", "ref_pixel_to_ray", "ref_cell_functions", "ref_local_rotations", "ref_mvc_compute", "ref_mvc_apply", "ref_poisson_interpolate", "ref_affine_map_rays", "ref_affine_map_positions"):
             getattr(_lib, fn).restype = None
     return _lib
 
@@ -269,3 +269,13 @@ def affine_map_positions(desc, op, pos3):
     empty = np.zeros(c.shape[0], np.uint8)
     lib.ref_affine_map_positions(C.byref(desc), C.byref(op), C.c_uint32(c.shape[0]), _p(c), _p(empty))
     return c, empty
+
+
+def poisson_interpolate(gamma, inside_density, outside_density, inside_shs, outside_shs):
+    lib = load()
+    g = _f32(gamma)
+    i_d, o_d, i_s, o_s = _f32(inside_density), _f32(outside_density), _f32(inside_shs).reshape(-1, 27), _f32(outside_shs).reshape(-1, 27)
+    n = g.shape[0]
+    sh, od, rd = np.zeros((n, 27), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    lib.ref_poisson_interpolate(_p(g), C.c_uint32(n), C.c_uint32(g.shape[1]), _p(i_d), _p(o_d), _p(i_s), _p(o_s), _p(sh), _p(od), _p(rd))
+    return sh, od, rd

@@ -53,6 +53,8 @@ FRAGMENTS = [
     ("src/editing/tools/growing_selection.cu", "composite_shot_rays", r"^__global__ void composite_shot_rays\(", "fn"),
     ("src/editing/tools/growing_selection.cu", "activate_network_output", r"^__global__ void activate_network_output\(", "fn"),
     ("src/editing/tools/growing_selection.cu", "filter_empty", r"^__global__ void filter_empty\(", "fn"),
+    # GrowingSelection::interpolate_poisson_boundary: the per-tet-vertex loop (MVC-weighted transfer of the cage's membrane terms)
+    ("src/editing/tools/growing_selection.cu", "interpolate_poisson_boundary_loop", r"^\tfor \(int i = 0; i < n_tet_vertices; i\+\+\) \{", "block:interpolate_poisson_boundary:0"),
     # TetMesh::update_local_rotations: the per-tet loop (centroids, correlation matrix, svd_eigen, R = U V^T)
     ("src/editing/datastructures/tet_mesh.cu", "update_local_rotations_loop", r"^\tfor \(int i = 0; i < n_tets; i\+\+\) \{", "block:update_local_rotations:0"),
     # Cage::interpolate_with_mvc(weights, points): the accumulation loop

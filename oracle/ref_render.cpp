@@ -467,6 +467,29 @@ void ref_mvc_apply(const float* weights_in, const float* cage_vertices, uint32_t
 	for (uint32_t i = 0; i < n_pts; ++i) for (int c = 0; c < 3; ++c) out3[3 * (size_t)i + c] = points[i][c];
 }
 
+// ---- GrowingSelection::interpolate_poisson_boundary, growing_selection.cu:2350-2395: loop compiled from the reference --------------------------------
+// per-cage-vertex inside / outside densities and SH9RGB colours (compute_poisson_boundary) -> per-tet-vertex boundary_shs / outside / residual density
+void ref_poisson_interpolate(const float* gamma /*[V_tet x V_cage]*/, uint32_t n_tet_vertices_in, uint32_t n_cage_vertices_in, const float* inside_density, const float* outside_density,
+                             const float* inside_shs27, const float* outside_shs27, float* boundary_shs27_out, float* outside_density_out, float* residual_density_out) {
+	struct { std::vector<float> outside_density, inside_density; std::vector<SH9RGB> outside_shs, inside_shs; } proxy_cage;
+	struct TetMeshGamma { std::vector<std::vector<float>> gamma_coordinates; } tet_mesh_storage;
+	TetMeshGamma* tet_interpolation_mesh = &tet_mesh_storage;
+	const uint32_t n_tet_vertices = n_tet_vertices_in, n_cage_vertices = n_cage_vertices_in;
+	proxy_cage.outside_density.assign(outside_density, outside_density + n_cage_vertices);
+	proxy_cage.inside_density.assign(inside_density, inside_density + n_cage_vertices);
+	proxy_cage.outside_shs.resize(n_cage_vertices); proxy_cage.inside_shs.resize(n_cage_vertices);
+	memcpy((void*)proxy_cage.outside_shs.data(), outside_shs27, 108 * (size_t)n_cage_vertices);
+	memcpy((void*)proxy_cage.inside_shs.data(), inside_shs27, 108 * (size_t)n_cage_vertices);
+	tet_mesh_storage.gamma_coordinates.resize(n_tet_vertices);
+	for (uint32_t i = 0; i < n_tet_vertices; ++i) tet_mesh_storage.gamma_coordinates[i].assign(gamma + (size_t)i * n_cage_vertices, gamma + (size_t)(i + 1) * n_cage_vertices);
+	std::vector<SH9RGB> boundary_shs_host(n_tet_vertices, SH9RGB::Zero());
+	std::vector<float> boundary_residual_density_host(n_tet_vertices, 0.f), boundary_outside_density_host(n_tet_vertices, 0.f), boundary_inside_density_host(n_tet_vertices, 0.f);
+#include "interpolate_poisson_boundary_loop.inc"
+	memcpy(boundary_shs27_out, (const void*)boundary_shs_host.data(), 108 * (size_t)n_tet_vertices);
+	memcpy(outside_density_out, boundary_outside_density_host.data(), 4 * (size_t)n_tet_vertices);
+	memcpy(residual_density_out, boundary_residual_density_host.data(), 4 * (size_t)n_tet_vertices);
+}
+
 // ---- update_density_grid_mean_and_bitfield, testbed_nerf.cu:3642-3657: grid_to_bitfield + bitfield_max_pool (the mean is the caller's) ------
 void ref_grid_to_bitfield(const float* grid /*[5*128^3]*/, float mean_density, uint8_t* bitfield /*[5*128^3/8]*/) {
 	const uint32_t n_elements = NERF_GRIDSIZE() * NERF_GRIDSIZE() * NERF_GRIDSIZE();

@@ -333,6 +333,17 @@ def authoring_cases(scenes, which):
         w, lab = orc.mvc_compute(cv, ct, pts)
         moved = orc.mvc_apply(w, cv * np.float32(1.07) + np.float32(0.013))
     out["mvc"] = [w, lab, moved]
+    # GrowingSelection::interpolate_poisson_boundary: cage-vertex membrane terms -> tet vertices, with the MVC weights above as gamma coordinates
+    r = np.random.default_rng(17)
+    n_cv = cv.shape[0]
+    inside_d = r.uniform(0.0, 60.0, n_cv).astype(np.float32)
+    outside_d = r.uniform(0.5, 80.0, n_cv).astype(np.float32)
+    inside_d[::5] = 0.0                                            # empty inside: w_inside = 0
+    outside_d[1::7] = inside_d[1::7] * np.float32(0.5) + np.float32(0.01)  # outside thinner than inside: the min(.., 1) clamp and a negative residual
+    inside_s = r.normal(scale=0.5, size=(n_cv, 27)).astype(np.float32)
+    outside_s = r.normal(scale=0.5, size=(n_cv, 27)).astype(np.float32)
+    fn = ref.poisson_interpolate if which == "ref" else orc.poisson_interpolate
+    out["poisson_interpolate"] = list(fn(w, inside_d, outside_d, inside_s, outside_s))
     return out
 
 

@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size-2 gloo processes exercise the tile sharding + gather + de-tile host logic of
+"""N > 1 path on CPU: world_size-2 and world_size-8 gloo processes exercise the tile sharding + gather + de-tile host logic of
 nerfshop_amd.tiles exactly as bench.py drives it on GPUs (there the backend is RCCL and the renderer the HIP kernel;
 here the backend is gloo and each rank's tiles come from the CPU oracle, which honours the same nrs_render_params
 tile fields)."""
@@ -72,12 +72,13 @@ def _worker(rank, world, port, W, H, tile, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("W,H,tile", [(96, 56, 16), (100, 60, 24)])
-def test_tile_shard_gather_world2(built, W, H, tile):
+@pytest.mark.parametrize("world,W,H,tile", [(2, 96, 56, 16), (2, 100, 60, 24), (8, 120, 72, 16)])
+def test_tile_shard_gather(built, world, W, H, tile):
+    """world 8 = the configuration BASELINE configs[4] names; (120, 72, 16) gives 40 tiles: 5 per rank."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, W, H, tile, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, tile, q)) for r in range(world)]
     for pr in procs:
         pr.start()
     for pr in procs:

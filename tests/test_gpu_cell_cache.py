@@ -198,3 +198,30 @@ def test_sparse_brick_records_are_a_layout_of_the_same_numbers(rig16):
         rig.net.set_cell_cache(10 << 30)
         rig.net.set_params(scene.params)
         rig.use_edit(False)
+
+
+def test_set_params_from_a_device_pointer(rig):
+    """nrs_model_set_params_device (NerfNetworkFull::set_params takes device pointers, nerf_network_full.h:316-349): the same model state as the host
+    entry point -- features, network outputs and the cell records rebuilt from it."""
+    torch = rig.torch
+    c = _coords(30000, 12, 0.0, 1.0)
+    before = _encode(rig, c)
+    other = rig.scene.params.copy()
+    rng = np.random.default_rng(13)
+    other[:] = rng.uniform(-0.4, 0.4, size=other.size).astype(np.float16).view(np.uint16)
+    try:
+        rig.net.set_params(other)
+        want_feat = _encode(rig, c)
+        want = torch.zeros((16, c.shape[0]), dtype=torch.float16, device="cuda:0")
+        rig.net.inference_mixed_precision(None, torch.from_numpy(c).cuda(), want)
+        rig.net.set_params(rig.scene.params)
+        assert np.array_equal(_encode(rig, c), before)
+        d = torch.from_numpy(other.view(np.int16)).cuda()
+        rig.net.set_params_device(d)
+        got = torch.zeros_like(want)
+        rig.net.inference_mixed_precision(None, torch.from_numpy(c).cuda(), got)
+        assert np.array_equal(_encode(rig, c), want_feat) and torch.equal(got.view(torch.int16), want.view(torch.int16))
+        with pytest.raises(_abi.NrsError):
+            rig.net.set_params_device(d[:-2])
+    finally:
+        rig.net.set_params(rig.scene.params)

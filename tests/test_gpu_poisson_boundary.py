@@ -72,3 +72,82 @@ def test_errors(rig):
     v = np.zeros((1, 3), np.float32)
     with pytest.raises(_abi.NrsError):
         rig.testbed.compute_poisson_boundary(v, False, np.zeros((100 * 100, 2), np.float32), 100, 100)
+
+
+def _cage_membrane_terms(rig, edit, w=8):
+    """compute_poisson_boundary at the CAGE vertices, inside and outside (growing_selection.cu:2362-2368), on the device and by the oracle"""
+    cv = np.ascontiguousarray(edit.cage_vertices, np.float32)
+    n = cv.shape[0]
+    jit = np.random.default_rng(21).uniform(0, 1, size=(n * w * w, 2)).astype(np.float32)
+    dev = [rig.testbed.compute_poisson_boundary(cv, inside, jit, w, w) for inside in (True, False)]
+    orc = [rig.scene.oracle_model.poisson_boundary(cv, w, w, jit, inside)[:2] for inside in (True, False)]
+    return dev, orc
+
+
+def test_poisson_interpolate_matches_oracle_bit_for_bit(rig):
+    """nrs_edit_poisson_interpolate = GrowingSelection::interpolate_poisson_boundary (growing_selection.cu:2350-2395): the V_tet x V_cage weighted
+    sums on the device in the reference's order; per-cage-vertex factors from the host libm as in the reference.  Same inputs -> same bits as the
+    oracle's restatement (itself pinned to the reference's compiled loop, tests/test_ref_pin.py)."""
+    from oracle import oracle as orc
+    scene = rig.scene
+    edit = scene.edit
+    op = rig.rt.CageDeformation(rig.ctx, scene.desc, edit)
+    try:
+        n_cv = edit.cage_vertices.shape[0]
+        rng = np.random.default_rng(5)
+        inside_d = rng.uniform(0, 60, n_cv).astype(np.float32); inside_d[::4] = 0
+        outside_d = rng.uniform(0.5, 80, n_cv).astype(np.float32)
+        inside_s, outside_s = rng.normal(scale=0.5, size=(n_cv, 27)).astype(np.float32), rng.normal(scale=0.5, size=(n_cv, 27)).astype(np.float32)
+        ref = orc.poisson_interpolate(edit.mvc_weights, inside_d, outside_d, inside_s, outside_s)
+        # with explicit gamma coordinates ...
+        op.poisson_interpolate(None, inside_d, outside_d, inside_s, outside_s, 0.8, gamma=edit.mvc_weights)
+        got = op.download_poisson(edit.vertices.shape[0])
+        for a, b in zip(got, ref):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        # ... and with the operator's own MVC weights
+        op.set_mvc(edit.mvc_weights)
+        op.poisson_interpolate(None, inside_d * 0.5, outside_d, inside_s, outside_s, 0.8)
+        got2 = op.download_poisson(edit.vertices.shape[0])
+        ref2 = orc.poisson_interpolate(edit.mvc_weights, inside_d * 0.5, outside_d, inside_s, outside_s)
+        for a, b in zip(got2, ref2):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert (ref[2] > 0).sum() > 50 and np.abs(ref[0]).max() > 0.05
+    finally:
+        op.close()
+
+
+def test_membrane_chain_end_to_end(rig):
+    """cage-vertex boundary fit (nrs_poisson_boundary, inside and outside) -> nrs_edit_poisson_interpolate -> render with the membrane correction,
+    against the same chain through the oracle (poisson_boundary -> poisson_interpolate -> Edit with membrane arrays -> render)."""
+    import copy
+    from oracle import oracle as orc
+    from test_gpu_parity import _compare_frames
+    scene = rig.scene
+    edit = scene.edit
+    rig.use_edit(True)
+    op = rig.rt.CageDeformation(rig.ctx, scene.desc, edit)
+    saved = rig.testbed.edit_operators
+    try:
+        (dev_in, dev_out), (orc_in, orc_out) = _cage_membrane_terms(rig, edit)
+        assert (orc_out[0] > 0).any()
+        op.poisson_interpolate(None, dev_in[0], dev_out[0], dev_in[1], dev_out[1], 0.8, gamma=edit.mvc_weights)
+        sh, od, rd = orc.poisson_interpolate(edit.mvc_weights, orc_in[0], orc_out[0], orc_in[1], orc_out[1])
+        got = op.download_poisson(edit.vertices.shape[0])
+        assert np.abs(got[0] - sh).max() < 2e-2 * max(1.0, np.abs(sh).max()) and np.allclose(got[1], od, rtol=3e-2, atol=1e-4)   # boundary-fit tolerance carried through
+        e2 = copy.copy(edit)
+        e2.boundary_shs, e2.boundary_outside_density, e2.boundary_residual_density, e2.residual_amplitude = sh, od, rd, 0.8
+        o_edit = orc.Edit(scene.desc, e2.tet_mesh_struct(), keepalive=e2)
+        # render with the ORACLE's per-vertex terms on both sides (the fit's tolerance is checked above; here the chain's last link)
+        op.poisson_interpolate(None, orc_in[0], orc_out[0], orc_in[1], orc_out[1], 0.8, gamma=edit.mvc_weights)
+        rig.testbed.edit_operators = [op]
+        p = scene.params_for(256, 144, 60.0)
+        frame, depth, steps, stats = rig.render(p)
+        ref_frame, ref_depth, ref_steps, _ = scene.oracle_model.render(p, [o_edit])
+        _compare_frames(frame, depth, steps, ref_frame, ref_depth, ref_steps)
+        rig.testbed.edit_operators = saved
+        plain, _, _, _ = rig.render(p)
+        assert np.abs(plain - frame).max() > 1e-3   # the correction is visible
+    finally:
+        rig.testbed.edit_operators = saved
+        op.close()
+        rig.use_edit(False)
