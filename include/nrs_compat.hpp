@@ -64,6 +64,8 @@ public:
 	// set_params(params, inference_params, ...) of the reference takes device pointers into the trainer's blob; here the fp16
 	// blob (density MLP | rgb MLP | hash grid, nerf_network_full.h:316-349) is handed over from the host once.
 	void set_params(const void* h_params_fp16, size_t n) { check(nrs_model_set_params(m_model, h_params_fp16, n), "nrs_model_set_params"); }
+	// ... or, as in the reference, from device pointers (call again after every optimiser step: nrs.h)
+	void set_params_device(const void* d_params_fp16, size_t n, void* stream) { check(nrs_model_set_params_device(m_model, d_params_fp16, n, stream), "nrs_model_set_params_device"); }
 	// budget of the cell-record cache (no counterpart in the reference; results do not depend on it), 0 = off
 	void set_cell_cache(size_t max_bytes) { check(nrs_model_set_cell_cache(m_model, max_bytes), "nrs_model_set_cell_cache"); }
 
@@ -89,13 +91,13 @@ private:
 	nrs_model* m_model = nullptr;
 };
 
-// EditOperator subset on the render path (edit_operator.h:43-91)
-class CageDeformation {
+// EditOperator (edit_operator.h:43-91): the interface NerfTracer::m_edit_operators holds (testbed.h:237) -- cage deformations and affine
+// duplications alike.  An operator owns its device tables.
+class EditOperator {
 public:
-	CageDeformation(Context& ctx, const nrs_model_desc& desc, const nrs_tet_mesh& mesh) { check(nrs_edit_create(ctx.get(), &desc, &mesh, &m_edit), "nrs_edit_create"); }
-	~CageDeformation() { nrs_edit_destroy(m_edit); }
-	CageDeformation(const CageDeformation&) = delete;
-	CageDeformation& operator=(const CageDeformation&) = delete;
+	virtual ~EditOperator() { nrs_edit_destroy(m_edit); }
+	EditOperator(const EditOperator&) = delete;
+	EditOperator& operator=(const EditOperator&) = delete;
 
 	void map_rays(void* stream, float* d_nerf_coords /*[n x 7]*/, uint8_t* d_empty_mask, uint32_t n_elements) const {
 		check(nrs_edit_map_rays(m_edit, stream, n_elements, d_nerf_coords, d_empty_mask), "nrs_edit_map_rays");
@@ -103,6 +105,16 @@ public:
 	void map_positions(void* stream, float* d_nerf_pos, uint32_t stride_floats, uint8_t* d_empty_mask, uint32_t n_elements) const {
 		check(nrs_edit_map_positions(m_edit, stream, n_elements, d_nerf_pos, stride_floats, d_empty_mask), "nrs_edit_map_positions");
 	}
+	nrs_edit* get() const { return m_edit; }
+
+protected:
+	EditOperator() = default;
+	nrs_edit* m_edit = nullptr;
+};
+
+class CageDeformation : public EditOperator {
+public:
+	CageDeformation(Context& ctx, const nrs_model_desc& desc, const nrs_tet_mesh& mesh) { check(nrs_edit_create(ctx.get(), &desc, &mesh, &m_edit), "nrs_edit_create"); }
 	// The per-gizmo-move chain (Cage::interpolate_with_mvc -> TetMesh::post_update_vertices -> build_tet_grid ->
 	// update_local_rotations), on the device.  set_mvc once after Cage::compute_mvc; update_cage per move.
 	void set_mvc(const float* h_weights, uint32_t n_cage_vertices) { check(nrs_edit_set_mvc(m_edit, h_weights, n_cage_vertices), "nrs_edit_set_mvc"); }
@@ -112,10 +124,20 @@ public:
 	void update_vertices(void* stream, const float* h_vertices, uint32_t n_vertices) {
 		check(nrs_edit_update_vertices(m_edit, stream, h_vertices, n_vertices), "nrs_edit_update_vertices");
 	}
-	nrs_edit* get() const { return m_edit; }
+	// GrowingSelection::interpolate_poisson_boundary (growing_selection.cu:2350): cage-vertex membrane terms -> the operator's per-tet-vertex ones;
+	// h_gamma = TetMesh::gamma_coordinates or nullptr for the weights given to set_mvc
+	void interpolate_poisson_boundary(void* stream, const float* h_gamma, uint32_t n_cage_vertices, const float* h_inside_density, const float* h_outside_density,
+	                                  const float* h_inside_shs, const float* h_outside_shs, float residual_amplitude) {
+		check(nrs_edit_poisson_interpolate(m_edit, stream, h_gamma, n_cage_vertices, h_inside_density, h_outside_density, h_inside_shs, h_outside_shs, residual_amplitude),
+		      "nrs_edit_poisson_interpolate");
+	}
+};
 
-private:
-	nrs_edit* m_edit = nullptr;
+class AffineDuplication : public EditOperator { // editing/affine_duplication.h:23-106
+public:
+	AffineDuplication(Context& ctx, const nrs_model_desc& desc, const nrs_affine_duplication& op) {
+		check(nrs_edit_create_affine(ctx.get(), &desc, &op, &m_edit), "nrs_edit_create_affine");
+	}
 };
 
 // View over the caller's frame / depth device arrays (CudaRenderBuffer::frame_buffer() / depth_buffer() / spp()).
@@ -138,7 +160,9 @@ public:
 	bool m_snap_to_pixel_centers = true;
 	bool m_enable_edits = true;
 	nrs_render_mode m_render_mode = NRS_RENDER_SHADE;
-	std::vector<const CageDeformation*> m_edit_operators; // NerfTracer::m_edit_operators, applied last-to-first
+	std::vector<const EditOperator*> m_edit_operators; // NerfTracer::m_edit_operators (testbed.h:237), applied last-to-first
+	bool m_poisson_target = false;                    // NerfTracer::m_poisson_target (passed to composite_kernel_nerf, testbed_nerf.cu:2951)
+	int m_show_accel = -1;                            // m_nerf.show_accel: >= 0 forces that cascade as the minimum while marching (:2751, :2849)
 
 	// Testbed state update_density_grid_nerf_operator advances: m_rng, m_nerf.density_grid_ema_step, density_grid_decay, max_cascade
 	nrs_grid_update m_density_grid_update{};
@@ -152,7 +176,7 @@ public:
 	// void Testbed::update_density_grid_nerf_render(uint32_t n_iterations, bool reset_grid, cudaStream_t)  -- testbed_nerf.cu:3514
 	void update_density_grid_nerf_render(NerfNetwork& network, uint32_t n_iterations, bool reset_grid, void* stream) {
 		std::vector<nrs_edit*> edits;
-		if (m_enable_edits) for (const CageDeformation* op : m_edit_operators) edits.push_back(op->get());
+		if (m_enable_edits) for (const EditOperator* op : m_edit_operators) edits.push_back(op->get());
 		for (uint32_t i = 0; i < n_iterations; ++i) {
 			m_density_grid_update.reset_grid = (reset_grid && i == 0) ? 1u : 0u;
 			check(nrs_model_update_density_grid(network.get(), edits.data(), (int)edits.size(), &m_density_grid_update, stream),
@@ -181,8 +205,10 @@ public:
 		p.render_mode = m_render_mode;
 		p.linear_colors = m_nerf.training_linear_colors;
 		p.apply_operators = apply_operators && m_enable_edits;
+		p.poisson_target = m_poisson_target ? 1u : 0u;
+		p.min_mip = m_show_accel >= 0 ? (uint32_t)m_show_accel : 0u;
 		std::vector<nrs_edit*> edits;
-		for (const CageDeformation* op : m_edit_operators) edits.push_back(op->get());
+		for (const EditOperator* op : m_edit_operators) edits.push_back(op->get());
 		check(nrs_render_nerf(network.get(), &p, edits.data(), (int)edits.size(), render_buffer.frame_buffer, render_buffer.depth_buffer, nullptr, stream,
 		                      stats),
 		      "nrs_render_nerf");

@@ -221,8 +221,14 @@ int main() {
         for (int i = 0; i < 3; ++i) { d.aabb_min[i] = 0.f; d.aabb_max[i] = 1.f; }
         nrs::compat::NerfNetwork net(ctx, d);
         nrs::compat::Testbed tb;
+        // the operator list holds cage deformations and affine duplications alike (EditOperator*, testbed.h:237)
+        nrs_affine_duplication ad{};
+        for (int i = 0; i < 3; ++i) { ad.selection_center[i] = 0.5f; ad.selection_scale[i] = 0.2f; ad.scale[i] = 1.f; ad.selection_rot[4 * i] = ad.rotation[4 * i] = 1.f; }
+        nrs::compat::AffineDuplication dup(ctx, d, ad);
+        tb.m_edit_operators.push_back(&dup);
+        tb.m_poisson_target = true;
+        tb.m_show_accel = -1;
         std::printf("gpu %zu\\n", net.n_params());
-        (void)tb;
     } catch (const std::exception& e) {
         std::printf("error: %s\\n", e.what());
     }
