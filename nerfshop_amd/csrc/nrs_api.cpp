@@ -1343,15 +1343,31 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		const unsigned long long fb = ctx->h_feedback ? __atomic_load_n(ctx->h_feedback, __ATOMIC_RELAXED) : 0ull;
 		const double hit_share = (fb >> 32) ? (double)(uint32_t)fb / (double)(fb >> 32) : 0.25;
 		a.pixels_owned = (uint32_t)std::min<uint64_t>((uint64_t)a.n_packets * 64ull, 0xffffffffull);
-		const double rays_per_lane = hit_share * (double)a.pixels_owned / (64.0 * 16.0 * (double)ctx->n_cus);
+		// Launches of this context still running on OTHER streams (frames in flight: a rank of a multi-GPU job that overlaps its frames, a viewer that
+		// double-buffers) share the GPU with this one: the launch gets 1 / (1 + busy) of the lanes, and once three or more overlap the GPU is full
+		// whatever the size of one launch -- lane teams (a latency device) then only cost fill passes.  Measured, 1/8 share of the 1080p bench frame,
+		// ms per share-frame with 1 / 2 / 4 frames in flight: automatic choice before this rule 0.69 / 0.69 / 0.46, one lane per ray 0.99 / 0.54 / 0.36,
+		// two lanes 0.77 / 0.47 / 0.49 (tools/scale_probe_teams.py) -- i.e. 0.95 of the single-GPU per-GPU throughput at an eighth of the frame.
+		uint32_t busy = 0; // = number of OTHER streams with an unfinished launch (launches queued behind one another on a stream do not overlap)
+		hipStream_t seen[nrs_ctx::kInFlight];
+		for (int k = 0; k < nrs_ctx::kInFlight; ++k) {
+			if ((uint32_t)k == slot || !ctx->slot_used[k] || ctx->slot_stream[k] == s) continue;
+			bool dup = false;
+			for (uint32_t q = 0; q < busy; ++q) dup = dup || seen[q] == ctx->slot_stream[k];
+			if (!dup && hipEventQuery(ctx->slot_done[k]) == hipErrorNotReady) seen[busy++] = ctx->slot_stream[k];
+		}
+		(void)hipGetLastError(); // hipErrorNotReady is an answer, not an error
+		const double rays_per_lane = hit_share * (double)a.pixels_owned * (double)(1u + busy) / (64.0 * 16.0 * (double)ctx->n_cus);
 		uint32_t team = rays_per_lane <= 0.55 ? 4u : (rays_per_lane <= 4.5 ? 2u : 1u);
+		if (busy >= 2) team = 1;
+		else if (busy == 1 && team > 2) team = 2;
 		// the fill runs once per pixel and lane of a team: keep it to ~8 passes over the GPU (an all-miss 1080p frame is 8)
-		while (team > 1 && (double)team * (double)a.pixels_owned > 8.5 * 64.0 * 16.0 * (double)ctx->n_cus) team >>= 1;
+		while (team > 1 && (double)team * (double)a.pixels_owned * (double)(1u + busy) > 8.5 * 64.0 * 16.0 * (double)ctx->n_cus) team >>= 1;
 		if (forced == 1 || forced == 2 || forced == 4) team = (uint32_t)forced;
 		if (forced == -1) team = 1;
 		if (a.any_poisson || a.any_affine) team = 1; // (those instantiations are built for one lane per ray)
 		static const bool log_teams = getenv("NRS_TEAM_LOG") != nullptr;
-		if (log_teams) fprintf(stderr, "[nrs team] pixels=%u hit_share=%.3f rays/lane=%.3f team=%u\n", a.pixels_owned, hit_share, rays_per_lane, team);
+		if (log_teams) fprintf(stderr, "[nrs team] pixels=%u hit_share=%.3f busy=%u rays/lane=%.3f team=%u\n", a.pixels_owned, hit_share, busy, rays_per_lane, team);
 		static const uint32_t tail_target = []() { const char* e = getenv("NRS_TAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)atoi(e) : 24u; }(); // 8 / 16 / 24 / 32 / 48: 8.92 / 8.91 / 9.11 / 9.01 / 8.47 Gsamples/s
 		a.tail_target = tail_target;
 		if (((team == 4 && !forced && hybrid_on) || forced == -2) && !a.any_poisson && !a.any_affine && !(a.dbg & 4u)) {

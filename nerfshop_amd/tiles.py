@@ -80,7 +80,7 @@ class TileSharder:
         import os
         self.gather_impl = "torch.distributed"
         self.comm = None
-        if self.device.type == "cuda" and world > 1 and os.environ.get("NRS_GATHER", "nrs") != "torch":
+        if self.device.type == "cuda" and world > 1 and dist.is_initialized() and os.environ.get("NRS_GATHER", "nrs") != "torch":
             try:
                 self.comm = _nrs_comm(self.device, rank, world)
                 self.gather_impl = "nrs_gather_tiles (RCCL send/recv, C-ABI)"
