@@ -263,6 +263,10 @@ int    nrs_model_set_density_bitfield(nrs_model* model, const uint8_t* h_bitfiel
  * exactly as update_density_grid_mean_and_bitfield does (testbed_nerf.cu:514-555, 3642-3657). */
 int    nrs_model_set_density_grid(nrs_model* model, const float* h_grid, size_t n_floats);
 int    nrs_model_get_density_bitfield(nrs_model* model, uint8_t* h_bitfield_out, size_t n_bytes);
+/* Test hook: the marching accelerator the library derived from the bitfield (no reference counterpart; the reference marches cell by
+ * cell, testbed_nerf.cu:1100-1131).  which 0: the flavour used for general step parameters, 1: for cone_angle == 0 && min_mip == 0.
+ * h_box12 = {min[3], max[3], cell[3], 1/cell[3]} of the occupied box and its 32^3 look-ahead blocks, h_mask = 32^3 / 32 words. */
+int    nrs_model_get_march_accelerator(nrs_model* model, int which, float* h_box12, uint32_t* h_mask1024);
 /* The float grid the bitfield was last derived from ([5*128^3]; zeros if only a bitfield was ever set). */
 int    nrs_model_get_density_grid(nrs_model* model, float* h_grid_out, size_t n_floats);
 /* Deformed-space occupancy refresh ("next" row f2): Testbed::update_density_grid_nerf_operator, testbed_nerf.cu:3533.

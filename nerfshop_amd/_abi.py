@@ -123,7 +123,7 @@ EXPORTS = [
     "nrs_ctx_create", "nrs_ctx_destroy", "nrs_ctx_device_info", "nrs_ctx_set_lane_teams",
     "nrs_model_create", "nrs_model_destroy", "nrs_model_n_params", "nrs_model_level_table",
     "nrs_model_set_params", "nrs_model_set_params_device", "nrs_model_set_numerics", "nrs_model_set_cell_cache", "nrs_model_cell_cache_bytes", "nrs_model_set_sparse_cell_cache", "nrs_model_sparse_cell_cache_bytes", "nrs_model_set_density_bitfield", "nrs_model_set_density_grid",
-    "nrs_model_get_density_bitfield", "nrs_model_get_density_grid", "nrs_model_update_density_grid", "nrs_rng_seed",
+    "nrs_model_get_density_bitfield", "nrs_model_get_march_accelerator", "nrs_model_get_density_grid", "nrs_model_update_density_grid", "nrs_rng_seed",
     "nrs_network_inference", "nrs_network_density", "nrs_hashgrid_encode", "nrs_density_on_grid", "nrs_rgba_on_grid",
     "nrs_poisson_boundary", "nrs_poisson_sample_coords", "nrs_project_selection_pixels", "nrs_upper_cell_idx", "nrs_selection_cells",
     "nrs_edit_create", "nrs_edit_create_affine", "nrs_edit_destroy", "nrs_edit_map_rays", "nrs_edit_map_positions",
@@ -198,6 +198,7 @@ def load():
     lib.nrs_model_set_density_grid.argtypes = [P, P, C.c_size_t]
     lib.nrs_model_get_density_bitfield.argtypes = [P, P, C.c_size_t]
     lib.nrs_model_get_density_grid.argtypes = [P, P, C.c_size_t]
+    lib.nrs_model_get_march_accelerator.argtypes = [P, I, P, P]
     lib.nrs_model_update_density_grid.argtypes = [P, C.POINTER(P), I, C.POINTER(GridUpdate), P]
     lib.nrs_rng_seed.argtypes = [C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.nrs_rng_seed.restype = None

@@ -218,95 +218,6 @@ static void warp_box(const Box3& b, const Box3& aabb, Box3& out) { // BoundingBo
 	}
 }
 
-// World-space bounds of every occupied cell of every cascade (cell (x,y,z) of level l spans
-// ((x/128 - 0.5) * 2^l + 0.5, ((x+1)/128 - 0.5) * 2^l + 0.5) per axis), inflated by 1/16 of a cell of the level.
-static uint32_t compact3(uint32_t x) {
-	x &= 0x49249249u;
-	x = (x | (x >> 2)) & 0xc30c30c3u;
-	x = (x | (x >> 4)) & 0x0f00f00fu;
-	x = (x | (x >> 8)) & 0xff0000ffu;
-	x = (x | (x >> 16)) & 0x0000ffffu;
-	return x;
-}
-// exact_mip: the caller renders with cone_angle == 0 and min_mip == 0, so the cascade tested at a position is
-// mip_from_pos(pos) and nothing else: a cell of cascade L >= 1 can only ever be consulted from the shell
-// 2^(L-2) <= max|pos - 0.5| (cn:163-168); cells that lie entirely inside that shell's hole are ignored.  This is what keeps
-// the OR-pooled coarse cascades of an aabb_scale-1 scene from blowing the box (and the mask below) up to their resolution.
-static bool cell_block_relevant(uint32_t level, const uint32_t c[3], bool exact_mip, float margin) {
-	if (!exact_mip || level == 0) return true;
-	const float s = std::ldexp(1.0f, (int)level);
-	float far = 0.f;
-	for (int k = 0; k < 3; ++k) {
-		const float a = ((float)c[k] / (float)kGrid - 0.5f) * s - margin, b = ((float)(c[k] + 2u) / (float)kGrid - 0.5f) * s + margin; // pos - 0.5
-		far = std::fmax(far, std::fmax(std::fabs(a), std::fabs(b)));
-	}
-	return far >= std::ldexp(1.0f, (int)level - 2);
-}
-static void occupied_bounds(const uint8_t* bitfield, bool exact_mip, Box3& out) {
-	const float inf = std::numeric_limits<float>::infinity();
-	for (int k = 0; k < 3; ++k) { out.mn[k] = inf; out.mx[k] = -inf; }
-	for (uint32_t level = 0; level < kCascades; ++level) {
-		const uint8_t* b = bitfield + (size_t)level * kGridVol / 8;
-		const float s = std::ldexp(1.0f, (int)level), margin = s / (float)kGrid / 16.f;
-		for (uint32_t byte = 0; byte < kGridVol / 8; ++byte) {
-			if ((byte & 7u) == 0) { // most of the field is empty: skip 8 bytes (64 cells) at a time
-				uint64_t w;
-				memcpy(&w, b + byte, 8);
-				if (!w) { byte += 7; continue; }
-			}
-			if (!b[byte]) continue;
-			// the 8 cells of a byte are one 2x2x2 Morton block: bounds of the block are exact enough (<= 1 cell slack)
-			const uint32_t m = byte * 8;
-			const uint32_t c[3] = {compact3(m), compact3(m >> 1), compact3(m >> 2)};
-			if (!cell_block_relevant(level, c, exact_mip, margin)) continue;
-			for (int k = 0; k < 3; ++k) {
-				out.mn[k] = std::fmin(out.mn[k], ((float)c[k] / (float)kGrid - 0.5f) * s + 0.5f - margin);
-				out.mx[k] = std::fmax(out.mx[k], ((float)(c[k] + 2u) / (float)kGrid - 0.5f) * s + 0.5f + margin);
-			}
-		}
-	}
-}
-
-// The look-ahead mask over occ_box (OccAccel::mask): every relevant occupied 2x2x2 Morton block of every cascade marks the
-// coarse blocks its (inflated) extent overlaps.
-static void occupied_accel(const uint8_t* bitfield, bool exact_mip, OccAccel& acc, uint32_t* host_mask) {
-	occupied_bounds(bitfield, exact_mip, acc.box);
-	memset(host_mask, 0, kCoarseWords * 4);
-	for (int k = 0; k < 3; ++k) { acc.cell[k] = 1.f; acc.inv_cell[k] = 1.f; }
-	if (!(acc.box.mn[0] <= acc.box.mx[0])) return; // nothing occupied
-	for (int k = 0; k < 3; ++k) {
-		acc.cell[k] = (acc.box.mx[k] - acc.box.mn[k]) / (float)kCoarse;
-		acc.inv_cell[k] = 1.0f / acc.cell[k];
-	}
-	for (uint32_t level = 0; level < kCascades; ++level) {
-		const uint8_t* b = bitfield + (size_t)level * kGridVol / 8;
-		const float s = std::ldexp(1.0f, (int)level), margin = s / (float)kGrid / 16.f;
-		for (uint32_t byte = 0; byte < kGridVol / 8; ++byte) {
-			if ((byte & 7u) == 0) {
-				uint64_t w;
-				memcpy(&w, b + byte, 8);
-				if (!w) { byte += 7; continue; }
-			}
-			if (!b[byte]) continue;
-			const uint32_t m = byte * 8;
-			const uint32_t c[3] = {compact3(m), compact3(m >> 1), compact3(m >> 2)};
-			if (!cell_block_relevant(level, c, exact_mip, margin)) continue;
-			int lo[3], hi[3];
-			for (int k = 0; k < 3; ++k) {
-				const float wmin = ((float)c[k] / (float)kGrid - 0.5f) * s + 0.5f - margin;
-				const float wmax = ((float)(c[k] + 2u) / (float)kGrid - 0.5f) * s + 0.5f + margin;
-				lo[k] = std::min((int)kCoarse - 1, std::max(0, (int)std::floor((wmin - acc.box.mn[k]) * acc.inv_cell[k])));
-				hi[k] = std::min((int)kCoarse - 1, std::max(0, (int)std::floor((wmax - acc.box.mn[k]) * acc.inv_cell[k])));
-			}
-			for (int z = lo[2]; z <= hi[2]; ++z)
-				for (int y = lo[1]; y <= hi[1]; ++y)
-					for (int x = lo[0]; x <= hi[0]; ++x) {
-						const uint32_t idx = ((uint32_t)z * kCoarse + (uint32_t)y) * kCoarse + (uint32_t)x;
-						host_mask[idx >> 5] |= 1u << (idx & 31);
-					}
-		}
-	}
-}
 // DeviceModel as one render / trace launch sees it: the marching accelerator that matches the launch's step parameters
 static DeviceModel model_for_launch(const nrs_model* m, const nrs_render_params& p);
 
@@ -320,12 +231,23 @@ static int upload(nrs_edit* e, const T* h, size_t count, const T** d_out) {
 	return NRS_OK;
 }
 
-// both flavours of the marching accelerator from a host copy of the bitfield; masks go to the model's device buffers
-static int refresh_accel(nrs_model* m, const uint8_t* h_bitfield) {
-	std::vector<uint32_t> mask(2 * kCoarseWords);
-	occupied_accel(h_bitfield, false, m->accel_any, mask.data());
-	occupied_accel(h_bitfield, true, m->accel_exact, mask.data() + kCoarseWords);
-	HIP_TRY(hipMemcpy(m->d_accel_masks, mask.data(), mask.size() * 4, hipMemcpyHostToDevice));
+// Both flavours of the marching accelerator from m->d_bitfield (launch_occ_accel: bounds, box and look-ahead masks are built on the device);
+// the host reads back the 2 x 12 floats a launch carries in its kernel arguments, and synchronises the stream for that.
+static int refresh_accel(nrs_model* m, void* stream) {
+	hipStream_t s = (hipStream_t)stream;
+	float* d_out = reinterpret_cast<float*>(m->d_accel_masks + 2 * kCoarseWords);
+	NRS_TRY(launch_occ_accel(m->dm.bitfield, m->d_accel_masks, d_out, m->d_accel_masks + 2 * kCoarseWords + 24, stream));
+	float h[24];
+	HIP_TRY(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	OccAccel* acc[2] = {&m->accel_any, &m->accel_exact};
+	for (int f = 0; f < 2; ++f)
+		for (int k = 0; k < 3; ++k) {
+			acc[f]->box.mn[k] = h[f * 12 + k];
+			acc[f]->box.mx[k] = h[f * 12 + 3 + k];
+			acc[f]->cell[k] = h[f * 12 + 6 + k];
+			acc[f]->inv_cell[k] = h[f * 12 + 9 + k];
+		}
 	m->accel_any.mask = m->d_accel_masks;
 	m->accel_exact.mask = m->d_accel_masks + kCoarseWords;
 	return NRS_OK;
@@ -446,7 +368,7 @@ int nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out) 
 	hipError_t he = hipMalloc((void**)&m->d_grid, (size_t)m->total_entries * 4);
 	if (he == hipSuccess) he = hipMalloc((void**)&m->d_wfrag, kWfragBytes);
 	if (he == hipSuccess) he = hipMalloc((void**)&m->d_bitfield, NRS_BITFIELD_BYTES);
-	if (he == hipSuccess) he = hipMalloc((void**)&m->d_accel_masks, 2 * kCoarseWords * 4);
+	if (he == hipSuccess) he = hipMalloc((void**)&m->d_accel_masks, 2 * kCoarseWords * 4 + 256); // + 24 floats of OccAccel numbers + 12 words of scratch (refresh_accel)
 	if (he == hipSuccess) he = hipMemset(m->d_accel_masks, 0, 2 * kCoarseWords * 4);
 	if (he == hipSuccess) he = hipMalloc((void**)&m->d_density_grid, (size_t)kGridVol * kCascades * 4);
 	if (he == hipSuccess) he = hipMemset(m->d_density_grid, 0, (size_t)kGridVol * kCascades * 4);
@@ -687,19 +609,16 @@ int nrs_model_set_density_bitfield(nrs_model* m, const uint8_t* h_bitfield, size
 	if (n_bytes != NRS_BITFIELD_BYTES) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_density_bitfield: expected 5*128^3/8 bytes");
 	HIP_TRY(hipSetDevice(m->ctx->device));
 	HIP_TRY(hipMemcpy(m->d_bitfield, h_bitfield, n_bytes, hipMemcpyHostToDevice));
-	NRS_TRY(refresh_accel(m, h_bitfield));
+	NRS_TRY(refresh_accel(m, nullptr));
 	m->have_bitfield = true;
 	return NRS_OK;
 }
-// bitfield + mips from m->d_density_grid, then the marching shortcut's bounds (host pass over 1.3 MB; synchronises)
+// bitfield + mips from m->d_density_grid, then the marching shortcut's bounds and masks (all on the device; synchronises for 96 bytes)
 static int refresh_bitfield(nrs_model* m, void* stream) {
 	hipStream_t s = (hipStream_t)stream;
 	HIP_TRY(hipMemsetAsync(m->d_bitfield, 0, NRS_BITFIELD_BYTES, s));
 	NRS_TRY(launch_grid_to_bitfield(m->d_density_grid, m->d_bitfield, m->ctx->d_mean, stream));
-	std::vector<uint8_t> host_bits(NRS_BITFIELD_BYTES);
-	HIP_TRY(hipMemcpyAsync(host_bits.data(), m->d_bitfield, NRS_BITFIELD_BYTES, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
-	NRS_TRY(refresh_accel(m, host_bits.data()));
+	NRS_TRY(refresh_accel(m, stream));
 	m->have_bitfield = true;
 	return NRS_OK;
 }
@@ -770,6 +689,15 @@ int nrs_model_update_density_grid(nrs_model* m, nrs_edit* const* edits, int n_ed
 	u->rng_state = pcg_advance(u->rng_state, u->rng_inc, 2ull << 32);
 	u->ema_step += 1;
 	return refresh_bitfield(m, stream);
+}
+int nrs_model_get_march_accelerator(nrs_model* m, int which, float* h_box12, uint32_t* h_mask) {
+	if (!m || !h_box12 || !h_mask || which < 0 || which > 1) return fail(NRS_ERR_INVALID_ARG, "nrs_model_get_march_accelerator: bad argument");
+	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_model_get_march_accelerator: occupancy not set (nrs_model_set_density_bitfield/_grid)");
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	const OccAccel& a = which ? m->accel_exact : m->accel_any;
+	for (int k = 0; k < 3; ++k) { h_box12[k] = a.box.mn[k]; h_box12[3 + k] = a.box.mx[k]; h_box12[6 + k] = a.cell[k]; h_box12[9 + k] = a.inv_cell[k]; }
+	HIP_TRY(hipMemcpy(h_mask, a.mask, kCoarseWords * 4, hipMemcpyDeviceToHost));
+	return NRS_OK;
 }
 int nrs_model_get_density_bitfield(nrs_model* m, uint8_t* h_out, size_t n_bytes) {
 	if (!m || !h_out || n_bytes != NRS_BITFIELD_BYTES) return fail(NRS_ERR_INVALID_ARG, "nrs_model_get_density_bitfield: bad argument");

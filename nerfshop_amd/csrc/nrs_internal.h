@@ -42,7 +42,7 @@ constexpr uint32_t kWfragBytes = kNumFrags * kFragBytes; // 24 KiB
 
 struct Box3 { float mn[3]; float mx[3]; };
 
-// Result-preserving marching accelerator derived from the occupancy bitfield on the host:
+// Result-preserving marching accelerator derived from the occupancy bitfield (launch_occ_accel, on the device):
 //   box   world-space bounds of every occupied cell that can be consulted, slightly inflated (shortcut 1)
 //   mask  kCoarse^3 bits over box: bit (z*kCoarse + y)*kCoarse + x set iff such a cell (inflated alike) overlaps that block (shortcut 2)
 struct OccAccel {
@@ -157,6 +157,9 @@ int launch_grid_eval(const DeviceModel& m, int mode, const uint32_t res[3], cons
                      const float* d_density_grid, float* d_out, int n_cus, void* stream);
 int launch_map_rays(const DeviceEdit& e, uint32_t n, float* d_coords, uint32_t ld, int with_dir, uint8_t* d_empty, void* stream);
 int launch_grid_to_bitfield(const float* d_grid, uint8_t* d_bitfield, float* d_scratch_mean, void* stream);
+// both flavours of the marching accelerator from the bitfield: d_masks 2 x kCoarseWords words; d_out 2 x {mn[3], mx[3], cell[3], inv_cell[3]}
+// (slot 0: any step parameters, slot 1: cone_angle == 0 && min_mip == 0); d_keys: 12 words of scratch
+int launch_occ_accel(const uint8_t* d_bitfield, uint32_t* d_masks, float* d_out, uint32_t* d_keys, void* stream);
 // one iteration of update_density_grid_nerf_operator up to (not including) mean/bitfield; d_grid_tmp must be zeroed
 int launch_grid_update(const DeviceModel& m, const DeviceEdit* d_edits, int n_edits, const nrs_grid_update& u, uint64_t rng_state_nonuniform,
                        float* d_grid, uint32_t* d_grid_tmp, int n_cus, void* stream);

@@ -1206,6 +1206,129 @@ int launch_grid_to_bitfield(const float* d_grid, uint8_t* d_bitfield, float* d_s
 	return NRS_OK;
 }
 
+// ---- the marching accelerator (OccAccel) from the bitfield, on the device --------------------------------------------------
+// Two flavours at once (slot 0: any step parameters; slot 1: cone_angle == 0 && min_mip == 0, where a cell of cascade L >= 1 can only
+// be consulted from the shell 2^(L-2) <= max|pos - 0.5| (cn:163-168), so blocks that lie inside that shell's hole are ignored: this is
+// what keeps the OR-pooled coarse cascades of an aabb_scale-1 scene from blowing box and mask up to their resolution).
+// One thread per 8 bytes of the bitfield = 8 Morton 2x2x2 blocks; a block's world bounds, inflated by 1/16 cell of its cascade, feed
+//   pass 1: min / max per axis (wave reduction, then atomicMin / atomicMax on order-preserving integer keys: exact, order-independent),
+//   pass 2: box, cell and 1 / cell of the kCoarse^3 look-ahead mask (one thread; the host downloads exactly these numbers),
+//   pass 3: the mask bits every relevant block's extent overlaps (atomicOr, skipped when the bit is already visible).
+struct OccAccelOut { float mn[3], mx[3], cell[3], inv_cell[3]; };
+__device__ __forceinline__ uint32_t float_key(float f) { const uint32_t u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u); }
+__device__ __forceinline__ float key_float(uint32_t k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }
+__device__ __forceinline__ bool accel_block_relevant(uint32_t level, const uint32_t c[3], float s, float margin) {
+	if (level == 0) return true;
+	float far = 0.f;
+	for (int k = 0; k < 3; ++k) {
+		const float a = ((float)c[k] / (float)kGrid - 0.5f) * s - margin, b = ((float)(c[k] + 2u) / (float)kGrid - 0.5f) * s + margin; // pos - 0.5
+		far = fmaxf(far, fmaxf(fabsf(a), fabsf(b)));
+	}
+	return far >= ldexpf(1.0f, (int)level - 2);
+}
+__global__ void __launch_bounds__(256) occ_accel_bounds_kernel(const uint64_t* __restrict__ bitfield, uint32_t* __restrict__ keys) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x; // kCascades * kGridVol / 64 words exactly
+	const uint64_t w = bitfield[i];
+	const float inf = __builtin_huge_valf();
+	float mn[2][3] = {{inf, inf, inf}, {inf, inf, inf}}, mx[2][3] = {{-inf, -inf, -inf}, {-inf, -inf, -inf}};
+	if (w) {
+		const uint32_t level = i / (kGridVol / 64), byte0 = (i % (kGridVol / 64)) * 8;
+		const float s = ldexpf(1.0f, (int)level), margin = s / (float)kGrid / 16.f;
+		for (uint32_t j = 0; j < 8; ++j) {
+			if (!((w >> (8 * j)) & 0xffu)) continue;
+			const uint32_t m = (byte0 + j) * 8;
+			const uint32_t c[3] = {morton3D_invert(m), morton3D_invert(m >> 1), morton3D_invert(m >> 2)};
+			const bool exact = accel_block_relevant(level, c, s, margin);
+			for (int k = 0; k < 3; ++k) {
+				const float lo = ((float)c[k] / (float)kGrid - 0.5f) * s + 0.5f - margin, hi = ((float)(c[k] + 2u) / (float)kGrid - 0.5f) * s + 0.5f + margin;
+				mn[0][k] = fminf(mn[0][k], lo); mx[0][k] = fmaxf(mx[0][k], hi);
+				if (exact) { mn[1][k] = fminf(mn[1][k], lo); mx[1][k] = fmaxf(mx[1][k], hi); }
+			}
+		}
+	}
+	if (!__ballot(w != 0)) return;
+	for (int f = 0; f < 2; ++f)
+		for (int k = 0; k < 3; ++k) {
+			float a = mn[f][k], b = mx[f][k];
+			for (int o = 32; o; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); }
+			if ((threadIdx.x & 63) == 0) {
+				if (a < inf) atomicMin(&keys[f * 6 + k], float_key(a));
+				if (b > -inf) atomicMax(&keys[f * 6 + 3 + k], float_key(b));
+			}
+		}
+}
+__global__ void occ_accel_box_kernel(const uint32_t* __restrict__ keys, OccAccelOut* __restrict__ out) {
+	const uint32_t f = threadIdx.x;
+	if (f >= 2) return;
+	const float inf = __builtin_huge_valf();
+	OccAccelOut o;
+	const bool any = keys[f * 6] != 0xffffffffu; // the keys start at (0xffffffff, 0): untouched = nothing occupied
+	for (int k = 0; k < 3; ++k) {
+		o.mn[k] = any ? key_float(keys[f * 6 + k]) : inf;
+		o.mx[k] = any ? key_float(keys[f * 6 + 3 + k]) : -inf;
+		o.cell[k] = any ? (o.mx[k] - o.mn[k]) / (float)kCoarse : 1.f;
+		o.inv_cell[k] = any ? 1.0f / o.cell[k] : 1.f;
+	}
+	out[f] = o;
+}
+constexpr uint32_t kAccelMaskBlocks = 160, kAccelWordsPerThread = kCascades * (kGridVol / 64) / (kAccelMaskBlocks * 256);
+static_assert(kAccelMaskBlocks * 256 * kAccelWordsPerThread == kCascades * (kGridVol / 64), "the mask pass covers the bitfield exactly");
+// A workgroup owns a contiguous (Morton-compact) run of the bitfield, collects its bits in LDS and merges the non-zero words at the end.
+__global__ void __launch_bounds__(256) occ_accel_mask_kernel(const uint64_t* __restrict__ bitfield, const OccAccelOut* __restrict__ acc, uint32_t* __restrict__ masks) {
+	__shared__ uint32_t lmask[2 * kCoarseWords];
+	for (uint32_t j = threadIdx.x; j < 2 * kCoarseWords; j += 256) lmask[j] = 0u;
+	__syncthreads();
+	const OccAccelOut a0 = acc[0], a1 = acc[1];
+	for (uint32_t r = 0; r < kAccelWordsPerThread; ++r) {
+		const uint32_t i = (blockIdx.x * kAccelWordsPerThread + r) * 256 + threadIdx.x;
+		const uint64_t w = bitfield[i];
+		if (!w) continue;
+		const uint32_t level = i / (kGridVol / 64), byte0 = (i % (kGridVol / 64)) * 8;
+		const float s = ldexpf(1.0f, (int)level), margin = s / (float)kGrid / 16.f;
+		for (uint32_t j = 0; j < 8; ++j) {
+			if (!((w >> (8 * j)) & 0xffu)) continue;
+			const uint32_t m = (byte0 + j) * 8;
+			const uint32_t c[3] = {morton3D_invert(m), morton3D_invert(m >> 1), morton3D_invert(m >> 2)};
+			const bool exact = accel_block_relevant(level, c, s, margin);
+			for (int f = 0; f < (exact ? 2 : 1); ++f) {
+				const OccAccelOut& a = f ? a1 : a0;
+				int lo[3], hi[3];
+				for (int k = 0; k < 3; ++k) {
+					const float wmin = ((float)c[k] / (float)kGrid - 0.5f) * s + 0.5f - margin, wmax = ((float)(c[k] + 2u) / (float)kGrid - 0.5f) * s + 0.5f + margin;
+					lo[k] = min((int)kCoarse - 1, max(0, (int)floorf((wmin - a.mn[k]) * a.inv_cell[k])));
+					hi[k] = min((int)kCoarse - 1, max(0, (int)floorf((wmax - a.mn[k]) * a.inv_cell[k])));
+				}
+				uint32_t* mask = lmask + f * kCoarseWords;
+				static_assert(kCoarse == 32, "one mask word = one row of blocks along x");
+				const uint32_t row = (0xffffffffu >> (31 - hi[0])) & (0xffffffffu << lo[0]);
+				for (int z = lo[2]; z <= hi[2]; ++z)
+					for (int y = lo[1]; y <= hi[1]; ++y) {
+						const uint32_t word = (uint32_t)z * kCoarse + (uint32_t)y;
+						if ((mask[word] & row) != row) atomicOr(&mask[word], row);
+					}
+			}
+		}
+	}
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < 2 * kCoarseWords; j += 256)
+		if (lmask[j]) atomicOr(&masks[j], lmask[j]);
+}
+// d_masks: 2 x kCoarseWords words; d_out: 2 x 12 floats (OccAccelOut of slot 0 / slot 1); d_keys: 12 words of scratch
+int launch_occ_accel(const uint8_t* d_bitfield, uint32_t* d_masks, float* d_out, uint32_t* d_keys, void* stream) {
+	hipStream_t s = (hipStream_t)stream;
+	static const uint32_t init_keys[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+	hipError_t e = hipMemcpyAsync(d_keys, init_keys, sizeof(init_keys), hipMemcpyHostToDevice, s);
+	if (e == hipSuccess) e = hipMemsetAsync(d_masks, 0, 2 * kCoarseWords * 4, s);
+	if (e != hipSuccess) return hip_fail(e, "occ_accel: clear");
+	const uint32_t n_words = kCascades * (kGridVol / 64);
+	static_assert(kCascades * (kGridVol / 64) % 256 == 0, "one thread per bitfield word, no tail");
+	hipLaunchKernelGGL(occ_accel_bounds_kernel, dim3(n_words / 256), dim3(256), 0, s, (const uint64_t*)d_bitfield, d_keys);
+	hipLaunchKernelGGL(occ_accel_box_kernel, dim3(1), dim3(64), 0, s, d_keys, (OccAccelOut*)d_out);
+	hipLaunchKernelGGL(occ_accel_mask_kernel, dim3(kAccelMaskBlocks), dim3(256), 0, s, (const uint64_t*)d_bitfield, (const OccAccelOut*)d_out, d_masks);
+	NRS_LAUNCH_CHECK("occ_accel launch");
+	return NRS_OK;
+}
+
 // ---- deformed-space occupancy refresh (update_density_grid_nerf_operator, tn:3533-3640) ----------------------------------
 // One fused kernel replaces the reference's generate x2 -> map_positions per operator -> density() -> clear_empty_space ->
 // activate -> residual -> splat train and its four scratch arrays (positions, indices, mlp_out, empty mask): each lane draws
@@ -1218,10 +1341,31 @@ struct GridUpdateArgs {
 	int32_t n_edits;
 	uint32_t n_uniform, n_nonuniform, step, n_cascades;
 	uint64_t rng_state, rng_inc, rng_state_nonuniform;
+	uint32_t cell_order; // walk the cells in Morton order (see grid_refresh_kernel); 0 = sample order (NRS_REFRESH_ORDER=0, for A/B measurements)
 };
+
+// Sample order.  The reference draws sample i in cell (i * 56924617 + 96925573) mod 2^21 of a random cascade (common_nerf.cu:189-195): consecutive
+// samples land in cells scattered over the whole grid, so every gather of a wave is its own cache line.  The map i -> cell is a bijection of
+// [0, 2^21) (the multiplier is odd), and the sample count is a multiple of 2^21 (128^3 per cascade): so the wave walks the CELLS in Morton order --
+// 64 neighbouring cells = a 4 x 4 x 4 block of the grid, whose samples share the coarse levels' lines -- and recovers from each cell the sample
+// index i (and with it the sample's own random numbers) by inverting the map: i = Kinv * (cell - 96925573) mod 2^21 (+ k * 2^21 for the k-th block
+// of 2^21 samples).  Every sample is still evaluated exactly once with exactly its numbers; the max-splat is order-independent: bit-identical.
+// pcg32.advance(4 i) per lane, without a 64-step skip loop per lane: i(cell0 + l) = i(cell0) + l * Kinv - w * 2^21 (w = wraps of the sum past 2^21),
+// and LCG skips compose, so state = WrapSkip[w] o LaneSkip[l] o Skip(4 i(cell0) + 4 k 2^21): a wave-uniform skip on the scalar unit, a per-lane
+// skip whose coefficients are computed once, and a 65-entry table of "minus w * 2^23 steps" in LDS.
+constexpr uint32_t kSampleMul = 56924617u, kSampleAdd = 96925573u;
+__host__ __device__ constexpr uint32_t inverse_mod_2_32(uint32_t k) { // Newton: x <- x (2 - k x) doubles the number of correct low bits
+	uint32_t x = k;
+	for (int i = 0; i < 5; ++i) x *= 2u - k * x;
+	return x;
+}
+constexpr uint32_t kSampleMulInv = inverse_mod_2_32(kSampleMul) & (kGridVol - 1u);
+static_assert(((kSampleMul * kSampleMulInv) & (kGridVol - 1u)) == 1u, "inverse of the sample multiplier mod 2^21");
 
 __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, const GridUpdateArgs a) {
 	__shared__ NetSmem sm;
+	__shared__ uint64_t wrap_mult[65], wrap_plus[65];
+	if (threadIdx.x < 65) Pcg32::skip_coefficients(a.rng_inc, 0ull - ((uint64_t)threadIdx.x << 23), wrap_mult[threadIdx.x], wrap_plus[threadIdx.x]);
 	stage_model_to_lds(m, sm.ml);
 	const int lane = threadIdx.x & 63;
 	const int g = lane >> 5;
@@ -1229,8 +1373,10 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 	const GridView gv = make_grid_view(m);
 	const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-	uint64_t lane_mult, lane_plus;
+	uint64_t lane_mult, lane_plus, mlane_mult, mlane_plus;
 	Pcg32::skip_coefficients(a.rng_inc, (uint64_t)(4 * lane), lane_mult, lane_plus);
+	Pcg32::skip_coefficients(a.rng_inc, 4ull * (uint64_t)lane * (uint64_t)kSampleMulInv, mlane_mult, mlane_plus);
+	const bool morton = a.cell_order && (a.n_uniform & (kGridVol - 1u)) == 0u; // whole blocks of 2^21 samples: always so for update_density_grid_nerf_render
 	const uint32_t n = a.n_uniform + a.n_nonuniform;
 	const uint32_t n_tiles = (n + 63) / 64;
 	for (uint32_t tile = wave_global; tile < n_tiles; tile += n_waves) {
@@ -1240,14 +1386,23 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 		uint32_t cell = 0;
 		bool empty = false;
 		if (have) {
-			const bool uni = s < a.n_uniform;
-			const uint32_t i = uni ? s : s - a.n_uniform;
-			Pcg32 rng{uni ? a.rng_state : a.rng_state_nonuniform, a.rng_inc};
-			// rng.advance(4 * i): the 64-bit skip-ahead loop costs more than the density MLP when every lane runs it, so for
-			// a tile that lies in one draw it is split into a wave-uniform skip to the tile's first sample (scalar unit) and
-			// the per-lane skip by 4 * lane whose coefficients were computed once (LCG skips compose exactly mod 2^64).
 			const uint32_t t0 = tile * 64, t1 = t0 + 63;
-			if ((t0 < a.n_uniform) == (t1 < a.n_uniform)) {
+			const bool uni = s < a.n_uniform;
+			uint32_t i = uni ? s : s - a.n_uniform;
+			Pcg32 rng{uni ? a.rng_state : a.rng_state_nonuniform, a.rng_inc};
+			if (morton && t1 < a.n_uniform) {
+				// cells c0 .. c0 + 63 of block k; (i + step * n) * K + C = cell (mod 2^21) with step * n = 0 (mod 2^21)
+				const uint32_t k = t0 >> 21, c0 = t0 & (kGridVol - 1u);
+				const uint32_t i_first = ((c0 - kSampleAdd) * kSampleMulInv) & (kGridVol - 1u);
+				const uint32_t sum = i_first + (uint32_t)lane * kSampleMulInv; // < 65 * 2^21
+				const uint32_t w = sum >> 21;
+				i = (sum & (kGridVol - 1u)) + (k << 21);
+				uint64_t mt, pt;
+				Pcg32::skip_coefficients(a.rng_inc, 4ull * (uint64_t)i_first + ((uint64_t)k << 23), mt, pt);
+				const uint64_t st = mlane_mult * (mt * rng.state + pt) + mlane_plus;
+				rng.state = wrap_mult[w] * st + wrap_plus[w];
+			} else if ((t0 < a.n_uniform) == (t1 < a.n_uniform)) {
+				// rng.advance(4 * i) as a wave-uniform skip to the tile's first sample (scalar unit) and the per-lane skip by 4 * lane
 				const uint32_t i0 = (t0 < a.n_uniform) ? t0 : t0 - a.n_uniform;
 				uint64_t mt, pt;
 				Pcg32::skip_coefficients(a.rng_inc, (uint64_t)(i0 * 4u), mt, pt);
@@ -1308,6 +1463,8 @@ int launch_grid_update(const DeviceModel& m, const DeviceEdit* d_edits, int n_ed
 	a.rng_state = u.rng_state;
 	a.rng_inc = u.rng_inc;
 	a.rng_state_nonuniform = rng_state_nonuniform;
+	static const uint32_t cell_order = []() { const char* e = getenv("NRS_REFRESH_ORDER"); return e ? (uint32_t)atoi(e) : 1u; }();
+	a.cell_order = cell_order;
 	const uint32_t n = a.n_uniform + a.n_nonuniform;
 	if (n > 0) {
 		const uint32_t n_tiles = (n + 63) / 64;

@@ -143,6 +143,14 @@ class NerfNetwork:
         check(self.lib.nrs_model_get_density_bitfield(self.h, out.ctypes.data, out.size))
         return out
 
+    def get_march_accelerator(self, which):
+        """Test hook: (box12 = min, max, cell, 1/cell; mask bits [32, 32, 32] as bool, z-major) of the marching accelerator."""
+        box = np.zeros(12, np.float32)
+        mask = np.zeros(1024, np.uint32)
+        check(self.lib.nrs_model_get_march_accelerator(self.h, int(which), box.ctypes.data, mask.ctypes.data))
+        bits = np.unpackbits(mask.view(np.uint8), bitorder="little").reshape(32, 32, 32).astype(bool)
+        return box, bits
+
     def get_density_grid(self):
         out = np.zeros(_abi.GRID_VOLUME * _abi.GRID_CASCADES, np.float32)
         check(self.lib.nrs_model_get_density_grid(self.h, out.ctypes.data, out.size))
