@@ -1309,7 +1309,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		} else if (team > 1) {
 			a.team = team;
 			NRS_TRY(tile_geometry(*p, team, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x));
-		} else if (p->tile_size == 0 && !a.any_poisson && !a.any_affine && !(a.dbg & 4u) && (forced == -1 || (!forced && hybrid_on))) {
+		} else if (p->tile_size == 0 && !a.any_poisson && !a.any_affine && (forced == -1 || (!forced && hybrid_on))) {
 			// hybrid: every 3rd packet row leaves the 8x8 list and joins the end of the queue as 4x4 tail packets (packet_pixel_bulk/_tail);
 			// measured on 1080p lego + cage, every 2nd / 3rd / 4th / 6th / 8th / 16th row: 8.88 / 8.89 / 8.79 / 8.75 / 8.65 / 8.65 Gsamples/s
 			static const uint32_t tail_every = []() { const char* e = getenv("NRS_TAIL_EVERY"); return e && atoi(e) >= 2 ? (uint32_t)atoi(e) : 3u; }();

@@ -123,8 +123,14 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 // WAVES = waves per workgroup (they share one LDS copy of the weights); OCC = waves per SIMD the register allocator must
 // leave room for (__launch_bounds__' second argument).
 // PROF adds s_memtime stamps around the phases of a round (NRS_DEBUG & 4); the production instantiation has none.
+#ifdef NRS_MARKERS // ISA listing with phase boundaries (make isa-markers): comments only, for counting instructions per phase
+#define NRS_MARK(i) asm volatile("; NRS_MARK " #i)
+#else
+#define NRS_MARK(i)
+#endif
 #define NRS_PHASE(i)                                                         \
 	do {                                                                     \
+		NRS_MARK(i);                                                         \
 		if (PROF) {                                                          \
 			const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
 			ph_acc[ph_cur] += now_ - ph_last;                                \
@@ -632,7 +638,7 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 	}
 	if (a.any_poisson) return launch_render_cfg<8, 2, false, true, true>(m, a, n_cus, s);
 	if (a.any_affine) return launch_render_cfg<8, 4, false, false, true>(m, a, n_cus, s);
-	if (a.dbg & 4u) return launch_render_cfg<8, 4, true>(m, a, n_cus, s);
+	if (a.dbg & 4u) return a.team == 0 ? launch_render_cfg<8, 4, true, false, false, 0>(m, a, n_cus, s) : launch_render_cfg<8, 4, true>(m, a, n_cus, s);
 	if (a.team == 0) return cfg == 105 ? launch_render_cfg<10, 5, false, false, false, 0>(m, a, n_cus, s) : launch_render_cfg<8, 4, false, false, false, 0>(m, a, n_cus, s);
 	if (a.team == 2) return launch_render_cfg<8, 4, false, false, false, 2>(m, a, n_cus, s);
 	if (a.team == 4) return launch_render_cfg<8, 4, false, false, false, 4>(m, a, n_cus, s);
