@@ -56,6 +56,10 @@ struct RenderSmem {
 	uint32_t sum_alive, sum_hit, n_finished;
 };
 
+// (XCD-aware order -- one cursor per XCD over stripes of 8 / 16 / 32 / 64 pixel rows, workgroups of an XCD working on neighbouring packets so
+// that they share their L2, with stealing at the end -- was built and measured in round 2: 1080p lego 9.58 -> 9.67 / 9.47 / 9.24 / 8.68
+// Gsamples/s, aabb-16 4.36 -> 4.35 / 4.34 / 4.35 / 4.24: the L2 misses of this kernel come from the fine levels, whose lines no two
+// samples share wherever they run (profiles/r02_gather_probe.md), so there is nothing for a shared L2 to keep.  One queue it stays.)
 // The frame's work queue is one device-wide counter.  Device-scope atomics on one address serialise across the 8 XCDs at
 // ~18 ns each (an all-miss 1080p frame, 32 400 packets, took 0.57 ms for that reason alone), so the waves of a workgroup
 // share a chunk of kQueueChunk packets held in LDS and only the wave that finds the chunk used up goes to the global
@@ -128,8 +132,14 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 #else
 #define NRS_MARK(i)
 #endif
+#ifdef NRS_MARKERS // ISA listing with phase boundaries (tools/isa_phases.py): comments only, for counting instructions per phase
+#define NRS_MARK(i) asm volatile("; NRS_MARK " #i)
+#else
+#define NRS_MARK(i)
+#endif
 #define NRS_PHASE(i)                                                         \
 	do {                                                                     \
+		NRS_MARK(i);                                                         \
 		NRS_MARK(i);                                                         \
 		if (PROF) {                                                          \
 			const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
