@@ -1298,6 +1298,8 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		if (log_teams) fprintf(stderr, "[nrs team] pixels=%u hit_share=%.3f busy=%u rays/lane=%.3f team=%u\n", a.pixels_owned, hit_share, busy, rays_per_lane, team);
 		static const uint32_t tail_target = []() { const char* e = getenv("NRS_TAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)atoi(e) : 24u; }(); // 8 / 16 / 24 / 32 / 48: 8.92 / 8.91 / 9.11 / 9.01 / 8.47 Gsamples/s
 		a.tail_target = tail_target;
+		static const uint32_t reteam = []() { const char* e = getenv("NRS_RETEAM"); return e ? (uint32_t)atoi(e) : 1u; }();
+		a.reteam = reteam;
 		if (((team == 4 && !forced && hybrid_on) || forced == -2) && !a.any_poisson && !a.any_affine && !(a.dbg & 4u)) {
 			// few rays for the GPU: 4x4 packets only, and every generation takes ALL the rays its wave has pending with as many
 			// lanes per ray as fit (4 up to 16 rays, 2 up to 32), so that no wave is left with a second, nearly empty generation

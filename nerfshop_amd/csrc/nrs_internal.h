@@ -125,6 +125,7 @@ struct RenderArgs {
 	uint32_t pixels_owned;     // pixels this launch covers (for the feedback word)
 	unsigned long long* feedback; // host-mapped: rays that found an occupied cell | pixels_owned << 32, written by the last workgroup
 	uint32_t tail_every;       // hybrid launches: every tail_every-th packet row is a tail row (3)
+	uint32_t reteam;           // hybrid launches: spread a wave's last rays over its idle lanes (render_kernel)
 	uint32_t tail_target;      // hybrid launches: rays a wave collects per generation once it works on tail packets (24)
 	uint32_t all_tail;         // hybrid launches: every packet is a 4x4 tail packet (packet_pixel<4>'s geometry, whole-image or tiles)
 	uint32_t p_big;            // hybrid launches (team == 0): packets [0, p_big) are 8x8, the rest 4x4 tail packets; else 0

@@ -254,6 +254,44 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 		NRS_FRESH_ARGS(m1, a1);
 		const nrs_render_params& p1 = a1.p;
 		NRS_PHASE(0); // fill
+		// ---- the end of a wave's work (TEAM == 0): nothing left to claim, nothing pending, and at most half of the lanes still hold a ray --
+		// the survivors are the long rays, and each of them costs one latency-bound round per sample whatever the wave's occupancy.  Spread them
+		// over the idle lanes: 2 or 4 lanes per ray, as in a team generation (lane k of a team stands k samples ahead, all composite the team's
+		// samples in order: same bits).  The state of a ray moves with 15 shuffles, once.
+		if (TEAM == 0 && a1.reteam && !more && ring_count == 0u) {
+			const unsigned long long lead_mask = __ballot(have && tk == 0);
+			const uint32_t live = (uint32_t)__popcll(lead_mask);
+			const uint32_t new_t = live <= 16u ? 4u : (live <= 32u ? 2u : 1u);
+			if (live != 0u && new_t > gen_t) {
+				if (have && tk == 0) {
+					const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lead_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lead_mask, 0u));
+					ring[rank].x = (uint32_t)lane; // (the ring is empty: scratch)
+				}
+				__builtin_amdgcn_wave_barrier();
+				const uint32_t r = (uint32_t)lane / new_t;
+				const int src = r < live ? (int)ring[r].x : lane;
+				__builtin_amdgcn_wave_barrier();
+				o.x = __shfl(o.x, src, 64); o.y = __shfl(o.y, src, 64); o.z = __shfl(o.z, src, 64);
+				d.x = __shfl(d.x, src, 64); d.y = __shfl(d.y, src, 64); d.z = __shfl(d.z, src, 64);
+				t = __shfl(t, src, 64);
+				cr = __shfl(cr, src, 64); cg = __shfl(cg, src, 64); cb = __shfl(cb, src, 64); ca = __shfl(ca, src, 64);
+				ray_depth = __shfl(ray_depth, src, 64); max_weight = __shfl(max_weight, src, 64);
+				out_idx = (uint32_t)__shfl((int)out_idx, src, 64); n_steps = (uint32_t)__shfl((int)n_steps, src, 64);
+				have = r < live;
+				valid = true;
+				gen_t = new_t;
+				tk = lane & (int)(gen_t - 1u);
+				team_base = lane & ~(int)(gen_t - 1u);
+				if (have) {
+					const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+					for (int j = 0; j < tk && valid; ++j) {
+						t += calc_dt(t, p1.cone_angle_constant);
+						f3 npos; float ndt;
+						valid = march_to_occupied(p1, m1, sm.coarse, o, d, idir, t, npos, ndt, nullptr);
+					}
+				}
+			}
+		}
 		const unsigned long long free_mask = __ballot(!have);
 		const uint32_t nfree = (uint32_t)__popcll(free_mask);
 
