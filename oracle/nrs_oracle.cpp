@@ -6,20 +6,22 @@
  * `cpu_baseline` leg may load it -- as the checker, never as the thing measured or shipped.  Nothing
  * under nerfshop_amd/ imports, links or calls it.
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors, fixtures or snapshots for this path
- * (SURVEY.md F3, 8c), its hash-grid / fully-fused-MLP / SH arithmetic lives in tiny-cuda-nn, an EMPTY,
- * un-pinned submodule (fork gitlab.inria.fr/cjambon/tcnn-pyngp, branch pyngp-api, .gitmodules:16-19), and
- * the reference cannot be compiled here (needs nvcc, Eigen, tcnn, GLFW...).  What IS pinned: the mean-value-coordinate
- * routine -- the one piece of the reference that compiles from its own sources (editing/tools/mvc.h -> oracle/_ref/libref_mvc.so,
- * oracle/ref_mvc.cpp; mvc_compute below reproduces its weights bit for bit on tests/golden/ref_mvc_golden.npz) -- and the 3x3 SVD
- * behind the per-tet rotations (editing/tools/svd3.h -> oracle/_ref/libref_svd.so; tests/golden/ref_rotations_golden.npz) --, pcg32 against
- * the PCG library's published demo vector, the Sobol
- * direction numbers / scramble (tests/golden/sobol_golden.json is generated from the reference's own
- * table in include/neural-graphics-primitives/random_val.cuh by tests/golden/make_sobol_golden.py) and
- * hand-derived known-answer values for the in-tree formulas.  The tcnn parts restate upstream
- * NVlabs/tiny-cuda-nn semantics as published; where upstream rounding is ambiguous we
- * state ours: hash-grid trilinear sum in fp32 (fmaf per corner, corners 0..7) rounded to fp16; MLP dot
- * products of fp16 x fp16 accumulated exactly (double) then rounded fp32 -> ReLU -> fp16.
+ * PARITY: pinned to the reference's own compiled code everywhere except tiny-cuda-nn.  The reference ships no tests, golden vectors,
+ * fixtures or snapshots for this path and cannot be built as a whole (nvcc, Eigen and tcnn are absent), but its
+ * render-path headers, src/common_nerf.cu and the kernels of testbed_nerf.cu / cage_deformation.cu / tet_mesh.cu / affine_duplication.cu
+ * compile as host code against the stand-ins of oracle/ref_stubs/ (oracle/Makefile -> oracle/_ref/libref_render.so, oracle/ref_render.cpp,
+ * oracle/ref_extract.py).  tests/test_ref_pin.py holds this file to that library bit for bit: every header function on 1e5 seeded
+ * inputs, the operators, the LUT builder, rotations, MVC, the membrane interpolation, 10 whole frames and 5 whole sample streams; the
+ * same numbers travel as tests/golden/ref_pin_golden.npz.  To match, every dot product / small matrix product / camera transform here
+ * follows Eigen's reduction order (sum3: x0 + (x1 + x2); 9 terms: ((x0+x1)+(x2+x3)) + ((x4+x5)+(x6+(x7+x8)))) and mvc.h's float / double
+ * overload choices.
+ * PARITY UNPINNED for tiny-cuda-nn (hash grid, fully fused MLPs, SH encoding): an EMPTY, un-pinned submodule (fork
+ * gitlab.inria.fr/cjambon/tcnn-pyngp, branch pyngp-api, .gitmodules:16-19).  Its published algorithm is restated; its two
+ * ambiguous roundings are switchable (orc_model_set_numerics, mirrored by nrs_model_set_numerics): grid accumulation fp32 per corner
+ * (fmaf, corners 0..7) rounded to fp16 once | every corner's product rounded to fp16 and added in fp16; MLP products fp16 x fp16
+ * accumulated exactly (double) then rounded fp32 -> ReLU -> fp16 | the running sum rounded to fp16 after every 16-wide k step.
+ * Also checked: pcg32 against the PCG library's demo vector, the level table against instant-ngp's 12 196 240 lego parameters,
+ * hand-derived known answers (tests/test_oracle_kat.py).
  *
  * Floating point: built with -ffp-contract=off; fused multiply-adds appear only as explicit fmaf().
  * The HIP kernels are built the same way so that ray/sample indexing is bit-exact oracle <-> HIP.
@@ -1211,7 +1213,7 @@ bool mvc_one(V3 eta, const uint32_t* tris, uint32_t n_tris, const V3* cv, uint32
 // fp32 with its operation order: four cyclic Jacobi sweeps with approximate Givens rotations on A^T A (quaternion
 // accumulation), column sort with sign flips, QR by three Givens rotations.  Inexact by design: U V^T is up to 1.3e-2 away
 // from the exact polar factor on ordinary tets, which is why it is restated rather than replaced.  Pinned bit for bit by
-// tests/golden/ref_rotations_golden.npz (the reference header itself, oracle/ref_svd.cpp).  Matrices are row-major [r][c].
+// tests/golden/ref_rotations_golden.npz (the reference header itself, compiled into oracle/_ref/libref_render.so).  Matrices are row-major [r][c].
 struct Quat { float x, y, z, w; };
 inline float ref_rsqrt(float x) { return 1.0f / sqrtf(x); }            // rsqrt(float) of nvcc's host math
 inline float ref_rsqrt1(float x) {                                    // svd3.h:54-63

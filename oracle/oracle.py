@@ -1,7 +1,8 @@
 """ctypes wrapper of the CPU oracle (oracle/nrs_oracle.cpp).  TEST INFRASTRUCTURE ONLY.
 
 Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never from nerfshop_amd/.
-PARITY UNPINNED at the tiny-cuda-nn boundary (see the .cpp header).
+Pinned to the reference's compiled code (oracle/ref.py, tests/test_ref_pin.py) except at the tiny-cuda-nn boundary, where parity is
+UNPINNED and the two ambiguous roundings are switchable (Model.set_numerics; see the .cpp header).
 """
 import ctypes as C
 import os

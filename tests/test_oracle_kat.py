@@ -333,9 +333,9 @@ def test_occupancy_refresh_oracle_properties(built):
 
 
 def test_mvc_pinned_to_the_reference_code(built):
-    """The one piece of the reference that compiles from its own sources here: MVC3D::computeCoordinatesCustomCode
-    (include/neural-graphics-primitives/editing/tools/mvc.h), built as oracle/_ref/libref_mvc.so (oracle/ref_mvc.cpp) and run
-    on the test cage by tests/golden/make_ref_mvc_golden.py.  Oracle and product reproduce its weights (550 points incl. cage
+    """MVC3D::computeCoordinatesCustomCode (include/neural-graphics-primitives/editing/tools/mvc.h) compiled from the reference into
+    oracle/_ref/libref_render.so (point_t = Eigen::Vector3f against the Eigen stand-in) and run on the test cage by
+    tests/golden/make_ref_mvc_golden.py.  Oracle and product reproduce its weights (550 points incl. cage
     vertices, points on cage faces, points outside the cage) and its success labels."""
     import os
     from nerfshop_amd import synth
@@ -346,7 +346,7 @@ def test_mvc_pinned_to_the_reference_code(built):
         assert np.array_equal(labels, g["labels"]), name
         assert np.abs(w - g["weights"]).max() <= 1e-6, (name, np.abs(w - g["weights"]).max())
     assert sorted(np.bincount(g["labels"]).tolist()) == [3, 547]
-    ref_lib = os.path.join(root, "oracle", "_ref", "libref_mvc.so")
+    ref_lib = os.path.join(root, "oracle", "_ref", "libref_render.so")
     if os.path.exists(ref_lib):   # this container: the fixture is what the reference code produces today
         import importlib.util
         spec = importlib.util.spec_from_file_location("make_ref_mvc_golden", os.path.join(root, "tests", "golden", "make_ref_mvc_golden.py"))
@@ -357,8 +357,8 @@ def test_mvc_pinned_to_the_reference_code(built):
 
 
 def test_local_rotations_pinned_to_the_reference_code(built):
-    """TetMesh::update_local_rotations uses the approximate McAdams SVD of editing/tools/svd3.h; oracle/ref_svd.cpp compiles that
-    header in place and tests/golden/make_ref_rotations_golden.py records its R = U V^T for 2592 tets (a mild and a harsh
+    """TetMesh::update_local_rotations uses the approximate McAdams SVD of editing/tools/svd3.h; oracle/ref_render.cpp compiles that
+    header and the reference's loop in place and tests/golden/make_ref_rotations_golden.py records its R = U V^T for 2592 tets (a mild and a harsh
     deformation).  The oracle's restatement and the product's (host here, device in tests/test_gpu_cage_update.py) match bit for bit."""
     import os
     from nerfshop_amd import synth
@@ -377,7 +377,7 @@ def test_local_rotations_pinned_to_the_reference_code(built):
     exact = (U @ Vt).transpose(0, 2, 1).reshape(-1, 9)      # column-major like the fixture
     err = np.abs(exact - g["rotations"]).max(1)
     assert np.median(err) < 1e-5 and 1e-3 < err.max() < 5e-2
-    ref_lib = os.path.join(root, "oracle", "_ref", "libref_svd.so")
+    ref_lib = os.path.join(root, "oracle", "_ref", "libref_render.so")
     if os.path.exists(ref_lib):
         import importlib.util
         spec = importlib.util.spec_from_file_location("make_ref_rotations_golden", os.path.join(root, "tests", "golden", "make_ref_rotations_golden.py"))
