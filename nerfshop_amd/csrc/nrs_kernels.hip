@@ -193,7 +193,7 @@ __device__ __forceinline__ bool packet_pixel_tail(const RenderArgs& a, uint32_t 
 // discarded, as the reference discards the rest of a batch (tn:951-960).  The fill works on 64 / TEAM pixels per packet.
 // NUM: the non-default tiny-cuda-nn roundings (DeviceModel::numerics: bit 0 grid accumulation in network precision, bit 1 fp16 MLP accumulators)
 template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0>
-__global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceModel m_arg, const RenderArgs a_arg) {
+__device__ __forceinline__ void render_body(const DeviceModel& m_arg, const RenderArgs& a_arg) {
 	// The two argument structs (~1.3 KB of wave-uniform values) live in the kernel-argument segment and are read with scalar loads.
 	// Left alone, the compiler hoists every such load out of the frame loop and then spills ~150 scalar registers into VGPR lanes
 	// (v_writelane / v_readlane: VALU slots in the round loop, 3 VGPRs).  NRS_FRESH_ARGS re-derives the two references from an
@@ -654,6 +654,32 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 	}
 }
 
+template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0>
+__global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceModel m_arg, const RenderArgs a_arg) {
+	render_body<WAVES, OCC, PROF, POISSON, AFFINE, TEAM, NUM>(m_arg, a_arg);
+}
+// The same kernel scheduled for 3 waves per SIMD but held to the 128 VGPRs that still give 4 (512-thread workgroups, 2 per CU): the
+// scheduler hides more latency per wave when it does not aim at occupancy 4, and the cap keeps the occupancy it did not aim at.
+// (An attribute argument cannot depend on a template parameter, hence a second entry point rather than a template flag.)
+template <int WAVES, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0>
+__global__ __launch_bounds__(64 * WAVES, 3) __attribute__((amdgpu_num_vgpr(128))) void render_kernel_c128(const DeviceModel m_arg, const RenderArgs a_arg) {
+	render_body<WAVES, 3, PROF, POISSON, AFFINE, TEAM, NUM>(m_arg, a_arg);
+}
+template <int WAVES, bool PROF = false, bool POISSON = false, bool AFFINE = false, int TEAM = 1, int NUM = 0>
+static int launch_render_c128(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream) {
+	int blocks_per_cu = 0;
+	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel_c128<WAVES, PROF, POISSON, AFFINE, TEAM, NUM>, 64 * WAVES, 0);
+	if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(render_kernel_c128)");
+	if (blocks_per_cu < 1) blocks_per_cu = 1;
+	uint32_t grid = (uint32_t)(n_cus * blocks_per_cu);
+	const uint32_t max_useful = (a.n_packets + WAVES - 1) / WAVES; // at least one packet per wave
+	if (grid > max_useful) grid = max_useful;
+	if (grid == 0) return NRS_OK;
+	hipLaunchKernelGGL((render_kernel_c128<WAVES, PROF, POISSON, AFFINE, TEAM, NUM>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
+	NRS_LAUNCH_CHECK("render_kernel launch");
+	return NRS_OK;
+}
+
 template <int WAVES, int OCC, bool PROF = false, bool POISSON = false, bool AFFINE = false, int TEAM = 1, int NUM = 0>
 static int launch_render_cfg(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream) {
 	int blocks_per_cu = 0;
@@ -685,18 +711,25 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 		}
 	}
 	if (a.any_poisson) return launch_render_cfg<8, 2, false, true, true>(m, a, n_cus, s);
-	if (a.any_affine) return launch_render_cfg<8, 4, false, false, true>(m, a, n_cus, s);
 	if (a.dbg & 4u) return a.team == 0 ? launch_render_cfg<8, 4, true, false, false, 0>(m, a, n_cus, s) : launch_render_cfg<8, 4, true>(m, a, n_cus, s);
-	if (a.team == 0) return cfg == 105 ? launch_render_cfg<10, 5, false, false, false, 0>(m, a, n_cus, s) : launch_render_cfg<8, 4, false, false, false, 0>(m, a, n_cus, s);
-	if (a.team == 2) return launch_render_cfg<8, 4, false, false, false, 2>(m, a, n_cus, s);
-	if (a.team == 4) return launch_render_cfg<8, 4, false, false, false, 4>(m, a, n_cus, s);
-	// <8, 3>: __launch_bounds__(512, 3) lets the register allocator aim at 168 VGPRs; it settles at 128 (still 4 waves/SIMD,
-	// the LDS allows 2 workgroups per CU) with a schedule that measures 3-5 % faster than the <8, 4> one (122 VGPRs).
-	switch (cfg) {
-		case 42: return launch_render_cfg<4, 2>(m, a, n_cus, s);
-		case 83: return launch_render_cfg<8, 3>(m, a, n_cus, s);
-		default: return launch_render_cfg<8, 4>(m, a, n_cus, s);
+	// Production instantiations: scheduled for 3 waves/SIMD, capped at 128 VGPRs = 4 waves/SIMD (render_kernel_c128).  Measured against the
+	// __launch_bounds__(512, 4) build of the same code (NRS_RENDER_CFG=84): 1080p lego + cage 9.43 -> 9.82 Gsamples/s, lego 10.7 -> 11.0,
+	// varied-opacity scene 7.65 -> 7.89, aabb-16 4.35 -> 4.72.  (Plain __launch_bounds__(512, 3), round 1's choice, now lets the allocator
+	// take 131 VGPRs = 3 waves/SIMD: 7.3.)
+	if (cfg == 84) {
+		if (a.any_affine) return launch_render_cfg<8, 4, false, false, true>(m, a, n_cus, s);
+		if (a.team == 0) return launch_render_cfg<8, 4, false, false, false, 0>(m, a, n_cus, s);
+		if (a.team == 2) return launch_render_cfg<8, 4, false, false, false, 2>(m, a, n_cus, s);
+		if (a.team == 4) return launch_render_cfg<8, 4, false, false, false, 4>(m, a, n_cus, s);
+		return launch_render_cfg<8, 4>(m, a, n_cus, s);
 	}
+	if (cfg == 105 && a.team == 0) return launch_render_cfg<10, 5, false, false, false, 0>(m, a, n_cus, s); // the 5-waves/SIMD probe
+	if (cfg == 42 && a.team == 1 && !a.any_affine) return launch_render_cfg<4, 2>(m, a, n_cus, s);
+	if (a.any_affine) return launch_render_cfg<8, 4, false, false, true>(m, a, n_cus, s); // (its c128 build takes 133 VGPRs: the attribute is a target, not a limit)
+	if (a.team == 0) return launch_render_c128<8, false, false, false, 0>(m, a, n_cus, s);
+	if (a.team == 2) return launch_render_c128<8, false, false, false, 2>(m, a, n_cus, s);
+	if (a.team == 4) return launch_render_c128<8, false, false, false, 4>(m, a, n_cus, s);
+	return launch_render_c128<8>(m, a, n_cus, s);
 }
 
 // ---- trace_samples ------------------------------------------------------------------------------------------------
