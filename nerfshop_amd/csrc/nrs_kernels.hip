@@ -770,10 +770,12 @@ int launch_trace_samples(const DeviceModel& m, const nrs_render_params& p, uint3
 }
 
 // ---- NerfNetwork operator on caller batches ----------------------------------------------------------------------------
-struct NetSmem {
+template <int WAVES>
+struct NetSmemT {
 	ModelLds ml;
-	FeatLds fl[4];
+	FeatLds fl[WAVES];
 };
+typedef NetSmemT<4> NetSmem;
 
 // ---- selection rays ------------------------------------------------------------------------------------------------
 // GrowingSelection::project_selection_pixels (growing_selection.cu:1832-2035) in one launch: shoot_selection_rays_kernel
@@ -1029,10 +1031,14 @@ int launch_brick_fill(const DeviceModel& m, const LevelParams& lp, const uint32_
 }
 
 // MODE 0: inference_mixed_precision (16 channels, c3 = density raw), 1: density(), 2: hash-grid features [n x 32]
+// 768-thread workgroups: 12 waves share one LDS copy of the weights (24 KB) next to their 12 feature slabs (48 KB), two workgroups per CU
+// = 6 waves/SIMD at <= 80 VGPRs.  (256-thread workgroups, the first shape, put 3 workgroups = 3 waves/SIMD on a CU: the weights' copy
+// per workgroup was what filled the LDS.)
+constexpr int kNetWaves = 12;
 template <int MODE, int NUM = 0>
-__global__ __launch_bounds__(256) void network_kernel(const DeviceModel m, uint32_t n, const float* __restrict__ in, uint32_t ld_in,
+__global__ __launch_bounds__(64 * kNetWaves, 6) void network_kernel(const DeviceModel m, uint32_t n, const float* __restrict__ in, uint32_t ld_in,
                                                       _Float16* __restrict__ out, uint32_t ld_out, int layout) {
-	__shared__ NetSmem sm;
+	__shared__ NetSmemT<kNetWaves> sm;
 	stage_model_to_lds(m, sm.ml);
 	const int lane = threadIdx.x & 63;
 	const int g = lane >> 5, j = lane & 31;
@@ -1098,12 +1104,12 @@ int launch_network(const DeviceModel& m, int mode, uint32_t n, const float* d_in
                    int n_cus, void* stream) {
 	if (n == 0) return NRS_OK;
 	const uint32_t n_tiles = (n + 63) / 64;
-	uint32_t grid = (n_tiles + 3) / 4;
-	const uint32_t cap = (uint32_t)n_cus * 8;
+	uint32_t grid = (n_tiles + kNetWaves - 1) / kNetWaves;
+	const uint32_t cap = (uint32_t)n_cus * 2; // resident workgroups: the tiles are strided over them
 	if (grid > cap) grid = cap;
 	hipStream_t s = (hipStream_t)stream;
 	_Float16* out = (_Float16*)d_out;
-#define NRS_NET_LAUNCH(MODE, NUM) hipLaunchKernelGGL((network_kernel<MODE, NUM>), dim3(grid), dim3(256), 0, s, m, n, d_in, ld_in, out, ld_out, layout)
+#define NRS_NET_LAUNCH(MODE, NUM) hipLaunchKernelGGL((network_kernel<MODE, NUM>), dim3(grid), dim3(64 * kNetWaves), 0, s, m, n, d_in, ld_in, out, ld_out, layout)
 #define NRS_NET_MODE(MODE)                                      \
 	switch (m.numerics & 3u) {                                  \
 		case 0: NRS_NET_LAUNCH(MODE, 0); break;                 \
@@ -1200,8 +1206,8 @@ int launch_grid_eval(const DeviceModel& m, int mode, const uint32_t res[3], cons
 	const uint32_t n = res[0] * res[1] * res[2];
 	if (n == 0) return NRS_OK;
 	const uint32_t n_tiles = (n + 63) / 64;
-	uint32_t grid = (n_tiles + 3) / 4;
-	const uint32_t cap = (uint32_t)n_cus * 8;
+	uint32_t grid = (n_tiles + kNetWaves - 1) / kNetWaves;
+	const uint32_t cap = (uint32_t)n_cus * 2; // resident workgroups: the tiles are strided over them
 	if (grid > cap) grid = cap;
 	if (mode == 0) hipLaunchKernelGGL(grid_eval_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m, a);
 	else hipLaunchKernelGGL(grid_eval_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m, a);
