@@ -53,9 +53,27 @@ def _nrs_comm(device, rank, world):
         dist.broadcast(ident, src=0)
         raw = bytes(ident.cpu().tolist())
         h = C.c_void_p()
-        _abi.check(lib.nrs_comm_create(device.index or 0, rank, world, raw, C.byref(h)))
+        ok = 1
+        try:
+            _abi.check(lib.nrs_comm_create(device.index or 0, rank, world, raw, C.byref(h)))
+        except _abi.NrsError as e:
+            import sys
+            print(f"[nerfshop_amd.tiles] rank {rank}: nrs_comm_create failed ({e})", file=sys.stderr)
+            ok = 0
+        # every rank must take the same path: the C-ABI gather is used only if every rank has a communicator
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if ok:
+                lib.nrs_comm_destroy(h)
+            h = None
         _COMM[key] = h
+    if _COMM[key] is None:
+        raise _abi.NrsError("no RCCL communicator on some rank")
     return _COMM[key]
+
+
+_VERIFIED = {}  # (device index, world) -> True once the C-ABI gather has reproduced torch.distributed.gather on this process's first frame
 
 
 class TileSharder:
@@ -88,6 +106,42 @@ class TileSharder:
                 import sys
                 print(f"[nerfshop_amd.tiles] nrs_comm_create failed ({e}); falling back to torch.distributed.gather", file=sys.stderr)
 
+    def _c_gather(self, ctx, p, frame, depth):
+        lib = _abi.load()
+        s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        root = self.rank == 0
+        _abi.check(lib.nrs_gather_tiles(ctx.h, self.comm, 0, C.byref(p), self.padded, self.local.data_ptr(), self.all.data_ptr() if root else None,
+                                        frame.data_ptr() if root else None, depth.data_ptr() if root else None, s))
+
+    def _verify_c_gather(self, ctx, p):
+        """First frame of the process: the C-ABI gather must reproduce torch.distributed.gather + nrs_detile bit for bit on the root, and every
+        rank must get through it; otherwise all ranks fall back together (the verdict is agreed with one all_reduce)."""
+        ok = 1
+        if self.rank == 0:
+            f1 = torch.zeros((self.height, self.width, 4), dtype=torch.float32, device=self.device)
+            d1 = torch.zeros((self.height, self.width), dtype=torch.float32, device=self.device)
+            f2, d2 = torch.zeros_like(f1), torch.zeros_like(d1)
+        else:
+            f1 = d1 = f2 = d2 = None
+        try:
+            self._c_gather(ctx, p, f1, d1)
+            torch.cuda.current_stream(self.device).synchronize()
+        except _abi.NrsError as e:
+            import sys
+            print(f"[nerfshop_amd.tiles] rank {self.rank}: nrs_gather_tiles failed ({e})", file=sys.stderr)
+            ok = 0
+        comm, self.comm = self.comm, None  # every rank takes part in the torch.distributed gather, whatever happened above
+        try:
+            self.gather(ctx, p, f2, d2)
+        finally:
+            self.comm = comm
+        if self.rank == 0 and ok:
+            torch.cuda.current_stream(self.device).synchronize()
+            ok = int(torch.equal(f1, f2) and torch.equal(d1, d2))
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
     def fill(self, p):
         """Write the sharding fields of an nrs_render_params."""
         p.tile_size, p.tile_first, p.tile_stride = self.tile, self.rank, self.world
@@ -99,12 +153,13 @@ class TileSharder:
     def gather(self, ctx, p, frame, depth):
         """One gather to rank 0, then de-tile there.  `frame` [H, W, 4] / `depth` [H, W] are written on rank 0."""
         if self.comm is not None:
-            lib = _abi.load()
-            s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            root = self.rank == 0
-            _abi.check(lib.nrs_gather_tiles(ctx.h, self.comm, 0, C.byref(p), self.padded, self.local.data_ptr(), self.all.data_ptr() if root else None,
-                                            frame.data_ptr() if root else None, depth.data_ptr() if root else None, s))
-            return
+            key = (self.device.index or 0, self.world)
+            if key not in _VERIFIED:
+                _VERIFIED[key] = self._verify_c_gather(ctx, p)
+            if _VERIFIED[key]:
+                self._c_gather(ctx, p, frame, depth)
+                return
+            self.gather_impl = "torch.distributed (the C-ABI gather failed its first-frame check)"
         if self.world > 1:
             dist.gather(self.local, list(self.all.unbind(0)) if self.rank == 0 else None, dst=0)
         elif self.rank == 0:
