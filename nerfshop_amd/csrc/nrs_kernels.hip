@@ -1477,7 +1477,6 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 		const bool have = s < n;
 		f3 wpos = mk3(0, 0, 0);
 		uint32_t cell = 0;
-		bool empty = false;
 		if (have) {
 			const uint32_t t0 = tile * 64, t1 = t0 + 63;
 			const bool uni = s < a.n_uniform;
@@ -1505,7 +1504,7 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 			}
 			cell = generate_grid_sample(rng, i, uni ? a.n_uniform : a.n_nonuniform, a.step, m.aabb, a.grid, a.n_cascades, uni ? -0.01f : 0.01f, wpos);
 			f3 unused = mk3(0.5f, 0.5f, 0.5f);
-			for (int k = a.n_edits - 1; k >= 0; --k) empty |= edit_warp(a.edits[k], false, wpos, unused);
+			for (int k = a.n_edits - 1; k >= 0; --k) (void)edit_warp(a.edits[k], false, wpos, unused);
 		}
 		encode_to_lds(gv, m.levels, sm.ml, fl, lane, g, wpos, have);
 		_Float16 raw_b[2];
@@ -1520,7 +1519,8 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 		const float from_partner = xchg32((float)raw_b[1]);
 		_Float16 raw = g ? (_Float16)from_partner : raw_b[0];
 		if (!have) continue;
-		if (a.n_edits > 0 && empty) raw = (_Float16)(-10000.f);
+		// (clear_empty_space, which the reference launches here (tn:3606), has its body commented out (tn:2759-2770): the operators' empty mask changes
+		// nothing in the refresh -- a sample that falls into vacated space keeps the density of the place it stands on.  Pinned: tests/test_ref_pin.py.)
 		_Float16 act = (_Float16)network_to_density((float)raw, m.density_activation);
 		for (int k = a.n_edits - 1; k >= 0; --k) {
 			const DeviceEdit& e = a.edits[k];

@@ -1941,7 +1941,8 @@ void orc_update_density_grid(void* model, void* const* edits, int n_edits, float
 		hashgrid_encode_one(m, p, feat);
 		density_mlp_one(m, feat, o);
 		uint16_t raw = o[0];
-		if (n_edits > 0 && empty) raw = f2h(-10000.f);                              // clear_empty_space, tn:2759
+		(void)empty; // clear_empty_space (tn:2759-2770) is launched here (tn:3606) but its body is commented out in the reference: the mask changes nothing,
+		             // a sample whose position falls into vacated space keeps the density of the place it stands on
 		uint16_t act = f2h(network_to_density(h2f(raw), m.desc.density_activation)); // activate_network_density, tn:3522
 		for (int k = n_edits - 1; k >= 0; --k) {
 			const Edit& e = *(const Edit*)edits[k];

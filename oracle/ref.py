@@ -65,6 +65,20 @@ def render_frame(desc, params, bitfield, meshes, oracle_model, frame=None, want_
     return frame, depth, steps, stats
 
 
+def update_density_grid(desc, meshes, grid, update, oracle_model):
+    """Testbed::update_density_grid_nerf_operator with the reference's kernels (density network = the oracle's); grid [5*128^3] is updated in
+    place, `update` (nrs_grid_update) advances as the reference advances m_rng / density_grid_ema_step."""
+    lib = load()
+    from . import oracle as orc
+    olib = orc.load()
+    g = grid
+    assert g.dtype == np.float32 and g.flags.c_contiguous and g.size == 5 * 128 ** 3
+    arr = (C.c_void_p * max(len(meshes), 1))(*[C.cast(C.pointer(m), C.c_void_p) for m in meshes])
+    net = C.cast(olib.orc_network_density, C.c_void_p)
+    lib.ref_update_density_grid(C.byref(desc), arr, C.c_int(len(meshes)), C.byref(update), _p(g), net, C.c_void_p(oracle_model.h))
+    return g
+
+
 def trace_coords(desc, params, bitfield, pixel_idx, max_samples, which="ref"):
     fn = _fn(which, "trace_coords")
     px = _u32(pixel_idx)

@@ -36,6 +36,8 @@ FRAGMENTS = [
     ("src/testbed_nerf.cu", "compact_kernel_nerf", r"^__global__ void compact_kernel_nerf\(", "fn"),
     ("src/testbed_nerf.cu", "init_rays_with_payload_kernel_nerf", r"^__global__ void init_rays_with_payload_kernel_nerf\(", "fn"),
     ("src/testbed_nerf.cu", "activate_network_density", r"^__global__ void activate_network_density\(", "fn"),
+    # (the "template <typename T>" line above it is supplied by the including file)
+    ("src/testbed_nerf.cu", "clear_empty_space", r"^__global__ void clear_empty_space\(", "fn"),
     ("src/editing/cage_deformation.cu", "interpolate_tet_pos", r"^__global__ void interpolate_tet_pos\(", "fn"),
     ("src/editing/cage_deformation.cu", "interpolate_tet", r"^__global__ void interpolate_tet\(", "fn"),
     ("src/editing/cage_deformation.cu", "compute_poisson_residual_density_kernel", r"^__global__ void compute_poisson_residual_density_kernel\(", "fn"),

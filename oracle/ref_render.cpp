@@ -29,6 +29,7 @@ thread_local dim3 blockDim, gridDim;
 
 #include <src/common_nerf.cu> // -I/root/reference
 
+#include <memory>
 #include <tuple>
 
 // svd3.h calls rsqrt(), which nvcc's host math headers provide (1 / sqrt in host code); g++ has no such function
@@ -56,6 +57,8 @@ NGP_NAMESPACE_BEGIN
 #include "compact_kernel_nerf.inc"
 #include "init_rays_with_payload_kernel_nerf.inc"
 #include "activate_network_density.inc"
+template <typename T>
+#include "clear_empty_space.inc"
 #include "interpolate_tet_pos.inc"
 #include "interpolate_tet.inc"
 #include "compute_poisson_residual_density_kernel.inc"
@@ -488,6 +491,56 @@ void ref_poisson_interpolate(const float* gamma /*[V_tet x V_cage]*/, uint32_t n
 	memcpy(boundary_shs27_out, (const void*)boundary_shs_host.data(), 108 * (size_t)n_tet_vertices);
 	memcpy(outside_density_out, boundary_outside_density_host.data(), 4 * (size_t)n_tet_vertices);
 	memcpy(residual_density_out, boundary_residual_density_host.data(), 4 * (size_t)n_tet_vertices);
+}
+
+// ---- Testbed::update_density_grid_nerf_operator, testbed_nerf.cu:3533-3640: the host sequence restated around the reference's kernels ----------
+// (generate_grid_samples_nerf_nonuniform x 2, map_positions per operator, density() = the callback, clear_empty_space -- whose body is commented
+// out in the reference --, activate_network_density, compute_poisson_residual_density per operator, the max-splat and the decayed maximum).
+// Deviation kept out of the pin, as in the oracle: clear_empty_space / compute_poisson_residual_density are launched over the n_samples samples
+// that exist, not over n_elements = 5 * 128^3 threads (:3606, :3622 read past the arrays when max_cascade < 4).
+typedef void (*ref_density_fn)(void* user, uint32_t n, const float* in, uint32_t ld_in, uint16_t* out, uint32_t ld_out, int layout);
+void ref_update_density_grid(const nrs_model_desc* desc, const nrs_tet_mesh* const* meshes, int n_edits, nrs_grid_update* u, float* density_grid /*[5*128^3] in/out*/,
+                             ref_density_fn density, void* user) {
+	const uint32_t n_elements = NERF_GRIDSIZE() * NERF_GRIDSIZE() * NERF_GRIDSIZE() * NERF_CASCADES();
+	const uint32_t n_uniform = u->n_uniform_samples, n_nonuniform = u->n_nonuniform_samples, n_samples = n_uniform + n_nonuniform;
+	const uint32_t padded_output_width = 16; // NerfNetwork::padded_density_output_width()
+	std::vector<RefEdit> edits;
+	for (int i = 0; i < n_edits; ++i) edits.push_back(make_edit(desc, meshes[i]));
+	const BoundingBox aabb = box(desc->aabb_min, desc->aabb_max);
+	std::vector<NerfPosition> positions(n_samples, NerfPosition(Vector3f::Zero(), 0.f));
+	std::vector<uint32_t> indices(n_samples);
+	std::vector<float> density_grid_tmp(n_elements, 0.f);
+	std::vector<network_precision_t> mlp_out((size_t)n_samples * padded_output_width);
+	if (u->reset_grid) memset(density_grid, 0, sizeof(float) * n_elements);
+	default_rng_t rng;
+	rng.state = u->rng_state; rng.inc = u->rng_inc;
+	launch_linear(true, n_uniform, generate_grid_samples_nerf_nonuniform, rng, (uint32_t)u->ema_step, aabb, (const float*)density_grid, positions.data(), indices.data(),
+	              u->max_cascade + 1u, -0.01f);
+	rng.advance();
+	launch_linear(true, n_nonuniform, generate_grid_samples_nerf_nonuniform, rng, (uint32_t)u->ema_step, aabb, (const float*)density_grid, positions.data() + n_uniform,
+	              indices.data() + n_uniform, u->max_cascade + 1u, NERF_MIN_OPTICAL_THICKNESS());
+	rng.advance();
+	std::unique_ptr<bool[]> empty_mask;
+	if (n_edits > 0) {
+		empty_mask.reset(new bool[n_elements]());
+		for (int i = n_edits - 1; i >= 0; --i) edit_map_positions(edits[i], PitchedPtr<NerfPosition>(positions.data(), 1, 0, 0), empty_mask.get(), n_samples);
+	}
+	// m_nerf_network->density(stream, positions 3 x n, density_matrix (row-major padded_output_width x n), false)
+	density(user, n_samples, (const float*)positions.data(), (uint32_t)(sizeof(NerfPosition) / sizeof(float)), (uint16_t*)mlp_out.data(), n_samples, NRS_PLANES);
+	if (n_edits > 0) launch_linear(true, n_samples, clear_empty_space<network_precision_t>, (const bool*)empty_mask.get(), mlp_out.data());
+	launch_linear(true, n_samples, activate_network_density, mlp_out.data(), (ENerfActivation)desc->density_activation);
+	for (int i = n_edits - 1; i >= 0; --i) { // CageDeformation::compute_poisson_residual_density, cage_deformation.cu:647-672
+		const nrs_tet_mesh& m = *edits[i].mesh;
+		if (!m.apply_poisson || m.n_tets == 0) continue;
+		launch_linear(true, n_samples, compute_poisson_residual_density_kernel, PitchedPtr<NerfPosition>(positions.data(), 1, 0, 0), mlp_out.data(), edits[i].scene_aabb,
+		              Vector3f(Vector3f::Zero()), Vector3f(Vector3f::Zero()), edits[i].bbox, m.h_lut_idx, m.h_lut_offsets, m.h_tets, (const Vector3f*)m.h_vertices,
+		              m.h_boundary_residual_density);
+	}
+	launch_linear(false, n_samples, splat_grid_samples_nerf_max_nearest_neighbor_already_activated, (const uint32_t*)indices.data(), (const network_precision_t*)mlp_out.data(),
+	              density_grid_tmp.data());
+	launch_linear(true, n_elements, ema_grid_samples_nerf, u->decay, (uint32_t)u->ema_step, density_grid, (const float*)density_grid_tmp.data());
+	u->ema_step += 1;
+	u->rng_state = rng.state;
 }
 
 // ---- update_density_grid_mean_and_bitfield, testbed_nerf.cu:3642-3657: grid_to_bitfield + bitfield_max_pool (the mean is the caller's) ------

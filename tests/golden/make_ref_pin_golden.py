@@ -34,6 +34,7 @@ def main():
     store_hashed("op", cases.operator_cases(scenes, "ref"))
     store_hashed("authoring", cases.authoring_cases(scenes, "ref"))
     store_hashed("bitfield", {"grids": cases.bitfield_case(scenes, "ref")})
+    store_hashed("refresh", cases.refresh_cases(scenes, "ref"))
     for case in cases.FRAME_CASES:
         f, d, s, st = cases.render_case(scenes, case, "ref")
         out[f"frame/{case[0]}/frame"], out[f"frame/{case[0]}/depth"], out[f"frame/{case[0]}/steps"], out[f"frame/{case[0]}/stats"] = f, d, s.astype(np.uint16), st

@@ -134,7 +134,10 @@ class Scenes:
     def get(self, key):
         if key not in self._s:
             from conftest import Scene
-            self._s[key] = Scene(aabb_scale=1, with_edit=True, lattice_n=6) if key == "lego" else Scene(aabb_scale=16, with_edit=True, lattice_n=5)
+            if key == "lego_shaped":  # geometry in the network: the occupancy refresh has something to find
+                self._s[key] = Scene(aabb_scale=1, with_edit=True, lattice_n=6, shaped=True)
+            else:
+                self._s[key] = Scene(aabb_scale=1, with_edit=True, lattice_n=6) if key == "lego" else Scene(aabb_scale=16, with_edit=True, lattice_n=5)
         return self._s[key]
 
 
@@ -363,3 +366,52 @@ def bitfield_case(scenes, which):
         else:
             outs.append(orc.density_grid_to_bitfield(grid))
     return outs
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# deformed-space occupancy refresh: Testbed::update_density_grid_nerf_operator (testbed_nerf.cu:3533-3640)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _grid_update(max_cascade, seed=1337):
+    import ctypes as C
+    from nerfshop_amd import _abi
+    from oracle import oracle as orc
+    u = _abi.GridUpdate()
+    u.n_uniform_samples = _abi.GRID_VOLUME * (max_cascade + 1)
+    u.n_nonuniform_samples = 0
+    u.reset_grid, u.max_cascade, u.decay, u.ema_step = 0, max_cascade, 0.95, 0
+    st, inc = C.c_uint64(), C.c_uint64()
+    orc.load().orc_pcg32_seed(C.c_uint64(seed), C.byref(st), C.byref(inc))  # m_rng = default_rng_t{m_seed}, testbed.cu:2220
+    u.rng_state, u.rng_inc = st.value, inc.value
+    return u
+
+
+def refresh_cases(scenes, which):
+    """-> {name: [grid after each iteration ..., (rng state, ema step)]}: the lego-like scene (geometry in the network) under a cage edit with
+    membrane terms, 2 iterations as update_density_grid_nerf_render runs them (all cells with reset, then a mixed uniform / non-uniform
+    draw), and one iteration over the 5 cascades of the aabb-16 scene.  The density network is the oracle's in both runs (tiny-cuda-nn)."""
+    from nerfshop_amd import _abi
+    from oracle import oracle as orc
+    from oracle import ref
+    out = {}
+    for name, key, max_cascade, iters in (("lego_membrane", "lego_shaped", 0, 2), ("aabb16", "aabb16", 4, 1)):
+        sc = scenes.get(key)
+        e = sc.edit.with_membrane(residual_amplitude=1.0) if name == "lego_membrane" else sc.edit
+        mesh = e.tet_mesh_struct()
+        grid = np.zeros(5 * 128 ** 3, np.float32)
+        u = _grid_update(max_cascade)
+        oe = orc.Edit(sc.desc, mesh, keepalive=e) if which == "orc" else None
+        res = []
+        for it in range(iters):
+            u.reset_grid = 1 if it == 0 else 0
+            if it == 1 or name == "aabb16":  # outside the first 256 training steps the reference mixes the two draws (testbed_nerf.cu:3508-3511)
+                u.n_uniform_samples = _abi.GRID_VOLUME * (max_cascade + 1) // 4
+                u.n_nonuniform_samples = _abi.GRID_VOLUME * (max_cascade + 1) // 4
+            if which == "ref":
+                ref.update_density_grid(sc.desc, [mesh], grid, u, sc.oracle_model)
+            else:
+                sc.oracle_model.update_density_grid(grid, u, [oe])
+            res.append(grid.copy())
+        res.append(np.array([u.rng_state, u.ema_step], np.uint64))
+        out[name] = res
+        sc.oracle_model.set_bitfield(sc.bitfield)  # (the oracle's refresh installs its bitfield in the model)
+    return out

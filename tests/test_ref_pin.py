@@ -100,6 +100,19 @@ def test_authoring_live(scenes):
     _check_live({"grids": cases.bitfield_case(scenes, "ref")}, {"grids": cases.bitfield_case(scenes, "orc")})
 
 
+# ---- deformed-space occupancy refresh: the reference's sample generator, map_positions, residual, splat and decayed-maximum kernels --------
+def test_refresh_golden(scenes, golden):
+    got = cases.refresh_cases(scenes, "orc")
+    _check_hashed(golden, "refresh", got)
+    g = got["lego_membrane"]
+    assert (g[0][:128 ** 3] > 0.01).sum() > 20000 and not g[0][128 ** 3:].any()  # the shape was found in cascade 0; the other cascades stay untouched
+
+
+@live
+def test_refresh_live(scenes):
+    _check_live(cases.refresh_cases(scenes, "ref"), cases.refresh_cases(scenes, "orc"))
+
+
 # ---- whole frames: init_rays -> advance_pos -> [compact -> generate inputs -> residuals -> map_rays -> network -> composite]* -> shade ----
 @pytest.mark.parametrize("case", cases.FRAME_CASES, ids=[c[0] for c in cases.FRAME_CASES])
 def test_frame_golden(scenes, golden, case):
