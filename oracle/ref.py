@@ -79,6 +79,70 @@ def update_density_grid(desc, meshes, grid, update, oracle_model):
     return g
 
 
+def density_on_grid(desc, res3d, box_min, box_max, oracle_model, density_grid=None):
+    """Testbed::get_density_on_grid with the reference's generator and conversion kernels (density network = the oracle's)."""
+    lib = load()
+    from . import oracle as orc
+    olib = orc.load()
+    res = (C.c_uint32 * 3)(*res3d)
+    mn, mx = (C.c_float * 3)(*box_min), (C.c_float * 3)(*box_max)
+    out = np.zeros(int(res3d[0]) * int(res3d[1]) * int(res3d[2]), np.float32)
+    g = np.ascontiguousarray(density_grid, np.float32) if density_grid is not None else None
+    lib.ref_density_on_grid(C.byref(desc), res, mn, mx, _p(g), C.cast(olib.orc_network_density, C.c_void_p), C.c_void_p(oracle_model.h), _p(out))
+    return out
+
+
+def rgba_on_grid(desc, res3d, box_min, box_max, ray_dir, oracle_model):
+    """Testbed::get_rgba_on_grid with the reference's generator and compute_nerf_density (network = the oracle's)."""
+    lib = load()
+    from . import oracle as orc
+    olib = orc.load()
+    res = (C.c_uint32 * 3)(*res3d)
+    mn, mx, rd = (C.c_float * 3)(*box_min), (C.c_float * 3)(*box_max), (C.c_float * 3)(*ray_dir)
+    out = np.zeros((int(res3d[0]) * int(res3d[1]) * int(res3d[2]), 4), np.float32)
+    lib.ref_rgba_on_grid(C.byref(desc), res, mn, mx, rd, C.cast(olib.orc_network_inference, C.c_void_p), C.c_void_p(oracle_model.h), _p(out))
+    return out
+
+
+def poisson_boundary(desc, vertices, sh_width, hemisphere_width, seed, is_inside, bitfield, oracle_model):
+    """GrowingSelection::compute_poisson_boundary with the reference's loops and kernels (network = the oracle's) after srand(seed)
+    -> (density [n], sh [n, 27], jitter [n * sh_width^2, 2] = the std::rand draws the reference consumed)."""
+    lib = load()
+    from . import oracle as orc
+    olib = orc.load()
+    v = _f32(vertices)
+    n = v.shape[0]
+    dens, sh = np.zeros(n, np.float32), np.zeros((n, 27), np.float32)
+    jitter = np.zeros((n * sh_width * sh_width, 2), np.float32)
+    bf = np.ascontiguousarray(bitfield, np.uint8)
+    lib.ref_poisson_boundary(C.byref(desc), _p(v), C.c_uint32(n), C.c_uint32(sh_width), C.c_uint32(hemisphere_width), C.c_uint(seed), C.c_int(1 if is_inside else 0), _p(bf),
+                             C.cast(olib.orc_network_inference, C.c_void_p), C.c_void_p(oracle_model.h), _p(dens), _p(sh), _p(jitter))
+    return dens, sh, jitter
+
+
+def upper_cell_idx(cell_idx, target_level):
+    lib = load()
+    c, t = _u32(cell_idx), _u32(target_level)
+    out = np.zeros(c.size, np.uint32)
+    lib.ref_upper_cell_idx(C.c_uint32(c.size), _p(c), _p(t), _p(out))
+    return out
+
+
+def project_selection_pixels(desc, params, bitfield, pixels_xy, oracle_model, threshold=0.1):
+    """GrowingSelection::project_selection_pixels up to the host bookkeeping, with the reference's kernels (density network = the oracle's):
+    per pixel the projected position, its grid cell and whether the transmittance threshold was reached."""
+    lib = load()
+    from . import oracle as orc
+    olib = orc.load()
+    px = np.ascontiguousarray(pixels_xy, np.int32).reshape(-1, 2)
+    n = px.shape[0]
+    pos, cells, found = np.zeros((n, 3), np.float32), np.zeros(n, np.uint32), np.zeros(n, np.uint8)
+    bf = np.ascontiguousarray(bitfield, np.uint8)
+    net = C.cast(olib.orc_network_density, C.c_void_p)
+    lib.ref_project_selection_pixels(C.byref(desc), C.byref(params), _p(bf), _p(px), C.c_uint32(n), C.c_float(threshold), net, C.c_void_p(oracle_model.h), _p(pos), _p(cells), _p(found))
+    return pos, cells, found
+
+
 def trace_coords(desc, params, bitfield, pixel_idx, max_samples, which="ref"):
     fn = _fn(which, "trace_coords")
     px = _u32(pixel_idx)

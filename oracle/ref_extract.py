@@ -36,6 +36,10 @@ FRAGMENTS = [
     ("src/testbed_nerf.cu", "compact_kernel_nerf", r"^__global__ void compact_kernel_nerf\(", "fn"),
     ("src/testbed_nerf.cu", "init_rays_with_payload_kernel_nerf", r"^__global__ void init_rays_with_payload_kernel_nerf\(", "fn"),
     ("src/testbed_nerf.cu", "activate_network_density", r"^__global__ void activate_network_density\(", "fn"),
+    ("src/testbed_nerf.cu", "generate_grid_samples_nerf_uniform", r"^__global__ void generate_grid_samples_nerf_uniform\(", "fn"),
+    ("src/testbed_nerf.cu", "generate_grid_samples_nerf_uniform_dir", r"^__global__ void generate_grid_samples_nerf_uniform_dir\(", "fn"),
+    ("src/testbed_nerf.cu", "grid_samples_half_to_float", r"^__global__ void grid_samples_half_to_float\(", "fn"),
+    ("src/testbed_nerf.cu", "compute_nerf_density", r"^__global__ void compute_nerf_density\(", "fn"),
     # (the "template <typename T>" line above it is supplied by the including file)
     ("src/testbed_nerf.cu", "clear_empty_space", r"^__global__ void clear_empty_space\(", "fn"),
     ("src/editing/cage_deformation.cu", "interpolate_tet_pos", r"^__global__ void interpolate_tet_pos\(", "fn"),
@@ -53,6 +57,12 @@ FRAGMENTS = [
     ("src/editing/tools/selection_utils.cu", "get_cell_at_pos", r"^Eigen::Vector3i get_cell_at_pos\(", "fn"),
     ("src/editing/tools/growing_selection.cu", "shoot_selection_rays_kernel", r"^__global__ void shoot_selection_rays_kernel\(", "fn"),
     ("src/editing/tools/growing_selection.cu", "composite_shot_rays", r"^__global__ void composite_shot_rays\(", "fn"),
+    ("src/editing/tools/growing_selection.cu", "activate_network_output", r"^__global__ void activate_network_output\(", "fn"),
+    ("src/editing/tools/growing_selection.cu", "filter_empty", r"^__global__ void filter_empty\(", "fn"),
+    # GrowingSelection::compute_poisson_boundary: the direction sampling loop (std::rand jitter), the density pick and the SH9 fit loop
+    ("src/editing/tools/growing_selection.cu", "poisson_boundary_sampling_loop", r"^\tfor \(uint32_t k = 0; k < n_verts; k\+\+\) \{", "block:compute_poisson_boundary:0"),
+    ("src/editing/tools/growing_selection.cu", "poisson_boundary_density_loop", r"^\tfor \(int k = 0; k < n_verts; k\+\+\) \{", "block:compute_poisson_boundary:0"),
+    ("src/editing/tools/growing_selection.cu", "poisson_boundary_fit_loop", r"^\tfor \(int k = 0; k < n_verts; k\+\+\) \{", "block:compute_poisson_boundary:1"),
     ("src/editing/tools/growing_selection.cu", "activate_network_output", r"^__global__ void activate_network_output\(", "fn"),
     ("src/editing/tools/growing_selection.cu", "filter_empty", r"^__global__ void filter_empty\(", "fn"),
     # GrowingSelection::interpolate_poisson_boundary: the per-tet-vertex loop (MVC-weighted transfer of the cage's membrane terms)

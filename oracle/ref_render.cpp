@@ -28,6 +28,7 @@ thread_local dim3 blockDim, gridDim;
 #include <neural-graphics-primitives/editing/tools/selection_utils.h>
 
 #include <src/common_nerf.cu> // -I/root/reference
+#include <src/editing/tools/sh_utils.cu> // project_sh9
 
 #include <memory>
 #include <tuple>
@@ -57,6 +58,10 @@ NGP_NAMESPACE_BEGIN
 #include "compact_kernel_nerf.inc"
 #include "init_rays_with_payload_kernel_nerf.inc"
 #include "activate_network_density.inc"
+#include "generate_grid_samples_nerf_uniform.inc"
+#include "generate_grid_samples_nerf_uniform_dir.inc"
+#include "grid_samples_half_to_float.inc"
+#include "compute_nerf_density.inc"
 template <typename T>
 #include "clear_empty_space.inc"
 #include "interpolate_tet_pos.inc"
@@ -65,6 +70,11 @@ template <typename T>
 #include "compute_residual_poisson_kernel.inc"
 #include "get_cell_pos.inc"
 #include "get_cell_at_pos.inc"
+#include "get_upper_cell_idx.inc"
+#include "shoot_selection_rays_kernel.inc"
+#include "composite_shot_rays.inc"
+#include "activate_network_output.inc"
+#include "filter_empty.inc"
 #include "corner_offsets.inc"
 #include "affine_bounding_box_struct.inc"
 }; // closes struct AffineBoundingBox: the fragment stops before its nlohmann::json members (affine_bounding_box.cuh:105-143), which are not compiled
@@ -89,6 +99,17 @@ template <typename K, typename... Args> void launch_linear(bool parallel, uint32
 	}
 }
 
+template <typename K, typename... Args> void launch_3d(const Vector3i& res, K kernel, const Args&... args) {
+	blockDim.x = blockDim.y = blockDim.z = 1;
+	threadIdx.x = threadIdx.y = threadIdx.z = 0;
+	for (int z = 0; z < res.z(); ++z)
+		for (int y = 0; y < res.y(); ++y)
+			for (int x = 0; x < res.x(); ++x) {
+				blockIdx.x = (uint32_t)x; blockIdx.y = (uint32_t)y; blockIdx.z = (uint32_t)z;
+				kernel(args...);
+			}
+	blockIdx.y = blockIdx.z = 0;
+}
 inline Vector3f v3(const float* p) { return Vector3f(p[0], p[1], p[2]); }
 inline Matrix<float, 3, 4> m34(const float* p) { Matrix<float, 3, 4> m; memcpy(m.data(), p, 48); return m; }
 inline BoundingBox box(const float* mn, const float* mx) { return BoundingBox(v3(mn), v3(mx)); }
@@ -543,6 +564,114 @@ void ref_update_density_grid(const nrs_model_desc* desc, const nrs_tet_mesh* con
 	u->rng_state = rng.state;
 }
 
+// ---- GrowingSelection::project_selection_pixels, growing_selection.cu:1832-1960: shoot_selection_rays_kernel -> density() -> composite_shot_rays ----
+// Per-pixel outputs in the caller's order (the reference compacts the rays with atomics; ray_indices maps back).  The kernels run one thread after
+// the other here, so the atomics hand out the slots in pixel order.  A ray that never reaches the transmittance threshold gets the reference's
+// sentinel (aabb.min - 1, :1826); the slots of rays without samples and of rays that reach the threshold only behind their last sample are never
+// written by the reference (uninitialised workspace): they start from the same sentinel here.  The bookkeeping that follows (:1962-2020) is host code
+// on these arrays and is restated, not compiled (std::set order).
+void ref_project_selection_pixels(const nrs_model_desc* desc, const nrs_render_params* p, const uint8_t* bitfield, const int32_t* pixels_xy, uint32_t n_rays,
+                                  float transmittance_threshold, ref_density_fn density, void* user, float* positions_out /*[n][3]*/, uint32_t* cells_out, uint8_t* found_out) {
+	const BoundingBox aabb = box(desc->aabb_min, desc->aabb_max);
+	const uint32_t padded_density_output_width = 16, floats_per_coord = sizeof(NerfCoordinate) / sizeof(float), max_samples = n_rays * NERF_STEPS();
+	std::vector<uint32_t> ray_indices(n_rays), numsteps(2 * (size_t)n_rays), grid_indices(n_rays, 0u);
+	std::vector<Ray> rays(n_rays);
+	std::vector<float> coords((size_t)max_samples * floats_per_coord, 0.f);
+	std::vector<Vector2i> pixels(n_rays);
+	for (uint32_t i = 0; i < n_rays; ++i) pixels[i] = Vector2i(pixels_xy[2 * i], pixels_xy[2 * i + 1]);
+	const Vector3f sentinel = aabb.min + Vector3f(-1.f, -1.f, -1.f);
+	std::vector<Vector3f> coords_projected(n_rays, sentinel);
+	uint32_t ray_counter = 0, numsteps_counter = 0;
+	launch_linear(false, n_rays, shoot_selection_rays_kernel, pixels.data(), Vector2i(p->resolution[0], p->resolution[1]), Vector2f(p->focal_length[0], p->focal_length[1]),
+	              m34(p->camera_matrix1), Vector2f(p->screen_center[0], p->screen_center[1]), aabb, max_samples, &ray_counter, &numsteps_counter, ray_indices.data(), rays.data(),
+	              numsteps.data(), PitchedPtr<NerfCoordinate>((NerfCoordinate*)coords.data(), 1, 0, 0), bitfield, p->cone_angle_constant, Vector3f(Vector3f(1.f, 0.f, 0.f)));
+	for (uint32_t i = 0; i < n_rays; ++i) {
+		found_out[i] = 0; cells_out[i] = 0;
+		for (int k = 0; k < 3; ++k) positions_out[3 * i + k] = sentinel[k];
+	}
+	if (numsteps_counter == 0) return;
+	std::vector<network_precision_t> mlp_out((size_t)numsteps_counter * padded_density_output_width);
+	density(user, numsteps_counter, coords.data(), floats_per_coord, (uint16_t*)mlp_out.data(), padded_density_output_width, NRS_INTERLEAVED); // column-major 16 x n
+	launch_linear(true, n_rays, composite_shot_rays, aabb, (const uint32_t*)&ray_counter, (int)padded_density_output_width, (const network_precision_t*)mlp_out.data(), &numsteps_counter,
+	              (const Ray*)rays.data(), numsteps.data(), PitchedPtr<const NerfCoordinate>((const NerfCoordinate*)coords.data(), 1, 0, 0), (ENerfActivation)desc->rgb_activation,
+	              (ENerfActivation)desc->density_activation, coords_projected.data(), grid_indices.data(), transmittance_threshold);
+	for (uint32_t r = 0; r < ray_counter; ++r) {
+		const uint32_t i = ray_indices[r];
+		for (int k = 0; k < 3; ++k) positions_out[3 * i + k] = coords_projected[r][k];
+		if (aabb.contains(coords_projected[r])) { found_out[i] = 1; cells_out[i] = grid_indices[r]; }
+	}
+}
+
+// ---- Testbed::get_density_on_grid (testbed_nerf.cu:4538-4586) and get_rgba_on_grid (:4588-4613): generators, network callback, conversion kernels ----
+// (the reference launches the generators on a 3-D grid of 16 x 8 x 1 blocks: one call per grid point here; the 2^20-point batching only bounds
+// its scratch memory)
+void ref_density_on_grid(const nrs_model_desc* desc, const uint32_t* res3d_in, const float* box_min, const float* box_max, const float* density_grid /*nullable*/,
+                         ref_density_fn density, void* user, float* out) {
+	const Vector3i res3d((int)res3d_in[0], (int)res3d_in[1], (int)res3d_in[2]);
+	const uint32_t n_elements = (uint32_t)(res3d.x() * res3d.y() * res3d.z());
+	const BoundingBox m_aabb = box(desc->aabb_min, desc->aabb_max), aabb = box(box_min, box_max);
+	std::vector<NerfPosition> positions(n_elements, NerfPosition(Vector3f::Zero(), 0.f));
+	launch_3d(res3d, generate_grid_samples_nerf_uniform, res3d, 0u, aabb, m_aabb, positions.data());
+	std::vector<network_precision_t> mlp_out((size_t)n_elements * 16);
+	density(user, n_elements, (const float*)positions.data(), (uint32_t)(sizeof(NerfPosition) / sizeof(float)), (uint16_t*)mlp_out.data(), n_elements, NRS_PLANES); // RM 16 x n
+	launch_linear(true, n_elements, grid_samples_half_to_float, m_aabb, out, (const network_precision_t*)mlp_out.data(), (ENerfActivation)desc->density_activation,
+	              (const NerfPosition*)positions.data(), density_grid);
+}
+// m_network->inference (full-precision 4 x n output) = the fp16 operator's rows 0..3 widened to float (exact)
+void ref_rgba_on_grid(const nrs_model_desc* desc, const uint32_t* res3d_in, const float* render_min, const float* render_max, const float* ray_dir, ref_network_fn inference,
+                      void* user, float* out_rgba) {
+	const Vector3i res3d((int)res3d_in[0], (int)res3d_in[1], (int)res3d_in[2]);
+	const uint32_t n_elements = (uint32_t)(res3d.x() * res3d.y() * res3d.z());
+	const BoundingBox m_aabb = box(desc->aabb_min, desc->aabb_max), render_aabb = box(render_min, render_max);
+	std::vector<NerfCoordinate> positions(n_elements, NerfCoordinate(Vector3f::Zero(), Vector3f::Zero(), 0.f));
+	launch_3d(res3d, generate_grid_samples_nerf_uniform_dir, res3d, 0u, render_aabb, m_aabb, v3(ray_dir), positions.data());
+	std::vector<network_precision_t> net_out((size_t)n_elements * 16);
+	inference(user, n_elements, (const float*)positions.data(), (uint16_t*)net_out.data(), 16, NRS_INTERLEAVED);
+	Array4f* rgba = (Array4f*)out_rgba;
+	for (uint32_t i = 0; i < n_elements; ++i)
+		rgba[i] = Array4f((float)net_out[(size_t)i * 16 + 0], (float)net_out[(size_t)i * 16 + 1], (float)net_out[(size_t)i * 16 + 2], (float)net_out[(size_t)i * 16 + 3]);
+	launch_linear(true, n_elements, compute_nerf_density, rgba, (ENerfActivation)desc->rgb_activation, (ENerfActivation)desc->density_activation);
+}
+
+// ---- GrowingSelection::compute_poisson_boundary, growing_selection.cu:2220-2348: the sampling loop, activate_network_output, filter_empty, the density pick
+// and the SH9 fit loop compiled from the reference; the network is the callback.  The reference jitters the directions with std::rand(): the loop runs
+// after srand(seed), and the same draws ((float)std::rand() / RAND_MAX, two per sample, in the loop's order) are handed back in jitter_out so that the
+// oracle / the product can be given the identical jitter.
+void ref_poisson_boundary(const nrs_model_desc* desc, const float* vertices_in, uint32_t n_verts_in, uint32_t sh_width, uint32_t hemisphere_width, unsigned seed, int is_inside_in,
+                          const uint8_t* bitfield, ref_network_fn inference, void* user, float* density_out /*[n_verts]*/, float* sh_out /*[n_verts][27]*/, float* jitter_out /*[n][2]*/) {
+	typedef Vector3f point_t;
+	const bool is_inside = is_inside_in != 0;
+	const BoundingBox m_aabb = box(desc->aabb_min, desc->aabb_max);
+	std::vector<point_t> vertices(n_verts_in);
+	for (uint32_t i = 0; i < n_verts_in; ++i) vertices[i] = v3(vertices_in + 3 * i);
+	const uint32_t n_verts = n_verts_in;
+	struct { int sh_sampling_width; } m_poisson_editing{(int)sh_width};
+	const int m_hemisphere_width = (int)hemisphere_width;
+	const uint32_t n_sh_samples = m_poisson_editing.sh_sampling_width * m_poisson_editing.sh_sampling_width; // :2227
+	const uint32_t padded_output_width = 16, floats_per_coord = sizeof(NerfCoordinate) / sizeof(float), extra_stride = 0;
+	const uint32_t n_samples = n_verts * n_sh_samples;
+	std::vector<float> coords_host((size_t)n_samples * floats_per_coord);
+	PitchedPtr<NerfCoordinate> coords_host_ptr = PitchedPtr<NerfCoordinate>((NerfCoordinate*)coords_host.data(), 1, 0, extra_stride);
+	srand(seed);
+	for (uint32_t s = 0; s < 2 * n_samples; ++s) jitter_out[s] = (float)std::rand() / RAND_MAX;
+	srand(seed);
+#include "poisson_boundary_sampling_loop.inc"
+	std::vector<network_precision_t> mlp_out((size_t)n_samples * padded_output_width);
+	inference(user, n_samples, coords_host.data(), (uint16_t*)mlp_out.data(), padded_output_width, NRS_INTERLEAVED);
+	std::vector<Array3f> rgb_host(n_samples);
+	std::vector<float> density_host(n_samples);
+	launch_linear(true, n_samples, activate_network_output, (int)padded_output_width, (const network_precision_t*)mlp_out.data(), (ENerfActivation)desc->rgb_activation,
+	              (ENerfActivation)desc->density_activation, rgb_host.data(), density_host.data());
+	if (is_inside)
+		launch_linear(true, n_samples, filter_empty, m_aabb, bitfield, PitchedPtr<NerfCoordinate>((NerfCoordinate*)coords_host.data(), 1, 0, extra_stride), density_host.data());
+	std::vector<float> target_density(n_verts);
+#include "poisson_boundary_density_loop.inc"
+	std::vector<SH9RGB> target_shs(n_verts);
+#include "poisson_boundary_fit_loop.inc"
+	memcpy(density_out, target_density.data(), sizeof(float) * n_verts);
+	memcpy(sh_out, (const void*)target_shs.data(), sizeof(float) * 27 * n_verts);
+}
+
 // ---- update_density_grid_mean_and_bitfield, testbed_nerf.cu:3642-3657: grid_to_bitfield + bitfield_max_pool (the mean is the caller's) ------
 void ref_grid_to_bitfield(const float* grid /*[5*128^3]*/, float mean_density, uint8_t* bitfield /*[5*128^3/8]*/) {
 	const uint32_t n_elements = NERF_GRIDSIZE() * NERF_GRIDSIZE() * NERF_GRIDSIZE();
@@ -639,6 +768,9 @@ void ref_pixel_to_ray(uint32_t n, const int32_t* pixel2, const nrs_render_params
 		Ray r = pixel_to_ray(p->spp_index, Vector2i(pixel2[2 * i], pixel2[2 * i + 1]), resolution, focal_length, cam, screen_center, (bool)p->snap_to_pixel_centers);
 		for (int c = 0; c < 3; ++c) { origin3[3 * (size_t)i + c] = r.o[c]; dir3[3 * (size_t)i + c] = r.d[c]; }
 	}
+}
+void ref_upper_cell_idx(uint32_t n, const uint32_t* cell_idx, const uint32_t* target_level, uint32_t* out) { // selection_utils.cu:36-48
+	for (uint32_t i = 0; i < n; ++i) out[i] = get_upper_cell_idx(cell_idx[i], target_level[i]);
 }
 void ref_cell_functions(uint32_t n, const uint32_t* xyz_level4, const float* pos3, float* cell_pos3, int32_t* cell_at_pos3) {
 	for (uint32_t i = 0; i < n; ++i) {

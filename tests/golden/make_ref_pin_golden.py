@@ -35,6 +35,9 @@ def main():
     store_hashed("authoring", cases.authoring_cases(scenes, "ref"))
     store_hashed("bitfield", {"grids": cases.bitfield_case(scenes, "ref")})
     store_hashed("refresh", cases.refresh_cases(scenes, "ref"))
+    store_hashed("selection", cases.selection_cases(scenes, "ref"))
+    store_hashed("grid_eval", cases.grid_eval_cases(scenes, "ref"))
+    store_hashed("poisson_boundary", cases.poisson_boundary_cases(scenes, "ref"))
     for case in cases.FRAME_CASES:
         f, d, s, st = cases.render_case(scenes, case, "ref")
         out[f"frame/{case[0]}/frame"], out[f"frame/{case[0]}/depth"], out[f"frame/{case[0]}/steps"], out[f"frame/{case[0]}/stats"] = f, d, s.astype(np.uint16), st

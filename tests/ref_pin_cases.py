@@ -415,3 +415,91 @@ def refresh_cases(scenes, which):
         out[name] = res
         sc.oracle_model.set_bitfield(sc.bitfield)  # (the oracle's refresh installs its bitfield in the model)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the selection tool: GrowingSelection::project_selection_pixels (growing_selection.cu:1673-1960), get_upper_cell_idx (selection_utils.cu:36)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def selection_cases(scenes, which):
+    """-> {name: [positions, cells, found]} for 6000 scribbled pixels of a 480x270 view, two transmittance thresholds, lego (geometry in the
+    network) and aabb 16 (cone stepping, 5 cascades); and get_upper_cell_idx on 10^5 (cell, level) pairs (the product's host function)."""
+    from oracle import ref
+    out = {}
+    for key, az in (("lego_shaped", 50.0), ("aabb16", 200.0)):
+        sc = scenes.get(key)
+        sc.oracle_model.set_bitfield(sc.bitfield)
+        W, H = 480, 270
+        p = sc.params_for(W, H, az)
+        r = _rng("selection" + key)
+        px = np.stack([r.integers(0, W, 6000), r.integers(0, H, 6000)], 1).astype(np.int32)
+        for thr in (0.1, 0.5):
+            if which == "ref":
+                res = ref.project_selection_pixels(sc.desc, p, sc.bitfield, px, sc.oracle_model, thr)
+            else:
+                res = sc.oracle_model.project_selection_pixels(p, px, thr)
+            out[f"{key}_thr{thr}"] = list(res)
+    r = _rng("upper")
+    level = r.integers(0, 5, N).astype(np.uint32)
+    cell = (level * np.uint32(128 ** 3) + r.integers(0, 128 ** 3, N).astype(np.uint32)).astype(np.uint32)
+    target = np.minimum(level + r.integers(0, 5, N).astype(np.uint32), 4).astype(np.uint32)
+    if which == "ref":
+        up = ref.upper_cell_idx(cell, target)
+    else:
+        from nerfshop_amd import _abi
+        lib = _abi.load()
+        up = np.array([lib.nrs_upper_cell_idx(int(c), int(t)) for c, t in zip(cell, target)], np.uint32)
+    out["upper_cell_idx"] = [up]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the network on a regular grid: Testbed::get_density_on_grid / get_rgba_on_grid (testbed_nerf.cu:4538-4613)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def grid_eval_cases(scenes, which):
+    """-> {name: [array]}: raw density on a 48 x 40 x 33 grid over a sub-box (masked by the density grid, and unmasked), premultiplied RGBA for a
+    fixed view direction; lego (geometry in the network) and aabb 16"""
+    from oracle import ref
+    out = {}
+    for key in ("lego_shaped", "aabb16"):
+        sc = scenes.get(key)
+        mn, mx = np.array(sc.desc.aabb_min[:]), np.array(sc.desc.aabb_max[:])
+        lo, hi = mn + 0.21 * (mx - mn), mn + 0.83 * (mx - mn)
+        res, d = (48, 40, 33), (0.3, -0.5, 0.81)
+        if which == "ref":
+            out[key] = [ref.density_on_grid(sc.desc, res, lo, hi, sc.oracle_model, sc.grid), ref.density_on_grid(sc.desc, res, lo, hi, sc.oracle_model, None),
+                        ref.rgba_on_grid(sc.desc, res, lo, hi, d, sc.oracle_model)]
+        else:
+            out[key] = [sc.oracle_model.density_on_grid(res, lo, hi, sc.grid), sc.oracle_model.density_on_grid(res, lo, hi, None), sc.oracle_model.rgba_on_grid(res, lo, hi, d)]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# membrane boundary values: GrowingSelection::compute_poisson_boundary (growing_selection.cu:2220-2348)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def libc_rand_jitter(seed, n):
+    """(float)std::rand() / RAND_MAX after srand(seed), n draws (glibc; the reference jitters its directions this way)"""
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(ctypes.c_uint(seed))
+    r = np.array([libc.rand() for _ in range(n)], np.int64)
+    return (r.astype(np.float32) / np.float32(2147483647)).astype(np.float32)
+
+
+def poisson_boundary_cases(scenes, which):
+    """-> {name: [density, sh9rgb]} at the cage vertices (outside pass) and at the cage vertices pulled half way to their centroid (inside
+    pass, with filter_empty), 10 x 10 directions per vertex, jitter = glibc rand() after srand(77) in both runs"""
+    from oracle import ref
+    sc = scenes.get("lego_shaped")
+    sc.oracle_model.set_bitfield(sc.bitfield)
+    cv = np.ascontiguousarray(sc.edit.cage_vertices, np.float32)
+    inner = (cv.mean(0) + np.float32(0.5) * (cv - cv.mean(0))).astype(np.float32)
+    out = {}
+    for name, verts, inside in (("outside", cv, False), ("inside", inner, True)):
+        if which == "ref":
+            d, sh, jit = ref.poisson_boundary(sc.desc, verts, 10, 10, 77, inside, sc.bitfield, sc.oracle_model)
+            assert np.array_equal(jit.reshape(-1), libc_rand_jitter(77, jit.size))
+        else:
+            jit = libc_rand_jitter(77, verts.shape[0] * 100 * 2).reshape(-1, 2)
+            d, sh = sc.oracle_model.poisson_boundary(verts, 10, 10, jit, inside)[:2]
+        out[name] = [d, sh]
+    return out

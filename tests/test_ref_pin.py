@@ -113,6 +113,42 @@ def test_refresh_live(scenes):
     _check_live(cases.refresh_cases(scenes, "ref"), cases.refresh_cases(scenes, "orc"))
 
 
+# ---- the selection tool's ray shooting: shoot_selection_rays_kernel -> density() -> composite_shot_rays; get_upper_cell_idx -------------
+def test_selection_golden(scenes, golden):
+    got = cases.selection_cases(scenes, "orc")
+    _check_hashed(golden, "selection", got)
+    assert got["lego_shaped_thr0.1"][2].sum() > 1000 and got["aabb16_thr0.5"][2].sum() > 3000  # rays did find a surface
+
+
+@live
+def test_selection_live(scenes):
+    _check_live(cases.selection_cases(scenes, "ref"), cases.selection_cases(scenes, "orc"))
+
+
+# ---- get_density_on_grid / get_rgba_on_grid: generate_grid_samples_nerf_uniform(_dir), grid_samples_half_to_float, compute_nerf_density -----
+def test_grid_eval_golden(scenes, golden):
+    got = cases.grid_eval_cases(scenes, "orc")
+    _check_hashed(golden, "grid_eval", got)
+    assert (got["lego_shaped"][0] == -10000).sum() > 1000 and got["lego_shaped"][2][:, 3].max() > 0.3
+
+
+@live
+def test_grid_eval_live(scenes):
+    _check_live(cases.grid_eval_cases(scenes, "ref"), cases.grid_eval_cases(scenes, "orc"))
+
+
+# ---- compute_poisson_boundary: the reference's sampling loop, activate_network_output, filter_empty, density pick and project_sh9 fit loop ----
+def test_poisson_boundary_golden(scenes, golden):
+    got = cases.poisson_boundary_cases(scenes, "orc")
+    _check_hashed(golden, "poisson_boundary", got)
+    assert (got["outside"][0] > 0).any() and 0 < (got["inside"][0] == 0).sum() < got["inside"][0].size  # filter_empty took both branches
+
+
+@live
+def test_poisson_boundary_live(scenes):
+    _check_live(cases.poisson_boundary_cases(scenes, "ref"), cases.poisson_boundary_cases(scenes, "orc"))
+
+
 # ---- whole frames: init_rays -> advance_pos -> [compact -> generate inputs -> residuals -> map_rays -> network -> composite]* -> shade ----
 @pytest.mark.parametrize("case", cases.FRAME_CASES, ids=[c[0] for c in cases.FRAME_CASES])
 def test_frame_golden(scenes, golden, case):
