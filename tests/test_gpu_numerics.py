@@ -111,3 +111,29 @@ def test_1080p_bench_view_against_the_oracle(rig):
         assert abs(int(stats.n_samples) - int(ref_stats.composited)) <= 0.0002 * ref_stats.composited
     finally:
         rig.use_edit(False)
+
+
+def test_1080p_aabb16_view_against_the_oracle(rig16):
+    """BASELINE configs[3] at full size: the aabb-16 scene (cone stepping, 5 cascades), one cage edit, sparse brick records installed (4 GiB), the
+    automatic schedule -- RGBA, depth and per-pixel sample counts against the oracle (about 38 M samples; ~40 s of oracle time on the host cores).
+    Same bars as the lego frame above."""
+    rig = rig16
+    rig.use_edit(True)
+    try:
+        rig.net.set_sparse_cell_cache(rig.scene.edited_bitfield, 4 << 30)
+        assert rig.net.sparse_cell_cache()[2] >= 2
+        p = rig.scene.params_for(1920, 1080, 30.0)
+        frame, depth, steps, stats = rig.render(p)
+        ref_frame, ref_depth, ref_steps, ref_stats = rig.scene.oracle_model.render(p, [rig.scene.oracle_edit])
+        assert ref_stats.n_hit > 1_000_000 and ref_stats.composited > 20_000_000
+        assert stats.n_rays_alive == ref_stats.n_alive0
+        d = np.abs(frame - ref_frame).max(axis=-1)
+        assert d.max() < 1.5e-2 and (d > 6e-3).mean() <= 1e-5 and float(np.abs(frame - ref_frame).mean()) < 1e-6, (d.max(), (d > 6e-3).sum(), np.abs(frame - ref_frame).mean())
+        ds = np.abs(steps.astype(np.int64) - ref_steps.astype(np.int64))
+        assert ds.max() <= 1 and (ds == 0).mean() >= 0.9999, (ds.max(), (ds == 0).mean())
+        hit = (ref_frame[..., 3] > 0.2) & (frame[..., 3] > 0.2) & (ds == 0)
+        assert np.allclose(depth[hit], ref_depth[hit], rtol=0, atol=2e-3 * 16)  # depth in scene units: 16x the lego scene's extent
+        assert abs(int(stats.n_samples) - int(ref_stats.composited)) <= 0.0002 * ref_stats.composited
+    finally:
+        rig.net.set_sparse_cell_cache(None, 0)
+        rig.use_edit(False)
