@@ -1,6 +1,7 @@
 # usage: tools/probe/run_gather_probe.sh  -> gpurun_out/gather_probe/{plain.jsonl,pmc_*.txt}
 R=$GRAFT_REPO_ROOT
 P=$R/tools/probe/gather_probe
+[ -x $P ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $R/tools/probe/gather_probe.hip -o $P
 OUT=$R/gpurun_out/gather_probe
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -1,5 +1,6 @@
 R=$GRAFT_REPO_ROOT
 P=$R/tools/probe/gather_probe
+[ -x $P ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $R/tools/probe/gather_probe.hip -o $P
 OUT=$R/gpurun_out/gather_probe
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
