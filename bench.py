@@ -39,7 +39,8 @@ def build_scene(workload, rt, synth, ctx, torch):
     if workload.endswith("varied"):
         # non-uniform opacity: geometry inside the network (shaped) and a strong density noise, so that per-sample alpha -- and with
         # it the number of samples a ray needs -- varies widely, as in a trained snapshot
-        params = synth.make_params(desc, sigma_raw=synth.default_sigma_raw(aabb_scale), shaped=True, density_noise=1.5, aabb_scale=aabb_scale)
+        noise = float(os.environ.get("NRS_BENCH_NOISE", "1.5"))  # (profiles/r02_noise_sweep.md sweeps it; the bench line is always 1.5)
+        params = synth.make_params(desc, sigma_raw=synth.default_sigma_raw(aabb_scale), shaped=True, density_noise=noise, aabb_scale=aabb_scale)
     else:
         params = synth.make_params(desc, sigma_raw=synth.default_sigma_raw(aabb_scale))
     grid = synth.density_grid(aabb_scale)
