@@ -232,9 +232,10 @@ int    nrs_model_level_table(const nrs_model_desc* desc, float* scale, uint32_t*
 /* fp16 parameter blob in tiny-cuda-nn order: density MLP | rgb MLP | hash grid (nerf_network_full.h:316-349).
  * h_params is a HOST pointer (what Trainer::deserialize hands over); synchronous. */
 int    nrs_model_set_params(nrs_model* model, const void* h_params_fp16, size_t n_params);
-/* The same from a DEVICE pointer, as NerfNetworkFull::set_params receives it (nerf_network_full.h:316-349: pointers into the trainer's blob):
- * the hash grid is copied device-to-device on `stream`, only the 20 KB of MLP weights visit the host (they are re-arranged into MFMA
- * fragments).  Copy semantics: call again after every optimiser step.  Synchronises `stream`. */
+/* The same from a DEVICE pointer, as NerfNetworkFull::set_params receives it (nerf_network_full.h:316-349: pointers into the trainer's blob).
+ * Asynchronous: the hash grid is copied device-to-device, the MLP weights are re-arranged into MFMA fragments by a small kernel and the cell
+ * records (if any are kept) rebuilt, all enqueued on `stream`; launches enqueued on the same stream afterwards see the new parameters, and the
+ * blob may be overwritten once the stream has passed this call.  Copy semantics: call again after every optimiser step. */
 int    nrs_model_set_params_device(nrs_model* model, const void* d_params_fp16, size_t n_params, void* stream);
 /* nrs_grid_acc / nrs_mlp_acc above.  Applies to every entry point that evaluates the network.  The render kernel runs the non-default modes
  * with one lane per ray and without the membrane / AffineDuplication instantiations (NRS_ERR_UNSUPPORTED for those combinations). */

@@ -77,6 +77,7 @@ struct nrs_model {
 	uint32_t total_entries = 0;
 	uint32_t* d_grid = nullptr;
 	uint16_t* d_wfrag = nullptr;
+	uint16_t* d_wfrag_src = nullptr;     // make_weight_fragments as a permutation (source index + 1, 0 = padding), for nrs_model_set_params_device
 	uint8_t* d_bitfield = nullptr;
 	uint32_t* d_accel_masks = nullptr;   // 2 x kCoarseWords: accel_any.mask | accel_exact.mask
 	OccAccel accel_any{}, accel_exact{}; // marching shortcuts for general step parameters / for cone_angle == 0 && min_mip == 0
@@ -392,6 +393,7 @@ void nrs_model_destroy(nrs_model* m) {
 	if (!m) return;
 	(void)hipFree(m->d_grid);
 	(void)hipFree(m->d_wfrag);
+	(void)hipFree(m->d_wfrag_src);
 	(void)hipFree(m->d_bitfield);
 	(void)hipFree(m->d_accel_masks);
 	(void)hipFree(m->d_density_grid);
@@ -426,12 +428,12 @@ static uint32_t plan_cell_cache(const LevelParams* lv, size_t budget, LevelParam
 	*bytes = (size_t)fit * 32;
 	return n;
 }
-static int rebuild_cell_cache(nrs_model* m) {
+static int rebuild_cell_cache(nrs_model* m, void* stream = nullptr, bool sync = true) {
 	if (!m->have_params) return NRS_OK;
-	if (m->cached_levels) NRS_TRY(launch_cell_records(m->dm, m->cached_levels, m->d_records, nullptr));
+	if (m->cached_levels) NRS_TRY(launch_cell_records(m->dm, m->cached_levels, m->d_records, stream));
 	for (uint32_t l = m->sparse_first; l < m->sparse_first + m->sparse_levels; ++l)
-		NRS_TRY(launch_brick_fill(m->dm, m->dm.levels[l], m->d_slots + m->slot_first[l], m->slot_count[l], m->d_records2, nullptr));
-	HIP_TRY(hipStreamSynchronize(nullptr));
+		NRS_TRY(launch_brick_fill(m->dm, m->dm.levels[l], m->d_slots + m->slot_first[l], m->slot_count[l], m->d_records2, stream));
+	if (sync) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
 	return NRS_OK;
 }
 static void drop_sparse_cell_cache(nrs_model* m) {
@@ -574,9 +576,11 @@ int nrs_model_set_params(nrs_model* m, const void* h_params_fp16, size_t n_param
 	return rebuild_cell_cache(m);
 }
 // NerfNetworkFull::set_params hands over DEVICE pointers into the trainer's parameter blob (nerf_network_full.h:316-349): the same for a caller
-// whose parameters already live on the device (a viewer that trains while it renders, src/testbed.cu:2502).  The hash grid (24-27 MB) is copied
-// device-to-device on `stream` (~10 us); only the 20 KB of MLP weights visit the host, to be re-arranged into MFMA fragments.  Copy semantics:
-// call it again after every optimiser step (the reference's renderer reads the blob in place; our weight fragments are a transformed copy).
+// whose parameters already live on the device (a viewer that trains while it renders, src/testbed.cu:2502).  Everything is enqueued on `stream` and
+// nothing waits: the hash grid (24-27 MB) is copied device-to-device (~10 us), the 20 KB of MLP weights are re-arranged into MFMA fragments by a
+// small kernel (the permutation is make_weight_fragments', uploaded once per model), the cell records -- if the caller keeps any -- are rebuilt
+// behind them.  Renders enqueued on the same stream afterwards see the new parameters; the blob may be overwritten once the stream has passed
+// this call.  Copy semantics: call it again after every optimiser step (the reference's renderer reads the blob in place; ours is a transformed copy).
 int nrs_model_set_params_device(nrs_model* m, const void* d_params_fp16, size_t n_params, void* stream) {
 	if (!m || !d_params_fp16) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_params_device: NULL argument");
 	const size_t expect = (size_t)kDensityW + kRgbW + (size_t)m->total_entries * 2;
@@ -588,15 +592,18 @@ int nrs_model_set_params_device(nrs_model* m, const void* d_params_fp16, size_t 
 	HIP_TRY(hipSetDevice(m->ctx->device));
 	hipStream_t s = (hipStream_t)stream;
 	const uint16_t* d = (const uint16_t*)d_params_fp16;
-	std::vector<uint16_t> w(kDensityW + kRgbW), frag(kWfragBytes / 2);
-	HIP_TRY(hipMemcpyAsync(w.data(), d, w.size() * 2, hipMemcpyDeviceToHost, s));
+	if (!m->d_wfrag_src) { // the fragment permutation as indices: run the host routine on the identity (index + 1; 0 stays "padding")
+		static_assert(kDensityW + kRgbW < 65535, "weight indices fit 16 bits");
+		std::vector<uint16_t> ident(kDensityW + kRgbW), src(kWfragBytes / 2);
+		for (size_t i = 0; i < ident.size(); ++i) ident[i] = (uint16_t)(i + 1);
+		make_weight_fragments(ident.data(), src.data());
+		HIP_TRY(hipMalloc((void**)&m->d_wfrag_src, kWfragBytes));
+		HIP_TRY(hipMemcpy(m->d_wfrag_src, src.data(), kWfragBytes, hipMemcpyHostToDevice));
+	}
+	NRS_TRY(launch_weight_fragments(d, m->d_wfrag_src, (uint16_t*)m->d_wfrag, kWfragBytes / 2, stream));
 	HIP_TRY(hipMemcpyAsync(m->d_grid, d + kDensityW + kRgbW, (size_t)m->total_entries * 4, hipMemcpyDeviceToDevice, s));
-	HIP_TRY(hipStreamSynchronize(s));
-	make_weight_fragments(w.data(), frag.data());
-	HIP_TRY(hipMemcpyAsync(m->d_wfrag, frag.data(), kWfragBytes, hipMemcpyHostToDevice, s));
-	HIP_TRY(hipStreamSynchronize(s)); // frag is a local
 	m->have_params = true;
-	return rebuild_cell_cache(m);
+	return rebuild_cell_cache(m, stream, false);
 }
 int nrs_model_set_numerics(nrs_model* m, uint32_t grid_acc, uint32_t mlp_acc) {
 	if (!m) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_numerics: NULL model");

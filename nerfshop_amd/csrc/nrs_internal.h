@@ -151,6 +151,7 @@ int launch_selection_rays(const DeviceModel& m, const nrs_render_params& p, cons
 int launch_poisson_fit(const DeviceModel& m, uint32_t n_verts, uint32_t n_sh, const float* d_coords, const void* d_net, int is_inside, float scale,
                        float* d_density, float* d_sh, void* stream);
 int launch_cell_records(const DeviceModel& m, uint32_t n_levels, void* d_records, void* stream);
+int launch_weight_fragments(const uint16_t* d_params, const uint16_t* d_src, uint16_t* d_frag, uint32_t n, void* stream);
 constexpr uint32_t kBrick = 8, kBrickCells = kBrick * kBrick * kBrick; // sparse cell records: 8^3 cells = 16 KiB of records per brick
 int launch_brick_mark(const DeviceModel& m, const LevelParams& lp, const uint8_t* d_mask, uint32_t* d_table, uint32_t* d_counter, uint32_t* d_slots, uint32_t capacity, void* stream);
 int launch_brick_fill(const DeviceModel& m, const LevelParams& lp, const uint32_t* d_slots, uint32_t n_bricks, void* d_records2, void* stream);

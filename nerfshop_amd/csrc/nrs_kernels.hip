@@ -960,6 +960,20 @@ int launch_cell_records(const DeviceModel& m, uint32_t n_levels, void* d_records
 	return hipGetLastError() == hipSuccess ? NRS_OK : NRS_ERR_HIP;
 }
 
+// MFMA weight fragments from a parameter blob that lives on the device (nrs_model_set_params_device): frag[i] = params[src[i] - 1], or 0 where
+// src[i] == 0 (padding rows).  src is make_weight_fragments' permutation, computed once per model on the host.
+__global__ __launch_bounds__(256) void weight_fragments_kernel(const uint16_t* __restrict__ params, const uint16_t* __restrict__ src, uint16_t* __restrict__ frag, uint32_t n) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t k = src[i];
+	frag[i] = k ? params[k - 1u] : (uint16_t)0;
+}
+int launch_weight_fragments(const uint16_t* d_params, const uint16_t* d_src, uint16_t* d_frag, uint32_t n, void* stream) {
+	hipLaunchKernelGGL(weight_fragments_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_params, d_src, d_frag, n);
+	NRS_LAUNCH_CHECK("weight_fragments_kernel launch");
+	return NRS_OK;
+}
+
 // ---- sparse cell records (nrs_model_set_sparse_cell_cache) -------------------------------------------------------------------------
 // brick_mark_kernel: one thread per cell of the 5-cascade mask (density-bitfield layout).  A marked cell allocates every 8^3-cell
 // brick of the level that its box touches (one cell of margin: samples sit anywhere inside the density cell, borders included).

@@ -221,6 +221,20 @@ def test_set_params_from_a_device_pointer(rig):
         got = torch.zeros_like(want)
         rig.net.inference_mixed_precision(None, torch.from_numpy(c).cuda(), got)
         assert np.array_equal(_encode(rig, c), want_feat) and torch.equal(got.view(torch.int16), want.view(torch.int16))
+        # asynchronous on a side stream: nothing waits between the hand-over and the launch that uses it; the blob is scribbled over right behind it
+        side = torch.cuda.Stream()
+        rig.net.set_params(rig.scene.params)
+        torch.cuda.synchronize()
+        d2 = d.clone()
+        cin = torch.from_numpy(c).cuda()
+        got2 = torch.zeros_like(want)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            rig.net.set_params_device(d2, stream=side)
+            rig.net.inference_mixed_precision(side, cin, got2)
+            d2.zero_()
+        side.synchronize()
+        assert torch.equal(got2.view(torch.int16), want.view(torch.int16))
         with pytest.raises(_abi.NrsError):
             rig.net.set_params_device(d[:-2])
     finally:
