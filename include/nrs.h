@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define NRS_ABI_VERSION 1
+#define NRS_ABI_VERSION 2   /* 2: nrs_render_params grew dof / slice_plane_z / depth_scale / show_accel (appended: a v1 struct zero-extended means the same) */
 
 typedef enum nrs_status {
 	NRS_OK = 0,
@@ -64,7 +64,10 @@ typedef enum nrs_activation {
 	NRS_ACT_NONE = 0, NRS_ACT_RELU = 1, NRS_ACT_LOGISTIC = 2, NRS_ACT_EXPONENTIAL = 3
 } nrs_activation;
 
-/* ERenderMode, common.h:71.  Only Shade (and Cost's step counter) are on the parity path. */
+/* ERenderMode, common.h:71.  Implemented: AO, Shade, Positions, Depth, Distance, Stepsize, Cost, Slice (composite_kernel_nerf's per-sample
+ * branches testbed_nerf.cu:905-937, shade_kernel_nerf :2466-2482, the Slice path :3111-3175).  Refused (NRS_ERR_UNSUPPORTED): Normals (needs the
+ * network's input gradient, tcnn input_gradient), Distortion (needs the camera-distortion map), EncodingVis (m_visualized_dimension, tcnn
+ * visualize_activation) -- all three live in tiny-cuda-nn / the distortion trainer, outside the path. */
 typedef enum nrs_render_mode {
 	NRS_RENDER_AO = 0, NRS_RENDER_SHADE = 1, NRS_RENDER_NORMALS = 2, NRS_RENDER_POSITIONS = 3,
 	NRS_RENDER_DEPTH = 4, NRS_RENDER_DISTANCE = 5, NRS_RENDER_STEPSIZE = 6, NRS_RENDER_DISTORTION = 7,
@@ -168,7 +171,7 @@ typedef struct nrs_render_params {
 	uint32_t snap_to_pixel_centers;
 	float    min_transmittance;   /* m_nerf.rendering_min_transmittance (0.01) */
 	float    cone_angle_constant; /* m_nerf.cone_angle_constant: 0 for aabb_scale 1, 1/256 otherwise */
-	uint32_t render_mode;         /* nrs_render_mode; Shade and Cost implemented */
+	uint32_t render_mode;         /* nrs_render_mode (m_render_mode); see the enum for what is implemented */
 	uint32_t linear_colors;       /* m_nerf.training.linear_colors: skip srgb_to_linear in shade */
 	uint32_t apply_operators;     /* m_enable_edits && !m_distill */
 	uint32_t poisson_target;      /* NerfTracer::m_poisson_target */
@@ -182,6 +185,13 @@ typedef struct nrs_render_params {
 	uint32_t tile_size;           /* multiple of 8, or 0 */
 	uint32_t tile_first;
 	uint32_t tile_stride;
+	/* ---- ABI 2: the remaining implicit Testbed members of render_nerf.  All zero = the behaviour of ABI 1. ---- */
+	float    dof;                 /* m_dof: aperture radius of pixel_to_ray's thin-lens branch (common_device.cuh:285-293); 0 = pinhole */
+	float    slice_plane_z;       /* m_slice_plane_z + m_scale (testbed_nerf.cu:3067): focus distance of the aperture branch, and the distance
+	                               * of the slice plane in render mode Slice (the call negates it itself, :3068-3070) */
+	float    depth_scale;         /* 1 / m_nerf.training.dataset.scale (:3113): factor of render modes Depth and Distance */
+	uint32_t show_accel;          /* m_nerf.show_accel >= 0 (the level is min_mip): every sample becomes opaque (:788-790) and render mode
+	                               * Positions colours the occupancy cell (:911-920) */
 } nrs_render_params;
 
 typedef struct nrs_render_stats {

@@ -162,7 +162,11 @@ public:
 	nrs_render_mode m_render_mode = NRS_RENDER_SHADE;
 	std::vector<const EditOperator*> m_edit_operators; // NerfTracer::m_edit_operators (testbed.h:237), applied last-to-first
 	bool m_poisson_target = false;                    // NerfTracer::m_poisson_target (passed to composite_kernel_nerf, testbed_nerf.cu:2951)
-	int m_show_accel = -1;                            // m_nerf.show_accel: >= 0 forces that cascade as the minimum while marching (:2751, :2849)
+	int m_show_accel = -1;                            // m_nerf.show_accel: >= 0 forces that cascade as the minimum while marching (:2751, :2849), makes
+	                                                  // every sample opaque (:788-790) and colours the occupancy cells in render mode Positions (:911-920)
+	float m_dof = 0.f;                                // aperture of pixel_to_ray's thin-lens branch (common_device.cuh:285-293)
+	float m_slice_plane_z = 0.f, m_scale = 1.f;       // plane_z = m_slice_plane_z + m_scale (testbed_nerf.cu:3067): focus distance / slice plane
+	float m_dataset_scale = 1.f;                      // m_nerf.training.dataset.scale: depth_scale = 1 / it (:3113)
 
 	// Testbed state update_density_grid_nerf_operator advances: m_rng, m_nerf.density_grid_ema_step, density_grid_decay, max_cascade
 	nrs_grid_update m_density_grid_update{};
@@ -207,6 +211,10 @@ public:
 		p.apply_operators = apply_operators && m_enable_edits;
 		p.poisson_target = m_poisson_target ? 1u : 0u;
 		p.min_mip = m_show_accel >= 0 ? (uint32_t)m_show_accel : 0u;
+		p.show_accel = m_show_accel >= 0 ? 1u : 0u;
+		p.dof = m_dof;
+		p.slice_plane_z = m_slice_plane_z + m_scale;
+		p.depth_scale = 1.0f / m_dataset_scale;
 		std::vector<nrs_edit*> edits;
 		for (const EditOperator* op : m_edit_operators) edits.push_back(op->get());
 		check(nrs_render_nerf(network.get(), &p, edits.data(), (int)edits.size(), render_buffer.frame_buffer, render_buffer.depth_buffer, nullptr, stream,

@@ -17,7 +17,7 @@ BITFIELD_BYTES = GRID_VOLUME * GRID_CASCADES // 8
 N_LUT_CELLS = GRID_VOLUME * GRID_CASCADES
 
 ACT_NONE, ACT_RELU, ACT_LOGISTIC, ACT_EXPONENTIAL = 0, 1, 2, 3
-RENDER_SHADE, RENDER_COST = 1, 8
+RENDER_AO, RENDER_SHADE, RENDER_NORMALS, RENDER_POSITIONS, RENDER_DEPTH, RENDER_DISTANCE, RENDER_STEPSIZE, RENDER_DISTORTION, RENDER_COST, RENDER_SLICE = range(10)
 LAYOUT_PLANES, LAYOUT_INTERLEAVED = 0, 1
 
 
@@ -97,6 +97,10 @@ class RenderParams(C.Structure):
         ("tile_size", C.c_uint32),
         ("tile_first", C.c_uint32),
         ("tile_stride", C.c_uint32),
+        ("dof", C.c_float),
+        ("slice_plane_z", C.c_float),
+        ("depth_scale", C.c_float),
+        ("show_accel", C.c_uint32),
     ]
 
 

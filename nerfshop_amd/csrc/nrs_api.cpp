@@ -598,7 +598,12 @@ int nrs_model_set_params_device(nrs_model* m, const void* d_params_fp16, size_t 
 		for (size_t i = 0; i < ident.size(); ++i) ident[i] = (uint16_t)(i + 1);
 		make_weight_fragments(ident.data(), src.data());
 		HIP_TRY(hipMalloc((void**)&m->d_wfrag_src, kWfragBytes));
-		HIP_TRY(hipMemcpy(m->d_wfrag_src, src.data(), kWfragBytes, hipMemcpyHostToDevice));
+		const hipError_t up = hipMemcpy(m->d_wfrag_src, src.data(), kWfragBytes, hipMemcpyHostToDevice);
+		if (up != hipSuccess) { // never keep a permutation that was not uploaded: later calls would scramble the weights silently
+			(void)hipFree(m->d_wfrag_src);
+			m->d_wfrag_src = nullptr;
+			return fail_hip(up, "nrs_model_set_params_device: upload of the weight permutation");
+		}
 	}
 	NRS_TRY(launch_weight_fragments(d, m->d_wfrag_src, (uint16_t*)m->d_wfrag, kWfragBytes / 2, stream));
 	HIP_TRY(hipMemcpyAsync(m->d_grid, d + kDensityW + kRgbW, (size_t)m->total_entries * 4, hipMemcpyDeviceToDevice, s));
@@ -691,7 +696,6 @@ int nrs_model_update_density_grid(nrs_model* m, nrs_edit* const* edits, int n_ed
 	if (u->reset_grid) HIP_TRY(hipMemsetAsync(m->d_density_grid, 0, grid_bytes, s));
 	HIP_TRY(hipMemsetAsync(m->d_density_tmp, 0, grid_bytes, s));
 	const uint64_t rng_nonuniform = pcg_advance(u->rng_state, u->rng_inc, 1ull << 32); // m_rng.advance() between the two draws
-	if (m->dm.numerics) return fail(NRS_ERR_UNSUPPORTED, "nrs_model_update_density_grid: only the default numerics are built for this entry point (nrs_model_set_numerics)");
 	NRS_TRY(launch_grid_update(m->dm, d_refresh_edits, n_edits, *u, rng_nonuniform, m->d_density_grid, m->d_density_tmp, ctx->n_cus, stream));
 	u->rng_state = pcg_advance(u->rng_state, u->rng_inc, 2ull << 32);
 	u->ema_step += 1;
@@ -742,7 +746,6 @@ int nrs_density_on_grid(nrs_model* m, void* stream, const uint32_t res3d[3], con
 	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_density_on_grid: parameters not set (nrs_model_set_params)");
 	if ((uint64_t)res3d[0] * res3d[1] * res3d[2] > 0x7fffffffull) return fail(NRS_ERR_INVALID_ARG, "nrs_density_on_grid: more than 2^31 grid points");
 	HIP_TRY(hipSetDevice(m->ctx->device));
-	if (m->dm.numerics) return fail(NRS_ERR_UNSUPPORTED, "nrs_density_on_grid: only the default numerics are built for this entry point (nrs_model_set_numerics)");
 	NRS_TRY(launch_grid_eval(m->dm, 0, res3d, aabb_min, aabb_max, nullptr, mask_with_density_grid ? m->d_density_grid : nullptr, d_out, m->ctx->n_cus, stream));
 	return NRS_OK;
 }
@@ -753,7 +756,6 @@ int nrs_rgba_on_grid(nrs_model* m, void* stream, const uint32_t res3d[3], const 
 	if ((uint64_t)res3d[0] * res3d[1] * res3d[2] > 0x7fffffffull) return fail(NRS_ERR_INVALID_ARG, "nrs_rgba_on_grid: more than 2^31 grid points");
 	HIP_TRY(hipSetDevice(m->ctx->device));
 	const float dir01[3] = {(ray_dir[0] + 1.0f) * 0.5f, (ray_dir[1] + 1.0f) * 0.5f, (ray_dir[2] + 1.0f) * 0.5f}; // warp_direction, not normalised (tn:430)
-	if (m->dm.numerics) return fail(NRS_ERR_UNSUPPORTED, "nrs_rgba_on_grid: only the default numerics are built for this entry point (nrs_model_set_numerics)");
 	NRS_TRY(launch_grid_eval(m->dm, 1, res3d, render_aabb_min, render_aabb_max, dir01, nullptr, d_out_rgba, m->ctx->n_cus, stream));
 	return NRS_OK;
 }
@@ -765,7 +767,6 @@ int nrs_project_selection_pixels(nrs_model* m, void* stream, const nrs_render_pa
 	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_project_selection_pixels: occupancy not set (nrs_model_set_density_bitfield/_grid)");
 	{ const int pc = check_march_params(*p, "nrs_project_selection_pixels"); if (pc != NRS_OK) return pc; }
 	HIP_TRY(hipSetDevice(m->ctx->device));
-	if (m->dm.numerics) return fail(NRS_ERR_UNSUPPORTED, "nrs_project_selection_pixels: only the default numerics are built for this entry point (nrs_model_set_numerics)");
 	NRS_TRY(launch_selection_rays(m->dm, *p, d_pixels_xy, n_pixels, transmittance_threshold, d_positions, d_cells, d_found, stream));
 	return NRS_OK;
 }
@@ -1222,13 +1223,13 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_render_nerf: parameters not set (nrs_model_set_params)");
 	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_render_nerf: occupancy not set (nrs_model_set_density_bitfield/_grid)");
 	{ const int pc = check_march_params(*p, "nrs_render_nerf"); if (pc != NRS_OK) return pc; }
-	if (p->render_mode != NRS_RENDER_SHADE && p->render_mode != NRS_RENDER_COST)
-		return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: only render modes Shade and Cost are implemented (debug visualisations are out of scope)");
+	if (p->render_mode > NRS_RENDER_SLICE) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: unknown render mode");
+	if (p->render_mode == NRS_RENDER_NORMALS || p->render_mode == NRS_RENDER_DISTORTION)
+		return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: render modes Normals (network input gradient) and Distortion (camera distortion map) need tiny-cuda-nn / the "
+		                                  "distortion trainer and are not on the path");
+	if (!std::isfinite(p->dof) || !std::isfinite(p->slice_plane_z) || !std::isfinite(p->depth_scale)) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: dof / slice_plane_z / depth_scale must be finite");
+	if (p->dof != 0.f && p->slice_plane_z == 0.f) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: dof != 0 needs a focus distance (slice_plane_z = m_slice_plane_z + m_scale != 0)");
 	if (n_edits < 0 || n_edits > nrs_ctx::kMaxEdits) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: too many edit operators");
-	if (m->dm.numerics)
-		for (int i = 0; i < n_edits; ++i)
-			if (edits && edits[i] && p->apply_operators && (edits[i]->de.apply_poisson || edits[i]->de.kind == kEditAffine))
-				return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: the non-default numerics (nrs_model_set_numerics) are built for cage edits without membrane correction only");
 	if (n_edits > 0 && !edits) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: edits is NULL");
 	nrs_ctx* ctx = m->ctx;
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -1267,6 +1268,25 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		static const uint32_t dbg = []() { const char* e = getenv("NRS_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
 		a.dbg = dbg;
 	}
+	// everything of render_nerf's surface beyond Shade / Cost with a pinhole camera runs the EXTRA instantiation (one lane per ray)
+	a.extra = ((p->render_mode != NRS_RENDER_SHADE && p->render_mode != NRS_RENDER_COST) || p->show_accel || p->dof != 0.f) ? 1u : 0u;
+	if (p->render_mode == NRS_RENDER_SLICE) { // tn:3109-3162: no marching at all; one network evaluation per owned pixel
+		a.frame = d_frame; a.depth = d_depth; a.steps = d_steps; a.counters = d_counters_slot;
+		HIP_TRY(hipMemsetAsync(d_counters_slot, 0, sizeof(RenderCounters), s));
+		NRS_TRY(launch_slice(m->dm, a, ctx->n_cus, s));
+		HIP_TRY(hipEventRecord(ctx->slot_done[slot], s));
+		ctx->slot_stream[slot] = s;
+		ctx->slot_used[slot] = true;
+		if (h_stats) {
+			RenderCounters c;
+			HIP_TRY(hipMemcpyAsync(&c, d_counters_slot, sizeof(c), hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			h_stats->n_samples = c.n_samples;
+			h_stats->n_rays_alive = c.n_rays_alive;
+			h_stats->n_rays_hit = c.n_rays_hit;
+		}
+		return NRS_OK;
+	}
 	{ // lane teams (render_kernel's TEAM) when the launch cannot fill the GPU with one ray per lane.  Rays per lane is
 	  // estimated from the share of pixels that became rays in the last finished launch (written by its last workgroup;
 	  // 0.25 until one has finished).  Measured on 1080p lego (0.22 of the pixels hit), frame shares 1/1 .. 1/8, ms per
@@ -1300,14 +1320,14 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		while (team > 1 && (double)team * (double)a.pixels_owned * (double)(1u + busy) > 8.5 * 64.0 * 16.0 * (double)ctx->n_cus) team >>= 1;
 		if (forced == 1 || forced == 2 || forced == 4) team = (uint32_t)forced;
 		if (forced == -1) team = 1;
-		if (a.any_poisson || a.any_affine) team = 1; // (those instantiations are built for one lane per ray)
+		if (a.any_poisson || a.any_affine || a.extra) team = 1; // (those instantiations are built for one lane per ray)
 		static const bool log_teams = getenv("NRS_TEAM_LOG") != nullptr;
 		if (log_teams) fprintf(stderr, "[nrs team] pixels=%u hit_share=%.3f busy=%u rays/lane=%.3f team=%u\n", a.pixels_owned, hit_share, busy, rays_per_lane, team);
 		static const uint32_t tail_target = []() { const char* e = getenv("NRS_TAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)atoi(e) : 24u; }(); // 8 / 16 / 24 / 32 / 48: 8.92 / 8.91 / 9.11 / 9.01 / 8.47 Gsamples/s
 		a.tail_target = tail_target;
 		static const uint32_t reteam = []() { const char* e = getenv("NRS_RETEAM"); return e ? (uint32_t)atoi(e) : 1u; }();
 		a.reteam = reteam;
-		if (((team == 4 && !forced && hybrid_on) || forced == -2) && !a.any_poisson && !a.any_affine && !(a.dbg & 4u)) {
+		if (((team == 4 && !forced && hybrid_on) || forced == -2) && !a.any_poisson && !a.any_affine && !a.extra && !(a.dbg & 4u)) {
 			// few rays for the GPU: 4x4 packets only, and every generation takes ALL the rays its wave has pending with as many
 			// lanes per ray as fit (4 up to 16 rays, 2 up to 32), so that no wave is left with a second, nearly empty generation
 			// (1/8 share of the bench frame: 0.88 -> 0.82 ms).
@@ -1318,7 +1338,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		} else if (team > 1) {
 			a.team = team;
 			NRS_TRY(tile_geometry(*p, team, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x));
-		} else if (p->tile_size == 0 && !a.any_poisson && !a.any_affine && (forced == -1 || (!forced && hybrid_on))) {
+		} else if (p->tile_size == 0 && !a.any_poisson && !a.any_affine && !a.extra && (forced == -1 || (!forced && hybrid_on))) {
 			// hybrid: every 3rd packet row leaves the 8x8 list and joins the end of the queue as 4x4 tail packets (packet_pixel_bulk/_tail);
 			// measured on 1080p lego + cage, every 2nd / 3rd / 4th / 6th / 8th / 16th row: 8.88 / 8.89 / 8.79 / 8.75 / 8.65 / 8.65 Gsamples/s
 			static const uint32_t tail_every = []() { const char* e = getenv("NRS_TAIL_EVERY"); return e && atoi(e) >= 2 ? (uint32_t)atoi(e) : 3u; }();

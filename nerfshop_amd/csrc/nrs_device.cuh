@@ -219,9 +219,23 @@ __device__ __forceinline__ void ray_intersect(const float* mn, const float* mx, 
 
 struct Ray { f3 o, d; float t; bool alive; };
 
-// pixel_to_ray: origin and normalised direction of pixel (x, y).  offset = ld_random_pixel_offset(snap ? 0 : spp),
-// computed once per thread by the caller.
-__device__ __forceinline__ void ray_origin_dir(const nrs_render_params& p, uint32_t x, uint32_t y, float off_x, float off_y, f3& o, f3& d) {
+// square2disk_shirley, random_val.cuh:109-125.  sincosf is the device library's (<= 2 ulp): the thin-lens branch is the one place on the path where
+// ray origins are not bit-identical to the host-compiled reference (glibc's sincosf) -- nor is CUDA's; tests/test_gpu_modes.py states the tolerance.
+__device__ __forceinline__ void square2disk_shirley(float a, float b, float& ox, float& oy) {
+	const float PI = 3.14159265358979323846f;
+	float phi, r;
+	if (a * a > b * b) { r = a; phi = (PI / 4.0f) * (b / a); }
+	else { r = b; phi = (PI / 2.0f) - (PI / 4.0f) * (a / b); }
+	float sin_phi, cos_phi;
+	sincosf(phi, &sin_phi, &cos_phi);
+	ox = r * cos_phi; oy = r * sin_phi;
+}
+
+// pixel_to_ray (common_device.cuh:245-295): origin and UN-normalised direction of pixel (x, y) through the camera of its ray time
+// (init_rays_with_payload_kernel_nerf, tn:2551-2567).  offset = ld_random_pixel_offset(snap ? 0 : spp), computed once per thread by the caller.
+// LENS compiles in the thin-lens branch (:285-293; m_dof, focus distance focus_z = plane_z): only the instantiations that serve dof != 0 carry it.
+template <bool LENS = false>
+__device__ __forceinline__ void pixel_ray_raw(const nrs_render_params& p, uint32_t x, uint32_t y, float off_x, float off_y, float focus_z, f3& o, f3& d) {
 	const float W = (float)p.resolution[0], H = (float)p.resolution[1];
 	const uint32_t idx = x + (uint32_t)p.resolution[0] * y;
 	float u = ((float)x + 0.5f) * (1.f / W);
@@ -237,13 +251,29 @@ __device__ __forceinline__ void ray_origin_dir(const nrs_render_params& p, uint3
 	f3 dir = {(uvx - p.screen_center[0]) * W / p.focal_length[0], (uvy - p.screen_center[1]) * H / p.focal_length[1], 1.0f};
 	d = mat3_mul(cam, dir); // camera_matrix.block<3, 3>(0, 0) * dir, common_device.cuh:279
 	o = {cam[9], cam[10], cam[11]};
+	if (LENS && p.dof != 0.0f) {
+		const f3 lookat = o + d * focus_z;
+		float r0, r1, bx, by;
+		ld_random_val_2d(p.spp_index, x * 19349663u + y * 96925573u, r0, r1);
+		square2disk_shirley(r0 * 2.0f - 1.0f, r1 * 2.0f - 1.0f, bx, by);
+		bx = p.dof * bx; by = p.dof * by;
+		o = {o.x + (cam[0] * bx + cam[3] * by), o.y + (cam[1] * bx + cam[4] * by), o.z + (cam[2] * bx + cam[5] * by)};
+		const f3 diff = lookat - o;
+		d = {diff.x / focus_z, diff.y / focus_z, diff.z / focus_z};
+	}
+}
+// origin and normalised direction (tn:2588)
+template <bool LENS = false>
+__device__ __forceinline__ void ray_origin_dir(const nrs_render_params& p, uint32_t x, uint32_t y, float off_x, float off_y, f3& o, f3& d) {
+	pixel_ray_raw<LENS>(p, x, y, off_x, off_y, p.slice_plane_z, o, d);
 	float n = sqrtf(dot3(d, d));
 	d = {d.x / n, d.y / n, d.z / n};
 }
 
+template <bool LENS = false>
 __device__ __forceinline__ Ray init_ray(const nrs_render_params& p, uint32_t x, uint32_t y, float off_x, float off_y) {
 	Ray r;
-	ray_origin_dir(p, x, y, off_x, off_y, r.o, r.d);
+	ray_origin_dir<LENS>(p, x, y, off_x, off_y, r.o, r.d);
 	float tmin;
 	ray_intersect(p.render_aabb_min, p.render_aabb_max, r.o, r.d, tmin);
 	r.t = fmaxf(tmin, NRS_NEAR_DISTANCE) + 1e-6f;
@@ -631,6 +661,34 @@ __device__ __forceinline__ bool poisson_residual_density(const DeviceEdit& e, f3
 	bary_tet(a, b, c, d, pos, bc);
 	residual = ((bc[0] * e.res_density[tv.x] + bc[1] * e.res_density[tv.y]) + bc[2] * e.res_density[tv.z]) + bc[3] * e.res_density[tv.w];
 	return true;
+}
+
+// composite_kernel_nerf's per-sample render modes (tn:905-937): what replaces the network's colour.  pos = the (mapped) sample position in world
+// units, origin = payload.origin, cdt = unwarp_dt(input->dt), alpha after the show_accel override.  Normals / EncodingVis are refused by the host.
+__device__ __forceinline__ void render_mode_rgb(const nrs_render_params& p, f3 pos, f3 origin, f3 cam_fwd, float cdt, float alpha, float& r, float& g, float& b) {
+	switch (p.render_mode) {
+		case NRS_RENDER_POSITIONS:
+			if (p.show_accel) { // colour of the occupancy cell the sample stands in (tn:911-920); tcnn::default_rng_t = pcg32(initstate, initseq 1)
+				const uint32_t mip = (uint32_t)max((int)p.min_mip, mip_from_pos(pos));
+				const float res = (float)(kGrid >> mip);
+				const int ix = (int)(pos.x * res), iy = (int)(pos.y * res), iz = (int)(pos.z * res);
+				Pcg32 rng{0ull, 3ull};
+				rng.next_uint();
+				rng.state += (uint64_t)(int64_t)(int)((uint32_t)ix + (uint32_t)iy * 232323u + (uint32_t)iz * 727272u);
+				rng.next_uint();
+				r = 1.f - (float)mip * (1.f / (float)(kCascades - 1));
+				g = rng.next_float();
+				b = rng.next_float();
+			} else {
+				r = (pos.x - 0.5f) / 2.0f + 0.5f; g = (pos.y - 0.5f) / 2.0f + 0.5f; b = (pos.z - 0.5f) / 2.0f + 0.5f;
+			}
+			break;
+		case NRS_RENDER_DEPTH: r = g = b = dot3(cam_fwd, pos - origin) * p.depth_scale; break;
+		case NRS_RENDER_DISTANCE: { const f3 dv = pos - origin; r = g = b = sqrtf(dot3(dv, dv)) * p.depth_scale; break; }
+		case NRS_RENDER_STEPSIZE: r = g = b = warp_dt(cdt); break;
+		case NRS_RENDER_AO: r = g = b = alpha; break;
+		default: break; // Shade, Cost: the network's colour
+	}
 }
 
 // ---- activations (cn:38-66) and shade (common_device.cuh:31-37) ---------------------------------------------------

@@ -119,6 +119,7 @@ struct RenderArgs {
 	int32_t  n_edits;
 	uint32_t any_poisson;      // some edit has apply_poisson set
 	uint32_t any_affine;       // some edit is an AffineDuplication
+	uint32_t extra;            // a render mode other than Shade / Cost, show_accel or dof != 0: render_kernel's EXTRA instantiation
 	uint32_t n_packets;        // pixel packets owned by this call (8x8 pixels; 8x4 / 4x4 with lane teams of 2 / 4)
 	uint32_t tiles_x;          // image width in tiles (tiled mode) or in packets (whole-image mode)
 	uint32_t packets_per_tile_x;
@@ -141,6 +142,8 @@ struct RenderArgs {
 
 // kernel launchers (nrs_kernels.hip).  stream is a hipStream_t.
 int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* stream);
+// render mode Slice (Testbed::render_nerf's branch, testbed_nerf.cu:3111-3175): one network evaluation per owned pixel on the slice plane
+int launch_slice(const DeviceModel& m, const RenderArgs& a, int n_cus, void* stream);
 int launch_trace_samples(const DeviceModel& m, const nrs_render_params& p, uint32_t n_pixels, const uint32_t* d_pixel_idx,
                          uint32_t max_samples, float* d_t, float* d_dt, uint32_t* d_count, void* stream);
 // mode 0: full inference (16 channels, c3 = density), 1: density MLP outputs, 2: hash-grid features [n x 32]

@@ -127,11 +127,6 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 // WAVES = waves per workgroup (they share one LDS copy of the weights); OCC = waves per SIMD the register allocator must
 // leave room for (__launch_bounds__' second argument).
 // PROF adds s_memtime stamps around the phases of a round (NRS_DEBUG & 4); the production instantiation has none.
-#ifdef NRS_MARKERS // ISA listing with phase boundaries (make isa-markers): comments only, for counting instructions per phase
-#define NRS_MARK(i) asm volatile("; NRS_MARK " #i)
-#else
-#define NRS_MARK(i)
-#endif
 #ifdef NRS_MARKERS // ISA listing with phase boundaries (tools/isa_phases.py): comments only, for counting instructions per phase
 #define NRS_MARK(i) asm volatile("; NRS_MARK " #i)
 #else
@@ -139,7 +134,6 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 #endif
 #define NRS_PHASE(i)                                                         \
 	do {                                                                     \
-		NRS_MARK(i);                                                         \
 		NRS_MARK(i);                                                         \
 		if (PROF) {                                                          \
 			const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
@@ -191,8 +185,13 @@ __device__ __forceinline__ bool packet_pixel_tail(const RenderArgs& a, uint32_t 
 // team composites the TEAM samples in order (identical float operations => identical accumulators in every lane, the
 // result of the sequential loop bit for bit) and walks TEAM samples on.  Samples past the one that saturates the ray are
 // discarded, as the reference discards the rest of a batch (tn:951-960).  The fill works on 64 / TEAM pixels per packet.
-// NUM: the non-default tiny-cuda-nn roundings (DeviceModel::numerics: bit 0 grid accumulation in network precision, bit 1 fp16 MLP accumulators)
-template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0>
+// NUM: 0 = the default roundings compiled in; kNumRuntime = tiny-cuda-nn's other roundings chosen at run time from DeviceModel::numerics (bit 0 grid
+//      accumulation in network precision, bit 1 fp16 MLP accumulators; wave-uniform branches, both flavours in the code): every schedule and every
+//      operator combination has such a twin, so no entry point refuses a rounding mode.
+// EXTRA: the rest of render_nerf's surface -- composite_kernel_nerf's per-sample render modes (AO / Positions / Depth / Distance / Stepsize, tn:905-937),
+//      show_accel's opaque samples (tn:788-790), shade's mode handling (tn:2466-2478) and pixel_to_ray's thin-lens branch (common_device.cuh:285-293).
+//      A separate instantiation (one lane per ray): the Shade / Cost kernels carry none of it.
+template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0, bool EXTRA = false>
 __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const RenderArgs& a_arg) {
 	// The two argument structs (~1.3 KB of wave-uniform values) live in the kernel-argument segment and are read with scalar loads.
 	// Left alone, the compiler hoists every such load out of the frame loop and then spills ~150 scalar registers into VGPR lanes
@@ -222,6 +221,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 	FeatLds& fl = sm.fl[wave];
 	const GridView gv = make_grid_view(m);
 	const nrs_render_params& p = a.p;
+	const uint32_t nm = NUM == kNumRuntime ? (uint32_t)__builtin_amdgcn_readfirstlane((int)m.numerics) : (uint32_t)NUM;
 	const bool ops = p.apply_operators && a.n_edits > 0;
 	const f3 cam_fwd = mk3(p.camera_matrix1[6], p.camera_matrix1[7], p.camera_matrix1[8]);
 	const f3 cam_o = mk3(p.camera_matrix1[9], p.camera_matrix1[10], p.camera_matrix1[11]);
@@ -319,7 +319,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			}
 			const bool first_of_team = TEAM == 0 ? (!small || (lane & 3) == 0) : tk == 0;
 			if (inside) {
-				Ray r = init_ray(p1, x, y, off_x, off_y);
+				Ray r = init_ray<EXTRA>(p1, x, y, off_x, off_y);
 				if (first_of_team) {
 					a1.depth[oi] = 1e10f; // tn:2586
 					if (a1.steps) a1.steps[oi] = 0;
@@ -359,7 +359,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			if (!have && rank < take) {
 				const uint2 e = ring[(ring_head + rank) & (kRing - 1)];
 				const uint32_t x = e.x & 0xffffu, y = e.x >> 16;
-				ray_origin_dir(p1, x, y, off_x, off_y, o, d); // same arithmetic as at enqueue time -> same bits
+				ray_origin_dir<EXTRA>(p1, x, y, off_x, off_y, o, d); // same arithmetic as at enqueue time -> same bits
 				t = __uint_as_float(e.y);
 				out_idx = pixel_out_idx(a1, x, y);
 				cr = cg = cb = ca = 0.f;
@@ -413,12 +413,12 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			}
 			has_res = have && p_out > 1e-9f;
 			if (__any(has_res)) { // the reference evaluates the un-deformed network everywhere; only these samples consume it (tn:770-773)
-				encode_to_lds<(NUM & 1) != 0>(gv, m2.levels, sm.ml, fl, lane, g, wpos0, has_res);
+				encode_num<NUM>(nm, gv, m2.levels, sm.ml, fl, lane, g, wpos0, has_res);
 				uint32_t old_d = 0;
 				#pragma unroll 1
 				for (int b = 0; b < 2; ++b) {
 					const int sel = (b != g) ? 1 : 0;
-					const half8 dout = density_mlp<(NUM & 2) != 0>(sm.ml.w, lane, load_features(fl, lane, sel, 0), load_features(fl, lane, sel, 1));
+					const half8 dout = density_mlp_num<NUM>(nm, sm.ml.w, lane, load_features(fl, lane, sel, 0), load_features(fl, lane, sel, 1));
 					uint32_t vd = __builtin_bit_cast(u32x4, dout)[0];
 					if (b == 1) vd = xchg32u(vd);
 					if (g == b) old_d = vd;
@@ -429,7 +429,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 
 		NRS_PHASE(3); // gather
 		// ---- gather: own sample (block g) and the partner lane's sample (block 1-g), levels 2*it+g ----
-		encode_to_lds<(NUM & 1) != 0>(gv, m2.levels, sm.ml, fl, lane, g, wpos, act);
+		encode_num<NUM>(nm, gv, m2.levels, sm.ml, fl, lane, g, wpos, act);
 		NRS_PHASE(4); // SH + MLP
 		const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
 		half8 sh_own, sh_par;
@@ -443,8 +443,8 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
 			half8 dout = x0, rout = x1;
 			if (!(a2.dbg & 2u)) {
-				dout = density_mlp<(NUM & 2) != 0>(sm.ml.w, lane, x0, x1);
-				rout = rgb_mlp<(NUM & 2) != 0>(sm.ml.w, lane, dout, sel ? sh_par : sh_own);
+				dout = density_mlp_num<NUM>(nm, sm.ml.w, lane, x0, x1);
+				rout = rgb_mlp_num<NUM>(nm, sm.ml.w, lane, dout, sel ? sh_par : sh_own);
 			}
 			const u32x4 dd = __builtin_bit_cast(u32x4, dout), rr = __builtin_bit_cast(u32x4, rout);
 			// rows 0..2 of a block sit in its lanes 0..31; block 1's samples belong to the rays of lanes 32..63
@@ -476,7 +476,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				s_depth = dot3(cam_fwd, cpos - cam_o);
 			}
 			// every lane of the team composites the team's samples in marching order (composite_kernel_nerf, tn:750-955)
-			bool done = false, shade = true;
+			bool done = false, shade = true, exited = false; // exited: the ray left the render box un-saturated (Cost mode counts one more step for it, below)
 			#pragma unroll
 			for (int k = 0; k < (TEAM ? TEAM : 4); ++k) {
 				if (TEAM == 0 && k >= (int)gen_t) break;
@@ -486,7 +486,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				const float kdepth = __shfl(s_depth, src, 64);
 				if (have && !done) {
 					if (!v_k) {
-						done = true; // the walk after the previous sample left the render box
+						done = true; exited = true; // the walk after the previous sample left the render box
 					} else {
 						const float weight = al * (1.f - ca);
 						cr += kr * weight;
@@ -518,13 +518,15 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				}
 			}
 			const bool lead_valid = __shfl((int)valid, team_base, 64) != 0;
-			if (have && !done && !lead_valid) done = true; // no further sample: the ray is finished now rather than a round later
+			if (have && !done && !lead_valid) { done = true; exited = true; } // no further sample: the ray is finished now rather than a round later
 			if (have && done) {
 				if (tk == 0) {
 					if (shade && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
 						float tr = cr, tg = cg, tb = cb, ta = ca;
 						if (p3.render_mode == NRS_RENDER_COST) {
-							const float col = (float)n_steps / 128;
+							// payload.n_steps = j + current_step (tn:957-960): the samples composited for a ray that saturated (the loop broke AT sample j),
+							// one more for a ray that ran out of samples (j is then the count, and current_step starts at 1)
+							const float col = (float)(n_steps + (exited ? 1u : 0u)) / 128;
 							tr = tg = tb = col; ta = 1.0f;
 						} else if (!p3.linear_colors) {
 							tr = srgb_to_linear(tr); tg = srgb_to_linear(tg); tb = srgb_to_linear(tb);
@@ -553,8 +555,10 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				alpha = 1.f - __expf(-(val) * cdt);
 			}
 			if (empty) alpha = 0.0f;
+			if (EXTRA && p3.show_accel) alpha = 1.f; // tn:788-790
 			const float weight = alpha * T;
-			const float sr = network_to_rgb(raw_r, m3.rgb_activation), sg = network_to_rgb(raw_g, m3.rgb_activation), sb = network_to_rgb(raw_b, m3.rgb_activation);
+			float sr = network_to_rgb(raw_r, m3.rgb_activation), sg = network_to_rgb(raw_g, m3.rgb_activation), sb = network_to_rgb(raw_b, m3.rgb_activation);
+			if (EXTRA) render_mode_rgb(p3, cpos, o, cam_fwd, cdt, alpha, sr, sg, sb); // tn:905-937
 			if (POISSON && has_res) { // tn:796-805, 939-943
 				const float alpha_N = 1.f - __expf(-sigma * cdt);
 				const float alpha_R = 1.f - __expf(-p_out * cdt);
@@ -574,7 +578,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			}
 			++n_steps;
 			++st_samples;
-			bool done = false, shade = true;
+			bool done = false, shade = true, exited = false;
 			if (ca > (1.0f - p3.min_transmittance)) {
 				// rgba /= alpha (tn:951-953): one v_rcp (1 ulp) + three multiplies instead of four IEEE divisions -- this block runs
 				// nearly every round (some lane of the wave saturates), and the colour tolerance (tests) is 5 orders of magnitude wider
@@ -588,14 +592,15 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				f3 npos; float ndt;
 				const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // recomputed (IEEE, same bits) rather than held across the round
 				done = !march_to_occupied(p3, m3, sm.coarse, o, d, idir, t, npos, ndt, PROF ? &it_march : nullptr);
+				exited = done;
 			}
 			if (done) {
 				if (shade && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
 					float tr = cr, tg = cg, tb = cb, ta = ca;
 					if (p3.render_mode == NRS_RENDER_COST) {
-						const float col = (float)n_steps / 128;
+						const float col = (float)(n_steps + (exited ? 1u : 0u)) / 128; // payload.n_steps = j + current_step, tn:957-960 (see the team path)
 						tr = tg = tb = col; ta = 1.0f;
-					} else if (!p3.linear_colors) {
+					} else if (!p3.linear_colors && (!EXTRA || p3.render_mode == NRS_RENDER_SHADE)) { // tn:2474: only Shade (and Slice) accumulate in linear colours
 						tr = srgb_to_linear(tr); tg = srgb_to_linear(tg); tb = srgb_to_linear(tb);
 					}
 					float4* fb = reinterpret_cast<float4*>(a3.frame) + out_idx;
@@ -654,9 +659,9 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 	}
 }
 
-template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0>
+template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0, bool EXTRA = false>
 __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceModel m_arg, const RenderArgs a_arg) {
-	render_body<WAVES, OCC, PROF, POISSON, AFFINE, TEAM, NUM>(m_arg, a_arg);
+	render_body<WAVES, OCC, PROF, POISSON, AFFINE, TEAM, NUM, EXTRA>(m_arg, a_arg);
 }
 // The same kernel scheduled for 3 waves per SIMD but held to the 128 VGPRs that still give 4 (512-thread workgroups, 2 per CU): the
 // scheduler hides more latency per wave when it does not aim at occupancy 4, and the cap keeps the occupancy it did not aim at.
@@ -680,17 +685,17 @@ static int launch_render_c128(const DeviceModel& m, const RenderArgs& a, int n_c
 	return NRS_OK;
 }
 
-template <int WAVES, int OCC, bool PROF = false, bool POISSON = false, bool AFFINE = false, int TEAM = 1, int NUM = 0>
+template <int WAVES, int OCC, bool PROF = false, bool POISSON = false, bool AFFINE = false, int TEAM = 1, int NUM = 0, bool EXTRA = false>
 static int launch_render_cfg(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream) {
 	int blocks_per_cu = 0;
-	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC, PROF, POISSON, AFFINE, TEAM, NUM>, 64 * WAVES, 0);
+	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC, PROF, POISSON, AFFINE, TEAM, NUM, EXTRA>, 64 * WAVES, 0);
 	if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(render_kernel)");
 	if (blocks_per_cu < 1) blocks_per_cu = 1;
 	uint32_t grid = (uint32_t)(n_cus * blocks_per_cu);
 	const uint32_t max_useful = (a.n_packets + WAVES - 1) / WAVES; // at least one packet per wave
 	if (grid > max_useful) grid = max_useful;
 	if (grid == 0) return NRS_OK;
-	hipLaunchKernelGGL((render_kernel<WAVES, OCC, PROF, POISSON, AFFINE, TEAM, NUM>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
+	hipLaunchKernelGGL((render_kernel<WAVES, OCC, PROF, POISSON, AFFINE, TEAM, NUM, EXTRA>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
 	NRS_LAUNCH_CHECK("render_kernel launch");
 	return NRS_OK;
 }
@@ -703,12 +708,16 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 		return e ? atoi(e) : 0;
 	}();
 	hipStream_t s = (hipStream_t)stream;
-	if (m.numerics) { // non-default tiny-cuda-nn roundings: one lane per ray, cage edits only (checked by nrs_render_nerf)
-		switch (m.numerics & 3u) {
-			case 1: return launch_render_cfg<8, 3, false, false, false, 1, 1>(m, a, n_cus, s);
-			case 2: return launch_render_cfg<8, 3, false, false, false, 1, 2>(m, a, n_cus, s);
-			default: return launch_render_cfg<8, 3, false, false, false, 1, 3>(m, a, n_cus, s);
-		}
+	constexpr int R = kNumRuntime;
+	if (a.extra) // render modes / show_accel / depth of field: the catch-all instantiation (every operator kind, membrane correction, one lane per ray)
+		return m.numerics ? launch_render_cfg<8, 2, false, true, true, 1, R, true>(m, a, n_cus, s) : launch_render_cfg<8, 2, false, true, true, 1, 0, true>(m, a, n_cus, s);
+	if (m.numerics) { // tiny-cuda-nn's other roundings: the run-time twin of every schedule (nrs_render_nerf computed the packet geometry for a.team)
+		if (a.any_poisson) return launch_render_cfg<8, 2, false, true, true, 1, R>(m, a, n_cus, s);
+		if (a.any_affine) return launch_render_cfg<8, 3, false, false, true, 1, R>(m, a, n_cus, s);
+		if (a.team == 0) return launch_render_cfg<8, 3, false, false, false, 0, R>(m, a, n_cus, s);
+		if (a.team == 2) return launch_render_cfg<8, 3, false, false, false, 2, R>(m, a, n_cus, s);
+		if (a.team == 4) return launch_render_cfg<8, 3, false, false, false, 4, R>(m, a, n_cus, s);
+		return launch_render_cfg<8, 3, false, false, false, 1, R>(m, a, n_cus, s);
 	}
 	if (a.any_poisson) return launch_render_cfg<8, 2, false, true, true>(m, a, n_cus, s);
 	if (a.dbg & 4u) return a.team == 0 ? launch_render_cfg<8, 4, true, false, false, 0>(m, a, n_cus, s) : launch_render_cfg<8, 4, true>(m, a, n_cus, s);
@@ -730,6 +739,97 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 	if (a.team == 2) return launch_render_c128<8, false, false, false, 2>(m, a, n_cus, s);
 	if (a.team == 4) return launch_render_c128<8, false, false, false, 4>(m, a, n_cus, s);
 	return launch_render_c128<8>(m, a, n_cus, s);
+}
+
+// per-workgroup LDS of the kernels that run the network on caller batches: the weights + one feature slab per wave
+template <int WAVES>
+struct NetSmemT {
+	ModelLds ml;
+	FeatLds fl[WAVES];
+};
+typedef NetSmemT<4> NetSmem;
+
+// ---- render mode Slice ------------------------------------------------------------------------------------------------
+// Testbed::render_nerf's Slice branch (tn:3068-3070, 3109-3162): init_rays_with_payload_kernel_nerf with plane_z < 0 leaves every pixel's ray
+// standing on the plane at distance |plane_z| along the view axis (tn:2575-2585: t = -plane_z * |d|, depth buffer = -plane_z, no render-box test);
+// generate_nerf_network_inputs_at_current_position (tn:616-622) -> NerfNetwork::inference -> compute_nerf_density (tn:624-635: a = 1 - exp(-sigma / 100),
+// premultiplied colour) -> shade_kernel_nerf (srgb_to_linear, alpha-over the frame, NO depth write, tn:2474-2482).  One launch: a wave takes an
+// 8x8-pixel packet (the render kernel's packet geometry, whole image or owned tiles), a lane a pixel.
+template <int NUM>
+__global__ __launch_bounds__(256) void slice_kernel(const DeviceModel m, const RenderArgs a) {
+	__shared__ NetSmem sm;
+	stage_model_to_lds(m, sm.ml);
+	const int lane = threadIdx.x & 63;
+	const int g = lane >> 5;
+	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+	const GridView gv = make_grid_view(m);
+	const nrs_render_params& p = a.p;
+	const uint32_t nm = NUM == kNumRuntime ? (uint32_t)__builtin_amdgcn_readfirstlane((int)m.numerics) : (uint32_t)NUM;
+	float off_x, off_y;
+	ld_random_pixel_offset(p.snap_to_pixel_centers ? 0u : p.spp_index, off_x, off_y);
+	const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+	uint32_t n_px = 0;
+	for (uint32_t pk = wave_global; pk < a.n_packets; pk += n_waves) {
+		uint32_t x, y, oi;
+		const bool have = packet_pixel<1>(a, pk, lane, x, y, oi);
+		f3 wpos = mk3(0, 0, 0), wdir = mk3(0.5f, 0.5f, 0.5f);
+		if (have) {
+			f3 o, d;
+			pixel_ray_raw<false>(p, x, y, off_x, off_y, 1.0f, o, d); // (dof = 0 when plane_z < 0, tn:2543-2545)
+			const float n = sqrtf(dot3(d, d));
+			const f3 dir = (1.0f / n) * d;
+			const float t = p.slice_plane_z * n; // -plane_z * n, plane_z = -(m_slice_plane_z + m_scale)
+			wpos = warp_position(o + dir * t, m.aabb);
+			wdir = warp_direction(dir);
+			a.depth[oi] = p.slice_plane_z; // tn:2583
+			if (a.steps) a.steps[oi] = 0;
+			++n_px;
+		}
+		encode_num<NUM>(nm, gv, m.levels, sm.ml, fl, lane, g, wpos, have);
+		const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
+		half8 sh_own, sh_par;
+		encode_sh4_2(g, wdir, pdir, sh_own, sh_par);
+		uint32_t res_d = 0, res_rg = 0, res_b = 0;
+		#pragma unroll 1
+		for (int b = 0; b < 2; ++b) {
+			const int sel = (b != g) ? 1 : 0;
+			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
+			const half8 dout = density_mlp_num<NUM>(nm, sm.ml.w, lane, x0, x1);
+			const half8 rout = rgb_mlp_num<NUM>(nm, sm.ml.w, lane, dout, sel ? sh_par : sh_own);
+			const u32x4 dd = __builtin_bit_cast(u32x4, dout), rr = __builtin_bit_cast(u32x4, rout);
+			uint32_t vd = dd[0], vrg = rr[0], vb = rr[1];
+			if (b == 1) { vd = xchg32u(vd); vrg = xchg32u(vrg); vb = xchg32u(vb); }
+			if (g == b) { res_d = vd; res_rg = vrg; res_b = vb; }
+		}
+		if (!have) continue;
+		const half2v hd = __builtin_bit_cast(half2v, res_d), hrg = __builtin_bit_cast(half2v, res_rg), hb = __builtin_bit_cast(half2v, res_b);
+		const float alpha = clampf_(1.f - __expf(-network_to_density((float)hd[0], m.density_activation) / 100.0f), 0.0f, 1.0f);
+		float tr = network_to_rgb((float)hrg[0], m.rgb_activation) * alpha, tg = network_to_rgb((float)hrg[1], m.rgb_activation) * alpha,
+		      tb = network_to_rgb((float)hb[0], m.rgb_activation) * alpha;
+		if (!p.linear_colors) { tr = srgb_to_linear(tr); tg = srgb_to_linear(tg); tb = srgb_to_linear(tb); }
+		float4* fb = reinterpret_cast<float4*>(a.frame) + oi;
+		const float4 prev = *fb;
+		const float om = 1.0f - alpha;
+		*fb = make_float4(tr + prev.x * om, tg + prev.y * om, tb + prev.z * om, alpha + prev.w * om);
+	}
+	// statistics: one evaluated sample, one initialised and one shaded ray per pixel (trace() is not run: n_hit = n_rays_initialized, tn:3109)
+	for (int sh = 32; sh > 0; sh >>= 1) n_px += (uint32_t)__shfl_xor((int)n_px, sh, 64);
+	if (lane == 0 && n_px) {
+		atomicAdd(&a.counters->n_samples, (unsigned long long)n_px);
+		atomicAdd(&a.counters->n_rays_alive, n_px);
+		atomicAdd(&a.counters->n_rays_hit, n_px);
+	}
+}
+int launch_slice(const DeviceModel& m, const RenderArgs& a, int n_cus, void* stream) {
+	if (a.n_packets == 0) return NRS_OK;
+	uint32_t grid = (a.n_packets + 3) / 4;
+	const uint32_t cap = (uint32_t)n_cus * 8;
+	if (grid > cap) grid = cap;
+	if (m.numerics) hipLaunchKernelGGL(slice_kernel<kNumRuntime>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m, a);
+	else hipLaunchKernelGGL(slice_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m, a);
+	NRS_LAUNCH_CHECK("slice_kernel launch");
+	return NRS_OK;
 }
 
 // ---- trace_samples ------------------------------------------------------------------------------------------------
@@ -769,13 +869,6 @@ int launch_trace_samples(const DeviceModel& m, const nrs_render_params& p, uint3
 	return NRS_OK;
 }
 
-// ---- NerfNetwork operator on caller batches ----------------------------------------------------------------------------
-template <int WAVES>
-struct NetSmemT {
-	ModelLds ml;
-	FeatLds fl[WAVES];
-};
-typedef NetSmemT<4> NetSmem;
 
 // ---- selection rays ------------------------------------------------------------------------------------------------
 // GrowingSelection::project_selection_pixels (growing_selection.cu:1832-2035) in one launch: shoot_selection_rays_kernel
@@ -794,9 +887,11 @@ struct SelectionArgs {
 	uint32_t* cells;       // [n]
 	uint8_t* found;        // [n]
 };
+template <int NUM>
 __global__ __launch_bounds__(256) void selection_rays_kernel(const DeviceModel m, const SelectionArgs a) {
 	__shared__ NetSmem sm;
 	stage_model_to_lds(m, sm.ml);
+	const uint32_t nm = NUM == kNumRuntime ? (uint32_t)__builtin_amdgcn_readfirstlane((int)m.numerics) : (uint32_t)NUM;
 	const int lane = threadIdx.x & 63;
 	const int g = lane >> 5;
 	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
@@ -850,12 +945,12 @@ __global__ __launch_bounds__(256) void selection_rays_kernel(const DeviceModel m
 			have = false;
 		}
 		if (!__any(have)) break;
-		encode_to_lds(gv, m.levels, sm.ml, fl, lane, g, wpos, have);
+		encode_num<NUM>(nm, gv, m.levels, sm.ml, fl, lane, g, wpos, have);
 		uint32_t res_d = 0;
 		#pragma unroll 1
 		for (int b = 0; b < 2; ++b) {
 			const int sel = (b != g) ? 1 : 0;
-			const half8 dout = density_mlp(sm.ml.w, lane, load_features(fl, lane, sel, 0), load_features(fl, lane, sel, 1));
+			const half8 dout = density_mlp_num<NUM>(nm, sm.ml.w, lane, load_features(fl, lane, sel, 0), load_features(fl, lane, sel, 1));
 			uint32_t vd = __builtin_bit_cast(u32x4, dout)[0];
 			if (b == 1) vd = xchg32u(vd);
 			if (g == b) res_d = vd;
@@ -874,7 +969,8 @@ int launch_selection_rays(const DeviceModel& m, const nrs_render_params& p, cons
 	if (n == 0) return NRS_OK;
 	SelectionArgs a{};
 	a.p = p; a.pixels = d_pixels; a.n = n; a.threshold = threshold; a.positions = d_positions; a.cells = d_cells; a.found = d_found;
-	hipLaunchKernelGGL(selection_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, m, a);
+	if (m.numerics) hipLaunchKernelGGL(selection_rays_kernel<kNumRuntime>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, m, a);
+	else hipLaunchKernelGGL(selection_rays_kernel<0>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, m, a);
 	NRS_LAUNCH_CHECK("selection_rays_kernel launch");
 	return NRS_OK;
 }
@@ -1151,10 +1247,11 @@ struct GridEvalArgs {
 	const float* density_grid;   // MODE 0: nullable
 	float* out;                  // MODE 0: float [n]; MODE 1: float4 [n]
 };
-template <int MODE>
+template <int MODE, int NUM>
 __global__ __launch_bounds__(256) void grid_eval_kernel(const DeviceModel m, const GridEvalArgs a) {
 	__shared__ NetSmem sm;
 	stage_model_to_lds(m, sm.ml);
+	const uint32_t nm = NUM == kNumRuntime ? (uint32_t)__builtin_amdgcn_readfirstlane((int)m.numerics) : (uint32_t)NUM;
 	const int lane = threadIdx.x & 63;
 	const int g = lane >> 5, j = lane & 31;
 	FeatLds& fl = sm.fl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
@@ -1175,7 +1272,7 @@ __global__ __launch_bounds__(256) void grid_eval_kernel(const DeviceModel m, con
 			          pos.z * (a.box_mx[2] - a.box_mn[2]) + a.box_mn[2]);
 			wpos = warp_position(pos, m.aabb);
 		}
-		encode_to_lds(gv, m.levels, sm.ml, fl, lane, g, wpos, have);
+		encode_num<NUM>(nm, gv, m.levels, sm.ml, fl, lane, g, wpos, have);
 		half8 sh;
 		if (MODE == 1) sh = encode_sh4(g, wdir);
 		uint32_t res_d = 0, res_rg = 0, res_b = 0;
@@ -1183,9 +1280,9 @@ __global__ __launch_bounds__(256) void grid_eval_kernel(const DeviceModel m, con
 		for (int b = 0; b < 2; ++b) {
 			const int sel = (b != g) ? 1 : 0;
 			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
-			const half8 dout = density_mlp(sm.ml.w, lane, x0, x1);
+			const half8 dout = density_mlp_num<NUM>(nm, sm.ml.w, lane, x0, x1);
 			half8 rout = dout;
-			if (MODE == 1) rout = rgb_mlp(sm.ml.w, lane, dout, sh);
+			if (MODE == 1) rout = rgb_mlp_num<NUM>(nm, sm.ml.w, lane, dout, sh);
 			const u32x4 dd = __builtin_bit_cast(u32x4, dout), rr = __builtin_bit_cast(u32x4, rout);
 			uint32_t vd = dd[0], vrg = rr[0], vb = rr[1]; // rows 0..2 of a block sit in lanes 0..31
 			if (b == 1) { vd = xchg32u(vd); vrg = xchg32u(vrg); vb = xchg32u(vb); }
@@ -1220,11 +1317,12 @@ int launch_grid_eval(const DeviceModel& m, int mode, const uint32_t res[3], cons
 	const uint32_t n = res[0] * res[1] * res[2];
 	if (n == 0) return NRS_OK;
 	const uint32_t n_tiles = (n + 63) / 64;
-	uint32_t grid = (n_tiles + kNetWaves - 1) / kNetWaves;
-	const uint32_t cap = (uint32_t)n_cus * 2; // resident workgroups: the tiles are strided over them
+	uint32_t grid = (n_tiles + 3) / 4; // 256-thread workgroups: 4 waves, a tile each per trip
+	const uint32_t cap = (uint32_t)n_cus * 8; // resident workgroups: the tiles are strided over them
 	if (grid > cap) grid = cap;
-	if (mode == 0) hipLaunchKernelGGL(grid_eval_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m, a);
-	else hipLaunchKernelGGL(grid_eval_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, m, a);
+	constexpr int R = kNumRuntime;
+	if (mode == 0) { if (m.numerics) hipLaunchKernelGGL((grid_eval_kernel<0, R>), dim3(grid), dim3(256), 0, (hipStream_t)stream, m, a); else hipLaunchKernelGGL((grid_eval_kernel<0, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, m, a); }
+	else { if (m.numerics) hipLaunchKernelGGL((grid_eval_kernel<1, R>), dim3(grid), dim3(256), 0, (hipStream_t)stream, m, a); else hipLaunchKernelGGL((grid_eval_kernel<1, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, m, a); }
 	NRS_LAUNCH_CHECK("grid_eval_kernel launch");
 	return NRS_OK;
 }
@@ -1469,7 +1567,9 @@ __host__ __device__ constexpr uint32_t inverse_mod_2_32(uint32_t k) { // Newton:
 constexpr uint32_t kSampleMulInv = inverse_mod_2_32(kSampleMul) & (kGridVol - 1u);
 static_assert(((kSampleMul * kSampleMulInv) & (kGridVol - 1u)) == 1u, "inverse of the sample multiplier mod 2^21");
 
+template <int NUM>
 __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, const GridUpdateArgs a) {
+	const uint32_t nm = NUM == kNumRuntime ? (uint32_t)__builtin_amdgcn_readfirstlane((int)m.numerics) : (uint32_t)NUM;
 	__shared__ NetSmem sm;
 	__shared__ uint64_t wrap_mult[65], wrap_plus[65];
 	if (threadIdx.x < 65) Pcg32::skip_coefficients(a.rng_inc, 0ull - ((uint64_t)threadIdx.x << 23), wrap_mult[threadIdx.x], wrap_plus[threadIdx.x]);
@@ -1520,13 +1620,13 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 			f3 unused = mk3(0.5f, 0.5f, 0.5f);
 			for (int k = a.n_edits - 1; k >= 0; --k) (void)edit_warp(a.edits[k], false, wpos, unused);
 		}
-		encode_to_lds(gv, m.levels, sm.ml, fl, lane, g, wpos, have);
+		encode_num<NUM>(nm, gv, m.levels, sm.ml, fl, lane, g, wpos, have);
 		_Float16 raw_b[2];
 		#pragma unroll 1
 		for (int b = 0; b < 2; ++b) {
 			const int sel = (b != g) ? 1 : 0;
 			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
-			const half8 dout = density_mlp(sm.ml.w, lane, x0, x1);
+			const half8 dout = density_mlp_num<NUM>(nm, sm.ml.w, lane, x0, x1);
 			raw_b[b] = dout[0]; // row 0 of sample 32*b + (lane & 31) sits on the g == 0 lanes
 		}
 		// lane l < 32 owns block 0's sample l; lane 32 + j owns block 1's sample, computed on lane j
@@ -1578,7 +1678,8 @@ int launch_grid_update(const DeviceModel& m, const DeviceEdit* d_edits, int n_ed
 		uint32_t grid = (n_tiles + 3) / 4;
 		const uint32_t cap = (uint32_t)n_cus * 8;
 		if (grid > cap) grid = cap;
-		hipLaunchKernelGGL(grid_refresh_kernel, dim3(grid), dim3(256), 0, s, m, a);
+		if (m.numerics) hipLaunchKernelGGL(grid_refresh_kernel<kNumRuntime>, dim3(grid), dim3(256), 0, s, m, a);
+		else hipLaunchKernelGGL(grid_refresh_kernel<0>, dim3(grid), dim3(256), 0, s, m, a);
 		NRS_LAUNCH_CHECK("grid_refresh_kernel launch");
 	}
 	hipLaunchKernelGGL(grid_ema_kernel, dim3((n_elements + 255) / 256), dim3(256), 0, s, n_elements, u.decay, d_grid, d_grid_tmp);

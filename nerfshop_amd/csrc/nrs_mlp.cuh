@@ -235,6 +235,16 @@ __device__ __forceinline__ void issue_brick_record_loads(const GridView& gv, con
 	v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
 }
 
+// One sample at one sparse level when not every lane of the wave has a brick: records where the lane has one, else the level's own index function.
+template <bool NETACC>
+__device__ __forceinline__ uint32_t sparse_fallback(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t brick) {
+	uint32_t v[8];
+	if (brick) issue_brick_record_loads(gv, lp, c, brick, v);
+	else if (lp.hashed) issue_gathers<true>(gv, lp, c, v);
+	else return level_eval_exact<NETACC>(gv, lp, c); // dense level: exact tcnn index incl. the wrap at `count`
+	return interpolate<NETACC>(c, v);
+}
+
 // Issue the loads of one sample at one level of kind KIND (the level parameters are wave-uniform: scalar registers).
 template <int KIND>
 __device__ __forceinline__ void issue_level(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t v[8]) {
@@ -259,9 +269,13 @@ __device__ __forceinline__ void level_eval_two(const GridView& gv, const LevelPa
 		if (__builtin_expect(__all(b0 != 0u && b1 != 0u), 1)) {
 			issue_brick_record_loads(gv, lp0, c0, b0, v0);
 			issue_brick_record_loads(gv, lp1, c1, b1, v1);
-		} else { // some lane stands where the mask promised no lookups: that lane gathers the hashed way (same values)
-			if (b0) issue_brick_record_loads(gv, lp0, c0, b0, v0); else issue_gathers<true>(gv, lp0, c0, v0);
-			if (b1) issue_brick_record_loads(gv, lp1, c1, b1, v1); else issue_gathers<true>(gv, lp1, c1, v1);
+		} else { // some lane stands where the mask promised no lookups: that lane gathers the level's native way (same values).  A sparse level need
+			// not be hashed (a small dense budget leaves dense levels to the sparse records): those lanes take the exact dense index.
+			f0 = sparse_fallback<NETACC>(gv, lp0, c0, b0);
+			f1 = sparse_fallback<NETACC>(gv, lp1, c1, b1);
+			f0 = zero_if(!act, f0);
+			f1 = zero_if(!act, f1);
+			return;
 		}
 		f0 = zero_if(!act, interpolate<NETACC>(c0, v0));
 		f1 = zero_if(!act, interpolate<NETACC>(c1, v1));
@@ -334,6 +348,11 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 		fl.feat[it][0][lane] = g ? f1 : f0;
 		fl.feat[it][1][lane ^ 32] = g ? f0 : f1;
 	}
+	// feat[..][1][lane ^ 32] is another lane's slot: order the wave's writes before load_features' reads (no instruction: LDS operations of a wave
+	// stay in order; this keeps the compiler from moving a read above the write it cannot see through the xor)
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // B operand of block b for k-step ks: levels it = 4ks..4ks+3 of sample (b, j) as this lane gathered them
@@ -500,6 +519,25 @@ __device__ __forceinline__ half8 rgb_mlp(const half8* lds_w, int lane, half8 din
 	o = mfma_step<ACC16>(lds_w[NRS_FRAG_R3(3) * 64 + lane], q3, o);
 	NRS_STAGE_FENCE();
 	return pack(o, 0);
+}
+
+// tiny-cuda-nn's roundings as a template value: NUM >= 0 fixes them at compile time (bit 0 grid accumulation in network precision, bit 1 fp16 MLP
+// accumulators), kNumRuntime reads them from `nm` (DeviceModel::numerics, wave-uniform) -- both flavours compiled in, one scalar branch.
+constexpr int kNumRuntime = -1;
+template <int NUM>
+__device__ __forceinline__ void encode_num(uint32_t nm, const GridView& gv, const LevelParams* __restrict__ lv, const ModelLds& ml, FeatLds& fl, int lane, int g, f3 pos, bool act) {
+	if (NUM == kNumRuntime ? (nm & 1u) != 0u : (NUM & 1) != 0) encode_to_lds<true>(gv, lv, ml, fl, lane, g, pos, act);
+	else encode_to_lds<false>(gv, lv, ml, fl, lane, g, pos, act);
+}
+template <int NUM>
+__device__ __forceinline__ half8 density_mlp_num(uint32_t nm, const half8* lds_w, int lane, half8 x0, half8 x1) {
+	if (NUM == kNumRuntime ? (nm & 2u) != 0u : (NUM & 2) != 0) return density_mlp<true>(lds_w, lane, x0, x1);
+	return density_mlp<false>(lds_w, lane, x0, x1);
+}
+template <int NUM>
+__device__ __forceinline__ half8 rgb_mlp_num(uint32_t nm, const half8* lds_w, int lane, half8 din, half8 sh) {
+	if (NUM == kNumRuntime ? (nm & 2u) != 0u : (NUM & 2) != 0) return rgb_mlp<true>(lds_w, lane, din, sh);
+	return rgb_mlp<false>(lds_w, lane, din, sh);
 }
 
 // Exchange a value with the partner lane (l ^ 32): one ds_bpermute.

@@ -347,6 +347,10 @@ class Testbed:
         self.cone_angle_constant = 0.0 if aabb_scale <= 1 else 1.0 / 256.0
         self.render_mode = _abi.RENDER_SHADE
         self.linear_colors = False
+        self.show_accel = -1              # m_nerf.show_accel
+        self.dof = 0.0                    # m_dof
+        self.slice_plane_z, self.scale = 0.0, 1.0   # m_slice_plane_z, m_scale
+        self.dataset_scale = 1.0          # m_nerf.training.dataset.scale
         mn, mx = list(desc.aabb_min), list(desc.aabb_max)
         self.render_aabb = (mn, mx)       # m_render_aabb
         self.last_stats = None
@@ -371,6 +375,11 @@ class Testbed:
         p.render_mode = self.render_mode
         p.linear_colors = 1 if self.linear_colors else 0
         p.apply_operators = 1 if apply_operators else 0
+        p.min_mip = self.show_accel if self.show_accel >= 0 else 0
+        p.show_accel = 1 if self.show_accel >= 0 else 0
+        p.dof = self.dof
+        p.slice_plane_z = self.slice_plane_z + self.scale  # testbed_nerf.cu:3067
+        p.depth_scale = 1.0 / self.dataset_scale           # :3113
         return p
 
     def render_nerf(self, network, render_buffer, max_res, focal_length, camera_matrix0, camera_matrix1, rolling_shutter, screen_center,

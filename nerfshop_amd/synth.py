@@ -299,6 +299,10 @@ def render_params(width, height, camera, aabb_scale=1, spp_index=0, snap=True, a
     p.min_mip = 0
     p.max_march_steps = 0
     p.tile_size = p.tile_first = p.tile_stride = 0
+    p.dof = 0.0            # Testbed::m_dof (testbed.h)
+    p.slice_plane_z = 1.0  # m_slice_plane_z (0) + m_scale (1): testbed_nerf.cu:3067
+    p.depth_scale = 1.0    # 1 / dataset.scale
+    p.show_accel = 0       # m_nerf.show_accel = -1
     return p
 
 

@@ -289,6 +289,41 @@ inline float unwarp_dt(float dt) { // cn:33
 	return dt * (max_stepsize - MIN_STEP) + MIN_STEP;
 }
 
+// tcnn::pcg32 (provenance: see the note above orc_pcg32_seed)
+struct Pcg32 {
+	uint64_t state, inc;
+	uint32_t next_uint() {
+		uint64_t old = state;
+		state = old * 0x5851f42d4c957f2dULL + inc;
+		uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+		uint32_t rot = (uint32_t)(old >> 59u);
+		return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+	}
+	float next_float() {
+		uint32_t u = (next_uint() >> 9) | 0x3f800000u;
+		float f;
+		memcpy(&f, &u, 4);
+		return f - 1.0f;
+	}
+	void advance(uint64_t delta) {
+		uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+		while (delta > 0) {
+			if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+			cur_plus = (cur_mult + 1) * cur_plus;
+			cur_mult *= cur_mult;
+			delta >>= 1;
+		}
+		state = acc_mult * state + acc_plus;
+	}
+};
+inline Pcg32 pcg32_seeded(uint64_t initstate) { // pcg32(initstate, initseq = 1)
+	Pcg32 r{0u, (1u << 1u) | 1u};
+	r.next_uint();
+	r.state += initstate;
+	r.next_uint();
+	return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Rays: pixel_to_ray (common_device.cuh:245-295), init_rays_with_payload_kernel_nerf (tn:2512-2616)
 // ------------------------------------------------------------------------------------------------
@@ -320,11 +355,52 @@ inline void ray_intersect(const Box& b, V3 pos, V3 dir, float& tmin_out, float& 
 struct Camera { float m[12]; }; // 3x4 column-major
 inline V3 cam_col(const float* m, int c) { return {m[3 * c + 0], m[3 * c + 1], m[3 * c + 2]}; }
 
+// square2disk_shirley, random_val.cuh:109-125 (sincosf = the host libm's, as in the reference compiled as host code)
+inline void square2disk_shirley(float a, float b, float& ox, float& oy) {
+	const float PI = 3.14159265358979323846f;
+	float phi, r;
+	if (a * a > b * b) { r = a; phi = (PI / 4.0f) * (b / a); }
+	else { r = b; phi = (PI / 2.0f) - (PI / 4.0f) * (a / b); }
+	float sin_phi, cos_phi;
+	sincosf(phi, &sin_phi, &cos_phi);
+	ox = r * cos_phi; oy = r * sin_phi;
+}
+// render_nerf's plane_z (tn:3067-3070): m_slice_plane_z + m_scale, negated in render mode Slice
+inline float frame_plane_z(const nrs_render_params& p) { return p.render_mode == NRS_RENDER_SLICE ? -p.slice_plane_z : p.slice_plane_z; }
+
+// pixel_to_ray, common_device.cuh:245-295 (no lens distortion, no distortion map): origin and UN-normalised direction
+inline void pixel_to_ray(const nrs_render_params& p, const float* cam, uint32_t x, uint32_t y, float focus_z, float dof, V3& o, V3& d) {
+	const uint32_t W = (uint32_t)p.resolution[0], H = (uint32_t)p.resolution[1];
+	float offset[2];
+	ld_random_pixel_offset(p.snap_to_pixel_centers ? 0 : p.spp_index, offset);
+	float uvx = ((float)x + offset[0]) / (float)W;
+	float uvy = ((float)y + offset[1]) / (float)H;
+	V3 dir = {(uvx - p.screen_center[0]) * (float)W / p.focal_length[0],
+	          (uvy - p.screen_center[1]) * (float)H / p.focal_length[1], 1.0f};
+	d = mat3_mul(cam, dir); // camera_matrix.block<3, 3>(0, 0) * dir, common_device.cuh:279
+	o = cam_col(cam, 3);
+	if (dof == 0.0f) return;
+	// thin lens, common_device.cuh:286-292
+	V3 lookat = o + d * focus_z;
+	float r2[2];
+	ld_random_val_2d(p.spp_index, x * 19349663u + y * 96925573u, r2);
+	float bx, by;
+	square2disk_shirley(r2[0] * 2.0f - 1.0f, r2[1] * 2.0f - 1.0f, bx, by);
+	bx = dof * bx; by = dof * by;
+	// origin += camera_matrix.block<3, 2>(0, 0) * blur: a 2-term coefficient-based product per row
+	o = {o.x + (cam[0] * bx + cam[3] * by), o.y + (cam[1] * bx + cam[4] * by), o.z + (cam[2] * bx + cam[5] * by)};
+	V3 diff = lookat - o;
+	d = {diff.x / focus_z, diff.y / focus_z, diff.z / focus_z};
+}
+
 inline void init_ray(const nrs_render_params& p, uint32_t x, uint32_t y, Payload& payload, float& depth_out) {
 	const uint32_t W = (uint32_t)p.resolution[0], H = (uint32_t)p.resolution[1];
 	const uint32_t idx = x + W * y;
 	const Box aabb{v3(p.render_aabb_min[0], p.render_aabb_min[1], p.render_aabb_min[2]),
 	               v3(p.render_aabb_max[0], p.render_aabb_max[1], p.render_aabb_max[2])};
+	const float plane_z = frame_plane_z(p);
+	float dof = p.dof;
+	if (plane_z < 0) dof = 0.0f; // tn:2543-2545
 	// tn:2551-2553
 	float u = ((float)x + 0.5f) * (1.f / (float)W);
 	float v = ((float)y + 0.5f) * (1.f / (float)H);
@@ -332,18 +408,21 @@ inline void init_ray(const nrs_render_params& p, uint32_t x, uint32_t y, Payload
 	                 p.rolling_shutter[3] * ld_random_val(p.spp_index, idx * 72239731u);
 	float cam[12];
 	for (int i = 0; i < 12; ++i) cam[i] = p.camera_matrix0[i] * ray_time + p.camera_matrix1[i] * (1.f - ray_time); // tn:2559
-
-	// pixel_to_ray, common_device.cuh:259-284 (no distortion, no DoF: SURVEY App. A)
-	float offset[2];
-	ld_random_pixel_offset(p.snap_to_pixel_centers ? 0 : p.spp_index, offset);
-	float uvx = ((float)x + offset[0]) / (float)W;
-	float uvy = ((float)y + offset[1]) / (float)H;
-	V3 dir = {(uvx - p.screen_center[0]) * (float)W / p.focal_length[0],
-	          (uvy - p.screen_center[1]) * (float)H / p.focal_length[1], 1.0f};
-	V3 d = mat3_mul(cam, dir); // camera_matrix.block<3, 3>(0, 0) * dir, common_device.cuh:279
-	V3 o = cam_col(cam, 3);
+	V3 o, d;
+	pixel_to_ray(p, cam, x, y, plane_z, dof, o, d);
 
 	payload.max_weight = 0.0f; // tn:2573
+	if (plane_z < 0) { // Slice: the ray stands on the plane at distance -plane_z along the view axis, tn:2575-2585
+		float n = sqrtf(dot(d, d));
+		payload.origin = o;
+		payload.dir = (1.0f / n) * d;
+		payload.t = -plane_z * n;
+		payload.idx = idx;
+		payload.n_steps = 0;
+		payload.alive = false;
+		depth_out = -plane_z;
+		return;
+	}
 	depth_out = 1e10f;         // tn:2586
 	float n = sqrtf(dot(d, d)); // .normalized(), tn:2588
 	d = {d.x / n, d.y / n, d.z / n};
@@ -840,6 +919,9 @@ void render(const Model& m, const nrs_render_params& p, const Edit* const* edits
 	const bool ops = p.apply_operators && n_edits > 0;
 	const uint32_t march_iter = p.max_march_steps ? p.max_march_steps : MARCH_ITER;
 
+	const int show_accel = p.show_accel ? (int)p.min_mip : -1; // m_nerf.show_accel; min_mip = (show_accel >= 0) ? show_accel : 0, tn:2751, :2849
+	const uint32_t render_mode = p.render_mode;
+
 	std::vector<RayState> rays(N);
 	// tiles: a pixel belongs to this call iff its tile index matches (tile_first, tile_stride)
 	auto owned = [&](uint32_t x, uint32_t y) -> bool {
@@ -861,6 +943,33 @@ void render(const Model& m, const nrs_render_params& p, const Edit* const* edits
 		depth_buf[i] = d0;
 		advance_pos(p, grid, r.payload, (uint32_t)i);
 		if (steps_buf) steps_buf[i] = 0;
+	}
+
+	if (render_mode == NRS_RENDER_SLICE) {
+		// tn:3111-3175: every initialised ray stands on the slice plane (init_ray); one network evaluation there
+		// (generate_nerf_network_inputs_at_current_position tn:616-622 -> NerfNetwork::inference -> compute_nerf_density tn:624-635) -> shade
+		uint64_t n_px = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : n_px)
+		for (int64_t i = 0; i < (int64_t)N; ++i) {
+			uint32_t x = (uint32_t)i % W, y = (uint32_t)i / W;
+			if (!owned(x, y)) continue;
+			const Payload& pl = rays[i].payload;
+			V3 wp = warp_position(pl.origin + pl.dir * pl.t, train_aabb), wd = warp_direction(pl.dir);
+			float c7[7] = {wp.x, wp.y, wp.z, warp_dt(MIN_STEP), wd.x, wd.y, wd.z};
+			uint16_t out[16];
+			network_inference_one(m, c7, out);
+			// network.inference(): the fp16 outputs as floats; then compute_nerf_density
+			float a = clampf(1.f - expf(-network_to_density(h2f(out[3]), m.desc.density_activation) / 100.0f), 0.0f, 1.0f);
+			float tmp[4] = {network_to_rgb(h2f(out[0]), m.desc.rgb_activation) * a, network_to_rgb(h2f(out[1]), m.desc.rgb_activation) * a,
+			                network_to_rgb(h2f(out[2]), m.desc.rgb_activation) * a, a};
+			if (!p.linear_colors) { tmp[0] = srgb_to_linear(tmp[0]); tmp[1] = srgb_to_linear(tmp[1]); tmp[2] = srgb_to_linear(tmp[2]); } // tn:2474-2477
+			float* f = frame + 4 * (size_t)pl.idx;
+			float one_minus = 1.0f - tmp[3];
+			for (int c = 0; c < 4; ++c) f[c] = tmp[c] + f[c] * one_minus;
+			++n_px; // (no depth write in Slice mode, tn:2480: the depth buffer keeps -plane_z from init_rays)
+		}
+		if (stats) { stats->generated = n_px; stats->composited = n_px; stats->n_alive0 = (uint32_t)n_px; stats->n_hit = (uint32_t)n_px; stats->iterations = 0; }
+		return;
 	}
 
 	std::vector<uint32_t> alive, next_alive;
@@ -983,9 +1092,36 @@ void render(const Model& m, const nrs_render_params& p, const Edit* const* edits
 					} else {
 						alpha = 1.f - expf(-network_to_density(sigma_raw, m.desc.density_activation) * dt);
 					}
+					if (show_accel >= 0) alpha = 1.f; // tn:788-790
 					float weight = alpha * T;
 					float rgb[3] = {network_to_rgb(h2f(out[j][0]), m.desc.rgb_activation), network_to_rgb(h2f(out[j][1]), m.desc.rgb_activation),
 					                network_to_rgb(h2f(out[j][2]), m.desc.rgb_activation)};
+					// ---- per-sample render modes, tn:905-937 (Normals / EncodingVis need tiny-cuda-nn's input gradient / visualize_activation: not on the path)
+					if (render_mode == NRS_RENDER_POSITIONS) {
+						if (show_accel >= 0) {
+							uint32_t mip = (uint32_t)std::max(show_accel, mip_from_pos(pos));
+							uint32_t res = GRID >> mip;
+							int ix = (int)(pos.x * (float)res), iy = (int)(pos.y * (float)res), iz = (int)(pos.z * (float)res);
+							Pcg32 rng = pcg32_seeded((uint64_t)(int64_t)(int)((uint32_t)ix + (uint32_t)iy * 232323u + (uint32_t)iz * 727272u)); // int arithmetic, sign-extended
+							rgb[0] = 1.f - (float)mip * (1.f / (CASCADES - 1));
+							rgb[1] = rng.next_float();
+							rgb[2] = rng.next_float();
+						} else {
+							rgb[0] = (pos.x - 0.5f) / 2.0f + 0.5f; rgb[1] = (pos.y - 0.5f) / 2.0f + 0.5f; rgb[2] = (pos.z - 0.5f) / 2.0f + 0.5f;
+						}
+					} else if (render_mode == NRS_RENDER_DEPTH) {
+						float z = dot(cam_fwd, pos - payload.origin) * p.depth_scale;
+						rgb[0] = rgb[1] = rgb[2] = z;
+					} else if (render_mode == NRS_RENDER_DISTANCE) {
+						V3 dv = pos - payload.origin;
+						float z = sqrtf(dot(dv, dv)) * p.depth_scale;
+						rgb[0] = rgb[1] = rgb[2] = z;
+					} else if (render_mode == NRS_RENDER_STEPSIZE) {
+						float warped_dt = warp_dt(dt);
+						rgb[0] = rgb[1] = rgb[2] = warped_dt;
+					} else if (render_mode == NRS_RENDER_AO) {
+						rgb[0] = rgb[1] = rgb[2] = alpha;
+					}
 					if (has_res) {
 						float alpha_N = 1.f - expf(-network_to_density(sigma_raw, m.desc.density_activation) * dt);
 						float alpha_R = 1.f - expf(-dens_out_b[j] * dt);
@@ -1032,7 +1168,7 @@ void render(const Model& m, const nrs_render_params& p, const Edit* const* edits
 			float col = (float)r.payload.n_steps / 128;
 			tmp[0] = tmp[1] = tmp[2] = col; tmp[3] = 1.0f;
 		}
-		if (!p.linear_colors && p.render_mode == NRS_RENDER_SHADE) {
+		if (!p.linear_colors && (p.render_mode == NRS_RENDER_SHADE || p.render_mode == NRS_RENDER_SLICE)) { // tn:2474
 			tmp[0] = srgb_to_linear(tmp[0]); tmp[1] = srgb_to_linear(tmp[1]); tmp[2] = srgb_to_linear(tmp[2]);
 		}
 		float* f = frame + 4 * (size_t)r.payload.idx;
@@ -1828,32 +1964,6 @@ void orc_density_grid_to_bitfield(const float* grid, uint8_t* bitfield) {
 //   pcg32(seed): state = 0, inc = (1 << 1) | 1, next, state += seed, next
 //   next_float = bit_cast<float>((next_uint() >> 9) | 0x3f800000) - 1
 //   advance(delta) = LCG skip-ahead (Brown, "Random number generation with arbitrary strides");  tcnn's default delta is 2^32
-struct Pcg32 {
-	uint64_t state, inc;
-	uint32_t next_uint() {
-		uint64_t old = state;
-		state = old * 0x5851f42d4c957f2dULL + inc;
-		uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
-		uint32_t rot = (uint32_t)(old >> 59u);
-		return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
-	}
-	float next_float() {
-		uint32_t u = (next_uint() >> 9) | 0x3f800000u;
-		float f;
-		memcpy(&f, &u, 4);
-		return f - 1.0f;
-	}
-	void advance(uint64_t delta) {
-		uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
-		while (delta > 0) {
-			if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
-			cur_plus = (cur_mult + 1) * cur_plus;
-			cur_mult *= cur_mult;
-			delta >>= 1;
-		}
-		state = acc_mult * state + acc_plus;
-	}
-};
 void orc_pcg32_seed(uint64_t seed, uint64_t* state, uint64_t* inc) {
 	Pcg32 r{0u, (1u << 1u) | 1u};
 	r.next_uint();
@@ -2041,15 +2151,11 @@ void orc_p_activations(uint32_t n, const float* x, float* srgb_to_linear_out, fl
 		density_exp[i] = network_to_density(x[i], NRS_ACT_EXPONENTIAL);
 	}
 }
-// pixel_to_ray (common_device.cuh:245-295; camera_matrix1, no distortion, no DoF): the un-normalised direction
+// pixel_to_ray (common_device.cuh:245-295; camera_matrix1, no distortion; focus_z = slice_plane_z, dof): the un-normalised direction
 void orc_p_pixel_to_ray(uint32_t n, const int32_t* pixel2, const nrs_render_params* p, float* origin3, float* dir3) {
-	const uint32_t W = (uint32_t)p->resolution[0], H = (uint32_t)p->resolution[1];
-	float offset[2];
-	ld_random_pixel_offset(p->snap_to_pixel_centers ? 0 : p->spp_index, offset);
 	for (uint32_t i = 0; i < n; ++i) {
-		float uvx = ((float)pixel2[2 * (size_t)i] + offset[0]) / (float)W, uvy = ((float)pixel2[2 * (size_t)i + 1] + offset[1]) / (float)H;
-		V3 dir = {(uvx - p->screen_center[0]) * (float)W / p->focal_length[0], (uvy - p->screen_center[1]) * (float)H / p->focal_length[1], 1.0f};
-		V3 d = mat3_mul(p->camera_matrix1, dir), o = cam_col(p->camera_matrix1, 3);
+		V3 o, d;
+		pixel_to_ray(*p, p->camera_matrix1, (uint32_t)pixel2[2 * (size_t)i], (uint32_t)pixel2[2 * (size_t)i + 1], p->slice_plane_z, p->dof, o, d);
 		origin3[3 * (size_t)i] = o.x; origin3[3 * (size_t)i + 1] = o.y; origin3[3 * (size_t)i + 2] = o.z;
 		dir3[3 * (size_t)i] = d.x; dir3[3 * (size_t)i + 1] = d.y; dir3[3 * (size_t)i + 2] = d.z;
 	}

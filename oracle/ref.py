@@ -25,6 +25,14 @@ def available():
     return os.path.exists(LIB_PATH)
 
 
+def use_fma_build(on):
+    """Switch to oracle/_ref/libref_render_fma.so: the same reference sources compiled with -ffp-contract=fast (a model of nvcc's default FMA
+    contraction; measurement only, tools/fma_report.py)."""
+    global _lib, LIB_PATH
+    _lib = None
+    LIB_PATH = os.path.join(_HERE, "_ref", "libref_render_fma.so" if on else "libref_render.so")
+
+
 def load():
     global _lib
     if _lib is None:

@@ -40,6 +40,7 @@ FRAGMENTS = [
     ("src/testbed_nerf.cu", "generate_grid_samples_nerf_uniform_dir", r"^__global__ void generate_grid_samples_nerf_uniform_dir\(", "fn"),
     ("src/testbed_nerf.cu", "grid_samples_half_to_float", r"^__global__ void grid_samples_half_to_float\(", "fn"),
     ("src/testbed_nerf.cu", "compute_nerf_density", r"^__global__ void compute_nerf_density\(", "fn"),
+    ("src/testbed_nerf.cu", "generate_nerf_network_inputs_at_current_position", r"^__global__ void generate_nerf_network_inputs_at_current_position\(", "fn"),
     # (the "template <typename T>" line above it is supplied by the including file)
     ("src/testbed_nerf.cu", "clear_empty_space", r"^__global__ void clear_empty_space\(", "fn"),
     ("src/editing/cage_deformation.cu", "interpolate_tet_pos", r"^__global__ void interpolate_tet_pos\(", "fn"),

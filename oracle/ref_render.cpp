@@ -62,6 +62,7 @@ NGP_NAMESPACE_BEGIN
 #include "generate_grid_samples_nerf_uniform_dir.inc"
 #include "grid_samples_half_to_float.inc"
 #include "compute_nerf_density.inc"
+#include "generate_nerf_network_inputs_at_current_position.inc"
 template <typename T>
 #include "clear_empty_space.inc"
 #include "interpolate_tet_pos.inc"
@@ -227,7 +228,7 @@ void ref_render_frame(const nrs_model_desc* desc, const nrs_render_params* p, co
 	const BoundingBox render_aabb = box(p->render_aabb_min, p->render_aabb_max), train_aabb = box(desc->aabb_min, desc->aabb_max);
 	const ERenderMode render_mode = (ERenderMode)p->render_mode;
 	const ENerfActivation rgb_activation = (ENerfActivation)desc->rgb_activation, density_activation = (ENerfActivation)desc->density_activation;
-	const int show_accel = p->min_mip ? (int)p->min_mip : -1; // min_mip = (show_accel >= 0) ? show_accel : 0, :2751, :2849
+	const int show_accel = p->show_accel ? (int)p->min_mip : -1; // m_nerf.show_accel; min_mip = (show_accel >= 0) ? show_accel : 0, :2751, :2849
 	const bool apply_operators = p->apply_operators && n_edits > 0;
 
 	std::vector<RefEdit> edits;
@@ -245,9 +246,9 @@ void ref_render_frame(const nrs_model_desc* desc, const nrs_render_params* p, co
 	std::vector<float> density_out_boundary(n_max), density_residual_boundary(n_max);
 	std::vector<uint8_t> empty_mask_store(n_max);
 
-	// ---- init_rays_from_camera, :2709-2755.  plane_z = m_slice_plane_z + m_scale > 0 outside Slice mode (:3067), m_dof = 0, no envmap / distortion
+	// ---- init_rays_from_camera, :2709-2755.  plane_z = m_slice_plane_z + m_scale, negated in Slice mode (:3067-3070); no envmap / distortion
 	{
-		const float plane_z = 1.0f, dof = 0.0f;
+		const float plane_z = render_mode == ERenderMode::Slice ? -p->slice_plane_z : p->slice_plane_z, dof = p->dof;
 #pragma omp parallel for schedule(dynamic, 16)
 		for (int64_t y = 0; y < resolution.y(); ++y)
 			for (int64_t x = 0; x < resolution.x(); ++x) {
@@ -262,6 +263,28 @@ void ref_render_frame(const nrs_model_desc* desc, const nrs_render_params* p, co
 		for (uint32_t i = 0; i < N; ++i) { rays[0].rgba[i] = Array4f::Zero(); rays[0].depth[i] = 0.f; rays[0].normal[i] = Array3f::Zero(); } // :2741-2743
 		launch_linear(true, n_rays_initialized, advance_pos_nerf, render_aabb, (Vector3f)camera_matrix1.col(2), focal_length, p->spp_index, rays[0].payload.data(), bitfield,
 		              (uint32_t)((show_accel >= 0) ? show_accel : 0), p->cone_angle_constant);
+	}
+
+	if (render_mode == ERenderMode::Slice) { // :3109, :3126-3162: n_hit = n_rays_initialized, rays_hit = rays_init
+		const uint32_t n_hit = N, n_elements = next_multiple(n_hit, (uint32_t)batch_size_granularity);
+		std::vector<NerfCoordinate> vis_input(n_elements, NerfCoordinate(Vector3f::Zero(), Vector3f::Zero(), 0.f));
+		std::vector<Array4f> vis_rgba(n_elements);
+		launch_linear(true, n_hit, generate_nerf_network_inputs_at_current_position, train_aabb, (const NerfPayload*)rays[0].payload.data(), PitchedPtr<NerfCoordinate>(vis_input.data(), 1, 0, 0),
+		              Vector3f(Vector3f::Zero()));
+		// network.inference(stream, positions, rgbsigma): tcnn runs inference_mixed_precision and hands the fp16 outputs back as floats (4 x n, column-major)
+		std::vector<uint16_t> out16((size_t)n_elements * 16);
+		net(net_user, n_elements, (const float*)vis_input.data(), out16.data(), n_elements, 0);
+		for (uint32_t k = 0; k < n_elements; ++k) {
+			network_precision_t h[4];
+			for (int c = 0; c < 4; ++c) memcpy((void*)&h[c], &out16[(size_t)c * n_elements + k], 2);
+			vis_rgba[k] = Array4f((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+		}
+		launch_linear(true, n_hit, compute_nerf_density, vis_rgba.data(), rgb_activation, density_activation);
+		launch_linear(false, n_hit, shade_kernel_nerf, vis_rgba.data(), (float*)nullptr, rays[0].normal.data(), rays[0].payload.data(), render_mode, (bool)p->linear_colors, (Array4f*)frame,
+		              depth_buffer);
+		if (steps_out) memset(steps_out, 0, sizeof(uint32_t) * N);
+		if (stats) { stats->generated = N; stats->composited = N; stats->n_alive0 = N; stats->n_hit = N; stats->iterations = 0; stats->pad = 0; }
+		return;
 	}
 
 	// ---- trace, :2796-3001
@@ -317,7 +340,7 @@ void ref_render_frame(const nrs_model_desc* desc, const nrs_render_params* p, co
 		std::vector<uint16_t> n_steps_before(n_alive); // payload.n_steps as generate_next_nerf_network_inputs left it = samples this ray holds
 		for (uint32_t k = 0; k < n_alive; ++k) n_steps_before[k] = rays_current.payload[k].n_steps;
 		launch_linear(true, n_alive, composite_kernel_nerf, n_elements, i, train_aabb, 0.0f /*glow_y_cutoff*/, 0 /*glow_mode*/, 0u, (const TrainingXForm*)nullptr, camera_matrix1, focal_length,
-		              1.0f /*depth_scale*/, rays_current.rgba.data(), rays_current.depth.data(), rays_current.normal.data(), rays_current.payload.data(), input_data, gradient_data,
+		              p->depth_scale, rays_current.rgba.data(), rays_current.depth.data(), rays_current.normal.data(), rays_current.payload.data(), input_data, gradient_data,
 		              (const network_precision_t*)network_output_old.data(), (const network_precision_t*)network_output.data(), (const SH9RGB*)sh_boundary.data(),
 		              (const float*)density_out_boundary.data(), (const float*)density_residual_boundary.data(), 16u, n_steps_between_compaction, render_mode, bitfield, rgb_activation,
 		              density_activation, show_accel, p->min_transmittance, (const bool*)empty_mask_ptr, (bool)p->poisson_target);
@@ -765,7 +788,7 @@ void ref_pixel_to_ray(uint32_t n, const int32_t* pixel2, const nrs_render_params
 	const Vector2f focal_length(p->focal_length[0], p->focal_length[1]), screen_center(p->screen_center[0], p->screen_center[1]);
 	const Matrix<float, 3, 4> cam = m34(p->camera_matrix1);
 	for (uint32_t i = 0; i < n; ++i) {
-		Ray r = pixel_to_ray(p->spp_index, Vector2i(pixel2[2 * i], pixel2[2 * i + 1]), resolution, focal_length, cam, screen_center, (bool)p->snap_to_pixel_centers);
+		Ray r = pixel_to_ray(p->spp_index, Vector2i(pixel2[2 * i], pixel2[2 * i + 1]), resolution, focal_length, cam, screen_center, (bool)p->snap_to_pixel_centers, p->slice_plane_z, p->dof);
 		for (int c = 0; c < 3; ++c) { origin3[3 * (size_t)i + c] = r.o[c]; dir3[3 * (size_t)i + c] = r.d[c]; }
 	}
 }

@@ -97,9 +97,9 @@ def pixel_to_ray_case(scene, which):
     """pixel_to_ray (common_device.cuh:245-295) for every pixel of two views, snapped and jittered."""
     from oracle import ref
     outs = []
-    for az, snap, spp in ((30.0, 1, 0), (200.0, 0, 7)):
+    for az, snap, spp, dof, focus in ((30.0, 1, 0, 0.0, 1.0), (200.0, 0, 7, 0.0, 1.0), (75.0, 0, 5, 0.03, 1.4), (310.0, 1, 0, 0.1, 0.8)):  # the last two: thin-lens branch (:285-293)
         p = scene.params_for(160, 90, az)
-        p.snap_to_pixel_centers, p.spp_index = snap, spp
+        p.snap_to_pixel_centers, p.spp_index, p.dof, p.slice_plane_z = snap, spp, dof, focus
         ys, xs = np.mgrid[0:90, 0:160]
         px = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
         o, d = ref.pixel_to_ray(px, p, which)
@@ -122,6 +122,22 @@ FRAME_CASES = [
     ("lego_over_background", "lego", (64, 36, 30.0), {"_background": 0.25}, "cage"),
     ("aabb16_edit", "aabb16", (64, 36, 30.0), {}, "cage"),
     ("aabb16_edit_jitter", "aabb16", (64, 36, 120.0), {"snap_to_pixel_centers": 0, "spp_index": 3}, "cage"),
+    # round 3: the rest of render_nerf's surface -- composite_kernel_nerf's per-sample modes (tn:905-937), show_accel (tn:788-790, 911-920),
+    # depth of field (common_device.cuh:285-293), the Slice path (tn:3111-3175)
+    ("lego_edit_ao", "lego", (64, 36, 60.0), {"render_mode": 0}, "cage"),
+    ("lego_edit_positions", "lego", (64, 36, 100.0), {"render_mode": 3}, "cage"),
+    ("lego_positions_accel0", "lego", (64, 36, 30.0), {"render_mode": 3, "show_accel": 1, "min_mip": 0}, None),
+    ("aabb16_positions_accel1", "aabb16", (64, 36, 30.0), {"render_mode": 3, "show_accel": 1, "min_mip": 1}, "cage"),
+    ("lego_edit_depth", "lego", (64, 36, 200.0), {"render_mode": 4, "depth_scale": 0.7}, "cage"),
+    ("lego_edit_distance", "lego", (64, 36, 250.0), {"render_mode": 5, "depth_scale": 1.3}, "cage"),
+    ("aabb16_stepsize", "aabb16", (64, 36, 120.0), {"render_mode": 6}, "cage"),
+    ("lego_membrane_ao", "lego", (64, 36, 60.0), {"render_mode": 0}, "membrane"),
+    ("lego_show_accel_shade", "lego", (64, 36, 60.0), {"show_accel": 1, "min_mip": 0}, "cage"),
+    ("lego_dof", "lego", (64, 36, 60.0), {"dof": 0.02, "slice_plane_z": 1.2, "snap_to_pixel_centers": 0, "spp_index": 3}, "cage"),
+    ("aabb16_dof_snapped", "aabb16", (64, 36, 30.0), {"dof": 0.05, "slice_plane_z": 2.5, "spp_index": 11}, "cage"),
+    ("lego_slice", "lego", (64, 36, 30.0), {"render_mode": 9, "slice_plane_z": 1.3}, None),
+    ("lego_slice_linear_bg", "lego", (64, 36, 140.0), {"render_mode": 9, "slice_plane_z": 1.2, "linear_colors": 1, "_background": 0.25}, "cage"),
+    ("aabb16_slice", "aabb16", (64, 36, 30.0), {"render_mode": 9, "slice_plane_z": 2.0}, None),
 ]
 
 

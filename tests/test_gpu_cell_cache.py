@@ -200,6 +200,41 @@ def test_sparse_brick_records_are_a_layout_of_the_same_numbers(rig16):
         rig.use_edit(False)
 
 
+def test_sparse_records_on_dense_levels_with_a_mask_that_misses(rig16):
+    """with no dense record cache (set_cell_cache(0)) the sparse levels start at level 0, i.e. they include DENSE levels; a lane whose
+    brick has no records must then gather with the level's own (dense) index function, not the hashed one.  Arbitrary positions (the network
+    operators evaluate anywhere), a mask that allocates almost nothing, and one that covers half the scene."""
+    rig, scene = rig16, rig16.scene
+    c = _coords(120000, 33, 0.0, 1.0)
+    c[-8:, :3] = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], np.float32)
+    rig.use_edit(False)
+    try:
+        rig.net.set_sparse_cell_cache(None, 0)
+        rig.net.set_cell_cache(0)
+        assert rig.net.cell_cache()[1] == 0
+        base = _encode(rig, c)
+        assert np.array_equal(base[:4000], scene.oracle_model.hashgrid_encode(c[:4000]))
+        wrong_mask = np.zeros_like(scene.bitfield)
+        wrong_mask[:1000] = 0xff
+        half_mask = scene.bitfield.copy()
+        half_mask[half_mask.size // 10:] = 0
+        for m in (wrong_mask, half_mask, scene.bitfield):
+            rig.net.set_sparse_cell_cache(m, 2 << 30)
+            nbytes, first, n = rig.net.sparse_cell_cache()
+            assert first == 0 and n >= 2, (nbytes, first, n)   # dense levels (0..) carry sparse records now
+            got = _encode(rig, c)
+            assert np.array_equal(got, base), f"{(got != base).any(1).sum()} of {c.shape[0]} samples differ"
+        p = scene.params_for(256, 144, 60.0)
+        with_sparse = rig.render(p)
+        rig.net.set_sparse_cell_cache(None, 0)
+        plain = rig.render(p)
+        assert np.array_equal(with_sparse[0].view(np.uint32), plain[0].view(np.uint32)) and np.array_equal(with_sparse[2], plain[2])
+    finally:
+        rig.net.set_sparse_cell_cache(None, 0)
+        rig.net.set_cell_cache(10 << 30)
+        rig.use_edit(False)
+
+
 def test_set_params_from_a_device_pointer(rig):
     """nrs_model_set_params_device (NerfNetworkFull::set_params takes device pointers, nerf_network_full.h:316-349): the same model state as the host
     entry point -- features, network outputs and the cell records rebuilt from it."""

@@ -75,15 +75,12 @@ def test_render_in_each_mode(modes, grid_acc, mlp_acc):
     _compare_frames(frame, depth, steps, ref_frame, ref_depth, ref_steps)
 
 
-def test_unsupported_combinations_are_refused(modes):
+def test_unknown_mode_is_refused(modes):
     from nerfshop_amd import _abi
     rig = modes
     rig.net.set_numerics(1, 1)
     with pytest.raises(_abi.NrsError):
         rig.net.set_numerics(2, 0)
-    u = rig.testbed.new_grid_update(max_cascade=0, seed=1337)
-    with pytest.raises(_abi.NrsError):
-        rig.testbed.update_density_grid_nerf_render(1, True, u)
 
 
 def test_1080p_bench_view_against_the_oracle(rig):

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(built):
     assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nrs_abi_version() == 1
+    assert lib.nrs_abi_version() == 2
 
 
 def test_struct_layouts_match_header(built):
