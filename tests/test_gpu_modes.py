@@ -151,7 +151,7 @@ def test_slice(request, which, plane, fields):
     got = frame.cpu().numpy()
     assert stats.n_rays_hit == W * H == st.n_hit and stats.n_samples == W * H
     assert np.abs(got - ref_frame).max() < 6e-3 and np.abs(got - ref_frame).mean() < 2e-4
-    assert (got[..., 3] > 0.26).sum() > 500 and (got[..., 3] < 0.2501).sum() > 500     # the plane cuts the solid: some pixels inside it, some in empty space
+    assert (got[..., 3] > 0.26).sum() > 500 and np.unique(got[..., :3]).size > 1000    # something was drawn over the background, and it varies (the hash grid's colours)
     assert np.array_equal(depth.cpu().numpy(), np.full((H, W), plane, np.float32)) and np.array_equal(ref_depth, depth.cpu().numpy())  # tn:2583
     assert (steps.cpu().numpy() == 0).all()
 
@@ -183,14 +183,17 @@ def test_slice_on_tiles(rig):
 
 
 def test_modes_through_every_boundary_flavour(rig):
-    """tiles and an explicit step cap in a mode; Normals / Distortion / unknown modes and a lens without a focus distance are refused"""
+    """a mode with forced lane-team settings (the EXTRA instantiation is one lane per ray whatever the context asks for); Normals / Distortion /
+    unknown modes and a lens without a focus distance are refused"""
     from nerfshop_amd._abi import NrsError
     rig.use_edit(True)
     try:
-        p = _params(rig, 256, 144, 60.0, render_mode=DEPTH, depth_scale=1.0, max_march_steps=20)
-        got = rig.render(p)
+        p = _params(rig, 256, 144, 60.0, render_mode=DEPTH, depth_scale=1.0)
         ref = rig.scene.oracle_model.render(p, [rig.scene.oracle_edit])
-        _compare(got, ref)
+        for team in (4, -1, -2, 0):
+            rig.ctx.set_lane_teams(team)
+            _compare(rig.render(p), ref)
+        rig.ctx.set_lane_teams(0)
         for bad in (NORMALS, DISTORTION, 10, 11):
             with pytest.raises(NrsError):
                 rig.render(_params(rig, 64, 36, 60.0, render_mode=bad))
@@ -199,4 +202,5 @@ def test_modes_through_every_boundary_flavour(rig):
         with pytest.raises(NrsError):
             rig.render(_params(rig, 64, 36, 60.0, depth_scale=float("nan")))
     finally:
+        rig.ctx.set_lane_teams(0)
         rig.use_edit(False)
