@@ -412,7 +412,7 @@ static uint32_t plan_cell_cache(const LevelParams* lv, size_t budget, LevelParam
 	uint64_t records = 0, fit = 0;
 	for (uint32_t l = 0; l < kLevels; ++l) {
 		const uint64_t cells = (uint64_t)lv[l].resolution * lv[l].resolution * lv[l].resolution;
-		if ((records + cells) * 32ull > budget || records + cells >= (1ull << 32)) break;
+		if ((records + cells) * 32ull > budget || records + cells >= (1ull << 32) || lv[l].resolution >= 4096u) break; // (res < 4096: the gather's 24-bit index products, nrs_mlp.cuh mul24)
 		records += cells;
 		if (l & 1u) { n = l + 1; fit = records; }
 	}

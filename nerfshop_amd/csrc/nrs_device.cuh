@@ -353,8 +353,39 @@ __device__ __forceinline__ float coarse_safe_until(const DeviceModel& m, const u
 // retired at once (or lean-walked to the next marked block).  Measured (Gsamples/s, lego + cage edit; ms for a 64x40-pixel
 // frame): once per walk 9.0 / 0.84, every 3rd cell 9.43 / 0.58, 6th 9.92 / 0.56, 10th 9.80 / 0.55, 16th 9.82 / 0.58, 32nd 9.54 / 0.65.
 constexpr int kLookEvery = 6;
-__device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, const DeviceModel& m, const uint32_t* __restrict__ coarse_mask, f3 o, f3 d,
-                                                  f3 idir, float& t, f3& pos, float& dt, uint32_t* n_iter = nullptr) {
+// NRS_OPT_MORTON: the Morton code of an occupancy cell from a 128-entry table in LDS (spread3(v) = the bits of v at every third position; staged
+// behind the look-ahead mask by stage_march_lds) -- three ds_read + two v_lshl_or instead of 28 VALU instructions per occupancy test; the cell index
+// and therefore every decision stay the same.
+#ifndef NRS_OPT_MORTON
+#define NRS_OPT_MORTON 1
+#endif
+constexpr uint32_t kMarchLdsWords = kCoarseWords + kGrid; // look-ahead mask | spread3 table
+__device__ __forceinline__ void stage_march_lds(uint32_t* __restrict__ lds, const uint32_t* __restrict__ mask) { // (the caller's barrier publishes it)
+	for (uint32_t i = threadIdx.x; i < kCoarseWords; i += blockDim.x) lds[i] = mask[i];
+	for (uint32_t i = threadIdx.x; i < kGrid; i += blockDim.x) lds[kCoarseWords + i] = expand_bits(i);
+}
+__device__ __forceinline__ bool occupied_at(f3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip, const uint32_t* __restrict__ march_lds) {
+#if NRS_OPT_MORTON
+	const float mip_scale = ldexpf(1.0f, -(int)mip);
+	f3 q = pos - mk3(0.5f, 0.5f, 0.5f);
+	q = q * mip_scale;
+	q = q + mk3(0.5f, 0.5f, 0.5f);
+	const int ix = (int)(q.x * (float)kGrid), iy = (int)(q.y * (float)kGrid), iz = (int)(q.z * (float)kGrid);
+	const uint32_t* spread = march_lds + kCoarseWords;
+	const uint32_t idx = spread[clampi_(ix, 0, kGrid - 1)] | (spread[clampi_(iy, 0, kGrid - 1)] << 1) | (spread[clampi_(iz, 0, kGrid - 1)] << 2);
+	return get_bitfield_at(idx, mip, bitfield);
+#else
+	return density_grid_occupied_at(pos, bitfield, mip);
+#endif
+}
+// NRS_OPT_LAZY_IDIR: 1 / d (three IEEE divisions, ~40 issue slots) is only needed once the ray stands in an EMPTY cell; the common call -- the next
+// sample of a ray inside the object -- finds an occupied cell at once.  The first test is peeled off in front of the loop, the reciprocal formed behind it.
+#ifndef NRS_OPT_LAZY_IDIR
+#define NRS_OPT_LAZY_IDIR 1
+#endif
+__device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, const DeviceModel& m, const uint32_t* __restrict__ march_lds, f3 o, f3 d,
+                                                  float& t, f3& pos, float& dt, uint32_t* n_iter = nullptr) {
+	const uint32_t* __restrict__ coarse_mask = march_lds;
 	const uint8_t* __restrict__ bitfield = m.bitfield;
 	const Box3& occ_box = m.occ.box;
 	Box3 bb;
@@ -362,17 +393,31 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 	for (int i = 0; i < 3; ++i) { bb.mn[i] = p.render_aabb_min[i]; bb.mx[i] = p.render_aabb_max[i]; }
 	const float cone = p.cone_angle_constant;
 	int until_look = 0; // trips until the next look-ahead
+	uint32_t mip;
+	bool in_occ;
+#if NRS_OPT_LAZY_IDIR
+	if (n_iter) ++*n_iter; // profiling build only
+	pos = o + d * t;
+	if (!box_contains(bb, pos)) return false;
+	dt = calc_dt(t, cone);
+	mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
+	in_occ = box_contains(occ_box, pos);
+	if (in_occ && occupied_at(pos, bitfield, mip, march_lds)) return true;
+#endif
+	const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	bool first = NRS_OPT_LAZY_IDIR != 0;
 	while (1) {
-		if (n_iter) ++*n_iter; // profiling build only
-		pos = o + d * t;
-		if (!box_contains(bb, pos)) return false;
-		dt = calc_dt(t, cone);
-		uint32_t mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
-		if (box_contains(occ_box, pos)) {
-			if (density_grid_occupied_at(pos, bitfield, mip)) return true;
-		} else if (!ray_meets_box_ahead(occ_box, o, idir, t)) {
-			return false;
+		if (!first) {
+			if (n_iter) ++*n_iter; // profiling build only
+			pos = o + d * t;
+			if (!box_contains(bb, pos)) return false;
+			dt = calc_dt(t, cone);
+			mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
+			in_occ = box_contains(occ_box, pos);
+			if (in_occ && occupied_at(pos, bitfield, mip, march_lds)) return true;
 		}
+		first = false;
+		if (!in_occ && !ray_meets_box_ahead(occ_box, o, idir, t)) return false;
 		if (until_look-- == 0) {
 			until_look = kLookEvery;
 			float t_safe = coarse_safe_until(m, coarse_mask, o, d, idir, t);
@@ -403,13 +448,12 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 }
 
 // advance_pos_nerf, tn:557-606: jitter by one Sobol value, then skip to the first occupied cell
-__device__ __forceinline__ bool first_hit(const nrs_render_params& p, const DeviceModel& m, const uint32_t* __restrict__ coarse_mask, uint32_t pixel_idx, Ray& r,
+__device__ __forceinline__ bool first_hit(const nrs_render_params& p, const DeviceModel& m, const uint32_t* __restrict__ march_lds, uint32_t pixel_idx, Ray& r,
                                           uint32_t* n_iter = nullptr) {
-	f3 idir = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
 	float dt = calc_dt(r.t, p.cone_angle_constant);
 	r.t += ld_random_val(p.spp_index, pixel_idx * 786433u) * dt;
 	f3 pos;
-	return march_to_occupied(p, m, coarse_mask, r.o, r.d, idir, r.t, pos, dt, n_iter);
+	return march_to_occupied(p, m, march_lds, r.o, r.d, r.t, pos, dt, n_iter);
 }
 
 // ---- tet warp: selection_utils.h:10-47, cage_deformation.cu:136-269 -----------------------------------------------

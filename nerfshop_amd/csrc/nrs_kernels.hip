@@ -50,7 +50,7 @@ struct RenderSmem {
 	ModelLds ml;
 	FeatLds fl[WAVES];
 	uint2 ring[WAVES][kRing]; // {x | y << 16, t bits}; the output index follows from the pixel (pixel_out_idx)
-	uint32_t coarse[kCoarseWords]; // DeviceModel::coarse_mask (marching shortcut 2)
+	uint32_t coarse[kMarchLdsWords]; // DeviceModel::coarse_mask (marching shortcut 2) | the Morton spread table (stage_march_lds)
 	unsigned long long queue;       // the workgroup's chunk of the frame's packet queue: next packet | end << 32 (claim_packet)
 	unsigned long long sum_samples; // statistics of the workgroup's waves, flushed by the last one to finish
 	uint32_t sum_alive, sum_hit, n_finished;
@@ -206,7 +206,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 	const DeviceModel& m = m_arg;
 	const RenderArgs& a = a_arg;
 	__shared__ RenderSmem<WAVES> sm;
-	for (uint32_t i = threadIdx.x; i < kCoarseWords; i += blockDim.x) sm.coarse[i] = m.occ.mask[i];
+	stage_march_lds(sm.coarse, m.occ.mask);
 	if (threadIdx.x == 0) { sm.queue = 0ull; sm.sum_samples = 0ull; sm.sum_alive = 0u; sm.sum_hit = 0u; sm.n_finished = 0u; }
 	stage_model_to_lds(m, sm.ml, a.dbg); // (ends with the barrier that also publishes sm.coarse and the words above)
 
@@ -283,11 +283,10 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				tk = lane & (int)(gen_t - 1u);
 				team_base = lane & ~(int)(gen_t - 1u);
 				if (have) {
-					const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 					for (int j = 0; j < tk && valid; ++j) {
 						t += calc_dt(t, p1.cone_angle_constant);
 						f3 npos; float ndt;
-						valid = march_to_occupied(p1, m1, sm.coarse, o, d, idir, t, npos, ndt, nullptr);
+						valid = march_to_occupied(p1, m1, sm.coarse, o, d, t, npos, ndt, nullptr);
 					}
 				}
 			}
@@ -367,11 +366,10 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				have = true;
 				if (TEAM != 1) { // lane k of the team walks k samples ahead
 					valid = true;
-					const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 					for (int j = 0; j < tk && valid; ++j) {
 						t += calc_dt(t, p1.cone_angle_constant);
 						f3 npos; float ndt;
-						valid = march_to_occupied(p1, m1, sm.coarse, o, d, idir, t, npos, ndt, nullptr);
+						valid = march_to_occupied(p1, m1, sm.coarse, o, d, t, npos, ndt, nullptr);
 					}
 				}
 			}
@@ -395,7 +393,9 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		f3 wpos = m2.diag_pow2 ? mk3((pos.x - m2.aabb.mn[0]) * m2.inv_diag[0], (pos.y - m2.aabb.mn[1]) * m2.inv_diag[1], (pos.z - m2.aabb.mn[2]) * m2.inv_diag[2])
 		                      : warp_position(pos, m2.aabb);
 		f3 wdir = warp_direction(d);
-		const float wdt = warp_dt(dt);
+		// (constant stepping: dt == MIN_STEP, so warp_dt is exactly 0 and the IEEE division it contains -- by a constant, but the compiler may not turn
+		// it into a multiplication -- is skipped with a scalar branch)
+		const float wdt = p2.cone_angle_constant == 0.f ? 0.f : warp_dt(dt);
 		bool empty = false;
 		const f3 wpos0 = wpos; // un-deformed sample position (membrane terms live in deformed space)
 		const bool act = TEAM != 1 ? (have && valid) : have; // this lane evaluates a sample in this round
@@ -510,11 +510,10 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				}
 			}
 			if (have && !done) { // on to this lane's next sample, TEAM samples ahead
-				const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 				for (int j = 0; j < (int)gen_t && valid; ++j) {
 					t += calc_dt(t, p3.cone_angle_constant);
 					f3 npos; float ndt;
-					valid = march_to_occupied(p3, m3, sm.coarse, o, d, idir, t, npos, ndt, nullptr);
+					valid = march_to_occupied(p3, m3, sm.coarse, o, d, t, npos, ndt, nullptr);
 				}
 			}
 			const bool lead_valid = __shfl((int)valid, team_base, 64) != 0;
@@ -590,8 +589,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			} else {
 				t += dt;
 				f3 npos; float ndt;
-				const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); // recomputed (IEEE, same bits) rather than held across the round
-				done = !march_to_occupied(p3, m3, sm.coarse, o, d, idir, t, npos, ndt, PROF ? &it_march : nullptr);
+				done = !march_to_occupied(p3, m3, sm.coarse, o, d, t, npos, ndt, PROF ? &it_march : nullptr);
 				exited = done;
 			}
 			if (done) {
@@ -670,16 +668,23 @@ template <int WAVES, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0
 __global__ __launch_bounds__(64 * WAVES, 3) __attribute__((amdgpu_num_vgpr(128))) void render_kernel_c128(const DeviceModel m_arg, const RenderArgs a_arg) {
 	render_body<WAVES, 3, PROF, POISSON, AFFINE, TEAM, NUM>(m_arg, a_arg);
 }
+template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM, bool EXTRA>
+static int launch_render_cfg(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream);
 template <int WAVES, bool PROF = false, bool POISSON = false, bool AFFINE = false, int TEAM = 1, int NUM = 0>
 static int launch_render_c128(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream) {
 	int blocks_per_cu = 0;
 	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel_c128<WAVES, PROF, POISSON, AFFINE, TEAM, NUM>, 64 * WAVES, 0);
 	if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(render_kernel_c128)");
+	// amdgpu_num_vgpr is a target, not a limit: when the allocator went past 128 registers for this instantiation (3 waves per SIMD: 7.3 instead of 9.8
+	// Gsamples/s), the __launch_bounds__(512, 4) build of the same body -- which cannot -- is the one to launch
+	if (blocks_per_cu * WAVES < 16) return launch_render_cfg<WAVES, 4, PROF, POISSON, AFFINE, TEAM, NUM, false>(m, a, n_cus, stream);
 	if (blocks_per_cu < 1) blocks_per_cu = 1;
 	uint32_t grid = (uint32_t)(n_cus * blocks_per_cu);
 	const uint32_t max_useful = (a.n_packets + WAVES - 1) / WAVES; // at least one packet per wave
 	if (grid > max_useful) grid = max_useful;
 	if (grid == 0) return NRS_OK;
+	static const bool log_kernel = getenv("NRS_KERNEL_LOG") != nullptr;
+	if (log_kernel) fprintf(stderr, "[nrs kernel] render_kernel_c128<%d, team %d>\n", WAVES, TEAM);
 	hipLaunchKernelGGL((render_kernel_c128<WAVES, PROF, POISSON, AFFINE, TEAM, NUM>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
 	NRS_LAUNCH_CHECK("render_kernel launch");
 	return NRS_OK;
@@ -687,6 +692,8 @@ static int launch_render_c128(const DeviceModel& m, const RenderArgs& a, int n_c
 
 template <int WAVES, int OCC, bool PROF = false, bool POISSON = false, bool AFFINE = false, int TEAM = 1, int NUM = 0, bool EXTRA = false>
 static int launch_render_cfg(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream) {
+	static const bool log_kernel = getenv("NRS_KERNEL_LOG") != nullptr;
+	if (log_kernel) fprintf(stderr, "[nrs kernel] render_kernel<%d, %d, prof %d, poisson %d, affine %d, team %d, num %d, extra %d>\n", WAVES, OCC, (int)PROF, (int)POISSON, (int)AFFINE, TEAM, NUM, (int)EXTRA);
 	int blocks_per_cu = 0;
 	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC, PROF, POISSON, AFFINE, TEAM, NUM, EXTRA>, 64 * WAVES, 0);
 	if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor(render_kernel)");
@@ -835,8 +842,8 @@ int launch_slice(const DeviceModel& m, const RenderArgs& a, int n_cus, void* str
 // ---- trace_samples ------------------------------------------------------------------------------------------------
 __global__ void trace_samples_kernel(const DeviceModel m, const nrs_render_params p, uint32_t n_pixels, const uint32_t* __restrict__ pixel_idx,
                                      uint32_t max_samples, float* __restrict__ t_out, float* __restrict__ dt_out, uint32_t* __restrict__ count_out) {
-	__shared__ uint32_t coarse[kCoarseWords];
-	for (uint32_t i = threadIdx.x; i < kCoarseWords; i += blockDim.x) coarse[i] = m.occ.mask[i];
+	__shared__ uint32_t coarse[kMarchLdsWords];
+	stage_march_lds(coarse, m.occ.mask);
 	__syncthreads();
 	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k >= n_pixels) return;
@@ -846,11 +853,10 @@ __global__ void trace_samples_kernel(const DeviceModel m, const nrs_render_param
 	Ray r = init_ray(p, idx % W, idx / W, off_x, off_y);
 	uint32_t cnt = 0;
 	if (r.alive && first_hit(p, m, coarse, idx, r)) {
-		const f3 idir = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
 		float t = r.t;
 		while (cnt < max_samples) {
 			f3 pos; float dt;
-			if (!march_to_occupied(p, m, coarse, r.o, r.d, idir, t, pos, dt)) break;
+			if (!march_to_occupied(p, m, coarse, r.o, r.d, t, pos, dt)) break;
 			t_out[(size_t)k * max_samples + cnt] = t;
 			dt_out[(size_t)k * max_samples + cnt] = dt;
 			++cnt;

@@ -125,6 +125,21 @@ __device__ __forceinline__ void level_eval_slow(const GridView gv, const LevelPa
 	*out1 = NETACC ? (float)h1 : acc1;
 }
 
+// Index arithmetic on the full-rate 24-bit multiplier.  v_mul_lo_u32 is a quarter-rate instruction (16 cycles per wave64 against 4), and the gather
+// issues four of them per level pair.  v_mul_u32_u24 returns the low 32 bits of the product of the operands' low 24 bits -- the same number whenever
+// both operands are below 2^24 (grid coordinates, resolutions, and resolution^2 of every level that can have dense storage or records: res < 4096),
+// and the same LOW 24 BITS for any operands, which is all a hashed index keeps (mask = 2^log2_T - 1, log2_T <= 24).  NRS_OPT_U24=0: the plain products.
+#ifndef NRS_OPT_U24
+#define NRS_OPT_U24 1
+#endif
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
+#if NRS_OPT_U24
+	return __umul24(a, b);
+#else
+	return a * b;
+#endif
+}
+
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32x2 grid_load2_bytes(const GridView& v, uint32_t byte_offset) {
 	return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(v.rsrc, (int)byte_offset, 0, 0));
@@ -144,7 +159,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // dense fast path precondition: no index of the cell reaches `count`, so no wrap and x-neighbours are adjacent entries
 __device__ __forceinline__ bool dense_needs_slow(const LevelParams& lp, const CellCoords& c) {
 	return c.gx >= lp.resolution || c.gy >= lp.resolution || c.gz >= lp.resolution ||
-	       c.gx + c.gy * lp.resolution + c.gz * lp.res2 + 1u + lp.resolution + lp.res2 >= lp.count;
+	       c.gx + mul24(c.gy, lp.resolution) + mul24(c.gz, lp.res2) + 1u + lp.resolution + lp.res2 >= lp.count; // (the products are only used when the three tests before passed)
 }
 // Issue the gathers of one sample at one level: v[2q + bx] = entry of corner (bx, q&1, q>>1).
 // Dense levels fetch the two x-neighbours with ONE 8-byte load (entry(x+1) = entry(x) + 1; MUBUF needs dword alignment only).
@@ -152,14 +167,16 @@ template <bool HASHED>
 __device__ __forceinline__ void issue_gathers(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t v[8]) {
 	const uint32_t off4 = lp.offset * 4u;
 	if (HASHED) {
-		const uint32_t hx0 = c.gx, hx1 = c.gx + 1u, hy0 = c.gy * 2654435761u, hy1 = hy0 + 2654435761u, hz0 = c.gz * 805459861u, hz1 = hz0 + 805459861u;
+		// (only the bits under lp.mask < 2^24 survive: the low 24 bits of the primes on the 24-bit multiplier give the same index)
+		const uint32_t hx0 = c.gx, hx1 = c.gx + 1u, hy0 = mul24(c.gy, NRS_OPT_U24 ? (2654435761u & 0xffffffu) : 2654435761u), hy1 = hy0 + 2654435761u,
+		               hz0 = mul24(c.gz, NRS_OPT_U24 ? (805459861u & 0xffffffu) : 805459861u), hz1 = hz0 + 805459861u;
 		#pragma unroll
 		for (int k = 0; k < 8; ++k) {
 			const uint32_t e = (((k & 1) ? hx1 : hx0) ^ ((k & 2) ? hy1 : hy0) ^ ((k & 4) ? hz1 : hz0)) & lp.mask;
 			v[k] = grid_load_bytes(gv, (e << 2) + off4);
 		}
 	} else {
-		const uint32_t base = c.gx + c.gy * lp.resolution + c.gz * lp.res2;
+		const uint32_t base = c.gx + mul24(c.gy, lp.resolution) + mul24(c.gz, lp.res2); // dense level: res^3 <= 2^24, coordinates checked by dense_needs_slow
 		#pragma unroll
 		for (int q = 0; q < 4; ++q) {
 			const uint32_t i = base + ((q & 1) ? lp.resolution : 0u) + ((q & 2) ? lp.res2 : 0u);
@@ -177,7 +194,7 @@ __device__ __forceinline__ bool outside_unit_cube(f3 p) {
 	return !(p.x >= 0.f && p.x <= 1.f && p.y >= 0.f && p.y <= 1.f && p.z >= 0.f && p.z <= 1.f);
 }
 __device__ __forceinline__ void issue_record_loads(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t v[8]) {
-	const uint32_t rec = lp.rec_first + c.gx + c.gy * lp.rec_res + c.gz * lp.rec_res2;
+	const uint32_t rec = lp.rec_first + c.gx + mul24(c.gy, lp.rec_res) + mul24(c.gz, lp.rec_res2); // rec_res < 4096 (plan_cell_cache), product < 2^32 records
 	const uint4* p = gv.records + 2 * (size_t)rec;
 	const uint4 lo = p[0], hi = p[1];
 	v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
@@ -225,7 +242,9 @@ __device__ __forceinline__ uint32_t level_eval_exact(const GridView& gv, const L
 // Sparse level (nrs_model_set_sparse_cell_cache): the level's cells are grouped in 8 x 8 x 8 bricks; a table says which bricks carry
 // records (slot + 1) and which do not (0).  One table load (neighbouring samples share its lines), then the record as in a dense level.
 __device__ __forceinline__ uint32_t brick_entry(const GridView& gv, const LevelParams& lp, const CellCoords& c) {
-	return gv.bricks[lp.tab_first + (c.gz >> 3) * lp.rec_res2 + (c.gy >> 3) * lp.rec_res + (c.gx >> 3)];
+	// bricks per side <= 4097 (res 32769 of an aabb-16 level 15): rec_res2 can exceed 2^24 by a hair -- wave-uniform choice of the multiplier
+	const uint32_t zy = lp.rec_res2 < (1u << 24) ? mul24(c.gz >> 3, lp.rec_res2) + mul24(c.gy >> 3, lp.rec_res) : (c.gz >> 3) * lp.rec_res2 + (c.gy >> 3) * lp.rec_res;
+	return gv.bricks[lp.tab_first + zy + (c.gx >> 3)];
 }
 __device__ __forceinline__ void issue_brick_record_loads(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t brick, uint32_t v[8]) {
 	const uint32_t rec = lp.rec_first + (brick - 1u) * 512u + (((c.gz & 7u) << 6) | ((c.gy & 7u) << 3) | (c.gx & 7u));
