@@ -49,6 +49,8 @@ def build_scene(workload, rt, synth, ctx, torch):
     edit = None
     if with_edit:
         edit = synth.make_cage_edit(lattice_n=10, scene_scale=1.0 if aabb_scale == 1 else 6.0)
+        if workload.endswith("membrane"):  # "one extra run with it on" -- the membrane ("Poisson") correction of cage_deformation.h:163
+            edit = edit.with_membrane(residual_amplitude=0.8)
         op = rt.CageDeformation(ctx, desc, edit)
         tb.add_edit_operator(op)
 
@@ -61,7 +63,7 @@ def build_scene(workload, rt, synth, ctx, torch):
 
         grid = synth.deformed_density_grid(grid, desc, map_positions, aabb_scale)
     tb.nerf_network.set_density_grid(grid)  # threshold + mip pooling on the device
-    if aabb_scale > 1 and os.environ.get("NRS_SPARSE_GB", "64") != "0":
+    if aabb_scale > 1 and os.environ.get("NRS_SPARSE_GB", "64") != "0" and not workload.endswith("norecords"):
         # aabb-16 scenes: the dense cell records end at level 7 (7.3 GB); levels 8.. get occupancy-sparse brick records wherever lookups can
         # happen: the occupancy of the edited scene OR the un-edited one (the cage carries samples back to canonical space)
         mask = synth.grid_to_bitfield(grid) | synth.grid_to_bitfield(synth.density_grid(aabb_scale))
@@ -127,7 +129,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage", "garden", "lego_cage_varied"])
+    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage", "garden", "lego_cage_varied", "lego_cage_membrane", "garden_cage_norecords"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -278,7 +280,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra and args.workload == "lego_cage":
         # secondary workloads, one frame at a time like `value`: BASELINE configs[3] (garden-style: aabb_scale 16, cone stepping, 5 cascades, one
         # cage edit) and the lego-like scene with non-uniform opacity (a wide distribution of ray lengths, as a trained snapshot has)
-        for name in ("garden_cage", "lego_cage_varied"):
+        # plus the membrane correction on (SURVEY 8d's "one extra run with it on") and the garden scene WITHOUT the 64 GB of sparse brick records
+        # (they are an option of the boundary, INTEGRATION.md: the figure a caller gets who does not install them)
+        for name in ("garden_cage", "garden_cage_norecords", "lego_cage_varied", "lego_cage_membrane"):
             sc2 = build_scene(name, rt, synth, ctx, torch)
             tb2 = sc2["tb"]
 
@@ -327,7 +331,9 @@ def main():
                                     "lego": "lego-like snapshot 1920x1080, no edits (BASELINE configs[1])",
                                     "garden_cage": "garden-style aabb_scale 16 1920x1080, one cage edit (BASELINE configs[3])",
                                     "garden": "garden-style aabb_scale 16 1920x1080, no edits",
-                                    "lego_cage_varied": "lego-like snapshot with non-uniform opacity (geometry in the network, density noise 1.5) 1920x1080, one cage edit"}[args.workload],
+                                    "lego_cage_varied": "lego-like snapshot with non-uniform opacity (geometry in the network, density noise 1.5) 1920x1080, one cage edit",
+                                    "lego_cage_membrane": "lego-like snapshot 1920x1080, one cage edit with the membrane (Poisson) correction on",
+                                    "garden_cage_norecords": "garden-style aabb_scale 16 1920x1080, one cage edit, no sparse brick records"}[args.workload],
                        "resolution": [W, H], "samples_per_frame": int(total_samples / args.steps),
                        "sharding": f"{TILE}x{TILE} image tiles round-robin over {world} GPU(s)" + (f", gather to rank 0 by {all_sharders[0].gather_impl}" if world > 1 else ""),
                        "frames_in_flight": n_buf,
@@ -340,6 +346,13 @@ def main():
                          "algorithmic_bytes_per_launch": int(per_launch_samples * BYTES_PER_SAMPLE),
                          "mfma_tflops": round(per_launch_samples * FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12, 2)},
         }
+        if world > 1 and all_sharders[0].comm is not None:  # what the exchange actually ran on: ranks RCCL connected, its version, the library loaded
+            import ctypes as C
+            from nerfshop_amd import _abi
+            ci = [C.c_int(), C.c_int(), C.c_int()]
+            lp = C.create_string_buffer(256)
+            _abi.check(_abi.load().nrs_comm_info(all_sharders[0].comm, C.byref(ci[0]), C.byref(ci[1]), C.byref(ci[2]), lp, 256))
+            line["config"]["comm"] = {"n_ranks": ci[1].value, "rccl_version": ci[2].value, "library": lp.value.decode()}
         line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(synth)

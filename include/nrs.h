@@ -301,6 +301,9 @@ typedef struct nrs_comm nrs_comm;
 int  nrs_comm_unique_id(uint8_t* out128);
 int  nrs_comm_create(int device, int rank, int n_ranks, const uint8_t* unique_id128, nrs_comm** out);
 void nrs_comm_destroy(nrs_comm* comm);
+/* What the communicator is: this process's rank, the number of ranks RCCL connected, ncclGetVersion() (0 if the library has none) and the library
+ * that was loaded (NRS_RCCL_LIB overrides the search: tests/fake_rccl runs several ranks on one GPU).  Any pointer may be NULL. */
+int  nrs_comm_info(const nrs_comm* comm, int* rank_out, int* n_ranks_out, int* rccl_version_out, char* lib_path_out, size_t lib_path_len);
 /* d_local: this rank's buffer.  Root only: d_recv = n_ranks such buffers (rank-major); d_image [H*W*4] / d_depth [H*W] may be NULL. */
 int  nrs_gather_tiles(nrs_ctx* ctx, nrs_comm* comm, int root, const nrs_render_params* p, uint32_t tiles_per_rank_padded, const float* d_local,
                       float* d_recv, float* d_image, float* d_depth, void* stream);

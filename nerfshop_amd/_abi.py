@@ -123,7 +123,7 @@ class GridUpdate(C.Structure):
 
 # every symbol include/nrs.h declares; tests check the library exports exactly these
 EXPORTS = [
-    "nrs_last_error", "nrs_abi_version", "nrs_edit_poisson_interpolate", "nrs_edit_download_poisson", "nrs_comm_unique_id", "nrs_comm_create", "nrs_comm_destroy", "nrs_gather_tiles",
+    "nrs_last_error", "nrs_abi_version", "nrs_edit_poisson_interpolate", "nrs_edit_download_poisson", "nrs_comm_unique_id", "nrs_comm_create", "nrs_comm_info", "nrs_comm_destroy", "nrs_gather_tiles",
     "nrs_ctx_create", "nrs_ctx_destroy", "nrs_ctx_device_info", "nrs_ctx_set_lane_teams",
     "nrs_model_create", "nrs_model_destroy", "nrs_model_n_params", "nrs_model_level_table",
     "nrs_model_set_params", "nrs_model_set_params_device", "nrs_model_set_numerics", "nrs_model_set_cell_cache", "nrs_model_cell_cache_bytes", "nrs_model_set_sparse_cell_cache", "nrs_model_sparse_cell_cache_bytes", "nrs_model_set_density_bitfield", "nrs_model_set_density_grid",
@@ -192,6 +192,7 @@ def load():
     lib.nrs_edit_download_poisson.argtypes = [P, P, P, P]
     lib.nrs_comm_unique_id.argtypes = [P]
     lib.nrs_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, P, P]
+    lib.nrs_comm_info.argtypes = [P, P, P, P, P, C.c_size_t]
     lib.nrs_comm_destroy.argtypes = [P]
     lib.nrs_comm_destroy.restype = None
     lib.nrs_gather_tiles.argtypes = [P, P, C.c_int, P, C.c_uint32, P, P, P, P, P]

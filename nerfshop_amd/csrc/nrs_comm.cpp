@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -36,16 +37,25 @@ struct Rccl {
 	int (*GroupEnd)() = nullptr;
 	int (*Send)(const void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
 	int (*Recv)(void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
-	std::string error;
+	int (*GetVersion)(int*) = nullptr; // optional
+	std::string error, path;
 };
 
 Rccl& rccl() {
 	static Rccl r;
 	static std::once_flag once;
 	std::call_once(once, []() {
+		// NRS_RCCL_LIB: load THIS library instead (tests/fake_rccl: several ranks on one GPU, so that the N > 1 legs below run on a one-GPU box).
+		// A local load, so that it never shadows the RCCL the process may already hold.
+		if (const char* over = getenv("NRS_RCCL_LIB")) {
+			r.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+			if (!r.lib) { r.error = std::string("NRS_RCCL_LIB: ") + dlerror(); return; }
+			r.path = over;
+		}
 		for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-			r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
 			if (r.lib) break;
+			r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+			if (r.lib) r.path = name;
 		}
 		if (!r.lib) { r.error = std::string("librccl.so not found: ") + dlerror(); return; }
 		auto sym = [&](const char* n) -> void* {
@@ -61,6 +71,7 @@ Rccl& rccl() {
 		r.GroupEnd = (int (*)())sym("ncclGroupEnd");
 		r.Send = (int (*)(const void*, size_t, int, int, ncclComm_t_, hipStream_t))sym("ncclSend");
 		r.Recv = (int (*)(void*, size_t, int, int, ncclComm_t_, hipStream_t))sym("ncclRecv");
+		r.GetVersion = (int (*)(int*))dlsym(r.lib, "ncclGetVersion");
 	});
 	return r;
 }
@@ -107,6 +118,16 @@ int nrs_comm_create(int device, int rank, int n_ranks, const uint8_t* unique_id1
 	const int rc = r.CommInitRank(&c->comm, n_ranks, id, rank);
 	if (rc != 0) { delete c; return ccl_fail(rc, "ncclCommInitRank"); }
 	*out = c;
+	return NRS_OK;
+}
+
+int nrs_comm_info(const nrs_comm* c, int* rank_out, int* n_ranks_out, int* rccl_version_out, char* lib_out, size_t lib_len) {
+	if (!c) return fail(NRS_ERR_INVALID_ARG, "nrs_comm_info: NULL communicator");
+	Rccl& r = rccl();
+	if (rank_out) *rank_out = c->rank;
+	if (n_ranks_out) *n_ranks_out = c->n_ranks;
+	if (rccl_version_out) { int v = 0; if (!r.GetVersion || r.GetVersion(&v) != 0) v = 0; *rccl_version_out = v; }
+	if (lib_out && lib_len) snprintf(lib_out, lib_len, "%s", r.path.c_str());
 	return NRS_OK;
 }
 
