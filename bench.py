@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 BYTES_PER_SAMPLE = 512          # 16 levels x 8 corners x (2 x fp16): SURVEY 8(d)
 FLOP_PER_SAMPLE = 20480         # density MLP 6144 + rgb MLP 14336
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-TILE = 64
+TILE = int(os.environ.get("NRS_BENCH_TILE", "32"))  # image tiles dealt round-robin to the ranks (multiple of 8): 32 halves the load imbalance of 64 (profiles/r03_scaling.md)
 
 
 def build_scene(workload, rt, synth, ctx, torch):

@@ -1327,7 +1327,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		a.tail_target = tail_target;
 		static const uint32_t reteam = []() { const char* e = getenv("NRS_RETEAM"); return e ? (uint32_t)atoi(e) : 1u; }();
 		a.reteam = reteam;
-		if (((team == 4 && !forced && hybrid_on) || forced == -2) && !a.any_poisson && !a.any_affine && !a.extra && !(a.dbg & 4u)) {
+		if (((team == 4 && !forced && hybrid_on) || forced == -2) && !a.any_poisson && !a.any_affine && !a.extra) {
 			// few rays for the GPU: 4x4 packets only, and every generation takes ALL the rays its wave has pending with as many
 			// lanes per ray as fit (4 up to 16 rays, 2 up to 32), so that no wave is left with a second, nearly empty generation
 			// (1/8 share of the bench frame: 0.88 -> 0.82 ms).

@@ -364,6 +364,30 @@ __device__ __forceinline__ void stage_march_lds(uint32_t* __restrict__ lds, cons
 	for (uint32_t i = threadIdx.x; i < kCoarseWords; i += blockDim.x) lds[i] = mask[i];
 	for (uint32_t i = threadIdx.x; i < kGrid; i += blockDim.x) lds[kCoarseWords + i] = expand_bits(i);
 }
+// NRS_OPT_OCCWORD: the voxel walk keeps the 64-bit word of the bitfield it last read -- in Morton order that is one 4 x 4 x 4 block of cells of one
+// cascade -- and a test that falls into the same block is answered from the registers.  A ray that walks through empty cells next to the surface (the
+// silhouette rays that bound small launches: DESIGN 5) then pays the bitfield's load latency once per block instead of once per cell; when no lane of
+// the wave needs a new word the load is skipped altogether.  Pure caching: the decisions are the bitfield's.
+#ifndef NRS_OPT_OCCWORD
+#define NRS_OPT_OCCWORD 1
+#endif
+struct OccWord { uint32_t tag; uint32_t lo, hi; };
+__device__ __forceinline__ bool occupied_at_cached(f3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip, const uint32_t* __restrict__ march_lds, OccWord& w) {
+	const float mip_scale = ldexpf(1.0f, -(int)mip);
+	f3 q = pos - mk3(0.5f, 0.5f, 0.5f);
+	q = q * mip_scale;
+	q = q + mk3(0.5f, 0.5f, 0.5f);
+	const int ix = (int)(q.x * (float)kGrid), iy = (int)(q.y * (float)kGrid), iz = (int)(q.z * (float)kGrid);
+	const uint32_t* spread = march_lds + kCoarseWords;
+	const uint32_t idx = (spread[clampi_(ix, 0, kGrid - 1)] | (spread[clampi_(iy, 0, kGrid - 1)] << 1) | (spread[clampi_(iz, 0, kGrid - 1)] << 2)) + mip * kGridVol;
+	const uint32_t tag = idx >> 6;
+	if (tag != w.tag) {
+		const uint2 v = reinterpret_cast<const uint2*>(bitfield)[tag];
+		w.tag = tag; w.lo = v.x; w.hi = v.y;
+	}
+	const uint32_t bit = idx & 63u;
+	return (((bit & 32u) ? w.hi : w.lo) >> (bit & 31u)) & 1u;
+}
 __device__ __forceinline__ bool occupied_at(f3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip, const uint32_t* __restrict__ march_lds) {
 #if NRS_OPT_MORTON
 	const float mip_scale = ldexpf(1.0f, -(int)mip);
@@ -395,6 +419,12 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 	int until_look = 0; // trips until the next look-ahead
 	uint32_t mip;
 	bool in_occ;
+#if NRS_OPT_OCCWORD && NRS_OPT_MORTON
+	OccWord occ_word{0xffffffffu, 0u, 0u};
+	#define NRS_OCCUPIED(pos_, mip_) occupied_at_cached(pos_, bitfield, mip_, march_lds, occ_word)
+#else
+	#define NRS_OCCUPIED(pos_, mip_) occupied_at(pos_, bitfield, mip_, march_lds)
+#endif
 #if NRS_OPT_LAZY_IDIR
 	if (n_iter) ++*n_iter; // profiling build only
 	pos = o + d * t;
@@ -402,7 +432,7 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 	dt = calc_dt(t, cone);
 	mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
 	in_occ = box_contains(occ_box, pos);
-	if (in_occ && occupied_at(pos, bitfield, mip, march_lds)) return true;
+	if (in_occ && NRS_OCCUPIED(pos, mip)) return true;
 #endif
 	const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 	bool first = NRS_OPT_LAZY_IDIR != 0;
@@ -414,7 +444,7 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 			dt = calc_dt(t, cone);
 			mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
 			in_occ = box_contains(occ_box, pos);
-			if (in_occ && occupied_at(pos, bitfield, mip, march_lds)) return true;
+			if (in_occ && NRS_OCCUPIED(pos, mip)) return true;
 		}
 		first = false;
 		if (!in_occ && !ray_meets_box_ahead(occ_box, o, idir, t)) return false;
@@ -445,6 +475,7 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 		uint32_t res = kGrid >> mip;
 		t = advance_to_next_voxel(t, cone, pos, d, idir, res, ldexpf(1.0f, (int)mip - 7));
 	}
+	#undef NRS_OCCUPIED
 }
 
 // advance_pos_nerf, tn:557-606: jitter by one Sobol value, then skip to the first occupied cell
@@ -623,7 +654,7 @@ __device__ __forceinline__ void poisson_residual_rgb(const DeviceEdit& e, f3 wpo
 	const float* s1 = e.shs + 27 * (size_t)tv.y;
 	const float* s2 = e.shs + 27 * (size_t)tv.z;
 	const float* s3 = e.shs + 27 * (size_t)tv.w;
-	#pragma unroll
+	#pragma unroll 1 // one colour at a time: 36 coefficient loads in flight instead of 108 (the unrolled form costs the membrane instantiation a wave of occupancy)
 	for (int c = 0; c < 3; ++c) {
 		float q[9];
 		#pragma unroll

@@ -132,9 +132,21 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 #else
 #define NRS_MARK(i)
 #endif
+// NRS_PRIO (experiment knob, default 0 = off): wave priorities per phase (s_setprio).  1: memory phases (warp, gather) above the rest;
+// 2: the MFMA chain above the rest; 3: gather only.
+#ifndef NRS_PRIO
+#define NRS_PRIO 0
+#endif
+#define NRS_SETPRIO(i)                                                                                         \
+	do {                                                                                                       \
+		if (NRS_PRIO == 1) { if ((i) == 2 || (i) == 3) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); } \
+		if (NRS_PRIO == 2) { if ((i) == 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }             \
+		if (NRS_PRIO == 3) { if ((i) == 3) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }             \
+	} while (0)
 #define NRS_PHASE(i)                                                         \
 	do {                                                                     \
 		NRS_MARK(i);                                                         \
+		NRS_SETPRIO(i);                                                      \
 		if (PROF) {                                                          \
 			const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
 			ph_acc[ph_cur] += now_ - ph_last;                                \
@@ -717,16 +729,18 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 	hipStream_t s = (hipStream_t)stream;
 	constexpr int R = kNumRuntime;
 	if (a.extra) // render modes / show_accel / depth of field: the catch-all instantiation (every operator kind, membrane correction, one lane per ray)
-		return m.numerics ? launch_render_cfg<8, 2, false, true, true, 1, R, true>(m, a, n_cus, s) : launch_render_cfg<8, 2, false, true, true, 1, 0, true>(m, a, n_cus, s);
+		return m.numerics ? launch_render_cfg<8, 3, false, true, true, 1, R, true>(m, a, n_cus, s) : launch_render_cfg<8, 3, false, true, true, 1, 0, true>(m, a, n_cus, s);
 	if (m.numerics) { // tiny-cuda-nn's other roundings: the run-time twin of every schedule (nrs_render_nerf computed the packet geometry for a.team)
-		if (a.any_poisson) return launch_render_cfg<8, 2, false, true, true, 1, R>(m, a, n_cus, s);
+		if (a.any_poisson) return launch_render_cfg<8, 3, false, true, true, 1, R>(m, a, n_cus, s);
 		if (a.any_affine) return launch_render_cfg<8, 3, false, false, true, 1, R>(m, a, n_cus, s);
 		if (a.team == 0) return launch_render_cfg<8, 3, false, false, false, 0, R>(m, a, n_cus, s);
 		if (a.team == 2) return launch_render_cfg<8, 3, false, false, false, 2, R>(m, a, n_cus, s);
 		if (a.team == 4) return launch_render_cfg<8, 3, false, false, false, 4, R>(m, a, n_cus, s);
 		return launch_render_cfg<8, 3, false, false, false, 1, R>(m, a, n_cus, s);
 	}
-	if (a.any_poisson) return launch_render_cfg<8, 2, false, true, true>(m, a, n_cus, s);
+	// membrane correction: 142 VGPRs, no scratch, 3 waves per SIMD (the SH9 colour loop is kept rolled for that: unrolled it held 108 coefficient loads
+	// in flight, 250 VGPRs, 2 waves per SIMD: 6.1 Gsamples/s on the bench's lego_cage_membrane)
+	if (a.any_poisson) return launch_render_cfg<8, 3, false, true, true>(m, a, n_cus, s);
 	if (a.dbg & 4u) return a.team == 0 ? launch_render_cfg<8, 4, true, false, false, 0>(m, a, n_cus, s) : launch_render_cfg<8, 4, true>(m, a, n_cus, s);
 	// Production instantiations: scheduled for 3 waves/SIMD, capped at 128 VGPRs = 4 waves/SIMD (render_kernel_c128).  Measured against the
 	// __launch_bounds__(512, 4) build of the same code (NRS_RENDER_CFG=84): 1080p lego + cage 9.43 -> 9.82 Gsamples/s, lego 10.7 -> 11.0,

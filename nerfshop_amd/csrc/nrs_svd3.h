@@ -4,8 +4,9 @@
 // Jacobi sweeps with approximate Givens rotations on A^T A, column sort, Givens QR -- all in fp32.  Its R = U V^T deviates
 // from the exact polar factor by up to 1.3e-2 per entry on ordinary tets (median 1e-6), so "the same picture as the
 // reference" means restating that procedure step by step, not computing a better rotation.  Host and device share this
-// header; tests/golden/ref_rotations_golden.npz holds what the reference header itself produces (oracle/ref_svd.cpp) and
-// both must match it bit for bit (-ffp-contract=off, same operation order).
+// header; the reference header itself, compiled from /root/reference by oracle/Makefile into oracle/_ref/libref_render.so (ref_local_rotations in
+// oracle/ref_render.cpp), is what both must match bit for bit (tests/test_ref_pin.py authoring cases; its outputs travel in
+// tests/golden/ref_pin_golden.npz; -ffp-contract=off, same operation order).
 #pragma once
 #include <math.h>
 #include <stdint.h>

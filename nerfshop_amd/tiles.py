@@ -7,7 +7,7 @@ renders its tiles into a COMPACT buffer [tiles_per_rank, tile, tile, C] (nrs_ren
 collects them on rank 0 and nrs_detile scatters them back into the W x H image.  On GPUs the exchange is libnrs's own
 nrs_gather_tiles (host C++: ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on RCCL over xGMI, include/nrs.h) on a
 communicator bootstrapped through one torch.distributed broadcast of the 128-byte id; on CPU (the gloo tests) it is a
-torch.distributed gather.  The model (~26 MB) is replicated; nothing else is exchanged per frame.
+torch.distributed gather.  The model is replicated (24-27 MB of parameters plus the optional cell records: 9.2 GB by default, up to 68 GB with the sparse brick records of an aabb-16 scene); nothing else is exchanged per frame.
 """
 import ctypes as C
 
@@ -125,7 +125,7 @@ class TileSharder:
             f1 = d1 = f2 = d2 = None
         try:
             self._c_gather(ctx, p, f1, d1)
-            torch.cuda.current_stream(self.device).synchronize()
+            self._wait_bounded(torch.cuda.current_stream(self.device), "the first nrs_gather_tiles")
         except _abi.NrsError as e:
             import sys
             print(f"[nerfshop_amd.tiles] rank {self.rank}: nrs_gather_tiles failed ({e})", file=sys.stderr)
@@ -141,6 +141,17 @@ class TileSharder:
         flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(int(flag.item()))
+
+    @staticmethod
+    def _wait_bounded(stream, what, seconds=120.0):
+        """stream.synchronize() with a deadline: if a peer failed before it enqueued its half of a send / receive pair, the matching operation here
+        never completes -- fail loudly instead of hanging the job (the RCCL operation itself cannot be cancelled: the process must exit)."""
+        import time
+        t0 = time.monotonic()
+        while not stream.query():
+            if time.monotonic() - t0 > seconds:
+                raise RuntimeError(f"nerfshop_amd.tiles: {what} did not complete within {seconds:.0f} s (a peer rank failed?)")
+            time.sleep(0.0005)
 
     def fill(self, p):
         """Write the sharding fields of an nrs_render_params."""
