@@ -372,14 +372,30 @@ __device__ __forceinline__ void stage_march_lds(uint32_t* __restrict__ lds, cons
 #define NRS_OPT_OCCWORD 1
 #endif
 struct OccWord { uint32_t tag; uint32_t lo, hi; };
-__device__ __forceinline__ bool occupied_at_cached(f3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip, const uint32_t* __restrict__ march_lds, OccWord& w) {
+// bit number of the cell of cascade `mip` that holds pos, in the concatenated bitfield (cn:117-141 through the LDS spread table)
+__device__ __forceinline__ uint32_t occupancy_bit_index(f3 pos, uint32_t mip, const uint32_t* __restrict__ march_lds) {
 	const float mip_scale = ldexpf(1.0f, -(int)mip);
 	f3 q = pos - mk3(0.5f, 0.5f, 0.5f);
 	q = q * mip_scale;
 	q = q + mk3(0.5f, 0.5f, 0.5f);
 	const int ix = (int)(q.x * (float)kGrid), iy = (int)(q.y * (float)kGrid), iz = (int)(q.z * (float)kGrid);
 	const uint32_t* spread = march_lds + kCoarseWords;
-	const uint32_t idx = (spread[clampi_(ix, 0, kGrid - 1)] | (spread[clampi_(iy, 0, kGrid - 1)] << 1) | (spread[clampi_(iz, 0, kGrid - 1)] << 2)) + mip * kGridVol;
+	return (spread[clampi_(ix, 0, kGrid - 1)] | (spread[clampi_(iy, 0, kGrid - 1)] << 1) | (spread[clampi_(iz, 0, kGrid - 1)] << 2)) + mip * kGridVol;
+}
+// The occupancy word the walk from parameter t will ask for first, requested NOW (the caller issues this in front of the MLPs and hands the word to
+// march_to_occupied behind the compositing: the bitfield's round trip then overlaps the MFMA chain instead of extending the round).
+__device__ __forceinline__ OccWord prefetch_occupancy_word(const nrs_render_params& p, const DeviceModel& m, const uint32_t* __restrict__ march_lds, f3 o, f3 d, float t) {
+	const f3 pos = o + d * t;
+	const float dt = calc_dt(t, p.cone_angle_constant);
+	const uint32_t mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
+	OccWord w;
+	w.tag = occupancy_bit_index(pos, mip, march_lds) >> 6;
+	const uint2 v = reinterpret_cast<const uint2*>(m.bitfield)[w.tag];
+	w.lo = v.x; w.hi = v.y;
+	return w;
+}
+__device__ __forceinline__ bool occupied_at_cached(f3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip, const uint32_t* __restrict__ march_lds, OccWord& w) {
+	const uint32_t idx = occupancy_bit_index(pos, mip, march_lds);
 	const uint32_t tag = idx >> 6;
 	if (tag != w.tag) {
 		const uint2 v = reinterpret_cast<const uint2*>(bitfield)[tag];
@@ -408,7 +424,7 @@ __device__ __forceinline__ bool occupied_at(f3 pos, const uint8_t* __restrict__ 
 #define NRS_OPT_LAZY_IDIR 1
 #endif
 __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, const DeviceModel& m, const uint32_t* __restrict__ march_lds, f3 o, f3 d,
-                                                  float& t, f3& pos, float& dt, uint32_t* n_iter = nullptr) {
+                                                  float& t, f3& pos, float& dt, uint32_t* n_iter = nullptr, const OccWord* seed = nullptr) {
 	const uint32_t* __restrict__ coarse_mask = march_lds;
 	const uint8_t* __restrict__ bitfield = m.bitfield;
 	const Box3& occ_box = m.occ.box;
@@ -421,6 +437,7 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 	bool in_occ;
 #if NRS_OPT_OCCWORD && NRS_OPT_MORTON
 	OccWord occ_word{0xffffffffu, 0u, 0u};
+	if (seed) occ_word = *seed;
 	#define NRS_OCCUPIED(pos_, mip_) occupied_at_cached(pos_, bitfield, mip_, march_lds, occ_word)
 #else
 	#define NRS_OCCUPIED(pos_, mip_) occupied_at(pos_, bitfield, mip_, march_lds)
