@@ -107,7 +107,7 @@ def cpu_baseline(synth):
             "one_thread": {"value": round(int(st1.composited) / dt1 / 1e6, 5), "unit": "Msamples/s", "sample": f"64x64 view of the same camera, {int(st1.composited)} samples in {dt1:.1f} s"}}
 
 
-TRAFFIC_FILE = "profiles/r02_traffic.json"
+TRAFFIC_FILE = "profiles/r03_traffic.json"
 
 
 def measured_traffic(workload):

@@ -71,7 +71,7 @@ typedef enum nrs_activation {
 typedef enum nrs_render_mode {
 	NRS_RENDER_AO = 0, NRS_RENDER_SHADE = 1, NRS_RENDER_NORMALS = 2, NRS_RENDER_POSITIONS = 3,
 	NRS_RENDER_DEPTH = 4, NRS_RENDER_DISTANCE = 5, NRS_RENDER_STEPSIZE = 6, NRS_RENDER_DISTORTION = 7,
-	NRS_RENDER_COST = 8, NRS_RENDER_SLICE = 9
+	NRS_RENDER_COST = 8, NRS_RENDER_SLICE = 9, NRS_RENDER_ENCODING_VIS = 11 /* ERenderMode::EncodingVis sits behind NumRenderModes (10) */
 } nrs_render_mode;
 
 /* GPUMatrixDynamic<T>::layout() of the network output: planes = row-major [16 x n_el]

@@ -1223,10 +1223,10 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_render_nerf: parameters not set (nrs_model_set_params)");
 	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_render_nerf: occupancy not set (nrs_model_set_density_bitfield/_grid)");
 	{ const int pc = check_march_params(*p, "nrs_render_nerf"); if (pc != NRS_OK) return pc; }
+	if (p->render_mode == NRS_RENDER_NORMALS || p->render_mode == NRS_RENDER_DISTORTION || p->render_mode == NRS_RENDER_ENCODING_VIS)
+		return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: render modes Normals (network input gradient), EncodingVis (visualize_activation) and Distortion (camera "
+		                                  "distortion map) need tiny-cuda-nn / the distortion trainer and are not on the path");
 	if (p->render_mode > NRS_RENDER_SLICE) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: unknown render mode");
-	if (p->render_mode == NRS_RENDER_NORMALS || p->render_mode == NRS_RENDER_DISTORTION)
-		return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: render modes Normals (network input gradient) and Distortion (camera distortion map) need tiny-cuda-nn / the "
-		                                  "distortion trainer and are not on the path");
 	if (!std::isfinite(p->dof) || !std::isfinite(p->slice_plane_z) || !std::isfinite(p->depth_scale)) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: dof / slice_plane_z / depth_scale must be finite");
 	if (p->dof != 0.f && p->slice_plane_z == 0.f) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: dof != 0 needs a focus distance (slice_plane_z = m_slice_plane_z + m_scale != 0)");
 	if (n_edits < 0 || n_edits > nrs_ctx::kMaxEdits) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: too many edit operators");

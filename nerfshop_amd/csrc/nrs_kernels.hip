@@ -739,9 +739,9 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 	hipStream_t s = (hipStream_t)stream;
 	constexpr int R = kNumRuntime;
 	if (a.extra) // render modes / show_accel / depth of field: the catch-all instantiation (every operator kind, membrane correction, one lane per ray)
-		return m.numerics ? launch_render_cfg<8, 3, false, true, true, 1, R, true>(m, a, n_cus, s) : launch_render_cfg<8, 3, false, true, true, 1, 0, true>(m, a, n_cus, s);
+		return m.numerics ? launch_render_cfg<12, 3, false, true, true, 1, R, true>(m, a, n_cus, s) : launch_render_cfg<12, 3, false, true, true, 1, 0, true>(m, a, n_cus, s);
 	if (m.numerics) { // tiny-cuda-nn's other roundings: the run-time twin of every schedule (nrs_render_nerf computed the packet geometry for a.team)
-		if (a.any_poisson) return launch_render_cfg<8, 3, false, true, true, 1, R>(m, a, n_cus, s);
+		if (a.any_poisson) return launch_render_cfg<12, 3, false, true, true, 1, R>(m, a, n_cus, s);
 		if (a.any_affine) return launch_render_cfg<8, 3, false, false, true, 1, R>(m, a, n_cus, s);
 		if (a.team == 0) return launch_render_cfg<8, 3, false, false, false, 0, R>(m, a, n_cus, s);
 		if (a.team == 2) return launch_render_cfg<8, 3, false, false, false, 2, R>(m, a, n_cus, s);
@@ -750,7 +750,9 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 	}
 	// membrane correction: 142 VGPRs, no scratch, 3 waves per SIMD (the SH9 colour loop is kept rolled for that: unrolled it held 108 coefficient loads
 	// in flight, 250 VGPRs, 2 waves per SIMD: 6.1 Gsamples/s on the bench's lego_cage_membrane)
-	if (a.any_poisson) return launch_render_cfg<8, 3, false, true, true>(m, a, n_cus, s);
+	// (12-wave workgroups: at 3 waves per SIMD a CU holds 12 waves, i.e. ONE 8-wave workgroup and a half -- the first r03 profile showed 256 workgroups,
+	// 2 waves per SIMD; one 768-thread workgroup per CU uses all three)
+	if (a.any_poisson) return launch_render_cfg<12, 3, false, true, true>(m, a, n_cus, s);
 	if (a.dbg & 4u) return a.team == 0 ? launch_render_cfg<8, 4, true, false, false, 0>(m, a, n_cus, s) : launch_render_cfg<8, 4, true>(m, a, n_cus, s);
 	// Production instantiations: scheduled for 3 waves/SIMD, capped at 128 VGPRs = 4 waves/SIMD (render_kernel_c128).  Measured against the
 	// __launch_bounds__(512, 4) build of the same code (NRS_RENDER_CFG=84): 1080p lego + cage 9.43 -> 9.82 Gsamples/s, lego 10.7 -> 11.0,
