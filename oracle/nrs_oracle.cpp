@@ -531,6 +531,11 @@ struct Model {
 	//             sum after every 16-wide k block (acc = fp16(acc + exact sum of 16 products)); how a tensor core sums inside a block is not
 	//             specified by NVIDIA, so this is a model of it, not a pin.
 	uint32_t grid_acc = 0, mlp_acc = 0;
+	// CPU-baseline flavour (orc_model_set_fast; bench.py's cpu_baseline leg ONLY, never a checker): SURVEY 8(d)'s "fp32 math with fp16 rounding points
+	// emulated (_Float16 / F16C)" -- hardware half conversions, MLP sums accumulated in fp32 (vectorised) instead of exactly, power-of-two table sizes
+	// masked instead of divided.  Same algorithm, same rounding POINTS as the checker; sums may differ from it in the last fp16 bit
+	// (tests/test_oracle_kat.py::test_fast_flavour_stays_within_the_network_tolerance).
+	bool fast = false;
 	LevelTable lt;
 	Box aabb;
 	std::vector<uint16_t> params; // tcnn order: density | rgb | grid
@@ -654,9 +659,75 @@ void rgb_mlp_one(const Model& m, const uint16_t in32[32], uint16_t out[16]) {
 	dense_layer(W2, 64, 64, h1, h2, true, m.mlp_acc);
 	dense_layer(W3, 16, 64, h2, out, false, m.mlp_acc);
 }
+// ---- the CPU-baseline flavour of the network (Model::fast) ------------------------------------------------------------------------
+#if defined(__F16C__)
+#include <immintrin.h>
+static inline float h2f_hw(uint16_t h) { return _cvtsh_ss(h); }
+static inline uint16_t f2h_hw(float f) { return _cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
+#else
+static inline float h2f_hw(uint16_t h) { return h2f(h); }
+static inline uint16_t f2h_hw(float f) { return f2h(f); }
+#endif
+static inline void dense_layer_fast(const float* W, uint32_t n_out, uint32_t n_in, const float* in, float* out, bool relu) {
+	for (uint32_t j = 0; j < n_out; ++j) {
+		const float* w = W + (size_t)j * n_in;
+		float acc = 0.f;
+#pragma omp simd reduction(+ : acc)
+		for (uint32_t k = 0; k < n_in; ++k) acc += w[k] * in[k];
+		if (relu && !(acc > 0.f)) acc = 0.f;
+		out[j] = h2f_hw(f2h_hw(acc)); // the fp16 rounding point between layers
+	}
+}
+static void network_inference_fast(const Model& m, const float coord[7], uint16_t out16[16]) {
+	const uint16_t* grid = m.grid();
+	float in32[32], dout[16], h1[64], h2[64], o[16];
+	for (uint32_t l = 0; l < m.desc.n_levels; ++l) { // hash grid: the checker's arithmetic (fmaf per corner, one rounding) with hardware conversions
+		const float scale = m.lt.scale[l];
+		const uint32_t res = m.lt.resolution[l], cnt = m.lt.count[l], off = m.lt.offset[l];
+		const bool pow2 = (cnt & (cnt - 1u)) == 0u;
+		float w[3];
+		uint32_t g[3];
+		for (int d = 0; d < 3; ++d) {
+			const float p = fmaf(scale, coord[d], 0.5f), fl = floorf(p);
+			g[d] = (uint32_t)(int)fl;
+			w[d] = p - fl;
+		}
+		float acc0 = 0.f, acc1 = 0.f;
+		for (uint32_t c = 0; c < 8; ++c) {
+			float weight = 1.0f;
+			uint32_t gl[3];
+			for (int d = 0; d < 3; ++d) {
+				if ((c & (1u << d)) == 0) { weight *= 1.0f - w[d]; gl[d] = g[d]; }
+				else { weight *= w[d]; gl[d] = g[d] + 1u; }
+			}
+			uint32_t index = m.lt.hashed[l] ? ((gl[0] * 1u) ^ (gl[1] * 2654435761u) ^ (gl[2] * 805459861u)) : (gl[0] + gl[1] * res + gl[2] * res * res);
+			index = pow2 ? (index & (cnt - 1u)) : (index % cnt);
+			const uint16_t* e = grid + 2 * (size_t)(off + index);
+			acc0 = fmaf(weight, h2f_hw(e[0]), acc0);
+			acc1 = fmaf(weight, h2f_hw(e[1]), acc1);
+		}
+		in32[2 * l] = h2f_hw(f2h_hw(acc0));
+		in32[2 * l + 1] = h2f_hw(f2h_hw(acc1));
+	}
+	const float* W = m.wf.data();
+	dense_layer_fast(W, 64, 32, in32, h1, true);
+	dense_layer_fast(W + 64 * 32, 16, 64, h1, dout, false);
+	uint16_t sh[16];
+	sh4_encode_one(coord + 4, sh);
+	float rin[32];
+	for (int i = 0; i < 16; ++i) { rin[i] = dout[i]; rin[16 + i] = h2f_hw(sh[i]); }
+	const float* R = W + N_DENSITY_W;
+	dense_layer_fast(R, 64, 32, rin, h1, true);
+	dense_layer_fast(R + 64 * 32, 64, 64, h1, h2, true);
+	dense_layer_fast(R + 64 * 32 + 64 * 64, 16, 64, h2, o, false);
+	for (int i = 0; i < 16; ++i) out16[i] = f2h_hw(o[i]);
+	out16[3] = f2h_hw(dout[0]);
+}
+
 // NerfNetworkFull::inference_mixed_precision_impl, nerf_network_full.h:62-96.  coord: 7 floats. out16: channels
 // 0..2 rgb raw, 3 = density raw (extract_density :89-95), 4..15 rgb-net padding outputs.
 void network_inference_one(const Model& m, const float coord[7], uint16_t out16[16]) {
+	if (m.fast) { network_inference_fast(m, coord, out16); return; }
 	uint16_t feat[32], in32[32];
 	hashgrid_encode_one(m, coord, feat);
 	density_mlp_one(m, feat, in32);          // rows 0..15 of rgb_network_input
@@ -1537,6 +1608,7 @@ void* orc_model_create(const nrs_model_desc* d, const uint16_t* params, size_t n
 }
 void orc_model_set_bitfield(void* model, const uint8_t* bitfield) { ((Model*)model)->bitfield.assign(bitfield, bitfield + NRS_BITFIELD_BYTES); }
 void orc_model_destroy(void* model) { delete (Model*)model; }
+void orc_model_set_fast(void* model, int on) { ((Model*)model)->fast = on != 0; } // bench.py's cpu_baseline flavour; see Model::fast
 void orc_model_set_numerics(void* model, uint32_t grid_acc, uint32_t mlp_acc) { ((Model*)model)->grid_acc = grid_acc; ((Model*)model)->mlp_acc = mlp_acc; }
 
 // out: [n x 32] fp16 interleaved
@@ -1821,7 +1893,7 @@ struct orc_render_stats { uint64_t generated, composited; uint32_t n_alive0, n_h
 void orc_render(void* model, const nrs_render_params* p, void* const* edits, int n_edits, float* frame, float* depth, uint32_t* steps,
                 orc_render_stats* stats, int fixed_S, int n_threads) {
 #ifdef _OPENMP
-	if (n_threads > 0) omp_set_num_threads(n_threads);
+	omp_set_num_threads(n_threads > 0 ? n_threads : omp_get_num_procs()); // 0 = every core (and not whatever an earlier call left behind)
 #endif
 	RenderStats rs{};
 	render(*(Model*)model, *p, (const Edit* const*)edits, n_edits, frame, depth, steps, &rs, fixed_S);

@@ -85,6 +85,11 @@ class Model:
         if not self.h:
             raise ValueError("oracle: unsupported model description or wrong parameter count")
 
+    def set_fast(self, on=True):
+        """bench.py's cpu_baseline flavour (F16C conversions, fp32-accumulated MLP sums): for TIMING only, never as the checker."""
+        self.lib.orc_model_set_fast.restype = None
+        self.lib.orc_model_set_fast(C.c_void_p(self.h), C.c_int(1 if on else 0))
+
     def set_numerics(self, grid_acc=0, mlp_acc=0):
         self.lib.orc_model_set_numerics.restype = None
         self.lib.orc_model_set_numerics(C.c_void_p(self.h), C.c_uint32(grid_acc), C.c_uint32(mlp_acc))

@@ -384,3 +384,25 @@ def test_local_rotations_pinned_to_the_reference_code(built):
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         assert np.array_equal(mod.ref_rotations(g["vertices"], g["original_vertices"], g["tets"]).view(np.uint32), want)
+
+
+def test_fast_flavour_stays_within_the_network_tolerance(built):
+    """Model.set_fast (bench.py's cpu_baseline leg only): hardware half conversions and fp32-accumulated MLP sums instead of the checker's exact ones.
+    Same algorithm and rounding points: hash-grid features identical, network outputs within the tolerance the GPU kernels are held to (<= 4 fp16
+    ulps or 2e-3 abs), nearly all identical; and a frame rendered with it is the checker's frame within the renderer's colour bar."""
+    from nerfshop_amd import synth
+    from oracle import oracle as orc
+    desc = synth.model_desc(1)
+    params = synth.make_params(desc, sigma_raw=synth.default_sigma_raw(1))
+    model = orc.Model(desc, params, synth.grid_to_bitfield(synth.density_grid(1)))
+    c = np.random.default_rng(3).uniform(0, 1, (20000, 7)).astype(np.float32)
+    a = model.inference(c, 0)
+    p = synth.render_params(96, 54, synth.orbit_camera(30.0), aabb_scale=1, apply_operators=False)
+    fa, da, sa, _ = model.render(p, [])
+    model.set_fast(True)
+    b = model.inference(c, 0)
+    fb, db, sb, _ = model.render(p, [])
+    af, bf = a.view(np.float16).astype(np.float32), b.view(np.float16).astype(np.float32)
+    ulp = np.maximum(np.abs(af), 2.0 ** -14) * 2.0 ** -10
+    assert ((np.abs(af - bf) <= 4 * ulp) | (np.abs(af - bf) <= 2e-3)).all() and (a == b).mean() > 0.98
+    assert np.abs(fa - fb).max() < 6e-3 and np.abs(sa.astype(np.int64) - sb.astype(np.int64)).max() <= 1
