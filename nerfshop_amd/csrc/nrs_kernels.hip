@@ -444,7 +444,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 
 		NRS_PHASE(3); // gather
 		// ---- gather: own sample (block g) and the partner lane's sample (block 1-g), levels 2*it+g ----
-		encode_num<NUM>(nm, gv, m2.levels, sm.ml, fl, lane, g, wpos, act);
+		encode_num<NUM, (TEAM == 0 && !POISSON && !AFFINE && !EXTRA && NUM == 0)>(nm, gv, m2.levels, sm.ml, fl, lane, g, wpos, act); // (four record levels in flight: the hybrid instantiation has the registers)
 		// NRS_OPT_EARLY_MARCH: the walk to the NEXT sample does not depend on the network, and its first step is nearly always its last (the next
 		// sample of a ray inside the object stands in an occupied cell).  The bitfield word that first test needs is requested HERE, in front of the
 		// MLPs, and handed to march_to_occupied behind the compositing: one memory round trip less on the round's dependency chain.

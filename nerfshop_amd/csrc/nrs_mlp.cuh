@@ -313,6 +313,29 @@ __device__ __forceinline__ void level_eval_two(const GridView& gv, const LevelPa
 	f0 = zero_if(!act, f0);
 	f1 = zero_if(!act, f1);
 }
+// FOUR record levels (two consecutive pairs) of one sample with all their loads in flight at once: a round is a chain of dependent memory round
+// trips and the gather is eight of them; the twelve record levels then cost three trips instead of six.  The price is registers (32 loaded dwords
+// instead of 16): the interpolation weights are therefore NOT kept across the loads but recomputed from the position (9 instructions per level),
+// behind an opaque copy of the position so that the compiler cannot keep the first set alive.
+#ifndef NRS_OPT_QUADS
+#define NRS_OPT_QUADS 1
+#endif
+template <bool NETACC = false>
+__device__ __forceinline__ void record_eval_four(const GridView& gv, const LevelParams& lp0, const LevelParams& lp1, const LevelParams& lp2, const LevelParams& lp3, f3 pos, bool act,
+                                                 uint32_t& f0, uint32_t& f1, uint32_t& f2, uint32_t& f3_) {
+	f3 q = act ? pos : mk3(0.f, 0.f, 0.f);
+	uint32_t v0[8], v1[8], v2[8], v3[8];
+	issue_record_loads(gv, lp0, cell_coords(lp0, q), v0);
+	issue_record_loads(gv, lp1, cell_coords(lp1, q), v1);
+	issue_record_loads(gv, lp2, cell_coords(lp2, q), v2);
+	issue_record_loads(gv, lp3, cell_coords(lp3, q), v3);
+	asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z)); // the weights below are recomputed, not carried across the loads
+	f0 = zero_if(!act, interpolate<NETACC>(cell_coords(lp0, q), v0));
+	f1 = zero_if(!act, interpolate<NETACC>(cell_coords(lp1, q), v1));
+	f2 = zero_if(!act, interpolate<NETACC>(cell_coords(lp2, q), v2));
+	f3_ = zero_if(!act, interpolate<NETACC>(cell_coords(lp3, q), v3));
+}
+
 // One level of one sample, kind decided at run time (wave-uniform): the pairs whose two levels are of different kinds (the one
 // dense | hashed pair of a model without cell records, a records | no-records boundary at an odd level) come here, level after level.
 template <bool NETACC = false>
@@ -344,17 +367,28 @@ __device__ __forceinline__ uint32_t level_eval_one(const GridView& gv, const Lev
 // same bits as before: the arithmetic per (sample, level) did not change.  The slab layout the MLP reads is unchanged too:
 // feat[it][0][l] = level 2 it + g(l) of lane l's sample, feat[it][1][l] = the same level of lane (l ^ 32)'s sample; so the level
 // of the lane's own parity goes to [0][lane] and the other one to [1][lane ^ 32] (a conflict-free permutation of the banks).
-template <bool NETACC = false>
+template <bool NETACC = false, bool QUADS = false>
 __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelParams* __restrict__ lv, const ModelLds& ml, FeatLds& fl, int lane, int g, f3 pos, bool act) {
 	// the records cover [0,1]^3; a wave with a sample outside it (a warped sample of an edit, rarely) gathers the native way
 	const bool outside = __any(act && outside_unit_cube(pos));
 	const uint32_t* kinds = outside ? ml.kinds_native : ml.kinds;
 	const bool one_line = __builtin_amdgcn_readfirstlane(ml.one_line) != 0u; // profiling (NRS_DEBUG & 1): every gather of a wave hits one 128-byte line
+	int it = 0;
 	#pragma unroll 1
-	for (int it = 0; it < 8; ++it) {
+	while (it < 8) {
 		LevelParams lp0 = lv[2 * it], lp1 = lv[2 * it + 1];
 		if (one_line) { lp0.hashed = lp1.hashed = 1u; lp0.mask = lp1.mask = 31u; lp0.offset = lp1.offset = 0u; lp0.count = lp1.count = 32u; }
 		const uint32_t kind = __builtin_amdgcn_readfirstlane(kinds[it]);
+		if (NRS_OPT_QUADS && QUADS && kind == KIND_RECORD && it + 1 < 8 && __builtin_amdgcn_readfirstlane(kinds[it + 1]) == KIND_RECORD) {
+			uint32_t f0, f1, f2, f3_;
+			record_eval_four<NETACC>(gv, lp0, lp1, lv[2 * it + 2], lv[2 * it + 3], pos, act, f0, f1, f2, f3_);
+			fl.feat[it][0][lane] = g ? f1 : f0;
+			fl.feat[it][1][lane ^ 32] = g ? f0 : f1;
+			fl.feat[it + 1][0][lane] = g ? f3_ : f2;
+			fl.feat[it + 1][1][lane ^ 32] = g ? f2 : f3_;
+			it += 2;
+			continue;
+		}
 		uint32_t f0, f1;
 		if (kind == KIND_RECORD) level_eval_two<KIND_RECORD, NETACC>(gv, lp0, lp1, pos, act, f0, f1);
 		else if (kind == KIND_HASHED) level_eval_two<KIND_HASHED, NETACC>(gv, lp0, lp1, pos, act, f0, f1);
@@ -366,6 +400,7 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 		}
 		fl.feat[it][0][lane] = g ? f1 : f0;
 		fl.feat[it][1][lane ^ 32] = g ? f0 : f1;
+		++it;
 	}
 	// feat[..][1][lane ^ 32] is another lane's slot: order the wave's writes before load_features' reads (no instruction: LDS operations of a wave
 	// stay in order; this keeps the compiler from moving a read above the write it cannot see through the xor)
@@ -543,10 +578,10 @@ __device__ __forceinline__ half8 rgb_mlp(const half8* lds_w, int lane, half8 din
 // tiny-cuda-nn's roundings as a template value: NUM >= 0 fixes them at compile time (bit 0 grid accumulation in network precision, bit 1 fp16 MLP
 // accumulators), kNumRuntime reads them from `nm` (DeviceModel::numerics, wave-uniform) -- both flavours compiled in, one scalar branch.
 constexpr int kNumRuntime = -1;
-template <int NUM>
+template <int NUM, bool QUADS = false>
 __device__ __forceinline__ void encode_num(uint32_t nm, const GridView& gv, const LevelParams* __restrict__ lv, const ModelLds& ml, FeatLds& fl, int lane, int g, f3 pos, bool act) {
-	if (NUM == kNumRuntime ? (nm & 1u) != 0u : (NUM & 1) != 0) encode_to_lds<true>(gv, lv, ml, fl, lane, g, pos, act);
-	else encode_to_lds<false>(gv, lv, ml, fl, lane, g, pos, act);
+	if (NUM == kNumRuntime ? (nm & 1u) != 0u : (NUM & 1) != 0) encode_to_lds<true, QUADS>(gv, lv, ml, fl, lane, g, pos, act);
+	else encode_to_lds<false, QUADS>(gv, lv, ml, fl, lane, g, pos, act);
 }
 template <int NUM>
 __device__ __forceinline__ half8 density_mlp_num(uint32_t nm, const half8* lds_w, int lane, half8 x0, half8 x1) {
