@@ -153,6 +153,24 @@ struct nrs_tet_lut {
 
 static thread_local std::string g_auth_err;
 
+// hardware threads this process may really use: hardware_concurrency() cut to the cgroup's CPU quota (a container that shows 256 CPUs under a 16-core
+// quota is throttled when 256 busy threads start)
+static uint32_t usable_threads() {
+	uint32_t n = std::max(1u, std::thread::hardware_concurrency());
+	double quota = -1.0, period = 100000.0;
+	if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char q[64] = {0};
+		if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0) quota = atof(q);
+		fclose(f);
+	} else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+		if (fscanf(g, "%lf", &quota) != 1) quota = -1.0;
+		fclose(g);
+		if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lf", &period) != 1) period = 100000.0; fclose(h); }
+	}
+	if (quota > 0.0 && period > 0.0) n = std::min<uint32_t>(n, (uint32_t)std::max(1.0, std::ceil(quota / period)));
+	return n;
+}
+
 extern "C" {
 
 int nrs_tet_lut_build(const float* h_vertices, uint32_t n_vertices, const uint32_t* h_tets, uint32_t n_tets, int n_threads, nrs_tet_lut** out) {
@@ -162,7 +180,7 @@ int nrs_tet_lut_build(const float* h_vertices, uint32_t n_vertices, const uint32
 	nrs_tet_lut* lut = new (std::nothrow) nrs_tet_lut();
 	if (!lut) return NRS_ERR_STATE;
 	const P3* verts = reinterpret_cast<const P3*>(h_vertices);
-	uint32_t nt = n_threads > 0 ? (uint32_t)n_threads : std::max(1u, std::thread::hardware_concurrency());
+	uint32_t nt = n_threads > 0 ? (uint32_t)n_threads : usable_threads();
 	nt = std::min(nt, n_tets);
 	// contiguous tet ranges per thread, merged in thread order: within a cell the LUT lists tets in ascending index
 	// (the order the reference's thread-ordered second pass produces, tet_mesh.cu:496-512)

@@ -1890,22 +1890,41 @@ void orc_edit_map_positions(void* edit, uint32_t n, float* pos, uint32_t ld, uin
 struct orc_render_stats { uint64_t generated, composited; uint32_t n_alive0, n_hit, iterations, pad; };
 // frame must be pre-cleared by the caller; depth/steps are written for owned pixels.
 // fixed_S: 0 = the reference's dynamic S, else force n_steps_between_compaction (S-invariance tests).
+static int effective_cores();
 void orc_render(void* model, const nrs_render_params* p, void* const* edits, int n_edits, float* frame, float* depth, uint32_t* steps,
                 orc_render_stats* stats, int fixed_S, int n_threads) {
 #ifdef _OPENMP
-	omp_set_num_threads(n_threads > 0 ? n_threads : omp_get_num_procs()); // 0 = every core (and not whatever an earlier call left behind)
+	omp_set_num_threads(n_threads > 0 ? n_threads : effective_cores()); // 0 = every core this process may use (and not whatever an earlier call left behind)
 #endif
 	RenderStats rs{};
 	render(*(Model*)model, *p, (const Edit* const*)edits, n_edits, frame, depth, steps, &rs, fixed_S);
 	if (stats) { stats->generated = rs.generated; stats->composited = rs.composited; stats->n_alive0 = rs.n_alive0; stats->n_hit = rs.n_hit; stats->iterations = rs.iterations; stats->pad = 0; }
 }
-int orc_max_threads(void) {
+// The cores this process may actually use: the affinity mask, cut to the cgroup's CPU quota (cpu.max of cgroup v2, cpu.cfs_quota_us / cpu.cfs_period_us
+// of v1).  A container that sees 256 logical CPUs under a 16-core quota -- the GPU boxes of this project -- is throttled to a crawl when OpenMP starts
+// 256 busy threads: every parallel region of this file runs with this count (set once when the library is loaded, and by orc_render's n_threads = 0).
+static int effective_cores() {
+	int n = 1;
 #ifdef _OPENMP
-	return omp_get_max_threads();
-#else
-	return 1;
+	n = omp_get_num_procs();
 #endif
+	double quota = -1.0, period = 100000.0;
+	if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char q[64] = {0};
+		if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0) quota = atof(q);
+		fclose(f);
+	} else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+		if (fscanf(g, "%lf", &quota) != 1) quota = -1.0;
+		fclose(g);
+		if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lf", &period) != 1) period = 100000.0; fclose(h); }
+	}
+	if (quota > 0.0 && period > 0.0) n = std::min(n, std::max(1, (int)ceil(quota / period)));
+	return std::max(n, 1);
 }
+#ifdef _OPENMP
+static const int g_threads_at_load = []() { const int n = effective_cores(); if (!getenv("OMP_NUM_THREADS")) omp_set_num_threads(n); return n; }();
+#endif
+int orc_max_threads(void) { return effective_cores(); }
 
 // per listed pixel: the (t, dt) stream of init -> jitter -> first hit -> successive samples, ignoring compositing
 void orc_trace_samples(void* model, const nrs_render_params* p, uint32_t n_pixels, const uint32_t* pixel_idx, uint32_t max_samples,
