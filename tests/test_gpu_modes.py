@@ -204,3 +204,46 @@ def test_modes_through_every_boundary_flavour(rig):
     finally:
         rig.ctx.set_lane_teams(0)
         rig.use_edit(False)
+
+
+def test_modes_with_affine_stack_and_on_tiles(rig):
+    """the EXTRA instantiation is the catch-all: AffineDuplication + cage operators in a mode against the oracle, and a mode rendered through the
+    multi-GPU tile interface (three 'ranks') reassembles the whole-image frame bit for bit"""
+    from nerfshop_amd import _abi
+    from test_gpu_affine import _edited_bitfield
+    scene, torch = rig.scene, rig.torch
+    op = scene.synth.make_affine_edit(hide_original=False)
+    dev = rig.rt.AffineDuplication(rig.ctx, scene.desc, op)
+    ref_op = scene.orc.AffineEdit(scene.desc, op)
+    bits = _edited_bitfield(scene, [scene.oracle_edit, ref_op])
+    saved = rig.testbed.edit_operators
+    try:
+        rig.testbed.edit_operators = [rig.op, dev]
+        rig.net.set_density_bitfield(bits)
+        scene.oracle_model.set_bitfield(bits)
+        W, H, T = 256, 144, 32
+        p = _params(rig, W, H, 60.0, render_mode=POSITIONS)
+        whole = rig.render(p)
+        ref = scene.oracle_model.render(p, [scene.oracle_edit, ref_op])
+        assert ref[3].n_hit > 1000
+        _compare(whole, ref)
+        tiles_x = (W + T - 1) // T
+        image = np.zeros((H, W, 4), np.float32)
+        for rank in range(3):
+            q = _params(rig, W, H, 60.0, render_mode=POSITIONS, tile_size=T, tile_first=rank, tile_stride=3)
+            owned = _abi.load().nrs_render_owned_tiles(C.byref(q))
+            frame = torch.zeros((owned, T, T, 4), dtype=torch.float32, device="cuda:0")
+            depth = torch.zeros((owned, T, T), dtype=torch.float32, device="cuda:0")
+            rig.testbed.render_with_params(rig.net, q, frame, depth, None, None, want_stats=True)
+            torch.cuda.synchronize()
+            f = frame.cpu().numpy()
+            for k in range(owned):
+                t = rank + 3 * k
+                tx, ty = t % tiles_x, t // tiles_x
+                h, w = min(T, H - ty * T), min(T, W - tx * T)
+                image[ty * T:ty * T + h, tx * T:tx * T + w] = f[k, :h, :w]
+        assert np.array_equal(image.view(np.uint32), whole[0].view(np.uint32))
+    finally:
+        rig.testbed.edit_operators = saved
+        rig.use_edit(False)
+        dev.close()
