@@ -247,8 +247,9 @@ int    nrs_model_set_params(nrs_model* model, const void* h_params_fp16, size_t 
  * records (if any are kept) rebuilt, all enqueued on `stream`; launches enqueued on the same stream afterwards see the new parameters, and the
  * blob may be overwritten once the stream has passed this call.  Copy semantics: call again after every optimiser step. */
 int    nrs_model_set_params_device(nrs_model* model, const void* d_params_fp16, size_t n_params, void* stream);
-/* nrs_grid_acc / nrs_mlp_acc above.  Applies to every entry point that evaluates the network.  The render kernel runs the non-default modes
- * with one lane per ray and without the membrane / AffineDuplication instantiations (NRS_ERR_UNSUPPORTED for those combinations). */
+/* nrs_grid_acc / nrs_mlp_acc above.  Applies to every entry point that evaluates the network -- nrs_render_nerf in every schedule, mode and operator
+ * combination, the network operators, the occupancy refresh, the grid evaluators, selection rays, the membrane boundary (round 3: no combination is
+ * refused any more; the non-default modes run the run-time twins of the kernels, a little slower than the default instantiations). */
 int    nrs_model_set_numerics(nrs_model* model, uint32_t grid_acc, uint32_t mlp_acc);
 /* Cell-record cache (no counterpart in the reference: a memory-for-bandwidth trade the 288 GB of HBM allow).  For the
  * coarsest levels that fit `max_bytes` (an even number of them), every grid cell gets a 32-byte record holding its 8

@@ -155,6 +155,23 @@ __device__ __forceinline__ CellCoords cell_coords(const LevelParams& lp, f3 pos)
 	c.wx = px - fx; c.wy = py - fy; c.wz = pz - fz;
 	return c;
 }
+// The same for a position inside [0,1]^3 (every caller of the record paths: a wave with a sample outside the cube gathers the native way): there
+// p = scale * x + 0.5 >= 0.5, so the cell is the truncation of p (v_cvt_u32_f32: no floor, no second conversion) and the weight its fractional part
+// (v_fract_f32 = p - floor(p), exact for p >= 0): the same cell and the same weight bits in 9 instructions per level instead of 12.
+#ifndef NRS_OPT_FRACT
+#define NRS_OPT_FRACT 1
+#endif
+__device__ __forceinline__ CellCoords cell_coords_incube(const LevelParams& lp, f3 pos) {
+#if NRS_OPT_FRACT
+	CellCoords c;
+	const float px = fmaf(lp.scale, pos.x, 0.5f), py = fmaf(lp.scale, pos.y, 0.5f), pz = fmaf(lp.scale, pos.z, 0.5f);
+	c.gx = (uint32_t)px; c.gy = (uint32_t)py; c.gz = (uint32_t)pz;
+	c.wx = __builtin_amdgcn_fractf(px); c.wy = __builtin_amdgcn_fractf(py); c.wz = __builtin_amdgcn_fractf(pz);
+	return c;
+#else
+	return cell_coords(lp, pos);
+#endif
+}
 typedef float f2 __attribute__((ext_vector_type(2)));
 // dense fast path precondition: no index of the cell reaches `count`, so no wrap and x-neighbours are adjacent entries
 __device__ __forceinline__ bool dense_needs_slow(const LevelParams& lp, const CellCoords& c) {
@@ -280,7 +297,8 @@ __device__ __forceinline__ uint32_t zero_if(bool cond, uint32_t v) { return cond
 template <int KIND, bool NETACC = false>
 __device__ __forceinline__ void level_eval_two(const GridView& gv, const LevelParams& lp0, const LevelParams& lp1, f3 pos, bool act, uint32_t& f0, uint32_t& f1) {
 	const f3 q = act ? pos : mk3(0.f, 0.f, 0.f);
-	const CellCoords c0 = cell_coords(lp0, q), c1 = cell_coords(lp1, q);
+	const bool incube = KIND == KIND_RECORD || KIND == KIND_SPARSE; // (record kinds are only chosen for waves whose samples all lie in [0,1]^3)
+	const CellCoords c0 = incube ? cell_coords_incube(lp0, q) : cell_coords(lp0, q), c1 = incube ? cell_coords_incube(lp1, q) : cell_coords(lp1, q);
 	if (KIND == KIND_SPARSE) {
 		uint32_t b0 = brick_entry(gv, lp0, c0), b1 = brick_entry(gv, lp1, c1);
 		if (!act) { b0 = 1u; b1 = 1u; } // idle lanes read the level's first record
@@ -325,15 +343,15 @@ __device__ __forceinline__ void record_eval_four(const GridView& gv, const Level
                                                  uint32_t& f0, uint32_t& f1, uint32_t& f2, uint32_t& f3_) {
 	f3 q = act ? pos : mk3(0.f, 0.f, 0.f);
 	uint32_t v0[8], v1[8], v2[8], v3[8];
-	issue_record_loads(gv, lp0, cell_coords(lp0, q), v0);
-	issue_record_loads(gv, lp1, cell_coords(lp1, q), v1);
-	issue_record_loads(gv, lp2, cell_coords(lp2, q), v2);
-	issue_record_loads(gv, lp3, cell_coords(lp3, q), v3);
+	issue_record_loads(gv, lp0, cell_coords_incube(lp0, q), v0);
+	issue_record_loads(gv, lp1, cell_coords_incube(lp1, q), v1);
+	issue_record_loads(gv, lp2, cell_coords_incube(lp2, q), v2);
+	issue_record_loads(gv, lp3, cell_coords_incube(lp3, q), v3);
 	asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z)); // the weights below are recomputed, not carried across the loads
-	f0 = zero_if(!act, interpolate<NETACC>(cell_coords(lp0, q), v0));
-	f1 = zero_if(!act, interpolate<NETACC>(cell_coords(lp1, q), v1));
-	f2 = zero_if(!act, interpolate<NETACC>(cell_coords(lp2, q), v2));
-	f3_ = zero_if(!act, interpolate<NETACC>(cell_coords(lp3, q), v3));
+	f0 = zero_if(!act, interpolate<NETACC>(cell_coords_incube(lp0, q), v0));
+	f1 = zero_if(!act, interpolate<NETACC>(cell_coords_incube(lp1, q), v1));
+	f2 = zero_if(!act, interpolate<NETACC>(cell_coords_incube(lp2, q), v2));
+	f3_ = zero_if(!act, interpolate<NETACC>(cell_coords_incube(lp3, q), v3));
 }
 
 // One level of one sample, kind decided at run time (wave-uniform): the pairs whose two levels are of different kinds (the one
