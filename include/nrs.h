@@ -64,10 +64,10 @@ typedef enum nrs_activation {
 	NRS_ACT_NONE = 0, NRS_ACT_RELU = 1, NRS_ACT_LOGISTIC = 2, NRS_ACT_EXPONENTIAL = 3
 } nrs_activation;
 
-/* ERenderMode, common.h:71.  Implemented: AO, Shade, Positions, Depth, Distance, Stepsize, Cost, Slice (composite_kernel_nerf's per-sample
- * branches testbed_nerf.cu:905-937, shade_kernel_nerf :2466-2482, the Slice path :3111-3175).  Refused (NRS_ERR_UNSUPPORTED): Normals (needs the
- * network's input gradient, tcnn input_gradient), Distortion (needs the camera-distortion map), EncodingVis (m_visualized_dimension, tcnn
- * visualize_activation) -- all three live in tiny-cuda-nn / the distortion trainer, outside the path. */
+/* ERenderMode, common.h:71.  Implemented: AO, Shade, Positions, Depth, Distance, Stepsize, Distortion, Cost, Slice (composite_kernel_nerf's per-sample
+ * branches testbed_nerf.cu:905-937, shade_kernel_nerf :2466-2482, init_rays' Distortion branch :2602-2613, the Slice path :3111-3175).  Refused
+ * (NRS_ERR_UNSUPPORTED): Normals (needs the network's input gradient, tcnn input_gradient) and EncodingVis (m_visualized_dimension, tcnn
+ * visualize_activation) -- both live in tiny-cuda-nn, outside the path. */
 typedef enum nrs_render_mode {
 	NRS_RENDER_AO = 0, NRS_RENDER_SHADE = 1, NRS_RENDER_NORMALS = 2, NRS_RENDER_POSITIONS = 3,
 	NRS_RENDER_DEPTH = 4, NRS_RENDER_DISTANCE = 5, NRS_RENDER_STEPSIZE = 6, NRS_RENDER_DISTORTION = 7,
@@ -192,6 +192,16 @@ typedef struct nrs_render_params {
 	float    depth_scale;         /* 1 / m_nerf.training.dataset.scale (:3113): factor of render modes Depth and Distance */
 	uint32_t show_accel;          /* m_nerf.show_accel >= 0 (the level is min_mip): every sample becomes opaque (:788-790) and render mode
 	                               * Positions colours the occupancy cell (:911-920) */
+	/* camera model and background (init_rays_with_payload_kernel_nerf :2523-2533, 2585-2613; pixel_to_ray common_device.cuh:262-280).  The pointers are
+	 * DEVICE pointers for nrs_render_nerf (HOST pointers for the CPU oracle, which takes the same struct); NULL / 0 = absent. */
+	uint32_t distortion_mode;     /* ECameraDistortionMode, common.h:166: 0 None, 1 Iterative (OpenCV k1 k2 p1 p2, Newton undistortion :162-199), 2 FTheta (:231-243)
+	                               * = m_nerf.render_distortion when m_nerf.render_with_camera_distortion (:3078-3080) */
+	float    distortion_params[7];
+	const float* d_distortion_map;        /* m_distortion.map->params_inference(): float2 [res.y][res.x], added to the ray's xy (read_image<2>, :278-280) */
+	int32_t  distortion_resolution[2];
+	int32_t  envmap_resolution[2];
+	const float* d_envmap;                /* m_envmap.envmap->params_inference(): float RGBA [res.y][res.x]; every pixel's frame value is REPLACED by the
+	                                       * environment seen along its ray before the NeRF composites over it (read_envmap, envmap.cuh:30-63; :2590-2592) */
 } nrs_render_params;
 
 typedef struct nrs_render_stats {

@@ -167,6 +167,13 @@ public:
 	float m_dof = 0.f;                                // aperture of pixel_to_ray's thin-lens branch (common_device.cuh:285-293)
 	float m_slice_plane_z = 0.f, m_scale = 1.f;       // plane_z = m_slice_plane_z + m_scale (testbed_nerf.cu:3067): focus distance / slice plane
 	float m_dataset_scale = 1.f;                      // m_nerf.training.dataset.scale: depth_scale = 1 / it (:3113)
+	// camera model and background (render_nerf passes them to init_rays_from_camera, :3078-3100).  Device pointers, owned by the caller.
+	uint32_t m_render_distortion_mode = 0;            // m_nerf.render_distortion.mode when m_nerf.render_with_camera_distortion (ECameraDistortionMode)
+	float m_render_distortion_params[7] = {};         // m_nerf.render_distortion.params
+	const float* m_distortion_map = nullptr;          // m_distortion.map->params_inference() (float2 [res.y][res.x]) when render_with_camera_distortion, else NULL
+	int m_distortion_resolution[2] = {0, 0};          // m_distortion.resolution
+	const float* m_envmap = nullptr;                  // m_envmap.envmap->params_inference() (float RGBA [res.y][res.x]), NULL when the snapshot has none
+	int m_envmap_resolution[2] = {0, 0};              // m_envmap.resolution
 
 	// Testbed state update_density_grid_nerf_operator advances: m_rng, m_nerf.density_grid_ema_step, density_grid_decay, max_cascade
 	nrs_grid_update m_density_grid_update{};
@@ -215,6 +222,11 @@ public:
 		p.dof = m_dof;
 		p.slice_plane_z = m_slice_plane_z + m_scale;
 		p.depth_scale = 1.0f / m_dataset_scale;
+		p.distortion_mode = m_render_distortion_mode;
+		for (int i = 0; i < 7; ++i) p.distortion_params[i] = m_render_distortion_params[i];
+		p.d_distortion_map = m_distortion_map;
+		p.d_envmap = m_envmap;
+		for (int i = 0; i < 2; ++i) { p.distortion_resolution[i] = m_distortion_resolution[i]; p.envmap_resolution[i] = m_envmap_resolution[i]; }
 		std::vector<nrs_edit*> edits;
 		for (const EditOperator* op : m_edit_operators) edits.push_back(op->get());
 		check(nrs_render_nerf(network.get(), &p, edits.data(), (int)edits.size(), render_buffer.frame_buffer, render_buffer.depth_buffer, nullptr, stream,

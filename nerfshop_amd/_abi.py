@@ -101,6 +101,12 @@ class RenderParams(C.Structure):
         ("slice_plane_z", C.c_float),
         ("depth_scale", C.c_float),
         ("show_accel", C.c_uint32),
+        ("distortion_mode", C.c_uint32),
+        ("distortion_params", C.c_float * 7),
+        ("d_distortion_map", C.c_void_p),
+        ("distortion_resolution", C.c_int32 * 2),
+        ("envmap_resolution", C.c_int32 * 2),
+        ("d_envmap", C.c_void_p),
     ]
 
 

@@ -1223,9 +1223,13 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_render_nerf: parameters not set (nrs_model_set_params)");
 	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_render_nerf: occupancy not set (nrs_model_set_density_bitfield/_grid)");
 	{ const int pc = check_march_params(*p, "nrs_render_nerf"); if (pc != NRS_OK) return pc; }
-	if (p->render_mode == NRS_RENDER_NORMALS || p->render_mode == NRS_RENDER_DISTORTION || p->render_mode == NRS_RENDER_ENCODING_VIS)
-		return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: render modes Normals (network input gradient), EncodingVis (visualize_activation) and Distortion (camera "
-		                                  "distortion map) need tiny-cuda-nn / the distortion trainer and are not on the path");
+	if (p->render_mode == NRS_RENDER_NORMALS || p->render_mode == NRS_RENDER_ENCODING_VIS)
+		return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: render modes Normals (network input gradient) and EncodingVis (visualize_activation) need tiny-cuda-nn and are not on the path");
+	if (p->distortion_mode > 2u) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: distortion_mode must be 0 (None), 1 (Iterative) or 2 (FTheta)");
+	for (int i = 0; i < 7; ++i)
+		if (!std::isfinite(p->distortion_params[i])) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: distortion parameters must be finite");
+	if (p->d_envmap && (p->envmap_resolution[0] < 1 || p->envmap_resolution[1] < 1)) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: envmap without a resolution");
+	if (p->d_distortion_map && (p->distortion_resolution[0] < 1 || p->distortion_resolution[1] < 1)) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: distortion map without a resolution");
 	if (p->render_mode > NRS_RENDER_SLICE) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: unknown render mode");
 	if (!std::isfinite(p->dof) || !std::isfinite(p->slice_plane_z) || !std::isfinite(p->depth_scale)) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: dof / slice_plane_z / depth_scale must be finite");
 	if (p->dof != 0.f && p->slice_plane_z == 0.f) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: dof != 0 needs a focus distance (slice_plane_z = m_slice_plane_z + m_scale != 0)");
@@ -1269,7 +1273,8 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		a.dbg = dbg;
 	}
 	// everything of render_nerf's surface beyond Shade / Cost with a pinhole camera runs the EXTRA instantiation (one lane per ray)
-	a.extra = ((p->render_mode != NRS_RENDER_SHADE && p->render_mode != NRS_RENDER_COST) || p->show_accel || p->dof != 0.f) ? 1u : 0u;
+	a.extra = ((p->render_mode != NRS_RENDER_SHADE && p->render_mode != NRS_RENDER_COST) || p->show_accel || p->dof != 0.f || p->distortion_mode || p->d_distortion_map ||
+	           p->d_envmap) ? 1u : 0u;
 	if (p->render_mode == NRS_RENDER_SLICE) { // tn:3109-3162: no marching at all; one network evaluation per owned pixel
 		a.frame = d_frame; a.depth = d_depth; a.steps = d_steps; a.counters = d_counters_slot;
 		HIP_TRY(hipMemsetAsync(d_counters_slot, 0, sizeof(RenderCounters), s));

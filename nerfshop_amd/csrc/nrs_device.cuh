@@ -231,11 +231,76 @@ __device__ __forceinline__ void square2disk_shirley(float a, float b, float& ox,
 	ox = r * cos_phi; oy = r * sin_phi;
 }
 
+// ---- camera model and background (LENS instantiations only) ------------------------------------------------------------------------------------
+// apply_camera_distortion / iterative_camera_undistortion (common_device.cuh:146-200): OpenCV radial + tangential model, undone by Newton iterations with
+// a central-difference Jacobian and Eigen's 2x2 inverse (adjugate times 1 / det) -- plain fp32 in the reference's order: bit-identical to the oracle.
+__device__ __forceinline__ void apply_camera_distortion(const float* prm, float u, float v, float& du, float& dv) {
+	const float k1 = prm[0], k2 = prm[1], p1 = prm[2], p2 = prm[3];
+	const float u2 = u * u, uv = u * v, v2 = v * v, r2 = u2 + v2;
+	const float radial = k1 * r2 + k2 * r2 * r2;
+	du = u * radial + 2.f * p1 * uv + p2 * (r2 + 2.f * u2);
+	dv = v * radial + 2.f * p2 * uv + p1 * (r2 + 2.f * v2);
+}
+__device__ __forceinline__ void iterative_camera_undistortion(const float* prm, float& u, float& v) {
+	const float kMaxStepNorm = 1e-10f, kRelStepSize = 1e-6f, eps = 1.1920928955078125e-07f;
+	const float x00 = u, x01 = v;
+	float x0 = u, x1 = v;
+	#pragma unroll 1
+	for (uint32_t i = 0; i < 100; ++i) {
+		const float step0 = fmaxf(eps, fabsf(kRelStepSize * x0)), step1 = fmaxf(eps, fabsf(kRelStepSize * x1));
+		float dx0, dx1, b00, b01, f00, f01, b10, b11, f10, f11;
+		apply_camera_distortion(prm, x0, x1, dx0, dx1);
+		apply_camera_distortion(prm, x0 - step0, x1, b00, b01);
+		apply_camera_distortion(prm, x0 + step0, x1, f00, f01);
+		apply_camera_distortion(prm, x0, x1 - step1, b10, b11);
+		apply_camera_distortion(prm, x0, x1 + step1, f10, f11);
+		const float J00 = 1 + (f00 - b00) / (2 * step0), J01 = (f10 - b10) / (2 * step1), J10 = (f01 - b01) / (2 * step0), J11 = 1 + (f11 - b11) / (2 * step1);
+		const float invdet = 1.0f / (J00 * J11 - J10 * J01);
+		const float i00 = J11 * invdet, i10 = -J10 * invdet, i01 = -J01 * invdet, i11 = J00 * invdet;
+		const float r0 = x0 + dx0 - x00, r1 = x1 + dx1 - x01;
+		const float s0 = i00 * r0 + i01 * r1, s1 = i10 * r0 + i11 * r1;
+		x0 -= s0; x1 -= s1;
+		if (s0 * s0 + s1 * s1 < kMaxStepNorm) break;
+	}
+	u = x0; v = x1;
+}
+// read_image<2> (common_device.cuh:80-110): bilinear, texels clamped
+__device__ __forceinline__ void read_image2(const float* __restrict__ data, const int32_t* res, float px, float py, float& o0, float& o1) {
+	const float fx = px * (float)(res[0] - 1), fy = py * (float)(res[1] - 1);
+	const int tx = (int)fx, ty = (int)fy;
+	const float wx = fx - (float)tx, wy = fy - (float)ty;
+	const int x0 = max(min(tx, res[0] - 1), 0), x1 = max(min(tx + 1, res[0] - 1), 0), y0 = max(min(ty, res[1] - 1), 0), y1 = max(min(ty + 1, res[1] - 1), 0);
+	const float2* d = reinterpret_cast<const float2*>(data);
+	const float2 a = d[x0 + y0 * res[0]], b = d[x1 + y0 * res[0]], c = d[x0 + y1 * res[0]], e = d[x1 + y1 * res[0]];
+	const float w00 = (1 - wx) * (1 - wy), w10 = (wx) * (1 - wy), w01 = (1 - wx) * (wy), w11 = (wx) * (wy);
+	o0 = ((w00 * a.x + w10 * b.x) + w01 * c.x) + w11 * e.x;
+	o1 = ((w00 * a.y + w10 * b.y) + w01 * c.y) + w11 * e.y;
+}
+// read_envmap (envmap.cuh:30-63): spherical coordinates of the direction (acosf / atan2f: the device library's, as sincosf in the thin-lens branch --
+// tolerance, not bits, against the host-compiled reference), bilinear lookup wrapping in x and clamped in y
+__device__ __forceinline__ float4 read_envmap(const float* __restrict__ data, const int32_t* res, f3 dir) {
+	const float PI = 3.14159265358979323846f;
+	const f3 d = {dir.z, -dir.x, dir.y};
+	const float theta = acosf(fminf(fmaxf(d.z, -1.0f), 1.0f));
+	const float phi = atan2f(d.y, d.x);
+	const float cyl_x = theta / PI, cyl_y = (phi / (2.0f * PI) + 0.5f);
+	const float fx = cyl_y * (float)(res[0] - 1), fy = cyl_x * (float)(res[1] - 1);
+	const int tx = (int)fx, ty = (int)fy;
+	const float wx = fx - (float)tx, wy = fy - (float)ty;
+	auto wrapx = [&](int x) { return x < 0 ? x + res[0] : (x >= res[0] ? x - res[0] : x); };
+	const int x0 = wrapx(tx), x1 = wrapx(tx + 1), y0 = max(min(ty, res[1] - 1), 0), y1 = max(min(ty + 1, res[1] - 1), 0);
+	const float4* q = reinterpret_cast<const float4*>(data);
+	const float4 a = q[x0 + y0 * res[0]], b = q[x1 + y0 * res[0]], c = q[x0 + y1 * res[0]], e = q[x1 + y1 * res[0]];
+	const float w00 = (1 - wx) * (1 - wy), w10 = (wx) * (1 - wy), w01 = (1 - wx) * (wy), w11 = (wx) * (wy);
+	return make_float4(((w00 * a.x + w10 * b.x) + w01 * c.x) + w11 * e.x, ((w00 * a.y + w10 * b.y) + w01 * c.y) + w11 * e.y,
+	                   ((w00 * a.z + w10 * b.z) + w01 * c.z) + w11 * e.z, ((w00 * a.w + w10 * b.w) + w01 * c.w) + w11 * e.w);
+}
+
 // pixel_to_ray (common_device.cuh:245-295): origin and UN-normalised direction of pixel (x, y) through the camera of its ray time
 // (init_rays_with_payload_kernel_nerf, tn:2551-2567).  offset = ld_random_pixel_offset(snap ? 0 : spp), computed once per thread by the caller.
 // LENS compiles in the thin-lens branch (:285-293; m_dof, focus distance focus_z = plane_z): only the instantiations that serve dof != 0 carry it.
 template <bool LENS = false>
-__device__ __forceinline__ void pixel_ray_raw(const nrs_render_params& p, uint32_t x, uint32_t y, float off_x, float off_y, float focus_z, f3& o, f3& d) {
+__device__ __forceinline__ void pixel_ray_raw(const nrs_render_params& p, uint32_t x, uint32_t y, float off_x, float off_y, float focus_z, f3& o, f3& d, bool use_dof = true) {
 	const float W = (float)p.resolution[0], H = (float)p.resolution[1];
 	const uint32_t idx = x + (uint32_t)p.resolution[0] * y;
 	float u = ((float)x + 0.5f) * (1.f / W);
@@ -249,9 +314,30 @@ __device__ __forceinline__ void pixel_ray_raw(const nrs_render_params& p, uint32
 	float uvx = ((float)x + off_x) / W;
 	float uvy = ((float)y + off_y) / H;
 	f3 dir = {(uvx - p.screen_center[0]) * W / p.focal_length[0], (uvy - p.screen_center[1]) * H / p.focal_length[1], 1.0f};
-	d = mat3_mul(cam, dir); // camera_matrix.block<3, 3>(0, 0) * dir, common_device.cuh:279
+	if (LENS && p.distortion_mode == 2u) { // FTheta, common_device.cuh:231-243, :263-267
+		const float* prm = p.distortion_params;
+		const float xpix = (uvx - p.screen_center[0]) * prm[5], ypix = (uvy - p.screen_center[1]) * prm[6];
+		const float norm = sqrtf(xpix * xpix + ypix * ypix);
+		const float alpha = prm[0] + norm * (prm[1] + norm * (prm[2] + norm * (prm[3] + norm * prm[4])));
+		float sin_alpha, cos_alpha;
+		sincosf(alpha, &sin_alpha, &cos_alpha);
+		if (cos_alpha <= 1.17549435e-38f || norm == 0.f) { // the error direction: a point outside the aabb so that the pixel is not rendered
+			o = mk3(1000.f, 0.f, 0.f); d = mk3(0.f, 0.f, 1.f);
+			return;
+		}
+		sin_alpha *= 1.f / norm;
+		dir = {sin_alpha * xpix, sin_alpha * ypix, cos_alpha};
+	} else if (LENS && p.distortion_mode == 1u) {
+		iterative_camera_undistortion(p.distortion_params, dir.x, dir.y);
+	}
+	if (LENS && p.d_distortion_map) { // :278-280
+		float d0, d1;
+		read_image2(p.d_distortion_map, p.distortion_resolution, uvx, uvy, d0, d1);
+		dir.x += d0; dir.y += d1;
+	}
+	d = mat3_mul(cam, dir); // camera_matrix.block<3, 3>(0, 0) * dir, common_device.cuh:282
 	o = {cam[9], cam[10], cam[11]};
-	if (LENS && p.dof != 0.0f) {
+	if (LENS && use_dof && p.dof != 0.0f) {
 		const f3 lookat = o + d * focus_z;
 		float r0, r1, bx, by;
 		ld_random_val_2d(p.spp_index, x * 19349663u + y * 96925573u, r0, r1);

@@ -339,6 +339,21 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					if (a1.steps) a1.steps[oi] = 0;
 				}
 				alive = r.alive;
+				if (EXTRA) {
+					if (p1.d_envmap) reinterpret_cast<float4*>(a1.frame)[oi] = read_envmap(p1.d_envmap, p1.envmap_resolution, r.d); // tn:2590-2592: replaces the frame value
+					if (alive && p1.render_mode == NRS_RENDER_DISTORTION) { // tn:2602-2613: the distortion map as a picture; nothing is traced
+						float d0 = 0.f, d1 = 0.f;
+						if (p1.d_distortion_map) {
+							read_image2(p1.d_distortion_map, p1.distortion_resolution, ((float)x + 0.5f) / (float)p1.resolution[0], ((float)y + 0.5f) / (float)p1.resolution[1], d0, d1);
+							d0 = d0 * 50.0f + 0.5f; d1 = d1 * 50.0f + 0.5f;
+						} else {
+							d0 = 0.5f; d1 = 0.5f;
+						}
+						reinterpret_cast<float4*>(a1.frame)[oi] = make_float4(d0, d1, 0.5f, 1.0f);
+						a1.depth[oi] = 1.0f;
+						alive = false;
+					}
+				}
 				uint32_t it_fill = 0;
 				if (alive) alive = first_hit(p1, m1, sm.coarse, x + (uint32_t)p1.resolution[0] * y, r, PROF ? &it_fill : nullptr);
 				if (PROF) {
@@ -809,7 +824,7 @@ __global__ __launch_bounds__(256) void slice_kernel(const DeviceModel m, const R
 		f3 wpos = mk3(0, 0, 0), wdir = mk3(0.5f, 0.5f, 0.5f);
 		if (have) {
 			f3 o, d;
-			pixel_ray_raw<false>(p, x, y, off_x, off_y, 1.0f, o, d); // (dof = 0 when plane_z < 0, tn:2543-2545)
+			pixel_ray_raw<true>(p, x, y, off_x, off_y, 1.0f, o, d, false); // lens distortion applies; dof = 0 when plane_z < 0 (tn:2543-2545)
 			const float n = sqrtf(dot3(d, d));
 			const f3 dir = (1.0f / n) * d;
 			const float t = p.slice_plane_z * n; // -plane_z * n, plane_z = -(m_slice_plane_z + m_scale)

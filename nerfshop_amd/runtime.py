@@ -334,6 +334,23 @@ class RenderBuffer:
         self._depth.zero_()
 
 
+def set_camera_extras(p, render_distortion=None, distortion_map=None, envmap=None):
+    """Camera model and background of an nrs_render_params (init_rays_from_camera's arguments, testbed_nerf.cu:3078-3100): lens distortion (mode, 7 params),
+    the distortion map [H, W, 2] and the environment map [H, W, 4] as float32 CUDA tensors (the struct keeps raw device pointers: keep the tensors alive)."""
+    if render_distortion is not None:
+        p.distortion_mode = int(render_distortion[0])
+        p.distortion_params[:] = [float(v) for v in render_distortion[1]]
+    if distortion_map is not None:
+        _require_cuda(distortion_map, torch.float32, "distortion_map")
+        p.d_distortion_map = distortion_map.data_ptr()
+        p.distortion_resolution[:] = (distortion_map.shape[1], distortion_map.shape[0])
+    if envmap is not None:
+        _require_cuda(envmap, torch.float32, "envmap")
+        p.d_envmap = envmap.data_ptr()
+        p.envmap_resolution[:] = (envmap.shape[1], envmap.shape[0])
+    return p
+
+
 class Testbed:
     """The slice of ngp::Testbed the render path reads: network, occupancy, edit operators and the render knobs."""
 
@@ -351,6 +368,9 @@ class Testbed:
         self.dof = 0.0                    # m_dof
         self.slice_plane_z, self.scale = 0.0, 1.0   # m_slice_plane_z, m_scale
         self.dataset_scale = 1.0          # m_nerf.training.dataset.scale
+        self.render_distortion = (0, (0.0,) * 7)   # m_nerf.render_distortion (mode, params) when render_with_camera_distortion
+        self.distortion_map = None        # m_distortion.map: float32 CUDA tensor [H, W, 2] or None
+        self.envmap = None                # m_envmap.envmap: float32 CUDA tensor [H, W, 4] or None
         mn, mx = list(desc.aabb_min), list(desc.aabb_max)
         self.render_aabb = (mn, mx)       # m_render_aabb
         self.last_stats = None
@@ -380,6 +400,7 @@ class Testbed:
         p.dof = self.dof
         p.slice_plane_z = self.slice_plane_z + self.scale  # testbed_nerf.cu:3067
         p.depth_scale = 1.0 / self.dataset_scale           # :3113
+        set_camera_extras(p, self.render_distortion, self.distortion_map, self.envmap)
         return p
 
     def render_nerf(self, network, render_buffer, max_res, focal_length, camera_matrix0, camera_matrix1, rolling_shutter, screen_center,

@@ -368,16 +368,101 @@ inline void square2disk_shirley(float a, float b, float& ox, float& oy) {
 // render_nerf's plane_z (tn:3067-3070): m_slice_plane_z + m_scale, negated in render mode Slice
 inline float frame_plane_z(const nrs_render_params& p) { return p.render_mode == NRS_RENDER_SLICE ? -p.slice_plane_z : p.slice_plane_z; }
 
-// pixel_to_ray, common_device.cuh:245-295 (no lens distortion, no distortion map): origin and UN-normalised direction
+// apply_camera_distortion (OpenCV radial k1 k2 + tangential p1 p2), common_device.cuh:146-159
+inline void apply_camera_distortion(const float* prm, float u, float v, float* du, float* dv) {
+	const float k1 = prm[0], k2 = prm[1], p1 = prm[2], p2 = prm[3];
+	const float u2 = u * u, uv = u * v, v2 = v * v, r2 = u2 + v2;
+	const float radial = k1 * r2 + k2 * r2 * r2;
+	*du = u * radial + 2.f * p1 * uv + p2 * (r2 + 2.f * u2);
+	*dv = v * radial + 2.f * p2 * uv + p1 * (r2 + 2.f * v2);
+}
+// iterative_camera_undistortion, common_device.cuh:161-200: Newton with a central-difference Jacobian, Eigen's 2x2 inverse (adjugate times 1 / det)
+inline void iterative_camera_undistortion(const float* prm, float* u, float* v) {
+	const float kMaxStepNorm = 1e-10f, kRelStepSize = 1e-6f, eps = std::numeric_limits<float>::epsilon();
+	const float x00 = *u, x01 = *v;
+	float x0 = *u, x1 = *v;
+	for (uint32_t i = 0; i < 100; ++i) {
+		const float step0 = std::max(eps, std::abs(kRelStepSize * x0)), step1 = std::max(eps, std::abs(kRelStepSize * x1));
+		float dx0, dx1, b00, b01, f00, f01, b10, b11, f10, f11;
+		apply_camera_distortion(prm, x0, x1, &dx0, &dx1);
+		apply_camera_distortion(prm, x0 - step0, x1, &b00, &b01);
+		apply_camera_distortion(prm, x0 + step0, x1, &f00, &f01);
+		apply_camera_distortion(prm, x0, x1 - step1, &b10, &b11);
+		apply_camera_distortion(prm, x0, x1 + step1, &f10, &f11);
+		const float J00 = 1 + (f00 - b00) / (2 * step0), J01 = (f10 - b10) / (2 * step1), J10 = (f01 - b01) / (2 * step0), J11 = 1 + (f11 - b11) / (2 * step1);
+		const float invdet = 1.0f / (J00 * J11 - J10 * J01);              // Eigen: compute_inverse<..., 2>
+		const float i00 = J11 * invdet, i10 = -J10 * invdet, i01 = -J01 * invdet, i11 = J00 * invdet;
+		const float r0 = x0 + dx0 - x00, r1 = x1 + dx1 - x01;              // (x + dx - x0)
+		const float s0 = i00 * r0 + i01 * r1, s1 = i10 * r0 + i11 * r1;    // J^-1 * r: 2-term rows
+		x0 -= s0; x1 -= s1;
+		if (s0 * s0 + s1 * s1 < kMaxStepNorm) break;
+	}
+	*u = x0; *v = x1;
+}
+// read_image<2> (common_device.cuh:80-110): bilinear lookup, texels clamped
+inline void read_image2(const float* data, const int32_t res[2], float px, float py, float out[2]) {
+	const float fx = px * (float)(res[0] - 1), fy = py * (float)(res[1] - 1);
+	const int tx = (int)fx, ty = (int)fy;
+	const float wx = fx - (float)tx, wy = fy - (float)ty;
+	auto rd = [&](int x, int y, int c) {
+		x = std::max(std::min(x, res[0] - 1), 0); y = std::max(std::min(y, res[1] - 1), 0);
+		return data[((size_t)x + (size_t)y * res[0]) * 2 + c];
+	};
+	for (int c = 0; c < 2; ++c)
+		out[c] = (((1 - wx) * (1 - wy) * rd(tx, ty, c) + (wx) * (1 - wy) * rd(tx + 1, ty, c)) + (1 - wx) * (wy)*rd(tx, ty + 1, c)) + (wx) * (wy)*rd(tx + 1, ty + 1, c);
+}
+// read_envmap (envmap.cuh:30-63): the direction in spherical coordinates (dir_to_spherical_unorm, random_val.cuh:64-69: acosf / atan2f of the host libm),
+// bilinear lookup wrapping in x and clamped in y
+inline void read_envmap(const float* data, const int32_t res[2], V3 dir, float out[4]) {
+	const float PI = 3.14159265358979323846f;
+	const V3 d = {dir.z, -dir.x, dir.y};
+	const float cos_theta = fminf(fmaxf(d.z, -1.0f), 1.0f);
+	const float theta = acosf(cos_theta);
+	const float phi = atan2f(d.y, d.x);
+	const float cyl_x = theta / PI, cyl_y = (phi / (2.0f * PI) + 0.5f);
+	const float fx = cyl_y * (float)(res[0] - 1), fy = cyl_x * (float)(res[1] - 1);
+	const int tx = (int)fx, ty = (int)fy;
+	const float wx = fx - (float)tx, wy = fy - (float)ty;
+	auto rd = [&](int x, int y, int c) {
+		if (x < 0) x += res[0]; else if (x >= res[0]) x -= res[0];
+		y = std::max(std::min(y, res[1] - 1), 0);
+		return data[((size_t)x + (size_t)y * res[0]) * 4 + c];
+	};
+	for (int c = 0; c < 4; ++c)
+		out[c] = (((1 - wx) * (1 - wy) * rd(tx, ty, c) + (wx) * (1 - wy) * rd(tx + 1, ty, c)) + (1 - wx) * (wy)*rd(tx, ty + 1, c)) + (wx) * (wy)*rd(tx + 1, ty + 1, c);
+}
+
+// pixel_to_ray, common_device.cuh:245-295: origin and UN-normalised direction
 inline void pixel_to_ray(const nrs_render_params& p, const float* cam, uint32_t x, uint32_t y, float focus_z, float dof, V3& o, V3& d) {
 	const uint32_t W = (uint32_t)p.resolution[0], H = (uint32_t)p.resolution[1];
 	float offset[2];
 	ld_random_pixel_offset(p.snap_to_pixel_centers ? 0 : p.spp_index, offset);
 	float uvx = ((float)x + offset[0]) / (float)W;
 	float uvy = ((float)y + offset[1]) / (float)H;
-	V3 dir = {(uvx - p.screen_center[0]) * (float)W / p.focal_length[0],
-	          (uvy - p.screen_center[1]) * (float)H / p.focal_length[1], 1.0f};
-	d = mat3_mul(cam, dir); // camera_matrix.block<3, 3>(0, 0) * dir, common_device.cuh:279
+	V3 dir;
+	if (p.distortion_mode == 2) { // FTheta, :231-243, :263-267
+		const float* prm = p.distortion_params;
+		const float xpix = (uvx - p.screen_center[0]) * prm[5], ypix = (uvy - p.screen_center[1]) * prm[6];
+		const float norm = sqrtf(xpix * xpix + ypix * ypix);
+		const float alpha = prm[0] + norm * (prm[1] + norm * (prm[2] + norm * (prm[3] + norm * prm[4])));
+		float sin_alpha, cos_alpha;
+		sincosf(alpha, &sin_alpha, &cos_alpha);
+		if (cos_alpha <= std::numeric_limits<float>::min() || norm == 0.f) { // error direction: a point outside the aabb so the pixel is not rendered
+			o = v3(1000.f, 0.f, 0.f); d = v3(0.f, 0.f, 1.f);
+			return;
+		}
+		sin_alpha *= 1.f / norm;
+		dir = {sin_alpha * xpix, sin_alpha * ypix, cos_alpha};
+	} else {
+		dir = {(uvx - p.screen_center[0]) * (float)W / p.focal_length[0], (uvy - p.screen_center[1]) * (float)H / p.focal_length[1], 1.0f};
+		if (p.distortion_mode == 1) iterative_camera_undistortion(p.distortion_params, &dir.x, &dir.y);
+	}
+	if (p.d_distortion_map) { // :278-280
+		float dd[2];
+		read_image2(p.d_distortion_map, p.distortion_resolution, uvx, uvy, dd);
+		dir.x += dd[0]; dir.y += dd[1];
+	}
+	d = mat3_mul(cam, dir); // camera_matrix.block<3, 3>(0, 0) * dir, common_device.cuh:282
 	o = cam_col(cam, 3);
 	if (dof == 0.0f) return;
 	// thin lens, common_device.cuh:286-292
@@ -393,7 +478,7 @@ inline void pixel_to_ray(const nrs_render_params& p, const float* cam, uint32_t 
 	d = {diff.x / focus_z, diff.y / focus_z, diff.z / focus_z};
 }
 
-inline void init_ray(const nrs_render_params& p, uint32_t x, uint32_t y, Payload& payload, float& depth_out) {
+inline void init_ray(const nrs_render_params& p, uint32_t x, uint32_t y, Payload& payload, float& depth_out, float* frame_px = nullptr) {
 	const uint32_t W = (uint32_t)p.resolution[0], H = (uint32_t)p.resolution[1];
 	const uint32_t idx = x + W * y;
 	const Box aabb{v3(p.render_aabb_min[0], p.render_aabb_min[1], p.render_aabb_min[2]),
@@ -426,6 +511,7 @@ inline void init_ray(const nrs_render_params& p, uint32_t x, uint32_t y, Payload
 	depth_out = 1e10f;         // tn:2586
 	float n = sqrtf(dot(d, d)); // .normalized(), tn:2588
 	d = {d.x / n, d.y / n, d.z / n};
+	if (p.d_envmap && frame_px) read_envmap(p.d_envmap, p.envmap_resolution, d, frame_px); // tn:2590-2592: replaces the frame value
 	float tmin, tmax;
 	ray_intersect(aabb, o, d, tmin, tmax);
 	float t = fmaxf(tmin, NEAR_DISTANCE) + 1e-6f; // tn:2594
@@ -435,6 +521,22 @@ inline void init_ray(const nrs_render_params& p, uint32_t x, uint32_t y, Payload
 	payload.dir = d;
 	payload.t = t;
 	if (!box_contains(aabb, o + d * t)) { // tn:2596-2600
+		payload.alive = false;
+		return;
+	}
+	if (p.render_mode == NRS_RENDER_DISTORTION) { // tn:2602-2613: the distortion map as a picture, no tracing
+		if (frame_px) {
+			if (p.d_distortion_map) {
+				float dd[2];
+				read_image2(p.d_distortion_map, p.distortion_resolution, ((float)x + 0.5f) / (float)W, ((float)y + 0.5f) / (float)H, dd);
+				frame_px[0] = dd[0] * 50.0f + 0.5f; frame_px[1] = dd[1] * 50.0f + 0.5f;
+			} else {
+				frame_px[0] = 0.5f; frame_px[1] = 0.5f;
+			}
+			frame_px[2] = 0.5f; frame_px[3] = 1.0f;
+		}
+		depth_out = 1.0f;
+		payload.origin = o + d * 10000.0f;
 		payload.alive = false;
 		return;
 	}
@@ -1010,7 +1112,7 @@ void render(const Model& m, const nrs_render_params& p, const Edit* const* edits
 		memset(&r, 0, sizeof(r));
 		if (!owned(x, y)) { r.payload.alive = false; r.payload.idx = (uint32_t)i; continue; }
 		float d0;
-		init_ray(p, x, y, r.payload, d0);
+		init_ray(p, x, y, r.payload, d0, frame + 4 * (size_t)i);
 		depth_buf[i] = d0;
 		advance_pos(p, grid, r.payload, (uint32_t)i);
 		if (steps_buf) steps_buf[i] = 0;

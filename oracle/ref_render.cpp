@@ -231,6 +231,10 @@ void ref_render_frame(const nrs_model_desc* desc, const nrs_render_params* p, co
 	const int show_accel = p->show_accel ? (int)p->min_mip : -1; // m_nerf.show_accel; min_mip = (show_accel >= 0) ? show_accel : 0, :2751, :2849
 	const bool apply_operators = p->apply_operators && n_edits > 0;
 
+	CameraDistortion camera_distortion{};                       // m_nerf.render_distortion (render_with_camera_distortion), :3078-3100
+	camera_distortion.mode = (ECameraDistortionMode)p->distortion_mode;
+	for (int k = 0; k < 7; ++k) camera_distortion.params[k] = p->distortion_params[k];
+
 	std::vector<RefEdit> edits;
 	bool any_poisson = false;
 	for (int i = 0; i < n_edits; ++i) { edits.push_back(make_edit(desc, meshes[i])); any_poisson |= meshes[i]->apply_poisson != 0; }
@@ -256,8 +260,8 @@ void ref_render_frame(const nrs_model_desc* desc, const nrs_render_params* p, co
 				threadIdx.x = threadIdx.y = threadIdx.z = 0;
 				blockIdx.x = (uint32_t)x; blockIdx.y = (uint32_t)y; blockIdx.z = 0;
 				init_rays_with_payload_kernel_nerf(p->spp_index, rays[0].payload.data(), resolution, focal_length, camera_matrix0, camera_matrix1, rolling_shutter, screen_center,
-				                                   (bool)p->snap_to_pixel_centers, render_aabb, plane_z, dof, CameraDistortion{}, (const float*)nullptr, Vector2i(0, 0), (Array4f*)frame,
-				                                   depth_buffer, (const float*)nullptr, Vector2i(0, 0), render_mode);
+				                                   (bool)p->snap_to_pixel_centers, render_aabb, plane_z, dof, camera_distortion, p->d_envmap, Vector2i(p->envmap_resolution[0], p->envmap_resolution[1]),
+				                                   (Array4f*)frame, depth_buffer, p->d_distortion_map, Vector2i(p->distortion_resolution[0], p->distortion_resolution[1]), render_mode);
 			}
 		const uint32_t n_rays_initialized = N; // :2739
 		for (uint32_t i = 0; i < N; ++i) { rays[0].rgba[i] = Array4f::Zero(); rays[0].depth[i] = 0.f; rays[0].normal[i] = Array3f::Zero(); } // :2741-2743
@@ -788,7 +792,11 @@ void ref_pixel_to_ray(uint32_t n, const int32_t* pixel2, const nrs_render_params
 	const Vector2f focal_length(p->focal_length[0], p->focal_length[1]), screen_center(p->screen_center[0], p->screen_center[1]);
 	const Matrix<float, 3, 4> cam = m34(p->camera_matrix1);
 	for (uint32_t i = 0; i < n; ++i) {
-		Ray r = pixel_to_ray(p->spp_index, Vector2i(pixel2[2 * i], pixel2[2 * i + 1]), resolution, focal_length, cam, screen_center, (bool)p->snap_to_pixel_centers, p->slice_plane_z, p->dof);
+		CameraDistortion cd{};
+		cd.mode = (ECameraDistortionMode)p->distortion_mode;
+		for (int k = 0; k < 7; ++k) cd.params[k] = p->distortion_params[k];
+		Ray r = pixel_to_ray(p->spp_index, Vector2i(pixel2[2 * i], pixel2[2 * i + 1]), resolution, focal_length, cam, screen_center, (bool)p->snap_to_pixel_centers, p->slice_plane_z, p->dof, cd,
+		                     p->d_distortion_map, Vector2i(p->distortion_resolution[0], p->distortion_resolution[1]));
 		for (int c = 0; c < 3; ++c) { origin3[3 * (size_t)i + c] = r.o[c]; dir3[3 * (size_t)i + c] = r.d[c]; }
 	}
 }

@@ -104,6 +104,18 @@ def pixel_to_ray_case(scene, which):
         px = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
         o, d = ref.pixel_to_ray(px, p, which)
         outs += [o, d]
+    # lens distortion (:262-280): OpenCV iterative undistortion, f-theta, the distortion map
+    for az, mode, prm, dmap in ((45.0, 1, (0.2, -0.08, 0.006, -0.004, 0, 0, 0), None), (45.0, 1, (-0.25, 0.1, 0.0, 0.0, 0, 0, 0), (20, 10, 3, 0.01)),
+                                (130.0, 2, (0.0, 0.8, 0.03, -0.02, 0.004, 1.0, 0.5625), None), (130.0, 2, (0.0, 2.9, 0.0, 0.0, 0.0, 1.0, 0.5625), None)):  # the last: rays beyond 90 degrees -> error direction
+        p = scene.params_for(160, 90, az)
+        p.snap_to_pixel_centers, p.spp_index = 0, 4
+        p.distortion_mode = mode
+        p.distortion_params[:] = prm
+        camera_extras(p, {"_distmap": dmap} if dmap else {})
+        ys, xs = np.mgrid[0:90, 0:160]
+        px = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
+        o, d = ref.pixel_to_ray(px, p, which)
+        outs += [o, d]
     return outs
 
 
@@ -138,7 +150,38 @@ FRAME_CASES = [
     ("lego_slice", "lego", (64, 36, 30.0), {"render_mode": 9, "slice_plane_z": 1.3}, None),
     ("lego_slice_linear_bg", "lego", (64, 36, 140.0), {"render_mode": 9, "slice_plane_z": 1.2, "linear_colors": 1, "_background": 0.25}, "cage"),
     ("aabb16_slice", "aabb16", (64, 36, 30.0), {"render_mode": 9, "slice_plane_z": 2.0}, None),
+    # camera model and background: OpenCV / f-theta lens distortion, the distortion map, the environment map, render mode Distortion
+    # (init_rays_with_payload_kernel_nerf tn:2523-2613, pixel_to_ray common_device.cuh:262-280, envmap.cuh:30-63)
+    ("lego_envmap", "lego", (64, 36, 60.0), {"_envmap": (32, 16, 5)}, "cage"),
+    ("lego_opencv_distortion", "lego", (64, 36, 100.0), {"distortion_mode": 1, "distortion_params": (0.12, -0.05, 0.004, -0.003, 0, 0, 0), "snap_to_pixel_centers": 0, "spp_index": 2}, "cage"),
+    ("lego_ftheta", "lego", (64, 36, 30.0), {"distortion_mode": 2, "distortion_params": (0.0, 0.7, 0.02, -0.01, 0.002, 1.0, 0.5625)}, None),
+    ("aabb16_distortion_map_envmap", "aabb16", (64, 36, 120.0), {"_distmap": (24, 12, 9, 0.02), "_envmap": (40, 20, 6)}, "cage"),
+    ("lego_mode_distortion_map", "lego", (64, 36, 60.0), {"render_mode": 7, "_distmap": (24, 12, 9, 0.004)}, "cage"),
+    ("lego_mode_distortion_nomap", "lego", (64, 36, 60.0), {"render_mode": 7, "_background": 0.25}, None),
+    ("lego_slice_distorted_lens", "lego", (64, 36, 30.0), {"render_mode": 9, "slice_plane_z": 1.3, "distortion_mode": 1, "distortion_params": (0.15, -0.05, 0.003, 0.002, 0, 0, 0), "dof": 0.05,
+                                                          "_distmap": (24, 12, 9, 0.01)}, None),
 ]
+
+
+def camera_extras(p, over):
+    """fill the pointer fields of an nrs_render_params from the '_envmap' / '_distmap' keys of a case (host arrays, kept alive on the struct)"""
+    import ctypes as C
+    keep = []
+    if "_envmap" in over:
+        w, h, seed = over["_envmap"]
+        env = _rng(f"envmap{seed}").uniform(0, 1, (h, w, 4)).astype(np.float32)
+        env[..., 3] = _rng(f"envalpha{seed}").uniform(0.2, 1.0, (h, w)).astype(np.float32)
+        p.d_envmap = env.ctypes.data_as(C.c_void_p)
+        p.envmap_resolution[:] = (w, h)
+        keep.append(env)
+    if "_distmap" in over:
+        w, h, seed, amp = over["_distmap"]
+        dm = _rng(f"distmap{seed}").uniform(-amp, amp, (h, w, 2)).astype(np.float32)
+        p.d_distortion_map = dm.ctypes.data_as(C.c_void_p)
+        p.distortion_resolution[:] = (w, h)
+        keep.append(dm)
+    p._keep = keep
+    return keep
 
 
 class Scenes:
@@ -166,8 +209,13 @@ def _case_setup(scenes, case):
     for k, v in over.items():
         if k == "_background":
             background = v
+        elif k.startswith("_"):
+            continue
+        elif k == "distortion_params":
+            p.distortion_params[:] = v
         else:
             setattr(p, k, v)
+    camera_extras(p, over)
     edit = None
     if kind == "cage":
         edit = sc.edit

@@ -247,3 +247,98 @@ def test_modes_with_affine_stack_and_on_tiles(rig):
         rig.testbed.edit_operators = saved
         rig.use_edit(False)
         dev.close()
+
+
+# ---- camera model and background: lens distortion, distortion map, environment map, render mode Distortion (init_rays :2523-2613) ----------------------
+def _camera_pair(rig, w, h, az, fields, envmap=None, distmap=None):
+    """the same nrs_render_params twice: DEVICE pointers for libnrs, HOST pointers for the oracle"""
+    from nerfshop_amd import runtime
+    from ref_pin_cases import camera_extras
+    torch = rig.torch
+    over = {}
+    if envmap:
+        over["_envmap"] = envmap
+    if distmap:
+        over["_distmap"] = distmap
+    p_cpu, p_gpu = _params(rig, w, h, az), _params(rig, w, h, az)
+    for p in (p_cpu, p_gpu):
+        for k, v in fields.items():
+            if k == "distortion_params":
+                p.distortion_params[:] = v
+            else:
+                setattr(p, k, v)
+    host = camera_extras(p_cpu, over)
+    keep, i = [host], 0
+    env_t = dm_t = None
+    if envmap:
+        env_t = torch.from_numpy(host[i]).cuda(); i += 1
+    if distmap:
+        dm_t = torch.from_numpy(host[i]).cuda()
+    runtime.set_camera_extras(p_gpu, None, dm_t, env_t)
+    keep += [env_t, dm_t]
+    return p_gpu, p_cpu, keep
+
+
+@pytest.mark.parametrize("name,fields,envmap,distmap,exact_rays", [
+    ("envmap", {}, (32, 16, 5), None, True),
+    ("opencv", {"distortion_mode": 1, "distortion_params": (0.12, -0.05, 0.004, -0.003, 0, 0, 0), "snap_to_pixel_centers": 0, "spp_index": 2}, None, None, True),
+    ("ftheta", {"distortion_mode": 2, "distortion_params": (0.0, 0.7, 0.02, -0.01, 0.002, 1.0, 0.5625)}, None, None, False),
+    ("ftheta_wide", {"distortion_mode": 2, "distortion_params": (0.0, 2.9, 0.0, 0.0, 0.0, 1.0, 0.5625)}, (32, 16, 5), None, False),
+    ("distmap_envmap", {}, (40, 20, 6), (24, 12, 9, 0.02), True),
+    ("everything_in_depth_mode", {"render_mode": DEPTH, "depth_scale": 1.0, "distortion_mode": 1, "distortion_params": (-0.2, 0.08, 0.0, 0.0, 0, 0, 0), "dof": 0.02, "slice_plane_z": 1.2,
+                                  "snap_to_pixel_centers": 0, "spp_index": 7}, (32, 16, 5), (24, 12, 9, 0.01), False),
+])
+def test_camera_model_and_background(rig, name, fields, envmap, distmap, exact_rays):
+    rig.use_edit(True)
+    try:
+        p_gpu, p_cpu, keep = _camera_pair(rig, 256, 144, 60.0, fields, envmap, distmap)
+        got = rig.render(p_gpu)
+        ref = rig.scene.oracle_model.render(p_cpu, [rig.scene.oracle_edit])
+        assert ref[3].n_hit > 500
+        frame, depth, steps, _ = got
+        ds = np.abs(steps.astype(np.int64) - ref[2].astype(np.int64))
+        d = np.abs(frame - ref[0]).max(-1)
+        if exact_rays:   # plain fp32 arithmetic in the reference's order: the rays are the oracle's bits, the usual frame bar applies (acosf / atan2f of the envmap lookup: 1e-6 in the angle)
+            assert ds.max() <= 1 and (ds == 0).mean() >= 0.998
+            assert d.max() < 6e-3 and np.abs(frame - ref[0]).mean() < 2e-4, (d.max(), np.abs(frame - ref[0]).mean())
+        else:            # sincosf (f-theta, thin lens): the depth-of-field bar
+            assert (ds == 0).mean() >= 0.99 and (d > 6e-3 * max(1.0, float(ref[0][..., :3].max()))).mean() <= 0.01, ((ds == 0).mean(), (d > 6e-3).mean())
+        plain = rig.render(_params(rig, 256, 144, 60.0))
+        assert np.abs(plain[0] - frame).max() > 0.02   # not a no-op
+        if envmap:
+            assert (frame[..., 3] > 0).all()             # every pixel got its background
+    finally:
+        rig.use_edit(False)
+
+
+@pytest.mark.parametrize("distmap", [None, (24, 12, 9, 0.004)])
+def test_render_mode_distortion(rig, distmap):
+    rig.use_edit(False)
+    p_gpu, p_cpu, keep = _camera_pair(rig, 250, 130, 40.0, {"render_mode": DISTORTION}, None, distmap)
+    torch = rig.torch
+    frame = torch.full((130, 250, 4), 0.25, dtype=torch.float32, device="cuda:0")
+    depth = torch.zeros((130, 250), dtype=torch.float32, device="cuda:0")
+    stats = rig.testbed.render_with_params(rig.net, p_gpu, frame, depth, None, None, want_stats=True)
+    torch.cuda.synchronize()
+    lib = rig.scene.orc.load()
+    ref_frame = np.full((130, 250, 4), 0.25, np.float32)
+    ref_depth = np.zeros((130, 250), np.float32)
+    ref_steps = np.zeros((130, 250), np.uint32)
+    st = rig.scene.orc.OrcRenderStats()
+    lib.orc_render(rig.scene.oracle_model.h, C.byref(p_cpu), (C.c_void_p * 1)(), 0, ref_frame.ctypes.data, ref_depth.ctypes.data, ref_steps.ctypes.data, C.byref(st), 0, 0)
+    got = frame.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref_frame.view(np.uint32))     # plain arithmetic: the same bits
+    assert np.array_equal(depth.cpu().numpy(), ref_depth) and stats.n_samples == 0 and stats.n_rays_hit == 0
+    assert (got[..., 3] == 1.0).sum() > 1000 and ((ref_depth == 1.0) | (ref_depth == 1e10)).all()
+
+
+def test_slice_through_a_distorted_lens(rig):
+    """Slice takes its rays through pixel_to_ray like every mode: lens distortion applies (the aperture does not, tn:2543-2545)"""
+    rig.use_edit(False)
+    fields = {"render_mode": SLICE, "slice_plane_z": 1.3, "distortion_mode": 1, "distortion_params": (0.15, -0.05, 0.003, 0.002, 0, 0, 0), "dof": 0.05}
+    p_gpu, p_cpu, keep = _camera_pair(rig, 200, 120, 40.0, fields, None, (24, 12, 9, 0.01))
+    got = rig.render(p_gpu)
+    ref = rig.scene.oracle_model.render(p_cpu, [])
+    assert np.abs(got[0] - ref[0]).max() < 6e-3 and np.abs(got[0] - ref[0]).mean() < 2e-4
+    straight = rig.render(_params(rig, 200, 120, 40.0, render_mode=SLICE, slice_plane_z=1.3))
+    assert np.abs(straight[0] - got[0]).max() > 0.01

@@ -158,7 +158,7 @@ def test_frame_golden(scenes, golden, case):
     assert np.array_equal(s, g("steps").astype(np.uint32))
     assert np.array_equal(f.view(np.uint32), g("frame").view(np.uint32)), int((f.view(np.uint32) != g("frame").view(np.uint32)).sum())
     assert np.array_equal(d.view(np.uint32), g("depth").view(np.uint32))
-    assert st[0] > 500 and (f[..., 3] > 0).sum() > 500  # not an empty picture
+    assert (st[0] > 500 or case[3].get("render_mode") == 7) and (f[..., 3] > 0).sum() > 500  # not an empty picture (render mode Distortion traces nothing: n_hit = 0)
 
 
 @live
