@@ -5,7 +5,9 @@ oracle, which tests/test_ref_pin.py pins bit for bit to the reference's own comp
   * shade_kernel_nerf's mode handling (:2466-2482),
   * pixel_to_ray's thin-lens branch (m_dof, common_device.cuh:285-293),
   * render mode Slice (:3067-3070, 3109-3162).
-Normals / Distortion (tiny-cuda-nn's input gradient, the distortion map) are refused.
+  * the camera model and the background: OpenCV (iterative) and f-theta lens distortion, the distortion map, the environment map, render mode
+    Distortion (init_rays_with_payload_kernel_nerf :2523-2613, common_device.cuh:146-243, 262-280, envmap.cuh:30-63).
+Normals / EncodingVis (tiny-cuda-nn's input gradient / visualize_activation) are refused.
 
 Tolerances.  The modes replace the network's colour by a function of the (bit-exact) sample position, so the frame bar is the Shade bar
 (6e-3 max, 2e-4 mean) scaled by the magnitude of the colours a mode produces (depths and distances in scene units).  Depth of field is the one
@@ -183,8 +185,8 @@ def test_slice_on_tiles(rig):
 
 
 def test_modes_through_every_boundary_flavour(rig):
-    """a mode with forced lane-team settings (the EXTRA instantiation is one lane per ray whatever the context asks for); Normals / Distortion /
-    unknown modes and a lens without a focus distance are refused"""
+    """a mode with forced lane-team settings (the EXTRA instantiation is one lane per ray whatever the context asks for); Normals / EncodingVis /
+    unknown modes, an unknown lens model and a lens without a focus distance are refused"""
     from nerfshop_amd._abi import NrsError
     rig.use_edit(True)
     try:
@@ -194,13 +196,15 @@ def test_modes_through_every_boundary_flavour(rig):
             rig.ctx.set_lane_teams(team)
             _compare(rig.render(p), ref)
         rig.ctx.set_lane_teams(0)
-        for bad in (NORMALS, DISTORTION, 10, 11):
+        for bad in (NORMALS, 10, 11, 12):   # Normals, NumRenderModes, EncodingVis, out of range
             with pytest.raises(NrsError):
                 rig.render(_params(rig, 64, 36, 60.0, render_mode=bad))
         with pytest.raises(NrsError):
             rig.render(_params(rig, 64, 36, 60.0, dof=0.1, slice_plane_z=0.0))
         with pytest.raises(NrsError):
             rig.render(_params(rig, 64, 36, 60.0, depth_scale=float("nan")))
+        with pytest.raises(NrsError):
+            rig.render(_params(rig, 64, 36, 60.0, distortion_mode=3))
     finally:
         rig.ctx.set_lane_teams(0)
         rig.use_edit(False)
