@@ -178,7 +178,10 @@ typedef struct nrs_render_params {
 	uint32_t min_mip;             /* show_accel >= 0 ? show_accel : 0 (marching only) */
 	uint32_t max_march_steps;     /* 0 = reference bound (MARCH_ITER, testbed_nerf.cu:56) */
 	/* Multi-GPU image-tile sharding (no reference counterpart).  The image is cut into
-	 * tile_size x tile_size pixel tiles in row-major tile order; this call renders tiles
+	 * tile_size x tile_size pixel tiles; tile (Tx, Ty) has the index t = Ty * pitch + Tx with the ODD row pitch
+	 * pitch = ceil(W / tile_size) | 1 (nrs_render_tile_pitch) -- with an even pitch and a power-of-two number of ranks, t mod ranks would put
+	 * every rank on two columns of tiles; an odd pitch turns the deal into diagonals (max / mean samples per rank at 8 ranks, 32-pixel tiles:
+	 * 1.032 -> 1.016).  Indices whose Tx lies beyond the image are virtual (no pixels).  This call renders tiles
 	 * t = tile_first, tile_first + tile_stride, ...  tile_size == 0 means "whole image" and frame/depth
 	 * are indexed x + W*y.  With tiling, pixel (tx,ty) of the k-th owned tile is written at
 	 * ((k * tile_size + ty) * tile_size + tx): a compact buffer ready for one RCCL gather. */
@@ -414,8 +417,10 @@ int  nrs_edit_download(nrs_edit* edit, float* h_vertices, uint32_t* h_lut_offset
  * synchronises the stream before returning (the reference's trace() syncs to read n_hit). */
 int nrs_render_nerf(nrs_model* model, const nrs_render_params* params, nrs_edit* const* edits, int n_edits,
                     float* d_frame, float* d_depth, uint32_t* d_steps, void* stream, nrs_render_stats* h_stats);
-/* number of tiles this rank owns / pixels of the compact buffer for given params (host-only) */
+/* number of tiles this rank owns / pixels of the compact buffer for given params (host-only; virtual tiles of the odd pitch included) */
 uint32_t nrs_render_owned_tiles(const nrs_render_params* params);
+/* the row pitch of the tile index: ceil(W / tile_size) | 1 (0 when tile_size == 0) */
+uint32_t nrs_render_tile_pitch(const nrs_render_params* params);
 /* scatter compact tile buffers of all ranks (rank-major, as a gather delivers them) back into a full W x H image.
  * Rank r's tiles start at d_tiles + r * rank_stride_floats (0 = densely packed: tiles_per_rank_padded * tile^2 * channels);
  * a stride lets frame and depth share one gathered buffer [rank][frame block | depth block] -> one collective per frame. */

@@ -1202,13 +1202,17 @@ static int tile_geometry(const nrs_render_params& p, uint32_t team, uint32_t& ti
 		return NRS_OK;
 	}
 	if (p.tile_size % 8) return fail(NRS_ERR_INVALID_ARG, "tile_size must be a multiple of 8");
-	tiles_x = (W + p.tile_size - 1) / p.tile_size;
+	tiles_x = tile_pitch(W, p.tile_size); // (odd row pitch: indices beyond the image's last tile column are virtual)
 	const uint32_t tiles_y = (H + p.tile_size - 1) / p.tile_size, total = tiles_x * tiles_y;
 	const uint32_t stride = p.tile_stride ? p.tile_stride : 1;
 	owned = p.tile_first < total ? (total - p.tile_first + stride - 1) / stride : 0;
 	ppt_x = p.tile_size / pw;
 	n_packets = owned * ppt_x * (p.tile_size / ph);
 	return NRS_OK;
+}
+uint32_t nrs_render_tile_pitch(const nrs_render_params* p) {
+	if (!p || p->resolution[0] <= 0 || p->tile_size == 0) return 0;
+	return tile_pitch((uint32_t)p->resolution[0], p->tile_size);
 }
 uint32_t nrs_render_owned_tiles(const nrs_render_params* p) {
 	if (!p || p->resolution[0] <= 0 || p->resolution[1] <= 0) return 0;

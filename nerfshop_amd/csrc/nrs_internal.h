@@ -42,6 +42,9 @@ constexpr uint32_t kWfragBytes = kNumFrags * kFragBytes; // 24 KiB
 
 struct Box3 { float mn[3]; float mx[3]; };
 
+// row pitch of the multi-GPU tile index (nrs.h, nrs_render_params::tile_size): odd, so that t mod (a power-of-two number of ranks) walks diagonals
+inline uint32_t tile_pitch(uint32_t width, uint32_t tile_size) { return ((width + tile_size - 1u) / tile_size) | 1u; }
+
 // Result-preserving marching accelerator derived from the occupancy bitfield (launch_occ_accel, on the device):
 //   box   world-space bounds of every occupied cell that can be consulted, slightly inflated (shortcut 1)
 //   mask  kCoarse^3 bits over box: bit (z*kCoarse + y)*kCoarse + x set iff such a cell (inflated alike) overlaps that block (shortcut 2)

@@ -1749,7 +1749,7 @@ __global__ void detile_kernel(int W, int H, uint32_t tile, uint32_t tiles_x, uin
 int launch_detile(const nrs_render_params& p, uint32_t n_ranks, size_t rank_stride_floats, const float* d_tiles, uint32_t channels,
                   float* d_image, void* stream) {
 	const int W = p.resolution[0], H = p.resolution[1];
-	const uint32_t tiles_x = ((uint32_t)W + p.tile_size - 1) / p.tile_size;
+	const uint32_t tiles_x = tile_pitch((uint32_t)W, p.tile_size);
 	const uint32_t n = (uint32_t)(W * H);
 	hipLaunchKernelGGL(detile_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, H, p.tile_size, tiles_x, n_ranks, rank_stride_floats,
 	                   d_tiles, channels, d_image);

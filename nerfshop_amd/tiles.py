@@ -1,8 +1,8 @@
 """Image-tile sharding of one frame across the GPUs of a node (the reference is single-GPU, README.md:423).
 
 Rays are independent, so the only exchange step is the final gather of the rendered tiles.  The image is cut into
-tile x tile pixel tiles in row-major tile order and dealt round-robin: rank r owns tiles r, r + N, r + 2N, ...
-(lego rays are spatially clustered; an interleave balances the load where contiguous strips would not).  Each rank
+tile x tile pixel tiles indexed t = Ty * pitch + Tx with an ODD row pitch (tile_pitch) and dealt round-robin: rank r owns tiles r, r + N, r + 2N, ...
+(lego rays are spatially clustered; an interleave balances the load where contiguous strips would not, and the odd pitch makes it a diagonal one).  Each rank
 renders its tiles into a COMPACT buffer [tiles_per_rank, tile, tile, C] (nrs_render_params.tile_*); ONE exchange step
 collects them on rank 0 and nrs_detile scatters them back into the W x H image.  On GPUs the exchange is libnrs's own
 nrs_gather_tiles (host C++: ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on RCCL over xGMI, include/nrs.h) on a
@@ -17,8 +17,14 @@ import torch.distributed as dist
 from . import _abi
 
 
+def tile_pitch(width, tile):
+    """row pitch of the tile index (include/nrs.h): odd, so that `index mod ranks` deals diagonals rather than columns; indices beyond the image's
+    last tile column are virtual (they own no pixels)"""
+    return ((width + tile - 1) // tile) | 1
+
+
 def tile_counts(width, height, tile, world):
-    tiles_x = (width + tile - 1) // tile
+    tiles_x = tile_pitch(width, tile)
     tiles_y = (height + tile - 1) // tile
     total = tiles_x * tiles_y
     per_rank = [(total - r + world - 1) // world if r < total else 0 for r in range(world)]
@@ -28,7 +34,7 @@ def tile_counts(width, height, tile, world):
 def detile_index(width, height, tile, world, padded):
     """For every pixel of the full image, the flat pixel index inside the rank-major gathered buffer
     [world, padded, tile, tile].  (CPU twin of the nrs_detile kernel, used by the gloo tests.)"""
-    tiles_x = (width + tile - 1) // tile
+    tiles_x = tile_pitch(width, tile)
     y = torch.arange(height).view(-1, 1).expand(height, width)
     x = torch.arange(width).view(1, -1).expand(height, width)
     T = (y // tile) * tiles_x + (x // tile)

@@ -1099,7 +1099,7 @@ void render(const Model& m, const nrs_render_params& p, const Edit* const* edits
 	// tiles: a pixel belongs to this call iff its tile index matches (tile_first, tile_stride)
 	auto owned = [&](uint32_t x, uint32_t y) -> bool {
 		if (p.tile_size == 0) return true;
-		uint32_t tiles_x = (W + p.tile_size - 1) / p.tile_size;
+		uint32_t tiles_x = ((W + p.tile_size - 1) / p.tile_size) | 1u; // the odd row pitch of the tile index (nrs.h)
 		uint32_t t = (y / p.tile_size) * tiles_x + (x / p.tile_size);
 		uint32_t stride = p.tile_stride ? p.tile_stride : 1;
 		return t >= p.tile_first && (t - p.tile_first) % stride == 0;

@@ -74,7 +74,7 @@ def _worker(rank, world, port, W, H, tile, q):
 
 @pytest.mark.parametrize("world,W,H,tile", [(2, 96, 56, 16), (2, 100, 60, 24), (8, 120, 72, 16)])
 def test_tile_shard_gather(built, world, W, H, tile):
-    """world 8 = the configuration BASELINE configs[4] names; (120, 72, 16) gives 40 tiles: 5 per rank."""
+    """world 8 = the configuration BASELINE configs[4] names; (120, 72, 16) gives 8 x 5 tiles on a pitch of 9: 45 indices, 5-6 per rank."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -86,7 +86,8 @@ def test_tile_shard_gather(built, world, W, H, tile):
         assert pr.exitcode == 0
     ok, samples_ok, per_rank, padded = q.get(timeout=10)
     assert ok and samples_ok
-    assert sum(per_rank) == ((W + tile - 1) // tile) * ((H + tile - 1) // tile) and padded == max(per_rank)
+    # every index of the (odd-pitch) tile grid is owned exactly once: ceil(W / tile) | 1 columns, of which those beyond the image are virtual
+    assert sum(per_rank) == (((W + tile - 1) // tile) | 1) * ((H + tile - 1) // tile) and padded == max(per_rank)
 
 
 def test_detile_index_is_a_bijection_on_owned_pixels():

@@ -165,7 +165,7 @@ def test_slice_on_tiles(rig):
     torch = rig.torch
     W, H, T = 320, 200, 64
     whole = rig.render(_params(rig, W, H, 40.0, render_mode=SLICE, slice_plane_z=1.3))
-    tiles_x, tiles_y = (W + T - 1) // T, (H + T - 1) // T
+    tiles_x, tiles_y = ((W + T - 1) // T) | 1, (H + T - 1) // T   # the odd row pitch of the tile index (nrs.h)
     image = np.zeros((H, W, 4), np.float32)
     for rank in range(3):
         p = _params(rig, W, H, 40.0, render_mode=SLICE, slice_plane_z=1.3, tile_size=T, tile_first=rank, tile_stride=3)
@@ -178,7 +178,7 @@ def test_slice_on_tiles(rig):
         for k in range(owned):
             t = rank + 3 * k
             tx, ty = t % tiles_x, t // tiles_x
-            h, w = min(T, H - ty * T), min(T, W - tx * T)
+            h, w = min(T, H - ty * T), max(0, min(T, W - tx * T))
             image[ty * T:ty * T + h, tx * T:tx * T + w] = f[k, :h, :w]
     assert tiles_x * tiles_y > 9
     assert np.array_equal(image.view(np.uint32), whole[0].view(np.uint32))
@@ -231,7 +231,7 @@ def test_modes_with_affine_stack_and_on_tiles(rig):
         ref = scene.oracle_model.render(p, [scene.oracle_edit, ref_op])
         assert ref[3].n_hit > 1000
         _compare(whole, ref)
-        tiles_x = (W + T - 1) // T
+        tiles_x = ((W + T - 1) // T) | 1   # the odd row pitch of the tile index (nrs.h)
         image = np.zeros((H, W, 4), np.float32)
         for rank in range(3):
             q = _params(rig, W, H, 60.0, render_mode=POSITIONS, tile_size=T, tile_first=rank, tile_stride=3)
@@ -244,7 +244,7 @@ def test_modes_with_affine_stack_and_on_tiles(rig):
             for k in range(owned):
                 t = rank + 3 * k
                 tx, ty = t % tiles_x, t // tiles_x
-                h, w = min(T, H - ty * T), min(T, W - tx * T)
+                h, w = min(T, H - ty * T), max(0, min(T, W - tx * T))
                 image[ty * T:ty * T + h, tx * T:tx * T + w] = f[k, :h, :w]
         assert np.array_equal(image.view(np.uint32), whole[0].view(np.uint32))
     finally:

@@ -108,7 +108,7 @@ def test_every_schedule_and_tiles(anyrig, grid_acc, mlp_acc):
         assert np.array_equal(steps, out[1][2]) and stats.n_samples == out[1][3].n_samples, team
     # tiles (automatic choice = lane teams for a small share): reassembled == the whole image
     W, H, T = 320, 180, 64
-    tiles_x = (W + T - 1) // T
+    tiles_x = ((W + T - 1) // T) | 1   # the odd row pitch of the tile index (nrs.h)
     for team in (0, 4):
         image = np.zeros((H, W, 4), np.float32)
         rig.ctx.set_lane_teams(team)
@@ -124,7 +124,7 @@ def test_every_schedule_and_tiles(anyrig, grid_acc, mlp_acc):
             for k in range(owned):
                 t = rank + 4 * k
                 tx, ty = t % tiles_x, t // tiles_x
-                h, w = min(T, H - ty * T), min(T, W - tx * T)
+                h, w = min(T, H - ty * T), max(0, min(T, W - tx * T))
                 image[ty * T:ty * T + h, tx * T:tx * T + w] = f[k, :h, :w]
         assert np.array_equal(image.view(np.uint32), out[1][0].view(np.uint32)), team
 
