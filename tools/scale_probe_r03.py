@@ -59,7 +59,7 @@ def main():
     if os.environ.get("NRS_PROBE_QUICK"):
         return
     # ---- load balance of the round-robin deal
-    print("\n## Load balance of the 64x64 round-robin deal\n")
+    print("\n## Load balance of the round-robin deal (odd-pitch tile index)\n")
     print("Samples per rank (from the per-pixel step counts of whole-frame renders), max / mean over the ranks: the slowest rank bounds a frame.\n")
     print("| view | N = 2 max/mean | N = 4 max/mean | N = 8 max/mean | N = 8 min/mean |")
     print("|---|---|---|---|---|")
@@ -73,7 +73,10 @@ def main():
         torch.cuda.synchronize()
         s = steps.cpu().numpy().astype(np.int64)
         pad = np.zeros((ty * T, tx * T), np.int64); pad[:H, :W] = s
-        per_tile = pad.reshape(ty, T, tx, T).sum(axis=(1, 3)).reshape(-1)
+        per_tile = pad.reshape(ty, T, tx, T).sum(axis=(1, 3))
+        pitch = tiles.tile_pitch(W, T)          # the tile index runs over an ODD row pitch (include/nrs.h): indices beyond the last column are virtual
+        grid = np.zeros((ty, pitch), np.int64); grid[:, :tx] = per_tile
+        per_tile = grid.reshape(-1)
         row = [f"{view}"]
         for N in (2, 4, 8):
             per_rank = np.array([per_tile[r::N].sum() for r in range(N)], np.float64)
