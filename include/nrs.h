@@ -205,6 +205,9 @@ typedef struct nrs_render_params {
 	int32_t  envmap_resolution[2];
 	const float* d_envmap;                /* m_envmap.envmap->params_inference(): float RGBA [res.y][res.x]; every pixel's frame value is REPLACED by the
 	                                       * environment seen along its ray before the NeRF composites over it (read_envmap, envmap.cuh:30-63; :2590-2592) */
+	uint32_t glow_mode;           /* m_nerf.m_glow_mode: composite_kernel_nerf's grid / cut-line overlay (:806-903); bits 1 green grid, 2 cut line, 4 mask to
+	                               * alpha, 8 radial, 16 grid only.  0 = off (the reference's default) */
+	float    glow_y_cutoff;       /* m_nerf.m_glow_y_cutoff */
 } nrs_render_params;
 
 typedef struct nrs_render_stats {

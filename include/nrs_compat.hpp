@@ -174,6 +174,8 @@ public:
 	int m_distortion_resolution[2] = {0, 0};          // m_distortion.resolution
 	const float* m_envmap = nullptr;                  // m_envmap.envmap->params_inference() (float RGBA [res.y][res.x]), NULL when the snapshot has none
 	int m_envmap_resolution[2] = {0, 0};              // m_envmap.resolution
+	int m_glow_mode = 0;                              // m_nerf.m_glow_mode, m_nerf.m_glow_y_cutoff: composite_kernel_nerf's grid / cut-line overlay (:806-903)
+	float m_glow_y_cutoff = 0.f;
 
 	// Testbed state update_density_grid_nerf_operator advances: m_rng, m_nerf.density_grid_ema_step, density_grid_decay, max_cascade
 	nrs_grid_update m_density_grid_update{};
@@ -226,6 +228,8 @@ public:
 		for (int i = 0; i < 7; ++i) p.distortion_params[i] = m_render_distortion_params[i];
 		p.d_distortion_map = m_distortion_map;
 		p.d_envmap = m_envmap;
+		p.glow_mode = (uint32_t)m_glow_mode;
+		p.glow_y_cutoff = m_glow_y_cutoff;
 		for (int i = 0; i < 2; ++i) { p.distortion_resolution[i] = m_distortion_resolution[i]; p.envmap_resolution[i] = m_envmap_resolution[i]; }
 		std::vector<nrs_edit*> edits;
 		for (const EditOperator* op : m_edit_operators) edits.push_back(op->get());

@@ -107,6 +107,8 @@ class RenderParams(C.Structure):
         ("distortion_resolution", C.c_int32 * 2),
         ("envmap_resolution", C.c_int32 * 2),
         ("d_envmap", C.c_void_p),
+        ("glow_mode", C.c_uint32),
+        ("glow_y_cutoff", C.c_float),
     ]
 
 

@@ -1229,6 +1229,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	{ const int pc = check_march_params(*p, "nrs_render_nerf"); if (pc != NRS_OK) return pc; }
 	if (p->render_mode == NRS_RENDER_NORMALS || p->render_mode == NRS_RENDER_ENCODING_VIS)
 		return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: render modes Normals (network input gradient) and EncodingVis (visualize_activation) need tiny-cuda-nn and are not on the path");
+	if (!std::isfinite(p->glow_y_cutoff) || p->glow_mode > 31u) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: glow_mode is a 5-bit mask and glow_y_cutoff must be finite");
 	if (p->distortion_mode > 2u) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: distortion_mode must be 0 (None), 1 (Iterative) or 2 (FTheta)");
 	for (int i = 0; i < 7; ++i)
 		if (!std::isfinite(p->distortion_params[i])) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: distortion parameters must be finite");
@@ -1278,7 +1279,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	}
 	// everything of render_nerf's surface beyond Shade / Cost with a pinhole camera runs the EXTRA instantiation (one lane per ray)
 	a.extra = ((p->render_mode != NRS_RENDER_SHADE && p->render_mode != NRS_RENDER_COST) || p->show_accel || p->dof != 0.f || p->distortion_mode || p->d_distortion_map ||
-	           p->d_envmap) ? 1u : 0u;
+	           p->d_envmap || p->glow_mode) ? 1u : 0u;
 	if (p->render_mode == NRS_RENDER_SLICE) { // tn:3109-3162: no marching at all; one network evaluation per owned pixel
 		a.frame = d_frame; a.depth = d_depth; a.steps = d_steps; a.counters = d_counters_slot;
 		HIP_TRY(hipMemsetAsync(d_counters_slot, 0, sizeof(RenderCounters), s));

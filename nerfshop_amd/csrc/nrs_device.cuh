@@ -841,6 +841,53 @@ __device__ __forceinline__ bool poisson_residual_density(const DeviceEdit& e, f3
 	return true;
 }
 
+// composite_kernel_nerf's glow overlay (tn:806-903; m_glow_mode, off by default): a grid / cut-line visualisation that adds to (or, "grid only", replaces)
+// the sample's colour and can scale its weight.  cosf is the device library's (the host-compiled reference uses glibc's): colour tolerance, not bits.
+__device__ __forceinline__ void glow_overlay(const nrs_render_params& p, f3 pos, f3 cam_o, float& weight, float& r, float& g, float& b) {
+	const uint32_t gm = p.glow_mode;
+	const bool green_grid = gm & 1u, green_cutline = gm & 2u, mask_to_alpha = gm & 4u, radial_mode = gm & 8u, grid_mode = gm & 16u;
+	float glow = 0.f, dist;
+	if (radial_mode) {
+		const f3 dv = pos - cam_o;
+		dist = sqrtf(dot3(dv, dv));
+		dist = fminf(dist, (4.5f - pos.y) * 0.333f);
+	} else {
+		dist = pos.y;
+	}
+	if (grid_mode) {
+		glow = 1.f / fmaxf(1.f, dist);
+	} else {
+		float y = p.glow_y_cutoff - dist;
+		float mask = 0.f;
+		if (y > 0.f) {
+			y *= 80.f;
+			mask = fminf(1.f, y);
+			if (green_cutline) glow += fmaxf(0.f, 1.f - fabsf(1.f - y)) * 4.f;
+			if (y > 1.f) y = 1.f - (y - 1.f) * 0.05f;
+			if (green_grid) glow += fmaxf(0.f, y / fmaxf(1.f, dist));
+		}
+		if (mask_to_alpha) weight *= mask;
+	}
+	if (glow > 0.f) {
+		const float PI = 3.141592653589793f;
+		float line = 0.f;
+		#pragma unroll
+		for (int k = 0; k < 4; ++k) { // y, x, z at 2, 4, 8, 16 times the base frequency, in the reference's order
+			const float f = (float)(2 << k);
+			line += fmaxf(0.f, cosf(pos.y * f * PI * 16.f) - 0.975f);
+			line += fmaxf(0.f, cosf(pos.x * f * PI * 16.f) - 0.975f);
+			line += fmaxf(0.f, cosf(pos.z * f * PI * 16.f) - 0.975f);
+		}
+		if (grid_mode) {
+			glow = glow * line * 15.f;
+			g = glow; b = glow * 0.5f; r = glow * 0.25f;
+		} else {
+			glow = glow * glow * 0.25f + glow * line * 15.f;
+			g += glow; b += glow * 0.5f; r += glow * 0.25f;
+		}
+	}
+}
+
 // composite_kernel_nerf's per-sample render modes (tn:905-937): what replaces the network's colour.  pos = the (mapped) sample position in world
 // units, origin = payload.origin, cdt = unwarp_dt(input->dt), alpha after the show_accel override.  Normals / EncodingVis are refused by the host.
 __device__ __forceinline__ void render_mode_rgb(const nrs_render_params& p, f3 pos, f3 origin, f3 cam_fwd, float cdt, float alpha, float& r, float& g, float& b) {

@@ -592,8 +592,9 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			}
 			if (empty) alpha = 0.0f;
 			if (EXTRA && p3.show_accel) alpha = 1.f; // tn:788-790
-			const float weight = alpha * T;
+			float weight = alpha * T;
 			float sr = network_to_rgb(raw_r, m3.rgb_activation), sg = network_to_rgb(raw_g, m3.rgb_activation), sb = network_to_rgb(raw_b, m3.rgb_activation);
+			if (EXTRA && p3.glow_mode) glow_overlay(p3, cpos, cam_o, weight, sr, sg, sb); // tn:806-903
 			if (EXTRA) render_mode_rgb(p3, cpos, o, cam_fwd, cdt, alpha, sr, sg, sb); // tn:905-937
 			if (POISSON && has_res) { // tn:796-805, 939-943
 				const float alpha_N = 1.f - __expf(-sigma * cdt);

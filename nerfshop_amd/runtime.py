@@ -371,6 +371,7 @@ class Testbed:
         self.render_distortion = (0, (0.0,) * 7)   # m_nerf.render_distortion (mode, params) when render_with_camera_distortion
         self.distortion_map = None        # m_distortion.map: float32 CUDA tensor [H, W, 2] or None
         self.envmap = None                # m_envmap.envmap: float32 CUDA tensor [H, W, 4] or None
+        self.glow_mode, self.glow_y_cutoff = 0, 0.0   # m_nerf.m_glow_mode / m_glow_y_cutoff
         mn, mx = list(desc.aabb_min), list(desc.aabb_max)
         self.render_aabb = (mn, mx)       # m_render_aabb
         self.last_stats = None
@@ -400,6 +401,7 @@ class Testbed:
         p.dof = self.dof
         p.slice_plane_z = self.slice_plane_z + self.scale  # testbed_nerf.cu:3067
         p.depth_scale = 1.0 / self.dataset_scale           # :3113
+        p.glow_mode, p.glow_y_cutoff = self.glow_mode, self.glow_y_cutoff
         set_camera_extras(p, self.render_distortion, self.distortion_map, self.envmap)
         return p
 

@@ -1269,6 +1269,56 @@ void render(const Model& m, const nrs_render_params& p, const Edit* const* edits
 					float weight = alpha * T;
 					float rgb[3] = {network_to_rgb(h2f(out[j][0]), m.desc.rgb_activation), network_to_rgb(h2f(out[j][1]), m.desc.rgb_activation),
 					                network_to_rgb(h2f(out[j][2]), m.desc.rgb_activation)};
+					// ---- the glow overlay ("random grid visualizations"), tn:806-903: adds to / replaces the colour, may scale the weight
+					if (p.glow_mode) {
+						const uint32_t gm = p.glow_mode;
+						const bool green_grid = gm & 1, green_cutline = gm & 2, mask_to_alpha = gm & 4, radial_mode = gm & 8, grid_mode = gm & 16;
+						float glow = 0.f;
+						float dist;
+						if (radial_mode) {
+							V3 dv = pos - cam_o;
+							dist = sqrtf(dot(dv, dv));
+							dist = std::min(dist, (4.5f - pos.y) * 0.333f);
+						} else {
+							dist = pos.y;
+						}
+						if (grid_mode) {
+							glow = 1.f / std::max(1.f, dist);
+						} else {
+							float y = p.glow_y_cutoff - dist;
+							float mask = 0.f;
+							if (y > 0.f) {
+								y *= 80.f;
+								mask = std::min(1.f, y);
+								if (green_cutline) glow += std::max(0.f, 1.f - fabsf(1.f - y)) * 4.f;
+								if (y > 1.f) y = 1.f - (y - 1.f) * 0.05f;
+								if (green_grid) glow += std::max(0.f, y / std::max(1.f, dist));
+							}
+							if (mask_to_alpha) weight *= mask;
+						}
+						if (glow > 0.f) {
+							const float PI = 3.141592653589793f;
+							float line = std::max(0.f, cosf(pos.y * 2.f * PI * 16.f) - 0.975f);
+							line += std::max(0.f, cosf(pos.x * 2.f * PI * 16.f) - 0.975f);
+							line += std::max(0.f, cosf(pos.z * 2.f * PI * 16.f) - 0.975f);
+							line += std::max(0.f, cosf(pos.y * 4.f * PI * 16.f) - 0.975f);
+							line += std::max(0.f, cosf(pos.x * 4.f * PI * 16.f) - 0.975f);
+							line += std::max(0.f, cosf(pos.z * 4.f * PI * 16.f) - 0.975f);
+							line += std::max(0.f, cosf(pos.y * 8.f * PI * 16.f) - 0.975f);
+							line += std::max(0.f, cosf(pos.x * 8.f * PI * 16.f) - 0.975f);
+							line += std::max(0.f, cosf(pos.z * 8.f * PI * 16.f) - 0.975f);
+							line += std::max(0.f, cosf(pos.y * 16.f * PI * 16.f) - 0.975f);
+							line += std::max(0.f, cosf(pos.x * 16.f * PI * 16.f) - 0.975f);
+							line += std::max(0.f, cosf(pos.z * 16.f * PI * 16.f) - 0.975f);
+							if (grid_mode) {
+								glow = glow * line * 15.f;
+								rgb[1] = glow; rgb[2] = glow * 0.5f; rgb[0] = glow * 0.25f;
+							} else {
+								glow = glow * glow * 0.25f + glow * line * 15.f;
+								rgb[1] += glow; rgb[2] += glow * 0.5f; rgb[0] += glow * 0.25f;
+							}
+						}
+					}
 					// ---- per-sample render modes, tn:905-937 (Normals / EncodingVis need tiny-cuda-nn's input gradient / visualize_activation: not on the path)
 					if (render_mode == NRS_RENDER_POSITIONS) {
 						if (show_accel >= 0) {

@@ -343,7 +343,7 @@ void ref_render_frame(const nrs_model_desc* desc, const nrs_render_params* p, co
 
 		std::vector<uint16_t> n_steps_before(n_alive); // payload.n_steps as generate_next_nerf_network_inputs left it = samples this ray holds
 		for (uint32_t k = 0; k < n_alive; ++k) n_steps_before[k] = rays_current.payload[k].n_steps;
-		launch_linear(true, n_alive, composite_kernel_nerf, n_elements, i, train_aabb, 0.0f /*glow_y_cutoff*/, 0 /*glow_mode*/, 0u, (const TrainingXForm*)nullptr, camera_matrix1, focal_length,
+		launch_linear(true, n_alive, composite_kernel_nerf, n_elements, i, train_aabb, p->glow_y_cutoff, (int)p->glow_mode, 0u, (const TrainingXForm*)nullptr, camera_matrix1, focal_length,
 		              p->depth_scale, rays_current.rgba.data(), rays_current.depth.data(), rays_current.normal.data(), rays_current.payload.data(), input_data, gradient_data,
 		              (const network_precision_t*)network_output_old.data(), (const network_precision_t*)network_output.data(), (const SH9RGB*)sh_boundary.data(),
 		              (const float*)density_out_boundary.data(), (const float*)density_residual_boundary.data(), 16u, n_steps_between_compaction, render_mode, bitfield, rgb_activation,

@@ -158,6 +158,10 @@ FRAME_CASES = [
     ("aabb16_distortion_map_envmap", "aabb16", (64, 36, 120.0), {"_distmap": (24, 12, 9, 0.02), "_envmap": (40, 20, 6)}, "cage"),
     ("lego_mode_distortion_map", "lego", (64, 36, 60.0), {"render_mode": 7, "_distmap": (24, 12, 9, 0.004)}, "cage"),
     ("lego_mode_distortion_nomap", "lego", (64, 36, 60.0), {"render_mode": 7, "_background": 0.25}, None),
+    # composite_kernel_nerf's glow overlay (tn:806-903): green grid + cut line, radial grid-only, mask to alpha
+    ("lego_glow_grid_cutline", "lego", (64, 36, 60.0), {"glow_mode": 3, "glow_y_cutoff": 0.55}, "cage"),
+    ("lego_glow_radial_gridonly", "lego", (64, 36, 100.0), {"glow_mode": 24, "glow_y_cutoff": 0.5}, None),
+    ("aabb16_glow_mask_to_alpha", "aabb16", (64, 36, 30.0), {"glow_mode": 5, "glow_y_cutoff": 0.6}, "cage"),
     ("lego_slice_distorted_lens", "lego", (64, 36, 30.0), {"render_mode": 9, "slice_plane_z": 1.3, "distortion_mode": 1, "distortion_params": (0.15, -0.05, 0.003, 0.002, 0, 0, 0), "dof": 0.05,
                                                           "_distmap": (24, 12, 9, 0.01)}, None),
 ]

@@ -346,3 +346,21 @@ def test_slice_through_a_distorted_lens(rig):
     assert np.abs(got[0] - ref[0]).max() < 6e-3 and np.abs(got[0] - ref[0]).mean() < 2e-4
     straight = rig.render(_params(rig, 200, 120, 40.0, render_mode=SLICE, slice_plane_z=1.3))
     assert np.abs(straight[0] - got[0]).max() > 0.01
+
+
+@pytest.mark.parametrize("which,glow_mode,cutoff", [("rig", 3, 0.55), ("rig", 24, 0.5), ("rig", 7, 0.5), ("rig16", 5, 0.6)])
+def test_glow_overlay(request, which, glow_mode, cutoff):
+    """composite_kernel_nerf's grid / cut-line overlay (tn:806-903): green grid + cut line, radial grid-only, all three with the mask scaling the weights
+    (which changes how far rays march), on the aabb-16 scene too.  cosf of the device library against glibc's: the Shade bar scaled by the overlay's brightness."""
+    rig = request.getfixturevalue(which)
+    rig.use_edit(True)
+    try:
+        p = _params(rig, 256, 144, 60.0, glow_mode=glow_mode, glow_y_cutoff=cutoff)
+        got = rig.render(p)
+        ref = rig.scene.oracle_model.render(p, [rig.scene.oracle_edit])
+        assert ref[3].n_hit > 1000
+        _compare(got, ref, depth_atol=2e-3 * (16 if which == "rig16" else 1))
+        plain = rig.render(_params(rig, 256, 144, 60.0))
+        assert np.abs(plain[0] - got[0]).max() > 0.05
+    finally:
+        rig.use_edit(False)
