@@ -1337,6 +1337,8 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		a.tail_target = tail_target;
 		static const uint32_t reteam = []() { const char* e = getenv("NRS_RETEAM"); return e ? (uint32_t)atoi(e) : 1u; }();
 		a.reteam = reteam;
+		static const uint32_t steal = []() { const char* e = getenv("NRS_STEAL"); return e ? (uint32_t)atoi(e) : 1u; }();
+		a.steal = steal;
 		if (((team == 4 && !forced && hybrid_on) || forced == -2) && !a.any_poisson && !a.any_affine && !a.extra) {
 			// few rays for the GPU: 4x4 packets only, and every generation takes ALL the rays its wave has pending with as many
 			// lanes per ray as fit (4 up to 16 rays, 2 up to 32), so that no wave is left with a second, nearly empty generation
@@ -1344,7 +1346,8 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 			a.team = 0;
 			a.all_tail = 1;
 			NRS_TRY(tile_geometry(*p, 4, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x));
-			a.tail_target = 16;
+			static const uint32_t all_tail_target = []() { const char* e = getenv("NRS_ALLTAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)atoi(e) : 16u; }();
+			a.tail_target = all_tail_target;
 		} else if (team > 1) {
 			a.team = team;
 			NRS_TRY(tile_geometry(*p, team, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x));
@@ -1381,6 +1384,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		h_stats->n_samples = c.n_samples;
 		h_stats->n_rays_alive = c.n_rays_alive;
 		h_stats->n_rays_hit = c.n_rays_hit;
+		if (a.dbg & 12u) fprintf(stderr, "[nrs hand-over] %llu rays in %llu hand-overs\n", c.walk[7] & 0xffffffffull, c.walk[7] >> 32);
 		if (a.dbg & 4u) {
 			static const char* names[8] = {"fill", "refill", "setup+warp", "gather", "sh+mlp", "composite+march+shade", "-", "exit"};
 			unsigned long long tot = 0;
@@ -1397,6 +1401,9 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 			// per-wave log: when did each wave finish (wall clock), when did it first find the frame's queue empty
 			std::vector<unsigned long long> wl(8192 * 4);
 			HIP_TRY(hipMemcpy(wl.data(), ctx->d_wave_log, wl.size() * 8, hipMemcpyDeviceToHost));
+			if (const char* dump = getenv("NRS_WAVE_LOG_FILE")) { // raw log of the LAST launch with statistics, for tools/wave_log_report.py
+				if (FILE* f = fopen(dump, "wb")) { fwrite(wl.data(), 8, wl.size(), f); fclose(f); }
+			}
 			std::vector<std::array<unsigned long long, 4>> rec; // {end tick (10 ns), rounds | rounds before queue-empty << 16 | t_queue_empty << 32, packets, xcc}
 			unsigned long long t0min = ~0ull;
 			for (size_t i = 0; i < 8192; ++i) if (wl[4 * i]) t0min = std::min(t0min, wl[4 * i + 3] >> 32);
@@ -1404,7 +1411,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 				if (wl[4 * i]) {
 					const unsigned long long wall = wl[4 * i + 3] & 0xffffffffull, start = (wl[4 * i + 3] >> 32) - t0min;
 					const unsigned long long rq = (wl[4 * i + 1] >> 16) & 0xffff, tq = (wl[4 * i + 1] >> 32) + start;
-					rec.push_back({wall + start, (wl[4 * i + 1] & 0xffffull) | (rq << 16) | (tq << 32), wl[4 * i + 2] & 0xffffffffull, wl[4 * i + 2] >> 56});
+					rec.push_back({wall + start, (wl[4 * i + 1] & 0xffffull) | (rq << 16) | (tq << 32), wl[4 * i + 2] & 0xffffull, wl[4 * i + 2] >> 56});
 				}
 			std::sort(rec.begin(), rec.end());
 			if (!rec.empty()) {

@@ -581,6 +581,19 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 	#undef NRS_OCCUPIED
 }
 
+// march_to_occupied's first test on its own: true when the walk from parameter t would return at once (inside the render box, in an occupied cell)
+__device__ __forceinline__ bool stands_in_occupied_cell(const nrs_render_params& p, const DeviceModel& m, const uint32_t* __restrict__ march_lds, f3 o, f3 d, float t) {
+	Box3 bb;
+	#pragma unroll
+	for (int i = 0; i < 3; ++i) { bb.mn[i] = p.render_aabb_min[i]; bb.mx[i] = p.render_aabb_max[i]; }
+	const f3 pos = o + d * t;
+	if (!box_contains(bb, pos)) return false;
+	const float dt = calc_dt(t, p.cone_angle_constant);
+	const uint32_t mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
+	if (!box_contains(m.occ.box, pos)) return false;
+	return occupied_at(pos, m.bitfield, mip, march_lds);
+}
+
 // advance_pos_nerf, tn:557-606: jitter by one Sobol value, then skip to the first occupied cell
 __device__ __forceinline__ bool first_hit(const nrs_render_params& p, const DeviceModel& m, const uint32_t* __restrict__ march_lds, uint32_t pixel_idx, Ray& r,
                                           uint32_t* n_iter = nullptr) {

@@ -54,6 +54,9 @@ struct RenderSmem {
 	unsigned long long queue;       // the workgroup's chunk of the frame's packet queue: next packet | end << 32 (claim_packet)
 	unsigned long long sum_samples; // statistics of the workgroup's waves, flushed by the last one to finish
 	uint32_t sum_alive, sum_hit, n_finished;
+	// ray hand-over between the waves of a workgroup (render_body, "donate"): waves that wait for rays (bit per wave), waves that still hold some,
+	// and per waiting wave the number of rays a sibling has put into its FeatLds (0 = none yet)
+	uint32_t idle_mask, n_busy, mail[WAVES];
 };
 
 // (XCD-aware order -- one cursor per XCD over stripes of 8 / 16 / 32 / 64 pixel rows, workgroups of an XCD working on neighbouring packets so
@@ -222,7 +225,8 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 	const RenderArgs& a = a_arg;
 	__shared__ RenderSmem<WAVES> sm;
 	stage_march_lds(sm.coarse, m.occ.mask);
-	if (threadIdx.x == 0) { sm.queue = 0ull; sm.sum_samples = 0ull; sm.sum_alive = 0u; sm.sum_hit = 0u; sm.n_finished = 0u; }
+	if (threadIdx.x == 0) { sm.queue = 0ull; sm.sum_samples = 0ull; sm.sum_alive = 0u; sm.sum_hit = 0u; sm.n_finished = 0u; sm.idle_mask = 0u; sm.n_busy = (uint32_t)WAVES; }
+	if (threadIdx.x < WAVES) sm.mail[threadIdx.x] = 0u;
 	stage_model_to_lds(m, sm.ml, a.dbg); // (ends with the barrier that also publishes sm.coarse and the words above)
 
 	const int lane = threadIdx.x & 63;
@@ -273,6 +277,50 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		// the survivors are the long rays, and each of them costs one latency-bound round per sample whatever the wave's occupancy.  Spread them
 		// over the idle lanes: 2 or 4 lanes per ray, as in a team generation (lane k of a team stands k samples ahead, all composite the team's
 		// samples in order: same bits).  The state of a ray moves with 15 shuffles, once.
+		// ---- ray hand-over (TEAM == 0): the queue is dry and this wave still holds more rays than run at four lanes each, while a sibling wave of the
+		// workgroup has run out of work and waits.  Half of the rays move to it through its (idle) FeatLds: 15 words per ray, written by the lead lanes;
+		// both waves then re-team (the block below here, the pick-up there), so the rays of both halves advance twice as many samples per round.
+		// The state of a ray at this point is its lead lane's registers (as for re-teaming): same float operations afterwards, same bits.
+		// (A wave in the middle of a generation does not look at the queue; a waiting sibling is how it learns that the queue is dry.)
+		if (TEAM == 0 && a1.steal && ring_count == 0u && __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&sm.idle_mask) != 0) {
+			more = false;
+			const unsigned long long lead_mask = __ballot(have && tk == 0);
+			const uint32_t live = (uint32_t)__popcll(lead_mask);
+			if (live > 16u) {
+				uint32_t target = 0xffffffffu;
+				if (lane == 0) {
+					uint32_t idle = *(volatile uint32_t*)&sm.idle_mask;
+					while (idle) {
+						const uint32_t w = (uint32_t)__builtin_ctz(idle), bit = 1u << w;
+						const uint32_t old = atomicAnd(&sm.idle_mask, ~bit); // the wave whose bit this wave clears is this wave's to serve: it waits for the mail
+						if (old & bit) { target = w; break; }
+						idle = old & ~bit;
+					}
+					if (target != 0xffffffffu) atomicAdd(&sm.n_busy, 1u); // (on the receiver's behalf, before it can look)
+				}
+				target = (uint32_t)__builtin_amdgcn_readfirstlane((int)target);
+				if (target != 0xffffffffu) {
+					const uint32_t keep = (live + 1u) / 2u, give = live - keep;
+					const bool team_live = ((lead_mask >> team_base) & 1ull) != 0ull;
+					const uint32_t lead_rank = (uint32_t)__popcll(lead_mask & ((1ull << team_base) - 1ull));
+					const bool moved = team_live && lead_rank >= keep;
+					uint32_t* mb = &sm.fl[target].feat[0][0][0];
+					if (moved && tk == 0) {
+						const uint32_t r = lead_rank - keep;
+						mb[0 * 32 + r] = __float_as_uint(o.x); mb[1 * 32 + r] = __float_as_uint(o.y); mb[2 * 32 + r] = __float_as_uint(o.z);
+						mb[3 * 32 + r] = __float_as_uint(d.x); mb[4 * 32 + r] = __float_as_uint(d.y); mb[5 * 32 + r] = __float_as_uint(d.z);
+						mb[6 * 32 + r] = __float_as_uint(t);
+						mb[7 * 32 + r] = __float_as_uint(cr); mb[8 * 32 + r] = __float_as_uint(cg); mb[9 * 32 + r] = __float_as_uint(cb); mb[10 * 32 + r] = __float_as_uint(ca);
+						mb[11 * 32 + r] = __float_as_uint(ray_depth); mb[12 * 32 + r] = __float_as_uint(max_weight);
+						mb[13 * 32 + r] = out_idx; mb[14 * 32 + r] = n_steps;
+					}
+					if (moved) have = false;
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					__builtin_amdgcn_wave_barrier();
+					if (lane == 0) { *(volatile uint32_t*)&sm.mail[target] = give; if (PROF || (a1.dbg & 8u)) atomicAdd(&a1.counters->walk[7], (unsigned long long)give | (1ull << 32)); }
+				}
+			}
+		}
 		if (TEAM == 0 && a1.reteam && !more && ring_count == 0u) {
 			const unsigned long long lead_mask = __ballot(have && tk == 0);
 			const uint32_t live = (uint32_t)__popcll(lead_mask);
@@ -378,7 +426,8 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		// ---- hand pending rays to idle lanes ----
 		if (nfree >= kRefillWhenIdle && ring_count) {
 			if (TEAM == 0) { // hybrid: full generations until the tail packets, then as many lanes per ray as the pending rays allow
-				gen_t = tail_seen ? (ring_count > 32u ? 1u : (ring_count > 16u ? 2u : 4u)) : 1u;
+				// (a launch of tail packets only never runs one lane per ray: more than 32 pending rays = 32 now as teams of two, the rest in the next generation)
+				gen_t = tail_seen ? (ring_count > 32u && !a1.all_tail ? 1u : (ring_count > 16u ? 2u : 4u)) : 1u;
 				tk = lane & (int)(gen_t - 1u);
 				team_base = lane & ~(int)(gen_t - 1u);
 			}
@@ -409,7 +458,51 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		__builtin_amdgcn_wave_barrier();
 
 		if (!__any(have)) {
-			if (!more && ring_count == 0) break;
+			if (!more && ring_count == 0) {
+				if (!(TEAM == 0 && a1.steal)) break;
+				// nothing left for this wave: wait for rays from a sibling that still holds many (see "ray hand-over" above), until no wave holds any
+				uint32_t got = 0u;
+				if (lane == 0) {
+					const uint32_t bit = 1u << wave;
+					atomicOr(&sm.idle_mask, bit);
+					atomicSub(&sm.n_busy, 1u);
+					bool promised = false; // a sibling has cleared this wave's bit: its rays are on their way
+					for (;;) {
+						got = *(volatile uint32_t*)&sm.mail[wave];
+						if (got) break;
+						if (!promised && *(volatile uint32_t*)&sm.n_busy == 0u) {
+							if (atomicAnd(&sm.idle_mask, ~bit) & bit) break; // nobody holds rays any more and nobody has picked this wave: done
+							promised = true;
+						}
+						__builtin_amdgcn_s_sleep(8);
+					}
+				}
+				got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+				if (!got) break;
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				const uint32_t* mb = &sm.fl[wave].feat[0][0][0];
+				gen_t = got <= 16u ? 4u : 2u; // (a sibling hands over at most 32 rays)
+				tk = lane & (int)(gen_t - 1u);
+				team_base = lane & ~(int)(gen_t - 1u);
+				const uint32_t r = (uint32_t)lane / gen_t;
+				have = r < got;
+				valid = true;
+				if (have) {
+					o = mk3(__uint_as_float(mb[0 * 32 + r]), __uint_as_float(mb[1 * 32 + r]), __uint_as_float(mb[2 * 32 + r]));
+					d = mk3(__uint_as_float(mb[3 * 32 + r]), __uint_as_float(mb[4 * 32 + r]), __uint_as_float(mb[5 * 32 + r]));
+					t = __uint_as_float(mb[6 * 32 + r]);
+					cr = __uint_as_float(mb[7 * 32 + r]); cg = __uint_as_float(mb[8 * 32 + r]); cb = __uint_as_float(mb[9 * 32 + r]); ca = __uint_as_float(mb[10 * 32 + r]);
+					ray_depth = __uint_as_float(mb[11 * 32 + r]); max_weight = __uint_as_float(mb[12 * 32 + r]);
+					out_idx = mb[13 * 32 + r]; n_steps = mb[14 * 32 + r];
+					for (int j = 0; j < tk && valid; ++j) { // lane k of a team stands k samples ahead
+						t += calc_dt(t, p1.cone_angle_constant);
+						f3 npos; float ndt;
+						valid = march_to_occupied(p1, m1, sm.coarse, o, d, t, npos, ndt, nullptr);
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+				if (lane == 0) *(volatile uint32_t*)&sm.mail[wave] = 0u;
+			}
 			continue;
 		}
 
@@ -546,11 +639,39 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					}
 				}
 			}
-			if (have && !done) { // on to this lane's next sample, TEAM samples ahead
-				for (int j = 0; j < (int)gen_t && valid; ++j) {
-					t += calc_dt(t, p3.cone_angle_constant);
-					f3 npos; float ndt;
-					valid = march_to_occupied(p3, m3, sm.coarse, o, d, t, npos, ndt, nullptr);
+			// ---- on to this lane's next sample, gen_t samples ahead.  Walked lane by lane that is gen_t dependent marches per round (measured on a 1/8 share
+			// of the bench frame: 0.32 of its 0.65 ms).  The team's next positions continue from its LAST lane's position u0, and as long as every
+			// position stands in an occupied cell the walk is nothing but `t += dt`: lane k forms its candidate (k + 1 steps from u0, the same additions
+			// in the same order) and ALL lanes test theirs at once; the candidates in front of the first one that fails ARE the walk's positions, the
+			// lanes from there on walk as before, starting at the last position that held (same arithmetic as lane by lane: same bits).
+			const bool need = have && !done;
+			if (__any(need)) {
+				const int last = team_base + (int)gen_t - 1;
+				const float u0 = __shfl(t, last, 64);
+				const bool chain = __shfl((int)valid, last, 64) != 0; // the last lane stands on a sample, hence every lane of the team does
+				float cand = u0;
+				#pragma unroll
+				for (int j = 0; j < 4; ++j)
+					if (j <= tk) cand += calc_dt(cand, p3.cone_angle_constant);
+				const bool holds = need && chain && stands_in_occupied_cell(p3, m3, sm.coarse, o, d, cand);
+				const uint32_t team_bits = (uint32_t)(__ballot(holds) >> team_base) & ((1u << gen_t) - 1u);
+				const int first_off = __builtin_ctz(~team_bits); // first lane of the team whose candidate does not hold (gen_t: all hold)
+				if (need) {
+					if (!chain) {
+						valid = false; // (walking on from a sample that does not exist: the ray has left the render box)
+					} else if (tk < first_off) {
+						t = cand;
+						valid = true;
+					} else {
+						t = u0;
+						for (int j = 0; j < first_off; ++j) t += calc_dt(t, p3.cone_angle_constant);
+						valid = true;
+						for (int j = first_off; j <= tk && valid; ++j) {
+							t += calc_dt(t, p3.cone_angle_constant);
+							f3 npos; float ndt;
+							valid = march_to_occupied(p3, m3, sm.coarse, o, d, t, npos, ndt, nullptr);
+						}
+					}
 				}
 			}
 			const bool lead_valid = __shfl((int)valid, team_base, 64) != 0;
@@ -668,9 +789,11 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				unsigned int xcc = 0;
 				asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
 				unsigned long long* w = a.wave_log + 4 * (size_t)(blockIdx.x * WAVES + wave);
-				w[0] = life;
+				unsigned int hw = 0;
+				asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+				w[0] = life | ((unsigned long long)st_alive << 48);
 				w[1] = pf_rounds | (pf_rounds_q << 16) | (pf_tq << 32);
-				w[2] = pf_packets | ((unsigned long long)(xcc & 0xf) << 56);
+				w[2] = (pf_packets & 0xffffull) | ((unsigned long long)(hw & 0xffffu) << 16) | ((unsigned long long)(ph_acc[0] >> 8) << 32 & 0x00ffffff00000000ull) | ((unsigned long long)(xcc & 0xf) << 56);
 				w[3] = (wall_clock64() - pf_wall0) | ((pf_wall0 & 0xffffffffull) << 32);
 			}
 		}

@@ -16,7 +16,7 @@ def main():
     import bench
     from nerfshop_amd import runtime as rt, synth, tiles
     ctx = rt.Context(0)
-    scene = bench.build_scene("lego_cage", rt, synth, ctx, torch)
+    scene = bench.build_scene(os.environ.get("NRS_PROBE_SCENE", "lego_cage"), rt, synth, ctx, torch)
     tb = scene["tb"]
     W, H, T = 1920, 1080, bench.TILE
     warm = synth.render_params(W, H, bench.camera_for(0, synth, 1), aabb_scale=1)
@@ -30,7 +30,7 @@ def main():
     print("| ranks N | share | frames in flight | ms per share-frame | Msamples/s on this GPU | retained |")
     print("|---|---|---|---|---|---|")
     base = None
-    for N in (1, 2, 4, 8):
+    for N in tuple(int(v) for v in os.environ.get('NRS_PROBE_N', '1,2,4,8').split(',')):
         for F in ((1, 2) if os.environ.get('NRS_PROBE_QUICK') else (1, 2, 4)):
             shs = [tiles.TileSharder(W, H, T, 0, N, "cuda:0") for _ in range(F)]
             streams = [torch.cuda.Stream() for _ in range(F)]

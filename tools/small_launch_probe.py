@@ -14,7 +14,7 @@ def main():
     from nerfshop_amd import runtime as rt, synth, tiles
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     ctx = rt.Context(0)
-    scene = bench.build_scene("lego_cage", rt, synth, ctx, torch)
+    scene = bench.build_scene(os.environ.get("NRS_PROBE_SCENE", "lego_cage"), rt, synth, ctx, torch)
     tb = scene["tb"]
     W, H, T = 1920, 1080, bench.TILE
     sh = tiles.TileSharder(W, H, T, 0, N, "cuda:0")
