@@ -43,6 +43,9 @@ constexpr int kRing = 128; // pending-ray ring entries per wave (>= 63 + 64)
 // 1 (refill every idle lane at once, 98 % of lanes busy) 7.41 Gsamples/s, 16/32 7.08, 48 7.60, 56 7.78, 60 7.80, 64 8.09 -- once
 // the marcher's VALU diet made the gather's L1/TA path the first limiter, coherence became worth more than occupancy (aabb-16
 // scene: 3.49 -> 3.92).
+#ifndef NRS_OPT_GIVE_RING
+#define NRS_OPT_GIVE_RING 1 // ray hand-over: rays pending in a busy wave's ring go to a waiting sibling (0: only rays already in lanes are handed over)
+#endif
 constexpr uint32_t kRefillWhenIdle = 64;
 
 template <int WAVES>
@@ -238,12 +241,9 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 	bool tail_seen = false; // TEAM == 0: this wave has reached the queue's tail packets
 	uint2* ring = sm.ring[wave];
 	FeatLds& fl = sm.fl[wave];
-	const GridView gv = make_grid_view(m);
 	const nrs_render_params& p = a.p;
 	const uint32_t nm = NUM == kNumRuntime ? (uint32_t)__builtin_amdgcn_readfirstlane((int)m.numerics) : (uint32_t)NUM;
 	const bool ops = p.apply_operators && a.n_edits > 0;
-	const f3 cam_fwd = mk3(p.camera_matrix1[6], p.camera_matrix1[7], p.camera_matrix1[8]);
-	const f3 cam_o = mk3(p.camera_matrix1[9], p.camera_matrix1[10], p.camera_matrix1[11]);
 
 	float off_x, off_y; // wave-uniform: kept in scalar registers
 	ld_random_pixel_offset(p.snap_to_pixel_centers ? 0u : p.spp_index, off_x, off_y);
@@ -282,23 +282,42 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		// both waves then re-team (the block below here, the pick-up there), so the rays of both halves advance twice as many samples per round.
 		// The state of a ray at this point is its lead lane's registers (as for re-teaming): same float operations afterwards, same bits.
 		// (A wave in the middle of a generation does not look at the queue; a waiting sibling is how it learns that the queue is dry.)
-		if (TEAM == 0 && a1.steal && ring_count == 0u && __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&sm.idle_mask) != 0) {
+		// Rays that wait in this wave's ring for its next generation go first (two words per ray, copied into the sibling's ring: it starts them at once).
+		if (TEAM == 0 && a1.steal && __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&sm.idle_mask) != 0) {
 			more = false;
-			const unsigned long long lead_mask = __ballot(have && tk == 0);
-			const uint32_t live = (uint32_t)__popcll(lead_mask);
-			if (live > 16u) {
+			int ln = lane; // (opaque copy: lane predicates of this rare block are then formed here, not hoisted into scalar-register pairs that live through the frame loop)
+			asm volatile("" : "+v"(ln));
+			auto claim_waiting_wave = [&]() -> uint32_t { // the wave whose bit this wave clears is this wave's to serve: it waits for the mail
 				uint32_t target = 0xffffffffu;
-				if (lane == 0) {
+				if (ln == 0) {
 					uint32_t idle = *(volatile uint32_t*)&sm.idle_mask;
 					while (idle) {
 						const uint32_t w = (uint32_t)__builtin_ctz(idle), bit = 1u << w;
-						const uint32_t old = atomicAnd(&sm.idle_mask, ~bit); // the wave whose bit this wave clears is this wave's to serve: it waits for the mail
+						const uint32_t old = atomicAnd(&sm.idle_mask, ~bit);
 						if (old & bit) { target = w; break; }
 						idle = old & ~bit;
 					}
 					if (target != 0xffffffffu) atomicAdd(&sm.n_busy, 1u); // (on the receiver's behalf, before it can look)
 				}
-				target = (uint32_t)__builtin_amdgcn_readfirstlane((int)target);
+				return (uint32_t)__builtin_amdgcn_readfirstlane((int)target);
+			};
+			if (NRS_OPT_GIVE_RING && ring_count != 0u) {
+				if (__any(have)) { // (a wave without running rays starts its pending ones itself, below)
+					const uint32_t target = claim_waiting_wave();
+					if (target != 0xffffffffu) {
+						const uint32_t n = min(ring_count, 64u);
+						if ((uint32_t)ln < n) sm.ring[target][ln] = ring[(ring_head + (uint32_t)ln) & (kRing - 1)];
+						ring_head += n;
+						ring_count -= n;
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+						__builtin_amdgcn_wave_barrier();
+						if (ln == 0) { *(volatile uint32_t*)&sm.mail[target] = n | 0x80000000u; if (PROF || (a1.dbg & 8u)) atomicAdd(&a1.counters->walk[7], (unsigned long long)n | (1ull << 32)); }
+					}
+				}
+			} else if (ring_count == 0u) {
+				const unsigned long long lead_mask = __ballot(have && tk == 0);
+				const uint32_t live = (uint32_t)__popcll(lead_mask);
+				const uint32_t target = live > 16u ? claim_waiting_wave() : 0xffffffffu;
 				if (target != 0xffffffffu) {
 					const uint32_t keep = (live + 1u) / 2u, give = live - keep;
 					const bool team_live = ((lead_mask >> team_base) & 1ull) != 0ull;
@@ -317,7 +336,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					if (moved) have = false;
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 					__builtin_amdgcn_wave_barrier();
-					if (lane == 0) { *(volatile uint32_t*)&sm.mail[target] = give; if (PROF || (a1.dbg & 8u)) atomicAdd(&a1.counters->walk[7], (unsigned long long)give | (1ull << 32)); }
+					if (ln == 0) { *(volatile uint32_t*)&sm.mail[target] = give; if (PROF || (a1.dbg & 8u)) atomicAdd(&a1.counters->walk[7], (unsigned long long)give | (1ull << 32)); }
 				}
 			}
 		}
@@ -462,7 +481,9 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				if (!(TEAM == 0 && a1.steal)) break;
 				// nothing left for this wave: wait for rays from a sibling that still holds many (see "ray hand-over" above), until no wave holds any
 				uint32_t got = 0u;
-				if (lane == 0) {
+				int ln = lane; // (opaque copy, as in the hand-over block above)
+				asm volatile("" : "+v"(ln));
+				if (ln == 0) {
 					const uint32_t bit = 1u << wave;
 					atomicOr(&sm.idle_mask, bit);
 					atomicSub(&sm.n_busy, 1u);
@@ -480,11 +501,19 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
 				if (!got) break;
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				if (got & 0x80000000u) { // rays that had not started: they stand in this wave's ring now
+					ring_head = 0u;
+					ring_count = got & 0x7fffffffu;
+					tail_seen = true; // (lane teams by the number of rays, as for the queue's tail packets)
+					__builtin_amdgcn_wave_barrier();
+					if (ln == 0) *(volatile uint32_t*)&sm.mail[wave] = 0u;
+					continue;
+				}
 				const uint32_t* mb = &sm.fl[wave].feat[0][0][0];
 				gen_t = got <= 16u ? 4u : 2u; // (a sibling hands over at most 32 rays)
-				tk = lane & (int)(gen_t - 1u);
-				team_base = lane & ~(int)(gen_t - 1u);
-				const uint32_t r = (uint32_t)lane / gen_t;
+				tk = ln & (int)(gen_t - 1u);
+				team_base = ln & ~(int)(gen_t - 1u);
+				const uint32_t r = (uint32_t)ln / gen_t;
 				have = r < got;
 				valid = true;
 				if (have) {
@@ -501,13 +530,14 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					}
 				}
 				__builtin_amdgcn_wave_barrier();
-				if (lane == 0) *(volatile uint32_t*)&sm.mail[wave] = 0u;
+				if (ln == 0) *(volatile uint32_t*)&sm.mail[wave] = 0u;
 			}
 			continue;
 		}
 
 		NRS_FRESH_ARGS(m2, a2);
 		const nrs_render_params& p2 = a2.p;
+		const GridView gv = make_grid_view(m2); // (formed per round from fresh scalar loads: ten scalar registers that need not live through the other phases)
 		NRS_PHASE(2); // sample set-up + cage warp
 		if (PROF) ++pf_rounds;
 		// ---- one sample per live ray: generate_next_nerf_network_inputs body (tn:668-692) ----
@@ -589,6 +619,9 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		NRS_FRESH_ARGS(m3, a3);
 		const nrs_render_params& p3 = a3.p;
 		NRS_PHASE(5); // composite + march + shade
+		// (read here, not in front of the frame loop: six scalar registers that would otherwise live through every phase)
+		const f3 cam_fwd = mk3(p3.camera_matrix1[6], p3.camera_matrix1[7], p3.camera_matrix1[8]);
+		const f3 cam_o = mk3(p3.camera_matrix1[9], p3.camera_matrix1[10], p3.camera_matrix1[11]);
 		// ---- composite_kernel_nerf body (tn:750-955, Shade mode) + next-sample march ----
 		uint32_t it_march = 0;
 		if (PROF) { pf_walk[4] += (lane == 0) ? 1u : 0u; pf_walk[5] += have ? 1u : 0u; }
