@@ -247,6 +247,12 @@ int  nrs_ctx_device_info(const nrs_ctx* ctx, char* name_out, size_t name_len, in
  * third of the frame's work queue ("hybrid", whole-image mode).  1 / 2 / 4 force a size for every ray, -1 forces the
  * hybrid schedule, -2 the small-launch schedule (4x4-pixel packets, team size chosen per generation).  Pixel values, depth, step counts and statistics do not depend on it (tests/test_gpu_lane_teams.py). */
 int  nrs_ctx_set_lane_teams(nrs_ctx* ctx, int lanes_per_ray);
+/* Ray hand-over (on by default): in whole-image and small-launch ("hybrid") schedules a wave that has run out of work takes rays from a sibling wave of its
+ * workgroup -- rays that wait in the sibling's ring for its next generation, or half of the rays it holds in lanes (both halves then run with more lanes per
+ * ray) -- instead of leaving its lanes idle for the frame's tail.  Results do not depend on it (tests/test_gpu_lane_teams.py).  nrs_ctx_ray_handovers reports
+ * what the last render launch that returned statistics (h_stats != NULL) handed over: rays moved, hand-overs. */
+int  nrs_ctx_set_ray_handover(nrs_ctx* ctx, int enabled);
+int  nrs_ctx_ray_handovers(const nrs_ctx* ctx, uint64_t* n_rays, uint64_t* n_handovers);
 
 int    nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out);
 void   nrs_model_destroy(nrs_model* model);

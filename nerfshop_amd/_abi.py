@@ -132,7 +132,7 @@ class GridUpdate(C.Structure):
 # every symbol include/nrs.h declares; tests check the library exports exactly these
 EXPORTS = [
     "nrs_last_error", "nrs_abi_version", "nrs_edit_poisson_interpolate", "nrs_edit_download_poisson", "nrs_comm_unique_id", "nrs_comm_create", "nrs_comm_info", "nrs_comm_destroy", "nrs_gather_tiles",
-    "nrs_ctx_create", "nrs_ctx_destroy", "nrs_ctx_device_info", "nrs_ctx_set_lane_teams",
+    "nrs_ctx_create", "nrs_ctx_destroy", "nrs_ctx_device_info", "nrs_ctx_set_lane_teams", "nrs_ctx_set_ray_handover", "nrs_ctx_ray_handovers",
     "nrs_model_create", "nrs_model_destroy", "nrs_model_n_params", "nrs_model_level_table",
     "nrs_model_set_params", "nrs_model_set_params_device", "nrs_model_set_numerics", "nrs_model_set_cell_cache", "nrs_model_cell_cache_bytes", "nrs_model_set_sparse_cell_cache", "nrs_model_sparse_cell_cache_bytes", "nrs_model_set_density_bitfield", "nrs_model_set_density_grid",
     "nrs_model_get_density_bitfield", "nrs_model_get_march_accelerator", "nrs_model_get_density_grid", "nrs_model_update_density_grid", "nrs_rng_seed",
@@ -178,6 +178,8 @@ def load():
     lib.nrs_ctx_device_info.argtypes = [P, C.c_char_p, C.c_size_t, C.POINTER(I), C.POINTER(C.c_size_t)]
     lib.nrs_model_create.argtypes = [P, C.POINTER(ModelDesc), C.POINTER(P)]
     lib.nrs_ctx_set_lane_teams.argtypes = [P, C.c_int]
+    lib.nrs_ctx_set_ray_handover.argtypes = [P, C.c_int]
+    lib.nrs_ctx_ray_handovers.argtypes = [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.nrs_model_destroy.argtypes = [P]
     lib.nrs_model_destroy.restype = None
     lib.nrs_model_n_params.argtypes = [C.POINTER(ModelDesc)]

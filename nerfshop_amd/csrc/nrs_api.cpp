@@ -41,6 +41,8 @@ static int fail_hip(hipError_t e, const char* what) {
 
 struct nrs_ctx {
 	int lane_teams = 0; // nrs_ctx_set_lane_teams: 0 = automatic, 1 / 2 / 4 = lanes per ray for every render launch
+	int handover = -1;  // nrs_ctx_set_ray_handover: -1 = default (on; NRS_STEAL=0 turns it off), 0 / 1
+	unsigned long long last_handover = 0; // rays | hand-overs << 32 of the last launch that returned statistics
 	int device = 0;
 	int n_cus = 0;
 	size_t hbm_bytes = 0;
@@ -315,6 +317,17 @@ int nrs_ctx_set_lane_teams(nrs_ctx* ctx, int lanes_per_ray) {
 	if (!ctx || !(lanes_per_ray == -2 || lanes_per_ray == -1 || lanes_per_ray == 0 || lanes_per_ray == 1 || lanes_per_ray == 2 || lanes_per_ray == 4))
 		return fail(NRS_ERR_INVALID_ARG, "nrs_ctx_set_lane_teams: lanes_per_ray must be 0 (automatic), 1, 2, 4, -1 (hybrid) or -2 (4x4 packets, teams sized per generation)");
 	ctx->lane_teams = lanes_per_ray;
+	return NRS_OK;
+}
+int nrs_ctx_set_ray_handover(nrs_ctx* ctx, int enabled) {
+	if (!ctx) return fail(NRS_ERR_INVALID_ARG, "ctx is NULL");
+	ctx->handover = enabled ? 1 : 0;
+	return NRS_OK;
+}
+int nrs_ctx_ray_handovers(const nrs_ctx* ctx, uint64_t* n_rays, uint64_t* n_handovers) {
+	if (!ctx) return fail(NRS_ERR_INVALID_ARG, "ctx is NULL");
+	if (n_rays) *n_rays = ctx->last_handover & 0xffffffffull;
+	if (n_handovers) *n_handovers = ctx->last_handover >> 32;
 	return NRS_OK;
 }
 int nrs_ctx_device_info(const nrs_ctx* c, char* name_out, size_t name_len, int* n_cus, size_t* hbm_bytes) {
@@ -1338,7 +1351,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		static const uint32_t reteam = []() { const char* e = getenv("NRS_RETEAM"); return e ? (uint32_t)atoi(e) : 1u; }();
 		a.reteam = reteam;
 		static const uint32_t steal = []() { const char* e = getenv("NRS_STEAL"); return e ? (uint32_t)atoi(e) : 1u; }();
-		a.steal = steal;
+		a.steal = ctx->handover >= 0 ? (uint32_t)ctx->handover : steal;
 		if (((team == 4 && !forced && hybrid_on) || forced == -2) && !a.any_poisson && !a.any_affine && !a.extra) {
 			// few rays for the GPU: 4x4 packets only, and every generation takes ALL the rays its wave has pending with as many
 			// lanes per ray as fit (4 up to 16 rays, 2 up to 32), so that no wave is left with a second, nearly empty generation
@@ -1384,6 +1397,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		h_stats->n_samples = c.n_samples;
 		h_stats->n_rays_alive = c.n_rays_alive;
 		h_stats->n_rays_hit = c.n_rays_hit;
+		ctx->last_handover = c.walk[7];
 		if (a.dbg & 12u) fprintf(stderr, "[nrs hand-over] %llu rays in %llu hand-overs\n", c.walk[7] & 0xffffffffull, c.walk[7] >> 32);
 		if (a.dbg & 4u) {
 			static const char* names[8] = {"fill", "refill", "setup+warp", "gather", "sh+mlp", "composite+march+shade", "-", "exit"};

@@ -311,7 +311,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 						ring_count -= n;
 						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 						__builtin_amdgcn_wave_barrier();
-						if (ln == 0) { *(volatile uint32_t*)&sm.mail[target] = n | 0x80000000u; if (PROF || (a1.dbg & 8u)) atomicAdd(&a1.counters->walk[7], (unsigned long long)n | (1ull << 32)); }
+						if (ln == 0) { *(volatile uint32_t*)&sm.mail[target] = n | 0x80000000u; atomicAdd(&a1.counters->walk[7], (unsigned long long)n | (1ull << 32)); }
 					}
 				}
 			} else if (ring_count == 0u) {
@@ -336,7 +336,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					if (moved) have = false;
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 					__builtin_amdgcn_wave_barrier();
-					if (ln == 0) { *(volatile uint32_t*)&sm.mail[target] = give; if (PROF || (a1.dbg & 8u)) atomicAdd(&a1.counters->walk[7], (unsigned long long)give | (1ull << 32)); }
+					if (ln == 0) { *(volatile uint32_t*)&sm.mail[target] = give; atomicAdd(&a1.counters->walk[7], (unsigned long long)give | (1ull << 32)); }
 				}
 			}
 		}

@@ -51,6 +51,16 @@ class Context:
         """0 = automatic (default), 1 / 2 / 4 = lanes of a wavefront per ray in render launches (nrs_ctx_set_lane_teams)."""
         check(self.lib.nrs_ctx_set_lane_teams(self.h, int(lanes_per_ray)))
 
+    def set_ray_handover(self, enabled):
+        """Waves that run out of work take rays from a sibling wave of their workgroup (on by default; nrs_ctx_set_ray_handover)."""
+        check(self.lib.nrs_ctx_set_ray_handover(self.h, int(bool(enabled))))
+
+    def ray_handovers(self):
+        """(rays moved, hand-overs) of the last render launch that returned statistics."""
+        n, k = C.c_uint64(), C.c_uint64()
+        check(self.lib.nrs_ctx_ray_handovers(self.h, C.byref(n), C.byref(k)))
+        return n.value, k.value
+
     def close(self):
         if self.h:
             self.lib.nrs_ctx_destroy(self.h)

@@ -141,3 +141,29 @@ def test_bad_team_size_is_refused(rig):
     from nerfshop_amd import _abi
     with pytest.raises(_abi.NrsError):
         rig.ctx.set_lane_teams(3)
+
+
+@pytest.mark.parametrize("edit", [False, True])
+def test_ray_handover_does_not_change_the_picture(rig, edit):
+    """Waves that run out of work take rays from a sibling wave of their workgroup (pending ring entries, or half of the rays held in lanes):
+    the hybrid whole-image schedule and the small-launch schedule, hand-over on and off -- identical bits, and the hand-over did happen."""
+    rig.use_edit(edit)
+    try:
+        for size, team in (((960, 540), -1), ((640, 360), -2), ((1920, 1080), 0)):
+            p = rig.scene.params_for(size[0], size[1], 60.0)
+            out = {}
+            moved = {}
+            for on in (0, 1):
+                rig.ctx.set_ray_handover(on)
+                rig.ctx.set_lane_teams(team)
+                out[on] = rig.render(p)
+                moved[on] = rig.ctx.ray_handovers()
+            assert moved[0] == (0, 0)
+            assert moved[1][0] > 0 and moved[1][1] > 0, (size, team, moved)
+            for i in range(3):
+                assert np.array_equal(np.asarray(out[0][i]).view(np.uint32), np.asarray(out[1][i]).view(np.uint32)), (size, team, i)
+            assert (out[0][3].n_samples, out[0][3].n_rays_alive, out[0][3].n_rays_hit) == (out[1][3].n_samples, out[1][3].n_rays_alive, out[1][3].n_rays_hit)
+    finally:
+        rig.ctx.set_ray_handover(1)
+        rig.ctx.set_lane_teams(0)
+        rig.use_edit(False)
