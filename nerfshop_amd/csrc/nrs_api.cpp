@@ -1336,11 +1336,13 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		}
 		(void)hipGetLastError(); // hipErrorNotReady is an answer, not an error
 		const double rays_per_lane = hit_share * (double)a.pixels_owned * (double)(1u + busy) / (64.0 * 16.0 * (double)ctx->n_cus);
-		uint32_t team = rays_per_lane <= 0.55 ? 4u : (rays_per_lane <= 4.5 ? 2u : 1u);
-		if (busy >= 2) team = 1;
-		else if (busy == 1 && team > 2) team = 2;
-		// the fill runs once per pixel and lane of a team: keep it to ~8 passes over the GPU (an all-miss 1080p frame is 8)
-		while (team > 1 && (double)team * (double)a.pixels_owned * (double)(1u + busy) > 8.5 * 64.0 * 16.0 * (double)ctx->n_cus) team >>= 1;
+		// Round 3 (team rounds test the team's next positions in parallel, so lanes shared by a ray cost little; tools/schedule_probe.py, ms per frame
+		// with the small-launch schedule / 2 lanes per ray / hybrid): 960x540 0.92 / 1.12 / 1.20, 1280x720 1.39 / 1.43 / 1.43, 1600x900 2.00 / 1.88 / 1.81,
+		// 1/4 of the 1080p frame as tiles 0.85 / 0.94 / -, 1/2 1.48 / 1.47 / -, all of it 2.75 / 2.46 / - (2.68 with one lane per ray).  With frames
+		// in flight the same thresholds hold for the rays of ALL overlapping launches (1/8 share, 4 in flight: 0.375 / 0.338 / -, one lane 0.363).
+		uint32_t team = rays_per_lane <= 1.5 ? 4u : (rays_per_lane <= 4.5 ? 2u : 1u);
+		// the fill runs once per pixel and lane of a team: keep it to ~16 passes over the GPU (an all-miss 1080p frame is 8)
+		while (team > 1 && (double)team * (double)a.pixels_owned * (double)(1u + busy) > 17.0 * 64.0 * 16.0 * (double)ctx->n_cus) team >>= 1;
 		if (forced == 1 || forced == 2 || forced == 4) team = (uint32_t)forced;
 		if (forced == -1) team = 1;
 		if (a.any_poisson || a.any_affine || a.extra) team = 1; // (those instantiations are built for one lane per ray)
@@ -1361,10 +1363,11 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 			NRS_TRY(tile_geometry(*p, 4, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x));
 			static const uint32_t all_tail_target = []() { const char* e = getenv("NRS_ALLTAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)atoi(e) : 16u; }();
 			a.tail_target = all_tail_target;
-		} else if (team > 1) {
+		} else if (team > 1 && (forced > 0 || p->tile_size != 0 || !hybrid_on)) {
 			a.team = team;
 			NRS_TRY(tile_geometry(*p, team, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x));
 		} else if (p->tile_size == 0 && !a.any_poisson && !a.any_affine && !a.extra && (forced == -1 || (!forced && hybrid_on))) {
+			// whole images with more rays than the small-launch schedule is for: hybrid (one lane per ray, lane teams for the tail of the queue)
 			// hybrid: every 3rd packet row leaves the 8x8 list and joins the end of the queue as 4x4 tail packets (packet_pixel_bulk/_tail);
 			// measured on 1080p lego + cage, every 2nd / 3rd / 4th / 6th / 8th / 16th row: 8.88 / 8.89 / 8.79 / 8.75 / 8.65 / 8.65 Gsamples/s
 			static const uint32_t tail_every = []() { const char* e = getenv("NRS_TAIL_EVERY"); return e && atoi(e) >= 2 ? (uint32_t)atoi(e) : 3u; }();
