@@ -314,8 +314,8 @@ void nrs_ctx_destroy(nrs_ctx* c) {
 	delete c;
 }
 int nrs_ctx_set_lane_teams(nrs_ctx* ctx, int lanes_per_ray) {
-	if (!ctx || !(lanes_per_ray == -2 || lanes_per_ray == -1 || lanes_per_ray == 0 || lanes_per_ray == 1 || lanes_per_ray == 2 || lanes_per_ray == 4))
-		return fail(NRS_ERR_INVALID_ARG, "nrs_ctx_set_lane_teams: lanes_per_ray must be 0 (automatic), 1, 2, 4, -1 (hybrid) or -2 (4x4 packets, teams sized per generation)");
+	if (!ctx || !(lanes_per_ray == -4 || lanes_per_ray == -3 || lanes_per_ray == -2 || lanes_per_ray == -1 || lanes_per_ray == 0 || lanes_per_ray == 1 || lanes_per_ray == 2 || lanes_per_ray == 4))
+		return fail(NRS_ERR_INVALID_ARG, "nrs_ctx_set_lane_teams: lanes_per_ray must be 0 (automatic), 1, 2, 4, -1 (hybrid), -2, -3 or -4 (small-launch schedule: teams sized per generation, 4x4- / 8x4- / 8x8-pixel packets)");
 	ctx->lane_teams = lanes_per_ray;
 	return NRS_OK;
 }
@@ -1265,6 +1265,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	a.p = *p;
 	uint32_t owned_tiles = 0;
 	a.team = 1;
+	a.fill_lanes = 4;
 	int st = tile_geometry(*p, 1, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x);
 	if (st != NRS_OK) return st;
 	a.n_edits = n_edits;
@@ -1336,31 +1337,40 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		}
 		(void)hipGetLastError(); // hipErrorNotReady is an answer, not an error
 		const double rays_per_lane = hit_share * (double)a.pixels_owned * (double)(1u + busy) / (64.0 * 16.0 * (double)ctx->n_cus);
-		// Round 3 (team rounds test the team's next positions in parallel, so lanes shared by a ray cost little; tools/schedule_probe.py, ms per frame
-		// with the small-launch schedule / 2 lanes per ray / hybrid): 960x540 0.92 / 1.12 / 1.20, 1280x720 1.39 / 1.43 / 1.43, 1600x900 2.00 / 1.88 / 1.81,
-		// 1/4 of the 1080p frame as tiles 0.85 / 0.94 / -, 1/2 1.48 / 1.47 / -, all of it 2.75 / 2.46 / - (2.68 with one lane per ray).  With frames
-		// in flight the same thresholds hold for the rays of ALL overlapping launches (1/8 share, 4 in flight: 0.375 / 0.338 / -, one lane 0.363).
-		uint32_t team = rays_per_lane <= 1.5 ? 4u : (rays_per_lane <= 4.5 ? 2u : 1u);
-		// the fill runs once per pixel and lane of a team: keep it to ~16 passes over the GPU (an all-miss 1080p frame is 8)
-		while (team > 1 && (double)team * (double)a.pixels_owned * (double)(1u + busy) > 17.0 * 64.0 * 16.0 * (double)ctx->n_cus) team >>= 1;
+		// Round 3: team rounds test the team's next positions in parallel and waves hand rays over, so the small-launch schedule (packets of 16 / 32 / 64
+		// pixels = 4 / 2 / 1 lanes on a pixel during the fill, every generation sized by the rays its wave has pending) is the automatic choice up to
+		// the sizes where the hybrid schedule of whole images takes over.  tools/schedule_probe.py (profiles/r03_schedules.md), ms per frame with
+		// 16- / 32- / 64-pixel packets | hybrid | fixed 2 lanes per ray: 640x360 0.66 / 0.77 / 1.18 | 1.15 | 0.85, 960x540 0.93 / 0.96 / 1.16 | 1.20 | 1.12,
+		// 1280x720 1.40 / 1.28 / 1.51 | 1.43 | 1.44, 1600x900 2.02 / 1.76 / 1.85 | 1.83 | 1.90, 1080p 2.77 / 2.36 / 2.37 | 2.35 | 2.48, 1440p 4.66 / 3.86 / 3.71 |
+		// 3.79 | 3.96; a rank's tiles of the 1080p frame, N = 8: 0.53 / 0.57 / 0.89 | - | 0.57, N = 4: 0.85 / 0.82 / 1.01 | - | 0.94, N = 2: 1.49 / 1.32 / 1.43 | - | 1.47,
+		// N = 1: 2.78 / 2.36 / 2.37 | - | 2.49.  With frames in flight the thresholds hold for the rays of ALL overlapping launches.
+		uint32_t fill_lanes = rays_per_lane <= 0.6 ? 4u : (rays_per_lane <= 2.6 ? 2u : 1u);
+		// the fill runs once per pixel and lane on it: keep it to ~16 passes over the GPU (an all-miss 1080p frame is 8)
+		while (fill_lanes > 1 && (double)fill_lanes * (double)a.pixels_owned * (double)(1u + busy) > 17.0 * 64.0 * 16.0 * (double)ctx->n_cus) fill_lanes >>= 1;
+		// Whole images with many rays per lane take the hybrid schedule (64-ray generations at one lane per ray for the bulk of the queue).  Between 2.8 and 6
+		// rays per lane the two are close and the scene decides -- bench frames, Gsamples/s hybrid / 64-pixel packets: lego + cage 10.8 / 11.0, lego 12.1 / 12.4,
+		// varied opacity 9.7 / 9.3, and at 7.9 rays per lane (aabb-16, every pixel hits) 4.76 / 4.65.
+		const bool small_launch = p->tile_size != 0 || rays_per_lane <= 6.0;
+		uint32_t team = 1; // fixed lanes per ray: only when forced
 		if (forced == 1 || forced == 2 || forced == 4) team = (uint32_t)forced;
 		if (forced == -1) team = 1;
 		if (a.any_poisson || a.any_affine || a.extra) team = 1; // (those instantiations are built for one lane per ray)
 		static const bool log_teams = getenv("NRS_TEAM_LOG") != nullptr;
-		if (log_teams) fprintf(stderr, "[nrs team] pixels=%u hit_share=%.3f busy=%u rays/lane=%.3f team=%u\n", a.pixels_owned, hit_share, busy, rays_per_lane, team);
+		if (log_teams) fprintf(stderr, "[nrs team] pixels=%u hit_share=%.3f busy=%u rays/lane=%.3f small-launch=%d fill lanes=%u forced=%d\n", a.pixels_owned, hit_share, busy, rays_per_lane, (int)small_launch, fill_lanes, forced);
 		static const uint32_t tail_target = []() { const char* e = getenv("NRS_TAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)atoi(e) : 24u; }(); // 8 / 16 / 24 / 32 / 48: 8.92 / 8.91 / 9.11 / 9.01 / 8.47 Gsamples/s
 		a.tail_target = tail_target;
-		static const uint32_t reteam = []() { const char* e = getenv("NRS_RETEAM"); return e ? (uint32_t)atoi(e) : 1u; }();
+		static const uint32_t reteam = []() { const char* e = getenv("NRS_RETEAM"); return e ? (uint32_t)atoi(e) : 3u; }(); // bit 0: at the end of a wave's work, bit 1: whenever a tail generation has thinned out
 		a.reteam = reteam;
 		static const uint32_t steal = []() { const char* e = getenv("NRS_STEAL"); return e ? (uint32_t)atoi(e) : 1u; }();
 		a.steal = ctx->handover >= 0 ? (uint32_t)ctx->handover : steal;
-		if (((team == 4 && !forced && hybrid_on) || forced == -2) && !a.any_poisson && !a.any_affine && !a.extra) {
+		if (((small_launch && !forced && hybrid_on) || forced == -2 || forced == -3 || forced == -4) && !a.any_poisson && !a.any_affine && !a.extra) {
 			// few rays for the GPU: 4x4 packets only, and every generation takes ALL the rays its wave has pending with as many
 			// lanes per ray as fit (4 up to 16 rays, 2 up to 32), so that no wave is left with a second, nearly empty generation
 			// (1/8 share of the bench frame: 0.88 -> 0.82 ms).
 			a.team = 0;
 			a.all_tail = 1;
-			NRS_TRY(tile_geometry(*p, 4, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x));
+			a.fill_lanes = forced == -4 ? 1u : (forced == -3 ? 2u : (forced == -2 ? 4u : fill_lanes));
+			NRS_TRY(tile_geometry(*p, a.fill_lanes, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x));
 			static const uint32_t all_tail_target = []() { const char* e = getenv("NRS_ALLTAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)atoi(e) : 16u; }();
 			a.tail_target = all_tail_target;
 		} else if (team > 1 && (forced > 0 || p->tile_size != 0 || !hybrid_on)) {
@@ -1374,9 +1384,11 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 			const uint32_t rows = ((uint32_t)p->resolution[1] + 7u) / 8u, tail_rows = rows / tail_every;
 			a.tail_every = tail_every;
 			if (tail_rows) {
+				static const uint32_t tail_fill = []() { const char* e = getenv("NRS_TAIL_FILL"); return e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4) ? (uint32_t)atoi(e) : 4u; }();
 				a.team = 0;
+				a.fill_lanes = tail_fill; // lanes on a pixel while a tail packet is filled: packets of 4x4 / 8x4 / 8x8 pixels (packet_pixel_tail)
 				a.p_big = (rows - tail_rows) * a.tiles_x;
-				a.n_packets = a.p_big + tail_rows * a.tiles_x * 4u;
+				a.n_packets = a.p_big + tail_rows * a.tiles_x * tail_fill;
 			}
 		}
 		a.feedback = ctx->d_feedback;

@@ -133,6 +133,7 @@ struct RenderArgs {
 	uint32_t tail_target;      // hybrid launches: rays a wave collects per generation once it works on tail packets (24)
 	uint32_t all_tail;         // hybrid launches: every packet is a 4x4 tail packet (packet_pixel<4>'s geometry, whole-image or tiles)
 	uint32_t steal;            // hybrid launches: waves that run out of work take half the rays of a sibling of their workgroup (render_body, "ray hand-over")
+	uint32_t fill_lanes;       // small-launch schedule (all_tail): lanes that stand on one pixel during the fill (4, 2 or 1: packets of 16 / 32 / 64 pixels)
 	uint32_t p_big;            // hybrid launches (team == 0): packets [0, p_big) are 8x8, the rest 4x4 tail packets; else 0
 	uint32_t team;             // 0 = hybrid (full generations, lane teams for the queue's tail); lanes per ray: 1, or 2 / 4 for launches with too few rays to fill the GPU (render_kernel's TEAM)
 	uint32_t max_steps;

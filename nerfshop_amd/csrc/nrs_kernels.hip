@@ -191,10 +191,12 @@ __device__ __forceinline__ bool packet_pixel_bulk(const RenderArgs& a, uint32_t 
 }
 __device__ __forceinline__ bool packet_pixel_tail(const RenderArgs& a, uint32_t q, int lane, uint32_t& x, uint32_t& y, uint32_t& out_idx) {
 	const uint32_t W = (uint32_t)a.p.resolution[0], H = (uint32_t)a.p.resolution[1];
-	const uint32_t per_row = a.tiles_x * 4u, trow = q / per_row, s = q % per_row, sy = s / (a.tiles_x * 2u), sx = s % (a.tiles_x * 2u);
-	const uint32_t idx = (uint32_t)lane >> 2; // 4 lanes per pixel, as in packet_pixel<4>
-	x = sx * 4u + (idx & 3u);
-	y = (trow * a.tail_every + a.tail_every - 1u) * 8u + sy * 4u + (idx >> 2);
+	// a tail row is 8 pixels high; its packets are 4x4 / 8x4 / 8x8 pixels with fill_lanes = 4 / 2 / 1 lanes on a pixel (as in packet_pixel<4 / 2 / 1>)
+	const uint32_t L = a.fill_lanes, cols = L == 4u ? a.tiles_x * 2u : a.tiles_x, per_row = cols * (L == 1u ? 1u : 2u);
+	const uint32_t trow = q / per_row, s = q % per_row, sy = s / cols, sx = s % cols;
+	const uint32_t idx = (uint32_t)lane / L, pw = L == 4u ? 4u : 8u;
+	x = sx * pw + (idx % pw);
+	y = (trow * a.tail_every + a.tail_every - 1u) * 8u + sy * 4u + (idx / pw);
 	out_idx = x + W * y;
 	return x < W && y < H;
 }
@@ -340,18 +342,18 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				}
 			}
 		}
-		if (TEAM == 0 && a1.reteam && !more && ring_count == 0u) {
+		if (TEAM == 0 && a1.reteam && (((a1.reteam & 2u) && tail_seen) || (!more && ring_count == 0u))) { // (bit 1: at any time once the wave runs tail generations, not only at its end)
 			const unsigned long long lead_mask = __ballot(have && tk == 0);
 			const uint32_t live = (uint32_t)__popcll(lead_mask);
 			const uint32_t new_t = live <= 16u ? 4u : (live <= 32u ? 2u : 1u);
 			if (live != 0u && new_t > gen_t) {
 				if (have && tk == 0) {
 					const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lead_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lead_mask, 0u));
-					ring[rank].x = (uint32_t)lane; // (the ring is empty: scratch)
+					fl.feat[0][0][rank] = (uint32_t)lane; // (the feature staging area is free between rounds: scratch)
 				}
 				__builtin_amdgcn_wave_barrier();
 				const uint32_t r = (uint32_t)lane / new_t;
-				const int src = r < live ? (int)ring[r].x : lane;
+				const int src = r < live ? (int)fl.feat[0][0][r] : lane;
 				__builtin_amdgcn_wave_barrier();
 				o.x = __shfl(o.x, src, 64); o.y = __shfl(o.y, src, 64); o.z = __shfl(o.z, src, 64);
 				d.x = __shfl(d.x, src, 64); d.y = __shfl(d.y, src, 64); d.z = __shfl(d.z, src, 64);
@@ -390,7 +392,8 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			if (TEAM == 0 && a1.all_tail) { // a launch of 4x4 packets only (few rays for the GPU): every generation sizes its teams
 				small = true;
 				tail_seen = true;
-				inside = packet_pixel<4>(a1, pk, lane, x, y, oi);
+				// (a1.fill_lanes lanes stand on one pixel during the fill: packets of 16 / 32 / 64 pixels)
+				inside = a1.fill_lanes == 4u ? packet_pixel<4>(a1, pk, lane, x, y, oi) : (a1.fill_lanes == 2u ? packet_pixel<2>(a1, pk, lane, x, y, oi) : packet_pixel<1>(a1, pk, lane, x, y, oi));
 			} else if (TEAM == 0 && a1.p_big) {
 				small = pk >= a1.p_big;
 				tail_seen = tail_seen || small;
@@ -398,7 +401,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			} else {
 				inside = packet_pixel<(TEAM ? TEAM : 1)>(a1, pk, lane, x, y, oi);
 			}
-			const bool first_of_team = TEAM == 0 ? (!small || (lane & 3) == 0) : tk == 0;
+			const bool first_of_team = TEAM == 0 ? (!small || (lane & (int)(a1.fill_lanes - 1u)) == 0) : tk == 0;
 			if (inside) {
 				Ray r = init_ray<EXTRA>(p1, x, y, off_x, off_y);
 				if (first_of_team) {
@@ -445,8 +448,9 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		// ---- hand pending rays to idle lanes ----
 		if (nfree >= kRefillWhenIdle && ring_count) {
 			if (TEAM == 0) { // hybrid: full generations until the tail packets, then as many lanes per ray as the pending rays allow
-				// (a launch of tail packets only never runs one lane per ray: more than 32 pending rays = 32 now as teams of two, the rest in the next generation)
-				gen_t = tail_seen ? (ring_count > 32u && !a1.all_tail ? 1u : (ring_count > 16u ? 2u : 4u)) : 1u;
+				// (a launch of tail packets only runs one lane per ray only where it is large -- 64-pixel packets -- and the wave can fill its lanes:
+				// otherwise more than 32 pending rays = 32 now as teams of two, the rest in the next generation or handed to a waiting sibling)
+				gen_t = tail_seen ? (ring_count > 32u && (!a1.all_tail || (a1.fill_lanes == 1u && ring_count >= 56u)) ? 1u : (ring_count > 16u ? 2u : 4u)) : 1u;
 				tk = lane & (int)(gen_t - 1u);
 				team_base = lane & ~(int)(gen_t - 1u);
 			}

@@ -18,7 +18,7 @@ def _params(rig, w, h, az, **fields):
 def _render_all(rig, p):
     out = {}
     try:
-        for team in (1, 2, 4, -1, -2, 0):
+        for team in (1, 2, 4, -1, -2, -3, 0):
             rig.ctx.set_lane_teams(team)
             out[team] = rig.render(p)
     finally:

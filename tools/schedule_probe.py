@@ -1,5 +1,5 @@
 """Which schedule for which launch size?  Whole-image renders of the bench scene at several resolutions, and one rank's tiles of the 1080p frame for
-N = 1, 2, 4, 8, each with the schedule forced through nrs_ctx_set_lane_teams (0 automatic, -1 hybrid, -2 small-launch, 1 / 2 / 4 lanes per ray):
+N = 1, 2, 4, 8, each with the schedule forced through nrs_ctx_set_lane_teams (0 automatic, -1 hybrid, -2 / -3 / -4 small-launch with 4x4 / 8x4 / 8x8-pixel packets, 1 / 2 / 4 lanes per ray):
 ms per frame over the 8 bench views, one frame at a time.  Markdown to stdout.
     python tools/schedule_probe.py [whole|tiles|all]"""
 import os
@@ -9,7 +9,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-TEAMS = (0, -1, -2, 1, 2, 4)
+TEAMS = (0, -1, -2, -3, -4, 1, 2, 4)
 
 
 def main():
