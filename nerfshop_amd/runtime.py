@@ -48,7 +48,8 @@ class Context:
         self.device_name, self.n_cus, self.hbm_bytes = name.value.decode(), ncu.value, hbm.value
 
     def set_lane_teams(self, lanes_per_ray):
-        """0 = automatic (default), 1 / 2 / 4 = lanes of a wavefront per ray in render launches (nrs_ctx_set_lane_teams)."""
+        """0 = automatic (default), 1 / 2 / 4 = lanes of a wavefront per ray in render launches, -1 = hybrid, -2 / -3 / -4 = small-launch schedule with
+        16- / 32- / 64-pixel packets (nrs_ctx_set_lane_teams)."""
         check(self.lib.nrs_ctx_set_lane_teams(self.h, int(lanes_per_ray)))
 
     def set_ray_handover(self, enabled):
