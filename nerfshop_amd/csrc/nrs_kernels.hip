@@ -43,6 +43,9 @@ constexpr int kRing = 128; // pending-ray ring entries per wave (>= 63 + 64)
 // 1 (refill every idle lane at once, 98 % of lanes busy) 7.41 Gsamples/s, 16/32 7.08, 48 7.60, 56 7.78, 60 7.80, 64 8.09 -- once
 // the marcher's VALU diet made the gather's L1/TA path the first limiter, coherence became worth more than occupancy (aabb-16
 // scene: 3.49 -> 3.92).
+#ifndef NRS_EXP_DBL
+#define NRS_EXP_DBL 0 // measurement builds: 1 fill, 2 cage warp, 3 gather, 4 MLPs, 5 march executed twice (results unchanged) -- the frame time's difference is that phase's marginal cost
+#endif
 #ifndef NRS_OPT_GIVE_RING
 #define NRS_OPT_GIVE_RING 1 // ray hand-over: rays pending in a busy wave's ring go to a waiting sibling (0: only rays already in lanes are handed over)
 #endif
@@ -425,6 +428,9 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					}
 				}
 				uint32_t it_fill = 0;
+#if NRS_EXP_DBL == 1
+				if (alive) { Ray r2 = r; const bool a2 = first_hit(p1, m1, sm.coarse, x + (uint32_t)p1.resolution[0] * y, r2, nullptr); asm volatile("" :: "v"(r2.t), "s"((int)__ballot(a2))); }
+#endif
 				if (alive) alive = first_hit(p1, m1, sm.coarse, x + (uint32_t)p1.resolution[0] * y, r, PROF ? &it_fill : nullptr);
 				if (PROF) {
 					uint32_t mx = it_fill;
@@ -557,6 +563,11 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		const f3 wpos0 = wpos; // un-deformed sample position (membrane terms live in deformed space)
 		const bool act = TEAM != 1 ? (have && valid) : have; // this lane evaluates a sample in this round
 		if (ops && act) { // map_rays, last-to-first (tn:2899-2902)
+#if NRS_EXP_DBL == 2
+			{ f3 wp2 = wpos, wd2 = wdir; asm volatile("" : "+v"(wp2.x), "+v"(wp2.y), "+v"(wp2.z)); bool e2 = false;
+			  for (int ei = a2.n_edits - 1; ei >= 0; --ei) e2 |= AFFINE ? edit_warp(a2.edits[ei], true, wp2, wd2) : tet_warp(a2.edits[ei], true, wp2, wd2);
+			  asm volatile("" :: "v"(wp2.x), "v"(wp2.y), "v"(wp2.z), "v"(wd2.x), "v"(wd2.y), "v"(wd2.z), "s"((int)__ballot(e2))); }
+#endif
 			for (int ei = a2.n_edits - 1; ei >= 0; --ei) empty |= AFFINE ? edit_warp(a2.edits[ei], true, wpos, wdir) : tet_warp(a2.edits[ei], true, wpos, wdir);
 		}
 		// ---- membrane correction inputs (compute_poisson_full_residuals, tn:2867-2883) + first network pass (tn:2890-2892) ----
@@ -586,6 +597,10 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 
 		NRS_PHASE(3); // gather
 		// ---- gather: own sample (block g) and the partner lane's sample (block 1-g), levels 2*it+g ----
+#if NRS_EXP_DBL == 3
+		{ f3 wp2 = wpos; asm volatile("" : "+v"(wp2.x), "+v"(wp2.y), "+v"(wp2.z));
+		  encode_num<NUM, (TEAM == 0 && !POISSON && !AFFINE && !EXTRA && NUM == 0)>(nm, gv, m2.levels, sm.ml, fl, lane, g, wp2, act); }
+#endif
 		encode_num<NUM, (TEAM == 0 && !POISSON && !AFFINE && !EXTRA && NUM == 0)>(nm, gv, m2.levels, sm.ml, fl, lane, g, wpos, act); // (four record levels in flight: the hybrid instantiation has the registers)
 		// NRS_OPT_EARLY_MARCH: the walk to the NEXT sample does not depend on the network, and its first step is nearly always its last (the next
 		// sample of a ray inside the object stands in an occupied cell).  The bitfield word that first test needs is requested HERE, in front of the
@@ -600,6 +615,19 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		encode_sh4_2(g, wdir, pdir, sh_own, sh_par);
 
 		// ---- fused MLPs on MFMA, one 32-sample block at a time ----
+#if NRS_EXP_DBL == 4
+		{ uint32_t sink = 0;
+		  #pragma unroll 1
+		  for (int b = 0; b < 2; ++b) {
+			const int sel = (b != g) ? 1 : 0;
+			half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
+			asm volatile("" : "+v"(x0), "+v"(x1));
+			const half8 dout = density_mlp_num<NUM>(nm, sm.ml.w, lane, x0, x1);
+			const half8 rout = rgb_mlp_num<NUM>(nm, sm.ml.w, lane, dout, sel ? sh_par : sh_own);
+			sink ^= __builtin_bit_cast(u32x4, dout)[0] ^ __builtin_bit_cast(u32x4, rout)[1];
+		  }
+		  asm volatile("" :: "v"(sink)); }
+#endif
 		uint32_t res_d = 0, res_rg = 0, res_b = 0;
 		#pragma unroll 1
 		for (int b = 0; b < 2; ++b) {
@@ -785,6 +813,9 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			} else {
 				t += dt;
 				f3 npos; float ndt;
+#if NRS_EXP_DBL == 5
+				{ float t2 = t; asm volatile("" : "+v"(t2)); f3 np2; float nd2; const bool v2 = march_to_occupied(p3, m3, sm.coarse, o, d, t2, np2, nd2, nullptr, nullptr); asm volatile("" :: "v"(t2), "s"((int)__ballot(v2))); }
+#endif
 				done = !march_to_occupied(p3, m3, sm.coarse, o, d, t, npos, ndt, PROF ? &it_march : nullptr, NRS_OPT_EARLY_MARCH ? &occ_seed : nullptr);
 				exited = done;
 			}

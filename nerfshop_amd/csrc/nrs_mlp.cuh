@@ -217,6 +217,9 @@ __device__ __forceinline__ void issue_record_loads(const GridView& gv, const Lev
 	v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
 	v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
 }
+#ifndef NRS_OPT_PKW
+#define NRS_OPT_PKW 1 // trilinear weights as packed fp32 products (v_pk_mul_f32: twelve products in six issue slots; 0: scalar products)
+#endif
 // Trilinear interpolation in the oracle's order (corner 0..7, x fastest; weight = (wx' * wy') * wz') -> packed fp16 pair.
 // NETACC (nrs_grid_acc NETWORK): tiny-cuda-nn's kernel_grid as recalled -- every corner's fp32 product is rounded to fp16 and added in fp16.
 template <bool NETACC = false>
@@ -235,12 +238,27 @@ __device__ __forceinline__ uint32_t interpolate(const CellCoords& c, const uint3
 		return __builtin_bit_cast(uint32_t, r);
 	}
 	float acc0 = 0.f, acc1 = 0.f;
+#if NRS_OPT_PKW
+	{ // the same twelve products as packed fp32 multiplies (v_pk_mul_f32: two IEEE products per issue slot; same bits)
+		typedef float f2v __attribute__((ext_vector_type(2)));
+		const f2v xs = {ux, c.wx};
+		const f2v p01 = xs * uy, p23 = xs * c.wy;
+		const f2v w01 = p01 * uz, w23 = p23 * uz, w45 = p01 * c.wz, w67 = p23 * c.wz;
+		const float wk[8] = {w01.x, w01.y, w23.x, w23.y, w45.x, w45.y, w67.x, w67.y};
+		#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			acc0 = fma_mix_lo(wk[k], v[k], acc0);
+			acc1 = fma_mix_hi(wk[k], v[k], acc1);
+		}
+	}
+#else
 	#pragma unroll
 	for (int k = 0; k < 8; ++k) {
 		const float weight = wxy[k & 3] * ((k & 4) ? c.wz : uz);
 		acc0 = fma_mix_lo(weight, v[k], acc0);
 		acc1 = fma_mix_hi(weight, v[k], acc1);
 	}
+#endif
 	half2v r;
 	r[0] = (_Float16)acc0;
 	r[1] = (_Float16)acc1;
