@@ -126,10 +126,14 @@ def measured_traffic(workload):
     MI355X_MICROARCH.md prescribes).  PMC counters cannot be sampled from inside this process, so this is a RECORDED number from
     TRAFFIC_FILE (same workload, same kernel; `traffic_source` in the line says so); null for the other workloads."""
     path = os.path.join(ROOT, TRAFFIC_FILE)
-    if workload != "lego_cage" or not os.path.exists(path):
+    if not os.path.exists(path):
         return None, None
     try:
         j = json.load(open(path))
+        if workload != "lego_cage":  # (other workloads with a committed PMC pass sit under their own key)
+            j = j.get(workload)
+            if not j:
+                return None, None
         return int(j["traffic_bytes_per_launch"]), f"recorded: {TRAFFIC_FILE} ({j.get('source', 'rocprofv3 --pmc passes')}), not measured by this run"
     except Exception:
         return None, None
@@ -314,6 +318,14 @@ def main():
             extra[name] = {"msamples_per_s": round(ns / dt / 1e6, 2), "fps": round(8 / dt, 2), "samples_per_frame": ns // 8, "rays_view0": rays,
                            "roofline_frac": round(ns / dt * BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4),
                            "cell_records_gb": round((tb2.nerf_network.cell_cache()[0] + tb2.nerf_network.sparse_cell_cache()[0]) / 1e9, 1)}
+            try:  # recorded PMC traffic of this workload's kernel, where profiles/ holds it: the HBM rate the frame really runs at
+                rec_t = json.load(open(os.path.join(ROOT, TRAFFIC_FILE))).get(name)
+                if rec_t:
+                    extra[name]["traffic"] = int(rec_t["traffic_bytes_per_launch"])
+                    extra[name]["traffic_rate_frac"] = round(rec_t["traffic_bytes_per_launch"] / (dt / 8) / 1e9 / HBM_PEAK_GBS, 4)
+                    extra[name]["traffic_source"] = f"recorded: {TRAFFIC_FILE} [{name}], not measured by this run"
+            except Exception:
+                pass
             del sc2, tb2
             torch.cuda.empty_cache()
 
