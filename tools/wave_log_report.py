@@ -30,7 +30,7 @@ def main():
     simd_key = cu_key * 4 + simd
     n = len(end)
     print(f"waves {n}, last end {end.max():.1f} us, mean end {end.mean():.1f} us ({100 * end.mean() / end.max():.1f} %), start spread {start.max():.1f} us")
-    print(f"rays per wave: mean {rays.mean():.1f}, max {rays.max()}; rounds: mean {rounds.mean():.1f}, max {rounds.max()}; packets: mean {packets.mean():.1f}, max {packets.max()}")
+    print(f"rounds per wave: mean {rounds.mean():.1f}, max {rounds.max()}; packets: mean {packets.mean():.1f}, max {packets.max()}")
     busy = rounds > 0
     us_per_round = (wall[busy] - fill[busy] / life[busy] * wall[busy]) / rounds[busy]
     print(f"fill share of a wave's life: mean {100 * (fill[busy] / life[busy]).mean():.1f} %; us per round (life minus fill): "
@@ -45,13 +45,16 @@ def main():
         nw = np.array([(key == k).sum() for k in keys])
         print(f"\n{name}: {len(keys)} units, waves per unit {nw.min()}..{nw.max()}; last end per unit: min {ends.min():.1f}, mean {ends.mean():.1f}, max {ends.max():.1f} us "
               f"(mean / max = {100 * ends.mean() / ends.max():.1f} %)")
-        for label, v in (("rounds", tot_rounds), ("rays", tot_rays), ("packets", tot_packets)):
+        for label, v in (("rounds", tot_rounds), ("packets", tot_packets)):
             c = np.corrcoef(v, ends)[0, 1] if v.std() > 0 else float("nan")
             print(f"   {label} per unit: min {v.min()}, mean {v.mean():.1f}, max {v.max()}; correlation with the unit's end {c:+.2f}")
         order = np.argsort(ends)
         for tag, i in (("earliest", order[0]), ("median", order[len(order) // 2]), ("latest", order[-1])):
             sel = key == keys[i]
-            print(f"   {tag} unit: end {ends[i]:.1f} us, waves {sel.sum()}, rounds {rounds[sel].tolist()}, rays {rays[sel].tolist()}, packets {packets[sel].tolist()}")
+            if sel.sum() <= 16:
+                print(f"   {tag} unit: end {ends[i]:.1f} us, waves {sel.sum()}, rounds {rounds[sel].tolist()}, packets {packets[sel].tolist()}")
+            else:
+                print(f"   {tag} unit: end {ends[i]:.1f} us, waves {sel.sum()}, rounds in all {rounds[sel].sum()}, packets in all {packets[sel].sum()}")
 
     group(simd_key, "SIMDs")
     group(cu_key, "CUs")
