@@ -179,12 +179,28 @@ __device__ __forceinline__ bool dense_needs_slow(const LevelParams& lp, const Ce
 	       c.gx + mul24(c.gy, lp.resolution) + mul24(c.gz, lp.res2) + 1u + lp.resolution + lp.res2 >= lp.count; // (the products are only used when the three tests before passed)
 }
 // Issue the gathers of one sample at one level: v[2q + bx] = entry of corner (bx, q&1, q>>1).
+#ifndef NRS_OPT_HASH4
+#define NRS_OPT_HASH4 1 // hashed levels: the entry's byte offset formed directly (pre-shifted hash terms, level offset in the load's scalar offset)
+#endif
 // Dense levels fetch the two x-neighbours with ONE 8-byte load (entry(x+1) = entry(x) + 1; MUBUF needs dword alignment only).
 template <bool HASHED>
 __device__ __forceinline__ void issue_gathers(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t v[8]) {
 	const uint32_t off4 = lp.offset * 4u;
 	if (HASHED) {
 		// (only the bits under lp.mask < 2^24 survive: the low 24 bits of the primes on the 24-bit multiplier give the same index)
+#if NRS_OPT_U24 && NRS_OPT_HASH4
+		// The BYTE offset of an entry directly: 4 e = (4 x ^ 4 y P1 ^ 4 z P2) & 4 mask (shifts commute with xor and and), with 4 P < 2^24 on the 24-bit
+		// multiplier (the low 24 bits of the primes, as above: 4 mask < 2^26 keeps bits 2..25 of the products, i.e. bits 0..23 of y P), and the level's
+		// first entry in the instruction's scalar offset -- no shift and no add per corner.
+		const uint32_t hx0 = c.gx << 2, hx1 = hx0 + 4u, hy0 = mul24(c.gy, (2654435761u & 0xffffffu) * 4u), hy1 = hy0 + (2654435761u & 0xffffffu) * 4u,
+		               hz0 = mul24(c.gz, (805459861u & 0xffffffu) * 4u), hz1 = hz0 + (805459861u & 0xffffffu) * 4u;
+		const uint32_t mask4 = lp.mask << 2;
+		#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const uint32_t e4 = (((k & 1) ? hx1 : hx0) ^ ((k & 2) ? hy1 : hy0) ^ ((k & 4) ? hz1 : hz0)) & mask4;
+			v[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(gv.rsrc, (int)e4, (int)off4, 0);
+		}
+#else
 		const uint32_t hx0 = c.gx, hx1 = c.gx + 1u, hy0 = mul24(c.gy, NRS_OPT_U24 ? (2654435761u & 0xffffffu) : 2654435761u), hy1 = hy0 + 2654435761u,
 		               hz0 = mul24(c.gz, NRS_OPT_U24 ? (805459861u & 0xffffffu) : 805459861u), hz1 = hz0 + 805459861u;
 		#pragma unroll
@@ -192,6 +208,7 @@ __device__ __forceinline__ void issue_gathers(const GridView& gv, const LevelPar
 			const uint32_t e = (((k & 1) ? hx1 : hx0) ^ ((k & 2) ? hy1 : hy0) ^ ((k & 4) ? hz1 : hz0)) & lp.mask;
 			v[k] = grid_load_bytes(gv, (e << 2) + off4);
 		}
+#endif
 	} else {
 		const uint32_t base = c.gx + mul24(c.gy, lp.resolution) + mul24(c.gz, lp.res2); // dense level: res^3 <= 2^24, coordinates checked by dense_needs_slow
 		#pragma unroll
