@@ -7,7 +7,7 @@
 A "step" is one full frame: clear -> nrs_render_nerf (one persistent HIP launch) [-> RCCL gather of the image tiles to
 rank 0 + de-tile when N > 1].  The camera orbits (azimuth = 45 deg * step) so steps are not replays of one view.
 All inputs (parameters, bitfield, cage tables) are resident in HBM before the timed region.  With N > 1 the SAME frame
-is cut into 64x64 tiles dealt round-robin to the ranks ("scaling": "strong": total work per step is fixed).
+is cut into 32x32 tiles dealt round-robin to the ranks ("scaling": "strong": total work per step is fixed).
 
 Workloads (BASELINE.json configs): lego_cage (default; config[2]/[4]: one active cage edit -- the configuration the
 north-star target is quoted on), lego (config[1], no edit; also reported as `noedit` in the default line), garden_cage
@@ -137,6 +137,48 @@ def measured_traffic(workload):
         return int(j["traffic_bytes_per_launch"]), f"recorded: {TRAFFIC_FILE} ({j.get('source', 'rocprofv3 --pmc passes')}), not measured by this run"
     except Exception:
         return None, None
+
+
+def live_traffic(workload, width, height):
+    """HBM bytes per render_kernel launch measured NOW: two rocprofv3 PMC passes (FETCH_SIZE, then WRITE_SIZE -- separate passes, --kernel-trace only, as
+    MI355X_MICROARCH.md prescribes) over a short child run of this script (8 steps = the 8 bench views; its render_kernel dispatches are averaged), corrected
+    as that guide says for gfx950 (FETCH_SIZE tallies the 128-byte requests at 64 bytes: doubled).  Returns (bytes, description) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("NRS_BENCH_LIVE_TRAFFIC", "1") == "0":
+        return None, "switched off (NRS_BENCH_LIVE_TRAFFIC=0)"
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="nrs_traffic_", dir="/tmp")
+    kb, n_disp = {}, 0
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "t", "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", workload, "--steps", "8", "--warmup", "0", "--no-cpu-baseline", "--no-extra", "--width", str(width), "--height", str(height)]
+            env = dict(os.environ, NRS_BENCH_LIVE_TRAFFIC="0", TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
+            vals = []
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if "render_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"no render_kernel rows in the {counter} pass"
+            kb[counter] = sum(vals) / len(vals)
+            n_disp = len(vals)
+    except Exception as e:  # (a measurement aid must never take the benchmark down)
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    traffic = int(2 * kb["FETCH_SIZE"] * 1024 + kb["WRITE_SIZE"] * 1024)
+    return traffic, (f"measured by this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over a child `bench.py --workload {workload} --steps 8`, "
+                     f"mean of its {n_disp} render_kernel dispatches; 2 x FETCH_SIZE ({kb['FETCH_SIZE']:.0f} KB) + WRITE_SIZE ({kb['WRITE_SIZE']:.0f} KB), gfx950 correction of MI355X_MICROARCH.md")
 
 
 def main():
@@ -334,7 +376,16 @@ def main():
         value = total_samples / elapsed / 1e6
         # roofline of the dominant kernel (render_kernel): algorithmic bytes per launch / mean launch duration (HIP events)
         per_launch_samples = total_samples / args.steps / world
-        traffic, traffic_source = measured_traffic(args.workload)
+        traffic, traffic_source = (None, None)
+        if world == 1 and not args.no_extra:  # (the default run; the child runs it spawns carry --no-extra)
+            traffic, traffic_source = live_traffic(args.workload, W, H)
+            if traffic is None:
+                why = traffic_source
+                traffic, traffic_source = measured_traffic(args.workload)
+                if traffic_source:
+                    traffic_source += f" (live measurement unavailable: {why})"
+        else:
+            traffic, traffic_source = measured_traffic(args.workload)
         ach = per_launch_samples * BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": "render_msamples_per_s_1080p",
