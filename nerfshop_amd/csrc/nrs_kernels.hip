@@ -46,6 +46,9 @@ constexpr int kRing = 128; // pending-ray ring entries per wave (>= 63 + 64)
 #ifndef NRS_EXP_DBL
 #define NRS_EXP_DBL 0 // measurement builds: 1 fill, 2 cage warp, 3 gather, 4 MLPs, 5 march executed twice (results unchanged) -- the frame time's difference is that phase's marginal cost
 #endif
+#ifndef NRS_OPT_NOZERO
+#define NRS_OPT_NOZERO 1 // the render rounds do not zero the features of idle lanes (nobody reads them): one select per level saved
+#endif
 #ifndef NRS_OPT_GIVE_RING
 #define NRS_OPT_GIVE_RING 1 // ray hand-over: rays pending in a busy wave's ring go to a waiting sibling (0: only rays already in lanes are handed over)
 #endif
@@ -601,7 +604,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		{ f3 wp2 = wpos; asm volatile("" : "+v"(wp2.x), "+v"(wp2.y), "+v"(wp2.z));
 		  encode_num<NUM, (TEAM == 0 && !POISSON && !AFFINE && !EXTRA && NUM == 0)>(nm, gv, m2.levels, sm.ml, fl, lane, g, wp2, act); }
 #endif
-		encode_num<NUM, (TEAM == 0 && !POISSON && !AFFINE && !EXTRA && NUM == 0)>(nm, gv, m2.levels, sm.ml, fl, lane, g, wpos, act); // (four record levels in flight: the hybrid instantiation has the registers)
+		encode_num<NUM, (TEAM == 0 && !POISSON && !AFFINE && !EXTRA && NUM == 0), !NRS_OPT_NOZERO>(nm, gv, m2.levels, sm.ml, fl, lane, g, wpos, act); // (four record levels in flight: the hybrid instantiation has the registers; features of idle lanes are never looked at: not zeroed)
 		// NRS_OPT_EARLY_MARCH: the walk to the NEXT sample does not depend on the network, and its first step is nearly always its last (the next
 		// sample of a ray inside the object stands in an occupied cell).  The bitfield word that first test needs is requested HERE, in front of the
 		// MLPs, and handed to march_to_occupied behind the compositing: one memory round trip less on the round's dependency chain.

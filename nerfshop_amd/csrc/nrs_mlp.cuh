@@ -323,13 +323,15 @@ __device__ __forceinline__ void issue_level(const GridView& gv, const LevelParam
 	else if (KIND == KIND_HASHED) issue_gathers<true>(gv, lp, c, v);
 	else issue_gathers<false>(gv, lp, c, v);
 }
-__device__ __forceinline__ uint32_t zero_if(bool cond, uint32_t v) { return cond ? 0u : v; }
+// (ZERO = false: the caller never looks at the features of its idle lanes -- the render kernel's rounds -- and the select per level is saved)
+template <bool ZERO = true>
+__device__ __forceinline__ uint32_t zero_if(bool cond, uint32_t v) { return ZERO && cond ? 0u : v; }
 
 // TWO levels (an even one and the odd one after it) of ONE sample, both of kind KIND.  All loads of both levels are issued before the
 // first is consumed: a round is a chain of dependent memory round trips, and when few waves are left on a CU (the end of a frame)
 // its latency, not its throughput, sets the frame time.  Idle lanes gather for position 0 (one shared cache line) so that the code
 // stays branch-free; their result is zeroed.
-template <int KIND, bool NETACC = false>
+template <int KIND, bool NETACC = false, bool ZERO = true>
 __device__ __forceinline__ void level_eval_two(const GridView& gv, const LevelParams& lp0, const LevelParams& lp1, f3 pos, bool act, uint32_t& f0, uint32_t& f1) {
 	const f3 q = act ? pos : mk3(0.f, 0.f, 0.f);
 	const bool incube = KIND == KIND_RECORD || KIND == KIND_SPARSE; // (record kinds are only chosen for waves whose samples all lie in [0,1]^3)
@@ -345,12 +347,12 @@ __device__ __forceinline__ void level_eval_two(const GridView& gv, const LevelPa
 			// not be hashed (a small dense budget leaves dense levels to the sparse records): those lanes take the exact dense index.
 			f0 = sparse_fallback<NETACC>(gv, lp0, c0, b0);
 			f1 = sparse_fallback<NETACC>(gv, lp1, c1, b1);
-			f0 = zero_if(!act, f0);
-			f1 = zero_if(!act, f1);
+			f0 = zero_if<ZERO>(!act, f0);
+			f1 = zero_if<ZERO>(!act, f1);
 			return;
 		}
-		f0 = zero_if(!act, interpolate<NETACC>(c0, v0));
-		f1 = zero_if(!act, interpolate<NETACC>(c1, v1));
+		f0 = zero_if<ZERO>(!act, interpolate<NETACC>(c0, v0));
+		f1 = zero_if<ZERO>(!act, interpolate<NETACC>(c1, v1));
 		return;
 	}
 	if (KIND == KIND_DENSE && __builtin_expect(__any(dense_needs_slow(lp0, c0) || dense_needs_slow(lp1, c1)), 0)) { // exact tcnn wrap for samples outside [0,1)^3: rare
@@ -363,8 +365,8 @@ __device__ __forceinline__ void level_eval_two(const GridView& gv, const LevelPa
 		f0 = interpolate<NETACC>(c0, v0);
 		f1 = interpolate<NETACC>(c1, v1);
 	}
-	f0 = zero_if(!act, f0);
-	f1 = zero_if(!act, f1);
+	f0 = zero_if<ZERO>(!act, f0);
+	f1 = zero_if<ZERO>(!act, f1);
 }
 // FOUR record levels (two consecutive pairs) of one sample with all their loads in flight at once: a round is a chain of dependent memory round
 // trips and the gather is eight of them; the twelve record levels then cost three trips instead of six.  The price is registers (32 loaded dwords
@@ -373,7 +375,7 @@ __device__ __forceinline__ void level_eval_two(const GridView& gv, const LevelPa
 #ifndef NRS_OPT_QUADS
 #define NRS_OPT_QUADS 1
 #endif
-template <bool NETACC = false>
+template <bool NETACC = false, bool ZERO = true>
 __device__ __forceinline__ void record_eval_four(const GridView& gv, const LevelParams& lp0, const LevelParams& lp1, const LevelParams& lp2, const LevelParams& lp3, f3 pos, bool act,
                                                  uint32_t& f0, uint32_t& f1, uint32_t& f2, uint32_t& f3_) {
 	f3 q = act ? pos : mk3(0.f, 0.f, 0.f);
@@ -383,15 +385,15 @@ __device__ __forceinline__ void record_eval_four(const GridView& gv, const Level
 	issue_record_loads(gv, lp2, cell_coords_incube(lp2, q), v2);
 	issue_record_loads(gv, lp3, cell_coords_incube(lp3, q), v3);
 	asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z)); // the weights below are recomputed, not carried across the loads
-	f0 = zero_if(!act, interpolate<NETACC>(cell_coords_incube(lp0, q), v0));
-	f1 = zero_if(!act, interpolate<NETACC>(cell_coords_incube(lp1, q), v1));
-	f2 = zero_if(!act, interpolate<NETACC>(cell_coords_incube(lp2, q), v2));
-	f3_ = zero_if(!act, interpolate<NETACC>(cell_coords_incube(lp3, q), v3));
+	f0 = zero_if<ZERO>(!act, interpolate<NETACC>(cell_coords_incube(lp0, q), v0));
+	f1 = zero_if<ZERO>(!act, interpolate<NETACC>(cell_coords_incube(lp1, q), v1));
+	f2 = zero_if<ZERO>(!act, interpolate<NETACC>(cell_coords_incube(lp2, q), v2));
+	f3_ = zero_if<ZERO>(!act, interpolate<NETACC>(cell_coords_incube(lp3, q), v3));
 }
 
 // One level of one sample, kind decided at run time (wave-uniform): the pairs whose two levels are of different kinds (the one
 // dense | hashed pair of a model without cell records, a records | no-records boundary at an odd level) come here, level after level.
-template <bool NETACC = false>
+template <bool NETACC = false, bool ZERO = true>
 __device__ __forceinline__ uint32_t level_eval_one(const GridView& gv, const LevelParams& lp, bool use_record, f3 pos, bool act) {
 	const f3 q = act ? pos : mk3(0.f, 0.f, 0.f);
 	const CellCoords c = cell_coords(lp, q);
@@ -409,7 +411,7 @@ __device__ __forceinline__ uint32_t level_eval_one(const GridView& gv, const Lev
 		issue_level<KIND_DENSE>(gv, lp, c, v);
 		f = interpolate<NETACC>(c, v);
 	}
-	return zero_if(!act, f);
+	return zero_if<ZERO>(!act, f);
 }
 
 // All 16 levels of the lane's OWN sample -> the wave's feature slab, two levels (2 it, 2 it + 1) per iteration.
@@ -420,7 +422,7 @@ __device__ __forceinline__ uint32_t level_eval_one(const GridView& gv, const Lev
 // same bits as before: the arithmetic per (sample, level) did not change.  The slab layout the MLP reads is unchanged too:
 // feat[it][0][l] = level 2 it + g(l) of lane l's sample, feat[it][1][l] = the same level of lane (l ^ 32)'s sample; so the level
 // of the lane's own parity goes to [0][lane] and the other one to [1][lane ^ 32] (a conflict-free permutation of the banks).
-template <bool NETACC = false, bool QUADS = false>
+template <bool NETACC = false, bool QUADS = false, bool ZERO = true>
 __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelParams* __restrict__ lv, const ModelLds& ml, FeatLds& fl, int lane, int g, f3 pos, bool act) {
 	// the records cover [0,1]^3; a wave with a sample outside it (a warped sample of an edit, rarely) gathers the native way
 	const bool outside = __any(act && outside_unit_cube(pos));
@@ -434,7 +436,7 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 		const uint32_t kind = __builtin_amdgcn_readfirstlane(kinds[it]);
 		if (NRS_OPT_QUADS && QUADS && kind == KIND_RECORD && it + 1 < 8 && __builtin_amdgcn_readfirstlane(kinds[it + 1]) == KIND_RECORD) {
 			uint32_t f0, f1, f2, f3_;
-			record_eval_four<NETACC>(gv, lp0, lp1, lv[2 * it + 2], lv[2 * it + 3], pos, act, f0, f1, f2, f3_);
+			record_eval_four<NETACC, ZERO>(gv, lp0, lp1, lv[2 * it + 2], lv[2 * it + 3], pos, act, f0, f1, f2, f3_);
 			fl.feat[it][0][lane] = g ? f1 : f0;
 			fl.feat[it][1][lane ^ 32] = g ? f0 : f1;
 			fl.feat[it + 1][0][lane] = g ? f3_ : f2;
@@ -443,13 +445,13 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 			continue;
 		}
 		uint32_t f0, f1;
-		if (kind == KIND_RECORD) level_eval_two<KIND_RECORD, NETACC>(gv, lp0, lp1, pos, act, f0, f1);
-		else if (kind == KIND_HASHED) level_eval_two<KIND_HASHED, NETACC>(gv, lp0, lp1, pos, act, f0, f1);
-		else if (kind == KIND_DENSE) level_eval_two<KIND_DENSE, NETACC>(gv, lp0, lp1, pos, act, f0, f1);
-		else if (kind == KIND_SPARSE) level_eval_two<KIND_SPARSE, NETACC>(gv, lp0, lp1, pos, act, f0, f1);
+		if (kind == KIND_RECORD) level_eval_two<KIND_RECORD, NETACC, ZERO>(gv, lp0, lp1, pos, act, f0, f1);
+		else if (kind == KIND_HASHED) level_eval_two<KIND_HASHED, NETACC, ZERO>(gv, lp0, lp1, pos, act, f0, f1);
+		else if (kind == KIND_DENSE) level_eval_two<KIND_DENSE, NETACC, ZERO>(gv, lp0, lp1, pos, act, f0, f1);
+		else if (kind == KIND_SPARSE) level_eval_two<KIND_SPARSE, NETACC, ZERO>(gv, lp0, lp1, pos, act, f0, f1);
 		else {
-			f0 = level_eval_one<NETACC>(gv, lp0, !outside && !one_line && lp0.cached == 1u, pos, act);
-			f1 = level_eval_one<NETACC>(gv, lp1, !outside && !one_line && lp1.cached == 1u, pos, act);
+			f0 = level_eval_one<NETACC, ZERO>(gv, lp0, !outside && !one_line && lp0.cached == 1u, pos, act);
+			f1 = level_eval_one<NETACC, ZERO>(gv, lp1, !outside && !one_line && lp1.cached == 1u, pos, act);
 		}
 		fl.feat[it][0][lane] = g ? f1 : f0;
 		fl.feat[it][1][lane ^ 32] = g ? f0 : f1;
@@ -631,10 +633,10 @@ __device__ __forceinline__ half8 rgb_mlp(const half8* lds_w, int lane, half8 din
 // tiny-cuda-nn's roundings as a template value: NUM >= 0 fixes them at compile time (bit 0 grid accumulation in network precision, bit 1 fp16 MLP
 // accumulators), kNumRuntime reads them from `nm` (DeviceModel::numerics, wave-uniform) -- both flavours compiled in, one scalar branch.
 constexpr int kNumRuntime = -1;
-template <int NUM, bool QUADS = false>
+template <int NUM, bool QUADS = false, bool ZERO = true>
 __device__ __forceinline__ void encode_num(uint32_t nm, const GridView& gv, const LevelParams* __restrict__ lv, const ModelLds& ml, FeatLds& fl, int lane, int g, f3 pos, bool act) {
-	if (NUM == kNumRuntime ? (nm & 1u) != 0u : (NUM & 1) != 0) encode_to_lds<true, QUADS>(gv, lv, ml, fl, lane, g, pos, act);
-	else encode_to_lds<false, QUADS>(gv, lv, ml, fl, lane, g, pos, act);
+	if (NUM == kNumRuntime ? (nm & 1u) != 0u : (NUM & 1) != 0) encode_to_lds<true, QUADS, ZERO>(gv, lv, ml, fl, lane, g, pos, act);
+	else encode_to_lds<false, QUADS, ZERO>(gv, lv, ml, fl, lane, g, pos, act);
 }
 template <int NUM>
 __device__ __forceinline__ half8 density_mlp_num(uint32_t nm, const half8* lds_w, int lane, half8 x0, half8 x1) {
