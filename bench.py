@@ -160,7 +160,7 @@ def live_traffic(workload, width, height):
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "t", "--", sys.executable, os.path.abspath(__file__),
                    "--workload", workload, "--steps", "8", "--warmup", "0", "--no-cpu-baseline", "--no-extra", "--width", str(width), "--height", str(height)]
             env = dict(os.environ, NRS_BENCH_LIVE_TRAFFIC="0", TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
             vals = []
