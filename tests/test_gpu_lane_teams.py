@@ -18,7 +18,7 @@ def _params(rig, w, h, az, **fields):
 def _render_all(rig, p):
     out = {}
     try:
-        for team in (1, 2, 4, -1, -2, -3, 0):
+        for team in (1, 2, 4, -1, -2, -3, -4, 0):
             rig.ctx.set_lane_teams(team)
             out[team] = rig.render(p)
     finally:
@@ -74,11 +74,11 @@ def test_teams_on_tiles(rig):
     rig.use_edit(True)
     try:
         for first, stride in ((0, 8), (3, 8), (1, 4)):
-            p = _params(rig, 640, 360, 45.0, tile_size=64, tile_first=first, tile_stride=stride)
+            p = _params(rig, 640, 360, 45.0, tile_size=64, tile_first=first, tile_stride=stride)  # (32-pixel tiles, the bench's: test_teams_on_small_tiles)
             torch = rig.torch
             got = {}
             try:
-                for team in (1, 2, 4, -2, 0):
+                for team in (1, 2, 4, -2, -3, -4, 0):
                     rig.ctx.set_lane_teams(team)
                     from nerfshop_amd import _abi
                     import ctypes as C
@@ -91,7 +91,7 @@ def test_teams_on_tiles(rig):
             finally:
                 rig.ctx.set_lane_teams(0)
             assert got[1][2] > 0
-            for team in (2, 4, -2, 0):
+            for team in (2, 4, -2, -3, -4, 0):
                 assert np.array_equal(got[team][0].view(np.uint32), got[1][0].view(np.uint32)), (first, stride, team)
                 assert np.array_equal(got[team][1].view(np.uint32), got[1][1].view(np.uint32)) and got[team][2] == got[1][2]
     finally:
@@ -135,6 +135,31 @@ def test_odd_resolutions(rig, size):
     for team, (frame, depth, steps, stats) in out.items():
         assert np.array_equal(frame.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(depth.view(np.uint32), ref[1].view(np.uint32)), (size, team)
         assert np.array_equal(steps, ref[2]) and stats.n_samples == ref[3].n_samples and stats.n_rays_alive == ref[3].n_rays_alive, (size, team)
+
+
+def test_teams_on_small_tiles(rig):
+    """32-pixel tiles (bench.py's tile size) of a 1/8 and a 1/2 share, every schedule against one lane per ray"""
+    import ctypes as C
+    from nerfshop_amd import _abi
+    torch = rig.torch
+    for first, stride in ((5, 8), (1, 2)):
+        p = _params(rig, 800, 450, 100.0, tile_size=32, tile_first=first, tile_stride=stride)
+        owned = _abi.load().nrs_render_owned_tiles(C.byref(p))
+        got = {}
+        try:
+            for team in (1, 2, 4, -2, -3, -4, 0):
+                rig.ctx.set_lane_teams(team)
+                frame = torch.zeros((owned, 32, 32, 4), dtype=torch.float32, device="cuda:0")
+                depth = torch.zeros((owned, 32, 32), dtype=torch.float32, device="cuda:0")
+                st = rig.testbed.render_with_params(rig.net, p, frame, depth, None, None, want_stats=True)
+                torch.cuda.synchronize()
+                got[team] = (frame.cpu().numpy(), depth.cpu().numpy(), st.n_samples)
+        finally:
+            rig.ctx.set_lane_teams(0)
+        assert got[1][2] > 0
+        for team in (2, 4, -2, -3, -4, 0):
+            assert np.array_equal(got[team][0].view(np.uint32), got[1][0].view(np.uint32)), (first, stride, team)
+            assert np.array_equal(got[team][1].view(np.uint32), got[1][1].view(np.uint32)) and got[team][2] == got[1][2]
 
 
 def test_bad_team_size_is_refused(rig):
