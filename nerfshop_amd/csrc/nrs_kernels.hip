@@ -76,7 +76,17 @@ struct RenderSmem {
 // ~18 ns each (an all-miss 1080p frame, 32 400 packets, took 0.57 ms for that reason alone), so the waves of a workgroup
 // share a chunk of kQueueChunk packets held in LDS and only the wave that finds the chunk used up goes to the global
 // counter.  State word: low half = next packet of the chunk, high half = its end; bit 31 of the low half = queue dry.
-constexpr uint32_t kQueueChunk = 8;
+// Round 3: kQueueChunk 8 -> 2.  With 64-pixel packets a chunk of 8 is 200 rays that only one workgroup can see, and its 8 waves march through neighbouring
+// packets in step; chunks of 16 / 8 / 4 / 2 / 1: 10.0 / 11.2 / 11.8 / 12.0 / 11.7 Gsamples/s on lego + cage, 8.4 / 9.6 / 10.3 / 10.6 / 10.8 on the varied scene, a 1/8 share
+// 0.509 (8) / 0.494 / 0.496 / 0.532 ms (chunks of 1 pay the atomics: 16 640 of them in half a millisecond); shrinking chunks towards the end of the queue only
+// ("guided") was no better than a constant 4.
+#ifndef NRS_FULL_GEN
+#define NRS_FULL_GEN 56u // small-launch schedule with 64-pixel packets: pending rays from which a generation runs one lane per ray
+#endif
+#ifndef NRS_QUEUE_CHUNK
+#define NRS_QUEUE_CHUNK 2
+#endif
+constexpr uint32_t kQueueChunk = NRS_QUEUE_CHUNK;
 constexpr uint32_t kNoPacket = 0xffffffffu;
 __device__ __forceinline__ uint32_t claim_packet(unsigned long long* state, uint32_t* global_next, uint32_t n_packets, int lane) {
 	uint32_t result = kNoPacket;
@@ -87,11 +97,12 @@ __device__ __forceinline__ uint32_t claim_packet(unsigned long long* state, uint
 			if (cur & 0x80000000u) break; // dry
 			if (cur < end) { result = cur; break; }
 			if (cur == end) { // the first wave past the end fetches the next chunk (and takes its first packet)
-				const uint32_t base = atomicAdd(global_next, kQueueChunk);
+				const uint32_t chunk = kQueueChunk;
+				const uint32_t base = atomicAdd(global_next, chunk);
 				if (base >= n_packets) {
 					atomicExch(state, 0x80000000ull);
 				} else {
-					const uint32_t e = min(base + kQueueChunk, n_packets);
+					const uint32_t e = min(base + chunk, n_packets);
 					atomicExch(state, ((unsigned long long)e << 32) | (unsigned long long)(base + 1u));
 					result = base;
 				}
@@ -459,7 +470,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			if (TEAM == 0) { // hybrid: full generations until the tail packets, then as many lanes per ray as the pending rays allow
 				// (a launch of tail packets only runs one lane per ray only where it is large -- 64-pixel packets -- and the wave can fill its lanes:
 				// otherwise more than 32 pending rays = 32 now as teams of two, the rest in the next generation or handed to a waiting sibling)
-				gen_t = tail_seen ? (ring_count > 32u && (!a1.all_tail || (a1.fill_lanes == 1u && ring_count >= 56u)) ? 1u : (ring_count > 16u ? 2u : 4u)) : 1u;
+				gen_t = tail_seen ? (ring_count > 32u && (!a1.all_tail || (a1.fill_lanes == 1u && ring_count >= NRS_FULL_GEN)) ? 1u : (ring_count > 16u ? 2u : 4u)) : 1u;
 				tk = lane & (int)(gen_t - 1u);
 				team_base = lane & ~(int)(gen_t - 1u);
 			}
