@@ -80,6 +80,9 @@ struct RenderSmem {
 // packets in step; chunks of 16 / 8 / 4 / 2 / 1: 10.0 / 11.2 / 11.8 / 12.0 / 11.7 Gsamples/s on lego + cage, 8.4 / 9.6 / 10.3 / 10.6 / 10.8 on the varied scene, a 1/8 share
 // 0.509 (8) / 0.494 / 0.496 / 0.532 ms (chunks of 1 pay the atomics: 16 640 of them in half a millisecond); shrinking chunks towards the end of the queue only
 // ("guided") was no better than a constant 4.
+#ifndef NRS_GIVE_MIN
+#define NRS_GIVE_MIN 16u // ray hand-over: a wave gives half of the rays it holds in lanes when it holds more than this many
+#endif
 #ifndef NRS_FULL_GEN
 #define NRS_FULL_GEN 56u // small-launch schedule with 64-pixel packets: pending rays from which a generation runs one lane per ray
 #endif
@@ -336,7 +339,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			} else if (ring_count == 0u) {
 				const unsigned long long lead_mask = __ballot(have && tk == 0);
 				const uint32_t live = (uint32_t)__popcll(lead_mask);
-				const uint32_t target = live > 16u ? claim_waiting_wave() : 0xffffffffu;
+				const uint32_t target = live > NRS_GIVE_MIN ? claim_waiting_wave() : 0xffffffffu;
 				if (target != 0xffffffffu) {
 					const uint32_t keep = (live + 1u) / 2u, give = live - keep;
 					const bool team_live = ((lead_mask >> team_base) & 1ull) != 0ull;
