@@ -246,8 +246,7 @@ int  nrs_ctx_device_info(const nrs_ctx* ctx, char* name_out, size_t name_len, in
  * otherwise be one ray's latency chain; one lane per ray for launches that fill the GPU, with teams only for the last
  * third of the frame's work queue ("hybrid", whole-image mode).  1 / 2 / 4 force a size for every ray, -1 forces the
  * hybrid schedule, -2 / -3 / -4 the small-launch schedule (team size chosen per generation from the rays a wave has pending) with packets of 16 / 32 / 64 pixels.
- * Since round 3 the automatic choice is the small-launch schedule with packets sized by the launch (every tiled launch, whole images up to 6 rays per lane) and the hybrid
- * schedule beyond.  Pixel values, depth, step counts and statistics do not depend on it (tests/test_gpu_lane_teams.py). */
+ * Since round 3 the automatic choice is the small-launch schedule with packets sized by the launch; the hybrid schedule runs only when forced.  Pixel values, depth, step counts and statistics do not depend on it (tests/test_gpu_lane_teams.py). */
 int  nrs_ctx_set_lane_teams(nrs_ctx* ctx, int lanes_per_ray);
 /* Ray hand-over (on by default): in whole-image and small-launch ("hybrid") schedules a wave that has run out of work takes rays from a sibling wave of its
  * workgroup -- rays that wait in the sibling's ring for its next generation, or half of the rays it holds in lanes (both halves then run with more lanes per

@@ -1347,10 +1347,10 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		uint32_t fill_lanes = rays_per_lane <= 0.6 ? 4u : (rays_per_lane <= 2.6 ? 2u : 1u);
 		// the fill runs once per pixel and lane on it: keep it to ~16 passes over the GPU (an all-miss 1080p frame is 8)
 		while (fill_lanes > 1 && (double)fill_lanes * (double)a.pixels_owned * (double)(1u + busy) > 17.0 * 64.0 * 16.0 * (double)ctx->n_cus) fill_lanes >>= 1;
-		// Whole images with many rays per lane take the hybrid schedule (64-ray generations at one lane per ray for the bulk of the queue).  Between 2.8 and 6
-		// rays per lane the two are close and the scene decides -- bench frames, Gsamples/s hybrid / 64-pixel packets: lego + cage 10.8 / 11.0, lego 12.1 / 12.4,
-		// varied opacity 9.7 / 9.3, and at 7.9 rays per lane (aabb-16, every pixel hits) 4.76 / 4.65.
-		const bool small_launch = p->tile_size != 0 || rays_per_lane <= 6.0;
+		// The hybrid schedule (64-ray generations at one lane per ray for the bulk of the queue, lane teams for its tail) was the choice for whole images with many
+		// rays per lane until the queue's chunks went from 8 to 2 packets; since then the small-launch schedule wins there too -- bench frames, Gsamples/s hybrid /
+		// 64-pixel packets: lego + cage 10.8 / 12.0, varied opacity 10.2 / 10.6, aabb-16 (7.9 rays per lane) 4.79 / 4.87 -- and hybrid runs only when forced (-1).
+		const bool small_launch = true;
 		uint32_t team = 1; // fixed lanes per ray: only when forced
 		if (forced == 1 || forced == 2 || forced == 4) team = (uint32_t)forced;
 		if (forced == -1) team = 1;
