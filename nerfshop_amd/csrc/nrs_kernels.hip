@@ -6,7 +6,11 @@
 //                        input / network output arrays exist in HBM; the only traffic is the hash-table gather, the
 //                        occupancy bitfield, the cage tables and one float4 per hit pixel.
 //                        Template parameter TEAM: 1 lane per ray, 2 / 4 lanes per ray (lane teams, for launches that cannot
-//                        fill the GPU), or 0 = hybrid (teams only for the tail of the frame's queue).
+//                        fill the GPU), or 0 = every generation sizes its teams by the rays its wave has pending: the
+//                        small-launch schedule (packets of 16 / 32 / 64 pixels by the size of the launch: the automatic choice
+//                        since round 3) and the hybrid schedule (one lane per ray for the bulk of a whole image's queue, teams
+//                        for its tail).  TEAM == 0 waves re-team when a generation has thinned out, test a team's next positions
+//                        in parallel, and hand rays over to waves of their workgroup that have run out of work.
 //   network_kernel       NerfNetwork::inference_mixed_precision / density / hash-grid encode on caller batches.
 //   cell_records_kernel  the cell-record cache of the coarse hash-grid levels (nrs_model_set_cell_cache).
 //   grid_eval_kernel     get_density_on_grid / get_rgba_on_grid; grid_refresh / grid_ema: the occupancy refresh.
