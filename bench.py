@@ -139,11 +139,23 @@ def measured_traffic(workload):
         return None, None
 
 
+def render_kernel_counter_values(csv_paths, counter):
+    """Per-dispatch values of one PMC counter for the render kernel from rocprofv3's `*_counter_collection.csv` files (columns Kernel_Name, Counter_Name,
+    Counter_Value; one row per dispatch and counter)."""
+    import csv
+    vals = []
+    for path in csv_paths:
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if "render_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                    vals.append(float(row["Counter_Value"]))
+    return vals
+
+
 def live_traffic(workload, width, height):
     """HBM bytes per render_kernel launch measured NOW: two rocprofv3 PMC passes (FETCH_SIZE, then WRITE_SIZE -- separate passes, --kernel-trace only, as
     MI355X_MICROARCH.md prescribes) over a short child run of this script (8 steps = the 8 bench views; its render_kernel dispatches are averaged), corrected
     as that guide says for gfx950 (FETCH_SIZE tallies the 128-byte requests at 64 bytes: doubled).  Returns (bytes, description) or (None, why)."""
-    import csv
     import glob
     import shutil
     import subprocess
@@ -163,11 +175,7 @@ def live_traffic(workload, width, height):
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
-            vals = []
-            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(path)):
-                    if "render_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                        vals.append(float(row["Counter_Value"]))
+            vals = render_kernel_counter_values(glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True), counter)
             if not vals:
                 return None, f"no render_kernel rows in the {counter} pass"
             kb[counter] = sum(vals) / len(vals)
