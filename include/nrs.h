@@ -48,7 +48,9 @@
 extern "C" {
 #endif
 
-#define NRS_ABI_VERSION 2   /* 2: nrs_render_params grew dof / slice_plane_z / depth_scale / show_accel (appended: a v1 struct zero-extended means the same) */
+#define NRS_ABI_VERSION 3   /* 3: nrs_render_params starts with struct_size (every entry point that takes the struct refuses a size other than its own: a client
+                             * built against another header is turned away instead of being read past its struct); visualized_layer / _dimension appended.
+                             * 2: dof / slice_plane_z / depth_scale / show_accel, camera model, background, glow */
 
 typedef enum nrs_status {
 	NRS_OK = 0,
@@ -159,6 +161,8 @@ typedef struct nrs_affine_duplication {
 
 /* Arguments + implicit Testbed members of render_nerf (SURVEY 8b "Renderer"). */
 typedef struct nrs_render_params {
+	uint32_t struct_size;         /* = sizeof(nrs_render_params) of the header the caller was built with (NRS_RENDER_PARAMS_INIT); anything else is
+	                               * NRS_ERR_INVALID_ARG -- the library never reads a struct of another layout */
 	int32_t  resolution[2];       /* render_buffer.in_resolution() */
 	float    focal_length[2];
 	float    camera_matrix0[12];  /* 3x4, Eigen column-major: col0,col1,col2 = axes, col3 = origin */
@@ -208,7 +212,15 @@ typedef struct nrs_render_params {
 	uint32_t glow_mode;           /* m_nerf.m_glow_mode: composite_kernel_nerf's grid / cut-line overlay (:806-903); bits 1 green grid, 2 cut line, 4 mask to
 	                               * alpha, 8 radial, 16 grid only.  0 = off (the reference's default) */
 	float    glow_y_cutoff;       /* m_nerf.m_glow_y_cutoff */
+	/* ---- ABI 3: render mode EncodingVis (render_mode = m_visualized_dimension > -1 ? EncodingVis : m_render_mode, testbed_nerf.cu:3072) ---- */
+	uint32_t visualized_layer;     /* m_visualized_layer: 0 = hash-grid output (32 wide), 1 = density MLP hidden layer (64), 2 = rgb network input
+	                                * (16 density outputs | 16 SH coefficients), 3 / 4 = rgb MLP hidden layers (64); NerfNetworkFull::forward_activations,
+	                                * nerf_network_full.h:523-534 */
+	uint32_t visualized_dimension; /* m_visualized_dimension (>= 0): the unit of that layer whose activation is shown (< NerfNetworkFull::width(layer), :507-517) */
 } nrs_render_params;
+/* envmap / distortion map contract: d_envmap holds envmap_resolution[0] x envmap_resolution[1] float4 texels, d_distortion_map
+ * distortion_resolution[0] x distortion_resolution[1] float2 texels (both >= 1 x 1, row-major); every lookup clamps (y; the envmap wraps in x) to that extent. */
+#define NRS_RENDER_PARAMS_INIT { (uint32_t)sizeof(nrs_render_params) }
 
 typedef struct nrs_render_stats {
 	uint64_t n_samples;      /* network-evaluated live samples (sum of per-ray n_steps)            */

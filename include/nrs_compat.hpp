@@ -160,8 +160,9 @@ public:
 	bool m_snap_to_pixel_centers = true;
 	bool m_enable_edits = true;
 	nrs_render_mode m_render_mode = NRS_RENDER_SHADE;
+	int m_visualized_layer = 0, m_visualized_dimension = -1; // testbed.h: > -1 selects render mode EncodingVis (testbed_nerf.cu:3072)
 	std::vector<const EditOperator*> m_edit_operators; // NerfTracer::m_edit_operators (testbed.h:237), applied last-to-first
-	bool m_poisson_target = false;                    // NerfTracer::m_poisson_target (passed to composite_kernel_nerf, testbed_nerf.cu:2951)
+	bool m_poisson_target = true;                     // NerfTracer::m_poisson_target (testbed.h:219: true, its checkbox is commented out; passed to composite_kernel_nerf, testbed_nerf.cu:2983)
 	int m_show_accel = -1;                            // m_nerf.show_accel: >= 0 forces that cascade as the minimum while marching (:2751, :2849), makes
 	                                                  // every sample opaque (:788-790) and colours the occupancy cells in render mode Positions (:911-920)
 	float m_dof = 0.f;                                // aperture of pixel_to_ray's thin-lens branch (common_device.cuh:285-293)
@@ -204,7 +205,7 @@ public:
 	void render_nerf(NerfNetwork& network, RenderBuffer& render_buffer, const int /*max_res*/[2], const float focal_length[2],
 	                 const float camera_matrix0[12], const float camera_matrix1[12], const float rolling_shutter[4], const float screen_center[2],
 	                 bool apply_operators, void* stream, nrs_render_stats* stats = nullptr) {
-		nrs_render_params p{};
+		nrs_render_params p = NRS_RENDER_PARAMS_INIT;
 		p.resolution[0] = render_buffer.width;
 		p.resolution[1] = render_buffer.height;
 		for (int i = 0; i < 2; ++i) { p.focal_length[i] = focal_length[i]; p.screen_center[i] = screen_center[i]; }
@@ -215,7 +216,9 @@ public:
 		p.snap_to_pixel_centers = m_snap_to_pixel_centers;
 		p.min_transmittance = m_nerf.rendering_min_transmittance;
 		p.cone_angle_constant = m_nerf.cone_angle_constant;
-		p.render_mode = m_render_mode;
+		p.render_mode = m_visualized_dimension > -1 ? (uint32_t)NRS_RENDER_ENCODING_VIS : m_render_mode; // testbed_nerf.cu:3072
+		p.visualized_layer = (uint32_t)m_visualized_layer;
+		p.visualized_dimension = m_visualized_dimension > -1 ? (uint32_t)m_visualized_dimension : 0u;
 		p.linear_colors = m_nerf.training_linear_colors;
 		p.apply_operators = apply_operators && m_enable_edits;
 		p.poisson_target = m_poisson_target ? 1u : 0u;

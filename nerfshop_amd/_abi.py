@@ -18,6 +18,7 @@ N_LUT_CELLS = GRID_VOLUME * GRID_CASCADES
 
 ACT_NONE, ACT_RELU, ACT_LOGISTIC, ACT_EXPONENTIAL = 0, 1, 2, 3
 RENDER_AO, RENDER_SHADE, RENDER_NORMALS, RENDER_POSITIONS, RENDER_DEPTH, RENDER_DISTANCE, RENDER_STEPSIZE, RENDER_DISTORTION, RENDER_COST, RENDER_SLICE = range(10)
+RENDER_ENCODING_VIS = 11
 LAYOUT_PLANES, LAYOUT_INTERLEAVED = 0, 1
 
 
@@ -75,7 +76,9 @@ class AffineDuplicationOp(C.Structure):
 
 
 class RenderParams(C.Structure):
+    """nrs_render_params; struct_size is filled in on construction (NRS_RENDER_PARAMS_INIT)."""
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("resolution", C.c_int32 * 2),
         ("focal_length", C.c_float * 2),
         ("camera_matrix0", C.c_float * 12),
@@ -109,7 +112,13 @@ class RenderParams(C.Structure):
         ("d_envmap", C.c_void_p),
         ("glow_mode", C.c_uint32),
         ("glow_y_cutoff", C.c_float),
+        ("visualized_layer", C.c_uint32),
+        ("visualized_dimension", C.c_uint32),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(RenderParams)
 
 
 class RenderStats(C.Structure):

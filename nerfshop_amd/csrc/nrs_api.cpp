@@ -124,7 +124,15 @@ struct nrs_edit {
 // Marching parameters every ray-marching entry point hands to the kernels: min_mip indexes the 5-cascade bitfield (min_mip > 4 reads past
 // it and makes kGrid >> mip zero, i.e. a voxel walk without progress), a negative / non-finite cone angle breaks calc_dt's clamp, a
 // non-positive resolution divides by zero on the device.
+static int check_params_abi(const nrs_render_params* p, const char* who) {
+	// (nothing zero-extends a struct built against another header -- the size is the contract)
+	if (p->struct_size != (uint32_t)sizeof(nrs_render_params))
+		return fail(NRS_ERR_INVALID_ARG, std::string(who) + ": nrs_render_params.struct_size is " + std::to_string(p->struct_size) + ", this library's is " +
+		            std::to_string(sizeof(nrs_render_params)) + " (ABI " + std::to_string(NRS_ABI_VERSION) + "): initialise with NRS_RENDER_PARAMS_INIT from the same nrs.h");
+	return NRS_OK;
+}
 static int check_march_params(const nrs_render_params& p, const char* who) {
+	{ const int ac = check_params_abi(&p, who); if (ac != NRS_OK) return ac; }
 	if (p.resolution[0] <= 0 || p.resolution[1] <= 0 || p.resolution[0] > 65535 || p.resolution[1] > 65535)
 		return fail(NRS_ERR_INVALID_ARG, std::string(who) + ": resolution out of range (1..65535)");
 	if (p.min_mip > kCascades - 1) return fail(NRS_ERR_INVALID_ARG, std::string(who) + ": min_mip > 4 (the occupancy grid has 5 cascades)");
@@ -1224,11 +1232,11 @@ static int tile_geometry(const nrs_render_params& p, uint32_t team, uint32_t& ti
 	return NRS_OK;
 }
 uint32_t nrs_render_tile_pitch(const nrs_render_params* p) {
-	if (!p || p->resolution[0] <= 0 || p->tile_size == 0) return 0;
+	if (!p || p->struct_size != (uint32_t)sizeof(nrs_render_params) || p->resolution[0] <= 0 || p->tile_size == 0) return 0;
 	return tile_pitch((uint32_t)p->resolution[0], p->tile_size);
 }
 uint32_t nrs_render_owned_tiles(const nrs_render_params* p) {
-	if (!p || p->resolution[0] <= 0 || p->resolution[1] <= 0) return 0;
+	if (!p || p->struct_size != (uint32_t)sizeof(nrs_render_params) || p->resolution[0] <= 0 || p->resolution[1] <= 0) return 0;
 	uint32_t tx, owned, np, ppt;
 	if (tile_geometry(*p, 1, tx, owned, np, ppt) != NRS_OK) return 0;
 	return owned;
@@ -1354,16 +1362,20 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		uint32_t team = 1; // fixed lanes per ray: only when forced
 		if (forced == 1 || forced == 2 || forced == 4) team = (uint32_t)forced;
 		if (forced == -1) team = 1;
-		if (a.any_poisson || a.any_affine || a.extra) team = 1; // (those instantiations are built for one lane per ray)
+		// (the AffineDuplication / EXTRA / run-time-numerics membrane instantiations are built for one lane per ray; the membrane correction of cage edits
+		// alone runs the automatic schedule since round 4)
+		const bool poisson_teams = a.any_poisson && !a.any_affine && !a.extra && m->dm.numerics == 0u;
+		const bool one_lane_only = (a.any_poisson && !poisson_teams) || a.any_affine || a.extra;
+		if (one_lane_only || a.any_poisson) team = 1; // (fixed 2 / 4 lanes per ray exist for the default kernel only; a forced size leaves the membrane path on the catch-all)
 		static const bool log_teams = getenv("NRS_TEAM_LOG") != nullptr;
 		if (log_teams) fprintf(stderr, "[nrs team] pixels=%u hit_share=%.3f busy=%u rays/lane=%.3f small-launch=%d fill lanes=%u forced=%d\n", a.pixels_owned, hit_share, busy, rays_per_lane, (int)small_launch, fill_lanes, forced);
-		static const uint32_t tail_target = []() { const char* e = getenv("NRS_TAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)atoi(e) : 24u; }(); // 8 / 16 / 24 / 32 / 48: 8.92 / 8.91 / 9.11 / 9.01 / 8.47 Gsamples/s
+		static const uint32_t tail_target = []() { const char* e = getenv("NRS_TAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)std::min(atoi(e), 64) : 24u; }(); // (<= kRing - 64: the fill adds up to 64 rays per packet to a 128-entry ring) 8 / 16 / 24 / 32 / 48: 8.92 / 8.91 / 9.11 / 9.01 / 8.47 Gsamples/s
 		a.tail_target = tail_target;
 		static const uint32_t reteam = []() { const char* e = getenv("NRS_RETEAM"); return e ? (uint32_t)atoi(e) : 3u; }(); // bit 0: at the end of a wave's work, bit 1: whenever a tail generation has thinned out
 		a.reteam = reteam;
 		static const uint32_t steal = []() { const char* e = getenv("NRS_STEAL"); return e ? (uint32_t)atoi(e) : 1u; }();
 		a.steal = ctx->handover >= 0 ? (uint32_t)ctx->handover : steal;
-		if (((small_launch && !forced && hybrid_on) || forced == -2 || forced == -3 || forced == -4) && !a.any_poisson && !a.any_affine && !a.extra) {
+		if (((small_launch && !forced && hybrid_on) || forced == -2 || forced == -3 || forced == -4) && !one_lane_only) {
 			// few rays for the GPU: 4x4 packets only, and every generation takes ALL the rays its wave has pending with as many
 			// lanes per ray as fit (4 up to 16 rays, 2 up to 32), so that no wave is left with a second, nearly empty generation
 			// (1/8 share of the bench frame: 0.88 -> 0.82 ms).
@@ -1371,12 +1383,12 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 			a.all_tail = 1;
 			a.fill_lanes = forced == -4 ? 1u : (forced == -3 ? 2u : (forced == -2 ? 4u : fill_lanes));
 			NRS_TRY(tile_geometry(*p, a.fill_lanes, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x));
-			static const uint32_t all_tail_target = []() { const char* e = getenv("NRS_ALLTAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)atoi(e) : 16u; }();
+			static const uint32_t all_tail_target = []() { const char* e = getenv("NRS_ALLTAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)std::min(atoi(e), 64) : 16u; }(); // (<= kRing - 64, as above)
 			a.tail_target = all_tail_target;
 		} else if (team > 1 && (forced > 0 || p->tile_size != 0 || !hybrid_on)) {
 			a.team = team;
 			NRS_TRY(tile_geometry(*p, team, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x));
-		} else if (p->tile_size == 0 && !a.any_poisson && !a.any_affine && !a.extra && (forced == -1 || (!forced && hybrid_on))) {
+		} else if (p->tile_size == 0 && !a.any_poisson && !a.any_affine && !a.extra && (forced == -1 || (!forced && hybrid_on))) { // (the hybrid schedule: forced only)
 			// whole images with more rays than the small-launch schedule is for: hybrid (one lane per ray, lane teams for the tail of the queue)
 			// hybrid: every 3rd packet row leaves the 8x8 list and joins the end of the queue as 4x4 tail packets (packet_pixel_bulk/_tail);
 			// measured on 1080p lego + cage, every 2nd / 3rd / 4th / 6th / 8th / 16th row: 8.88 / 8.89 / 8.79 / 8.75 / 8.65 / 8.65 Gsamples/s
@@ -1463,6 +1475,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 int nrs_detile(nrs_ctx* ctx, void* stream, const nrs_render_params* p, uint32_t n_ranks, uint32_t tiles_per_rank_padded, const float* d_tiles,
                uint32_t channels, size_t rank_stride_floats, float* d_image) {
 	if (!ctx || !p || !d_tiles || !d_image) return fail(NRS_ERR_INVALID_ARG, "nrs_detile: NULL argument");
+	{ const int ac = check_params_abi(p, "nrs_detile"); if (ac != NRS_OK) return ac; }
 	if (p->tile_size == 0 || p->tile_size % 8 || n_ranks == 0 || channels == 0) return fail(NRS_ERR_INVALID_ARG, "nrs_detile: bad tiling");
 	const size_t dense = (size_t)tiles_per_rank_padded * p->tile_size * p->tile_size * channels;
 	if (rank_stride_floats == 0) rank_stride_floats = dense;

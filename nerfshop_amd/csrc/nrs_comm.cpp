@@ -51,6 +51,8 @@ Rccl& rccl() {
 			r.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
 			if (!r.lib) { r.error = std::string("NRS_RCCL_LIB: ") + dlerror(); return; }
 			r.path = over;
+			// (an override of the transport must not be silent -- a stale variable would otherwise only show in nrs_comm_info)
+			fprintf(stderr, "[nrs comm] NRS_RCCL_LIB is set: every collective of this process goes through %s instead of RCCL\n", over);
 		}
 		for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
 			if (r.lib) break;
@@ -143,6 +145,7 @@ void nrs_comm_destroy(nrs_comm* c) {
 int nrs_gather_tiles(nrs_ctx* ctx, nrs_comm* c, int root, const nrs_render_params* p, uint32_t tiles_per_rank_padded, const float* d_local, float* d_recv,
                      float* d_image, float* d_depth, void* stream) {
 	if (!ctx || !c || !p || !d_local) return fail(NRS_ERR_INVALID_ARG, "nrs_gather_tiles: NULL argument");
+	if (p->struct_size != (uint32_t)sizeof(nrs_render_params)) return fail(NRS_ERR_INVALID_ARG, "nrs_gather_tiles: nrs_render_params.struct_size does not match this library (NRS_RENDER_PARAMS_INIT)");
 	if (root < 0 || root >= c->n_ranks) return fail(NRS_ERR_INVALID_ARG, "nrs_gather_tiles: root out of range");
 	if (p->tile_size == 0 || p->tile_size % 8) return fail(NRS_ERR_INVALID_ARG, "nrs_gather_tiles: bad tiling");
 	if (c->rank == root && !d_recv) return fail(NRS_ERR_INVALID_ARG, "nrs_gather_tiles: the root needs a receive buffer");

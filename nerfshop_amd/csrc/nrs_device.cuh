@@ -738,50 +738,97 @@ __device__ __forceinline__ bool edit_warp(const DeviceEdit& e, bool with_dir, f3
 // sample position BEFORE map_rays (residuals live in deformed space), dir the un-warped view direction AFTER map_rays.
 // The barycentric interpolation of the 27 SH9RGB coefficients and the dot product with the SH basis are evaluated in the
 // reference's order, coefficient by coefficient, so no 27-float array is kept.  Outputs untouched when no tet contains it.
-__device__ __forceinline__ void poisson_residual_rgb(const DeviceEdit& e, f3 wpos0, f3 dir, float rgb[3], float& out_density, float& res_density) {
+#ifndef NRS_SH_GROUP
+#define NRS_SH_GROUP 2
+#endif
+#ifndef NRS_SH_OPAQUE
+#define NRS_SH_OPAQUE 0
+#endif
+// Two steps (round 4), so that the renderer can run the un-deformed network pass between them with only three values live: _find decides which tet of the
+// deformed mesh holds the sample and interpolates the two densities; _colour re-derives the barycentric weights of that tet (the same arithmetic: the same
+// bits) and evaluates the SH9 colour.
+__device__ __forceinline__ bool poisson_residual_find(const DeviceEdit& e, f3 wpos0, uint32_t& found_out, float& out_density, float& res_density) {
 	const f3 pos = unwarp_position(wpos0, e.aabb);
-	if (!box_contains(e.bbox, pos)) return;
+	if (!box_contains(e.bbox, pos)) return false;
 	const int level = mip_from_pos(pos);
 	const uint32_t cell = (uint32_t)level * kGridVol + cascaded_grid_idx_at(pos, (uint32_t)level);
 	const uint32_t found = scan_cell_for_tet(e, cell, pos);
-	if (found == 0xffffffffu) return;
+	if (found == 0xffffffffu) return false;
 	const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[found];
 	float bc[4];
 	{
 		const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), dd = ld3(e.verts, tv.w);
 		bary_tet(a, b, c, dd, pos, bc);
 	}
-	// SH basis, cn:222-240
-	const float fZ2 = dir.z * dir.z;
-	float pSH[9];
-	pSH[0] = 0.2820947917738781f;
-	pSH[2] = 0.4886025119029199f * dir.z;
-	pSH[6] = 0.9461746957575601f * fZ2 + -0.3153915652525201f;
-	const float fC0 = dir.x, fS0 = dir.y;
-	const float fTmpA = -0.48860251190292f;
-	pSH[3] = fTmpA * fC0; pSH[1] = fTmpA * fS0;
-	const float fTmpB = -1.092548430592079f * dir.z;
-	pSH[7] = fTmpB * fC0; pSH[5] = fTmpB * fS0;
-	const float fC1 = dir.x * fC0 - dir.y * fS0;
-	const float fS1 = dir.x * fS0 + dir.y * fC0;
-	const float fTmpC = 0.5462742152960395f;
-	pSH[8] = fTmpC * fC1; pSH[4] = fTmpC * fS1;
-	const float* s0 = e.shs + 27 * (size_t)tv.x;
-	const float* s1 = e.shs + 27 * (size_t)tv.y;
-	const float* s2 = e.shs + 27 * (size_t)tv.z;
-	const float* s3 = e.shs + 27 * (size_t)tv.w;
-	#pragma unroll 1 // one colour at a time: 36 coefficient loads in flight instead of 108 (the unrolled form costs the membrane instantiation a wave of occupancy)
-	for (int c = 0; c < 3; ++c) {
-		float q[9];
-		#pragma unroll
-		for (int k = 0; k < 9; ++k) q[k] = pSH[k] * (((bc[0] * s0[9 * c + k] + bc[1] * s1[9 * c + k]) + bc[2] * s2[9 * c + k]) + bc[3] * s3[9 * c + k]);
-		// pSH.dot(sh.block<9, 1>(0, c)): Eigen's unrolled 9-term reduction, 4 | 5 -> (2|2) | (2|(1|2))
-		rgb[c] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + (q[7] + q[8])));
-	}
 	const float lo = ((bc[0] * e.out_density[tv.x] + bc[1] * e.out_density[tv.y]) + bc[2] * e.out_density[tv.z]) + bc[3] * e.out_density[tv.w];
 	const float lr = ((bc[0] * e.res_density[tv.x] + bc[1] * e.res_density[tv.y]) + bc[2] * e.res_density[tv.z]) + bc[3] * e.res_density[tv.w];
 	out_density = e.residual_amplitude * lo;
 	res_density = e.residual_amplitude * lr;
+	found_out = found;
+	return true;
+}
+__device__ __forceinline__ void poisson_residual_colour(const DeviceEdit& e, uint32_t found, f3 wpos0, f3 dir, float rgb[3]) {
+	const f3 pos = unwarp_position(wpos0, e.aabb);
+	const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[found];
+	float bc[4];
+	{
+		const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), dd = ld3(e.verts, tv.w);
+		bary_tet(a, b, c, dd, pos, bc);
+	}
+	// The 4 x 27 coefficients are read through a buffer descriptor (wave-uniform base in scalar registers, one 32-bit offset per vertex, the coefficient in
+	// the instruction's immediate) and in small groups: the registers of a wave, not the latency of a few more round trips, are what this instantiation is
+	// short of (the kernel must fit the 128 VGPRs of the default launch shape).  NRS_SH_GROUP terms of the dot product are in flight at once.
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)e.shs, 0, 0x7fffffff, 0x00020000);
+	const uint32_t o0 = tv.x * 108u, o1 = tv.y * 108u, o2 = tv.z * 108u, o3 = tv.w * 108u; // byte offset of a vertex's 27 floats
+	#pragma unroll 1 // one colour at a time (the unrolled form holds all 108 coefficient loads in flight: 250 VGPRs)
+	for (int c = 0; c < 3; ++c) {
+		const int cb = c * 36;
+		// SH basis (evaluate_sh9, cn:222-240), each coefficient formed where it is used from an opaque copy of the direction: nine basis values kept across
+		// the colour loop are nine registers this instantiation does not have (the products are the reference's, term by term)
+		float dx = dir.x, dy = dir.y, dz = dir.z;
+#if NRS_SH_OPAQUE
+		asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dz));
+#endif
+		auto pSH = [&](int k) -> float {
+			switch (k) {
+				case 0: return 0.2820947917738781f;
+				case 1: return -0.48860251190292f * dy;                          // fTmpA * fS0
+				case 2: return 0.4886025119029199f * dz;
+				case 3: return -0.48860251190292f * dx;                          // fTmpA * fC0
+				case 4: return 0.5462742152960395f * (dx * dy + dy * dx);         // fTmpC * fS1
+				case 5: return (-1.092548430592079f * dz) * dy;                  // fTmpB * fS0
+				case 6: return 0.9461746957575601f * (dz * dz) + -0.3153915652525201f;
+				case 7: return (-1.092548430592079f * dz) * dx;                  // fTmpB * fC0
+				default: return 0.5462742152960395f * (dx * dx - dy * dy);       // fTmpC * fC1
+			}
+		};
+		// pSH.dot(sh.block<9, 1>(0, c)): Eigen's unrolled 9-term reduction, 4 | 5 -> (2|2) | (2|(1|2))
+		auto L = [&](uint32_t ov, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)ov, cb + 4 * k, 0)); };
+		auto term = [&](int k) { return pSH(k) * (((bc[0] * L(o0, k) + bc[1] * L(o1, k)) + bc[2] * L(o2, k)) + bc[3] * L(o3, k)); };
+#if NRS_SH_GROUP == 2
+		const float q0 = term(0), q1 = term(1); const float a01 = q0 + q1;
+		__builtin_amdgcn_sched_barrier(0);
+		const float q2 = term(2), q3 = term(3); const float lo4 = a01 + (q2 + q3);
+		__builtin_amdgcn_sched_barrier(0);
+		const float q4 = term(4), q5 = term(5); const float a45 = q4 + q5;
+		__builtin_amdgcn_sched_barrier(0);
+		const float q7 = term(7), q8 = term(8); const float a78 = q7 + q8;
+		__builtin_amdgcn_sched_barrier(0);
+		const float q6 = term(6);
+		rgb[c] = lo4 + (a45 + (q6 + a78));
+#else
+		const float q0 = term(0), q1 = term(1), q2 = term(2), q3 = term(3);
+		const float lo4 = (q0 + q1) + (q2 + q3);
+		__builtin_amdgcn_sched_barrier(0);
+		const float q4 = term(4), q5 = term(5), q6 = term(6), q7 = term(7), q8 = term(8);
+		rgb[c] = lo4 + ((q4 + q5) + (q6 + (q7 + q8)));
+#endif
+	}
+}
+// (the two steps in one call, for callers without anything in between)
+__device__ __forceinline__ void poisson_residual_rgb(const DeviceEdit& e, f3 wpos0, f3 dir, float rgb[3], float& out_density, float& res_density) {
+	uint32_t found;
+	if (poisson_residual_find(e, wpos0, found, out_density, res_density)) poisson_residual_colour(e, found, wpos0, dir, rgb);
 }
 
 // ---- occupancy refresh pieces (update_density_grid_nerf_operator, tn:3533-3640) ----------------------------------------

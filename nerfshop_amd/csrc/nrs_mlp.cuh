@@ -234,6 +234,9 @@ __device__ __forceinline__ void issue_record_loads(const GridView& gv, const Lev
 	v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
 	v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
 }
+#ifndef NRS_OPT_NETACC_MIX
+#define NRS_OPT_NETACC_MIX 1 // NETACC interpolation: per-corner products by v_fma_mix_f32 (0: convert + packed multiply, as the compiler lowers the plain expression)
+#endif
 #ifndef NRS_OPT_PKW
 #define NRS_OPT_PKW 1 // trilinear weights as packed fp32 products (v_pk_mul_f32: twelve products in six issue slots; 0: scalar products)
 #endif
@@ -248,9 +251,16 @@ __device__ __forceinline__ uint32_t interpolate(const CellCoords& c, const uint3
 		#pragma unroll
 		for (int k = 0; k < 8; ++k) {
 			const float weight = wxy[k & 3] * ((k & 4) ? c.wz : uz);
+#if NRS_OPT_NETACC_MIX
+			// the two fp32 products straight from the packed fp16 entry (v_fma_mix_f32 with a zero addend: the product's own rounding; a product of -0 becomes
+			// +0, which no fp16 sum that starts at +0 can tell apart), one v_cvt_pk_f16_f32, one v_pk_add_f16: 4 issue slots per corner instead of 5
+			const half2v pr = {(_Float16)fma_mix_lo(weight, v[k], 0.f), (_Float16)fma_mix_hi(weight, v[k], 0.f)};
+			r = r + pr;
+#else
 			const half2v hv = __builtin_bit_cast(half2v, v[k]);
 			r[0] = r[0] + (_Float16)(weight * (float)hv[0]);
 			r[1] = r[1] + (_Float16)(weight * (float)hv[1]);
+#endif
 		}
 		return __builtin_bit_cast(uint32_t, r);
 	}
@@ -561,8 +571,15 @@ template <bool ACC16>
 __device__ __forceinline__ floatx16 mfma_step(half8 a, half8 b, floatx16 c) {
 	floatx16 d = NRS_MFMA(a, b, c);
 	if (ACC16) {
+		// round-trip through PACKED halfs: 8 v_cvt_pk_f16_f32 + 16 v_cvt_f32_f16 (the odd ones read the high half through SDWA) instead of 16 + 16 scalar
+		// conversions -- the same round-to-nearest-even values.  (The opaque copy keeps the compiler from splitting the pair again.)
 		#pragma unroll
-		for (int i = 0; i < 16; ++i) d[i] = (float)(_Float16)d[i];
+		for (int i = 0; i < 8; ++i) {
+			half2v h = {(_Float16)d[2 * i], (_Float16)d[2 * i + 1]};
+			asm volatile("" : "+v"(h));
+			d[2 * i] = (float)h[0];
+			d[2 * i + 1] = (float)h[1];
+		}
 	}
 	return d;
 }

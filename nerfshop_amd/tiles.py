@@ -178,7 +178,16 @@ class TileSharder:
                 return
             self.gather_impl = "torch.distributed (the C-ABI gather failed its first-frame check)"
         if self.world > 1:
-            dist.gather(self.local, list(self.all.unbind(0)) if self.rank == 0 else None, dst=0)
+            if self.device.type == "cuda" and dist.get_backend() == "gloo":
+                # gloo gathers host tensors only: stage through the host (bench.py's one-GPU mode NRS_BENCH_DIST=gloo and its first-frame cross-check of the
+                # C-ABI gather; never the timed path of a real multi-GPU job, whose backend is nccl)
+                loc = self.local.cpu()
+                parts = [torch.empty_like(loc) for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(loc, parts, dst=0)
+                if self.rank == 0:
+                    self.all.copy_(torch.stack(parts))
+            else:
+                dist.gather(self.local, list(self.all.unbind(0)) if self.rank == 0 else None, dst=0)
         elif self.rank == 0:
             self.all[0].copy_(self.local)
         if self.rank != 0:

@@ -205,6 +205,10 @@ def test_modes_through_every_boundary_flavour(rig):
             rig.render(_params(rig, 64, 36, 60.0, depth_scale=float("nan")))
         with pytest.raises(NrsError):
             rig.render(_params(rig, 64, 36, 60.0, distortion_mode=3))
+        old_client = _params(rig, 64, 36, 60.0)
+        old_client.struct_size -= 8   # built against another nrs.h (ABI 3: the size is the contract, nothing is read past a foreign struct)
+        with pytest.raises(NrsError):
+            rig.render(old_client)
     finally:
         rig.ctx.set_lane_teams(0)
         rig.use_edit(False)

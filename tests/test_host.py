@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(built):
     assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nrs_abi_version() == 2
+    assert lib.nrs_abi_version() == 3
 
 
 def test_struct_layouts_match_header(built):
@@ -251,3 +251,17 @@ def test_rng_seed_matches_oracle(built):
         lib.nrs_rng_seed(seed, C.byref(st), C.byref(inc))
         r = orc.Pcg32(seed)
         assert (st.value, inc.value) == (r.state.value, r.inc.value)
+
+
+def test_render_params_carry_their_size(built):
+    """ABI 3: nrs_render_params starts with struct_size; the ctypes mirror fills it in and has the library's size; a struct of
+    another size is turned away by the host-only entry points (the device entry points refuse it with NRS_ERR_INVALID_ARG: tests/test_gpu_modes.py)."""
+    import ctypes as C
+    from nerfshop_amd import _abi, synth
+    lib = _abi.load()
+    p = synth.render_params(64, 48, synth.orbit_camera(30.0))
+    assert p.struct_size == C.sizeof(_abi.RenderParams) and _abi.RenderParams().struct_size == C.sizeof(_abi.RenderParams)
+    p.tile_size, p.tile_first, p.tile_stride = 16, 0, 2
+    assert lib.nrs_render_tile_pitch(C.byref(p)) == 5 and lib.nrs_render_owned_tiles(C.byref(p)) == 8  # 4 x 3 tiles on a pitch of 5: indices 0..14, every second one
+    p.struct_size -= 8  # a client built against an older header
+    assert lib.nrs_render_tile_pitch(C.byref(p)) == 0 and lib.nrs_render_owned_tiles(C.byref(p)) == 0
