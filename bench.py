@@ -45,6 +45,12 @@ def build_scene(workload, rt, synth, ctx, torch):
         params = synth.make_params(desc, sigma_raw=synth.default_sigma_raw(aabb_scale))
     grid = synth.density_grid(aabb_scale)
     tb = rt.Testbed(ctx, desc, aabb_scale)
+    if aabb_scale == 1 and workload.endswith("norecords"):
+        tb.nerf_network.set_cell_cache(0)  # what a caller gets who keeps no cell records (a training viewer: nrs_model_set_cell_cache(0))
+    if workload.endswith("tcnn_numerics"):
+        # tiny-cuda-nn's roundings as recalled: per-corner fp16 grid accumulation + fp16 MLP accumulators (nrs_model_set_numerics) -- the
+        # pair a parity-minded integrator switches on; a compile-time instantiation of the automatic schedule since round 4
+        tb.nerf_network.set_numerics(1, 1)
     tb.nerf_network.set_params(params)
     edit = None
     if with_edit:
@@ -194,7 +200,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage", "garden", "lego_cage_varied", "lego_cage_membrane", "garden_cage_norecords"])
+    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage", "garden", "lego_cage_varied", "lego_cage_membrane", "garden_cage_norecords", "lego_cage_tcnn_numerics", "lego_cage_norecords"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -253,6 +259,7 @@ def main():
 
     def make_params(step, apply_ops=True, force_tiled=False):
         p = synth.render_params(W, H, camera_for(step, synth, scene["aabb_scale"]), aabb_scale=scene["aabb_scale"], apply_operators=apply_ops)
+        p.poisson_target = 1 if args.workload.endswith("membrane") else 0  # NerfTracer::m_poisson_target = true (testbed.h:219) wherever the membrane correction is on
         if sharder is not None or force_tiled:
             all_sharders[0].fill(p)
         return p
@@ -359,12 +366,13 @@ def main():
         # cage edit) and the lego-like scene with non-uniform opacity (a wide distribution of ray lengths, as a trained snapshot has)
         # plus the membrane correction on (SURVEY 8d's "one extra run with it on") and the garden scene WITHOUT the 64 GB of sparse brick records
         # (they are an option of the boundary, INTEGRATION.md: the figure a caller gets who does not install them)
-        for name in ("garden_cage", "garden_cage_norecords", "lego_cage_varied", "lego_cage_membrane"):
+        for name in ("garden_cage", "garden_cage_norecords", "lego_cage_varied", "lego_cage_membrane", "lego_cage_tcnn_numerics", "lego_cage_norecords"):
             sc2 = build_scene(name, rt, synth, ctx, torch)
             tb2 = sc2["tb"]
 
             def step2(step, want_stats=False):
                 p2 = synth.render_params(W, H, camera_for(step, synth, sc2["aabb_scale"]), aabb_scale=sc2["aabb_scale"], apply_operators=True)
+                p2.poisson_target = 1 if name.endswith("membrane") else 0  # (the reference's default, testbed.h:219)
                 frame.zero_()
                 return tb2.render_with_params(tb2.nerf_network, p2, frame, depth, None, None, want_stats=want_stats)
             ns = sum(int(step2(s2, want_stats=True).n_samples) for s2 in range(8))
@@ -380,16 +388,23 @@ def main():
             extra[name] = {"msamples_per_s": round(ns / dt / 1e6, 2), "fps": round(8 / dt, 2), "samples_per_frame": ns // 8, "rays_view0": rays,
                            "roofline_frac": round(ns / dt * BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBS, 4),
                            "cell_records_gb": round((tb2.nerf_network.cell_cache()[0] + tb2.nerf_network.sparse_cell_cache()[0]) / 1e9, 1)}
-            try:  # recorded PMC traffic of this workload's kernel, where profiles/ holds it: the HBM rate the frame really runs at
-                rec_t = json.load(open(os.path.join(ROOT, TRAFFIC_FILE))).get(name)
-                if rec_t:
-                    extra[name]["traffic"] = int(rec_t["traffic_bytes_per_launch"])
-                    extra[name]["traffic_rate_frac"] = round(rec_t["traffic_bytes_per_launch"] / (dt / 8) / 1e9 / HBM_PEAK_GBS, 4)
-                    extra[name]["traffic_source"] = f"recorded: {TRAFFIC_FILE} [{name}], not measured by this run"
-            except Exception:
-                pass
             del sc2, tb2
             torch.cuda.empty_cache()
+            # the HBM rate the frame really runs at: PMC traffic of this workload's kernel, measured NOW for the garden scene (two more child runs,
+            # like the headline's), else the figure profiles/ holds, if any (`traffic_source` says which)
+            tr, src = (None, None)
+            if name == "garden_cage":
+                tr, src = live_traffic(name, W, H)
+            if tr is None:
+                why = src
+                tr, src = measured_traffic(name)
+                if src and why:
+                    src += f" (live measurement unavailable: {why})"
+            if tr:
+                extra[name]["traffic"] = int(tr)
+                extra[name]["traffic_rate_frac"] = round(tr / (dt / 8) / 1e9 / HBM_PEAK_GBS, 4)
+                extra[name]["l2_misses_per_sample"] = round(tr / 128.0 / (ns / 8), 2)  # every L2 miss is one 128-byte fabric request (profiles/r02_gather_probe.md)
+                extra[name]["traffic_source"] = src
 
     gather_check = None
     if world > 1:
@@ -448,7 +463,9 @@ def main():
                                     "garden": "garden-style aabb_scale 16 1920x1080, no edits",
                                     "lego_cage_varied": "lego-like snapshot with non-uniform opacity (geometry in the network, density noise 1.5) 1920x1080, one cage edit",
                                     "lego_cage_membrane": "lego-like snapshot 1920x1080, one cage edit with the membrane (Poisson) correction on",
-                                    "garden_cage_norecords": "garden-style aabb_scale 16 1920x1080, one cage edit, no sparse brick records"}[args.workload],
+                                    "garden_cage_norecords": "garden-style aabb_scale 16 1920x1080, one cage edit, no sparse brick records",
+                                    "lego_cage_tcnn_numerics": "lego-like snapshot 1920x1080, one cage edit, tiny-cuda-nn's roundings (fp16 per-corner grid accumulation, fp16 MLP accumulators)",
+                                    "lego_cage_norecords": "lego-like snapshot 1920x1080, one cage edit, no cell records (nrs_model_set_cell_cache(0))"}[args.workload],
                        "resolution": [W, H], "samples_per_frame": int(total_samples / args.steps),
                        "sharding": f"{TILE}x{TILE} image tiles round-robin over {world} GPU(s)" + (f", gather to rank 0 by {all_sharders[0].gather_impl}" if world > 1 else ""),
                        "frames_in_flight": n_buf,

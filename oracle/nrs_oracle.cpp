@@ -838,6 +838,105 @@ void network_inference_one(const Model& m, const float coord[7], uint16_t out16[
 	out16[3] = in32[0];
 }
 
+// ---- the network's introspection entry points render_nerf uses (render modes Normals and EncodingVis) -----------------------------------------
+// Both live in tiny-cuda-nn (absent from /root/reference: empty, un-pinned submodule), so like the forward pass they are RESTATED from the published
+// algorithm (NVlabs/tiny-cuda-nn of 2022 as recalled: object.h `input_gradient`, network.h `visualize_activation`, grid.h `kernel_grid` /
+// `kernel_grid_backward_input`, fully_fused_mlp.cu's backward) around the reference's own NerfNetworkFull::backward_impl / forward_activations
+// (nerf_network_full.h:142-221, 523-534).  Parity at this boundary is "HIP == stated tcnn numerics" (DESIGN.md 2).
+//
+// network.input_gradient(stream, 3, positions, gradients) (tn:2924): d output[3] / d input with a backprop scale of 128 (object.h: "prevents underflows
+// during half-precision backprop"), i.e. backward of the one-hot 128 * e_3:
+//   * backward_impl copies rows 0..2 of dL_doutput into the rgb network's gradient (all zero here): its input gradients, the SH encoding's and hence
+//     rows 4..6 of the result are zero; add_density_gradient puts row 3 on the density network's output row 0: dL_ddensity_out = 128 * e_0;
+//   * fully fused backward of the density MLP: dL_dhidden[k] = (hidden[k] > 0) * fp16(W2[0][k] * 128) (one non-zero term: exact), then
+//     dL_dfeatures[i] = sum_k W1[k][i] * dL_dhidden[k] in network precision -- accumulated as Model::mlp_acc says (fp32: one rounding; fp16: one
+//     rounding of the running sum per 16-wide k block), the same model as the forward pass;
+//   * kernel_grid with prepare_input_gradients: dy_dx[level, feature][dim] = sum over the 4 corner pairs along dim of
+//     scale * w(other two dims) * (value_right - value_left), fp32, accumulated with the contraction nvcc applies (fmaf), dims 0..2, pairs in index order;
+//   * kernel_grid_backward_input: dL_dx[dim] = sum over the 32 features in order of (float)dL_dy[k] * dy_dx[k][dim], fp32 (fmaf);
+//   * mult by 1 / 128.
+// grad_out: 3 floats (d / d warped position); feat / hidden are the forward activations of the same sample.
+void hashgrid_input_gradient_one(const Model& m, const float pos[3], const uint16_t dLdy[32], float grad_out[3]) {
+	const uint16_t* grid = m.grid();
+	float result[3] = {0.f, 0.f, 0.f};
+	for (uint32_t l = 0; l < m.desc.n_levels; ++l) {
+		const float scale = m.lt.scale[l];
+		float p[3], w[3];
+		uint32_t g[3];
+		for (int d = 0; d < 3; ++d) {
+			p[d] = fmaf(scale, pos[d], 0.5f);
+			float fl = floorf(p[d]);
+			g[d] = (uint32_t)(int)fl;
+			w[d] = p[d] - fl;
+		}
+		float grads[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+		for (uint32_t grad_dim = 0; grad_dim < 3; ++grad_dim) {
+			for (uint32_t idx = 0; idx < 4; ++idx) {
+				float weight = scale;
+				uint32_t gl[3];
+				for (uint32_t non_grad_dim = 0; non_grad_dim < 2; ++non_grad_dim) {
+					const uint32_t dim = non_grad_dim >= grad_dim ? non_grad_dim + 1 : non_grad_dim;
+					if ((idx & (1u << non_grad_dim)) == 0) { weight *= 1 - w[dim]; gl[dim] = g[dim]; }
+					else { weight *= w[dim]; gl[dim] = g[dim] + 1u; }
+				}
+				gl[grad_dim] = g[grad_dim];
+				const uint32_t e_left = m.lt.offset[l] + grid_index(m.lt, l, gl[0], gl[1], gl[2]);
+				gl[grad_dim] = g[grad_dim] + 1u;
+				const uint32_t e_right = m.lt.offset[l] + grid_index(m.lt, l, gl[0], gl[1], gl[2]);
+				for (uint32_t f = 0; f < 2; ++f)
+					grads[f][grad_dim] = fmaf(weight, h2f(grid[2 * (size_t)e_right + f]) - h2f(grid[2 * (size_t)e_left + f]), grads[f][grad_dim]); // (* pos_derivative = 1: linear interpolation)
+			}
+		}
+		for (uint32_t f = 0; f < 2; ++f) {
+			const float dl = h2f(dLdy[2 * l + f]);
+			for (int d = 0; d < 3; ++d) result[d] = fmaf(dl, grads[f][d], result[d]);
+		}
+	}
+	for (int d = 0; d < 3; ++d) grad_out[d] = result[d] * (1.0f / 128.0f);
+}
+void density_input_gradient_one(const Model& m, const float coord[7], float grad_out[3]) {
+	const float* W1 = m.wf.data();       // [64 x 32]
+	const float* W2 = W1 + 64 * 32;      // [16 x 64]
+	uint16_t feat[32], h[64];
+	hashgrid_encode_one(m, coord, feat);
+	dense_layer(W1, 64, 32, feat, h, true, m.mlp_acc);
+	uint16_t dh[64];
+	for (uint32_t k = 0; k < 64; ++k) dh[k] = h2f(h[k]) > 0.f ? f2h(W2[k] * 128.0f) : (uint16_t)0; // row 0 of W2; x 128 is exact in fp16 up to overflow
+	// dL_dfeatures = W1^T dL_dhidden: a dense layer with the transposed matrix
+	float W1T[32 * 64];
+	for (uint32_t k = 0; k < 64; ++k)
+		for (uint32_t i = 0; i < 32; ++i) W1T[i * 64 + k] = W1[k * 32 + i];
+	uint16_t dfeat[32];
+	dense_layer(W1T, 32, 64, dh, dfeat, false, m.mlp_acc);
+	hashgrid_input_gradient_one(m, coord, dfeat, grad_out);
+}
+// network.visualize_activation(stream, layer, dimension, input, output) (tn:2926): a forward pass, then the activation `dimension` of
+// forward_activations(layer) -- 0: the hash-grid output (32), 1: the density MLP's hidden layer (64, after ReLU), 2: the rgb network's input (16 density
+// outputs | 16 SH coefficients), 3 / 4: the rgb MLP's hidden layers (64) -- written over the 7-row input matrix by extract_dimension_pos_neg_kernel:
+// row 0 = max(-v, 0), row 1 = max(v, 0), row 2 = 0, rows 3..6 = 1.  The reference passes the network INPUT as the output matrix, so the sample's
+// NerfCoordinate is overwritten: composite_kernel_nerf then reads pos = (max(-v, 0), max(v, 0), 0) as "warped_pos" (the colour, tn:925), dt = 1
+// (unwarp_dt(1) = the largest step: tn:762) and dir = (1, 1, 1).  Restated as it is.
+uint32_t network_layer_width(uint32_t layer) { return layer == 0 ? 32u : (layer == 2 ? 32u : 64u); } // NerfNetworkFull::width, nerf_network_full.h:507-517
+float network_activation_one(const Model& m, const float coord[7], uint32_t layer, uint32_t dim) {
+	const float* Wd1 = m.wf.data();
+	const float* Wd2 = Wd1 + 64 * 32;
+	const float* Wr1 = m.wf.data() + N_DENSITY_W;
+	const float* Wr2 = Wr1 + 64 * 32;
+	uint16_t feat[32], h[64], in32[32], h1[64], h2[64];
+	hashgrid_encode_one(m, coord, feat);
+	if (layer == 0) return h2f(feat[dim]);
+	dense_layer(Wd1, 64, 32, feat, h, true, m.mlp_acc);
+	if (layer == 1) return h2f(h[dim]);
+	dense_layer(Wd2, 16, 64, h, in32, false, m.mlp_acc);
+	sh4_encode_one(coord + 4, in32 + 16);
+	if (layer == 2) return h2f(in32[dim]);
+	dense_layer(Wr1, 64, 32, in32, h1, true, m.mlp_acc);
+	if (layer == 3) return h2f(h1[dim]);
+	dense_layer(Wr2, 64, 64, h1, h2, true, m.mlp_acc);
+	return h2f(h2[dim]);
+}
+inline float network_to_density_derivative(float v, uint32_t act); // below
+
 inline float logistic(float x) { return 1.0f / (1.0f + expf(-x)); }
 inline float network_to_rgb(float v, uint32_t act) { // cn:38-47
 	switch (act) {
@@ -856,6 +955,16 @@ inline float network_to_density(float v, uint32_t act) { // cn:57-66
 		case NRS_ACT_EXPONENTIAL: return expf(v);
 	}
 	return 0.f;
+}
+
+inline float network_to_density_derivative(float v, uint32_t act) { // tn:308-317
+	switch (act) {
+		case NRS_ACT_NONE: return 1.0f;
+		case NRS_ACT_RELU: return v > 0.0f ? 1.0f : 0.0f;
+		case NRS_ACT_LOGISTIC: { float density = logistic(v); return density * (1 - density); }
+		case NRS_ACT_EXPONENTIAL: return expf(clampf(v, -15.0f, 15.0f));
+	}
+	return 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1241,6 +1350,17 @@ void render(const Model& m, const nrs_render_params& p, const Edit* const* edits
 			// ---- second network pass, tn:2908-2913
 			uint16_t out[8][16];
 			for (uint32_t j = 0; j < actual_n_steps; ++j) network_inference_one(m, coords[j], out[j]);
+			// ---- tn:2923-2927: the input gradient of the density (render mode Normals), or the visualised activation written OVER the network input
+			float grad_pos[8][3];
+			if (render_mode == NRS_RENDER_NORMALS) {
+				for (uint32_t j = 0; j < actual_n_steps; ++j) density_input_gradient_one(m, coords[j], grad_pos[j]);
+			} else if (render_mode == NRS_RENDER_ENCODING_VIS) {
+				for (uint32_t j = 0; j < actual_n_steps; ++j) {
+					const float v = network_activation_one(m, coords[j], p.visualized_layer, p.visualized_dimension);
+					coords[j][0] = fmaxf(-v, 0.0f); coords[j][1] = fmaxf(v, 0.0f); coords[j][2] = 0.f;
+					coords[j][3] = coords[j][4] = coords[j][5] = coords[j][6] = 1.f;
+				}
+			}
 
 			// ---- composite_kernel_nerf, tn:698-979 (Shade mode)
 			{
@@ -1319,8 +1439,16 @@ void render(const Model& m, const nrs_render_params& p, const Edit* const* edits
 							}
 						}
 					}
-					// ---- per-sample render modes, tn:905-937 (Normals / EncodingVis need tiny-cuda-nn's input gradient / visualize_activation: not on the path)
-					if (render_mode == NRS_RENDER_POSITIONS) {
+					// ---- per-sample render modes, tn:905-937
+					if (render_mode == NRS_RENDER_NORMALS) { // tn:905-910: the direction of decreasing density
+						const float k = -network_to_density_derivative(sigma_raw, m.desc.density_activation);
+						const float nx = k * grad_pos[j][0], ny = k * grad_pos[j][1], nz = k * grad_pos[j][2];
+						const float z = nx * nx + (ny * ny + nz * nz); // Eigen: squaredNorm of a fixed-size 3-vector, then normalized() (z > 0 ? v / sqrt(z) : v)
+						if (z > 0.f) { const float n = sqrtf(z); rgb[0] = nx / n; rgb[1] = ny / n; rgb[2] = nz / n; }
+						else { rgb[0] = nx; rgb[1] = ny; rgb[2] = nz; }
+					} else if (render_mode == NRS_RENDER_ENCODING_VIS) { // tn:925: rgb = warped_pos (the overwritten input)
+						rgb[0] = coords[j][0]; rgb[1] = coords[j][1]; rgb[2] = coords[j][2];
+					} else if (render_mode == NRS_RENDER_POSITIONS) {
 						if (show_accel >= 0) {
 							uint32_t mip = (uint32_t)std::max(show_accel, mip_from_pos(pos));
 							uint32_t res = GRID >> mip;
@@ -1387,7 +1515,12 @@ void render(const Model& m, const nrs_render_params& p, const Edit* const* edits
 	for (uint32_t ri : hit) {
 		RayState& r = rays[ri];
 		float tmp[4] = {r.rgba[0], r.rgba[1], r.rgba[2], r.rgba[3]};
-		if (p.render_mode == NRS_RENDER_COST) {
+		if (p.render_mode == NRS_RENDER_NORMALS) { // tn:2466-2468
+			const float z = tmp[0] * tmp[0] + (tmp[1] * tmp[1] + tmp[2] * tmp[2]);
+			float n[3] = {tmp[0], tmp[1], tmp[2]};
+			if (z > 0.f) { const float s = sqrtf(z); n[0] = tmp[0] / s; n[1] = tmp[1] / s; n[2] = tmp[2] / s; }
+			for (int c = 0; c < 3; ++c) tmp[c] = (0.5f * n[c] + 0.5f) * tmp[3];
+		} else if (p.render_mode == NRS_RENDER_COST) {
 			float col = (float)r.payload.n_steps / 128;
 			tmp[0] = tmp[1] = tmp[2] = col; tmp[3] = 1.0f;
 		}
@@ -1783,6 +1916,20 @@ void orc_network_inference(void* model, uint32_t n, const float* in7, uint16_t* 
 			if (layout == NRS_PLANES) out[(size_t)c * ld_out + i] = o[c];
 			else out[(size_t)i * 16 + c] = o[c];
 	}
+}
+// tcnn input_gradient(stream, 3, ...) restated: d density_raw / d warped position of n samples [n x 7] -> [n x 3]
+void orc_density_input_gradient(void* model, uint32_t n, const float* in7, float* grad3) {
+	const Model& m = *(const Model*)model;
+#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < (int64_t)n; ++i) density_input_gradient_one(m, in7 + 7 * (size_t)i, grad3 + 3 * (size_t)i);
+}
+// tcnn visualize_activation restated: activation `dim` of forward_activations(layer) of n samples [n x 7] -> [n]; returns 0 for an unknown layer / unit
+int orc_network_activation(void* model, uint32_t n, const float* in7, uint32_t layer, uint32_t dim, float* out) {
+	const Model& m = *(const Model*)model;
+	if (layer > 4 || dim >= network_layer_width(layer)) return 0;
+#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = network_activation_one(m, in7 + 7 * (size_t)i, layer, dim);
+	return 1;
 }
 void orc_network_density(void* model, uint32_t n, const float* in, uint32_t ld_in, uint16_t* out, uint32_t ld_out, int layout) {
 	const Model& m = *(Model*)model;

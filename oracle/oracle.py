@@ -60,6 +60,7 @@ def load():
         "orc_density_on_grid": (None, [P, P, P, P, P, P]), "orc_rgba_on_grid": (None, [P, P, P, P, P, P]),
         "orc_project_selection_pixels": (None, [P, P, P, U32, F, P, P, P]),
         "orc_poisson_boundary": (None, [P, P, U32, U32, U32, P, I, P, P, P]),
+        "orc_density_input_gradient": (None, [P, U32, P, P]), "orc_network_activation": (I, [P, U32, P, U32, U32, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -116,6 +117,21 @@ class Model:
         n = pos.shape[0]
         out = np.zeros((16, n) if layout == 0 else (n, 16), np.uint16)
         self.lib.orc_network_density(self.h, n, pos.ctypes.data, pos.shape[1], out.ctypes.data, n, layout)
+        return out
+
+    def density_input_gradient(self, coords7):
+        """tcnn input_gradient(stream, 3, ...) as restated: d density_raw / d warped position, [n, 3] f32 (render mode Normals)."""
+        coords7 = _f32(coords7)
+        out = np.zeros((coords7.shape[0], 3), np.float32)
+        self.lib.orc_density_input_gradient(self.h, coords7.shape[0], coords7.ctypes.data, out.ctypes.data)
+        return out
+
+    def network_activation(self, coords7, layer, dim):
+        """tcnn visualize_activation as restated: unit `dim` of forward_activations(layer), [n] f32 (render mode EncodingVis)."""
+        coords7 = _f32(coords7)
+        out = np.zeros(coords7.shape[0], np.float32)
+        if not self.lib.orc_network_activation(self.h, coords7.shape[0], coords7.ctypes.data, int(layer), int(dim), out.ctypes.data):
+            raise ValueError(f"no unit {dim} in layer {layer}")
         return out
 
     def update_density_grid(self, grid, update, edits=()):

@@ -39,17 +39,19 @@ class BenchScene:
         return frame.cpu().numpy(), depth.cpu().numpy(), steps.cpu().numpy(), stats
 
 
-def check_against_oracle(bs, p, edits, min_samples, depth_scale=1.0):
+def check_against_oracle(bs, p, edits, min_samples, depth_scale=1.0, flip_share=1e-5, mean_bar=2e-6, equal_steps=0.9998):
     frame, depth, steps, stats = bs.render(p)
     ref_frame, ref_depth, ref_steps, ref_stats = bs.model.render(p, edits)
     assert ref_stats.composited > min_samples
     assert stats.n_rays_alive == ref_stats.n_alive0
     d = np.abs(frame - ref_frame).max(axis=-1)
     n_px = d.size
-    # at most 1e-5 of the pixels (and never fewer than 3 allowed) may sit on the other side of the alpha normalisation (|d| <= 1.01e-2), the rest within 6e-3
-    assert d.max() < 1.5e-2 and (d > 6e-3).sum() <= max(3, 1e-5 * n_px) and float(np.abs(frame - ref_frame).mean()) < 2e-6, (d.max(), (d > 6e-3).sum(), np.abs(frame - ref_frame).mean())
     ds = np.abs(steps.astype(np.int64) - ref_steps.astype(np.int64))
-    assert ds.max() <= 1 and (ds == 0).mean() >= 0.9998, (ds.max(), (ds == 0).mean())
+    print(f"[bench parity] max|dRGBA| {d.max():.3e}, pixels above 6e-3: {(d > 6e-3).sum()} of {n_px}, mean {np.abs(frame - ref_frame).mean():.3e}, "
+          f"steps equal {(ds == 0).mean():.6f}, max step difference {ds.max()}, samples {int(stats.n_samples)} / {int(ref_stats.composited)}")
+    # at most flip_share of the pixels (and never fewer than 3 allowed) may sit on the other side of the alpha normalisation (|d| <= 1.01e-2), the rest within 6e-3
+    assert d.max() < 1.5e-2 and (d > 6e-3).sum() <= max(3, flip_share * n_px) and float(np.abs(frame - ref_frame).mean()) < mean_bar, (d.max(), (d > 6e-3).sum(), np.abs(frame - ref_frame).mean())
+    assert ds.max() <= 1 and (ds == 0).mean() >= equal_steps, (ds.max(), (ds == 0).mean())
     hit = (ref_frame[..., 3] > 0.2) & (frame[..., 3] > 0.2) & (ds == 0)
     assert np.allclose(depth[hit], ref_depth[hit], rtol=0, atol=2e-3 * depth_scale)
     assert abs(int(stats.n_samples) - int(ref_stats.composited)) <= 0.0003 * ref_stats.composited
@@ -87,3 +89,18 @@ def test_varied_opacity_scene_against_the_oracle(built):
     finally:
         bs.ctx.set_ray_handover(True)
     assert np.array_equal(f1[0].view(np.uint32), f0[0].view(np.uint32)) and np.array_equal(f1[2], f0[2])
+
+
+def test_tcnn_numerics_1080p_against_the_oracle(built):
+    """`lego_cage_tcnn_numerics`: per-corner fp16 grid accumulation + fp16 MLP accumulators -- tiny-cuda-nn's roundings as
+    recalled -- on the compile-time instantiation of the automatic schedule, 1920x1080, bench view 0, against the oracle in the same mode.  The hash-grid
+    features are bit-exact in this mode (tests/test_gpu_numerics.py); the MFMA rounds the fp32 sum of a 16-wide k block where the oracle rounds the exact
+    one, so more rays sit one sample apart than in the default mode: the same colour bars, a wider share for the alpha-normalisation flips."""
+    bs = BenchScene("lego_cage_tcnn_numerics")
+    bs.model.set_numerics(1, 1)
+    check_against_oracle(bs, bs.params(0), bs.edits, 10_000_000, flip_share=1e-4, mean_bar=1e-5, equal_steps=0.999)
+    # the default roundings give another picture (the mode is not a no-op) within the colour tolerance of the path
+    frame_num = bs.render(bs.params(0, 480, 270))[0]
+    bs.tb.nerf_network.set_numerics(0, 0)
+    frame_def = bs.render(bs.params(0, 480, 270))[0]
+    assert not np.array_equal(frame_num, frame_def) and np.abs(frame_num - frame_def).max() < 0.1

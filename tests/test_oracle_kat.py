@@ -406,3 +406,91 @@ def test_fast_flavour_stays_within_the_network_tolerance(built):
     ulp = np.maximum(np.abs(af), 2.0 ** -14) * 2.0 ** -10
     assert ((np.abs(af - bf) <= 4 * ulp) | (np.abs(af - bf) <= 2e-3)).all() and (a == b).mean() > 0.98
     assert np.abs(fa - fb).max() < 6e-3 and np.abs(sa.astype(np.int64) - sb.astype(np.int64)).max() <= 1
+
+
+def _np_grid_features_and_jacobian(scene, pos):
+    """float64 trilinear hash-grid features [n, 32] and their Jacobian w.r.t. the position [n, 32, 3] from the parameter blob, with tcnn's index
+    function restated in numpy (an evaluation independent of oracle/nrs_oracle.cpp)."""
+    lt = scene.synth.level_table(scene.desc)
+    grid = scene.params[3072 + 7168:].view(np.float16).astype(np.float64).reshape(-1, 2)
+    n = pos.shape[0]
+    feat, jac = np.zeros((n, 32)), np.zeros((n, 32, 3))
+    for l in range(16):
+        scale, res, off, cnt, hashed = np.float32(lt["scale"][l]), int(lt["resolution"][l]), int(lt["offset"][l]), int(lt["count"][l]), int(lt["hashed"][l])
+        p = (scale * pos.astype(np.float32) + np.float32(0.5)).astype(np.float64)
+        g = np.floor(p).astype(np.int64)
+        w = p - g
+        for c in range(8):
+            bit = np.array([(c >> d) & 1 for d in range(3)])
+            gl = (g + bit).astype(np.uint64)
+            if hashed:
+                idx = ((gl[:, 0] * np.uint64(1)) ^ (gl[:, 1] * np.uint64(2654435761)) ^ (gl[:, 2] * np.uint64(805459861))) & np.uint64(0xffffffff)
+            else:
+                idx = gl[:, 0] + gl[:, 1] * np.uint64(res) + gl[:, 2] * np.uint64(res * res)
+            val = grid[off + (idx % np.uint64(cnt)).astype(np.int64)]            # [n, 2]
+            wd = np.where(bit[None, :] == 1, w, 1.0 - w)                         # [n, 3]
+            feat[:, 2 * l:2 * l + 2] += wd.prod(axis=1)[:, None] * val
+            for d in range(3):
+                others = [k for k in range(3) if k != d]
+                dw = (1.0 if bit[d] else -1.0) * float(scale) * wd[:, others[0]] * wd[:, others[1]]
+                jac[:, 2 * l:2 * l + 2, d] += dw[:, None] * val
+    return feat, jac
+
+
+def test_density_input_gradient_against_numpy(scene_shaped):
+    """Render mode Normals rests on tcnn's input_gradient, restated in the oracle (density_input_gradient_one): checked here against the chain rule
+    evaluated independently in float64 numpy -- d density_raw / d x = W2[0] . (relu'(W1 f(x)) * (W1 J_f(x))) -- which pins the wiring (one-hot on output
+    row 3 = density row 0, transposed matrices, the level scale in the feature Jacobian, the 1 / 128 un-scaling); the oracle's own fp16 rounding points
+    (dL/dhidden, dL/dfeatures) account for the tolerance."""
+    scene = scene_shaped
+    rng = np.random.default_rng(7)
+    n = 600
+    c = np.zeros((n, 7), np.float32)
+    c[:, :3] = rng.uniform(0.15, 0.85, size=(n, 3))
+    c[:, 4:] = 0.5
+    got = scene.oracle_model.density_input_gradient(c).astype(np.float64)
+    feat, jac = _np_grid_features_and_jacobian(scene, c[:, :3])
+    assert np.abs(feat - scene.oracle_model.hashgrid_encode(c).view(np.float16).astype(np.float64)).max() < 2e-3   # the numpy grid is the oracle's grid
+    w = scene.params[:3072].view(np.float16).astype(np.float64)
+    w1, w2 = w[:2048].reshape(64, 32), w[2048:3072].reshape(16, 64)
+    pre = feat @ w1.T                                                    # [n, 64]
+    # (the ReLU mask of the oracle's own fp16 hidden layer: a unit within rounding of its kink must not flip between the two evaluations)
+    mask = np.stack([scene.oracle_model.network_activation(c, 1, k) > 0 for k in range(64)], axis=1)
+    assert (mask == (pre > 0)).mean() > 0.995
+    want = np.einsum("k,nk,nkd->nd", w2[0], mask.astype(np.float64), np.einsum("ki,nid->nkd", w1, jac))
+    safe = np.ones(n, bool)
+    scale = np.abs(want[safe]).max()
+    assert scale > 1.0
+    err = np.abs(got[safe] - want[safe]).max(axis=1)
+    assert np.median(err) < 2e-3 * scale and err.max() < 2e-2 * scale, (np.median(err) / scale, err.max() / scale)
+    # both accumulation models of the backward GEMM stay within that tolerance of each other
+    scene.oracle_model.set_numerics(1, 1)
+    try:
+        got16 = scene.oracle_model.density_input_gradient(c).astype(np.float64)
+    finally:
+        scene.oracle_model.set_numerics(0, 0)
+    assert np.abs(got16[safe] - want[safe]).max() < 5e-2 * scale and not np.array_equal(got16, got)
+
+
+def test_network_activation_layers(scene):
+    """Render mode EncodingVis rests on tcnn's visualize_activation, restated in the oracle (network_activation_one): layer 0 is the hash-grid output, layer 2
+    the rgb network's input [density outputs | SH], hidden layers are non-negative (after ReLU); unknown units are refused."""
+    rng = np.random.default_rng(3)
+    c = rng.uniform(0.05, 0.95, size=(200, 7)).astype(np.float32)
+    m = scene.oracle_model
+    feat = m.hashgrid_encode(c).view(np.float16).astype(np.float32)
+    dens = m.density(c[:, :3].copy(), 1).view(np.float16).astype(np.float32)   # [n, 16]
+    sh = np.zeros((200, 16), np.uint16)
+    dirs = np.ascontiguousarray(c[:, 4:7])
+    orc.load().orc_sh4_encode(200, dirs.ctypes.data, 3, sh.ctypes.data)
+    for dim in (0, 5, 31):
+        assert np.array_equal(m.network_activation(c, 0, dim), feat[:, dim])
+    for dim in (0, 3, 15):
+        assert np.array_equal(m.network_activation(c, 2, dim), dens[:, dim])
+        assert np.array_equal(m.network_activation(c, 2, 16 + dim), sh.view(np.float16).astype(np.float32)[:, dim])
+    for layer in (1, 3, 4):
+        a = m.network_activation(c, layer, 17)
+        assert (a >= 0).all() and (a > 0).any()
+    for layer, dim in ((0, 32), (2, 32), (1, 64), (5, 0)):
+        with pytest.raises(ValueError):
+            m.network_activation(c, layer, dim)
