@@ -67,9 +67,9 @@ typedef enum nrs_activation {
 } nrs_activation;
 
 /* ERenderMode, common.h:71.  Implemented: AO, Shade, Positions, Depth, Distance, Stepsize, Distortion, Cost, Slice (composite_kernel_nerf's per-sample
- * branches testbed_nerf.cu:905-937, shade_kernel_nerf :2466-2482, init_rays' Distortion branch :2602-2613, the Slice path :3111-3175).  Refused
- * (NRS_ERR_UNSUPPORTED): Normals (needs the network's input gradient, tcnn input_gradient) and EncodingVis (m_visualized_dimension, tcnn
- * visualize_activation) -- both live in tiny-cuda-nn, outside the path. */
+ * branches testbed_nerf.cu:905-937, shade_kernel_nerf :2466-2482, init_rays' Distortion branch :2602-2613, the Slice path :3111-3175), and since ABI 3
+ * Normals (the network's input gradient, :2924, :905-910, :2466-2468) and EncodingVis (visualized_layer / visualized_dimension, :2926, :925) -- the two
+ * modes whose per-sample input lives in tiny-cuda-nn: restated like the forward pass (nrs_network_input_gradient / _visualize_activation below). */
 typedef enum nrs_render_mode {
 	NRS_RENDER_AO = 0, NRS_RENDER_SHADE = 1, NRS_RENDER_NORMALS = 2, NRS_RENDER_POSITIONS = 3,
 	NRS_RENDER_DEPTH = 4, NRS_RENDER_DISTANCE = 5, NRS_RENDER_STEPSIZE = 6, NRS_RENDER_DISTORTION = 7,
@@ -354,6 +354,17 @@ int nrs_network_inference(nrs_model* model, void* stream, uint32_t n, const floa
  * (nerf_network_full.h:231-236).  Output = the density MLP's 16 outputs (c 0 = density raw). */
 int nrs_network_density(nrs_model* model, void* stream, uint32_t n, const float* d_in, uint32_t ld_in,
                         void* d_out_fp16, uint32_t ld_out, int layout);
+/* The network's introspection entry points (tiny-cuda-nn's, restated: the submodule is absent from the reference checkout -- oracle/nrs_oracle.cpp
+ * density_input_gradient_one / network_activation_one carry the algorithm and its provenance):
+ * nrs_network_input_gradient <- NerfNetwork::input_gradient(stream, 3, positions, gradients) (render mode Normals, src/testbed_nerf.cu:2924; mesh vertex
+ *   normals :4491): d density_raw / d position of every sample through the density MLP and the hash grid, backprop scale 128 as in tiny-cuda-nn,
+ *   rows 0..2 of the result ([n x 3] f32; rows 3..6 -- dt and the direction -- are zero in the reference's 7-row matrix: the density does not depend on them).
+ * nrs_network_visualize_activation <- Network::visualize_activation(stream, layer, dimension, input, output) (render mode EncodingVis, :2926, :3159): unit
+ *   `dimension` of NerfNetworkFull::forward_activations(layer) (nerf_network_full.h:523-534: 0 hash grid [32], 1 density hidden [64], 2 rgb network input
+ *   = 16 density outputs | 16 SH coefficients, 3 / 4 rgb hidden [64]) as f32 [n]; the reference's output kernel writes max(-v, 0), max(v, 0), 0, 1, 1, 1, 1
+ *   into a 7-row matrix -- the caller that wants that picture forms it from v.  d_in is [n x 7] f32. */
+int nrs_network_input_gradient(nrs_model* model, void* stream, uint32_t n, const float* d_in, uint32_t ld_in, float* d_grad_out_nx3);
+int nrs_network_visualize_activation(nrs_model* model, void* stream, uint32_t layer, uint32_t dimension, uint32_t n, const float* d_in, float* d_out_n);
 /* The network on a regular grid ("next" row f4: the marching-cubes / volume-export callers of the operator).
  * nrs_density_on_grid <- Testbed::get_density_on_grid (src/testbed_nerf.cu:4538): point (x,y,z) of the res3d grid sits at
  *   aabb_min + (x/rx, y/ry, z/rz) * (aabb_max - aabb_min); d_out[x + y*rx + z*rx*ry] = raw density (fp16 network output as float),

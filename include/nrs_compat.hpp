@@ -76,6 +76,17 @@ public:
 	void density(void* stream, const InputMatrix& input, OutputMatrix& output, bool /*use_inference_params*/ = true) {
 		check(nrs_network_density(m_model, stream, input.n, input.data, input.rows, output.data, output.n, output.layout), "nrs_network_density");
 	}
+	// tcnn::DifferentiableObject::input_gradient(stream, dim, input, d_dinput) as the path calls it (dim = 3: the density; testbed_nerf.cu:2924, :4491).
+	// d_grad: [n x 3] f32, the position rows of the reference's gradient matrix (the dt / direction rows are zero there).
+	void input_gradient(void* stream, uint32_t dim, const InputMatrix& input, float* d_grad_nx3) {
+		if (dim != 3) throw std::runtime_error("NerfNetwork::input_gradient: the render path differentiates output 3 (the density) only");
+		check(nrs_network_input_gradient(m_model, stream, input.n, input.data, input.rows, d_grad_nx3), "nrs_network_input_gradient");
+	}
+	// tcnn::Network::visualize_activation(stream, layer, dimension, input, output): the activation itself, f32 [n] (testbed_nerf.cu:2926, :3159)
+	void visualize_activation(void* stream, uint32_t layer, uint32_t dimension, const InputMatrix& input, float* d_out_n) {
+		if (input.rows != NRS_NETWORK_INPUT_FLOATS) throw std::runtime_error("NerfNetwork::visualize_activation: input must have 7 rows");
+		check(nrs_network_visualize_activation(m_model, stream, layer, dimension, input.n, input.data, d_out_n), "nrs_network_visualize_activation");
+	}
 
 	// Testbed::m_nerf.density_grid_bitfield / update_density_grid_mean_and_bitfield
 	void set_density_bitfield(const uint8_t* h_bits, size_t n) { check(nrs_model_set_density_bitfield(m_model, h_bits, n), "nrs_model_set_density_bitfield"); }

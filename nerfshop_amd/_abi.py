@@ -145,7 +145,7 @@ EXPORTS = [
     "nrs_model_create", "nrs_model_destroy", "nrs_model_n_params", "nrs_model_level_table",
     "nrs_model_set_params", "nrs_model_set_params_device", "nrs_model_set_numerics", "nrs_model_set_cell_cache", "nrs_model_cell_cache_bytes", "nrs_model_set_sparse_cell_cache", "nrs_model_sparse_cell_cache_bytes", "nrs_model_set_density_bitfield", "nrs_model_set_density_grid",
     "nrs_model_get_density_bitfield", "nrs_model_get_march_accelerator", "nrs_model_get_density_grid", "nrs_model_update_density_grid", "nrs_rng_seed",
-    "nrs_network_inference", "nrs_network_density", "nrs_hashgrid_encode", "nrs_density_on_grid", "nrs_rgba_on_grid",
+    "nrs_network_inference", "nrs_network_density", "nrs_hashgrid_encode", "nrs_density_on_grid", "nrs_rgba_on_grid", "nrs_network_input_gradient", "nrs_network_visualize_activation",
     "nrs_poisson_boundary", "nrs_poisson_sample_coords", "nrs_project_selection_pixels", "nrs_upper_cell_idx", "nrs_selection_cells",
     "nrs_edit_create", "nrs_edit_create_affine", "nrs_edit_destroy", "nrs_edit_map_rays", "nrs_edit_map_positions",
     "nrs_edit_set_mvc", "nrs_edit_update_cage", "nrs_edit_update_vertices", "nrs_edit_lut_size", "nrs_edit_download",
@@ -229,6 +229,8 @@ def load():
     lib.nrs_network_inference.argtypes = [P, P, U32, P, P, U32, I]
     lib.nrs_network_density.argtypes = [P, P, U32, P, U32, P, U32, I]
     lib.nrs_hashgrid_encode.argtypes = [P, P, U32, P, U32, P]
+    lib.nrs_network_input_gradient.argtypes = [P, P, U32, P, U32, P]
+    lib.nrs_network_visualize_activation.argtypes = [P, P, U32, U32, U32, P, P]
     lib.nrs_density_on_grid.argtypes = [P, P, C.POINTER(U32 * 3), C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), I, P]
     lib.nrs_rgba_on_grid.argtypes = [P, P, C.POINTER(U32 * 3), C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), P]
     lib.nrs_edit_create.argtypes = [P, C.POINTER(ModelDesc), C.POINTER(TetMesh), C.POINTER(P)]

@@ -143,6 +143,8 @@ static int check_march_params(const nrs_render_params& p, const char* who) {
 	return NRS_OK;
 }
 // ---------------------------------------------------------------------------------------------------------------
+// NerfNetworkFull::width(layer) of forward_activations (nerf_network_full.h:507-517) for configs/nerf/base.json
+static uint32_t network_layer_width(uint32_t layer) { return (layer == 0u || layer == 2u) ? 32u : 64u; }
 static bool desc_supported(const nrs_model_desc& d) {
 	return d.n_levels == 16 && d.n_features_per_level == 2 && d.n_neurons == 64 && d.density_hidden_layers == 1 &&
 	       d.density_output_dims == 16 && d.rgb_hidden_layers == 2 && d.sh_degree == 4 && d.log2_hashmap_size >= 8 &&
@@ -180,7 +182,8 @@ static uint32_t make_levels(const nrs_model_desc& d, LevelParams* lv) {
 // Arrange the five row-major fp16 weight matrices (tcnn FullyFusedMLP: [out x in], no biases) as MFMA A operands
 // in the order nrs_mlp.cuh consumes them.  For fragment F, lane l = (i = l & 31, g = l >> 5), element e: the weight
 // of output unit (32*mb + i) for the input that the B operand's element e of lane-half g carries.
-static void make_weight_fragments(const uint16_t* w, uint16_t* frag) {
+// `one` = what the constant 1.0 is written as: 0x3C00 for real weights, kFragOne when the routine runs on the identity permutation (set_params_device).
+static void make_weight_fragments(const uint16_t* w, uint16_t* frag, uint16_t one = 0x3C00) {
 	const uint16_t* Wd1 = w;                 // [64 x 32]
 	const uint16_t* Wd2 = Wd1 + 64 * 32;     // [16 x 64]
 	const uint16_t* Wr1 = Wd2 + 16 * 64;     // [64 x 32]
@@ -188,10 +191,16 @@ static void make_weight_fragments(const uint16_t* w, uint16_t* frag) {
 	const uint16_t* Wr3 = Wr2 + 64 * 64;     // [16 x 64]
 	auto hidden_row = [](int mb, int g, int r) { return 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * g; }; // D-tile row of reg r
 	auto at = [&](int f, int lane, int e) -> uint16_t& { return frag[((size_t)f * 64 + lane) * 8 + e]; };
-	memset(frag, 0, kWfragBytes);
+	memset(frag, 0, kWfragDeviceBytes);
 	for (int lane = 0; lane < 64; ++lane) {
 		const int i = lane & 31, g = lane >> 5;
 		for (int e = 0; e < 8; ++e) {
+			// Sel0 / Sel1: row i of the product picks the packed accumulator that came out of D register e (Sel0) / 8 + e (Sel1) of lane-half g
+			at(24, lane, e) = i == hidden_row(0, g, e) ? one : (uint16_t)0;
+			at(25, lane, e) = i == hidden_row(0, g, 8 + e) ? one : (uint16_t)0;
+			// Bwd[ks]: dL/dfeatures[i] = sum_k W1[k][i] dL/dhidden[k] (density MLP, input gradient): output row i = feature i, the B operand of k step ks is
+			// the packed dL/dhidden in the layout the hidden layer's D tiles come out in (as for D2)
+			for (int ks = 0; ks < 4; ++ks) at(26 + ks, lane, e) = Wd1[hidden_row(ks >> 1, g, 8 * (ks & 1) + e) * 32 + i];
 			for (int mb = 0; mb < 2; ++mb)
 				for (int ks = 0; ks < 2; ++ks) {
 					const int feat = 2 * (2 * (4 * ks + (e >> 1)) + g) + (e & 1); // level 2*it+g, it = 4ks + e/2
@@ -388,7 +397,7 @@ int nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out) 
 	m->dm.rgb_activation = desc->rgb_activation;
 	m->dm.density_activation = desc->density_activation;
 	hipError_t he = hipMalloc((void**)&m->d_grid, (size_t)m->total_entries * 4);
-	if (he == hipSuccess) he = hipMalloc((void**)&m->d_wfrag, kWfragBytes);
+	if (he == hipSuccess) he = hipMalloc((void**)&m->d_wfrag, kWfragDeviceBytes);
 	if (he == hipSuccess) he = hipMalloc((void**)&m->d_bitfield, NRS_BITFIELD_BYTES);
 	if (he == hipSuccess) he = hipMalloc((void**)&m->d_accel_masks, 2 * kCoarseWords * 4 + 256); // + 24 floats of OccAccel numbers + 12 words of scratch (refresh_accel)
 	if (he == hipSuccess) he = hipMemset(m->d_accel_masks, 0, 2 * kCoarseWords * 4);
@@ -589,9 +598,9 @@ int nrs_model_set_params(nrs_model* m, const void* h_params_fp16, size_t n_param
 	}
 	HIP_TRY(hipSetDevice(m->ctx->device));
 	const uint16_t* w = (const uint16_t*)h_params_fp16;
-	std::vector<uint16_t> frag(kWfragBytes / 2);
+	std::vector<uint16_t> frag(kWfragDeviceBytes / 2);
 	make_weight_fragments(w, frag.data());
-	HIP_TRY(hipMemcpy(m->d_wfrag, frag.data(), kWfragBytes, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(m->d_wfrag, frag.data(), kWfragDeviceBytes, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(m->d_grid, w + kDensityW + kRgbW, (size_t)m->total_entries * 4, hipMemcpyHostToDevice));
 	m->have_params = true;
 	return rebuild_cell_cache(m);
@@ -615,18 +624,18 @@ int nrs_model_set_params_device(nrs_model* m, const void* d_params_fp16, size_t 
 	const uint16_t* d = (const uint16_t*)d_params_fp16;
 	if (!m->d_wfrag_src) { // the fragment permutation as indices: run the host routine on the identity (index + 1; 0 stays "padding")
 		static_assert(kDensityW + kRgbW < 65535, "weight indices fit 16 bits");
-		std::vector<uint16_t> ident(kDensityW + kRgbW), src(kWfragBytes / 2);
+		std::vector<uint16_t> ident(kDensityW + kRgbW), src(kWfragDeviceBytes / 2);
 		for (size_t i = 0; i < ident.size(); ++i) ident[i] = (uint16_t)(i + 1);
-		make_weight_fragments(ident.data(), src.data());
-		HIP_TRY(hipMalloc((void**)&m->d_wfrag_src, kWfragBytes));
-		const hipError_t up = hipMemcpy(m->d_wfrag_src, src.data(), kWfragBytes, hipMemcpyHostToDevice);
+		make_weight_fragments(ident.data(), src.data(), kFragOne);
+		HIP_TRY(hipMalloc((void**)&m->d_wfrag_src, kWfragDeviceBytes));
+		const hipError_t up = hipMemcpy(m->d_wfrag_src, src.data(), kWfragDeviceBytes, hipMemcpyHostToDevice);
 		if (up != hipSuccess) { // never keep a permutation that was not uploaded: later calls would scramble the weights silently
 			(void)hipFree(m->d_wfrag_src);
 			m->d_wfrag_src = nullptr;
 			return fail_hip(up, "nrs_model_set_params_device: upload of the weight permutation");
 		}
 	}
-	NRS_TRY(launch_weight_fragments(d, m->d_wfrag_src, (uint16_t*)m->d_wfrag, kWfragBytes / 2, stream));
+	NRS_TRY(launch_weight_fragments(d, m->d_wfrag_src, (uint16_t*)m->d_wfrag, kWfragDeviceBytes / 2, stream));
 	HIP_TRY(hipMemcpyAsync(m->d_grid, d + kDensityW + kRgbW, (size_t)m->total_entries * 4, hipMemcpyDeviceToDevice, s));
 	m->have_params = true;
 	return rebuild_cell_cache(m, stream, false);
@@ -759,6 +768,22 @@ int nrs_network_density(nrs_model* m, void* stream, uint32_t n, const float* d_i
 	if (layout == NRS_PLANES && ld_out < n) return fail(NRS_ERR_INVALID_ARG, "nrs_network_density: ld_out < n");
 	HIP_TRY(hipSetDevice(m->ctx->device));
 	NRS_TRY(launch_network(m->dm, 1, n, d_in, ld_in, d_out, ld_out, layout, m->ctx->n_cus, stream));
+	return NRS_OK;
+}
+int nrs_network_input_gradient(nrs_model* m, void* stream, uint32_t n, const float* d_in, uint32_t ld_in, float* d_grad_out) {
+	const int st = check_net(m, d_in, d_grad_out, "nrs_network_input_gradient");
+	if (st != NRS_OK) return st;
+	if (ld_in < 3) return fail(NRS_ERR_INVALID_ARG, "nrs_network_input_gradient: ld_in < 3");
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	NRS_TRY(launch_network(m->dm, 3, n, d_in, ld_in, d_grad_out, 3, 0, m->ctx->n_cus, stream));
+	return NRS_OK;
+}
+int nrs_network_visualize_activation(nrs_model* m, void* stream, uint32_t layer, uint32_t dimension, uint32_t n, const float* d_in, float* d_out) {
+	const int st = check_net(m, d_in, d_out, "nrs_network_visualize_activation");
+	if (st != NRS_OK) return st;
+	if (layer > 4u || dimension >= network_layer_width(layer)) return fail(NRS_ERR_INVALID_ARG, "nrs_network_visualize_activation: no such unit (layers 0..4 are 32 | 64 | 32 | 64 | 64 wide)");
+	HIP_TRY(hipSetDevice(m->ctx->device));
+	NRS_TRY(launch_network(m->dm, 4, n, d_in, NRS_NETWORK_INPUT_FLOATS, d_out, 1, (int)(layer | (dimension << 8)), m->ctx->n_cus, stream));
 	return NRS_OK;
 }
 int nrs_density_on_grid(nrs_model* m, void* stream, const uint32_t res3d[3], const float aabb_min[3], const float aabb_max[3], int mask_with_density_grid,
@@ -1248,15 +1273,15 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_render_nerf: parameters not set (nrs_model_set_params)");
 	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_render_nerf: occupancy not set (nrs_model_set_density_bitfield/_grid)");
 	{ const int pc = check_march_params(*p, "nrs_render_nerf"); if (pc != NRS_OK) return pc; }
-	if (p->render_mode == NRS_RENDER_NORMALS || p->render_mode == NRS_RENDER_ENCODING_VIS)
-		return fail(NRS_ERR_UNSUPPORTED, "nrs_render_nerf: render modes Normals (network input gradient) and EncodingVis (visualize_activation) need tiny-cuda-nn and are not on the path");
+	if (p->render_mode == NRS_RENDER_ENCODING_VIS && (p->visualized_layer > 4u || p->visualized_dimension >= network_layer_width(p->visualized_layer)))
+		return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: EncodingVis: visualized_layer is 0..4 (hash grid 32 | density hidden 64 | rgb input 32 | rgb hidden 64, 64) and visualized_dimension a unit of it");
 	if (!std::isfinite(p->glow_y_cutoff) || p->glow_mode > 31u) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: glow_mode is a 5-bit mask and glow_y_cutoff must be finite");
 	if (p->distortion_mode > 2u) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: distortion_mode must be 0 (None), 1 (Iterative) or 2 (FTheta)");
 	for (int i = 0; i < 7; ++i)
 		if (!std::isfinite(p->distortion_params[i])) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: distortion parameters must be finite");
 	if (p->d_envmap && (p->envmap_resolution[0] < 1 || p->envmap_resolution[1] < 1)) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: envmap without a resolution");
 	if (p->d_distortion_map && (p->distortion_resolution[0] < 1 || p->distortion_resolution[1] < 1)) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: distortion map without a resolution");
-	if (p->render_mode > NRS_RENDER_SLICE) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: unknown render mode");
+	if (p->render_mode > NRS_RENDER_SLICE && p->render_mode != NRS_RENDER_ENCODING_VIS) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: unknown render mode");
 	if (!std::isfinite(p->dof) || !std::isfinite(p->slice_plane_z) || !std::isfinite(p->depth_scale)) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: dof / slice_plane_z / depth_scale must be finite");
 	if (p->dof != 0.f && p->slice_plane_z == 0.f) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: dof != 0 needs a focus distance (slice_plane_z = m_slice_plane_z + m_scale != 0)");
 	if (n_edits < 0 || n_edits > nrs_ctx::kMaxEdits) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: too many edit operators");

@@ -993,6 +993,14 @@ __device__ __forceinline__ float network_to_density(float v, uint32_t act) {
 		default: return v;
 	}
 }
+__device__ __forceinline__ float network_to_density_derivative(float v, uint32_t act) { // tn:308-317
+	switch (act) {
+		case NRS_ACT_RELU: return v > 0.0f ? 1.0f : 0.0f;
+		case NRS_ACT_LOGISTIC: { const float density = 1.0f / (1.0f + __expf(-v)); return density * (1 - density); }
+		case NRS_ACT_EXPONENTIAL: return __expf(clampf_(v, -15.0f, 15.0f));
+		default: return 1.0f;
+	}
+}
 // x^2.4 as exp2(2.4 * log2 x) on the transcendental unit (v_log_f32 / v_exp_f32, ~1 ulp each): |rel. error| < 1e-5 on
 // (0.04, 1], far inside the stated colour tolerance, and ~100 instructions cheaper per channel than powf.
 __device__ __forceinline__ float srgb_to_linear(float s) {

@@ -36,9 +36,16 @@ struct LevelParams {
 
 // MFMA A-operand image of the five weight matrices: kNumFrags fragments of 64 lanes x 8 halfs (1 KiB each).
 // Fragment order (see nrs_mlp.cuh): D1[mb][ks] (4), D2[ks] (4), R1[mb][ks] (4), R2[mb][ks] (8), R3[ks] (4).
-constexpr uint32_t kNumFrags = 24;
+// Then two CONSTANT 0 / 1 fragments Sel0 / Sel1 (round 4): MFMA(Sel0, lo, 0) + MFMA(Sel1, hi, .) turn a D tile that was packed to fp16 (lo = rows of registers
+// 0..7, hi = 8..15) back into fp32 accumulator registers exactly -- the fp16-accumulator model (NRS_MLP_ACC_FP16) rounds the running sum after every k step,
+// and the way back from packed halfs through the matrix core costs two MFMA issues (the pipe is 10 % busy) instead of sixteen VALU conversions.
+// These 26 fragments are staged into LDS.  Behind them, in HBM only: Bwd[ks] (4), the A operands of dL/dfeatures = W1^T dL/dhidden (render mode Normals).
+constexpr uint32_t kNumFrags = 26;
+constexpr uint32_t kNumFragsDevice = 30;
 constexpr uint32_t kFragBytes = 64 * 8 * 2;
-constexpr uint32_t kWfragBytes = kNumFrags * kFragBytes; // 24 KiB
+constexpr uint32_t kWfragBytes = kNumFrags * kFragBytes; // 26 KiB: the LDS image
+constexpr uint32_t kWfragDeviceBytes = kNumFragsDevice * kFragBytes;
+constexpr uint16_t kFragOne = 0xffffu; // make_weight_fragments on the identity permutation: "the constant 1.0" (weight indices are < 65535)
 
 struct Box3 { float mn[3]; float mx[3]; };
 

@@ -235,7 +235,7 @@ __device__ __forceinline__ void issue_record_loads(const GridView& gv, const Lev
 	v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
 }
 #ifndef NRS_OPT_NETACC_MIX
-#define NRS_OPT_NETACC_MIX 1 // NETACC interpolation: per-corner products by v_fma_mix_f32 (0: convert + packed multiply, as the compiler lowers the plain expression)
+#define NRS_OPT_NETACC_MIX 1 // NETACC interpolation: per-corner products by v_fma_mix_f32 + one packed conversion (0: convert + packed multiply, as the compiler lowers the plain expression; 2: v_fma_mixlo/hi_f16, an experiment that is neither bit-exact nor faster)
 #endif
 #ifndef NRS_OPT_PKW
 #define NRS_OPT_PKW 1 // trilinear weights as packed fp32 products (v_pk_mul_f32: twelve products in six issue slots; 0: scalar products)
@@ -251,9 +251,18 @@ __device__ __forceinline__ uint32_t interpolate(const CellCoords& c, const uint3
 		#pragma unroll
 		for (int k = 0; k < 8; ++k) {
 			const float weight = wxy[k & 3] * ((k & 4) ? c.wz : uz);
-#if NRS_OPT_NETACC_MIX
-			// the two fp32 products straight from the packed fp16 entry (v_fma_mix_f32 with a zero addend: the product's own rounding; a product of -0 becomes
-			// +0, which no fp16 sum that starts at +0 can tell apart), one v_cvt_pk_f16_f32, one v_pk_add_f16: 4 issue slots per corner instead of 5
+#if NRS_OPT_NETACC_MIX == 2
+			// EXPERIMENT, not the shipped path: (T)(weight * (float)value) for both features by v_fma_mixlo_f16 / v_fma_mixhi_f16 (fp32 x fp16 -> fp16 into the low /
+			// high half of one register) + one v_pk_add_f16, 3 issue slots per corner.  Measured on the GPU (round 4): the features are NOT bit-identical to the
+			// oracle's two-step rounding (tests/test_gpu_numerics.py::test_operator_in_each_mode fails) and the frame is 2.5 % SLOWER than with NRS_OPT_NETACC_MIX=1
+			// (9.09 against 9.32 Gsamples/s: three dependent instructions per corner) -- profiles/r04/ab_numerics_variants.txt.
+			uint32_t pr = 0;
+			asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(pr) : "v"(weight), "v"(v[k]));
+			asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(pr) : "v"(weight), "v"(v[k]));
+			r = r + __builtin_bit_cast(half2v, pr);
+#elif NRS_OPT_NETACC_MIX == 1
+			// the two fp32 products straight from the packed fp16 entry (v_fma_mix_f32 with a zero addend: the product's own rounding), one v_cvt_pk_f16_f32,
+			// one v_pk_add_f16: 4 issue slots per corner
 			const half2v pr = {(_Float16)fma_mix_lo(weight, v[k], 0.f), (_Float16)fma_mix_hi(weight, v[k], 0.f)};
 			r = r + pr;
 #else
@@ -566,22 +575,57 @@ __device__ __forceinline__ floatx16 zero16() {
 }
 
 #define NRS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
-// ACC16 (nrs_mlp_acc FP16): the running sums are rounded to fp16 after every 16-wide k step, the model of tiny-cuda-nn's fp16 accumulator fragments
+#define NRS_FRAG_SEL(h) (24 + (h))
+#define NRS_FRAG_BWD(ks) (26 + (ks)) // (HBM only: DeviceModel::wfrag + ...; see nrs_internal.h)
+// ACC16 (nrs_mlp_acc FP16): the running sums are rounded to fp16 after every 16-wide k step, the model of tiny-cuda-nn's fp16 accumulator fragments.
+// NRS_OPT_ACC16_SEL (round 4): the rounded sums go back into the accumulator registers THROUGH THE MATRIX CORE -- pack to fp16 (8 v_cvt_pk_f16_f32: the
+// rounding), then MFMA(Sel0, lo, 0) and MFMA(Sel1, hi, .) with the two constant 0 / 1 fragments, which reproduce the packed values exactly in fp32
+// (1.0 x h summed with zeros) in the D layout -- and the k step's own MFMA accumulates on top as before.  8 VALU slots per rounding instead of 24-32 on a
+// kernel that is VALU-bound, paid with two issues on a pipe that is 10 % busy; same values (tests/test_gpu_numerics.py; A/B: NRS_OPT_ACC16_SEL=0).
+#ifndef NRS_OPT_ACC16_SEL
+#define NRS_OPT_ACC16_SEL 1
+#endif
+#ifndef NRS_ACC16_FENCE
+#define NRS_ACC16_FENCE 1
+#endif
 template <bool ACC16>
-__device__ __forceinline__ floatx16 mfma_step(half8 a, half8 b, floatx16 c) {
-	floatx16 d = NRS_MFMA(a, b, c);
+__device__ __forceinline__ floatx16 mfma_step(const half8* lds_w, int lane, half8 a, half8 b, floatx16 c) {
+#if NRS_OPT_ACC16_SEL
+	if (ACC16) {
+		half8 lo, hi;
+		#pragma unroll
+		for (int e = 0; e < 8; ++e) { lo[e] = (_Float16)c[e]; hi[e] = (_Float16)c[8 + e]; }
+		floatx16 z;
+		#pragma unroll
+		for (int i = 0; i < 16; ++i) z[i] = 0.f;
+#if NRS_ACC16_FENCE
+		__builtin_amdgcn_sched_barrier(0); // (keeps the selection fragments' LDS reads of later steps from being hoisted over this one: registers)
+#endif
+		c = NRS_MFMA(lds_w[NRS_FRAG_SEL(0) * 64 + lane], lo, z);
+		c = NRS_MFMA(lds_w[NRS_FRAG_SEL(1) * 64 + lane], hi, c);
+	}
+	return NRS_MFMA(a, b, c);
+#else
 	if (ACC16) {
 		// round-trip through PACKED halfs: 8 v_cvt_pk_f16_f32 + 16 v_cvt_f32_f16 (the odd ones read the high half through SDWA) instead of 16 + 16 scalar
 		// conversions -- the same round-to-nearest-even values.  (The opaque copy keeps the compiler from splitting the pair again.)
 		#pragma unroll
 		for (int i = 0; i < 8; ++i) {
-			half2v h = {(_Float16)d[2 * i], (_Float16)d[2 * i + 1]};
+			half2v h = {(_Float16)c[2 * i], (_Float16)c[2 * i + 1]};
 			asm volatile("" : "+v"(h));
-			d[2 * i] = (float)h[0];
-			d[2 * i + 1] = (float)h[1];
+			c[2 * i] = (float)h[0];
+			c[2 * i + 1] = (float)h[1];
 		}
 	}
-	return d;
+	return NRS_MFMA(a, b, c);
+#endif
+}
+// the first k step of a layer: nothing to round yet
+__device__ __forceinline__ floatx16 mfma_first(half8 a, half8 b) {
+	floatx16 z;
+	#pragma unroll
+	for (int i = 0; i < 16; ++i) z[i] = 0.f;
+	return NRS_MFMA(a, b, z);
 }
 // Scheduling fence between MLP stages: without it hipcc hoists all 24 weight-fragment LDS reads (96 VGPRs) to the top of
 // the MLP, which costs a wave of occupancy.  The gather, not the MLP, is the phase that needs the latency hiding.
@@ -592,21 +636,19 @@ __device__ __forceinline__ floatx16 mfma_step(half8 a, half8 b, floatx16 c) {
 template <bool ACC16 = false>
 __device__ __forceinline__ half8 density_mlp(const half8* lds_w, int lane, half8 x0, half8 x1) {
 	// hidden rows 0..31 then 32..63, each reduced to its two packed B operands before the next accumulator is started
-	floatx16 h = zero16();
-	h = mfma_step<ACC16>(lds_w[NRS_FRAG_D1(0, 0) * 64 + lane], x0, h);
-	h = mfma_step<ACC16>(lds_w[NRS_FRAG_D1(0, 1) * 64 + lane], x1, h);
+	// (ACC16: mfma_step rounds the sum it is handed before it adds its own k step; the last sum of a layer is rounded by relu_pack / pack themselves)
+	floatx16 h = mfma_first(lds_w[NRS_FRAG_D1(0, 0) * 64 + lane], x0);
+	h = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_D1(0, 1) * 64 + lane], x1, h);
 	const half8 p0 = relu_pack(h, 0), p1 = relu_pack(h, 8);
 	NRS_STAGE_FENCE();
-	h = zero16();
-	h = mfma_step<ACC16>(lds_w[NRS_FRAG_D1(1, 0) * 64 + lane], x0, h);
-	h = mfma_step<ACC16>(lds_w[NRS_FRAG_D1(1, 1) * 64 + lane], x1, h);
+	h = mfma_first(lds_w[NRS_FRAG_D1(1, 0) * 64 + lane], x0);
+	h = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_D1(1, 1) * 64 + lane], x1, h);
 	const half8 p2 = relu_pack(h, 0), p3 = relu_pack(h, 8);
 	NRS_STAGE_FENCE();
-	floatx16 o = zero16();
-	o = mfma_step<ACC16>(lds_w[NRS_FRAG_D2(0) * 64 + lane], p0, o);
-	o = mfma_step<ACC16>(lds_w[NRS_FRAG_D2(1) * 64 + lane], p1, o);
-	o = mfma_step<ACC16>(lds_w[NRS_FRAG_D2(2) * 64 + lane], p2, o);
-	o = mfma_step<ACC16>(lds_w[NRS_FRAG_D2(3) * 64 + lane], p3, o);
+	floatx16 o = mfma_first(lds_w[NRS_FRAG_D2(0) * 64 + lane], p0);
+	o = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_D2(1) * 64 + lane], p1, o);
+	o = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_D2(2) * 64 + lane], p2, o);
+	o = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_D2(3) * 64 + lane], p3, o);
 	NRS_STAGE_FENCE();
 	return pack(o, 0);
 }
@@ -614,37 +656,151 @@ __device__ __forceinline__ half8 density_mlp(const half8* lds_w, int lane, half8
 // RGB MLP [density out 16 | SH 16] -> 64 -> 64 -> 16 (3 used) for one block.  Same output row map.
 template <bool ACC16 = false>
 __device__ __forceinline__ half8 rgb_mlp(const half8* lds_w, int lane, half8 din, half8 sh) {
-	floatx16 a = zero16();
-	a = mfma_step<ACC16>(lds_w[NRS_FRAG_R1(0, 0) * 64 + lane], din, a);
-	a = mfma_step<ACC16>(lds_w[NRS_FRAG_R1(0, 1) * 64 + lane], sh, a);
+	floatx16 a = mfma_first(lds_w[NRS_FRAG_R1(0, 0) * 64 + lane], din);
+	a = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R1(0, 1) * 64 + lane], sh, a);
 	const half8 b0 = relu_pack(a, 0), b1 = relu_pack(a, 8);
 	NRS_STAGE_FENCE();
-	a = zero16();
-	a = mfma_step<ACC16>(lds_w[NRS_FRAG_R1(1, 0) * 64 + lane], din, a);
-	a = mfma_step<ACC16>(lds_w[NRS_FRAG_R1(1, 1) * 64 + lane], sh, a);
+	a = mfma_first(lds_w[NRS_FRAG_R1(1, 0) * 64 + lane], din);
+	a = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R1(1, 1) * 64 + lane], sh, a);
 	const half8 b2 = relu_pack(a, 0), b3 = relu_pack(a, 8);
 	NRS_STAGE_FENCE();
-	floatx16 c = zero16();
-	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(0, 0) * 64 + lane], b0, c);
-	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(0, 1) * 64 + lane], b1, c);
-	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(0, 2) * 64 + lane], b2, c);
-	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(0, 3) * 64 + lane], b3, c);
+	floatx16 c = mfma_first(lds_w[NRS_FRAG_R2(0, 0) * 64 + lane], b0);
+	c = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(0, 1) * 64 + lane], b1, c);
+	c = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(0, 2) * 64 + lane], b2, c);
+	c = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(0, 3) * 64 + lane], b3, c);
 	const half8 q0 = relu_pack(c, 0), q1 = relu_pack(c, 8);
 	NRS_STAGE_FENCE();
-	c = zero16();
-	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(1, 0) * 64 + lane], b0, c);
-	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(1, 1) * 64 + lane], b1, c);
-	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(1, 2) * 64 + lane], b2, c);
-	c = mfma_step<ACC16>(lds_w[NRS_FRAG_R2(1, 3) * 64 + lane], b3, c);
+	c = mfma_first(lds_w[NRS_FRAG_R2(1, 0) * 64 + lane], b0);
+	c = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(1, 1) * 64 + lane], b1, c);
+	c = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(1, 2) * 64 + lane], b2, c);
+	c = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(1, 3) * 64 + lane], b3, c);
 	const half8 q2 = relu_pack(c, 0), q3 = relu_pack(c, 8);
 	NRS_STAGE_FENCE();
-	floatx16 o = zero16();
-	o = mfma_step<ACC16>(lds_w[NRS_FRAG_R3(0) * 64 + lane], q0, o);
-	o = mfma_step<ACC16>(lds_w[NRS_FRAG_R3(1) * 64 + lane], q1, o);
-	o = mfma_step<ACC16>(lds_w[NRS_FRAG_R3(2) * 64 + lane], q2, o);
-	o = mfma_step<ACC16>(lds_w[NRS_FRAG_R3(3) * 64 + lane], q3, o);
+	floatx16 o = mfma_first(lds_w[NRS_FRAG_R3(0) * 64 + lane], q0);
+	o = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R3(1) * 64 + lane], q1, o);
+	o = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R3(2) * 64 + lane], q2, o);
+	o = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R3(3) * 64 + lane], q3, o);
 	NRS_STAGE_FENCE();
 	return pack(o, 0);
+}
+
+// ---- network introspection: render modes EncodingVis and Normals (render_body's INTRO instantiation only) ----------------------------------------
+// tiny-cuda-nn's visualize_activation / input_gradient as restated in oracle/nrs_oracle.cpp (network_activation_one, density_input_gradient_one).
+// register r (wave-uniform) of a D tile
+__device__ __forceinline__ float pick16(const floatx16& d, int r) {
+	float v = d[0];
+	#pragma unroll
+	for (int i = 1; i < 16; ++i) v = (r == i) ? d[i] : v;
+	return v;
+}
+__device__ __forceinline__ _Float16 pick8(const half8& h, int e) {
+	_Float16 v = h[0];
+	#pragma unroll
+	for (int i = 1; i < 8; ++i) v = (e == i) ? h[i] : v;
+	return v;
+}
+// Activation `unit` of hidden layer `layer` (1: density MLP hidden, 3 / 4: rgb MLP hidden 1 / 2) for one 32-sample block: the value of sample column j sits,
+// after the call, in the lanes whose half (lane >> 5) equals tile_half(unit); the other half returns another row.  din = density_mlp's output (layers 3, 4).
+__device__ __forceinline__ int tile_half(uint32_t unit) { return (int)((unit >> 2) & 1u); }
+template <bool ACC16>
+__device__ __forceinline__ float mlp_hidden_activation(const half8* lds_w, int lane, half8 x0, half8 x1, half8 din, half8 sh, uint32_t layer, uint32_t unit) {
+	const int mb = (int)((unit >> 5) & 1u), R = (int)(unit & 31u), r = (R & 3) + 4 * (R >> 3); // D register of row R in its lane half
+	floatx16 t;
+	if (layer == 1u) {
+		t = mfma_first(lds_w[NRS_FRAG_D1(mb, 0) * 64 + lane], x0);
+		t = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_D1(mb, 1) * 64 + lane], x1, t);
+	} else if (layer == 3u) {
+		t = mfma_first(lds_w[NRS_FRAG_R1(mb, 0) * 64 + lane], din);
+		t = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R1(mb, 1) * 64 + lane], sh, t);
+	} else {
+		floatx16 a = mfma_first(lds_w[NRS_FRAG_R1(0, 0) * 64 + lane], din);
+		a = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R1(0, 1) * 64 + lane], sh, a);
+		const half8 b0 = relu_pack(a, 0), b1 = relu_pack(a, 8);
+		NRS_STAGE_FENCE();
+		a = mfma_first(lds_w[NRS_FRAG_R1(1, 0) * 64 + lane], din);
+		a = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R1(1, 1) * 64 + lane], sh, a);
+		const half8 b2 = relu_pack(a, 0), b3 = relu_pack(a, 8);
+		NRS_STAGE_FENCE();
+		t = mfma_first(lds_w[NRS_FRAG_R2(mb, 0) * 64 + lane], b0);
+		t = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(mb, 1) * 64 + lane], b1, t);
+		t = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(mb, 2) * 64 + lane], b2, t);
+		t = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(mb, 3) * 64 + lane], b3, t);
+	}
+	NRS_STAGE_FENCE();
+	const _Float16 h = (_Float16)pick16(t, r);
+	return (float)(h > (_Float16)0 ? h : (_Float16)0); // the stored activation: ReLU, fp16
+}
+// Backward of 128 * e_0 through the density MLP for one 32-sample block (input_gradient(stream, 3, ...): the one-hot lands on the density network's output
+// row 0, nerf_network_full.h:188-195): dL/dhidden[k] = (hidden[k] > 0) * fp16(W2[0][k] * 128) in the layout of the hidden tiles, then
+// dL/dfeatures = W1^T dL/dhidden on MFMA (A operands Bwd[ks] from HBM: DeviceModel::wfrag), accumulated as the forward pass is (ACC16).
+// out[q] = features (2 L, 2 L + 1) packed, L = level_of_pair(q, lane >> 5), of sample column j.
+__device__ __forceinline__ int level_of_pair(int q, int gg) { const int r = 2 * q; return ((r & 3) + 8 * (r >> 2) + 4 * gg) >> 1; }
+template <bool ACC16>
+__device__ __forceinline__ void density_backward_features(const half8* lds_w, const half8* __restrict__ gfrag, int lane, half8 x0, half8 x1, uint32_t out[8]) {
+	floatx16 h = mfma_first(lds_w[NRS_FRAG_D1(0, 0) * 64 + lane], x0);
+	h = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_D1(0, 1) * 64 + lane], x1, h);
+	const half8 p0 = relu_pack(h, 0), p1 = relu_pack(h, 8);
+	NRS_STAGE_FENCE();
+	h = mfma_first(lds_w[NRS_FRAG_D1(1, 0) * 64 + lane], x0);
+	h = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_D1(1, 1) * 64 + lane], x1, h);
+	const half8 p2 = relu_pack(h, 0), p3 = relu_pack(h, 8);
+	NRS_STAGE_FENCE();
+	// W2[0][k] for the k's this lane's hidden registers stand for: what lane (0, lane >> 5) of the D2 fragments holds (output row 0)
+	const int row0 = lane & 32;
+	auto dhidden = [&](const half8& p, int ks) {
+		const half8 w = lds_w[NRS_FRAG_D2(ks) * 64 + row0];
+		half8 q;
+		#pragma unroll
+		for (int e = 0; e < 8; ++e) q[e] = p[e] > (_Float16)0 ? (_Float16)(w[e] * (_Float16)128) : (_Float16)0; // x 128 in fp16: the same value as fp16(float(w) * 128)
+		return q;
+	};
+	const half8 q0 = dhidden(p0, 0), q1 = dhidden(p1, 1), q2 = dhidden(p2, 2), q3 = dhidden(p3, 3);
+	NRS_STAGE_FENCE();
+	floatx16 d = mfma_first(gfrag[NRS_FRAG_BWD(0) * 64 + lane], q0);
+	d = mfma_step<ACC16>(lds_w, lane, gfrag[NRS_FRAG_BWD(1) * 64 + lane], q1, d);
+	d = mfma_step<ACC16>(lds_w, lane, gfrag[NRS_FRAG_BWD(2) * 64 + lane], q2, d);
+	d = mfma_step<ACC16>(lds_w, lane, gfrag[NRS_FRAG_BWD(3) * 64 + lane], q3, d);
+	NRS_STAGE_FENCE();
+	#pragma unroll
+	for (int q = 0; q < 8; ++q) {
+		half2v pr = {(_Float16)d[2 * q], (_Float16)d[2 * q + 1]};
+		out[q] = __builtin_bit_cast(uint32_t, pr);
+	}
+}
+// kernel_grid's dy_dx and kernel_grid_backward_input for ONE level of one sample (tiny-cuda-nn grid.h as restated in hashgrid_input_gradient_one):
+// result[d] += (float)dL_dy[f] * sum over the 4 corner pairs along d of scale * w(other two dims) * (right - left), fp32 with fmaf.  The 8 corners are
+// fetched with the level's own (exact) index function.  dl = (dL_dy[2 L], dL_dy[2 L + 1]) packed.
+__device__ __forceinline__ void level_input_gradient(const GridView& gv, const LevelParams& lp, f3 pos, uint32_t dl, float result[3]) {
+	const CellCoords c = cell_coords(lp, pos);
+	uint32_t v[8];
+	#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const uint32_t cx = c.gx + (k & 1), cy = c.gy + ((k >> 1) & 1), cz = c.gz + ((k >> 2) & 1);
+		uint32_t index = lp.hashed ? ((cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u)) : (cx + cy * lp.resolution + cz * lp.res2);
+		index %= lp.count;
+		v[k] = grid_load(gv, lp.offset + index);
+	}
+	const float w[3] = {c.wx, c.wy, c.wz};
+	const half2v dlh = __builtin_bit_cast(half2v, dl);
+	float grads[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+	#pragma unroll
+	for (int gd = 0; gd < 3; ++gd) {
+		const int da = gd == 0 ? 1 : 0, db = gd == 2 ? 1 : 2; // the two other dimensions, ascending
+		#pragma unroll
+		for (int idx = 0; idx < 4; ++idx) {
+			float weight = lp.scale;
+			weight *= (idx & 1) ? w[da] : 1 - w[da];
+			weight *= (idx & 2) ? w[db] : 1 - w[db];
+			const int left = ((idx & 1) << da) | (((idx >> 1) & 1) << db), right = left | (1 << gd);
+			const half2v hl = __builtin_bit_cast(half2v, v[left]), hr = __builtin_bit_cast(half2v, v[right]);
+			grads[0][gd] = fmaf(weight, (float)hr[0] - (float)hl[0], grads[0][gd]);
+			grads[1][gd] = fmaf(weight, (float)hr[1] - (float)hl[1], grads[1][gd]);
+		}
+	}
+	#pragma unroll
+	for (int f = 0; f < 2; ++f)
+		#pragma unroll
+		for (int d = 0; d < 3; ++d) result[d] = fmaf((float)dlh[f], grads[f][d], result[d]);
 }
 
 // tiny-cuda-nn's roundings as a template value: NUM >= 0 fixes them at compile time (bit 0 grid accumulation in network precision, bit 1 fp16 MLP

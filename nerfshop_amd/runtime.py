@@ -188,6 +188,22 @@ class NerfNetwork:
         layout, ld = self._out_layout(output, n)
         check(self.lib.nrs_network_density(self.h, _stream_handle(stream), n, input.data_ptr(), input.shape[1], output.data_ptr(), ld, layout))
 
+    def input_gradient(self, stream, input, output):
+        """NerfNetwork::input_gradient(stream, 3, input, output): d density_raw / d position, input [n, >= 3] f32, output [n, 3] f32 (cuda tensors)."""
+        _require_cuda(input, torch.float32, "input")
+        _require_cuda(output, torch.float32, "output")
+        n = input.shape[0]
+        assert output.shape == (n, 3) and output.is_contiguous() and input.is_contiguous()
+        check(self.lib.nrs_network_input_gradient(self.h, _stream_handle(stream), n, input.data_ptr(), input.shape[1], output.data_ptr()))
+
+    def visualize_activation(self, stream, layer, dimension, input, output):
+        """Network::visualize_activation: unit `dimension` of forward_activations(layer), input [n, 7] f32, output [n] f32 (cuda tensors)."""
+        _require_cuda(input, torch.float32, "input")
+        _require_cuda(output, torch.float32, "output")
+        n = input.shape[0]
+        assert input.shape[1] == 7 and output.shape == (n,) and output.is_contiguous() and input.is_contiguous()
+        check(self.lib.nrs_network_visualize_activation(self.h, _stream_handle(stream), int(layer), int(dimension), n, input.data_ptr(), output.data_ptr()))
+
     def hashgrid_encode(self, stream, input, output):
         _require_cuda(input, torch.float32, "input")
         _require_cuda(output, torch.float16, "output")

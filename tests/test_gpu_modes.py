@@ -7,7 +7,7 @@ oracle, which tests/test_ref_pin.py pins bit for bit to the reference's own comp
   * render mode Slice (:3067-3070, 3109-3162).
   * the camera model and the background: OpenCV (iterative) and f-theta lens distortion, the distortion map, the environment map, render mode
     Distortion (init_rays_with_payload_kernel_nerf :2523-2613, common_device.cuh:146-243, 262-280, envmap.cuh:30-63).
-Normals / EncodingVis (tiny-cuda-nn's input gradient / visualize_activation) are refused.
+Normals / EncodingVis (tiny-cuda-nn's input gradient / visualize_activation, restated): tests/test_gpu_introspection.py.
 
 Tolerances.  The modes replace the network's colour by a function of the (bit-exact) sample position, so the frame bar is the Shade bar
 (6e-3 max, 2e-4 mean) scaled by the magnitude of the colours a mode produces (depths and distances in scene units).  Depth of field is the one
@@ -185,8 +185,8 @@ def test_slice_on_tiles(rig):
 
 
 def test_modes_through_every_boundary_flavour(rig):
-    """a mode with forced lane-team settings (the EXTRA instantiation is one lane per ray whatever the context asks for); Normals / EncodingVis /
-    unknown modes, an unknown lens model and a lens without a focus distance are refused"""
+    """a mode with forced lane-team settings (the EXTRA instantiation is one lane per ray whatever the context asks for); unknown modes, an unknown lens
+    model, a lens without a focus distance and a parameter struct of another size are refused"""
     from nerfshop_amd._abi import NrsError
     rig.use_edit(True)
     try:
@@ -196,7 +196,7 @@ def test_modes_through_every_boundary_flavour(rig):
             rig.ctx.set_lane_teams(team)
             _compare(rig.render(p), ref)
         rig.ctx.set_lane_teams(0)
-        for bad in (NORMALS, 10, 11, 12):   # Normals, NumRenderModes, EncodingVis, out of range
+        for bad in (10, 12):   # NumRenderModes, out of range (Normals = 2 and EncodingVis = 11 are modes since round 4: tests/test_gpu_introspection.py)
             with pytest.raises(NrsError):
                 rig.render(_params(rig, 64, 36, 60.0, render_mode=bad))
         with pytest.raises(NrsError):
