@@ -624,7 +624,28 @@ __device__ __forceinline__ void bary_tet(f3 a, f3 b, f3 c, f3 d, f3 p, float out
 	float v6 = (float)(1. / (double)scalar_tp(vab, vac, vad)); // the reference divides in double ("1. / float")
 	out[0] = va6 * v6; out[1] = vb6 * v6; out[2] = vc6 * v6; out[3] = vd6 * v6;
 }
-__device__ __forceinline__ f3 ld3(const float* __restrict__ a, uint32_t i) { return {a[3 * i], a[3 * i + 1], a[3 * i + 2]}; }
+// The operator tables are reached through pointers that sit in a device-memory struct (DeviceEdit): left alone, the compiler cannot tell their address
+// space and emits FLAT loads (an aperture check per access, both wait counters) with one 64-bit address computation per dword.  They are global memory:
+// NRS_OPT_GLOBAL_EDIT casts them so (global_load), and a vertex / matrix column is one 12-byte load.
+#ifndef NRS_OPT_GLOBAL_EDIT
+#define NRS_OPT_GLOBAL_EDIT 1
+#endif
+#if NRS_OPT_GLOBAL_EDIT
+#define NRS_GLOBAL __attribute__((address_space(1)))
+#else
+#define NRS_GLOBAL
+#endif
+template <typename T>
+__device__ __forceinline__ const NRS_GLOBAL T* gp(const T* p) { return (const NRS_GLOBAL T*)p; }
+__device__ __forceinline__ f3 ld3(const float* __restrict__ a, uint32_t i) {
+#if NRS_OPT_GLOBAL_EDIT
+	typedef float f3a __attribute__((ext_vector_type(3), aligned(4)));
+	const f3a v = *(const NRS_GLOBAL f3a*)(gp(a) + 3 * (size_t)i);
+	return {v.x, v.y, v.z};
+#else
+	return {a[3 * i], a[3 * i + 1], a[3 * i + 2]};
+#endif
+}
 
 // point_in_tet with the per-tet part of same_side_tet hoisted out of the sample loop, and the tet's own vertices stored next to
 // it: tet_planes_kernel writes one 128-byte record per tet -- vertices v_0..v_3 (12 floats), normal_f = cross(v_{f+1} - v_f,
@@ -632,8 +653,9 @@ __device__ __forceinline__ f3 ld3(const float* __restrict__ a, uint32_t i) { ret
 // computes, so dot(normal_f, p - v_f) and the sign comparison are bit-identical to the direct evaluation.  One cache line per
 // candidate instead of the tets[] -> vertices[] chain, and a quarter of the arithmetic.
 __device__ __forceinline__ bool point_in_tet_rec(const float* __restrict__ recs, uint32_t t, f3 p) {
-	const float4* q = reinterpret_cast<const float4*>(recs) + 8 * (size_t)t;
-	const float4 v0 = q[0], v1 = q[1], v2 = q[2], n0 = q[3], n1 = q[4], n2 = q[5], sg = q[6];
+	typedef float f4n __attribute__((ext_vector_type(4))); // (a native vector: HIP's float4 is a class whose copy constructor wants a generic reference)
+	const NRS_GLOBAL f4n* q = gp(reinterpret_cast<const f4n*>(recs)) + 8 * (size_t)t;
+	const f4n v0 = q[0], v1 = q[1], v2 = q[2], n0 = q[3], n1 = q[4], n2 = q[5], sg = q[6];
 	const float d0 = dot3(mk3(n0.x, n0.y, n0.z), p - mk3(v0.x, v0.y, v0.z));
 	const float d1 = dot3(mk3(n0.w, n1.x, n1.y), p - mk3(v0.w, v1.x, v1.y));
 	const float d2 = dot3(mk3(n1.z, n1.w, n2.x), p - mk3(v1.z, v1.w, v2.x));
@@ -643,13 +665,15 @@ __device__ __forceinline__ bool point_in_tet_rec(const float* __restrict__ recs,
 }
 // first tet of the cell's list that contains p (0xffffffff: none); the next candidate's id is fetched while the current one is tested
 __device__ __forceinline__ uint32_t scan_cell_for_tet(const DeviceEdit& e, uint32_t cell, f3 p) {
-	const uint32_t j0 = e.lut_off[cell], j1 = e.lut_off[cell + 1];
+	const NRS_GLOBAL uint32_t* lut_off = gp(e.lut_off);
+	const NRS_GLOBAL uint32_t* lut_idx = gp(e.lut_idx);
+	const uint32_t j0 = lut_off[cell], j1 = lut_off[cell + 1];
 	uint32_t found = 0xffffffffu;
 	if (j0 < j1) {
-		uint32_t t = e.lut_idx[j0];
+		uint32_t t = lut_idx[j0];
 		#pragma unroll 1
 		for (uint32_t j = j0; j < j1; ++j) {
-			const uint32_t t_next = e.lut_idx[min(j + 1, j1 - 1)];
+			const uint32_t t_next = lut_idx[min(j + 1, j1 - 1)];
 			if (point_in_tet_rec(e.planes, t, p)) { found = t; break; }
 			t = t_next;
 		}
@@ -661,16 +685,23 @@ __device__ __forceinline__ uint32_t scan_cell_for_tet(const DeviceEdit& e, uint3
 // [0,1] values of the NerfCoordinate; returns true if the sample must be treated as empty space.
 // Two phases on purpose: the LUT scan only decides WHICH tet contains the sample; the barycentric map-back reloads that
 // tet's vertices afterwards.  Fusing them keeps ~48 more VGPRs live across the scan and costs the kernel a wave of occupancy.
-__device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3& wpos, f3& wdir) {
+// march_lds (optional): the kernel's LDS copy of the Morton spread table (stage_march_lds) -- the cell index then costs three LDS reads instead of 28 VALU
+// instructions (the same index: occupancy_bit_index is cascaded_grid_idx_at through the table)
+#ifndef NRS_OPT_WARP_MORTON
+#define NRS_OPT_WARP_MORTON 1
+#endif
+__device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3& wpos, f3& wdir, const uint32_t* __restrict__ march_lds = nullptr) {
 	bool in_deformed = false;
 	if (box_contains(e.warped_bbox, wpos)) {
 		const f3 u = unwarp_position(wpos, e.aabb);
 		const int level = mip_from_pos(u);
-		const uint32_t cell = (uint32_t)level * kGridVol + cascaded_grid_idx_at(u, (uint32_t)level);
+		const uint32_t cell = (NRS_OPT_WARP_MORTON && march_lds) ? occupancy_bit_index(u, (uint32_t)level, march_lds)
+		                                                         : (uint32_t)level * kGridVol + cascaded_grid_idx_at(u, (uint32_t)level);
 		const uint32_t found = scan_cell_for_tet(e, cell, u);
 		__builtin_amdgcn_sched_barrier(0);
 		if (found != 0xffffffffu) {
-			const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[found];
+			typedef uint32_t u4n __attribute__((ext_vector_type(4)));
+			const u4n tv = gp(reinterpret_cast<const u4n*>(e.tets))[found];
 			float bc[4];
 			{
 				const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), d = ld3(e.verts, tv.w);
@@ -685,7 +716,12 @@ __device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3&
 			__builtin_amdgcn_sched_barrier(0);
 			if (with_dir && e.rot) {
 				const f3 ud = unwarp_direction(wdir);
+#if NRS_OPT_GLOBAL_EDIT
+				const f3 c0 = ld3(e.rot, 3u * found), c1 = ld3(e.rot, 3u * found + 1u), c2 = ld3(e.rot, 3u * found + 2u); // the three columns
+				const float R[9] = {c0.x, c0.y, c0.z, c1.x, c1.y, c1.z, c2.x, c2.y, c2.z};
+#else
 				const float* R = e.rot + 9 * (size_t)found;
+#endif
 				const f3 rd = mat3_mul(R, ud);
 				wdir = warp_direction(rd);
 			}
@@ -698,7 +734,7 @@ __device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3&
 			const f3 u = unwarp_position(wpos, e.aabb);
 			const int level = mip_from_pos(u);
 			const uint32_t pos_idx = cascaded_grid_idx_at(u, (uint32_t)level);
-			empty = get_bitfield_at(pos_idx, (uint32_t)level, e.orig_bitfield);
+			empty = gp(e.orig_bitfield)[pos_idx / 8 + (kGridVol * (uint32_t)level) / 8] & (1 << (pos_idx % 8)); // get_bitfield_at
 		}
 	}
 	return empty;

@@ -40,6 +40,10 @@ static int hip_fail(hipError_t e, const char* what) {
 		if (e_ != hipSuccess) return hip_fail(e_, what);     \
 	} while (0)
 
+// The hand-over words in LDS are polled and published with relaxed atomics: a `volatile` access through a generic pointer loses the LDS address space and
+// becomes a FLAT load (aperture check, both wait counters) -- one per round at the top of the frame loop.
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void lds_poke(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 constexpr int kRing = 128; // pending-ray ring entries per wave (>= 63 + 64)
 // A wave takes new rays only when this many of its lanes are idle.  64 = "generations": all lanes are (re)filled at once with the hits
 // of the next few neighbouring packets, the rays then advance in step -- similar depth, neighbouring pixels -- and the wave's
@@ -318,14 +322,14 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		// The state of a ray at this point is its lead lane's registers (as for re-teaming): same float operations afterwards, same bits.
 		// (A wave in the middle of a generation does not look at the queue; a waiting sibling is how it learns that the queue is dry.)
 		// Rays that wait in this wave's ring for its next generation go first (two words per ray, copied into the sibling's ring: it starts them at once).
-		if (TEAM == 0 && a1.steal && __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&sm.idle_mask) != 0) {
+		if (TEAM == 0 && a1.steal && __builtin_amdgcn_readfirstlane((int)lds_peek(&sm.idle_mask)) != 0) {
 			more = false;
 			int ln = lane; // (opaque copy: lane predicates of this rare block are then formed here, not hoisted into scalar-register pairs that live through the frame loop)
 			asm volatile("" : "+v"(ln));
 			auto claim_waiting_wave = [&]() -> uint32_t { // the wave whose bit this wave clears is this wave's to serve: it waits for the mail
 				uint32_t target = 0xffffffffu;
 				if (ln == 0) {
-					uint32_t idle = *(volatile uint32_t*)&sm.idle_mask;
+					uint32_t idle = lds_peek(&sm.idle_mask);
 					while (idle) {
 						const uint32_t w = (uint32_t)__builtin_ctz(idle), bit = 1u << w;
 						const uint32_t old = atomicAnd(&sm.idle_mask, ~bit);
@@ -346,7 +350,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 						ring_count -= n;
 						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 						__builtin_amdgcn_wave_barrier();
-						if (ln == 0) { *(volatile uint32_t*)&sm.mail[target] = n | 0x80000000u; atomicAdd(&a1.counters->walk[7], (unsigned long long)n | (1ull << 32)); }
+						if (ln == 0) { lds_poke(&sm.mail[target], n | 0x80000000u); atomicAdd(&a1.counters->walk[7], (unsigned long long)n | (1ull << 32)); }
 					}
 				}
 			} else if (ring_count == 0u) {
@@ -371,7 +375,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					if (moved) have = false;
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 					__builtin_amdgcn_wave_barrier();
-					if (ln == 0) { *(volatile uint32_t*)&sm.mail[target] = give; atomicAdd(&a1.counters->walk[7], (unsigned long long)give | (1ull << 32)); }
+					if (ln == 0) { lds_poke(&sm.mail[target], give); atomicAdd(&a1.counters->walk[7], (unsigned long long)give | (1ull << 32)); }
 				}
 			}
 		}
@@ -529,9 +533,9 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					atomicSub(&sm.n_busy, 1u);
 					bool promised = false; // a sibling has cleared this wave's bit: its rays are on their way
 					for (;;) {
-						got = *(volatile uint32_t*)&sm.mail[wave];
+						got = lds_peek(&sm.mail[wave]);
 						if (got) break;
-						if (!promised && *(volatile uint32_t*)&sm.n_busy == 0u) {
+						if (!promised && lds_peek(&sm.n_busy) == 0u) {
 							if (atomicAnd(&sm.idle_mask, ~bit) & bit) break; // nobody holds rays any more and nobody has picked this wave: done
 							promised = true;
 						}
@@ -546,7 +550,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					ring_count = got & 0x7fffffffu;
 					tail_seen = true; // (lane teams by the number of rays, as for the queue's tail packets)
 					__builtin_amdgcn_wave_barrier();
-					if (ln == 0) *(volatile uint32_t*)&sm.mail[wave] = 0u;
+					if (ln == 0) lds_poke(&sm.mail[wave], 0u);
 					continue;
 				}
 				const uint32_t* mb = &sm.fl[wave].feat[0][0][0];
@@ -570,7 +574,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					}
 				}
 				__builtin_amdgcn_wave_barrier();
-				if (ln == 0) *(volatile uint32_t*)&sm.mail[wave] = 0u;
+				if (ln == 0) lds_poke(&sm.mail[wave], 0u);
 			}
 			continue;
 		}
@@ -597,7 +601,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			  for (int ei = a2.n_edits - 1; ei >= 0; --ei) e2 |= AFFINE ? edit_warp(a2.edits[ei], true, wp2, wd2) : tet_warp(a2.edits[ei], true, wp2, wd2);
 			  asm volatile("" :: "v"(wp2.x), "v"(wp2.y), "v"(wp2.z), "v"(wd2.x), "v"(wd2.y), "v"(wd2.z), "s"((int)__ballot(e2))); }
 #endif
-			for (int ei = a2.n_edits - 1; ei >= 0; --ei) empty |= AFFINE ? edit_warp(a2.edits[ei], true, wpos, wdir) : tet_warp(a2.edits[ei], true, wpos, wdir);
+			for (int ei = a2.n_edits - 1; ei >= 0; --ei) empty |= AFFINE ? edit_warp(a2.edits[ei], true, wpos, wdir) : tet_warp(a2.edits[ei], true, wpos, wdir, sm.coarse);
 		}
 		NRS_PHASE(3); // gather
 		// ---- gather: own sample (block g) and the partner lane's sample (block 1-g), levels 2*it+g ----

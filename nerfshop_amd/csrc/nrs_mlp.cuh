@@ -161,10 +161,20 @@ __device__ __forceinline__ CellCoords cell_coords(const LevelParams& lp, f3 pos)
 #ifndef NRS_OPT_FRACT
 #define NRS_OPT_FRACT 1
 #endif
+#ifndef NRS_OPT_PKCOORD
+#define NRS_OPT_PKCOORD 1 // scale * (x, y) + 0.5 as one v_pk_fma_f32 (two IEEE fmas: same bits), z alone
+#endif
 __device__ __forceinline__ CellCoords cell_coords_incube(const LevelParams& lp, f3 pos) {
 #if NRS_OPT_FRACT
 	CellCoords c;
+#if NRS_OPT_PKCOORD
+	typedef float f2p __attribute__((ext_vector_type(2)));
+	const f2p sc = {lp.scale, lp.scale}, xy = {pos.x, pos.y}, hf = {0.5f, 0.5f};
+	const f2p pxy = __builtin_elementwise_fma(sc, xy, hf);
+	const float px = pxy.x, py = pxy.y, pz = fmaf(lp.scale, pos.z, 0.5f);
+#else
 	const float px = fmaf(lp.scale, pos.x, 0.5f), py = fmaf(lp.scale, pos.y, 0.5f), pz = fmaf(lp.scale, pos.z, 0.5f);
+#endif
 	c.gx = (uint32_t)px; c.gy = (uint32_t)py; c.gz = (uint32_t)pz;
 	c.wx = __builtin_amdgcn_fractf(px); c.wy = __builtin_amdgcn_fractf(py); c.wz = __builtin_amdgcn_fractf(pz);
 	return c;
@@ -410,6 +420,29 @@ __device__ __forceinline__ void record_eval_four(const GridView& gv, const Level
 	f3_ = zero_if<ZERO>(!act, interpolate<NETACC>(cell_coords_incube(lp3, q), v3));
 }
 
+// The same for FOUR hashed levels (the two pairs behind the cell records: levels 12..15 of base.json's table): 32 single-dword gathers in flight, one round trip
+// instead of two.  The hashes need the cells before the loads; the weights are recomputed behind them (as above).
+#ifndef NRS_OPT_HQUADS
+#define NRS_OPT_HQUADS 1
+#endif
+// INCUBE: every sample of the wave lies in [0, 1]^3 (the caller's wave-uniform test): truncation / v_fract instead of floor / subtract, as for the records
+template <bool NETACC = false, bool ZERO = true, bool INCUBE = false>
+__device__ __forceinline__ void hashed_eval_four(const GridView& gv, const LevelParams& lp0, const LevelParams& lp1, const LevelParams& lp2, const LevelParams& lp3, f3 pos, bool act,
+                                                 uint32_t& f0, uint32_t& f1, uint32_t& f2, uint32_t& f3_) {
+	f3 q = act ? pos : mk3(0.f, 0.f, 0.f);
+	uint32_t v0[8], v1[8], v2[8], v3[8];
+	auto cc = [](const LevelParams& lp, f3 x) { return INCUBE ? cell_coords_incube(lp, x) : cell_coords(lp, x); };
+	issue_gathers<true>(gv, lp0, cc(lp0, q), v0);
+	issue_gathers<true>(gv, lp1, cc(lp1, q), v1);
+	issue_gathers<true>(gv, lp2, cc(lp2, q), v2);
+	issue_gathers<true>(gv, lp3, cc(lp3, q), v3);
+	asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z)); // the weights below are recomputed, not carried across the loads
+	f0 = zero_if<ZERO>(!act, interpolate<NETACC>(cc(lp0, q), v0));
+	f1 = zero_if<ZERO>(!act, interpolate<NETACC>(cc(lp1, q), v1));
+	f2 = zero_if<ZERO>(!act, interpolate<NETACC>(cc(lp2, q), v2));
+	f3_ = zero_if<ZERO>(!act, interpolate<NETACC>(cc(lp3, q), v3));
+}
+
 // One level of one sample, kind decided at run time (wave-uniform): the pairs whose two levels are of different kinds (the one
 // dense | hashed pair of a model without cell records, a records | no-records boundary at an odd level) come here, level after level.
 template <bool NETACC = false, bool ZERO = true>
@@ -456,6 +489,17 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 		if (NRS_OPT_QUADS && QUADS && kind == KIND_RECORD && it + 1 < 8 && __builtin_amdgcn_readfirstlane(kinds[it + 1]) == KIND_RECORD) {
 			uint32_t f0, f1, f2, f3_;
 			record_eval_four<NETACC, ZERO>(gv, lp0, lp1, lv[2 * it + 2], lv[2 * it + 3], pos, act, f0, f1, f2, f3_);
+			fl.feat[it][0][lane] = g ? f1 : f0;
+			fl.feat[it][1][lane ^ 32] = g ? f0 : f1;
+			fl.feat[it + 1][0][lane] = g ? f3_ : f2;
+			fl.feat[it + 1][1][lane ^ 32] = g ? f2 : f3_;
+			it += 2;
+			continue;
+		}
+		if (NRS_OPT_HQUADS && QUADS && kind == KIND_HASHED && it + 1 < 8 && __builtin_amdgcn_readfirstlane(kinds[it + 1]) == KIND_HASHED) {
+			uint32_t f0, f1, f2, f3_;
+			if (!outside) hashed_eval_four<NETACC, ZERO, true>(gv, lp0, lp1, lv[2 * it + 2], lv[2 * it + 3], pos, act, f0, f1, f2, f3_);
+			else hashed_eval_four<NETACC, ZERO, false>(gv, lp0, lp1, lv[2 * it + 2], lv[2 * it + 3], pos, act, f0, f1, f2, f3_);
 			fl.feat[it][0][lane] = g ? f1 : f0;
 			fl.feat[it][1][lane ^ 32] = g ? f0 : f1;
 			fl.feat[it + 1][0][lane] = g ? f3_ : f2;
