@@ -340,6 +340,9 @@ void nrs_comm_destroy(nrs_comm* comm);
 /* What the communicator is: this process's rank, the number of ranks RCCL connected, ncclGetVersion() (0 if the library has none) and the library
  * that was loaded (NRS_RCCL_LIB overrides the search: tests/fake_rccl runs several ranks on one GPU).  Any pointer may be NULL. */
 int  nrs_comm_info(const nrs_comm* comm, int* rank_out, int* n_ranks_out, int* rccl_version_out, char* lib_path_out, size_t lib_path_len);
+/* Diagnostic (no reference counterpart): `pairs` ncclSend / ncclRecv pairs of n_floats floats from this rank to itself in one group on `stream` -- RCCL's
+ * enqueue path of nrs_gather_tiles with one rank, for timing its host-side cost on a one-GPU box (tools/gather_probe.py). d_src / d_dst: pairs * n_floats. */
+int  nrs_comm_probe_self_p2p(nrs_comm* comm, const float* d_src, float* d_dst, size_t n_floats, int pairs, void* stream);
 /* d_local: this rank's buffer.  Root only: d_recv = n_ranks such buffers (rank-major); d_image [H*W*4] / d_depth [H*W] may be NULL. */
 int  nrs_gather_tiles(nrs_ctx* ctx, nrs_comm* comm, int root, const nrs_render_params* p, uint32_t tiles_per_rank_padded, const float* d_local,
                       float* d_recv, float* d_image, float* d_depth, void* stream);

@@ -140,7 +140,7 @@ class GridUpdate(C.Structure):
 
 # every symbol include/nrs.h declares; tests check the library exports exactly these
 EXPORTS = [
-    "nrs_last_error", "nrs_abi_version", "nrs_edit_poisson_interpolate", "nrs_edit_download_poisson", "nrs_comm_unique_id", "nrs_comm_create", "nrs_comm_info", "nrs_comm_destroy", "nrs_gather_tiles",
+    "nrs_last_error", "nrs_abi_version", "nrs_edit_poisson_interpolate", "nrs_edit_download_poisson", "nrs_comm_unique_id", "nrs_comm_create", "nrs_comm_info", "nrs_comm_destroy", "nrs_gather_tiles", "nrs_comm_probe_self_p2p",
     "nrs_ctx_create", "nrs_ctx_destroy", "nrs_ctx_device_info", "nrs_ctx_set_lane_teams", "nrs_ctx_set_ray_handover", "nrs_ctx_ray_handovers",
     "nrs_model_create", "nrs_model_destroy", "nrs_model_n_params", "nrs_model_level_table",
     "nrs_model_set_params", "nrs_model_set_params_device", "nrs_model_set_numerics", "nrs_model_set_cell_cache", "nrs_model_cell_cache_bytes", "nrs_model_set_sparse_cell_cache", "nrs_model_sparse_cell_cache_bytes", "nrs_model_set_density_bitfield", "nrs_model_set_density_grid",
@@ -215,6 +215,7 @@ def load():
     lib.nrs_comm_destroy.argtypes = [P]
     lib.nrs_comm_destroy.restype = None
     lib.nrs_gather_tiles.argtypes = [P, P, C.c_int, P, C.c_uint32, P, P, P, P, P]
+    lib.nrs_comm_probe_self_p2p.argtypes = [P, P, P, C.c_size_t, C.c_int, P]
     lib.nrs_model_set_sparse_cell_cache.argtypes = [P, P, C.c_size_t]
     lib.nrs_model_sparse_cell_cache_bytes.argtypes = [P, P, P]
     lib.nrs_model_sparse_cell_cache_bytes.restype = C.c_size_t

@@ -50,7 +50,9 @@ struct nrs_ctx {
 	// per-launch scratch comes from small rings so that render calls issued back to back on DIFFERENT streams (double-buffered
 	// frames) do not share a packet counter or an operator table: slot = launch number % kInFlight
 	static constexpr int kInFlight = 8;
-	RenderCounters* d_counters = nullptr;   // [kInFlight]
+	RenderCounters* d_counters = nullptr;   // [kInFlight][2]: the render kernel of a slot zeroes the OTHER block for the slot's next launch (no memset between frames)
+	uint8_t counter_parity[kInFlight] = {};   // block the slot's next launch uses; counters_clean: that block is known to be zero
+	bool counters_clean[kInFlight] = {};
 	DeviceEdit* d_edits = nullptr;          // [kInFlight + 1][kMaxEdits]; the last table belongs to the occupancy refresh
 	std::atomic<uint32_t> launch_serial{0};
 	// A slot is reused every kInFlight launches, possibly from ANOTHER stream: the launch that used it last records slot_done, and a
@@ -299,7 +301,9 @@ int nrs_ctx_create(int device, nrs_ctx** out) {
 	c->n_cus = prop.multiProcessorCount;
 	c->hbm_bytes = prop.totalGlobalMem;
 	snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
-	hipError_t he = hipMalloc((void**)&c->d_counters, sizeof(RenderCounters) * nrs_ctx::kInFlight);
+	hipError_t he = hipMalloc((void**)&c->d_counters, sizeof(RenderCounters) * nrs_ctx::kInFlight * 2);
+	if (he == hipSuccess) he = hipMemset(c->d_counters, 0, sizeof(RenderCounters) * nrs_ctx::kInFlight * 2);
+	for (int i = 0; i < nrs_ctx::kInFlight; ++i) c->counters_clean[i] = he == hipSuccess;
 	if (he == hipSuccess) he = hipMalloc((void**)&c->d_edits, sizeof(DeviceEdit) * nrs_ctx::kMaxEdits * (nrs_ctx::kInFlight + 1));
 	for (int i = 0; i < nrs_ctx::kInFlight && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming);
 	if (he == hipSuccess) he = hipMalloc((void**)&c->d_mean, 8 + 256 * 8); // mean + partial sums (launch_grid_to_bitfield)
@@ -1291,7 +1295,11 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	hipStream_t s = (hipStream_t)stream;
 	const uint32_t slot = ctx->launch_serial.fetch_add(1u) % (uint32_t)nrs_ctx::kInFlight;
 	if (ctx->slot_used[slot] && ctx->slot_stream[slot] != s) HIP_TRY(hipStreamWaitEvent(s, ctx->slot_done[slot], 0));
-	RenderCounters* d_counters_slot = ctx->d_counters + slot;
+	// The statistics / queue block of this launch.  A slot owns two: the render kernel's last workgroup zeroes the one it did NOT use, which the slot's next
+	// launch takes (launches of a slot are ordered: same stream, or the event wait above) -- so a frame costs no memset (two 5-us fill kernels per frame in
+	// the round-3 timeline: 2 % of a 1/8 share-frame).  The Slice path and a launch after a failed one still clear their block the plain way.
+	RenderCounters* d_counters_slot = ctx->d_counters + 2 * slot + ctx->counter_parity[slot];
+	RenderCounters* d_counters_other = ctx->d_counters + 2 * slot + (ctx->counter_parity[slot] ^ 1u);
 	DeviceEdit* d_edits_slot = ctx->d_edits + (size_t)slot * nrs_ctx::kMaxEdits;
 
 	RenderArgs a{};
@@ -1330,6 +1338,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	if (p->render_mode == NRS_RENDER_SLICE) { // tn:3109-3162: no marching at all; one network evaluation per owned pixel
 		a.frame = d_frame; a.depth = d_depth; a.steps = d_steps; a.counters = d_counters_slot;
 		HIP_TRY(hipMemsetAsync(d_counters_slot, 0, sizeof(RenderCounters), s));
+		ctx->counters_clean[slot] = false; // (slice_kernel leaves its statistics in the block and cleans nothing: the slot's next launch clears it)
 		NRS_TRY(launch_slice(m->dm, a, ctx->n_cus, s));
 		HIP_TRY(hipEventRecord(ctx->slot_done[slot], s));
 		ctx->slot_stream[slot] = s;
@@ -1435,10 +1444,18 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	a.depth = d_depth;
 	a.steps = d_steps;
 	a.counters = d_counters_slot;
+	a.counters_next = d_counters_other;
 	a.wave_log = (a.dbg & 4u) ? ctx->d_wave_log : nullptr;
 	if (a.wave_log) HIP_TRY(hipMemsetAsync(ctx->d_wave_log, 0, 8192 * 4 * 8, s));
-	HIP_TRY(hipMemsetAsync(d_counters_slot, 0, sizeof(RenderCounters), s));
-	NRS_TRY(launch_render(model_for_launch(m, *p), a, ctx->n_cus, s));
+	if (!ctx->counters_clean[slot]) HIP_TRY(hipMemsetAsync(d_counters_slot, 0, sizeof(RenderCounters), s));
+	ctx->counters_clean[slot] = false; // (until the launch is known to be enqueued: its last workgroup cleans the other block)
+	if (a.n_packets == 0) { // nothing to launch (no owned tiles): the block stays as it is -- zero
+		ctx->counters_clean[slot] = true;
+	} else {
+		NRS_TRY(launch_render(model_for_launch(m, *p), a, ctx->n_cus, s));
+		ctx->counter_parity[slot] ^= 1u;
+		ctx->counters_clean[slot] = true;
+	}
 	HIP_TRY(hipEventRecord(ctx->slot_done[slot], s));
 	ctx->slot_stream[slot] = s;
 	ctx->slot_used[slot] = true;

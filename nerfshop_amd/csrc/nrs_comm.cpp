@@ -133,6 +133,26 @@ int nrs_comm_info(const nrs_comm* c, int* rank_out, int* n_ranks_out, int* rccl_
 	return NRS_OK;
 }
 
+// Diagnostic: `pairs` point-to-point transfers of n_floats floats from this rank TO ITSELF in one ncclGroupStart / ncclGroupEnd on `stream` -- the enqueue
+// path nrs_gather_tiles takes at the root (N - 1 receives) with the sends of the peers folded in, executable with ONE rank: the only way to put RCCL's own
+// host-side cost per frame next to a share-frame's render time on a one-GPU box (RCCL refuses two ranks on a device).  tools/gather_probe.py times it.
+int nrs_comm_probe_self_p2p(nrs_comm* c, const float* d_src, float* d_dst, size_t n_floats, int pairs, void* stream) {
+	if (!c || !d_src || !d_dst || pairs < 1) return fail(NRS_ERR_INVALID_ARG, "nrs_comm_probe_self_p2p: bad argument");
+	Rccl& r = rccl();
+	if (hipSetDevice(c->device) != hipSuccess) return fail(NRS_ERR_HIP, "nrs_comm_probe_self_p2p: hipSetDevice failed");
+	hipStream_t s = (hipStream_t)stream;
+	int rc = r.GroupStart();
+	if (rc != 0) return ccl_fail(rc, "ncclGroupStart");
+	for (int k = 0; k < pairs && rc == 0; ++k) {
+		rc = r.Send(d_src + (size_t)k * n_floats, n_floats, kNcclFloat32, c->rank, c->comm, s);
+		if (rc == 0) rc = r.Recv(d_dst + (size_t)k * n_floats, n_floats, kNcclFloat32, c->rank, c->comm, s);
+	}
+	const int rc_end = r.GroupEnd();
+	if (rc != 0) return ccl_fail(rc, "ncclSend / ncclRecv");
+	if (rc_end != 0) return ccl_fail(rc_end, "ncclGroupEnd");
+	return NRS_OK;
+}
+
 void nrs_comm_destroy(nrs_comm* c) {
 	if (!c) return;
 	if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);

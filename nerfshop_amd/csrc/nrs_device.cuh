@@ -783,21 +783,26 @@ __device__ __forceinline__ bool edit_warp(const DeviceEdit& e, bool with_dir, f3
 // Two steps (round 4), so that the renderer can run the un-deformed network pass between them with only three values live: _find decides which tet of the
 // deformed mesh holds the sample and interpolates the two densities; _colour re-derives the barycentric weights of that tet (the same arithmetic: the same
 // bits) and evaluates the SH9 colour.
-__device__ __forceinline__ bool poisson_residual_find(const DeviceEdit& e, f3 wpos0, uint32_t& found_out, float& out_density, float& res_density) {
+__device__ __forceinline__ bool poisson_residual_find(const DeviceEdit& e, f3 wpos0, uint32_t& found_out, float& out_density, float& res_density,
+                                                      const uint32_t* __restrict__ march_lds = nullptr) {
 	const f3 pos = unwarp_position(wpos0, e.aabb);
 	if (!box_contains(e.bbox, pos)) return false;
 	const int level = mip_from_pos(pos);
-	const uint32_t cell = (uint32_t)level * kGridVol + cascaded_grid_idx_at(pos, (uint32_t)level);
+	const uint32_t cell = (NRS_OPT_WARP_MORTON && march_lds) ? occupancy_bit_index(pos, (uint32_t)level, march_lds)
+	                                                         : (uint32_t)level * kGridVol + cascaded_grid_idx_at(pos, (uint32_t)level);
 	const uint32_t found = scan_cell_for_tet(e, cell, pos);
 	if (found == 0xffffffffu) return false;
-	const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[found];
+	typedef uint32_t u4n __attribute__((ext_vector_type(4)));
+	const u4n tv = gp(reinterpret_cast<const u4n*>(e.tets))[found];
 	float bc[4];
 	{
 		const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), dd = ld3(e.verts, tv.w);
 		bary_tet(a, b, c, dd, pos, bc);
 	}
-	const float lo = ((bc[0] * e.out_density[tv.x] + bc[1] * e.out_density[tv.y]) + bc[2] * e.out_density[tv.z]) + bc[3] * e.out_density[tv.w];
-	const float lr = ((bc[0] * e.res_density[tv.x] + bc[1] * e.res_density[tv.y]) + bc[2] * e.res_density[tv.z]) + bc[3] * e.res_density[tv.w];
+	const NRS_GLOBAL float* od = gp(e.out_density);
+	const NRS_GLOBAL float* rd = gp(e.res_density);
+	const float lo = ((bc[0] * od[tv.x] + bc[1] * od[tv.y]) + bc[2] * od[tv.z]) + bc[3] * od[tv.w];
+	const float lr = ((bc[0] * rd[tv.x] + bc[1] * rd[tv.y]) + bc[2] * rd[tv.z]) + bc[3] * rd[tv.w];
 	out_density = e.residual_amplitude * lo;
 	res_density = e.residual_amplitude * lr;
 	found_out = found;
@@ -805,7 +810,8 @@ __device__ __forceinline__ bool poisson_residual_find(const DeviceEdit& e, f3 wp
 }
 __device__ __forceinline__ void poisson_residual_colour(const DeviceEdit& e, uint32_t found, f3 wpos0, f3 dir, float rgb[3]) {
 	const f3 pos = unwarp_position(wpos0, e.aabb);
-	const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[found];
+	typedef uint32_t u4n __attribute__((ext_vector_type(4)));
+	const u4n tv = gp(reinterpret_cast<const u4n*>(e.tets))[found];
 	float bc[4];
 	{
 		const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), dd = ld3(e.verts, tv.w);

@@ -149,6 +149,7 @@ struct RenderArgs {
 	float*    depth;
 	uint32_t* steps;           // nullable
 	RenderCounters* counters;
+	RenderCounters* counters_next; // the block the slot's NEXT launch will use: zeroed by this launch's last workgroup (nullable)
 	unsigned long long* wave_log; // NRS_DEBUG & 4: 4 words per wave (see nrs_render_nerf)
 };
 
@@ -168,6 +169,23 @@ int launch_poisson_fit(const DeviceModel& m, uint32_t n_verts, uint32_t n_sh, co
 int launch_cell_records(const DeviceModel& m, uint32_t n_levels, void* d_records, void* stream);
 int launch_weight_fragments(const uint16_t* d_params, const uint16_t* d_src, uint16_t* d_frag, uint32_t n, void* stream);
 constexpr uint32_t kBrick = 8, kBrickCells = kBrick * kBrick * kBrick; // sparse cell records: 8^3 cells = 16 KiB of records per brick
+// Order of the 512 records inside a brick.  0: x fastest (a 128-byte line = the 4 records of a 4 x 1 x 1 run of cells); 1: Morton (a line = a 2 x 2 x 1 block, two
+// lines = 2 x 2 x 2): VERDICT r3 next #7's experiment -- measured on the aabb-16 scene in round 4, see DESIGN.md 4 / profiles/r04_garden.md.
+#ifndef NRS_BRICK_MORTON
+#define NRS_BRICK_MORTON 0
+#endif
+// position of cell (x, y, z) (each 0..7) among its brick's records -- shared by the kernel that writes the records and the gather that reads them
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+inline uint32_t brick_slot(uint32_t x, uint32_t y, uint32_t z) {
+#if NRS_BRICK_MORTON
+	auto spread = [](uint32_t v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4); };
+	return spread(x) | (spread(y) << 1) | (spread(z) << 2);
+#else
+	return (z << 6) | (y << 3) | x;
+#endif
+}
 int launch_brick_mark(const DeviceModel& m, const LevelParams& lp, const uint8_t* d_mask, uint32_t* d_table, uint32_t* d_counter, uint32_t* d_slots, uint32_t capacity, void* stream);
 int launch_brick_fill(const DeviceModel& m, const LevelParams& lp, const uint32_t* d_slots, uint32_t n_bricks, void* d_records2, void* stream);
 int launch_grid_eval(const DeviceModel& m, int mode, const uint32_t res[3], const float box_mn[3], const float box_mx[3], const float dir01[3],

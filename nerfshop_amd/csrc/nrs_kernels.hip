@@ -752,7 +752,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				int found_edit = -1;
 				if (act && !(NRS_EXP_P & 4)) {
 					for (int ei = a2b.n_edits - 1; ei >= 0; --ei)
-						if (a2b.edits[ei].apply_poisson && poisson_residual_find(a2b.edits[ei], wpos0, found_tet, p_out, p_res)) found_edit = ei;
+						if (a2b.edits[ei].apply_poisson && poisson_residual_find(a2b.edits[ei], wpos0, found_tet, p_out, p_res, sm.coarse)) found_edit = ei;
 				}
 				has_res = act && p_out > 1e-9f;
 				// step 2: the un-deformed network's density.  The reference evaluates it for every sample; its only consumer is the clamp of tn:776-777, i.e.
@@ -1069,8 +1069,14 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		const uint32_t before = atomicAdd(&a.counters->n_rays_alive, __atomic_load_n(&sm.sum_alive, __ATOMIC_RELAXED));
 		uint32_t one = 1u;
 		asm volatile("" : "+v"(one) : "v"(before)); // the increment below waits for the count above to have returned
-		if (atomicAdd(&a.counters->blocks_done, one) == gridDim.x - 1u && a.feedback)
-			*a.feedback = (unsigned long long)atomicAdd(&a.counters->n_rays_alive, 0u) | ((unsigned long long)a.pixels_owned << 32);
+		if (atomicAdd(&a.counters->blocks_done, one) == gridDim.x - 1u) { // the launch's last workgroup
+			if (a.feedback) *a.feedback = (unsigned long long)atomicAdd(&a.counters->n_rays_alive, 0u) | ((unsigned long long)a.pixels_owned << 32);
+			if (a.counters_next) { // the slot's next launch finds its block zeroed (nrs_render_nerf: no memset between frames)
+				unsigned long long* z = reinterpret_cast<unsigned long long*>(a.counters_next);
+				#pragma unroll
+				for (uint32_t i = 0; i < sizeof(RenderCounters) / 8; ++i) z[i] = 0ull;
+			}
+		}
 	}
 }
 
@@ -1559,7 +1565,7 @@ __global__ __launch_bounds__(256) void brick_fill_kernel(const uint32_t* __restr
                                                          uint4* __restrict__ out) {
 	const uint64_t n = (uint64_t)n_bricks * kBrickCells;
 	for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
-		const uint32_t b = slots[i >> 9], within = (uint32_t)i & 511u;
+		const uint32_t b = slots[i >> 9], within = (uint32_t)i & 511u; // (the thread's cell in x-fastest order; its record sits at brick_slot)
 		const uint32_t bx = b % lp.rec_res, by = (b / lp.rec_res) % lp.rec_res, bz = b / lp.rec_res2;
 		const uint32_t gx = bx * 8u + (within & 7u), gy = by * 8u + ((within >> 3) & 7u), gz = bz * 8u + (within >> 6);
 		uint32_t v[8];
@@ -1570,7 +1576,7 @@ __global__ __launch_bounds__(256) void brick_fill_kernel(const uint32_t* __restr
 			index %= lp.count;
 			v[c] = grid[lp.offset + index];
 		}
-		uint4* o = out + 2 * ((size_t)lp.rec_first + i);
+		uint4* o = out + 2 * ((size_t)lp.rec_first + (i & ~(uint64_t)511u) + brick_slot(within & 7u, (within >> 3) & 7u, within >> 6));
 		o[0] = make_uint4(v[0], v[1], v[2], v[3]);
 		o[1] = make_uint4(v[4], v[5], v[6], v[7]);
 	}

@@ -328,7 +328,7 @@ __device__ __forceinline__ uint32_t brick_entry(const GridView& gv, const LevelP
 	return gv.bricks[lp.tab_first + zy + (c.gx >> 3)];
 }
 __device__ __forceinline__ void issue_brick_record_loads(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t brick, uint32_t v[8]) {
-	const uint32_t rec = lp.rec_first + (brick - 1u) * 512u + (((c.gz & 7u) << 6) | ((c.gy & 7u) << 3) | (c.gx & 7u));
+	const uint32_t rec = lp.rec_first + (brick - 1u) * 512u + brick_slot(c.gx & 7u, c.gy & 7u, c.gz & 7u);
 	const uint4* p = gv.records2 + 2 * (size_t)rec;
 	const uint4 lo = p[0], hi = p[1]; // (streaming these with non-temporal loads was measured: no gain on the aabb-16 scene)
 	v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;

@@ -509,6 +509,6 @@ def test_errors_are_loud(rig):
     with pytest.raises(NrsError):
         runtime.NerfNetwork(rig.ctx, bad)
     p = rig.scene.params_for(32, 32, 30.0)
-    p.render_mode = 2  # Normals: out of scope
+    p.render_mode = 10  # NumRenderModes: not a mode (Normals / EncodingVis are modes since round 4)
     with pytest.raises(NrsError):
         rig.render(p)
