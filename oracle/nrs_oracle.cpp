@@ -1931,6 +1931,26 @@ int orc_network_activation(void* model, uint32_t n, const float* in7, uint32_t l
 	for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = network_activation_one(m, in7 + 7 * (size_t)i, layer, dim);
 	return 1;
 }
+// the same two in the shape the reference calls them (7-row matrices; visualize_activation writes over its input): the callbacks of oracle/ref_render.cpp
+void orc_density_input_gradient7(void* model, uint32_t n, const float* in7, float* grad7) {
+	const Model& m = *(const Model*)model;
+#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < (int64_t)n; ++i) {
+		float* g = grad7 + 7 * (size_t)i;
+		density_input_gradient_one(m, in7 + 7 * (size_t)i, g);
+		g[3] = g[4] = g[5] = g[6] = 0.f;
+	}
+}
+void orc_visualize_activation7(void* model, uint32_t n, float* in7, uint32_t layer, uint32_t dim) {
+	const Model& m = *(const Model*)model;
+#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < (int64_t)n; ++i) {
+		float* c = in7 + 7 * (size_t)i;
+		const float v = network_activation_one(m, c, layer, dim);
+		c[0] = fmaxf(-v, 0.0f); c[1] = fmaxf(v, 0.0f); c[2] = 0.f; // extract_dimension_pos_neg_kernel
+		c[3] = c[4] = c[5] = c[6] = 1.f;
+	}
+}
 void orc_network_density(void* model, uint32_t n, const float* in, uint32_t ld_in, uint16_t* out, uint32_t ld_out, int layout) {
 	const Model& m = *(Model*)model;
 #pragma omp parallel for schedule(static)

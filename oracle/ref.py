@@ -37,7 +37,7 @@ def load():
     global _lib
     if _lib is None:
         _lib = C.CDLL(LIB_PATH)
-        for fn in ("ref_render_frame", "ref_trace_coords", "ref_edit_map_rays", "ref_edit_map_positions", "ref_edit_poisson_residuals", "ref_build_tet_grid",
+        for fn in ("ref_render_frame", "ref_set_introspection", "ref_trace_coords", "ref_edit_map_rays", "ref_edit_map_positions", "ref_edit_poisson_residuals", "ref_build_tet_grid",
                    "ref_grid_to_bitfield", "ref_bary_tet", "ref_point_in_tet", "ref_ld_random_val", "ref_ld_random_pixel_offset", "ref_sobol", "ref_ray_intersect",
                    "ref_box_intersects_triangle", "ref_grid_math", "ref_warp", "ref_evaluate_sh9", "ref_activations", "ref_pixel_to_ray", "ref_cell_functions", "ref_local_rotations", "ref_mvc_compute", "ref_mvc_apply", "ref_poisson_interpolate", "ref_affine_map_rays", "ref_affine_map_positions"):
             getattr(_lib, fn).restype = None
@@ -69,6 +69,7 @@ def render_frame(desc, params, bitfield, meshes, oracle_model, frame=None, want_
     bf = np.ascontiguousarray(bitfield, np.uint8)
     arr = (C.c_void_p * max(len(meshes), 1))(*[C.cast(C.pointer(m), C.c_void_p) for m in meshes])
     net = C.cast(olib.orc_network_inference, C.c_void_p)
+    lib.ref_set_introspection(C.cast(olib.orc_density_input_gradient7, C.c_void_p), C.cast(olib.orc_visualize_activation7, C.c_void_p))  # tcnn's input_gradient / visualize_activation: the oracle's restatements
     lib.ref_render_frame(C.byref(desc), C.byref(params), _p(bf), arr, C.c_int(len(meshes)), net, C.c_void_p(oracle_model.h), _p(frame), _p(depth), _p(steps), C.byref(stats))
     return frame, depth, steps, stats
 

@@ -213,6 +213,15 @@ void ref_affine_map_positions(const nrs_model_desc* desc, const nrs_affine_dupli
 // in7: [n x 7] f32; out: fp16 planes, out[c * ld + s].  Signature = oracle/nrs_oracle.cpp's orc_network_inference.
 typedef void (*ref_network_fn)(void* user, uint32_t n, const float* in7, uint16_t* out, uint32_t ld_out, int layout);
 
+// The two tiny-cuda-nn entry points render modes Normals / EncodingVis call (testbed_nerf.cu:2923-2927), as callbacks like the network itself:
+// gradient: network.input_gradient(stream, 3, positions, gradients) -> [n x 7] (rows 0..2 the position's, the rest zero);
+// visualize: network.visualize_activation(stream, layer, dim, positions, positions) -- it OVERWRITES the input records, as the reference's call does.
+typedef void (*ref_gradient_fn)(void* user, uint32_t n, const float* in7, float* grad7);
+typedef void (*ref_visualize_fn)(void* user, uint32_t n, float* in7_inout, uint32_t layer, uint32_t dim);
+static ref_gradient_fn g_gradient = nullptr;
+static ref_visualize_fn g_visualize = nullptr;
+void ref_set_introspection(ref_gradient_fn grad, ref_visualize_fn vis) { g_gradient = grad; g_visualize = vis; }
+
 struct ref_render_stats { uint64_t generated, composited; uint32_t n_alive0, n_hit, iterations, pad; };
 
 // One frame: Testbed::render_nerf (testbed_nerf.cu:3066-3201) = init_rays_from_camera (:2683) + trace (:2772) + shade (:3180), Shade / Cost
@@ -244,7 +253,7 @@ void ref_render_frame(const nrs_model_desc* desc, const nrs_render_params* p, co
 	Rays rays[2], rays_hit;
 	for (Rays* r : {&rays[0], &rays[1], &rays_hit}) { r->rgba.resize(N); r->depth.resize(N); r->normal.resize(N); r->payload.resize(N); memset((void*)r->payload.data(), 0, sizeof(NerfPayload) * N); }
 	const uint32_t n_max = next_multiple(N, (uint32_t)batch_size_granularity) + batch_size_granularity * 8;
-	std::vector<NerfCoordinate> network_input(n_max, NerfCoordinate(Vector3f::Zero(), Vector3f::Zero(), 0.f)), network_gradient(1, NerfCoordinate(Vector3f::Zero(), Vector3f::Zero(), 0.f));
+	std::vector<NerfCoordinate> network_input(n_max, NerfCoordinate(Vector3f::Zero(), Vector3f::Zero(), 0.f)), network_gradient(render_mode == ERenderMode::Normals ? n_max : 1, NerfCoordinate(Vector3f::Zero(), Vector3f::Zero(), 0.f));
 	std::vector<network_precision_t> network_output((size_t)n_max * 16), network_output_old((size_t)n_max * 16);
 	std::vector<SH9RGB> sh_boundary(n_max);
 	std::vector<float> density_out_boundary(n_max), density_residual_boundary(n_max);
@@ -340,6 +349,8 @@ void ref_render_frame(const nrs_model_desc* desc, const nrs_render_params* p, co
 
 		net(net_user, n_elements, (const float*)network_input.data(), (uint16_t*)network_output.data(), n_elements, 0); // :2913
 		// clear_empty_space (:2919) has an empty body (:2759-2770)
+		if (render_mode == ERenderMode::Normals && g_gradient) g_gradient(net_user, n_elements, (const float*)network_input.data(), (float*)network_gradient.data()); // :2924
+		else if (render_mode == ERenderMode::EncodingVis && g_visualize) g_visualize(net_user, n_elements, (float*)network_input.data(), p->visualized_layer, p->visualized_dimension); // :2926
 
 		std::vector<uint16_t> n_steps_before(n_alive); // payload.n_steps as generate_next_nerf_network_inputs left it = samples this ray holds
 		for (uint32_t k = 0; k < n_alive; ++k) n_steps_before[k] = rays_current.payload[k].n_steps;

@@ -32,7 +32,9 @@ def main():
             for k, cn, n, avg, mn, mx, vg, ag, sg, lds, grid, wg in rows:
                 lines.append(f"| `{k[:60]}` | {cn} | {n} | {avg:.6g} | {mn:.6g} | {mx:.6g} |")
             k, cn, n, avg, mn, mx, vg, ag, sg, lds, grid, wg = rows[0]
-            lines += ["", f"dispatch shape: grid {grid} x wg {wg}, vgpr {vg}, agpr {ag}, sgpr {sg}, lds {lds} B", ""]
+            # (rocprofv3's vgpr_count column is not the compiler's NumVgprs on gfx950 -- it printed 64 for the 125-register render kernel of round 3 --
+            # so it is labelled as what it is; the allocation is in `make -C nerfshop_amd/csrc resource-usage | python tools/resource_usage.py`)
+            lines += ["", f"dispatch shape: grid {grid} x wg {wg}, lds {lds} B, sgpr {sg}; rocprofv3 `vgpr_count` field {vg} (NOT the allocation: see tools/resource_usage.py), agpr {ag}", ""]
     open(out, "w").write("\n".join(lines) + "\n")
     print("wrote", out)
 

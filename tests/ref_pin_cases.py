@@ -137,6 +137,13 @@ FRAME_CASES = [
     # round 3: the rest of render_nerf's surface -- composite_kernel_nerf's per-sample modes (tn:905-937), show_accel (tn:788-790, 911-920),
     # depth of field (common_device.cuh:285-293), the Slice path (tn:3111-3175)
     ("lego_edit_ao", "lego", (64, 36, 60.0), {"render_mode": 0}, "cage"),
+    # render modes Normals / EncodingVis (round 4): the reference's composite / shade branches (:905-910, :925, :2466-2468) around the oracle's restatements of
+    # tiny-cuda-nn's input_gradient / visualize_activation -- incl. the overwritten network input of EncodingVis (dt = 1, direction (1, 1, 1): :762, :803)
+    ("lego_edit_normals", "lego", (64, 36, 60.0), {"render_mode": 2}, "cage"),
+    ("aabb16_normals", "aabb16", (64, 36, 30.0), {"render_mode": 2}, None),
+    ("lego_edit_encoding_vis_hidden", "lego", (64, 36, 100.0), {"render_mode": 11, "visualized_layer": 1, "visualized_dimension": 20}, "cage"),
+    ("lego_encoding_vis_grid", "lego", (64, 36, 30.0), {"render_mode": 11, "visualized_layer": 0, "visualized_dimension": 3}, None),
+    ("lego_membrane_encoding_vis", "lego", (64, 36, 60.0), {"render_mode": 11, "visualized_layer": 2, "visualized_dimension": 17, "poisson_target": 1}, "membrane"),
     ("lego_edit_positions", "lego", (64, 36, 100.0), {"render_mode": 3}, "cage"),
     ("lego_positions_accel0", "lego", (64, 36, 30.0), {"render_mode": 3, "show_accel": 1, "min_mip": 0}, None),
     ("aabb16_positions_accel1", "aabb16", (64, 36, 30.0), {"render_mode": 3, "show_accel": 1, "min_mip": 1}, "cage"),
