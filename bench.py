@@ -82,13 +82,12 @@ def camera_for(step, synth, aabb_scale):
     return synth.orbit_camera(45.0 * (step % 8) + 30.0, 30.0, scale=scale)
 
 
-def cpu_baseline(synth):
-    """The CPU leg: the render path on the host cores of the GPU box, no edits, through oracle/'s restatement in its CPU-baseline flavour
-    (Model.set_fast: F16C half conversions, fp32-accumulated MLP sums -- "fp32 math with fp16 rounding points emulated"; same algorithm and rounding
-    points as the checker, whose exact-double sums and software fp16 made round 2's figure a statement about the checker, not about a CPU).  The
-    reference itself has no CPU path; this is a port (`kind`), a baseline only.  `value` = a bounded 960x540 view (about 6 M samples: enough work for
-    every core), best of 3; `config1` = BASELINE config #1 as it is named (one 256x256 frame, best of 5; too small to occupy 128 cores), with the
-    checker flavour's figure next to it; `one_thread` on a 64x64 view."""
+def cpu_baseline(synth, scene=None):
+    """The CPU leg: the render path on the host cores of the GPU box through oracle/'s restatement in its CPU-baseline flavour (Model.set_fast: F16C half
+    conversions, fp32-accumulated MLP sums -- "fp32 math with fp16 rounding points emulated"; same algorithm and rounding points as the checker).  The reference itself has
+    no CPU path; this is a port (`kind`), a baseline only.  `value` = a BOUNDED SAMPLE OF THE BENCH'S OWN WORKLOAD: the same scene, the same cage edit and
+    occupancy, bench view 0 at 960x540 -- a quarter of the frame's pixels, about 6 M samples, work for every core -- best of 3; `config1` = BASELINE config #1 as it is named (one
+    256x256 frame, no edits, best of 5) with the checker flavour's figure next to it; `one_thread` on a 64x64 view."""
     from oracle import oracle as orc
     desc = synth.model_desc(1)
     params = synth.make_params(desc, sigma_raw=synth.default_sigma_raw(1))
@@ -96,27 +95,35 @@ def cpu_baseline(synth):
     cores = int(orc.load().orc_max_threads())
     cam = synth.orbit_camera(30.0, 30.0, scale=0.33)
 
-    def best_of(p, n, threads=0):
+    def best_of(m, p, n, edits=(), threads=0):
         best, samples = None, 0
         for _ in range(n):
             t0 = time.perf_counter()
-            _, _, _, st = model.render(p, [], n_threads=threads)
+            _, _, _, st = m.render(p, list(edits), n_threads=threads)
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
             samples = int(st.composited)
         return best, samples
 
     p256 = synth.render_params(256, 256, cam, aabb_scale=1, apply_operators=False)
-    t_checker, s256 = best_of(p256, 2)
+    t_checker, s256 = best_of(model, p256, 2)
     model.set_fast(True)
-    t256, _ = best_of(p256, 5)
-    pbig = synth.render_params(960, 540, cam, aabb_scale=1, apply_operators=False)
-    tbig, sbig = best_of(pbig, 3)
+    t256, _ = best_of(model, p256, 5)
     p1 = synth.render_params(64, 64, cam, aabb_scale=1, apply_operators=False)
-    t1, s1 = best_of(p1, 1, threads=1)
+    t1, s1 = best_of(model, p1, 1, threads=1)
+    # the bench's own workload, bounded: its scene, edit and occupancy (`scene` = build_scene's), view 0, 960x540
+    if scene is not None and scene.get("edit") is not None and scene["aabb_scale"] == 1:
+        wl_model = orc.Model(scene["desc"], scene["params"], synth.grid_to_bitfield(scene["grid"]))
+        wl_model.set_fast(True)
+        edits = [orc.Edit(scene["desc"], scene["edit"].tet_mesh_struct(), keepalive=scene["edit"])]
+        what = "the bench's lego-like scene with its cage edit (BASELINE configs[2])"
+    else:
+        wl_model, edits, what = model, [], "the lego-like scene, no edits"
+    pbig = synth.render_params(960, 540, camera_for(0, synth, 1), aabb_scale=1, apply_operators=bool(edits))
+    tbig, sbig = best_of(wl_model, pbig, 3, edits=edits)
     return {"value": round(sbig / tbig / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "note": "oracle/ restatement in its CPU-baseline flavour (F16C conversions, fp32-accumulated MLP sums, OpenMP over rays); the reference has no CPU path",
-            "sample": f"960x540 view of the lego-like scene, no edits, best of 3: {sbig} samples in {tbig * 1e3:.0f} ms ({1.0 / tbig:.2f} FPS)",
+            "sample": f"bounded sample of the N = 1 workload: {what}, bench view 0 at 960x540 (a quarter of the pixels), best of 3: {sbig} samples in {tbig * 1e3:.0f} ms ({1.0 / tbig:.2f} FPS)",
             "config1": {"sample": f"BASELINE config #1: one 256x256 frame, no edits, best of 5: {s256} samples in {t256 * 1e3:.0f} ms ({1.0 / t256:.2f} FPS)",
                         "value": round(s256 / t256 / 1e6, 3), "ms_per_frame_256": round(t256 * 1e3, 1),
                         "checker_flavour": {"value": round(s256 / t_checker / 1e6, 4), "ms_per_frame_256": round(t_checker * 1e3, 1),
@@ -493,7 +500,7 @@ def main():
             line["config"]["gather_check"] = gather_check
         line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(synth)
+            line["cpu_baseline"] = cpu_baseline(synth, scene)
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -385,7 +385,10 @@ int nrs_rgba_on_grid(nrs_model* model, void* stream, const uint32_t res3d[3], co
  * a ray is stepped through the occupied cells of the model's train box (pixel_to_ray with spp 0, direction not
  * normalised, up to NERF_STEPS = 1024 samples) while the density composites; the first sample reached with
  * transmittance <= threshold (the reference's 0.1) gives d_positions[i] (world space) and d_cells[i] =
- * mip * 128^3 + morton(cell); d_found[i] = 0 and position = aabb_min - 1 when the ray never gets there. */
+ * mip * 128^3 + morton(cell); d_found[i] = 0 and position = aabb_min - 1 when the ray never gets there.  The camera is a PINHOLE whatever the lens fields
+ * of `params` say: the reference's shoot_selection_rays_kernel calls pixel_to_ray with its default arguments (growing_selection.cu:1696-1703: no distortion,
+ * no aperture, spp 0), so dof / distortion_* / d_distortion_map are not read here -- unlike nrs_render_nerf and nrs_trace_samples, which march the lens
+ * the renderer uses. */
 int nrs_project_selection_pixels(nrs_model* model, void* stream, const nrs_render_params* params, const int32_t* d_pixels_xy,
                                  uint32_t n_pixels, float transmittance_threshold, float* d_positions, uint32_t* d_cells, uint8_t* d_found);
 /* host-only bookkeeping that follows (:1964-2021): automatic growing level = highest cascade found, cells below it lifted
