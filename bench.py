@@ -342,6 +342,27 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         extra["noedit"] = {"msamples_per_s": round(ns / dt / 1e6, 2), "fps": round(8 / dt, 2)}
+        # BASELINE configs[1] as scripts/run.py renders it offline: 8 spp per view -- 8 frames with the Sobol pixel offsets of spp_index 0..7, each joined to the
+        # running mean by nrs_accumulate (CudaRenderBuffer::accumulate); one "image" = 8 x (clear + render + accumulate)
+        from nerfshop_amd import _abi as abi
+        lib = abi.load()
+        accum = torch.zeros_like(frame)
+
+        def spp8_view(view):
+            for k in range(8):
+                p = synth.render_params(W, H, camera_for(view, synth, scene["aabb_scale"]), aabb_scale=scene["aabb_scale"], apply_operators=False, spp_index=k, snap=False)
+                frame.zero_()
+                tb.render_with_params(tb.nerf_network, p, frame, depth, None, None)
+                abi.check(lib.nrs_accumulate(ctx.h, None, W, H, frame.data_ptr(), accum.data_ptr(), k, 0))
+        spp8_view(0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for v in range(4):
+            spp8_view(v)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        extra["noedit_spp8"] = {"images_per_s": round(4 / dt, 2), "ms_per_8spp_image": round(dt / 4 * 1e3, 2), "msamples_per_s": round(ns / 8 * 32 / dt / 1e6, 2),
+                                "note": "BASELINE configs[1] offline: 8 frames (Sobol offsets of spp_index 0..7) + nrs_accumulate per 1920x1080 image, no edits"}
 
     if not args.no_extra:
         # secondary: the same frames with 2 and with 4 in flight (all ranks take part; `value` stays the one-at-a-time figure).  The drain of

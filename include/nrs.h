@@ -29,6 +29,7 @@
  *   nrs_mvc_compute / nrs_mvc_apply <- Cage::compute_mvc / interpolate_with_mvc    cage.cu:6 / :38          (host, "next" row f1)
  *   nrs_tet_local_rotations  <- TetMesh::update_local_rotations                    tet_mesh.cu:37           (host, "next" row f1)
  *   nrs_trace_samples        <- (test hook) the (t, dt) stream generate_next_nerf_network_inputs emits, testbed_nerf.cu:637
+ *   nrs_accumulate           <- CudaRenderBuffer::accumulate / accumulate_kernel                                   src/render_buffer.cu:540 / :217
  *   nrs_detile               <- (new) inverse of the multi-GPU tile packing, no reference counterpart
  *
  * Conventions: every function returns NRS_OK (0) or a negative nrs_status; nrs_last_error() returns a
@@ -456,6 +457,12 @@ int  nrs_edit_download(nrs_edit* edit, float* h_vertices, uint32_t* h_lut_offset
  * synchronises the stream before returning (the reference's trace() syncs to read n_hit). */
 int nrs_render_nerf(nrs_model* model, const nrs_render_params* params, nrs_edit* const* edits, int n_edits,
                     float* d_frame, float* d_depth, uint32_t* d_steps, void* stream, nrs_render_stats* h_stats);
+/* spp accumulation <- CudaRenderBuffer::accumulate (src/render_buffer.cu:540-560; accumulate_kernel :217-254): d_accumulate [H*W] f32x4 becomes the running mean
+ * of the frames rendered so far for this view; sample_count = frames already in it (0: the buffer is overwritten, as the reference clears it first).  The caller
+ * renders frame k with spp_index = k (the Sobol pixel offsets, snap_to_pixel_centers off) into a cleared d_frame and calls this: scripts/run.py's 8-spp test
+ * images are 8 such rounds.  color_space = EColorSpace (common.h:122): Linear | SRGB (linear_to_srgb applied to the frame before the mean) | VisPosNeg (EncodingVis). */
+typedef enum nrs_color_space { NRS_COLOR_LINEAR = 0, NRS_COLOR_SRGB = 1, NRS_COLOR_VISPOSNEG = 2 } nrs_color_space;
+int nrs_accumulate(nrs_ctx* ctx, void* stream, uint32_t width, uint32_t height, const float* d_frame, float* d_accumulate, uint32_t sample_count, uint32_t color_space);
 /* number of tiles this rank owns / pixels of the compact buffer for given params (host-only; virtual tiles of the odd pitch included) */
 uint32_t nrs_render_owned_tiles(const nrs_render_params* params);
 /* the row pitch of the tile index: ceil(W / tile_size) | 1 (0 when tile_size == 0) */

@@ -157,6 +157,13 @@ struct RenderBuffer {
 	float* depth_buffer;   // float [H*W]
 	int width, height;     // in_resolution()
 	uint32_t spp;          // sample index of this frame
+	float* accumulate_buffer = nullptr; // float4 [H*W], optional: CudaRenderBuffer::m_accumulate_buffer
+	// void CudaRenderBuffer::accumulate(float exposure, cudaStream_t stream) -- render_buffer.cu:540-560 (exposure is unused there too): the running mean of the spp frames
+	void accumulate(Context& ctx, void* stream, nrs_color_space color_space = NRS_COLOR_LINEAR) {
+		if (!accumulate_buffer) throw std::runtime_error("RenderBuffer::accumulate: no accumulate buffer");
+		check(nrs_accumulate(ctx.get(), stream, (uint32_t)width, (uint32_t)height, frame_buffer, accumulate_buffer, spp, (uint32_t)color_space), "nrs_accumulate");
+		++spp;
+	}
 };
 
 // The slice of ngp::Testbed that render_nerf reads (SURVEY 8b "implicit inputs"), with the reference's member names.

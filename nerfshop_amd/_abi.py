@@ -149,7 +149,7 @@ EXPORTS = [
     "nrs_poisson_boundary", "nrs_poisson_sample_coords", "nrs_project_selection_pixels", "nrs_upper_cell_idx", "nrs_selection_cells",
     "nrs_edit_create", "nrs_edit_create_affine", "nrs_edit_destroy", "nrs_edit_map_rays", "nrs_edit_map_positions",
     "nrs_edit_set_mvc", "nrs_edit_update_cage", "nrs_edit_update_vertices", "nrs_edit_lut_size", "nrs_edit_download",
-    "nrs_render_nerf", "nrs_render_owned_tiles", "nrs_render_tile_pitch", "nrs_detile", "nrs_trace_samples",
+    "nrs_render_nerf", "nrs_render_owned_tiles", "nrs_render_tile_pitch", "nrs_detile", "nrs_trace_samples", "nrs_accumulate",
     "nrs_snapshot_open", "nrs_snapshot_close", "nrs_snapshot_model_desc", "nrs_snapshot_params_fp16", "nrs_snapshot_density_grid",
     "nrs_snapshot_camera", "nrs_edits_open", "nrs_edits_close", "nrs_edits_count", "nrs_edits_type", "nrs_edits_cage", "nrs_edits_affine",
     "nrs_tet_lut_build", "nrs_tet_lut_n_idx", "nrs_tet_lut_max_per_cell", "nrs_tet_lut_offsets",
@@ -253,6 +253,7 @@ def load():
     lib.nrs_render_tile_pitch.restype = U32
     lib.nrs_detile.argtypes = [P, P, C.POINTER(RenderParams), U32, U32, P, U32, C.c_size_t, P]
     lib.nrs_trace_samples.argtypes = [P, C.POINTER(RenderParams), P, U32, P, U32, P, P, P]
+    lib.nrs_accumulate.argtypes = [P, P, U32, U32, P, P, U32, U32]
     lib.nrs_snapshot_open.argtypes = [C.c_char_p, C.POINTER(P)]
     lib.nrs_snapshot_close.argtypes = [P]
     lib.nrs_snapshot_close.restype = None

@@ -1514,6 +1514,15 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	return NRS_OK;
 }
 
+int nrs_accumulate(nrs_ctx* ctx, void* stream, uint32_t width, uint32_t height, const float* d_frame, float* d_accumulate, uint32_t sample_count, uint32_t color_space) {
+	if (!ctx || !d_frame || !d_accumulate) return fail(NRS_ERR_INVALID_ARG, "nrs_accumulate: NULL argument");
+	if (color_space > NRS_COLOR_VISPOSNEG) return fail(NRS_ERR_INVALID_ARG, "nrs_accumulate: color_space is 0 (Linear), 1 (SRGB) or 2 (VisPosNeg)");
+	if ((uint64_t)width * height > 0xffffffffull) return fail(NRS_ERR_INVALID_ARG, "nrs_accumulate: image too large");
+	HIP_TRY(hipSetDevice(ctx->device));
+	NRS_TRY(launch_accumulate(width * height, d_frame, d_accumulate, sample_count, (int)color_space, stream));
+	return NRS_OK;
+}
+
 int nrs_detile(nrs_ctx* ctx, void* stream, const nrs_render_params* p, uint32_t n_ranks, uint32_t tiles_per_rank_padded, const float* d_tiles,
                uint32_t channels, size_t rank_stride_floats, float* d_image) {
 	if (!ctx || !p || !d_tiles || !d_image) return fail(NRS_ERR_INVALID_ARG, "nrs_detile: NULL argument");

@@ -198,6 +198,7 @@ int launch_occ_accel(const uint8_t* d_bitfield, uint32_t* d_masks, float* d_out,
 // one iteration of update_density_grid_nerf_operator up to (not including) mean/bitfield; d_grid_tmp must be zeroed
 int launch_grid_update(const DeviceModel& m, const DeviceEdit* d_edits, int n_edits, const nrs_grid_update& u, uint64_t rng_state_nonuniform,
                        float* d_grid, uint32_t* d_grid_tmp, int n_cus, void* stream);
+int launch_accumulate(uint32_t n_pixels, const float* d_frame, float* d_accum, uint32_t sample_count, int color_space, void* stream);
 int launch_detile(const nrs_render_params& p, uint32_t n_ranks, size_t rank_stride_floats, const float* d_tiles, uint32_t channels,
                   float* d_image, void* stream);
 const char* launch_last_error();

@@ -1284,6 +1284,41 @@ int launch_slice(const DeviceModel& m, const RenderArgs& a, int n_cus, void* str
 	return NRS_OK;
 }
 
+// ---- CudaRenderBuffer::accumulate (render_buffer.cu:540-560, accumulate_kernel :217-254): the running mean over the spp frames of a view ----------------------
+// One thread per pixel, 16 B read x 2 + 16 B written: HBM-bound (100 MB per 1080p frame).  Linear / VisPosNeg are plain fp32 in the reference's order (bit-exact);
+// SRGB goes through powf (the device library's here, CUDA's in the reference, glibc's in the oracle: tolerance, not bits).
+__global__ __launch_bounds__(256) void accumulate_kernel(uint32_t n, const float4* __restrict__ frame, float4* __restrict__ accum, float sample_count, int color_space, int clear) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	float4 color = frame[i];
+	float4 tmp = clear ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[i]; // (sample_count == 0: the reference clears the buffer first, :545-547)
+	if (color_space == 2) { // VisPosNeg
+		const float val = color.x - color.y;
+		float tmp_val = tmp.x - tmp.y;
+		tmp_val = (tmp_val * sample_count + val) / (sample_count + 1);
+		tmp.x = fmaxf(tmp_val, 0.0f);
+		tmp.y = fmaxf(-tmp_val, 0.0f);
+	} else {
+		if (color_space == 1) { // linear_to_srgb, common_device.cuh:55-61
+			color.x = color.x < 0.0031308f ? 12.92f * color.x : 1.055f * powf(color.x, 0.41666f) - 0.055f;
+			color.y = color.y < 0.0031308f ? 12.92f * color.y : 1.055f * powf(color.y, 0.41666f) - 0.055f;
+			color.z = color.z < 0.0031308f ? 12.92f * color.z : 1.055f * powf(color.z, 0.41666f) - 0.055f;
+		}
+		tmp.x = (tmp.x * sample_count + color.x) / (sample_count + 1);
+		tmp.y = (tmp.y * sample_count + color.y) / (sample_count + 1);
+		tmp.z = (tmp.z * sample_count + color.z) / (sample_count + 1);
+	}
+	tmp.w = (tmp.w * sample_count + color.w) / (sample_count + 1);
+	accum[i] = tmp;
+}
+int launch_accumulate(uint32_t n_pixels, const float* d_frame, float* d_accum, uint32_t sample_count, int color_space, void* stream) {
+	if (n_pixels == 0) return NRS_OK;
+	hipLaunchKernelGGL(accumulate_kernel, dim3((n_pixels + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_pixels, reinterpret_cast<const float4*>(d_frame),
+	                   reinterpret_cast<float4*>(d_accum), (float)sample_count, color_space, sample_count == 0 ? 1 : 0);
+	NRS_LAUNCH_CHECK("accumulate_kernel launch");
+	return NRS_OK;
+}
+
 // ---- trace_samples ------------------------------------------------------------------------------------------------
 // LENS: the camera model nrs_render_nerf's EXTRA instantiation marches with (depth of field, lens distortion, the distortion map) -- the hook must
 // emit the samples of the rays the renderer really shoots

@@ -356,6 +356,14 @@ class RenderBuffer:
     def set_spp(self, v):
         self._spp = int(v)
 
+    def accumulate(self, ctx, stream=None, color_space=0):
+        """CudaRenderBuffer::accumulate (render_buffer.cu:540): the frame buffer joins the running mean of this view's spp frames; spp() counts them."""
+        if getattr(self, "_accumulate", None) is None:
+            self._accumulate = torch.zeros_like(self._frame)
+        check(_abi.load().nrs_accumulate(ctx.h, _stream_handle(stream), self.width, self.height, self._frame.data_ptr(), self._accumulate.data_ptr(), int(self._spp), int(color_space)))
+        self._spp += 1
+        return self._accumulate
+
     def clear_frame(self, stream=None):
         self._frame.zero_()
         self._depth.zero_()

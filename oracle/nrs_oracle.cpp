@@ -1917,6 +1917,30 @@ void orc_network_inference(void* model, uint32_t n, const float* in7, uint16_t* 
 			else out[(size_t)i * 16 + c] = o[c];
 	}
 }
+// CudaRenderBuffer::accumulate (render_buffer.cu:540-560) + accumulate_kernel (:217-254): the running mean over the spp frames of a view.
+// sample_count = frames already accumulated (0 clears the buffer first); color_space: 0 Linear, 1 SRGB (linear_to_srgb, common_device.cuh:55-61, before
+// the mean), 2 VisPosNeg (the EncodingVis picture: positive part in x, negative in y).
+static inline float linear_to_srgb(float linear) { return linear < 0.0031308f ? 12.92f * linear : 1.055f * powf(linear, 0.41666f) - 0.055f; }
+void orc_accumulate(int width, int height, const float* frame, float* accumulate, uint32_t sample_count, int color_space) {
+	const size_t n = (size_t)width * height;
+	if (sample_count == 0) memset(accumulate, 0, sizeof(float) * 4 * n);
+	const float sc = (float)sample_count;
+	for (size_t i = 0; i < n; ++i) {
+		float color[4] = {frame[4 * i], frame[4 * i + 1], frame[4 * i + 2], frame[4 * i + 3]};
+		float* tmp = accumulate + 4 * i;
+		if (color_space == 2) {
+			const float val = color[0] - color[1];
+			float tmp_val = tmp[0] - tmp[1];
+			tmp_val = (tmp_val * sc + val) / (sc + 1);
+			tmp[0] = fmaxf(tmp_val, 0.0f);
+			tmp[1] = fmaxf(-tmp_val, 0.0f);
+		} else {
+			if (color_space == 1) for (int c = 0; c < 3; ++c) color[c] = linear_to_srgb(color[c]);
+			for (int c = 0; c < 3; ++c) tmp[c] = (tmp[c] * sc + color[c]) / (sc + 1);
+		}
+		tmp[3] = (tmp[3] * sc + color[3]) / (sc + 1);
+	}
+}
 // tcnn input_gradient(stream, 3, ...) restated: d density_raw / d warped position of n samples [n x 7] -> [n x 3]
 void orc_density_input_gradient(void* model, uint32_t n, const float* in7, float* grad3) {
 	const Model& m = *(const Model*)model;

@@ -60,6 +60,7 @@ def load():
         "orc_density_on_grid": (None, [P, P, P, P, P, P]), "orc_rgba_on_grid": (None, [P, P, P, P, P, P]),
         "orc_project_selection_pixels": (None, [P, P, P, U32, F, P, P, P]),
         "orc_poisson_boundary": (None, [P, P, U32, U32, U32, P, I, P, P, P]),
+        "orc_accumulate": (None, [I, I, P, P, U32, I]),
         "orc_density_input_gradient": (None, [P, U32, P, P]), "orc_network_activation": (I, [P, U32, P, U32, U32, P]),
     }
     for name, (res, args) in sig.items():
@@ -233,6 +234,14 @@ class AffineEdit(Edit):
         self.lib = load()
         self.keepalive = affine_op
         self.h = self.lib.orc_edit_create_affine(C.byref(desc), C.byref(affine_op))
+
+
+def accumulate(frame, accum, sample_count, color_space=0):
+    """CudaRenderBuffer::accumulate: `accum` [H, W, 4] f32 is updated in place with frame number sample_count (0-based) of the view."""
+    f = np.ascontiguousarray(frame, np.float32)
+    assert accum.dtype == np.float32 and accum.flags.c_contiguous and accum.shape == f.shape
+    load().orc_accumulate(f.shape[1], f.shape[0], f.ctypes.data, accum.ctypes.data, int(sample_count), int(color_space))
+    return accum
 
 
 def tet_lut_build(vertices, tets):

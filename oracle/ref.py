@@ -37,7 +37,7 @@ def load():
     global _lib
     if _lib is None:
         _lib = C.CDLL(LIB_PATH)
-        for fn in ("ref_render_frame", "ref_set_introspection", "ref_trace_coords", "ref_edit_map_rays", "ref_edit_map_positions", "ref_edit_poisson_residuals", "ref_build_tet_grid",
+        for fn in ("ref_render_frame", "ref_accumulate", "ref_set_introspection", "ref_trace_coords", "ref_edit_map_rays", "ref_edit_map_positions", "ref_edit_poisson_residuals", "ref_build_tet_grid",
                    "ref_grid_to_bitfield", "ref_bary_tet", "ref_point_in_tet", "ref_ld_random_val", "ref_ld_random_pixel_offset", "ref_sobol", "ref_ray_intersect",
                    "ref_box_intersects_triangle", "ref_grid_math", "ref_warp", "ref_evaluate_sh9", "ref_activations", "ref_pixel_to_ray", "ref_cell_functions", "ref_local_rotations", "ref_mvc_compute", "ref_mvc_apply", "ref_poisson_interpolate", "ref_affine_map_rays", "ref_affine_map_positions"):
             getattr(_lib, fn).restype = None
@@ -72,6 +72,14 @@ def render_frame(desc, params, bitfield, meshes, oracle_model, frame=None, want_
     lib.ref_set_introspection(C.cast(olib.orc_density_input_gradient7, C.c_void_p), C.cast(olib.orc_visualize_activation7, C.c_void_p))  # tcnn's input_gradient / visualize_activation: the oracle's restatements
     lib.ref_render_frame(C.byref(desc), C.byref(params), _p(bf), arr, C.c_int(len(meshes)), net, C.c_void_p(oracle_model.h), _p(frame), _p(depth), _p(steps), C.byref(stats))
     return frame, depth, steps, stats
+
+
+def accumulate(frame, accum, sample_count, color_space=0):
+    """CudaRenderBuffer::accumulate with the reference's accumulate_kernel; `accum` [H, W, 4] f32 is updated in place."""
+    f = _f32(frame)
+    assert accum.dtype == np.float32 and accum.flags.c_contiguous and accum.shape == f.shape
+    load().ref_accumulate(C.c_int(f.shape[1]), C.c_int(f.shape[0]), _p(f), _p(accum), C.c_uint32(int(sample_count)), C.c_int(int(color_space)))
+    return accum
 
 
 def update_density_grid(desc, meshes, grid, update, oracle_model):

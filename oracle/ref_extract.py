@@ -21,6 +21,7 @@ import sys
 #   "block:<owner>:<n>" : brace-balanced block that starts on the n-th matching line inside member function <owner>
 #   "until:<regex>" : up to the first following line matching <regex>; "before:<regex>" : up to the line before it
 FRAGMENTS = [
+    ("src/render_buffer.cu", "accumulate_kernel", r"^__global__ void accumulate_kernel\(", "fn"),
     ("src/testbed_nerf.cu", "march_constants", r"^static constexpr uint32_t MARCH_ITER", r"until:^static constexpr uint32_t MAX_STEPS_INBETWEEN_COMPACTION"),
     ("include/neural-graphics-primitives/editing/datastructures/tet_mesh.h", "corner_offsets", r"^static const std::vector<Eigen::Vector3f> corner_offsets = \{", r"until:^\};"),
     ("src/testbed_nerf.cu", "network_to_rgb_derivative", r"^__device__ float network_to_rgb_derivative\(", "fn"),

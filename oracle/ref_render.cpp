@@ -44,6 +44,7 @@ using namespace Eigen;
 using namespace tcnn;
 
 NGP_NAMESPACE_BEGIN
+#include "accumulate_kernel.inc"
 #include "march_constants.inc"
 #include "network_to_rgb_derivative.inc"
 #include "network_to_density_derivative.inc"
@@ -708,6 +709,20 @@ void ref_poisson_boundary(const nrs_model_desc* desc, const float* vertices_in, 
 #include "poisson_boundary_fit_loop.inc"
 	memcpy(density_out, target_density.data(), sizeof(float) * n_verts);
 	memcpy(sh_out, (const void*)target_shs.data(), sizeof(float) * 27 * n_verts);
+}
+
+// ---- CudaRenderBuffer::accumulate, render_buffer.cu:540-560: the running mean of the spp frames (accumulate_kernel :217-254) ---------------------------
+// sample_count = m_spp before the call (0: the accumulate buffer is cleared first, :545-547); color_space = EColorSpace.
+void ref_accumulate(int width, int height, const float* frame, float* accumulate, uint32_t sample_count, int color_space) {
+	const Vector2i res(width, height);
+	if (sample_count == 0) memset(accumulate, 0, sizeof(float) * 4 * (size_t)width * height);
+	blockDim.x = blockDim.y = blockDim.z = 1;
+	threadIdx.x = threadIdx.y = threadIdx.z = 0;
+	for (int y = 0; y < height; ++y)
+		for (int x = 0; x < width; ++x) {
+			blockIdx.x = (uint32_t)x; blockIdx.y = (uint32_t)y; blockIdx.z = 0;
+			accumulate_kernel(res, (Array4f*)frame, (Array4f*)accumulate, (float)sample_count, (EColorSpace)color_space);
+		}
 }
 
 // ---- update_density_grid_mean_and_bitfield, testbed_nerf.cu:3642-3657: grid_to_bitfield + bitfield_max_pool (the mean is the caller's) ------

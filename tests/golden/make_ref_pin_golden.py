@@ -38,6 +38,7 @@ def main():
     store_hashed("selection", cases.selection_cases(scenes, "ref"))
     store_hashed("grid_eval", cases.grid_eval_cases(scenes, "ref"))
     store_hashed("poisson_boundary", cases.poisson_boundary_cases(scenes, "ref"))
+    store_hashed("accumulate", cases.accumulate_cases("ref"))
     for case in cases.FRAME_CASES:
         f, d, s, st = cases.render_case(scenes, case, "ref")
         out[f"frame/{case[0]}/frame"], out[f"frame/{case[0]}/depth"], out[f"frame/{case[0]}/steps"], out[f"frame/{case[0]}/stats"] = f, d, s.astype(np.uint16), st

@@ -578,3 +578,23 @@ def poisson_boundary_cases(scenes, which):
             d, sh = sc.oracle_model.poisson_boundary(verts, 10, 10, jit, inside)[:2]
         out[name] = [d, sh]
     return out
+
+
+def accumulate_cases(which):
+    """-> {colour space: [accumulate buffer after 1, 2, 5 frames]}: CudaRenderBuffer::accumulate over seeded frames (values above 1, tiny values below the sRGB
+    toe, negative VisPosNeg differences), 48 x 27 pixels"""
+    from oracle import oracle as orc
+    from oracle import ref
+    out = {}
+    for name, cs in (("linear", 0), ("srgb", 1), ("visposneg", 2)):
+        rng = _rng(f"accumulate{cs}")
+        acc = np.full((27, 48, 4), 7.0, np.float32)  # garbage that frame 0 must overwrite
+        snaps = []
+        for k in range(5):
+            f = rng.uniform(0.0, 1.5, (27, 48, 4)).astype(np.float32)
+            f[::3, ::5, :3] *= np.float32(1e-3)
+            (ref if which == "ref" else orc).accumulate(f, acc, k, cs)
+            if k in (0, 1, 4):
+                snaps.append(acc.copy())
+        out[name] = snaps
+    return out

@@ -188,3 +188,13 @@ def test_stream_live(scenes, k):
     a, b = cases.stream_case(scenes, cases.STREAM_CASES[k], "ref"), cases.stream_case(scenes, cases.STREAM_CASES[k], "orc")
     for x, y in zip(a, b):
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
+# ---- CudaRenderBuffer::accumulate: the reference's accumulate_kernel (render_buffer.cu:217-254), all three colour spaces ----
+def test_accumulate_golden(golden):
+    _check_hashed(golden, "accumulate", cases.accumulate_cases("orc"))
+
+
+@live
+def test_accumulate_live():
+    _check_live(cases.accumulate_cases("ref"), cases.accumulate_cases("orc"))
