@@ -92,7 +92,13 @@ typedef enum nrs_layout { NRS_PLANES = 0, NRS_INTERLEAVED = 1 } nrs_layout;
 typedef enum nrs_grid_acc { NRS_GRID_ACC_FP32 = 0, NRS_GRID_ACC_NETWORK = 1 } nrs_grid_acc;
 typedef enum nrs_mlp_acc { NRS_MLP_ACC_FP32 = 0, NRS_MLP_ACC_FP16 = 1 } nrs_mlp_acc;
 
-/* Network hyper-parameters: configs/nerf/base.json:23-58 + src/testbed.cu:2257-2333. */
+/* Network hyper-parameters: configs/nerf/base.json:23-58 + src/testbed.cu:2257-2333.
+ * Accepted: base.json's family -- the 16 x 2 hash grid with any table size (base_14 / small / base / big.json: log2_hashmap_size 14 / 15 / 19 / 21), the 64-wide
+ * density network with one hidden layer, and an rgb network of 0 (CutlassMLP, base_0layer.json), 1, 2 (base.json) or 3 hidden layers (base_{1,2,3}layer.json) on the
+ * degree-4 spherical harmonics -- or NO direction encoding and rgb network (base_nodir.json -> NerfNetworkNoDir, testbed.cu:2314-2353): sh_degree = 0,
+ * rgb_hidden_layers = 0; the colour is then the density network's outputs 1..3 (nerf_network_nodir.h:47-91).  Parameter blob: [density | rgb | grid] with the rgb part
+ * [64 x 32] + (L - 1) [64 x 64] + [16 x 64] for L >= 1 hidden layers, one [8 x 32] matrix for L = 0, nothing for NoDir (tiny-cuda-nn's layouts as recalled;
+ * nrs_model_n_params says what a description implies).  Other encodings (configs/nerf/{frequency,densegrid,tensor,...}.json) are refused: NRS_ERR_UNSUPPORTED. */
 typedef struct nrs_model_desc {
 	uint32_t n_levels;             /* 16 */
 	uint32_t n_features_per_level; /* 2  */
@@ -102,8 +108,8 @@ typedef struct nrs_model_desc {
 	uint32_t n_neurons;            /* 64 (both MLPs) */
 	uint32_t density_hidden_layers;/* 1  */
 	uint32_t density_output_dims;  /* 16, nerf_network_full.h:47-49 */
-	uint32_t rgb_hidden_layers;    /* 2  */
-	uint32_t sh_degree;            /* 4  */
+	uint32_t rgb_hidden_layers;    /* 2  (0..3; 0 with sh_degree 0) */
+	uint32_t sh_degree;            /* 4  (0 = NerfNetworkNoDir) */
 	uint32_t rgb_activation;       /* nrs_activation; lego: Logistic   (testbed.h:636) */
 	uint32_t density_activation;   /* nrs_activation; Exponential      (testbed.h:637) */
 	float    aabb_min[3];          /* Testbed::m_aabb (training box): [0,1]^3 for aabb_scale 1 */

@@ -145,13 +145,81 @@ static int check_march_params(const nrs_render_params& p, const char* who) {
 	return NRS_OK;
 }
 // ---------------------------------------------------------------------------------------------------------------
-// NerfNetworkFull::width(layer) of forward_activations (nerf_network_full.h:507-517) for configs/nerf/base.json
-static uint32_t network_layer_width(uint32_t layer) { return (layer == 0u || layer == 2u) ? 32u : 64u; }
-static bool desc_supported(const nrs_model_desc& d) {
-	return d.n_levels == 16 && d.n_features_per_level == 2 && d.n_neurons == 64 && d.density_hidden_layers == 1 &&
-	       d.density_output_dims == 16 && d.rgb_hidden_layers == 2 && d.sh_degree == 4 && d.log2_hashmap_size >= 8 &&
-	       d.log2_hashmap_size <= 24 && d.base_resolution >= 1;
+// NerfNetworkFull::width(layer) / num_forward_activations (nerf_network_full.h:507-521): the hash-grid output, the density network's hidden layer, the rgb
+// network's input, then one layer per rgb hidden layer.  NerfNetworkNoDir (nerf_network_nodir.h:419-438): the first two (its num_forward_activations counts two
+// more, which its own forward_activations cannot serve).  0 = no such layer.
+static uint32_t network_layer_width(const nrs_model_desc& d, uint32_t layer) {
+	if (layer == 0u) return 32u;
+	if (layer == 1u) return 64u;
+	if (d.sh_degree == 0u) return 0u;
+	if (layer == 2u) return 32u;
+	return layer - 3u < d.rgb_hidden_layers ? 64u : 0u;
 }
+// configs/nerf/base.json's family: hash grid of 16 x 2 features (any table size: base_14 / small / base / big.json), the 64-wide density network with one hidden
+// layer, and an rgb network of 0 (CutlassMLP, base_0layer.json), 1, 2 (base.json) or 3 hidden layers (base_{1,2,3}layer.json) on SH degree 4 -- or none at all
+// (base_nodir.json -> NerfNetworkNoDir, testbed.cu:2314-2353: sh_degree == 0).
+static bool desc_supported(const nrs_model_desc& d) {
+	const bool trunk = d.n_levels == 16 && d.n_features_per_level == 2 && d.n_neurons == 64 && d.density_hidden_layers == 1 && d.density_output_dims == 16 &&
+	                   d.log2_hashmap_size >= 8 && d.log2_hashmap_size <= 24 && d.base_resolution >= 1;
+	if (!trunk) return false;
+	if (d.sh_degree == 0) return d.rgb_hidden_layers == 0;
+	return d.sh_degree == 4 && d.rgb_hidden_layers <= 3;
+}
+// rgb network parameters in the caller's blob (tiny-cuda-nn's layouts as recalled: the submodule is absent): FullyFusedMLP with L >= 1 hidden layers =
+// [64 x 32] + (L - 1) [64 x 64] + [16 x 64] (3 outputs padded to 16 rows); CutlassMLP without hidden layer = one [8 x 32] matrix (outputs padded to 8).
+static uint32_t n_rgb_weights(const nrs_model_desc& d) {
+	if (d.sh_degree == 0) return 0u;
+	if (d.rgb_hidden_layers == 0) return 8u * 32u;
+	return 64u * 32u + (d.rgb_hidden_layers - 1u) * 64u * 64u + 16u * 64u;
+}
+static uint32_t n_mlp_weights(const nrs_model_desc& d) { return kDensityW + n_rgb_weights(d); }
+
+// ---- lowering of the family onto the kernels' network (kCanonW entries, nrs_internal.h) -------------------------------------------------------------
+// Entries are opaque 16-bit words: fp16 bit patterns (nrs_model_set_params) or weight indices (nrs_model_set_params_device's permutation); `ops` says what
+// zero, +1, -1 and a negated entry look like.  Every lowered network computes the values of the network it stands for EXACTLY, in both rounding models:
+//   one hidden layer:  Wr2 = I.  The second hidden layer is relu(round(1 x h)) = h (h >= 0, an fp16 value; the other addends are zeros).
+//   no hidden layer:   y = W x is formed by the FIRST layer with its own k blocks ([density outputs | SH coefficients]: the roundings of the one-matrix network),
+//                      once as W and once as -W (rounding is symmetric): hidden = (relu(y), relu(-y)); Wr2 = I; the output layer subtracts the two, one of which is 0.
+//   no rgb network:    the same with unit rows in place of W: (r, g, b) = density-network outputs 1..3 (NerfNetworkNoDir::inference_mixed_precision_impl,
+//                      nerf_network_nodir.h:47-91).
+//   three hidden layers: Wr2b, the kernels' optional layer (DeviceModel::rgb_deep).
+// (A value of -0 comes out as +0: equal, not bit-identical.)
+struct LowerOps { uint16_t one, minus_one; uint16_t (*negate)(uint16_t); };
+static void lower_weights(const nrs_model_desc& d, const uint16_t* w, uint16_t* canon, const LowerOps& ops) {
+	memset(canon, 0, kCanonW * sizeof(uint16_t));
+	memcpy(canon, w, kDensityW * sizeof(uint16_t));
+	const uint16_t* r = w + kDensityW;
+	uint16_t* Wr1 = canon + kDensityW;   // [64 x 32]
+	uint16_t* Wr2 = Wr1 + 64 * 32;       // [64 x 64]
+	uint16_t* Wr3 = Wr2 + 64 * 64;       // [16 x 64]
+	uint16_t* Wr2b = Wr3 + 16 * 64;      // [64 x 64]
+	auto identity = [&](uint16_t* M) { for (int i = 0; i < 64; ++i) M[i * 64 + i] = ops.one; };
+	const uint32_t L = d.rgb_hidden_layers;
+	if (d.sh_degree == 0 || L == 0) {
+		for (int row = 0; row < 8; ++row) {
+			if (d.sh_degree == 0) {
+				if (row < 3) { Wr1[row * 32 + 1 + row] = ops.one; Wr1[(8 + row) * 32 + 1 + row] = ops.minus_one; }
+			} else {
+				for (int k = 0; k < 32; ++k) { Wr1[row * 32 + k] = r[row * 32 + k]; Wr1[(8 + row) * 32 + k] = ops.negate(r[row * 32 + k]); }
+			}
+			Wr3[row * 64 + row] = ops.one;
+			Wr3[row * 64 + 8 + row] = ops.minus_one;
+		}
+		identity(Wr2);
+	} else if (L == 1) {
+		memcpy(Wr1, r, 64 * 32 * 2);
+		identity(Wr2);
+		memcpy(Wr3, r + 64 * 32, 16 * 64 * 2);
+	} else if (L == 2) {
+		memcpy(Wr1, r, kRgbW * 2);
+	} else {
+		memcpy(Wr1, r, (64 * 32 + 64 * 64) * 2);
+		memcpy(Wr2b, r + 64 * 32 + 64 * 64, 64 * 64 * 2);
+		memcpy(Wr3, r + 64 * 32 + 2 * 64 * 64, 16 * 64 * 2);
+	}
+}
+static const LowerOps kLowerValues{0x3C00, 0xBC00, [](uint16_t h) -> uint16_t { return (uint16_t)(h ^ 0x8000u); }};
+static const LowerOps kLowerIndices{kFragOne, kFragMinusOne, [](uint16_t i) -> uint16_t { return (uint16_t)(i | kFragNegate); }};
 
 // tcnn GridEncoding level geometry: scale = exp2(l*log2(b))*Nmin - 1, res = ceil(scale)+1,
 // entries = min(align8(res^3), 2^log2_T).  tiny-cuda-nn evaluates the scale in FLOAT -- exp2f(level * log2f(per_level_scale)) *
@@ -191,6 +259,7 @@ static void make_weight_fragments(const uint16_t* w, uint16_t* frag, uint16_t on
 	const uint16_t* Wr1 = Wd2 + 16 * 64;     // [64 x 32]
 	const uint16_t* Wr2 = Wr1 + 64 * 32;     // [64 x 64]
 	const uint16_t* Wr3 = Wr2 + 64 * 64;     // [16 x 64]
+	const uint16_t* Wr2b = Wr3 + 16 * 64;    // [64 x 64] (kCanonW: lower_weights' layout)
 	auto hidden_row = [](int mb, int g, int r) { return 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * g; }; // D-tile row of reg r
 	auto at = [&](int f, int lane, int e) -> uint16_t& { return frag[((size_t)f * 64 + lane) * 8 + e]; };
 	memset(frag, 0, kWfragDeviceBytes);
@@ -213,6 +282,7 @@ static void make_weight_fragments(const uint16_t* w, uint16_t* frag, uint16_t on
 				if (i < 16) at(4 + ks, lane, e) = Wd2[i * 64 + k];
 				if (i < 16) at(20 + ks, lane, e) = Wr3[i * 64 + k];
 				for (int mb = 0; mb < 2; ++mb) at(12 + mb * 4 + ks, lane, e) = Wr2[(32 * mb + i) * 64 + k];
+				for (int mb = 0; mb < 2; ++mb) at(30 + mb * 4 + ks, lane, e) = Wr2b[(32 * mb + i) * 64 + k];
 			}
 			for (int mb = 0; mb < 2; ++mb) {
 				const int kd = (e & 3) + 8 * (e >> 2) + 4 * g; // density-output row in element e
@@ -362,11 +432,11 @@ int nrs_ctx_device_info(const nrs_ctx* c, char* name_out, size_t name_len, int* 
 size_t nrs_model_n_params(const nrs_model_desc* d) {
 	if (!d || !desc_supported(*d)) return 0;
 	LevelParams lv[kLevels];
-	return (size_t)kDensityW + kRgbW + (size_t)make_levels(*d, lv) * 2;
+	return (size_t)n_mlp_weights(*d) + (size_t)make_levels(*d, lv) * 2;
 }
 int nrs_model_level_table(const nrs_model_desc* d, float* scale, uint32_t* resolution, uint32_t* entry_offset, uint32_t* entry_count,
                           uint32_t* hashed) {
-	if (!d || !desc_supported(*d)) return fail(NRS_ERR_UNSUPPORTED, "model description outside configs/nerf/base.json's architecture");
+	if (!d || !desc_supported(*d)) return fail(NRS_ERR_UNSUPPORTED, "model description outside configs/nerf/base.json's family (hash grid 16 x 2, 64-wide density network, rgb network of 0..3 hidden layers or none)");
 	LevelParams lv[kLevels];
 	make_levels(*d, lv);
 	for (uint32_t l = 0; l < d->n_levels; ++l) {
@@ -381,7 +451,7 @@ int nrs_model_level_table(const nrs_model_desc* d, float* scale, uint32_t* resol
 
 int nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out) {
 	if (!ctx || !desc || !out) return fail(NRS_ERR_INVALID_ARG, "nrs_model_create: NULL argument");
-	if (!desc_supported(*desc)) return fail(NRS_ERR_UNSUPPORTED, "model description outside configs/nerf/base.json's architecture");
+	if (!desc_supported(*desc)) return fail(NRS_ERR_UNSUPPORTED, "model description outside configs/nerf/base.json's family (hash grid 16 x 2, 64-wide density network, rgb network of 0..3 hidden layers or none)");
 	for (int k = 0; k < 3; ++k)
 		if (!(desc->aabb_max[k] > desc->aabb_min[k])) return fail(NRS_ERR_INVALID_ARG, "nrs_model_create: empty aabb");
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -398,6 +468,7 @@ int nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out) 
 		if (std::frexp(diag, &e) != 0.5f) m->dm.diag_pow2 = 0;
 		m->dm.inv_diag[k] = 1.0f / diag;
 	}
+	m->dm.rgb_deep = desc->sh_degree != 0 && desc->rgb_hidden_layers == 3 ? 1u : 0u;
 	m->dm.rgb_activation = desc->rgb_activation;
 	m->dm.density_activation = desc->density_activation;
 	hipError_t he = hipMalloc((void**)&m->d_grid, (size_t)m->total_entries * 4);
@@ -594,7 +665,8 @@ size_t nrs_model_cell_cache_bytes(const nrs_model* m, uint32_t* n_levels) {
 
 int nrs_model_set_params(nrs_model* m, const void* h_params_fp16, size_t n_params) {
 	if (!m || !h_params_fp16) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_params: NULL argument");
-	const size_t expect = (size_t)kDensityW + kRgbW + (size_t)m->total_entries * 2;
+	const uint32_t n_mlp = n_mlp_weights(m->desc);
+	const size_t expect = (size_t)n_mlp + (size_t)m->total_entries * 2;
 	if (n_params != expect) {
 		char buf[160];
 		snprintf(buf, sizeof(buf), "nrs_model_set_params: got %zu params, the description implies %zu", n_params, expect);
@@ -602,10 +674,11 @@ int nrs_model_set_params(nrs_model* m, const void* h_params_fp16, size_t n_param
 	}
 	HIP_TRY(hipSetDevice(m->ctx->device));
 	const uint16_t* w = (const uint16_t*)h_params_fp16;
-	std::vector<uint16_t> frag(kWfragDeviceBytes / 2);
-	make_weight_fragments(w, frag.data());
+	std::vector<uint16_t> canon(kCanonW), frag(kWfragDeviceBytes / 2);
+	lower_weights(m->desc, w, canon.data(), kLowerValues);
+	make_weight_fragments(canon.data(), frag.data());
 	HIP_TRY(hipMemcpy(m->d_wfrag, frag.data(), kWfragDeviceBytes, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(m->d_grid, w + kDensityW + kRgbW, (size_t)m->total_entries * 4, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(m->d_grid, w + n_mlp, (size_t)m->total_entries * 4, hipMemcpyHostToDevice));
 	m->have_params = true;
 	return rebuild_cell_cache(m);
 }
@@ -617,7 +690,8 @@ int nrs_model_set_params(nrs_model* m, const void* h_params_fp16, size_t n_param
 // this call.  Copy semantics: call it again after every optimiser step (the reference's renderer reads the blob in place; ours is a transformed copy).
 int nrs_model_set_params_device(nrs_model* m, const void* d_params_fp16, size_t n_params, void* stream) {
 	if (!m || !d_params_fp16) return fail(NRS_ERR_INVALID_ARG, "nrs_model_set_params_device: NULL argument");
-	const size_t expect = (size_t)kDensityW + kRgbW + (size_t)m->total_entries * 2;
+	const uint32_t n_mlp = n_mlp_weights(m->desc);
+	const size_t expect = (size_t)n_mlp + (size_t)m->total_entries * 2;
 	if (n_params != expect) {
 		char buf[160];
 		snprintf(buf, sizeof(buf), "nrs_model_set_params_device: got %zu params, the description implies %zu", n_params, expect);
@@ -627,10 +701,11 @@ int nrs_model_set_params_device(nrs_model* m, const void* d_params_fp16, size_t 
 	hipStream_t s = (hipStream_t)stream;
 	const uint16_t* d = (const uint16_t*)d_params_fp16;
 	if (!m->d_wfrag_src) { // the fragment permutation as indices: run the host routine on the identity (index + 1; 0 stays "padding")
-		static_assert(kDensityW + kRgbW < 65535, "weight indices fit 16 bits");
-		std::vector<uint16_t> ident(kDensityW + kRgbW), src(kWfragDeviceBytes / 2);
+		static_assert(kDensityW + 64 * 32 + 2 * 64 * 64 + 16 * 64 < kFragNegate, "weight indices + 1 fit 15 bits");
+		std::vector<uint16_t> ident(n_mlp), canon(kCanonW), src(kWfragDeviceBytes / 2);
 		for (size_t i = 0; i < ident.size(); ++i) ident[i] = (uint16_t)(i + 1);
-		make_weight_fragments(ident.data(), src.data(), kFragOne);
+		lower_weights(m->desc, ident.data(), canon.data(), kLowerIndices);
+		make_weight_fragments(canon.data(), src.data(), kFragOne);
 		HIP_TRY(hipMalloc((void**)&m->d_wfrag_src, kWfragDeviceBytes));
 		const hipError_t up = hipMemcpy(m->d_wfrag_src, src.data(), kWfragDeviceBytes, hipMemcpyHostToDevice);
 		if (up != hipSuccess) { // never keep a permutation that was not uploaded: later calls would scramble the weights silently
@@ -640,7 +715,7 @@ int nrs_model_set_params_device(nrs_model* m, const void* d_params_fp16, size_t 
 		}
 	}
 	NRS_TRY(launch_weight_fragments(d, m->d_wfrag_src, (uint16_t*)m->d_wfrag, kWfragDeviceBytes / 2, stream));
-	HIP_TRY(hipMemcpyAsync(m->d_grid, d + kDensityW + kRgbW, (size_t)m->total_entries * 4, hipMemcpyDeviceToDevice, s));
+	HIP_TRY(hipMemcpyAsync(m->d_grid, d + n_mlp, (size_t)m->total_entries * 4, hipMemcpyDeviceToDevice, s));
 	m->have_params = true;
 	return rebuild_cell_cache(m, stream, false);
 }
@@ -785,7 +860,8 @@ int nrs_network_input_gradient(nrs_model* m, void* stream, uint32_t n, const flo
 int nrs_network_visualize_activation(nrs_model* m, void* stream, uint32_t layer, uint32_t dimension, uint32_t n, const float* d_in, float* d_out) {
 	const int st = check_net(m, d_in, d_out, "nrs_network_visualize_activation");
 	if (st != NRS_OK) return st;
-	if (layer > 4u || dimension >= network_layer_width(layer)) return fail(NRS_ERR_INVALID_ARG, "nrs_network_visualize_activation: no such unit (layers 0..4 are 32 | 64 | 32 | 64 | 64 wide)");
+	if (dimension >= network_layer_width(m->desc, layer))
+		return fail(NRS_ERR_INVALID_ARG, "nrs_network_visualize_activation: no such unit (layers: hash grid 32 | density hidden 64 | rgb input 32 | one of 64 per rgb hidden layer)");
 	HIP_TRY(hipSetDevice(m->ctx->device));
 	NRS_TRY(launch_network(m->dm, 4, n, d_in, NRS_NETWORK_INPUT_FLOATS, d_out, 1, (int)(layer | (dimension << 8)), m->ctx->n_cus, stream));
 	return NRS_OK;
@@ -1277,8 +1353,8 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	if (!m->have_params) return fail(NRS_ERR_STATE, "nrs_render_nerf: parameters not set (nrs_model_set_params)");
 	if (!m->have_bitfield) return fail(NRS_ERR_STATE, "nrs_render_nerf: occupancy not set (nrs_model_set_density_bitfield/_grid)");
 	{ const int pc = check_march_params(*p, "nrs_render_nerf"); if (pc != NRS_OK) return pc; }
-	if (p->render_mode == NRS_RENDER_ENCODING_VIS && (p->visualized_layer > 4u || p->visualized_dimension >= network_layer_width(p->visualized_layer)))
-		return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: EncodingVis: visualized_layer is 0..4 (hash grid 32 | density hidden 64 | rgb input 32 | rgb hidden 64, 64) and visualized_dimension a unit of it");
+	if (p->render_mode == NRS_RENDER_ENCODING_VIS && p->visualized_dimension >= network_layer_width(m->desc, p->visualized_layer))
+		return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: EncodingVis: visualized_layer is hash grid 32 | density hidden 64 | rgb input 32 | one of 64 per rgb hidden layer (base.json: 0..4) and visualized_dimension a unit of it");
 	if (!std::isfinite(p->glow_y_cutoff) || p->glow_mode > 31u) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: glow_mode is a 5-bit mask and glow_y_cutoff must be finite");
 	if (p->distortion_mode > 2u) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: distortion_mode must be 0 (None), 1 (Iterative) or 2 (FTheta)");
 	for (int i = 0; i < 7; ++i)
@@ -1335,6 +1411,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	// everything of render_nerf's surface beyond Shade / Cost with a pinhole camera runs the EXTRA instantiation (one lane per ray)
 	a.extra = ((p->render_mode != NRS_RENDER_SHADE && p->render_mode != NRS_RENDER_COST) || p->show_accel || p->dof != 0.f || p->distortion_mode || p->d_distortion_map ||
 	           p->d_envmap || p->glow_mode) ? 1u : 0u;
+	if (m->dm.rgb_deep) a.extra = 1u; // (a third rgb hidden layer is evaluated by the catch-all instantiation only: launch_render)
 	if (p->render_mode == NRS_RENDER_SLICE) { // tn:3109-3162: no marching at all; one network evaluation per owned pixel
 		a.frame = d_frame; a.depth = d_depth; a.steps = d_steps; a.counters = d_counters_slot;
 		HIP_TRY(hipMemsetAsync(d_counters_slot, 0, sizeof(RenderCounters), s));

@@ -381,7 +381,7 @@ int nrs_snapshot_open(const char* path, nrs_snapshot** out) {
 		const Value& net = root.at("network");
 		const Value* rgb = root.find("rgb_network");
 		const Value* dir = root.find("dir_encoding");
-		if (!rgb || !dir) throw std::runtime_error("snapshot without dir_encoding / rgb_network (NerfNetworkNoDir) is not supported");
+		const bool has_dir = rgb && dir; // testbed.cu:2314: otherwise NerfNetworkNoDir (configs/nerf/base_nodir.json): sh_degree = 0 in nrs_model_desc
 		nrs_model_desc& d = s->desc;
 		// every hyper-parameter is validated BEFORE it is used in arithmetic (a crafted file must be refused, not divide by zero or shift by 200)
 		auto bounded = [](double v, double lo, double hi, const char* what) -> uint32_t {
@@ -402,11 +402,15 @@ int nrs_snapshot_open(const char* path, nrs_snapshot** out) {
 		d.n_neurons = bounded(net.number_or("n_neurons", 64), 1, 4096, "network.n_neurons");
 		d.density_hidden_layers = bounded(net.number_or("n_hidden_layers", 1), 0, 64, "network.n_hidden_layers");
 		d.density_output_dims = 16; // nerf_network_full.h:47-49
-		d.rgb_hidden_layers = bounded(rgb->number_or("n_hidden_layers", 2), 0, 64, "rgb_network.n_hidden_layers");
-		if ((uint32_t)rgb->number_or("n_neurons", 64) != d.n_neurons) throw std::runtime_error("density / rgb networks of different widths are not supported");
-		d.sh_degree = 4;
-		if (const Value* nested = dir->find("nested"))
-			if (nested->kind == Value::Arr && !nested->a.empty()) d.sh_degree = bounded(nested->a[0].number_or("degree", 4), 0, 16, "dir_encoding.degree");
+		d.rgb_hidden_layers = 0;
+		d.sh_degree = 0;
+		if (has_dir) {
+			d.rgb_hidden_layers = bounded(rgb->number_or("n_hidden_layers", 2), 0, 64, "rgb_network.n_hidden_layers");
+			if (d.rgb_hidden_layers > 0 && (uint32_t)rgb->number_or("n_neurons", 64) != d.n_neurons) throw std::runtime_error("density / rgb networks of different widths are not supported");
+			d.sh_degree = 4;
+			if (const Value* nested = dir->find("nested"))
+				if (nested->kind == Value::Arr && !nested->a.empty()) d.sh_degree = bounded(nested->a[0].number_or("degree", 4), 1, 16, "dir_encoding.degree");
+		}
 		d.rgb_activation = NRS_ACT_LOGISTIC;      // testbed.h:636-637 defaults; snapshots do not store them
 		d.density_activation = NRS_ACT_EXPONENTIAL;
 		const float half = 0.5f * (float)std::min<uint32_t>(1u << (kCascades - 1), as); // m_aabb, testbed_nerf.cu:3410-3411
@@ -416,7 +420,7 @@ int nrs_snapshot_open(const char* path, nrs_snapshot** out) {
 		if (pb.kind != Value::Bin) throw std::runtime_error("params_binary is not binary");
 		const std::string ptype = snap->string_or("params_type", "__half");
 		const size_t n_expected = nrs_model_n_params(&d);
-		if (n_expected == 0) throw std::runtime_error("network architecture outside configs/nerf/base.json's family");
+		if (n_expected == 0) throw std::runtime_error("network architecture outside configs/nerf/base.json's family (hash grid 16 x 2, 64-wide density network with one hidden layer, rgb network of 0..3 hidden layers on SH degree 4 or none)");
 		if (ptype == "float") {
 			if (pb.s.size() != n_expected * 4) throw std::runtime_error("params_binary has the wrong size for this architecture");
 			s->params.resize(n_expected);

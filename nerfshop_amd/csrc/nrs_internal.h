@@ -16,6 +16,11 @@ constexpr uint32_t kCoarseWords = kCoarse * kCoarse * kCoarse / 32;
 static_assert((kCoarse & (kCoarse - 1)) == 0, "the block walk's bounds test (cx | cy | cz) needs a power of two");
 constexpr uint32_t kDensityW = 64 * 32 + 16 * 64;           // density MLP params (base.json:30-36)
 constexpr uint32_t kRgbW = 64 * 32 + 64 * 64 + 16 * 64;     // rgb MLP params (base.json:52-58)
+// The kernels evaluate ONE network shape: base.json's (density 32 -> 64 -> 16, rgb 32 -> 64 -> 64 -> 16), plus an optional third rgb hidden layer.  The
+// other members of configs/nerf/'s family -- rgb network with 0 / 1 / 3 hidden layers, no rgb network at all -- are LOWERED onto it when their parameters
+// arrive (lower_weights, nrs_api.cpp): matrices of 0 / +-1 that reproduce the smaller network's values exactly.  The canonical blob the MFMA fragments are
+// cut from: [Wd1 64x32 | Wd2 16x64 | Wr1 64x32 | Wr2 64x64 | Wr3 16x64 | Wr2b 64x64 (third hidden layer, base_3layer.json)].
+constexpr uint32_t kCanonW = kDensityW + kRgbW + 64 * 64;
 
 // One hash-grid level as the kernels consume it (staged in LDS, 48 B).
 struct LevelParams {
@@ -39,13 +44,16 @@ struct LevelParams {
 // Then two CONSTANT 0 / 1 fragments Sel0 / Sel1 (round 4): MFMA(Sel0, lo, 0) + MFMA(Sel1, hi, .) turn a D tile that was packed to fp16 (lo = rows of registers
 // 0..7, hi = 8..15) back into fp32 accumulator registers exactly -- the fp16-accumulator model (NRS_MLP_ACC_FP16) rounds the running sum after every k step,
 // and the way back from packed halfs through the matrix core costs two MFMA issues (the pipe is 10 % busy) instead of sixteen VALU conversions.
-// These 26 fragments are staged into LDS.  Behind them, in HBM only: Bwd[ks] (4), the A operands of dL/dfeatures = W1^T dL/dhidden (render mode Normals).
+// These 26 fragments are staged into LDS.  Behind them, in HBM only: Bwd[ks] (4), the A operands of dL/dfeatures = W1^T dL/dhidden (render mode Normals),
+// and R2b[mb][ks] (8), the third hidden layer of an rgb network that has one (DeviceModel::rgb_deep; base_3layer.json).
 constexpr uint32_t kNumFrags = 26;
-constexpr uint32_t kNumFragsDevice = 30;
+constexpr uint32_t kNumFragsDevice = 38;
 constexpr uint32_t kFragBytes = 64 * 8 * 2;
 constexpr uint32_t kWfragBytes = kNumFrags * kFragBytes; // 26 KiB: the LDS image
 constexpr uint32_t kWfragDeviceBytes = kNumFragsDevice * kFragBytes;
-constexpr uint16_t kFragOne = 0xffffu; // make_weight_fragments on the identity permutation: "the constant 1.0" (weight indices are < 65535)
+// make_weight_fragments on the identity permutation (nrs_model_set_params_device): an entry is a weight index + 1 (< 0x8000), bit 15 = "negated",
+// 0 = padding, or one of the two constants
+constexpr uint16_t kFragOne = 0xffffu, kFragMinusOne = 0xfffeu, kFragNegate = 0x8000u;
 
 struct Box3 { float mn[3]; float mx[3]; };
 
@@ -76,6 +84,7 @@ struct DeviceModel {
 	uint32_t        rgb_activation;
 	uint32_t        density_activation;
 	uint32_t        numerics;  // bit 0: nrs_grid_acc NETWORK, bit 1: nrs_mlp_acc FP16 (nrs_model_set_numerics); 0 = the default roundings
+	uint32_t        rgb_deep;  // the rgb network has a third hidden layer (fragments R2b, read from wfrag in HBM): base_3layer.json
 };
 
 // AffineBoundingBox as the kernels test it (affine_bounding_box.cuh:83-88): u.(p - min) in [0, u.u) etc.

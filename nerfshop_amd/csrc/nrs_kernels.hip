@@ -249,10 +249,11 @@ __device__ __forceinline__ bool packet_pixel_tail(const RenderArgs& a, uint32_t 
 //      show_accel's opaque samples (tn:788-790), shade's mode handling (tn:2466-2478) and pixel_to_ray's thin-lens branch (common_device.cuh:285-293).
 //      A separate instantiation (one lane per ray): the Shade / Cost kernels carry none of it.
 // XTRA: 0 = none of it, 1 = EXTRA, 2 = EXTRA + INTRO: render modes Normals and EncodingVis (the network's input gradient / a visualised activation per sample,
-//      tn:2923-2927: a second pass over the hash grid and a backward or partial forward pass of the MLPs -- a separate instantiation again).
+//      tn:2923-2927: a second pass over the hash grid and a backward or partial forward pass of the MLPs -- a separate instantiation again);
+//      3 / 4 = 1 / 2 with a third hidden layer in the rgb MLP (DeviceModel::rgb_deep, configs/nerf/base_3layer.json; every mode of such a network runs there).
 template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0, int XTRA = 0>
 __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const RenderArgs& a_arg) {
-	constexpr bool EXTRA = XTRA != 0, INTRO = XTRA == 2;
+	constexpr bool EXTRA = XTRA != 0, INTRO = XTRA == 2 || XTRA == 4, DEEP = XTRA >= 3; // (3 / 4: 1 / 2 for a network whose rgb MLP has a third hidden layer, base_3layer.json)
 	// The two argument structs (~1.3 KB of wave-uniform values) live in the kernel-argument segment and are read with scalar loads.
 	// Left alone, the compiler hoists every such load out of the frame loop and then spills ~150 scalar registers into VGPR lanes
 	// (v_writelane / v_readlane: VALU slots in the round loop, 3 VGPRs).  NRS_FRESH_ARGS re-derives the two references from an
@@ -637,6 +638,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		  asm volatile("" :: "v"(sink)); }
 #endif
 		uint32_t res_d = 0, res_rg = 0, res_b = 0;
+		const half8* deep_w = DEEP ? reinterpret_cast<const half8*>(m2.wfrag) : nullptr; // (the third rgb hidden layer's fragments are read from HBM)
 		#pragma unroll 1
 		for (int b = 0; b < 2; ++b) {
 			const int sel = (b != g) ? 1 : 0;
@@ -644,7 +646,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			half8 dout = x0, rout = x1;
 			if (!(a2.dbg & 2u)) {
 				dout = density_mlp_num<NUM>(nm, sm.ml.w, lane, x0, x1);
-				rout = rgb_mlp_num<NUM>(nm, sm.ml.w, lane, dout, sel ? sh_par : sh_own);
+				rout = rgb_mlp_num<NUM, DEEP>(nm, sm.ml.w, lane, dout, sel ? sh_par : sh_own, deep_w);
 			}
 			const u32x4 dd = __builtin_bit_cast(u32x4, dout), rr = __builtin_bit_cast(u32x4, rout);
 			// rows 0..2 of a block sit in its lanes 0..31; block 1's samples belong to the rays of lanes 32..63
@@ -690,7 +692,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 							half8 din = x0;
 							if (layer >= 3u) din = acc16 ? density_mlp<true>(sm.ml.w, lane, x0, x1) : density_mlp<false>(sm.ml.w, lane, x0, x1);
 							const half8 shb = sel ? sh_par : sh_own;
-							val = acc16 ? mlp_hidden_activation<true>(sm.ml.w, lane, x0, x1, din, shb, layer, dim) : mlp_hidden_activation<false>(sm.ml.w, lane, x0, x1, din, shb, layer, dim);
+							val = acc16 ? mlp_hidden_activation<true>(sm.ml.w, lane, x0, x1, din, shb, layer, dim, deep_w) : mlp_hidden_activation<false>(sm.ml.w, lane, x0, x1, din, shb, layer, dim, deep_w);
 							half_of_row = tile_half(dim);
 						}
 						// the value of sample (b, j) sits in lane j + 32 * half_of_row; its ray is lane j + 32 * b
@@ -705,7 +707,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				wpos = intro_v;
 				wdt = 1.0f;
 				wdir = mk3(1.0f, 1.0f, 1.0f);
-			} else {
+			} else if (p2i.render_mode == NRS_RENDER_NORMALS) {
 				// network.input_gradient(stream, 3, positions, gradients): backward of 128 e_3 (see density_backward_features), then the grid's input gradient
 				uint32_t dfe[2][8];
 				#pragma unroll
@@ -958,9 +960,9 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					const float z = dot3(n, n); // Eigen: squaredNorm, then normalized() (z > 0 ? v / sqrt(z) : v)
 					if (z > 0.f) { const float len = sqrtf(z); sr = n.x / len; sg = n.y / len; sb = n.z / len; }
 					else { sr = n.x; sg = n.y; sb = n.z; }
-				} else { // EncodingVis, tn:925: rgb = warped_pos (the overwritten input)
+				} else if (p3.render_mode == NRS_RENDER_ENCODING_VIS) { // tn:925: rgb = warped_pos (the overwritten input)
 					sr = wpos.x; sg = wpos.y; sb = wpos.z;
-				}
+				} // (every other mode of a network with a third rgb hidden layer runs here too: nothing to add)
 			}
 			}
 			if (POISSON && EXTRA && has_res) { // tn:796-805, 939-943
@@ -1143,7 +1145,12 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 	if (a.extra) // render modes / show_accel / depth of field: the catch-all instantiation (every operator kind, membrane correction, one lane per ray)
 	{
 		// Normals / EncodingVis: the INTRO instantiation (145 / 165 VGPRs, no scratch: 12-wave workgroups at 3 waves per SIMD like the other modes)
-		if (a.p.render_mode == NRS_RENDER_NORMALS || a.p.render_mode == NRS_RENDER_ENCODING_VIS)
+		const bool intro = a.p.render_mode == NRS_RENDER_NORMALS || a.p.render_mode == NRS_RENDER_ENCODING_VIS;
+		if (m.rgb_deep) { // a network whose rgb MLP has a third hidden layer (base_3layer.json): the DEEP twins of the two catch-all instantiations, every mode
+			if (intro) return m.numerics ? launch_render_cfg<12, 3, false, true, true, 1, R, 4>(m, a, n_cus, s) : launch_render_cfg<12, 3, false, true, true, 1, 0, 4>(m, a, n_cus, s);
+			return m.numerics ? launch_render_cfg<12, 3, false, true, true, 1, R, 3>(m, a, n_cus, s) : launch_render_cfg<12, 3, false, true, true, 1, 0, 3>(m, a, n_cus, s);
+		}
+		if (intro)
 			return m.numerics ? launch_render_cfg<12, 3, false, true, true, 1, R, 2>(m, a, n_cus, s) : launch_render_cfg<12, 3, false, true, true, 1, 0, 2>(m, a, n_cus, s);
 		return m.numerics ? launch_render_cfg<12, 3, false, true, true, 1, R, 1>(m, a, n_cus, s) : launch_render_cfg<12, 3, false, true, true, 1, 0, 1>(m, a, n_cus, s);
 	}
@@ -1248,7 +1255,7 @@ __global__ __launch_bounds__(256) void slice_kernel(const DeviceModel m, const R
 			const int sel = (b != g) ? 1 : 0;
 			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
 			const half8 dout = density_mlp_num<NUM>(nm, sm.ml.w, lane, x0, x1);
-			const half8 rout = rgb_mlp_num<NUM>(nm, sm.ml.w, lane, dout, sel ? sh_par : sh_own);
+			const half8 rout = rgb_mlp_num<NUM, true>(nm, sm.ml.w, lane, dout, sel ? sh_par : sh_own, m.rgb_deep ? reinterpret_cast<const half8*>(m.wfrag) : nullptr);
 			const u32x4 dd = __builtin_bit_cast(u32x4, dout), rr = __builtin_bit_cast(u32x4, rout);
 			uint32_t vd = dd[0], vrg = rr[0], vb = rr[1];
 			if (b == 1) { vd = xchg32u(vd); vrg = xchg32u(vrg); vb = xchg32u(vb); }
@@ -1552,7 +1559,9 @@ __global__ __launch_bounds__(256) void weight_fragments_kernel(const uint16_t* _
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) return;
 	const uint32_t k = src[i];
-	frag[i] = k == kFragOne ? (uint16_t)0x3C00 : (k ? params[k - 1u] : (uint16_t)0); // (kFragOne: the constant 1.0 of the selection fragments)
+	// (kFragOne / kFragMinusOne: the constants of the selection fragments and of lowered networks; bit 15: a negated weight -- lower_weights, nrs_api.cpp)
+	const uint32_t idx = k & (uint32_t)(kFragNegate - 1u);
+	frag[i] = k == kFragOne ? (uint16_t)0x3C00 : (k == kFragMinusOne ? (uint16_t)0xBC00 : (idx ? (uint16_t)(params[idx - 1u] ^ (k & kFragNegate)) : (uint16_t)0));
 }
 int launch_weight_fragments(const uint16_t* d_params, const uint16_t* d_src, uint16_t* d_frag, uint32_t n, void* stream) {
 	hipLaunchKernelGGL(weight_fragments_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_params, d_src, d_frag, n);
@@ -1630,7 +1639,7 @@ int launch_brick_fill(const DeviceModel& m, const LevelParams& lp, const uint32_
 	return NRS_OK;
 }
 
-// MODE 0: inference_mixed_precision (16 channels, c3 = density raw), 1: density(), 2: hash-grid features [n x 32]
+// MODE 0: inference_mixed_precision (16 channels, c3 = density raw; MODE 5: the same for a network with a third rgb hidden layer), 1: density(), 2: hash-grid features [n x 32]
 // 768-thread workgroups: 12 waves share one LDS copy of the weights (24 KB) next to their 12 feature slabs (48 KB), two workgroups per CU
 // = 6 waves/SIMD at <= 80 VGPRs.  (256-thread workgroups, the first shape, put 3 workgroups = 3 waves/SIMD on a CU: the weights' copy
 // per workgroup was what filled the LDS.)
@@ -1639,8 +1648,9 @@ constexpr int kNetWaves = 12;
 // (layout = layer | dim << 8); both as restated in oracle/nrs_oracle.cpp -- the callers of the render path's Normals / EncodingVis modes and of
 // compute_mesh_vertex_normals (tn:4491).
 template <int MODE, int NUM = 0>
-__global__ __launch_bounds__(64 * kNetWaves, MODE >= 3 ? 3 : 6) void network_kernel(const DeviceModel m, uint32_t n, const float* __restrict__ in, uint32_t ld_in,
+__global__ __launch_bounds__(64 * kNetWaves, (MODE == 3 || MODE == 4) ? 3 : 6) void network_kernel(const DeviceModel m, uint32_t n, const float* __restrict__ in, uint32_t ld_in,
                                                       _Float16* __restrict__ out, uint32_t ld_out, int layout) {
+	constexpr bool FULL = MODE == 0 || MODE == 5; // (5: the full network with a third rgb hidden layer, DeviceModel::rgb_deep -- base_3layer.json)
 	__shared__ NetSmemT<kNetWaves> sm;
 	stage_model_to_lds(m, sm.ml);
 	const int lane = threadIdx.x & 63;
@@ -1657,7 +1667,7 @@ __global__ __launch_bounds__(64 * kNetWaves, MODE >= 3 ? 3 : 6) void network_ker
 		if (have) {
 			const float* c = in + (size_t)s * ld_in;
 			wpos = mk3(c[0], c[1], c[2]);
-			if (MODE == 0 || MODE == 4) wdir = mk3(c[4], c[5], c[6]);
+			if (FULL || MODE == 4) wdir = mk3(c[4], c[5], c[6]);
 		}
 		encode_to_lds<(NUM & 1) != 0>(gv, m.levels, sm.ml, fl, lane, g, wpos, have);
 
@@ -1714,7 +1724,7 @@ __global__ __launch_bounds__(64 * kNetWaves, MODE >= 3 ? 3 : 6) void network_ker
 					} else {
 						half8 din = x0;
 						if (layer >= 3u) din = density_mlp<(NUM & 2) != 0>(sm.ml.w, lane, x0, x1);
-						val = mlp_hidden_activation<(NUM & 2) != 0>(sm.ml.w, lane, x0, x1, din, sel ? sh_par : sh_own, layer, dim);
+						val = mlp_hidden_activation<(NUM & 2) != 0>(sm.ml.w, lane, x0, x1, din, sel ? sh_par : sh_own, layer, dim, m.rgb_deep ? reinterpret_cast<const half8*>(m.wfrag) : nullptr);
 						half_of_row = tile_half(dim);
 					}
 					if (half_of_row != b) val = xchg32(val);
@@ -1740,7 +1750,7 @@ __global__ __launch_bounds__(64 * kNetWaves, MODE >= 3 ? 3 : 6) void network_ker
 		}
 
 		half8 sh_own, sh_par;
-		if (MODE == 0) {
+		if (FULL) {
 			const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
 			sh_own = encode_sh4(g, wdir);
 			sh_par = encode_sh4(g, pdir);
@@ -1751,14 +1761,14 @@ __global__ __launch_bounds__(64 * kNetWaves, MODE >= 3 ? 3 : 6) void network_ker
 			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
 			const half8 dout = density_mlp<(NUM & 2) != 0>(sm.ml.w, lane, x0, x1);
 			half8 rout = dout;
-			if (MODE == 0) rout = rgb_mlp<(NUM & 2) != 0>(sm.ml.w, lane, dout, sel ? sh_par : sh_own);
+			if (FULL) rout = rgb_mlp<(NUM & 2) != 0, MODE == 5>(sm.ml.w, lane, dout, sel ? sh_par : sh_own, reinterpret_cast<const half8*>(m.wfrag));
 			const uint32_t sb = tile * 64 + 32 * b + j;
 			if (sb < n) {
 				#pragma unroll
 				for (int e = 0; e < 8; ++e) {
 					const int row = (e & 3) + 8 * (e >> 2) + 4 * g;
 					_Float16 v = rout[e];
-					if (MODE == 0 && e == 3) v = g ? v : dout[0]; // extract_density (nerf_network_full.h:89-95): row 3 <- density row 0, both on g == 0
+					if (FULL && e == 3) v = g ? v : dout[0]; // extract_density (nerf_network_full.h:89-95): row 3 <- density row 0, both on g == 0
 					if (layout == NRS_PLANES) out[(size_t)row * ld_out + sb] = v;
 					else out[(size_t)sb * 16 + row] = v;
 				}
@@ -1784,7 +1794,8 @@ int launch_network(const DeviceModel& m, int mode, uint32_t n, const float* d_in
 		case 2: NRS_NET_LAUNCH(MODE, 2); break;                 \
 		default: NRS_NET_LAUNCH(MODE, 3); break;                \
 	}
-	if (mode == 0) { NRS_NET_MODE(0) }
+	if (mode == 0 && m.rgb_deep) { NRS_NET_MODE(5) }
+	else if (mode == 0) { NRS_NET_MODE(0) }
 	else if (mode == 1) { NRS_NET_MODE(1) }
 	else if (mode == 3) { NRS_NET_MODE(3) }
 	else if (mode == 4) { NRS_NET_MODE(4) }
@@ -1841,7 +1852,7 @@ __global__ __launch_bounds__(256) void grid_eval_kernel(const DeviceModel m, con
 			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
 			const half8 dout = density_mlp_num<NUM>(nm, sm.ml.w, lane, x0, x1);
 			half8 rout = dout;
-			if (MODE == 1) rout = rgb_mlp_num<NUM>(nm, sm.ml.w, lane, dout, sh);
+			if (MODE == 1) rout = rgb_mlp_num<NUM, true>(nm, sm.ml.w, lane, dout, sh, m.rgb_deep ? reinterpret_cast<const half8*>(m.wfrag) : nullptr);
 			const u32x4 dd = __builtin_bit_cast(u32x4, dout), rr = __builtin_bit_cast(u32x4, rout);
 			uint32_t vd = dd[0], vrg = rr[0], vb = rr[1]; // rows 0..2 of a block sit in lanes 0..31
 			if (b == 1) { vd = xchg32u(vd); vrg = xchg32u(vrg); vb = xchg32u(vb); }

@@ -36,6 +36,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define NRS_FRAG_R1(mb, ks) (8 + (mb) * 2 + (ks))
 #define NRS_FRAG_R2(mb, ks) (12 + (mb) * 4 + (ks))
 #define NRS_FRAG_R3(ks) (20 + (ks))
+#define NRS_FRAG_R2B(mb, ks) (30 + (mb) * 4 + (ks)) // (HBM only, like NRS_FRAG_BWD: the third rgb hidden layer of base_3layer.json)
 
 enum { KIND_DENSE = 0, KIND_HASHED = 1, KIND_MIXED = 2, KIND_RECORD = 3, KIND_SPARSE = 4 };
 
@@ -697,33 +698,42 @@ __device__ __forceinline__ half8 density_mlp(const half8* lds_w, int lane, half8
 	return pack(o, 0);
 }
 
+// One 64 -> 64 ReLU layer of the rgb MLP whose fragments `w` (8: [mb][ks]) may live in LDS or in HBM: b0..b3 in, the packed B operands of the next layer out.
+template <bool ACC16>
+__device__ __forceinline__ void hidden_layer_64(const half8* lds_w, const half8* w, int lane, half8& b0, half8& b1, half8& b2, half8& b3) {
+	floatx16 c = mfma_first(w[0 * 64 + lane], b0);
+	c = mfma_step<ACC16>(lds_w, lane, w[1 * 64 + lane], b1, c);
+	c = mfma_step<ACC16>(lds_w, lane, w[2 * 64 + lane], b2, c);
+	c = mfma_step<ACC16>(lds_w, lane, w[3 * 64 + lane], b3, c);
+	const half8 q0 = relu_pack(c, 0), q1 = relu_pack(c, 8);
+	NRS_STAGE_FENCE();
+	c = mfma_first(w[4 * 64 + lane], b0);
+	c = mfma_step<ACC16>(lds_w, lane, w[5 * 64 + lane], b1, c);
+	c = mfma_step<ACC16>(lds_w, lane, w[6 * 64 + lane], b2, c);
+	c = mfma_step<ACC16>(lds_w, lane, w[7 * 64 + lane], b3, c);
+	const half8 q2 = relu_pack(c, 0), q3 = relu_pack(c, 8);
+	NRS_STAGE_FENCE();
+	b0 = q0; b1 = q1; b2 = q2; b3 = q3;
+}
 // RGB MLP [density out 16 | SH 16] -> 64 -> 64 -> 16 (3 used) for one block.  Same output row map.
-template <bool ACC16 = false>
-__device__ __forceinline__ half8 rgb_mlp(const half8* lds_w, int lane, half8 din, half8 sh) {
+// DEEP instantiations take `deep_w` (wave-uniform; DeviceModel::wfrag when DeviceModel::rgb_deep, else null): a third hidden layer between the second and the
+// output layer, its fragments read from HBM (base_3layer.json; the other members of the family are lowered onto the two-layer shape, nrs_api.cpp lower_weights).
+template <bool ACC16 = false, bool DEEP = false>
+__device__ __forceinline__ half8 rgb_mlp(const half8* lds_w, int lane, half8 din, half8 sh, const half8* deep_w = nullptr) {
 	floatx16 a = mfma_first(lds_w[NRS_FRAG_R1(0, 0) * 64 + lane], din);
 	a = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R1(0, 1) * 64 + lane], sh, a);
-	const half8 b0 = relu_pack(a, 0), b1 = relu_pack(a, 8);
+	half8 b0 = relu_pack(a, 0), b1 = relu_pack(a, 8);
 	NRS_STAGE_FENCE();
 	a = mfma_first(lds_w[NRS_FRAG_R1(1, 0) * 64 + lane], din);
 	a = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R1(1, 1) * 64 + lane], sh, a);
-	const half8 b2 = relu_pack(a, 0), b3 = relu_pack(a, 8);
+	half8 b2 = relu_pack(a, 0), b3 = relu_pack(a, 8);
 	NRS_STAGE_FENCE();
-	floatx16 c = mfma_first(lds_w[NRS_FRAG_R2(0, 0) * 64 + lane], b0);
-	c = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(0, 1) * 64 + lane], b1, c);
-	c = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(0, 2) * 64 + lane], b2, c);
-	c = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(0, 3) * 64 + lane], b3, c);
-	const half8 q0 = relu_pack(c, 0), q1 = relu_pack(c, 8);
-	NRS_STAGE_FENCE();
-	c = mfma_first(lds_w[NRS_FRAG_R2(1, 0) * 64 + lane], b0);
-	c = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(1, 1) * 64 + lane], b1, c);
-	c = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(1, 2) * 64 + lane], b2, c);
-	c = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(1, 3) * 64 + lane], b3, c);
-	const half8 q2 = relu_pack(c, 0), q3 = relu_pack(c, 8);
-	NRS_STAGE_FENCE();
-	floatx16 o = mfma_first(lds_w[NRS_FRAG_R3(0) * 64 + lane], q0);
-	o = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R3(1) * 64 + lane], q1, o);
-	o = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R3(2) * 64 + lane], q2, o);
-	o = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R3(3) * 64 + lane], q3, o);
+	hidden_layer_64<ACC16>(lds_w, lds_w + NRS_FRAG_R2(0, 0) * 64, lane, b0, b1, b2, b3);
+	if (DEEP && deep_w) hidden_layer_64<ACC16>(lds_w, deep_w + NRS_FRAG_R2B(0, 0) * 64, lane, b0, b1, b2, b3);
+	floatx16 o = mfma_first(lds_w[NRS_FRAG_R3(0) * 64 + lane], b0);
+	o = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R3(1) * 64 + lane], b1, o);
+	o = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R3(2) * 64 + lane], b2, o);
+	o = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R3(3) * 64 + lane], b3, o);
 	NRS_STAGE_FENCE();
 	return pack(o, 0);
 }
@@ -743,11 +753,11 @@ __device__ __forceinline__ _Float16 pick8(const half8& h, int e) {
 	for (int i = 1; i < 8; ++i) v = (e == i) ? h[i] : v;
 	return v;
 }
-// Activation `unit` of hidden layer `layer` (1: density MLP hidden, 3 / 4: rgb MLP hidden 1 / 2) for one 32-sample block: the value of sample column j sits,
+// Activation `unit` of hidden layer `layer` (1: density MLP hidden, 3 / 4 / 5: rgb MLP hidden 1 / 2 / 3 -- 5 with deep_w only) for one 32-sample block: the value of sample column j sits,
 // after the call, in the lanes whose half (lane >> 5) equals tile_half(unit); the other half returns another row.  din = density_mlp's output (layers 3, 4).
 __device__ __forceinline__ int tile_half(uint32_t unit) { return (int)((unit >> 2) & 1u); }
 template <bool ACC16>
-__device__ __forceinline__ float mlp_hidden_activation(const half8* lds_w, int lane, half8 x0, half8 x1, half8 din, half8 sh, uint32_t layer, uint32_t unit) {
+__device__ __forceinline__ float mlp_hidden_activation(const half8* lds_w, int lane, half8 x0, half8 x1, half8 din, half8 sh, uint32_t layer, uint32_t unit, const half8* deep_w = nullptr) {
 	const int mb = (int)((unit >> 5) & 1u), R = (int)(unit & 31u), r = (R & 3) + 4 * (R >> 3); // D register of row R in its lane half
 	floatx16 t;
 	if (layer == 1u) {
@@ -759,16 +769,21 @@ __device__ __forceinline__ float mlp_hidden_activation(const half8* lds_w, int l
 	} else {
 		floatx16 a = mfma_first(lds_w[NRS_FRAG_R1(0, 0) * 64 + lane], din);
 		a = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R1(0, 1) * 64 + lane], sh, a);
-		const half8 b0 = relu_pack(a, 0), b1 = relu_pack(a, 8);
+		half8 b0 = relu_pack(a, 0), b1 = relu_pack(a, 8);
 		NRS_STAGE_FENCE();
 		a = mfma_first(lds_w[NRS_FRAG_R1(1, 0) * 64 + lane], din);
 		a = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R1(1, 1) * 64 + lane], sh, a);
-		const half8 b2 = relu_pack(a, 0), b3 = relu_pack(a, 8);
+		half8 b2 = relu_pack(a, 0), b3 = relu_pack(a, 8);
 		NRS_STAGE_FENCE();
-		t = mfma_first(lds_w[NRS_FRAG_R2(mb, 0) * 64 + lane], b0);
-		t = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(mb, 1) * 64 + lane], b1, t);
-		t = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(mb, 2) * 64 + lane], b2, t);
-		t = mfma_step<ACC16>(lds_w, lane, lds_w[NRS_FRAG_R2(mb, 3) * 64 + lane], b3, t);
+		const half8* w = lds_w + NRS_FRAG_R2(mb, 0) * 64;
+		if (layer == 5u && deep_w) { // the third hidden layer: behind the whole second one
+			hidden_layer_64<ACC16>(lds_w, lds_w + NRS_FRAG_R2(0, 0) * 64, lane, b0, b1, b2, b3);
+			w = deep_w + NRS_FRAG_R2B(mb, 0) * 64;
+		}
+		t = mfma_first(w[0 * 64 + lane], b0);
+		t = mfma_step<ACC16>(lds_w, lane, w[1 * 64 + lane], b1, t);
+		t = mfma_step<ACC16>(lds_w, lane, w[2 * 64 + lane], b2, t);
+		t = mfma_step<ACC16>(lds_w, lane, w[3 * 64 + lane], b3, t);
 	}
 	NRS_STAGE_FENCE();
 	const _Float16 h = (_Float16)pick16(t, r);
@@ -860,10 +875,10 @@ __device__ __forceinline__ half8 density_mlp_num(uint32_t nm, const half8* lds_w
 	if (NUM == kNumRuntime ? (nm & 2u) != 0u : (NUM & 2) != 0) return density_mlp<true>(lds_w, lane, x0, x1);
 	return density_mlp<false>(lds_w, lane, x0, x1);
 }
-template <int NUM>
-__device__ __forceinline__ half8 rgb_mlp_num(uint32_t nm, const half8* lds_w, int lane, half8 din, half8 sh) {
-	if (NUM == kNumRuntime ? (nm & 2u) != 0u : (NUM & 2) != 0) return rgb_mlp<true>(lds_w, lane, din, sh);
-	return rgb_mlp<false>(lds_w, lane, din, sh);
+template <int NUM, bool DEEP = false>
+__device__ __forceinline__ half8 rgb_mlp_num(uint32_t nm, const half8* lds_w, int lane, half8 din, half8 sh, const half8* deep_w = nullptr) {
+	if (NUM == kNumRuntime ? (nm & 2u) != 0u : (NUM & 2) != 0) return rgb_mlp<true, DEEP>(lds_w, lane, din, sh, deep_w);
+	return rgb_mlp<false, DEEP>(lds_w, lane, din, sh, deep_w);
 }
 
 // Exchange a value with the partner lane (l ^ 32): one ds_bpermute.

@@ -49,16 +49,18 @@ def network_config(desc, explicit_per_level_scale=False):
            "log2_hashmap_size": int(desc.log2_hashmap_size), "base_resolution": int(desc.base_resolution)}
     if explicit_per_level_scale:
         enc["per_level_scale"] = float(desc.per_level_scale)
-    return {
+    cfg = {
         "loss": {"otype": "Huber"},
         "encoding": enc,
         "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": int(desc.n_neurons),
                     "n_hidden_layers": int(desc.density_hidden_layers)},
-        "dir_encoding": {"otype": "Composite", "nested": [{"n_dims_to_encode": 3, "otype": "SphericalHarmonics", "degree": int(desc.sh_degree)},
-                                                           {"otype": "Identity", "n_bins": 4, "degree": 4}]},
-        "rgb_network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": int(desc.n_neurons),
-                        "n_hidden_layers": int(desc.rgb_hidden_layers)},
     }
+    if desc.sh_degree:  # (configs/nerf/base_nodir.json has neither block: NerfNetworkNoDir, testbed.cu:2314)
+        cfg["dir_encoding"] = {"otype": "Composite", "nested": [{"n_dims_to_encode": 3, "otype": "SphericalHarmonics", "degree": int(desc.sh_degree)},
+                                                                 {"otype": "Identity", "n_bins": 4, "degree": 4}]}
+        cfg["rgb_network"] = {"otype": "FullyFusedMLP" if desc.rgb_hidden_layers else "CutlassMLP", "activation": "ReLU", "output_activation": "None",
+                              "n_neurons": int(desc.n_neurons), "n_hidden_layers": int(desc.rgb_hidden_layers)}
+    return cfg
 
 
 def save_snapshot(path, desc, aabb_scale, params_u16, density_grid, camera=None, exported=None, training_step=35000):

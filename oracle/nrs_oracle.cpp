@@ -577,10 +577,15 @@ struct LevelTable {
 	uint32_t total_entries;
 };
 
+// The architectures of configs/nerf/: base.json and its relatives that keep the hash grid and the 64-wide density network -- rgb network with 0 (CutlassMLP,
+// base_0layer.json), 1, 2 (base.json) or 3 hidden layers, and no rgb network / direction encoding at all (base_nodir.json -> NerfNetworkNoDir,
+// testbed.cu:2314-2353: nrs_model_desc::sh_degree == 0).  Table sizes: log2_hashmap_size 14 (base_14.json), 15 (small.json), 19, 21 (big.json), ...
 bool desc_supported(const nrs_model_desc& d) {
-	return d.n_levels == 16 && d.n_features_per_level == 2 && d.n_neurons == 64 && d.density_hidden_layers == 1 &&
-	       d.density_output_dims == 16 && d.rgb_hidden_layers == 2 && d.sh_degree == 4 && d.log2_hashmap_size >= 8 &&
-	       d.log2_hashmap_size <= 24 && d.base_resolution >= 1;
+	const bool trunk = d.n_levels == 16 && d.n_features_per_level == 2 && d.n_neurons == 64 && d.density_hidden_layers == 1 && d.density_output_dims == 16 &&
+	                   d.log2_hashmap_size >= 8 && d.log2_hashmap_size <= 24 && d.base_resolution >= 1;
+	if (!trunk) return false;
+	if (d.sh_degree == 0) return d.rgb_hidden_layers == 0; // NerfNetworkNoDir
+	return d.sh_degree == 4 && d.rgb_hidden_layers <= 3;
 }
 
 void make_level_table(const nrs_model_desc& d, LevelTable& lt) {
@@ -609,7 +614,14 @@ void make_level_table(const nrs_model_desc& d, LevelTable& lt) {
 }
 
 constexpr uint32_t N_DENSITY_W = 64 * 32 + 16 * 64;           // 3072
-constexpr uint32_t N_RGB_W = 64 * 32 + 64 * 64 + 16 * 64;     // 7168
+// rgb network parameters (tiny-cuda-nn's layouts as recalled): FullyFusedMLP with L >= 1 hidden layers = [64 x 32] + (L - 1) [64 x 64] + [16 x 64] (the 3
+// outputs padded to 16 rows); CutlassMLP with no hidden layer = one [8 x 32] matrix (outputs padded to the tensor-core width 8); NerfNetworkNoDir: none.
+// base.json (L = 2): 7168.
+inline uint32_t n_rgb_weights(const nrs_model_desc& d) {
+	if (d.sh_degree == 0) return 0u;
+	if (d.rgb_hidden_layers == 0) return 8u * 32u;
+	return 64u * 32u + (d.rgb_hidden_layers - 1u) * 64u * 64u + 16u * 64u;
+}
 
 // one correctly rounded double -> binary16 conversion: the double is first brought to float with round-to-odd (so that the float -> half
 // rounding cannot double-round); hadd = one binary16 addition (the exact sum of two halfs fits a double)
@@ -643,7 +655,9 @@ struct Model {
 	std::vector<uint16_t> params; // tcnn order: density | rgb | grid
 	std::vector<float> wf;        // MLP weights converted to float once
 	std::vector<uint8_t> bitfield;
-	const uint16_t* grid() const { return params.data() + N_DENSITY_W + N_RGB_W; }
+	bool no_dir() const { return desc.sh_degree == 0; }
+	uint32_t n_mlp_w() const { return N_DENSITY_W + n_rgb_weights(desc); }
+	const uint16_t* grid() const { return params.data() + n_mlp_w(); }
 };
 
 inline uint32_t grid_index(const LevelTable& lt, uint32_t l, uint32_t gx, uint32_t gy, uint32_t gz) {
@@ -751,15 +765,27 @@ void density_mlp_one(const Model& m, const uint16_t feat[32], uint16_t out[16]) 
 	dense_layer(W1, 64, 32, feat, h, true, m.mlp_acc);
 	dense_layer(W2, 16, 64, h, out, false, m.mlp_acc);
 }
-// rgb MLP 32->64->64->16 (base.json:52-58); input = [density out 16 | SH 16] (nerf_network_full.h:65-87)
-void rgb_mlp_one(const Model& m, const uint16_t in32[32], uint16_t out[16]) {
-	const float* W1 = m.wf.data() + N_DENSITY_W;
-	const float* W2 = W1 + 64 * 32;
-	const float* W3 = W2 + 64 * 64;
-	uint16_t h1[64], h2[64];
-	dense_layer(W1, 64, 32, in32, h1, true, m.mlp_acc);
-	dense_layer(W2, 64, 64, h1, h2, true, m.mlp_acc);
-	dense_layer(W3, 16, 64, h2, out, false, m.mlp_acc);
+// rgb MLP 32->64->64->16 (base.json:52-58); input = [density out 16 | SH 16] (nerf_network_full.h:65-87).  L hidden layers (base_{1,2,3}layer.json), or none:
+// one linear map (base_0layer.json's CutlassMLP: 8 padded output rows; the other 8 of `out` are zero).  hidden_out, if given, receives hidden layer `want` (0-based).
+void rgb_mlp_one(const Model& m, const uint16_t in32[32], uint16_t out[16], uint16_t* hidden_out = nullptr, uint32_t want = 0) {
+	const float* W = m.wf.data() + N_DENSITY_W;
+	const uint32_t L = m.desc.rgb_hidden_layers;
+	if (L == 0) {
+		dense_layer(W, 8, 32, in32, out, false, m.mlp_acc);
+		for (int i = 8; i < 16; ++i) out[i] = 0;
+		return;
+	}
+	uint16_t h[64], hn[64];
+	dense_layer(W, 64, 32, in32, h, true, m.mlp_acc);
+	W += 64 * 32;
+	if (hidden_out && want == 0) memcpy(hidden_out, h, sizeof(h));
+	for (uint32_t l = 1; l < L; ++l) {
+		dense_layer(W, 64, 64, h, hn, true, m.mlp_acc);
+		memcpy(h, hn, sizeof(h));
+		W += 64 * 64;
+		if (hidden_out && want == l) memcpy(hidden_out, h, sizeof(h));
+	}
+	dense_layer(W, 16, 64, h, out, false, m.mlp_acc);
 }
 // ---- the CPU-baseline flavour of the network (Model::fast) ------------------------------------------------------------------------
 #if defined(__F16C__)
@@ -819,9 +845,22 @@ static void network_inference_fast(const Model& m, const float coord[7], uint16_
 	float rin[32];
 	for (int i = 0; i < 16; ++i) { rin[i] = dout[i]; rin[16 + i] = h2f_hw(sh[i]); }
 	const float* R = W + N_DENSITY_W;
-	dense_layer_fast(R, 64, 32, rin, h1, true);
-	dense_layer_fast(R + 64 * 32, 64, 64, h1, h2, true);
-	dense_layer_fast(R + 64 * 32 + 64 * 64, 16, 64, h2, o, false);
+	const uint32_t L = m.desc.rgb_hidden_layers;
+	for (int i = 0; i < 16; ++i) o[i] = 0.f;
+	if (m.no_dir()) { // NerfNetworkNoDir: (r, g, b) = density-network outputs 1..3
+		o[0] = dout[1]; o[1] = dout[2]; o[2] = dout[3];
+	} else if (L == 0) {
+		dense_layer_fast(R, 8, 32, rin, o, false);
+	} else {
+		dense_layer_fast(R, 64, 32, rin, h1, true);
+		R += 64 * 32;
+		for (uint32_t l = 1; l < L; ++l) {
+			dense_layer_fast(R, 64, 64, h1, h2, true);
+			memcpy(h1, h2, sizeof(h1));
+			R += 64 * 64;
+		}
+		dense_layer_fast(R, 16, 64, h1, o, false);
+	}
 	for (int i = 0; i < 16; ++i) out16[i] = f2h_hw(o[i]);
 	out16[3] = f2h_hw(dout[0]);
 }
@@ -833,6 +872,11 @@ void network_inference_one(const Model& m, const float coord[7], uint16_t out16[
 	uint16_t feat[32], in32[32];
 	hashgrid_encode_one(m, coord, feat);
 	density_mlp_one(m, feat, in32);          // rows 0..15 of rgb_network_input
+	if (m.no_dir()) { // NerfNetworkNoDir::inference_mixed_precision_impl (nerf_network_nodir.h:47-91): the density network's outputs 1..3 are the colour, 0 the density
+		for (int i = 0; i < 16; ++i) out16[i] = 0;
+		out16[0] = in32[1]; out16[1] = in32[2]; out16[2] = in32[3]; out16[3] = in32[0];
+		return;
+	}
 	sh4_encode_one(coord + 4, in32 + 16);    // dir_offset = 4 (testbed.cu:2328)
 	rgb_mlp_one(m, in32, out16);
 	out16[3] = in32[0];
@@ -916,13 +960,19 @@ void density_input_gradient_one(const Model& m, const float coord[7], float grad
 // row 0 = max(-v, 0), row 1 = max(v, 0), row 2 = 0, rows 3..6 = 1.  The reference passes the network INPUT as the output matrix, so the sample's
 // NerfCoordinate is overwritten: composite_kernel_nerf then reads pos = (max(-v, 0), max(v, 0), 0) as "warped_pos" (the colour, tn:925), dt = 1
 // (unwarp_dt(1) = the largest step: tn:762) and dir = (1, 1, 1).  Restated as it is.
-uint32_t network_layer_width(uint32_t layer) { return layer == 0 ? 32u : (layer == 2 ? 32u : 64u); } // NerfNetworkFull::width, nerf_network_full.h:507-517
+// NerfNetworkFull::width / num_forward_activations (nerf_network_full.h:507-521): layers 0, 1, 2 and one per rgb hidden layer; NerfNetworkNoDir: the grid output
+// and the density network's hidden layer (its num_forward_activations counts two more, which its own forward_activations cannot serve: refused).  0 = no such layer.
+uint32_t network_layer_width(const nrs_model_desc& d, uint32_t layer) {
+	if (layer == 0) return 32u;
+	if (layer == 1) return 64u;
+	if (d.sh_degree == 0) return 0u;
+	if (layer == 2) return 32u;
+	return layer - 3u < d.rgb_hidden_layers ? 64u : 0u;
+}
 float network_activation_one(const Model& m, const float coord[7], uint32_t layer, uint32_t dim) {
 	const float* Wd1 = m.wf.data();
 	const float* Wd2 = Wd1 + 64 * 32;
-	const float* Wr1 = m.wf.data() + N_DENSITY_W;
-	const float* Wr2 = Wr1 + 64 * 32;
-	uint16_t feat[32], h[64], in32[32], h1[64], h2[64];
+	uint16_t feat[32], h[64], in32[32], h1[64];
 	hashgrid_encode_one(m, coord, feat);
 	if (layer == 0) return h2f(feat[dim]);
 	dense_layer(Wd1, 64, 32, feat, h, true, m.mlp_acc);
@@ -930,10 +980,9 @@ float network_activation_one(const Model& m, const float coord[7], uint32_t laye
 	dense_layer(Wd2, 16, 64, h, in32, false, m.mlp_acc);
 	sh4_encode_one(coord + 4, in32 + 16);
 	if (layer == 2) return h2f(in32[dim]);
-	dense_layer(Wr1, 64, 32, in32, h1, true, m.mlp_acc);
-	if (layer == 3) return h2f(h1[dim]);
-	dense_layer(Wr2, 64, 64, h1, h2, true, m.mlp_acc);
-	return h2f(h2[dim]);
+	uint16_t out[16];
+	rgb_mlp_one(m, in32, out, h1, layer - 3u);
+	return h2f(h1[dim]);
 }
 inline float network_to_density_derivative(float v, uint32_t act); // below
 
@@ -1868,7 +1917,7 @@ size_t orc_model_n_params(const nrs_model_desc* d) {
 	if (!desc_supported(*d)) return 0;
 	LevelTable lt;
 	make_level_table(*d, lt);
-	return (size_t)N_DENSITY_W + N_RGB_W + (size_t)lt.total_entries * 2;
+	return (size_t)N_DENSITY_W + n_rgb_weights(*d) + (size_t)lt.total_entries * 2;
 }
 int orc_model_level_table(const nrs_model_desc* d, float* scale, uint32_t* res, uint32_t* off, uint32_t* cnt, uint32_t* hashed) {
 	if (!desc_supported(*d)) return -1;
@@ -1882,11 +1931,11 @@ void* orc_model_create(const nrs_model_desc* d, const uint16_t* params, size_t n
 	Model* m = new Model();
 	m->desc = *d;
 	make_level_table(*d, m->lt);
-	if (n_params != (size_t)N_DENSITY_W + N_RGB_W + (size_t)m->lt.total_entries * 2) { delete m; return nullptr; }
+	if (n_params != (size_t)m->n_mlp_w() + (size_t)m->lt.total_entries * 2) { delete m; return nullptr; }
 	m->aabb = Box{v3(d->aabb_min[0], d->aabb_min[1], d->aabb_min[2]), v3(d->aabb_max[0], d->aabb_max[1], d->aabb_max[2])};
 	m->params.assign(params, params + n_params);
-	m->wf.resize(N_DENSITY_W + N_RGB_W);
-	for (uint32_t i = 0; i < N_DENSITY_W + N_RGB_W; ++i) m->wf[i] = h2f(params[i]);
+	m->wf.resize(m->n_mlp_w());
+	for (uint32_t i = 0; i < m->n_mlp_w(); ++i) m->wf[i] = h2f(params[i]);
 	if (bitfield) m->bitfield.assign(bitfield, bitfield + NRS_BITFIELD_BYTES);
 	else m->bitfield.assign(NRS_BITFIELD_BYTES, 0);
 	return m;
@@ -1950,7 +1999,7 @@ void orc_density_input_gradient(void* model, uint32_t n, const float* in7, float
 // tcnn visualize_activation restated: activation `dim` of forward_activations(layer) of n samples [n x 7] -> [n]; returns 0 for an unknown layer / unit
 int orc_network_activation(void* model, uint32_t n, const float* in7, uint32_t layer, uint32_t dim, float* out) {
 	const Model& m = *(const Model*)model;
-	if (layer > 4 || dim >= network_layer_width(layer)) return 0;
+	if (dim >= network_layer_width(m.desc, layer)) return 0;
 #pragma omp parallel for schedule(static)
 	for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = network_activation_one(m, in7 + 7 * (size_t)i, layer, dim);
 	return 1;

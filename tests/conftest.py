@@ -32,12 +32,12 @@ def built():
 class Scene:
     """Synthetic lego-like scene (nerfshop_amd.synth) + the CPU oracle's view of it."""
 
-    def __init__(self, aabb_scale=1, with_edit=True, lattice_n=6, shaped=False):
+    def __init__(self, aabb_scale=1, with_edit=True, lattice_n=6, shaped=False, **desc_kw):
         from nerfshop_amd import synth
         from oracle import oracle as orc
         self.synth, self.orc = synth, orc
         self.aabb_scale = aabb_scale
-        self.desc = synth.model_desc(aabb_scale)
+        self.desc = synth.model_desc(aabb_scale, **desc_kw)  # (desc_kw: the other members of configs/nerf/'s family, tests/test_gpu_architectures.py)
         self.params = synth.make_params(self.desc, sigma_raw=synth.default_sigma_raw(aabb_scale), shaped=shaped, aabb_scale=aabb_scale)
         self.grid = synth.density_grid(aabb_scale)
         self.bitfield = synth.grid_to_bitfield(self.grid)

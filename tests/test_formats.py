@@ -37,6 +37,34 @@ def test_snapshot_round_trip(built, tmp_path, aabb_scale, ext):
     assert np.array_equal(s.camera, np.asarray(cam, np.float32).reshape(-1))
 
 
+@pytest.mark.parametrize("kw", [dict(rgb_hidden_layers=0), dict(rgb_hidden_layers=1), dict(rgb_hidden_layers=3), dict(no_dir=True), dict(log2_hashmap_size=15),
+                                dict(log2_hashmap_size=21)], ids=["base_0layer", "base_1layer", "base_3layer", "base_nodir", "small", "big"])
+def test_snapshot_round_trip_of_the_family(built, tmp_path, kw):
+    """configs/nerf/base.json's relatives: the rgb network's depth is read from the file, a file with neither dir_encoding nor rgb_network describes a
+    NerfNetworkNoDir (testbed.cu:2314: sh_degree 0 in nrs_model_desc), and the parameter count follows."""
+    desc = synth.model_desc(1, **kw)
+    n = _abi.load().nrs_model_n_params(C.byref(desc))
+    assert n > 0
+    params = np.random.default_rng(4).integers(0, 0x7BFF, size=n, dtype=np.uint16)
+    grid = np.zeros(5 * 128 ** 3, np.float32)
+    path = tmp_path / "scene.msgpack"
+    formats.save_snapshot(path, desc, 1, params, grid)
+    s = formats.load_snapshot(path)
+    for f, _ in _abi.ModelDesc._fields_:
+        a, b = getattr(s.desc, f), getattr(desc, f)
+        assert (list(a) == list(b)) if hasattr(a, "__len__") else (a == b), f
+    assert np.array_equal(s.params, params)
+    # a file whose blob was written for another depth is refused by its size
+    import msgpack
+    cfg = msgpack.unpackb(path.read_bytes(), raw=False)
+    if "rgb_network" in cfg:
+        cfg["rgb_network"]["n_hidden_layers"] = (int(cfg["rgb_network"]["n_hidden_layers"]) + 1) % 4
+        (tmp_path / "other.msgpack").write_bytes(msgpack.packb(cfg, use_bin_type=True))
+        with pytest.raises(_abi.NrsError) as ei:
+            formats.load_snapshot(tmp_path / "other.msgpack")
+        assert "wrong size" in str(ei.value)
+
+
 def test_snapshot_float_params_and_errors(built, tmp_path):
     import msgpack
     desc = synth.model_desc(1)

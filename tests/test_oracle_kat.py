@@ -257,6 +257,61 @@ def test_network_oracle_against_numpy(scene):
     assert (got == rout).mean() > 0.95
 
 
+@pytest.mark.parametrize("kw", [dict(rgb_hidden_layers=1), dict(rgb_hidden_layers=3), dict(rgb_hidden_layers=0), dict(no_dir=True)], ids=["rgb1", "rgb3", "rgb0", "nodir"])
+def test_network_family_oracle_against_numpy(built, kw):
+    """configs/nerf/base_{0,1,3}layer.json and base_nodir.json in the oracle against an independent numpy evaluation: the rgb network's L hidden layers (or its single
+    matrix, or no rgb network: colour = density-network outputs 1..3, NerfNetworkNoDir::inference_mixed_precision_impl, nerf_network_nodir.h:47-91) and the
+    parameter layout [density | rgb | grid] -- also the layer numbering of visualize_activation."""
+    from nerfshop_amd import synth
+    d = synth.model_desc(1, **kw)
+    params = synth.make_params(d)
+    m = orc.Model(d, params, None)
+    L, nodir = d.rgb_hidden_layers, d.sh_degree == 0
+    n_rgb = 0 if nodir else (256 if L == 0 else 2048 + (L - 1) * 4096 + 1024)
+    lt = synth.level_table(d)
+    assert params.size == 3072 + n_rgb + 2 * int(lt["count"].sum())
+    rng = np.random.default_rng(2)
+    n = 96
+    c = rng.uniform(0, 1, size=(n, 7)).astype(np.float32)
+    out = m.inference(c, 1).view(np.float16).astype(np.float64)
+    feat = m.hashgrid_encode(c).view(np.float16).astype(np.float64)
+    w = params[:3072 + n_rgb].view(np.float16).astype(np.float64)
+    dw1, dw2 = w[:2048].reshape(64, 32), w[2048:3072].reshape(16, 64)
+    r16 = lambda x: x.astype(np.float32).astype(np.float16).astype(np.float64)
+    h = r16(np.maximum(feat @ dw1.T, 0))
+    dout = r16(h @ dw2.T)
+    assert (out[:, 3] == dout[:, 0]).all()
+    if nodir:
+        assert (out[:, :3] == dout[:, 1:4]).all() and (out[:, 4:] == 0).all()
+        with pytest.raises(ValueError):
+            m.network_activation(c, 2, 0)
+        assert m.network_activation(c, 1, 63) is not None
+        return
+    sh = np.stack([m.network_activation(c, 2, 16 + k) for k in range(16)], axis=1).astype(np.float64)  # the oracle's own SH (checked against numpy above)
+    rin = np.concatenate([dout, sh], axis=1)
+    r = w[3072:]
+    hidden = []
+    if L == 0:
+        rout = np.zeros((n, 16))
+        rout[:, :8] = r16(rin @ r.reshape(8, 32).T)
+    else:
+        x = r16(np.maximum(rin @ r[:2048].reshape(64, 32).T, 0))
+        hidden.append(x)
+        off = 2048
+        for _ in range(L - 1):
+            x = r16(np.maximum(x @ r[off:off + 4096].reshape(64, 64).T, 0))
+            hidden.append(x)
+            off += 4096
+        rout = r16(x @ r[off:off + 1024].reshape(16, 64).T)
+    rout[:, 3] = dout[:, 0]
+    assert np.abs(out - rout).max() <= 2e-2 * max(1.0, np.abs(rout).max()) and (out == rout).mean() > 0.95
+    for l, x in enumerate(hidden):  # forward_activations(3 + l)
+        got = m.network_activation(c, 3 + l, 17).astype(np.float64)
+        assert (got == x[:, 17]).mean() > 0.95 and np.abs(got - x[:, 17]).max() < 2e-2 * max(1.0, np.abs(x).max())
+    with pytest.raises(ValueError):  # one past the last layer
+        m.network_activation(c, 3 + L, 0)
+
+
 def test_pcg32_published_vector(built):
     """PCG32 XSH-RR known-answer vector: the output of the reference implementation's demo (pcg32-demo, seed 42, stream 54),
     as printed in the PCG C library's expected output.  tcnn::pcg32 is this generator (absent submodule; see oracle header)."""
