@@ -1764,12 +1764,14 @@ __global__ __launch_bounds__(64 * kNetWaves, (MODE == 3 || MODE == 4) ? 3 : 6) v
 			if (FULL) rout = rgb_mlp<(NUM & 2) != 0, MODE == 5>(sm.ml.w, lane, dout, sel ? sh_par : sh_own, reinterpret_cast<const half8*>(m.wfrag));
 			const uint32_t sb = tile * 64 + 32 * b + j;
 			if (sb < n) {
+				uint32_t ldo = ld_out; // (opaque per tile: the eight 64-bit row offsets were hoisted out of the tile loop and, in the fp16-accumulator twins, spilled)
+				asm volatile("" : "+s"(ldo));
 				#pragma unroll
 				for (int e = 0; e < 8; ++e) {
 					const int row = (e & 3) + 8 * (e >> 2) + 4 * g;
 					_Float16 v = rout[e];
 					if (FULL && e == 3) v = g ? v : dout[0]; // extract_density (nerf_network_full.h:89-95): row 3 <- density row 0, both on g == 0
-					if (layout == NRS_PLANES) out[(size_t)row * ld_out + sb] = v;
+					if (layout == NRS_PLANES) out[(size_t)row * ldo + sb] = v;
 					else out[(size_t)sb * 16 + row] = v;
 				}
 			}
@@ -2191,17 +2193,17 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 			for (int k = a.n_edits - 1; k >= 0; --k) (void)edit_warp(a.edits[k], false, wpos, unused);
 		}
 		encode_num<NUM>(nm, gv, m.levels, sm.ml, fl, lane, g, wpos, have);
-		_Float16 raw_b[2];
+		_Float16 raw_b0 = (_Float16)0, raw_b1 = (_Float16)0; // (two scalars, not an array indexed by the rolled loop's counter: that one lived in scratch)
 		#pragma unroll 1
 		for (int b = 0; b < 2; ++b) {
 			const int sel = (b != g) ? 1 : 0;
 			const half8 x0 = load_features(fl, lane, sel, 0), x1 = load_features(fl, lane, sel, 1);
 			const half8 dout = density_mlp_num<NUM>(nm, sm.ml.w, lane, x0, x1);
-			raw_b[b] = dout[0]; // row 0 of sample 32*b + (lane & 31) sits on the g == 0 lanes
+			if (b == 0) raw_b0 = dout[0]; else raw_b1 = dout[0]; // row 0 of sample 32*b + (lane & 31) sits on the g == 0 lanes
 		}
 		// lane l < 32 owns block 0's sample l; lane 32 + j owns block 1's sample, computed on lane j
-		const float from_partner = xchg32((float)raw_b[1]);
-		_Float16 raw = g ? (_Float16)from_partner : raw_b[0];
+		const float from_partner = xchg32((float)raw_b1);
+		_Float16 raw = g ? (_Float16)from_partner : raw_b0;
 		if (!have) continue;
 		// (clear_empty_space, which the reference launches here (tn:3606), has its body commented out (tn:2759-2770): the operators' empty mask changes
 		// nothing in the refresh -- a sample that falls into vacated space keeps the density of the place it stands on.  Pinned: tests/test_ref_pin.py.)
