@@ -690,14 +690,19 @@ __device__ __forceinline__ uint32_t scan_cell_for_tet(const DeviceEdit& e, uint3
 #ifndef NRS_OPT_WARP_MORTON
 #define NRS_OPT_WARP_MORTON 1
 #endif
-__device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3& wpos, f3& wdir, const uint32_t* __restrict__ march_lds = nullptr) {
+// scan_out (optional): what the tet search found (a tet number or 0xffffffff), kTetNotSearched when the sample is outside the deformed mesh's box -- the membrane
+// correction of the same operator looks for the same tet at the same position (poisson_residual_find) and takes it from here.
+constexpr uint32_t kTetNotSearched = 0xfffffffeu;
+__device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3& wpos, f3& wdir, const uint32_t* __restrict__ march_lds = nullptr, uint32_t* scan_out = nullptr) {
 	bool in_deformed = false;
+	if (scan_out) *scan_out = kTetNotSearched;
 	if (box_contains(e.warped_bbox, wpos)) {
 		const f3 u = unwarp_position(wpos, e.aabb);
 		const int level = mip_from_pos(u);
 		const uint32_t cell = (NRS_OPT_WARP_MORTON && march_lds) ? occupancy_bit_index(u, (uint32_t)level, march_lds)
 		                                                         : (uint32_t)level * kGridVol + cascaded_grid_idx_at(u, (uint32_t)level);
 		const uint32_t found = scan_cell_for_tet(e, cell, u);
+		if (scan_out) *scan_out = found;
 		__builtin_amdgcn_sched_barrier(0);
 		if (found != 0xffffffffu) {
 			typedef uint32_t u4n __attribute__((ext_vector_type(4)));
@@ -783,14 +788,19 @@ __device__ __forceinline__ bool edit_warp(const DeviceEdit& e, bool with_dir, f3
 // Two steps (round 4), so that the renderer can run the un-deformed network pass between them with only three values live: _find decides which tet of the
 // deformed mesh holds the sample and interpolates the two densities; _colour re-derives the barycentric weights of that tet (the same arithmetic: the same
 // bits) and evaluates the SH9 colour.
+// searched (optional): the result of tet_warp's search of THIS operator's mesh at THIS position (the first operator the sample met: its position was still wpos0), or
+// kTetNotSearched -- the same function of the same arguments, so it is taken instead of searched for again.
 __device__ __forceinline__ bool poisson_residual_find(const DeviceEdit& e, f3 wpos0, uint32_t& found_out, float& out_density, float& res_density,
-                                                      const uint32_t* __restrict__ march_lds = nullptr) {
+                                                      const uint32_t* __restrict__ march_lds = nullptr, uint32_t searched = kTetNotSearched) {
 	const f3 pos = unwarp_position(wpos0, e.aabb);
 	if (!box_contains(e.bbox, pos)) return false;
-	const int level = mip_from_pos(pos);
-	const uint32_t cell = (NRS_OPT_WARP_MORTON && march_lds) ? occupancy_bit_index(pos, (uint32_t)level, march_lds)
-	                                                         : (uint32_t)level * kGridVol + cascaded_grid_idx_at(pos, (uint32_t)level);
-	const uint32_t found = scan_cell_for_tet(e, cell, pos);
+	uint32_t found = searched;
+	if (searched == kTetNotSearched) {
+		const int level = mip_from_pos(pos);
+		const uint32_t cell = (NRS_OPT_WARP_MORTON && march_lds) ? occupancy_bit_index(pos, (uint32_t)level, march_lds)
+		                                                         : (uint32_t)level * kGridVol + cascaded_grid_idx_at(pos, (uint32_t)level);
+		found = scan_cell_for_tet(e, cell, pos);
+	}
 	if (found == 0xffffffffu) return false;
 	typedef uint32_t u4n __attribute__((ext_vector_type(4)));
 	const u4n tv = gp(reinterpret_cast<const u4n*>(e.tets))[found];

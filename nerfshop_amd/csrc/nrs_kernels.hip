@@ -54,6 +54,12 @@ constexpr int kRing = 128; // pending-ray ring entries per wave (>= 63 + 64)
 #ifndef NRS_QUADS_NUM3
 #define NRS_QUADS_NUM3 3 // four record levels in flight for the compile-time tcnn-numerics instantiation too (-100: off)
 #endif
+#ifndef NRS_OPT_POISSON_REUSE
+#define NRS_OPT_POISSON_REUSE 1
+#endif
+#ifndef NRS_OPT_POISSON_SIGN
+#define NRS_OPT_POISSON_SIGN 1
+#endif
 #ifndef NRS_EXP_P
 #define NRS_EXP_P 0 // register experiments on the membrane path: bit 0 no old-density pass, bit 1 no boundary colour, bit 2 no tet search (wrong pictures)
 #endif
@@ -267,6 +273,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 	const DeviceModel& m = m_arg;
 	const RenderArgs& a = a_arg;
 	__shared__ RenderSmem<WAVES> sm;
+	__shared__ uint32_t poisson_stash[(POISSON && !AFFINE) ? WAVES * 64 : 1]; // per lane: the tet the first operator's warp found (see warp_scan)
 	stage_march_lds(sm.coarse, m.occ.mask);
 	if (threadIdx.x == 0) { sm.queue = 0ull; sm.sum_samples = 0ull; sm.sum_alive = 0u; sm.sum_hit = 0u; sm.n_finished = 0u; sm.idle_mask = 0u; sm.n_busy = (uint32_t)WAVES; }
 	if (threadIdx.x < WAVES) sm.mail[threadIdx.x] = 0u;
@@ -595,6 +602,8 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		// it into a multiplication -- is skipped with a scalar branch)
 		float wdt = p2.cone_angle_constant == 0.f ? 0.f : warp_dt(dt);
 		bool empty = false;
+		// POISSON: the tet the first operator's search found for this sample (its membrane terms are interpolated in the same tet: poisson_residual_find)
+		uint32_t warp_scan = kTetNotSearched;
 		const bool act = TEAM != 1 ? (have && valid) : have; // this lane evaluates a sample in this round
 		if (ops && act) { // map_rays, last-to-first (tn:2899-2902)
 #if NRS_EXP_DBL == 2
@@ -602,8 +611,19 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			  for (int ei = a2.n_edits - 1; ei >= 0; --ei) e2 |= AFFINE ? edit_warp(a2.edits[ei], true, wp2, wd2) : tet_warp(a2.edits[ei], true, wp2, wd2);
 			  asm volatile("" :: "v"(wp2.x), "v"(wp2.y), "v"(wp2.z), "v"(wd2.x), "v"(wd2.y), "v"(wd2.z), "s"((int)__ballot(e2))); }
 #endif
-			for (int ei = a2.n_edits - 1; ei >= 0; --ei) empty |= AFFINE ? edit_warp(a2.edits[ei], true, wpos, wdir) : tet_warp(a2.edits[ei], true, wpos, wdir, sm.coarse);
+			for (int ei = a2.n_edits - 1; ei >= 0; --ei) {
+				if (AFFINE) {
+					empty |= edit_warp(a2.edits[ei], true, wpos, wdir);
+				} else if (NRS_OPT_POISSON_REUSE && POISSON) {
+					uint32_t scan; // (a local of the iteration, selected below: a pointer that is sometimes null made warp_scan a stack object)
+					empty |= tet_warp(a2.edits[ei], true, wpos, wdir, sm.coarse, &scan);
+					if (ei == a2.n_edits - 1) warp_scan = scan;
+				} else {
+					empty |= tet_warp(a2.edits[ei], true, wpos, wdir, sm.coarse);
+				}
+			}
 		}
+		if (NRS_OPT_POISSON_REUSE && POISSON && !AFFINE) poisson_stash[wave * 64 + lane] = warp_scan; // (through LDS, not a register across the gather -- this instantiation's peak)
 		NRS_PHASE(3); // gather
 		// ---- gather: own sample (block g) and the partner lane's sample (block 1-g), levels 2*it+g ----
 #if NRS_EXP_DBL == 3
@@ -753,15 +773,19 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				uint32_t found_tet = 0u;
 				int found_edit = -1;
 				if (act && !(NRS_EXP_P & 4)) {
+					const uint32_t searched = (NRS_OPT_POISSON_REUSE && !AFFINE) ? poisson_stash[wave * 64 + lane] : kTetNotSearched;
 					for (int ei = a2b.n_edits - 1; ei >= 0; --ei)
-						if (a2b.edits[ei].apply_poisson && poisson_residual_find(a2b.edits[ei], wpos0, found_tet, p_out, p_res, sm.coarse)) found_edit = ei;
+						if (a2b.edits[ei].apply_poisson && poisson_residual_find(a2b.edits[ei], wpos0, found_tet, p_out, p_res, sm.coarse, ei == a2b.n_edits - 1 ? searched : kTetNotSearched)) found_edit = ei;
 				}
 				has_res = act && p_out > 1e-9f;
 				// step 2: the un-deformed network's density.  The reference evaluates it for every sample; its only consumer is the clamp of tn:776-777, i.e.
 				// samples with a residual when m_poisson_target is set (the reference's default) -- otherwise the pass is skipped, results unchanged.
-				if (!(NRS_EXP_P & 1) && p2b.poisson_target && __any(has_res)) {
+				// (round 4, late: and of those only the samples whose residual is POSITIVE -- min(max(target, s), s + res) = s + res whatever the target is when
+				// res <= 0, because max(., s) >= s >= s + res: a round whose residuals are all negative or zero skips the pass, the others gather for fewer lanes)
+				const bool need_old = NRS_OPT_POISSON_SIGN ? (has_res && p_res > 0.f) : has_res;
+				if (!(NRS_EXP_P & 1) && p2b.poisson_target && __any(need_old)) {
 					const GridView gvb = make_grid_view(m2b);
-					encode_num<NUM>(nm, gvb, m2b.levels, sm.ml, fl, lane, g, wpos0, has_res);
+					encode_num<NUM>(nm, gvb, m2b.levels, sm.ml, fl, lane, g, wpos0, need_old);
 					uint32_t old_d = 0;
 					#pragma unroll 1
 					for (int b = 0; b < 2; ++b) {
