@@ -35,7 +35,9 @@ TILE = int(os.environ.get("NRS_BENCH_TILE", "32"))  # image tiles dealt round-ro
 def build_scene(workload, rt, synth, ctx, torch):
     aabb_scale = 16 if workload.startswith("garden") else 1
     with_edit = "cage" in workload
-    desc = synth.model_desc(aabb_scale)
+    # (configs/nerf/base_1layer.json / base_3layer.json: the rgb network with one hidden layer is lowered onto the kernels' network and runs the default
+    # instantiations; the third hidden layer has its own: DESIGN.md 4 "The network family")
+    desc = synth.model_desc(aabb_scale, rgb_hidden_layers=1 if workload.endswith("base_1layer") else (3 if workload.endswith("base_3layer") else 2))
     if workload.endswith("varied"):
         # non-uniform opacity: geometry inside the network (shaped) and a strong density noise, so that per-sample alpha -- and with
         # it the number of samples a ray needs -- varies widely, as in a trained snapshot
@@ -207,7 +209,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage", "garden", "lego_cage_varied", "lego_cage_membrane", "garden_cage_norecords", "lego_cage_tcnn_numerics", "lego_cage_norecords"])
+    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage", "garden", "lego_cage_varied", "lego_cage_membrane", "garden_cage_norecords", "lego_cage_tcnn_numerics", "lego_cage_norecords", "lego_cage_base_1layer", "lego_cage_base_3layer"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -394,7 +396,8 @@ def main():
         # cage edit) and the lego-like scene with non-uniform opacity (a wide distribution of ray lengths, as a trained snapshot has)
         # plus the membrane correction on (SURVEY 8d's "one extra run with it on") and the garden scene WITHOUT the 64 GB of sparse brick records
         # (they are an option of the boundary, INTEGRATION.md: the figure a caller gets who does not install them)
-        for name in ("garden_cage", "garden_cage_norecords", "lego_cage_varied", "lego_cage_membrane", "lego_cage_tcnn_numerics", "lego_cage_norecords"):
+        for name in ("garden_cage", "garden_cage_norecords", "lego_cage_varied", "lego_cage_membrane", "lego_cage_tcnn_numerics", "lego_cage_norecords", "lego_cage_base_1layer",
+                     "lego_cage_base_3layer"):
             sc2 = build_scene(name, rt, synth, ctx, torch)
             tb2 = sc2["tb"]
 
@@ -493,7 +496,9 @@ def main():
                                     "lego_cage_membrane": "lego-like snapshot 1920x1080, one cage edit with the membrane (Poisson) correction on",
                                     "garden_cage_norecords": "garden-style aabb_scale 16 1920x1080, one cage edit, no sparse brick records",
                                     "lego_cage_tcnn_numerics": "lego-like snapshot 1920x1080, one cage edit, tiny-cuda-nn's roundings (fp16 per-corner grid accumulation, fp16 MLP accumulators)",
-                                    "lego_cage_norecords": "lego-like snapshot 1920x1080, one cage edit, no cell records (nrs_model_set_cell_cache(0))"}[args.workload],
+                                    "lego_cage_norecords": "lego-like snapshot 1920x1080, one cage edit, no cell records (nrs_model_set_cell_cache(0))",
+                                    "lego_cage_base_1layer": "lego-like snapshot of configs/nerf/base_1layer.json (rgb network with one hidden layer) 1920x1080, one cage edit",
+                                    "lego_cage_base_3layer": "lego-like snapshot of configs/nerf/base_3layer.json (rgb network with three hidden layers) 1920x1080, one cage edit"}[args.workload],
                        "resolution": [W, H], "samples_per_frame": int(total_samples / args.steps),
                        "sharding": f"{TILE}x{TILE} image tiles round-robin over {world} GPU(s)" + (f", gather to rank 0 by {all_sharders[0].gather_impl}" if world > 1 else ""),
                        "frames_in_flight": n_buf,

@@ -469,6 +469,7 @@ int nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out) 
 		m->dm.inv_diag[k] = 1.0f / diag;
 	}
 	m->dm.rgb_deep = desc->sh_degree != 0 && desc->rgb_hidden_layers == 3 ? 1u : 0u;
+	m->dm.no_dir = desc->sh_degree == 0 ? 1u : 0u;
 	m->dm.rgb_activation = desc->rgb_activation;
 	m->dm.density_activation = desc->density_activation;
 	hipError_t he = hipMalloc((void**)&m->d_grid, (size_t)m->total_entries * 4);

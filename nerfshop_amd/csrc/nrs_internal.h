@@ -85,6 +85,7 @@ struct DeviceModel {
 	uint32_t        density_activation;
 	uint32_t        numerics;  // bit 0: nrs_grid_acc NETWORK, bit 1: nrs_mlp_acc FP16 (nrs_model_set_numerics); 0 = the default roundings
 	uint32_t        rgb_deep;  // the rgb network has a third hidden layer (fragments R2b, read from wfrag in HBM): base_3layer.json
+	uint32_t        no_dir;    // NerfNetworkNoDir (base_nodir.json): the direction rows of caller batches are not read
 };
 
 // AffineBoundingBox as the kernels test it (affine_bounding_box.cuh:83-88): u.(p - min) in [0, u.u) etc.

@@ -1691,7 +1691,8 @@ __global__ __launch_bounds__(64 * kNetWaves, (MODE == 3 || MODE == 4) ? 3 : 6) v
 		if (have) {
 			const float* c = in + (size_t)s * ld_in;
 			wpos = mk3(c[0], c[1], c[2]);
-			if (FULL || MODE == 4) wdir = mk3(c[4], c[5], c[6]);
+			// (NerfNetworkNoDir never looks at the direction rows: a caller may leave them unset, and 0-weights do not stop a NaN)
+			if ((FULL || MODE == 4) && !m.no_dir) wdir = mk3(c[4], c[5], c[6]);
 		}
 		encode_to_lds<(NUM & 1) != 0>(gv, m.levels, sm.ml, fl, lane, g, wpos, have);
 

@@ -75,6 +75,13 @@ def test_inference_against_the_oracle(arch_rig, numerics):
     assert ok.all(), f"max ulps {ulps.max()}, max abs {absd.max()}, bad {np.count_nonzero(~ok)}"
     assert (ulps[:4] == 0).mean() > 0.9
     assert np.abs(ref.view(np.float16).astype(np.float32)[:3]).max() > 0.05  # the colour channels carry values
+    if rig.arch == "nodir" and numerics == (0, 0):
+        # NerfNetworkNoDir does not read the direction rows (nerf_network_nodir.h:47-91 encodes the position only): garbage there changes nothing
+        c2 = c.copy()
+        c2[:, 3:] = np.nan
+        out2 = torch.zeros((16, n), dtype=torch.float16, device="cuda:0")
+        rig.net.inference_mixed_precision(None, torch.from_numpy(c2).cuda(), out2)
+        assert np.array_equal(out2.cpu().numpy().view(np.uint16), got.view(np.uint16))
     if rig.arch in ("rgb0", "nodir"):
         # channels the smaller network does not have are zero (rgb0: CutlassMLP pads its 3 outputs to 8; nodir: rgb + density only)
         first_pad = 8 if rig.arch == "rgb0" else 4
