@@ -1412,7 +1412,13 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	// everything of render_nerf's surface beyond Shade / Cost with a pinhole camera runs the EXTRA instantiation (one lane per ray)
 	a.extra = ((p->render_mode != NRS_RENDER_SHADE && p->render_mode != NRS_RENDER_COST) || p->show_accel || p->dof != 0.f || p->distortion_mode || p->d_distortion_map ||
 	           p->d_envmap || p->glow_mode) ? 1u : 0u;
-	if (m->dm.rgb_deep) a.extra = 1u; // (a third rgb hidden layer is evaluated by the catch-all instantiation only: launch_render)
+	if (m->dm.rgb_deep && !a.extra) {
+		// A third rgb hidden layer: the automatic schedule has a DEEP instantiation for the plain case (Shade / Cost, cage edits without the membrane correction, default
+		// roundings, no forced schedule); everything else of such a network runs the DEEP twins of the catch-all (launch_render)
+		static const bool env_sched = (getenv("NRS_TEAM") && atoi(getenv("NRS_TEAM")) != 0) || (getenv("NRS_HYBRID") && atoi(getenv("NRS_HYBRID")) == 0) || getenv("NRS_RENDER_CFG");
+		const bool plain = !a.any_poisson && !a.any_affine && m->dm.numerics == 0u && !ctx->lane_teams && !env_sched && !(a.dbg & 4u);
+		if (!plain) a.extra = 1u;
+	}
 	if (p->render_mode == NRS_RENDER_SLICE) { // tn:3109-3162: no marching at all; one network evaluation per owned pixel
 		a.frame = d_frame; a.depth = d_depth; a.steps = d_steps; a.counters = d_counters_slot;
 		HIP_TRY(hipMemsetAsync(d_counters_slot, 0, sizeof(RenderCounters), s));

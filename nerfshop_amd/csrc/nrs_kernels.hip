@@ -256,10 +256,11 @@ __device__ __forceinline__ bool packet_pixel_tail(const RenderArgs& a, uint32_t 
 //      A separate instantiation (one lane per ray): the Shade / Cost kernels carry none of it.
 // XTRA: 0 = none of it, 1 = EXTRA, 2 = EXTRA + INTRO: render modes Normals and EncodingVis (the network's input gradient / a visualised activation per sample,
 //      tn:2923-2927: a second pass over the hash grid and a backward or partial forward pass of the MLPs -- a separate instantiation again);
-//      3 / 4 = 1 / 2 with a third hidden layer in the rgb MLP (DeviceModel::rgb_deep, configs/nerf/base_3layer.json; every mode of such a network runs there).
+//      3 / 4 = 1 / 2 with a third hidden layer in the rgb MLP (DeviceModel::rgb_deep, configs/nerf/base_3layer.json), 5 = that layer and nothing else of EXTRA: the
+//      automatic schedule's instantiation for such a network (plain Shade / Cost frames; nrs_render_nerf decides).
 template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0, int XTRA = 0>
 __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const RenderArgs& a_arg) {
-	constexpr bool EXTRA = XTRA != 0, INTRO = XTRA == 2 || XTRA == 4, DEEP = XTRA >= 3; // (3 / 4: 1 / 2 for a network whose rgb MLP has a third hidden layer, base_3layer.json)
+	constexpr bool EXTRA = XTRA >= 1 && XTRA <= 4, INTRO = XTRA == 2 || XTRA == 4, DEEP = XTRA >= 3; // (3 / 4: 1 / 2 for a network whose rgb MLP has a third hidden layer, base_3layer.json; 5: that layer alone)
 	// The two argument structs (~1.3 KB of wave-uniform values) live in the kernel-argument segment and are read with scalar loads.
 	// Left alone, the compiler hoists every such load out of the frame loop and then spills ~150 scalar registers into VGPR lanes
 	// (v_writelane / v_readlane: VALU slots in the round loop, 3 VGPRs).  NRS_FRESH_ARGS re-derives the two references from an
@@ -1178,6 +1179,7 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 			return m.numerics ? launch_render_cfg<12, 3, false, true, true, 1, R, 2>(m, a, n_cus, s) : launch_render_cfg<12, 3, false, true, true, 1, 0, 2>(m, a, n_cus, s);
 		return m.numerics ? launch_render_cfg<12, 3, false, true, true, 1, R, 1>(m, a, n_cus, s) : launch_render_cfg<12, 3, false, true, true, 1, 0, 1>(m, a, n_cus, s);
 	}
+	if (m.rgb_deep) return launch_render_cfg<8, 4, false, false, false, 0, 0, 5>(m, a, n_cus, s); // (nrs_render_nerf sends only the plain case here: a.team == 0, default roundings)
 	if (m.numerics) { // tiny-cuda-nn's other roundings: the run-time twin of every schedule (nrs_render_nerf computed the packet geometry for a.team)
 		// ... except the pair a parity-minded integrator switches on -- per-corner fp16 grid accumulation + fp16 MLP accumulators, what tiny-cuda-nn's
 		// kernel_grid and fully fused MLP do as recalled -- on the automatic schedule: a compile-time instantiation like NUM = 0 (VERDICT r3 weak #1:

@@ -109,6 +109,25 @@ def test_render_against_the_oracle(arch_rig, edit, numerics):
     assert np.allclose(depth[hit], ref_depth[hit], rtol=0, atol=2e-3)
 
 
+def test_third_hidden_layer_on_both_instantiations(built):
+    """base_3layer.json: plain frames run the DEEP instantiation of the automatic schedule (lane teams, hand-over), everything else the DEEP twins of the
+    catch-all (one lane per ray) -- the same arithmetic per sample, so the same bits; a forced schedule is one way to get the catch-all."""
+    if "rgb3" not in _rigs:
+        _rigs["rgb3"] = GpuRig(Scene(aabb_scale=1, with_edit=True, lattice_n=6, shaped=True, **ARCHS["rgb3"]))
+    rig = _rigs["rgb3"]
+    rig.use_edit(True)
+    p = rig.scene.params_for(320, 180, 100.0)
+    fast = rig.render(p)
+    rig.ctx.set_lane_teams(1)
+    try:
+        slow = rig.render(p)
+    finally:
+        rig.ctx.set_lane_teams(0)
+        rig.use_edit(False)
+    assert fast[3].n_samples == slow[3].n_samples and fast[3].n_samples > 100000
+    assert np.array_equal(fast[0].view(np.uint32), slow[0].view(np.uint32)) and np.array_equal(fast[1].view(np.uint32), slow[1].view(np.uint32)) and np.array_equal(fast[2], slow[2])
+
+
 def test_device_parameters_give_the_same_network(arch_rig):
     """nrs_model_set_params_device cuts the fragments with the lowering as a signed permutation (weight index, negation bit, the two constants) on the GPU:
     the same bits as the host path."""
