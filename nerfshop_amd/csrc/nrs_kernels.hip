@@ -54,6 +54,10 @@ constexpr int kRing = 128; // pending-ray ring entries per wave (>= 63 + 64)
 #ifndef NRS_QUADS_NUM3
 #define NRS_QUADS_NUM3 3 // four record levels in flight for the compile-time tcnn-numerics instantiation too (-100: off)
 #endif
+// NRS_TEAM_MAX (experiment): the widest lane team of the automatic schedule (4; 8 = eight lanes per ray once a wave holds <= 8 rays)
+#ifndef NRS_TEAM_MAX
+#define NRS_TEAM_MAX 4
+#endif
 #ifndef NRS_OPT_POISSON_REUSE
 #define NRS_OPT_POISSON_REUSE 1
 #endif
@@ -391,7 +395,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		if (TEAM == 0 && a1.reteam && (((a1.reteam & 2u) && tail_seen) || (!more && ring_count == 0u))) { // (bit 1: at any time once the wave runs tail generations, not only at its end)
 			const unsigned long long lead_mask = __ballot(have && tk == 0);
 			const uint32_t live = (uint32_t)__popcll(lead_mask);
-			const uint32_t new_t = live <= 16u ? 4u : (live <= 32u ? 2u : 1u);
+			const uint32_t new_t = (NRS_TEAM_MAX >= 8 && live <= 8u) ? 8u : (live <= 16u ? 4u : (live <= 32u ? 2u : 1u));
 			if (live != 0u && new_t > gen_t) {
 				if (have && tk == 0) {
 					const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lead_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lead_mask, 0u));
@@ -499,7 +503,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			if (TEAM == 0) { // hybrid: full generations until the tail packets, then as many lanes per ray as the pending rays allow
 				// (a launch of tail packets only runs one lane per ray only where it is large -- 64-pixel packets -- and the wave can fill its lanes:
 				// otherwise more than 32 pending rays = 32 now as teams of two, the rest in the next generation or handed to a waiting sibling)
-				gen_t = tail_seen ? (ring_count > 32u && (!a1.all_tail || (a1.fill_lanes == 1u && ring_count >= NRS_FULL_GEN)) ? 1u : (ring_count > 16u ? 2u : 4u)) : 1u;
+				gen_t = tail_seen ? (ring_count > 32u && (!a1.all_tail || (a1.fill_lanes == 1u && ring_count >= NRS_FULL_GEN)) ? 1u : (ring_count > 16u ? 2u : ((NRS_TEAM_MAX >= 8 && ring_count <= 8u) ? 8u : 4u))) : 1u;
 				tk = lane & (int)(gen_t - 1u);
 				team_base = lane & ~(int)(gen_t - 1u);
 			}
@@ -563,7 +567,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					continue;
 				}
 				const uint32_t* mb = &sm.fl[wave].feat[0][0][0];
-				gen_t = got <= 16u ? 4u : 2u; // (a sibling hands over at most 32 rays)
+				gen_t = (NRS_TEAM_MAX >= 8 && got <= 8u) ? 8u : (got <= 16u ? 4u : 2u); // (a sibling hands over at most 32 rays)
 				tk = ln & (int)(gen_t - 1u);
 				team_base = ln & ~(int)(gen_t - 1u);
 				const uint32_t r = (uint32_t)ln / gen_t;
@@ -863,7 +867,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			// every lane of the team composites the team's samples in marching order (composite_kernel_nerf, tn:750-955)
 			bool done = false, shade = true, exited = false; // exited: the ray left the render box un-saturated (Cost mode counts one more step for it, below)
 			#pragma unroll
-			for (int k = 0; k < (TEAM ? TEAM : 4); ++k) {
+			for (int k = 0; k < (TEAM ? TEAM : NRS_TEAM_MAX); ++k) {
 				if (TEAM == 0 && k >= (int)gen_t) break;
 				const int src = team_base + k;
 				const bool v_k = __shfl((int)act, src, 64) != 0;
@@ -906,7 +910,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				const bool chain = __shfl((int)valid, last, 64) != 0; // the last lane stands on a sample, hence every lane of the team does
 				float cand = u0;
 				#pragma unroll
-				for (int j = 0; j < 4; ++j)
+				for (int j = 0; j < (TEAM ? TEAM : NRS_TEAM_MAX); ++j)
 					if (j <= tk) cand += calc_dt(cand, p3.cone_angle_constant);
 				const bool holds = need && chain && stands_in_occupied_cell(p3, m3, sm.coarse, o, d, cand);
 				const uint32_t team_bits = (uint32_t)(__ballot(holds) >> team_base) & ((1u << gen_t) - 1u);
