@@ -59,3 +59,20 @@ def test_verify_snapshot_on_synthetic_files(rig, tmp_path):
             assert rec["parity"] and rec["samples"] > 10000 and rec["max_sample_count_difference"] <= 1
         assert v["fp32_fp32 (default)"]["psnr"] > 38.0            # the picture it was made from, through 8-bit sRGB
         assert v["network_fp16 (tiny-cuda-nn as recalled)"]["psnr"] > 30.0
+
+
+@pytest.mark.parametrize("kw", [dict(no_dir=True), dict(rgb_hidden_layers=1), dict(rgb_hidden_layers=3)], ids=["base_nodir", "base_1layer", "base_3layer"])
+def test_verify_snapshot_on_the_network_family(built, tmp_path, kw):
+    """The same command on snapshots of base.json's relatives (the architecture is read from the file: nrs_snapshot_open)."""
+    from conftest import Scene
+    from nerfshop_amd import formats
+    scene = Scene(aabb_scale=1, with_edit=False, shaped=True, **kw)
+    formats.save_snapshot(tmp_path / "scene.msgpack", scene.desc, 1, scene.params, scene.grid, camera=scene.camera(60.0))
+    out = tmp_path / "report.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "verify_snapshot.py"), str(tmp_path / "scene.msgpack"), "--res", "160x90", "--max-views", "1", "--out", str(out)],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rep = json.load(open(out))
+    assert rep["parity_all_views"] and len(rep["views"]) == 1
+    for mode in ("fp32_fp32 (default)", "network_fp16 (tiny-cuda-nn as recalled)"):
+        assert rep["views"][0][mode]["parity"] and rep["views"][0][mode]["samples"] > 5000
