@@ -406,7 +406,7 @@ int nrs_snapshot_open(const char* path, nrs_snapshot** out) {
 		d.sh_degree = 0;
 		if (has_dir) {
 			d.rgb_hidden_layers = bounded(rgb->number_or("n_hidden_layers", 2), 0, 64, "rgb_network.n_hidden_layers");
-			if (d.rgb_hidden_layers > 0 && (uint32_t)rgb->number_or("n_neurons", 64) != d.n_neurons) throw std::runtime_error("density / rgb networks of different widths are not supported");
+			if (d.rgb_hidden_layers > 0 && bounded(rgb->number_or("n_neurons", 64), 1, 4096, "rgb_network.n_neurons") != d.n_neurons) throw std::runtime_error("density / rgb networks of different widths are not supported");
 			d.sh_degree = 4;
 			if (const Value* nested = dir->find("nested"))
 				if (nested->kind == Value::Arr && !nested->a.empty()) d.sh_degree = bounded(nested->a[0].number_or("degree", 4), 1, 16, "dir_encoding.degree");
