@@ -1,4 +1,7 @@
-bash tools/ab_env.sh gpurun_out/ab_center_out2.txt lego_cage "rowmajor=NRS_CENTER_OUT=0" "outsidein=NRS_CENTER_OUT=2" > /dev/null 2>&1 < /dev/null; cat gpurun_out/ab_center_out2.txt
-for co in 0 2; do
-  NRS_CENTER_OUT=$co timeout 100 python tools/small_launch_probe.py 8 2>&1 < /dev/null | grep "share:" | sed "s/^/center_out=$co /"
+V=$GRAFT_REPO_ROOT/nerfshop_amd/csrc/variants/libnrs_team8end.so
+bash tools/ab_bench.sh gpurun_out/ab_team8end_lego.txt lego_cage t4=default t8end=$V > /dev/null 2>&1 < /dev/null; cat gpurun_out/ab_team8end_lego.txt
+for rep in 1 2; do
+  timeout 100 python tools/small_launch_probe.py 8 2>&1 < /dev/null | grep "share:" | sed 's/^/default /'
+  NRS_LIB_PATH=$V timeout 100 python tools/small_launch_probe.py 8 2>&1 < /dev/null | grep "share:" | sed 's/^/team8end /'
 done
+NRS_LIB_PATH=$V timeout 200 python -m pytest tests/test_gpu_lane_teams.py -q -x 2>&1 < /dev/null | tail -1
