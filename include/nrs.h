@@ -94,7 +94,7 @@ typedef enum nrs_mlp_acc { NRS_MLP_ACC_FP32 = 0, NRS_MLP_ACC_FP16 = 1 } nrs_mlp_
 
 /* Network hyper-parameters: configs/nerf/base.json:23-58 + src/testbed.cu:2257-2333.
  * Accepted: base.json's family -- the 16 x 2 hash grid with any table size (base_14 / small / base / big.json: log2_hashmap_size 14 / 15 / 19 / 21), the 64-wide
- * density network with one hidden layer, and an rgb network of 0 (CutlassMLP, base_0layer.json), 1, 2 (base.json) or 3 hidden layers (base_{1,2,3}layer.json) on the
+ * density network with one hidden layer (or none: one [16 x 32] matrix, linear.json), and an rgb network of 0 (CutlassMLP, base_0layer.json), 1, 2 (base.json) or 3 hidden layers (base_{1,2,3}layer.json) on the
  * degree-4 spherical harmonics -- or NO direction encoding and rgb network (base_nodir.json -> NerfNetworkNoDir, testbed.cu:2314-2353): sh_degree = 0,
  * rgb_hidden_layers = 0; the colour is then the density network's outputs 1..3 (nerf_network_nodir.h:47-91).  Parameter blob: [density | rgb | grid] with the rgb part
  * [64 x 32] + (L - 1) [64 x 64] + [16 x 64] for L >= 1 hidden layers, one [8 x 32] matrix for L = 0, nothing for NoDir (tiny-cuda-nn's layouts as recalled;
@@ -106,7 +106,7 @@ typedef struct nrs_model_desc {
 	uint32_t base_resolution;      /* 16 */
 	float    per_level_scale;      /* exp(ln(2048*aabb_scale/16)/15), testbed.cu:2288-2292 */
 	uint32_t n_neurons;            /* 64 (both MLPs) */
-	uint32_t density_hidden_layers;/* 1  */
+	uint32_t density_hidden_layers;/* 1  (0..1) */
 	uint32_t density_output_dims;  /* 16, nerf_network_full.h:47-49 */
 	uint32_t rgb_hidden_layers;    /* 2  (0..3; 0 with sh_degree 0) */
 	uint32_t sh_degree;            /* 4  (0 = NerfNetworkNoDir) */

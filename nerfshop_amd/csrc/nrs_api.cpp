@@ -148,18 +148,22 @@ static int check_march_params(const nrs_render_params& p, const char* who) {
 // NerfNetworkFull::width(layer) / num_forward_activations (nerf_network_full.h:507-521): the hash-grid output, the density network's hidden layer, the rgb
 // network's input, then one layer per rgb hidden layer.  NerfNetworkNoDir (nerf_network_nodir.h:419-438): the first two (its num_forward_activations counts two
 // more, which its own forward_activations cannot serve).  0 = no such layer.
+// The kernels number the layers of base.json's shape: 0 grid, 1 density hidden, 2 rgb input, 3.. rgb hidden.  A density network WITHOUT hidden layer
+// (configs/nerf/linear.json) has no layer 1 in the reference's numbering: its layer k >= 1 is the kernels' layer k + 1.
+static uint32_t kernel_layer(const nrs_model_desc& d, uint32_t layer) { return (d.density_hidden_layers == 0u && layer >= 1u) ? layer + 1u : layer; }
 static uint32_t network_layer_width(const nrs_model_desc& d, uint32_t layer) {
-	if (layer == 0u) return 32u;
-	if (layer == 1u) return 64u;
+	const uint32_t k = kernel_layer(d, layer);
+	if (k == 0u) return 32u;
+	if (k == 1u) return 64u;
 	if (d.sh_degree == 0u) return 0u;
-	if (layer == 2u) return 32u;
-	return layer - 3u < d.rgb_hidden_layers ? 64u : 0u;
+	if (k == 2u) return 32u;
+	return k - 3u < d.rgb_hidden_layers ? 64u : 0u;
 }
 // configs/nerf/base.json's family: hash grid of 16 x 2 features (any table size: base_14 / small / base / big.json), the 64-wide density network with one hidden
-// layer, and an rgb network of 0 (CutlassMLP, base_0layer.json), 1, 2 (base.json) or 3 hidden layers (base_{1,2,3}layer.json) on SH degree 4 -- or none at all
+// layer -- or none: one [16 x 32] matrix (CutlassMLP, linear.json) --, and an rgb network of 0 (CutlassMLP, base_0layer.json), 1, 2 (base.json) or 3 hidden layers (base_{1,2,3}layer.json) on SH degree 4 -- or none at all
 // (base_nodir.json -> NerfNetworkNoDir, testbed.cu:2314-2353: sh_degree == 0).
 static bool desc_supported(const nrs_model_desc& d) {
-	const bool trunk = d.n_levels == 16 && d.n_features_per_level == 2 && d.n_neurons == 64 && d.density_hidden_layers == 1 && d.density_output_dims == 16 &&
+	const bool trunk = d.n_levels == 16 && d.n_features_per_level == 2 && d.n_neurons == 64 && d.density_hidden_layers <= 1 && d.density_output_dims == 16 &&
 	                   d.log2_hashmap_size >= 8 && d.log2_hashmap_size <= 24 && d.base_resolution >= 1;
 	if (!trunk) return false;
 	if (d.sh_degree == 0) return d.rgb_hidden_layers == 0;
@@ -172,7 +176,8 @@ static uint32_t n_rgb_weights(const nrs_model_desc& d) {
 	if (d.rgb_hidden_layers == 0) return 8u * 32u;
 	return 64u * 32u + (d.rgb_hidden_layers - 1u) * 64u * 64u + 16u * 64u;
 }
-static uint32_t n_mlp_weights(const nrs_model_desc& d) { return kDensityW + n_rgb_weights(d); }
+static uint32_t n_density_weights(const nrs_model_desc& d) { return d.density_hidden_layers == 0 ? 16u * 32u : kDensityW; }
+static uint32_t n_mlp_weights(const nrs_model_desc& d) { return n_density_weights(d) + n_rgb_weights(d); }
 
 // ---- lowering of the family onto the kernels' network (kCanonW entries, nrs_internal.h) -------------------------------------------------------------
 // Entries are opaque 16-bit words: fp16 bit patterns (nrs_model_set_params) or weight indices (nrs_model_set_params_device's permutation); `ops` says what
@@ -187,8 +192,21 @@ static uint32_t n_mlp_weights(const nrs_model_desc& d) { return kDensityW + n_rg
 struct LowerOps { uint16_t one, minus_one; uint16_t (*negate)(uint16_t); };
 static void lower_weights(const nrs_model_desc& d, const uint16_t* w, uint16_t* canon, const LowerOps& ops) {
 	memset(canon, 0, kCanonW * sizeof(uint16_t));
-	memcpy(canon, w, kDensityW * sizeof(uint16_t));
-	const uint16_t* r = w + kDensityW;
+	if (d.density_hidden_layers == 0) {
+		// no hidden layer in the density network (linear.json): y = W f by the first layer as (W, -W), the output layer subtracts relu(y) and relu(-y) -- as for the
+		// rgb network below.  (The density's input gradient goes through the same two layers: (y > 0) W^T 128 - (y < 0) (-W)^T 128 = W^T 128, the linear layer's
+		// own backward pass, for every y but an exact 0.)
+		uint16_t* Wd1 = canon;           // [64 x 32]
+		uint16_t* Wd2 = canon + 64 * 32; // [16 x 64]
+		for (int row = 0; row < 16; ++row) {
+			for (int k = 0; k < 32; ++k) { Wd1[row * 32 + k] = w[row * 32 + k]; Wd1[(16 + row) * 32 + k] = ops.negate(w[row * 32 + k]); }
+			Wd2[row * 64 + row] = ops.one;
+			Wd2[row * 64 + 16 + row] = ops.minus_one;
+		}
+	} else {
+		memcpy(canon, w, kDensityW * sizeof(uint16_t));
+	}
+	const uint16_t* r = w + n_density_weights(d);
 	uint16_t* Wr1 = canon + kDensityW;   // [64 x 32]
 	uint16_t* Wr2 = Wr1 + 64 * 32;       // [64 x 64]
 	uint16_t* Wr3 = Wr2 + 64 * 64;       // [16 x 64]
@@ -436,7 +454,7 @@ size_t nrs_model_n_params(const nrs_model_desc* d) {
 }
 int nrs_model_level_table(const nrs_model_desc* d, float* scale, uint32_t* resolution, uint32_t* entry_offset, uint32_t* entry_count,
                           uint32_t* hashed) {
-	if (!d || !desc_supported(*d)) return fail(NRS_ERR_UNSUPPORTED, "model description outside configs/nerf/base.json's family (hash grid 16 x 2, 64-wide density network, rgb network of 0..3 hidden layers or none)");
+	if (!d || !desc_supported(*d)) return fail(NRS_ERR_UNSUPPORTED, "model description outside configs/nerf/base.json's family (hash grid 16 x 2, 64-wide density network of 0..1 hidden layers, rgb network of 0..3 hidden layers or none)");
 	LevelParams lv[kLevels];
 	make_levels(*d, lv);
 	for (uint32_t l = 0; l < d->n_levels; ++l) {
@@ -451,7 +469,7 @@ int nrs_model_level_table(const nrs_model_desc* d, float* scale, uint32_t* resol
 
 int nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out) {
 	if (!ctx || !desc || !out) return fail(NRS_ERR_INVALID_ARG, "nrs_model_create: NULL argument");
-	if (!desc_supported(*desc)) return fail(NRS_ERR_UNSUPPORTED, "model description outside configs/nerf/base.json's family (hash grid 16 x 2, 64-wide density network, rgb network of 0..3 hidden layers or none)");
+	if (!desc_supported(*desc)) return fail(NRS_ERR_UNSUPPORTED, "model description outside configs/nerf/base.json's family (hash grid 16 x 2, 64-wide density network of 0..1 hidden layers, rgb network of 0..3 hidden layers or none)");
 	for (int k = 0; k < 3; ++k)
 		if (!(desc->aabb_max[k] > desc->aabb_min[k])) return fail(NRS_ERR_INVALID_ARG, "nrs_model_create: empty aabb");
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -864,7 +882,7 @@ int nrs_network_visualize_activation(nrs_model* m, void* stream, uint32_t layer,
 	if (dimension >= network_layer_width(m->desc, layer))
 		return fail(NRS_ERR_INVALID_ARG, "nrs_network_visualize_activation: no such unit (layers: hash grid 32 | density hidden 64 | rgb input 32 | one of 64 per rgb hidden layer)");
 	HIP_TRY(hipSetDevice(m->ctx->device));
-	NRS_TRY(launch_network(m->dm, 4, n, d_in, NRS_NETWORK_INPUT_FLOATS, d_out, 1, (int)(layer | (dimension << 8)), m->ctx->n_cus, stream));
+	NRS_TRY(launch_network(m->dm, 4, n, d_in, NRS_NETWORK_INPUT_FLOATS, d_out, 1, (int)(kernel_layer(m->desc, layer) | (dimension << 8)), m->ctx->n_cus, stream));
 	return NRS_OK;
 }
 int nrs_density_on_grid(nrs_model* m, void* stream, const uint32_t res3d[3], const float aabb_min[3], const float aabb_max[3], int mask_with_density_grid,
@@ -1381,6 +1399,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 
 	RenderArgs a{};
 	a.p = *p;
+	if (p->render_mode == NRS_RENDER_ENCODING_VIS) a.p.visualized_layer = kernel_layer(m->desc, p->visualized_layer); // (the kernels number base.json's layers)
 	uint32_t owned_tiles = 0;
 	a.team = 1;
 	a.fill_lanes = 4;

@@ -52,7 +52,7 @@ def network_config(desc, explicit_per_level_scale=False):
     cfg = {
         "loss": {"otype": "Huber"},
         "encoding": enc,
-        "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": int(desc.n_neurons),
+        "network": {"otype": "FullyFusedMLP" if desc.density_hidden_layers else "CutlassMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": int(desc.n_neurons),
                     "n_hidden_layers": int(desc.density_hidden_layers)},
     }
     if desc.sh_degree:  # (configs/nerf/base_nodir.json has neither block: NerfNetworkNoDir, testbed.cu:2314)

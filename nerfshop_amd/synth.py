@@ -82,13 +82,13 @@ def scene_aabb(aabb_scale):
     return (0.5 - h,) * 3, (0.5 + h,) * 3
 
 
-def model_desc(aabb_scale=1, rgb_hidden_layers=2, no_dir=False, log2_hashmap_size=19):
+def model_desc(aabb_scale=1, rgb_hidden_layers=2, no_dir=False, log2_hashmap_size=19, density_hidden_layers=1):
     """configs/nerf/base.json by default; its relatives: rgb_hidden_layers 0 / 1 / 3 (base_{0,1,3}layer.json), no_dir (base_nodir.json -> NerfNetworkNoDir:
-    sh_degree 0, no rgb network), log2_hashmap_size 14 / 15 / 21 (base_14 / small / big.json)."""
+    sh_degree 0, no rgb network), log2_hashmap_size 14 / 15 / 21 (base_14 / small / big.json), density_hidden_layers 0 (linear.json, with rgb_hidden_layers 0)."""
     d = ModelDesc()
     d.n_levels, d.n_features_per_level, d.log2_hashmap_size, d.base_resolution = 16, 2, log2_hashmap_size, 16
     d.per_level_scale = per_level_scale(aabb_scale)
-    d.n_neurons, d.density_hidden_layers, d.density_output_dims, d.rgb_hidden_layers, d.sh_degree = 64, 1, 16, (0 if no_dir else rgb_hidden_layers), (0 if no_dir else 4)
+    d.n_neurons, d.density_hidden_layers, d.density_output_dims, d.rgb_hidden_layers, d.sh_degree = 64, density_hidden_layers, 16, (0 if no_dir else rgb_hidden_layers), (0 if no_dir else 4)
     d.rgb_activation, d.density_activation = _abi.ACT_LOGISTIC, _abi.ACT_EXPONENTIAL
     mn, mx = scene_aabb(aabb_scale)
     d.aabb_min[:] = mn
@@ -138,7 +138,8 @@ def make_params(desc, seed=SEED, sigma_raw=None, density_noise=0.25, shaped=Fals
         lim = math.sqrt(6.0 / (n_in + n_out))
         return rng.uniform(-lim, lim, size=(n_out, n_in)).astype(np.float32)
 
-    dw1, dw2 = xavier(64, 32), xavier(16, 64)
+    linear_density = desc.density_hidden_layers == 0  # configs/nerf/linear.json: the density network is one [16 x 32] matrix
+    dw1, dw2 = (xavier(16, 32), np.zeros((0, 0), np.float32)) if linear_density else (xavier(64, 32), xavier(16, 64))
     # rgb network of the description (tiny-cuda-nn's layouts as recalled): none (NerfNetworkNoDir), one [8 x 32] matrix (CutlassMLP without hidden layer),
     # or [64 x 32] + (L - 1) [64 x 64] + [16 x 64]; base.json (L = 2) draws rgb W1, W2, W3 as it always did
     if desc.sh_degree == 0:
@@ -148,15 +149,19 @@ def make_params(desc, seed=SEED, sigma_raw=None, density_noise=0.25, shaped=Fals
     else:
         rgb = [xavier(64, 32)] + [xavier(64, 64) for _ in range(desc.rgb_hidden_layers - 1)] + [xavier(16, 64)]
     n_rgb = sum(w.size for w in rgb)
-    grid = rng.uniform(-0.5, 0.5, size=n - N_DENSITY_W - n_rgb).astype(np.float32)
+    grid = rng.uniform(-0.5, 0.5, size=n - dw1.size - dw2.size - n_rgb).astype(np.float32)
     lt = level_table(desc)
     # constant feature: level 0, feature 0
     o0, c0 = int(lt["offset"][0]), int(lt["count"][0])
     grid[2 * o0: 2 * (o0 + c0): 2] = 1.0
-    dw1[0, :] = 0.0
-    dw1[0, 0] = 1.0          # hidden unit 0 = relu(1 * const) = 1
-    dw2[0, :] *= density_noise
-    dw2[0, 0] = sigma_raw
+    if linear_density:       # density_raw = sigma_raw * const + density_noise * (mix of the other features)
+        dw1[0, :] *= density_noise
+        dw1[0, 0] = sigma_raw
+    else:
+        dw1[0, :] = 0.0
+        dw1[0, 0] = 1.0          # hidden unit 0 = relu(1 * const) = 1
+        dw2[0, :] *= density_noise
+        dw2[0, 0] = sigma_raw
     if rgb:
         rgb[0][:, 0] = 0.0   # keep the large density channel out of the colour network
     if shaped:
@@ -168,10 +173,14 @@ def make_params(desc, seed=SEED, sigma_raw=None, density_noise=0.25, shaped=Fals
         pts = np.stack([xx.ravel(), yy.ravel(), zz.ravel()], axis=1) * (mx - mn) + mn
         ind = scene_indicator(pts, aabb_scale)
         grid[2 * off: 2 * (off + res ** 3): 2] = ind
-        dw1[1, :] = 0.0
-        dw1[1, 2 * ls] = 1.0
-        dw2[0, 1] = shape_gain
-        dw2[0, 0] = sigma_raw - shape_gain
+        if linear_density:
+            dw1[0, 2 * ls] = shape_gain
+            dw1[0, 0] = sigma_raw - shape_gain
+        else:
+            dw1[1, :] = 0.0
+            dw1[1, 2 * ls] = 1.0
+            dw2[0, 1] = shape_gain
+            dw2[0, 0] = sigma_raw - shape_gain
     blob = np.concatenate([dw1.ravel(), dw2.ravel()] + [w.ravel() for w in rgb] + [grid]).astype(np.float16)
     assert blob.size == n
     return blob.view(np.uint16)

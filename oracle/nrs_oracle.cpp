@@ -581,7 +581,7 @@ struct LevelTable {
 // base_0layer.json), 1, 2 (base.json) or 3 hidden layers, and no rgb network / direction encoding at all (base_nodir.json -> NerfNetworkNoDir,
 // testbed.cu:2314-2353: nrs_model_desc::sh_degree == 0).  Table sizes: log2_hashmap_size 14 (base_14.json), 15 (small.json), 19, 21 (big.json), ...
 bool desc_supported(const nrs_model_desc& d) {
-	const bool trunk = d.n_levels == 16 && d.n_features_per_level == 2 && d.n_neurons == 64 && d.density_hidden_layers == 1 && d.density_output_dims == 16 &&
+	const bool trunk = d.n_levels == 16 && d.n_features_per_level == 2 && d.n_neurons == 64 && d.density_hidden_layers <= 1 && d.density_output_dims == 16 &&
 	                   d.log2_hashmap_size >= 8 && d.log2_hashmap_size <= 24 && d.base_resolution >= 1;
 	if (!trunk) return false;
 	if (d.sh_degree == 0) return d.rgb_hidden_layers == 0; // NerfNetworkNoDir
@@ -617,6 +617,8 @@ constexpr uint32_t N_DENSITY_W = 64 * 32 + 16 * 64;           // 3072
 // rgb network parameters (tiny-cuda-nn's layouts as recalled): FullyFusedMLP with L >= 1 hidden layers = [64 x 32] + (L - 1) [64 x 64] + [16 x 64] (the 3
 // outputs padded to 16 rows); CutlassMLP with no hidden layer = one [8 x 32] matrix (outputs padded to the tensor-core width 8); NerfNetworkNoDir: none.
 // base.json (L = 2): 7168.
+// density network: FullyFusedMLP [64 x 32] + [16 x 64], or -- without hidden layer (configs/nerf/linear.json, CutlassMLP) -- one [16 x 32] matrix
+inline uint32_t n_density_weights(const nrs_model_desc& d) { return d.density_hidden_layers == 0 ? 16u * 32u : N_DENSITY_W; }
 inline uint32_t n_rgb_weights(const nrs_model_desc& d) {
 	if (d.sh_degree == 0) return 0u;
 	if (d.rgb_hidden_layers == 0) return 8u * 32u;
@@ -656,7 +658,8 @@ struct Model {
 	std::vector<float> wf;        // MLP weights converted to float once
 	std::vector<uint8_t> bitfield;
 	bool no_dir() const { return desc.sh_degree == 0; }
-	uint32_t n_mlp_w() const { return N_DENSITY_W + n_rgb_weights(desc); }
+	uint32_t n_density_w() const { return n_density_weights(desc); }
+	uint32_t n_mlp_w() const { return n_density_w() + n_rgb_weights(desc); }
 	const uint16_t* grid() const { return params.data() + n_mlp_w(); }
 };
 
@@ -759,6 +762,7 @@ inline void dense_layer(const float* W, uint32_t n_out, uint32_t n_in, const uin
 
 // density MLP 32->64->16 (base.json:30-36).  feat: 32 fp16.  out: 16 fp16.
 void density_mlp_one(const Model& m, const uint16_t feat[32], uint16_t out[16]) {
+	if (m.desc.density_hidden_layers == 0) { dense_layer(m.wf.data(), 16, 32, feat, out, false, m.mlp_acc); return; } // linear.json: one matrix
 	const float* W1 = m.wf.data();
 	const float* W2 = W1 + 64 * 32;
 	uint16_t h[64];
@@ -768,7 +772,7 @@ void density_mlp_one(const Model& m, const uint16_t feat[32], uint16_t out[16]) 
 // rgb MLP 32->64->64->16 (base.json:52-58); input = [density out 16 | SH 16] (nerf_network_full.h:65-87).  L hidden layers (base_{1,2,3}layer.json), or none:
 // one linear map (base_0layer.json's CutlassMLP: 8 padded output rows; the other 8 of `out` are zero).  hidden_out, if given, receives hidden layer `want` (0-based).
 void rgb_mlp_one(const Model& m, const uint16_t in32[32], uint16_t out[16], uint16_t* hidden_out = nullptr, uint32_t want = 0) {
-	const float* W = m.wf.data() + N_DENSITY_W;
+	const float* W = m.wf.data() + m.n_density_w();
 	const uint32_t L = m.desc.rgb_hidden_layers;
 	if (L == 0) {
 		dense_layer(W, 8, 32, in32, out, false, m.mlp_acc);
@@ -838,13 +842,17 @@ static void network_inference_fast(const Model& m, const float coord[7], uint16_
 		in32[2 * l + 1] = h2f_hw(f2h_hw(acc1));
 	}
 	const float* W = m.wf.data();
-	dense_layer_fast(W, 64, 32, in32, h1, true);
-	dense_layer_fast(W + 64 * 32, 16, 64, h1, dout, false);
+	if (m.desc.density_hidden_layers == 0) {
+		dense_layer_fast(W, 16, 32, in32, dout, false);
+	} else {
+		dense_layer_fast(W, 64, 32, in32, h1, true);
+		dense_layer_fast(W + 64 * 32, 16, 64, h1, dout, false);
+	}
 	uint16_t sh[16];
 	sh4_encode_one(coord + 4, sh);
 	float rin[32];
 	for (int i = 0; i < 16; ++i) { rin[i] = dout[i]; rin[16 + i] = h2f_hw(sh[i]); }
-	const float* R = W + N_DENSITY_W;
+	const float* R = W + m.n_density_w();
 	const uint32_t L = m.desc.rgb_hidden_layers;
 	for (int i = 0; i < 16; ++i) o[i] = 0.f;
 	if (m.no_dir()) { // NerfNetworkNoDir: (r, g, b) = density-network outputs 1..3
@@ -939,6 +947,12 @@ void hashgrid_input_gradient_one(const Model& m, const float pos[3], const uint1
 	for (int d = 0; d < 3; ++d) grad_out[d] = result[d] * (1.0f / 128.0f);
 }
 void density_input_gradient_one(const Model& m, const float coord[7], float grad_out[3]) {
+	if (m.desc.density_hidden_layers == 0) { // linear.json: dL_dfeatures = W^T (128 e_0) = fp16(W[0][i] * 128), one non-zero term
+		uint16_t dfeat[32];
+		for (uint32_t i = 0; i < 32; ++i) dfeat[i] = f2h(m.wf[i] * 128.0f);
+		hashgrid_input_gradient_one(m, coord, dfeat, grad_out);
+		return;
+	}
 	const float* W1 = m.wf.data();       // [64 x 32]
 	const float* W2 = W1 + 64 * 32;      // [16 x 64]
 	uint16_t feat[32], h[64];
@@ -964,10 +978,11 @@ void density_input_gradient_one(const Model& m, const float coord[7], float grad
 // and the density network's hidden layer (its num_forward_activations counts two more, which its own forward_activations cannot serve: refused).  0 = no such layer.
 uint32_t network_layer_width(const nrs_model_desc& d, uint32_t layer) {
 	if (layer == 0) return 32u;
-	if (layer == 1) return 64u;
+	const uint32_t nd = d.density_hidden_layers; // forward activations of the density network (none for linear.json's single matrix)
+	if (layer <= nd) return 64u;
 	if (d.sh_degree == 0) return 0u;
-	if (layer == 2) return 32u;
-	return layer - 3u < d.rgb_hidden_layers ? 64u : 0u;
+	if (layer == nd + 1u) return 32u;
+	return layer - nd - 2u < d.rgb_hidden_layers ? 64u : 0u;
 }
 float network_activation_one(const Model& m, const float coord[7], uint32_t layer, uint32_t dim) {
 	const float* Wd1 = m.wf.data();
@@ -975,9 +990,14 @@ float network_activation_one(const Model& m, const float coord[7], uint32_t laye
 	uint16_t feat[32], h[64], in32[32], h1[64];
 	hashgrid_encode_one(m, coord, feat);
 	if (layer == 0) return h2f(feat[dim]);
-	dense_layer(Wd1, 64, 32, feat, h, true, m.mlp_acc);
-	if (layer == 1) return h2f(h[dim]);
-	dense_layer(Wd2, 16, 64, h, in32, false, m.mlp_acc);
+	if (m.desc.density_hidden_layers == 0) {
+		density_mlp_one(m, feat, in32);
+		layer += 1; // (no density hidden layer: the reference's layer k >= 1 is layer k + 1 of the numbering below)
+	} else {
+		dense_layer(Wd1, 64, 32, feat, h, true, m.mlp_acc);
+		if (layer == 1) return h2f(h[dim]);
+		dense_layer(Wd2, 16, 64, h, in32, false, m.mlp_acc);
+	}
 	sh4_encode_one(coord + 4, in32 + 16);
 	if (layer == 2) return h2f(in32[dim]);
 	uint16_t out[16];
@@ -1917,7 +1937,7 @@ size_t orc_model_n_params(const nrs_model_desc* d) {
 	if (!desc_supported(*d)) return 0;
 	LevelTable lt;
 	make_level_table(*d, lt);
-	return (size_t)N_DENSITY_W + n_rgb_weights(*d) + (size_t)lt.total_entries * 2;
+	return (size_t)n_density_weights(*d) + n_rgb_weights(*d) + (size_t)lt.total_entries * 2;
 }
 int orc_model_level_table(const nrs_model_desc* d, float* scale, uint32_t* res, uint32_t* off, uint32_t* cnt, uint32_t* hashed) {
 	if (!desc_supported(*d)) return -1;

@@ -38,7 +38,8 @@ def test_snapshot_round_trip(built, tmp_path, aabb_scale, ext):
 
 
 @pytest.mark.parametrize("kw", [dict(rgb_hidden_layers=0), dict(rgb_hidden_layers=1), dict(rgb_hidden_layers=3), dict(no_dir=True), dict(log2_hashmap_size=15),
-                                dict(log2_hashmap_size=21)], ids=["base_0layer", "base_1layer", "base_3layer", "base_nodir", "small", "big"])
+                                dict(log2_hashmap_size=21), dict(rgb_hidden_layers=0, density_hidden_layers=0)],
+                         ids=["base_0layer", "base_1layer", "base_3layer", "base_nodir", "small", "big", "linear"])
 def test_snapshot_round_trip_of_the_family(built, tmp_path, kw):
     """configs/nerf/base.json's relatives: the rgb network's depth is read from the file, a file with neither dir_encoding nor rgb_network describes a
     NerfNetworkNoDir (testbed.cu:2314: sh_degree 0 in nrs_model_desc), and the parameter count follows."""

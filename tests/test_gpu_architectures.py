@@ -23,8 +23,9 @@ ARCHS = {
     "rgb0": dict(rgb_hidden_layers=0),
     "nodir": dict(no_dir=True),
     "small": dict(log2_hashmap_size=15),
+    "linear": dict(rgb_hidden_layers=0, density_hidden_layers=0),  # configs/nerf/linear.json: both networks a single matrix
 }
-N_LAYERS = {"rgb1": 4, "rgb3": 6, "rgb0": 3, "nodir": 2, "small": 5}  # forward_activations layers (nerf_network_full.h:519-521)
+N_LAYERS = {"rgb1": 4, "rgb3": 6, "rgb0": 3, "nodir": 2, "small": 5, "linear": 2}  # forward_activations layers (nerf_network_full.h:519-521)
 _rigs = {}
 
 
@@ -46,7 +47,7 @@ def test_parameter_counts(built):
     lib = _abi.load()
     grid19 = 12196240
     for kw, mlp in ((dict(), 3072 + 7168), (dict(rgb_hidden_layers=1), 3072 + 3072), (dict(rgb_hidden_layers=3), 3072 + 11264), (dict(rgb_hidden_layers=0), 3072 + 256),
-                    (dict(no_dir=True), 3072)):
+                    (dict(no_dir=True), 3072), (dict(rgb_hidden_layers=0, density_hidden_layers=0), 512 + 256)):
         d = synth.model_desc(1, **kw)
         assert lib.nrs_model_n_params(C.byref(d)) == mlp + grid19, kw
     d = synth.model_desc(1)
@@ -82,9 +83,9 @@ def test_inference_against_the_oracle(arch_rig, numerics):
         out2 = torch.zeros((16, n), dtype=torch.float16, device="cuda:0")
         rig.net.inference_mixed_precision(None, torch.from_numpy(c2).cuda(), out2)
         assert np.array_equal(out2.cpu().numpy().view(np.uint16), got.view(np.uint16))
-    if rig.arch in ("rgb0", "nodir"):
+    if rig.arch in ("rgb0", "nodir", "linear"):
         # channels the smaller network does not have are zero (rgb0: CutlassMLP pads its 3 outputs to 8; nodir: rgb + density only)
-        first_pad = 8 if rig.arch == "rgb0" else 4
+        first_pad = 4 if rig.arch == "nodir" else 8
         assert (got[first_pad:] == 0).all() and (ref.view(np.float16)[first_pad:] == 0).all()
 
 
@@ -153,13 +154,13 @@ def test_activation_layers_follow_the_architecture(arch_rig):
     cin = torch.from_numpy(c).cuda()
     n_layers = N_LAYERS[rig.arch]
     for layer in range(n_layers):
-        width = 32 if layer in (0, 2) else 64
+        width = 32 if layer in ((0, 1) if rig.arch == "linear" else (0, 2)) else 64  # (linear.json: layer 1 is the rgb network's input)
         for dim in (0, width // 2 + 3, width - 1):
             ref = rig.scene.oracle_model.network_activation(c, layer, dim)
             out = torch.zeros(n, dtype=torch.float32, device="cuda:0")
             rig.net.visualize_activation(None, layer, dim, cin, out)
             got = out.cpu().numpy()
-            if layer == 0 or (layer == 2 and dim >= 16):
+            if layer == 0 or (layer == (1 if rig.arch == "linear" else 2) and dim >= 16):
                 assert np.array_equal(got, ref), (layer, dim)
             else:
                 ulps = _half_ulp_distance(got.astype(np.float16).view(np.uint16), ref.astype(np.float16).view(np.uint16))

@@ -257,7 +257,8 @@ def test_network_oracle_against_numpy(scene):
     assert (got == rout).mean() > 0.95
 
 
-@pytest.mark.parametrize("kw", [dict(rgb_hidden_layers=1), dict(rgb_hidden_layers=3), dict(rgb_hidden_layers=0), dict(no_dir=True)], ids=["rgb1", "rgb3", "rgb0", "nodir"])
+@pytest.mark.parametrize("kw", [dict(rgb_hidden_layers=1), dict(rgb_hidden_layers=3), dict(rgb_hidden_layers=0), dict(no_dir=True), dict(rgb_hidden_layers=0, density_hidden_layers=0)],
+                         ids=["rgb1", "rgb3", "rgb0", "nodir", "linear"])
 def test_network_family_oracle_against_numpy(built, kw):
     """configs/nerf/base_{0,1,3}layer.json and base_nodir.json in the oracle against an independent numpy evaluation: the rgb network's L hidden layers (or its single
     matrix, or no rgb network: colour = density-network outputs 1..3, NerfNetworkNoDir::inference_mixed_precision_impl, nerf_network_nodir.h:47-91) and the
@@ -268,18 +269,26 @@ def test_network_family_oracle_against_numpy(built, kw):
     m = orc.Model(d, params, None)
     L, nodir = d.rgb_hidden_layers, d.sh_degree == 0
     n_rgb = 0 if nodir else (256 if L == 0 else 2048 + (L - 1) * 4096 + 1024)
+    linear = d.density_hidden_layers == 0
+    n_den = 512 if linear else 3072
     lt = synth.level_table(d)
-    assert params.size == 3072 + n_rgb + 2 * int(lt["count"].sum())
+    assert params.size == n_den + n_rgb + 2 * int(lt["count"].sum())
     rng = np.random.default_rng(2)
     n = 96
     c = rng.uniform(0, 1, size=(n, 7)).astype(np.float32)
     out = m.inference(c, 1).view(np.float16).astype(np.float64)
     feat = m.hashgrid_encode(c).view(np.float16).astype(np.float64)
-    w = params[:3072 + n_rgb].view(np.float16).astype(np.float64)
-    dw1, dw2 = w[:2048].reshape(64, 32), w[2048:3072].reshape(16, 64)
+    w = params[:n_den + n_rgb].view(np.float16).astype(np.float64)
     r16 = lambda x: x.astype(np.float32).astype(np.float16).astype(np.float64)
-    h = r16(np.maximum(feat @ dw1.T, 0))
-    dout = r16(h @ dw2.T)
+    if linear:  # configs/nerf/linear.json: density outputs = one [16 x 32] matrix on the features
+        dout = r16(feat @ w[:512].reshape(16, 32).T)
+        # its input gradient: dL/dfeatures = fp16(128 W[0]), then the grid's own derivative (checked against numpy below for the default network)
+        g = m.density_input_gradient(c)
+        assert np.isfinite(g).all() and np.abs(g).max() > 0
+    else:
+        dw1, dw2 = w[:2048].reshape(64, 32), w[2048:3072].reshape(16, 64)
+        h = r16(np.maximum(feat @ dw1.T, 0))
+        dout = r16(h @ dw2.T)
     assert (out[:, 3] == dout[:, 0]).all()
     if nodir:
         assert (out[:, :3] == dout[:, 1:4]).all() and (out[:, 4:] == 0).all()
@@ -287,9 +296,10 @@ def test_network_family_oracle_against_numpy(built, kw):
             m.network_activation(c, 2, 0)
         assert m.network_activation(c, 1, 63) is not None
         return
-    sh = np.stack([m.network_activation(c, 2, 16 + k) for k in range(16)], axis=1).astype(np.float64)  # the oracle's own SH (checked against numpy above)
+    li = 1 if linear else 2  # the rgb network's input in forward_activations' numbering
+    sh = np.stack([m.network_activation(c, li, 16 + k) for k in range(16)], axis=1).astype(np.float64)  # the oracle's own SH (checked against numpy above)
     rin = np.concatenate([dout, sh], axis=1)
-    r = w[3072:]
+    r = w[n_den:]
     hidden = []
     if L == 0:
         rout = np.zeros((n, 16))
@@ -306,10 +316,10 @@ def test_network_family_oracle_against_numpy(built, kw):
     rout[:, 3] = dout[:, 0]
     assert np.abs(out - rout).max() <= 2e-2 * max(1.0, np.abs(rout).max()) and (out == rout).mean() > 0.95
     for l, x in enumerate(hidden):  # forward_activations(3 + l)
-        got = m.network_activation(c, 3 + l, 17).astype(np.float64)
+        got = m.network_activation(c, li + 1 + l, 17).astype(np.float64)
         assert (got == x[:, 17]).mean() > 0.95 and np.abs(got - x[:, 17]).max() < 2e-2 * max(1.0, np.abs(x).max())
     with pytest.raises(ValueError):  # one past the last layer
-        m.network_activation(c, 3 + L, 0)
+        m.network_activation(c, li + 1 + L, 0)
 
 
 def test_pcg32_published_vector(built):
