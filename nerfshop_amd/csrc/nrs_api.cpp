@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -55,6 +56,7 @@ struct nrs_ctx {
 	bool counters_clean[kInFlight] = {};
 	DeviceEdit* d_edits = nullptr;          // [kInFlight + 1][kMaxEdits]; the last table belongs to the occupancy refresh
 	std::atomic<uint32_t> launch_serial{0};
+	std::mutex launch_mutex; // slot acquisition .. launch enqueued: two threads rendering on one ctx must not share a slot's counter block / parity
 	// A slot is reused every kInFlight launches, possibly from ANOTHER stream: the launch that used it last records slot_done, and a
 	// launch on a different stream makes its stream wait on that event before it clears the counters / re-sends the operator table
 	// (same-stream reuse is ordered by the stream itself).
@@ -150,7 +152,11 @@ static int check_march_params(const nrs_render_params& p, const char* who) {
 // more, which its own forward_activations cannot serve).  0 = no such layer.
 // The kernels number the layers of base.json's shape: 0 grid, 1 density hidden, 2 rgb input, 3.. rgb hidden.  A density network WITHOUT hidden layer
 // (configs/nerf/linear.json) has no layer 1 in the reference's numbering: its layer k >= 1 is the kernels' layer k + 1.
-static uint32_t kernel_layer(const nrs_model_desc& d, uint32_t layer) { return (d.density_hidden_layers == 0u && layer >= 1u) ? layer + 1u : layer; }
+// (A layer number beyond every network of the family -- e.g. 0xFFFFFFFF, which `layer + 1` would wrap to the hash grid -- maps to a layer nobody has: width 0.)
+static uint32_t kernel_layer(const nrs_model_desc& d, uint32_t layer) {
+	if (layer >= 8u) return 0xFFu;
+	return (d.density_hidden_layers == 0u && layer >= 1u) ? layer + 1u : layer;
+}
 static uint32_t network_layer_width(const nrs_model_desc& d, uint32_t layer) {
 	const uint32_t k = kernel_layer(d, layer);
 	if (k == 0u) return 32u;
@@ -1388,6 +1394,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	nrs_ctx* ctx = m->ctx;
 	HIP_TRY(hipSetDevice(ctx->device));
 	hipStream_t s = (hipStream_t)stream;
+	std::unique_lock<std::mutex> launch_lock(ctx->launch_mutex); // held until the launch is enqueued and the slot's book-keeping is written (released before the statistics' sync)
 	const uint32_t slot = ctx->launch_serial.fetch_add(1u) % (uint32_t)nrs_ctx::kInFlight;
 	if (ctx->slot_used[slot] && ctx->slot_stream[slot] != s) HIP_TRY(hipStreamWaitEvent(s, ctx->slot_done[slot], 0));
 	// The statistics / queue block of this launch.  A slot owns two: the render kernel's last workgroup zeroes the one it did NOT use, which the slot's next
@@ -1446,6 +1453,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		HIP_TRY(hipEventRecord(ctx->slot_done[slot], s));
 		ctx->slot_stream[slot] = s;
 		ctx->slot_used[slot] = true;
+		launch_lock.unlock();
 		if (h_stats) {
 			RenderCounters c;
 			HIP_TRY(hipMemcpyAsync(&c, d_counters_slot, sizeof(c), hipMemcpyDeviceToHost, s));
@@ -1562,6 +1570,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	HIP_TRY(hipEventRecord(ctx->slot_done[slot], s));
 	ctx->slot_stream[slot] = s;
 	ctx->slot_used[slot] = true;
+	launch_lock.unlock();
 	if (h_stats) {
 		RenderCounters c;
 		HIP_TRY(hipMemcpyAsync(&c, d_counters_slot, sizeof(c), hipMemcpyDeviceToHost, s));

@@ -12,6 +12,7 @@
 // zstr or tiny-cuda-nn is used.  The accessors hand out the arrays in the layout the rest of the C-ABI consumes.
 #include <zlib.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +30,17 @@
 using namespace nrs;
 
 namespace {
+
+// what the path does not render (another encoding, light directions, ...): nrs_snapshot_open answers NRS_ERR_UNSUPPORTED, not "corrupt file"
+struct Unsupported : std::runtime_error {
+	// (the message quotes strings of the file: printable ASCII only, bounded -- a fuzzed file must not put raw bytes into nrs_last_error())
+	static std::string clean(const std::string& m) {
+		std::string o;
+		for (char ch : m) { if (o.size() >= 400) break; o += (ch >= 32 && ch < 127) ? ch : '?'; }
+		return o;
+	}
+	explicit Unsupported(const std::string& m) : std::runtime_error(clean(m)) {}
+};
 
 // ---- value tree ------------------------------------------------------------------------------------------------------
 struct Value {
@@ -383,6 +395,46 @@ int nrs_snapshot_open(const char* path, nrs_snapshot** out) {
 		const Value* dir = root.find("dir_encoding");
 		const bool has_dir = rgb && dir; // testbed.cu:2314: otherwise NerfNetworkNoDir (configs/nerf/base_nodir.json): sh_degree = 0 in nrs_model_desc
 		nrs_model_desc& d = s->desc;
+		// What this path renders is configs/nerf/base.json's family: HashGrid positions, SH directions, ReLU networks without output activation.  Anything else
+		// tiny-cuda-nn can build (configs/nerf/{frequency,densegrid,tensor,none,...}.json; create_encoding / create_network compare otype case-insensitively) is REFUSED
+		// here rather than mis-rendered.
+		auto lower = [](std::string v) { for (char& ch : v) ch = (char)std::tolower((unsigned char)ch); return v; };
+		const std::string enc_type = lower(enc.string_or("otype", "HashGrid"));
+		if (enc_type != "hashgrid" && enc_type != "grid") throw Unsupported("encoding.otype \"" + enc.string_or("otype", "") + "\": only HashGrid is rendered by this path");
+		if (lower(enc.string_or("type", "Hash")) != "hash") throw Unsupported("encoding.type \"" + enc.string_or("type", "") + "\": only the hashed grid (type Hash) is rendered by this path");
+		if (lower(enc.string_or("interpolation", "Linear")) != "linear") throw Unsupported("encoding.interpolation \"" + enc.string_or("interpolation", "") + "\": only Linear is rendered by this path");
+		auto check_mlp = [&](const Value& n, const char* what) {
+			if (lower(n.string_or("activation", "ReLU")) != "relu") throw Unsupported(std::string(what) + ".activation \"" + n.string_or("activation", "") + "\": only ReLU");
+			if (lower(n.string_or("output_activation", "None")) != "none") throw Unsupported(std::string(what) + ".output_activation \"" + n.string_or("output_activation", "") + "\": only None");
+			const std::string t = lower(n.string_or("otype", "FullyFusedMLP"));
+			if (t != "fullyfusedmlp" && t != "cutlassmlp" && t != "megakernelmlp") throw Unsupported(std::string(what) + ".otype \"" + n.string_or("otype", "") + "\": not a plain MLP");
+		};
+		check_mlp(net, "network");
+		if (has_dir) {
+			check_mlp(*rgb, "rgb_network");
+			// configs/nerf/base.json:37-51: Composite[SphericalHarmonics on 3 dims; Identity on the rest] -- or SphericalHarmonics alone
+			const std::string dt = lower(dir->string_or("otype", "Composite"));
+			const Value* first = dir;
+			if (dt == "composite") {
+				const Value* nested = dir->find("nested");
+				if (!nested || nested->kind != Value::Arr || nested->a.empty()) throw Unsupported("dir_encoding: Composite without nested encodings");
+				first = &nested->a[0];
+				for (size_t k = 1; k < nested->a.size(); ++k)
+					if (lower(nested->a[k].string_or("otype", "Identity")) != "identity") throw Unsupported("dir_encoding.nested[" + std::to_string(k) + "]: only Identity may follow the spherical harmonics");
+				if ((uint32_t)first->number_or("n_dims_to_encode", 3) != 3u) throw Unsupported("dir_encoding.nested[0].n_dims_to_encode must be 3");
+			} else if (dt != "sphericalharmonics") throw Unsupported("dir_encoding.otype \"" + dir->string_or("otype", "") + "\": only SphericalHarmonics (alone or first in a Composite)");
+			if (lower(first->string_or("otype", "SphericalHarmonics")) != "sphericalharmonics") throw Unsupported("dir_encoding: the view direction must be encoded by SphericalHarmonics");
+		}
+		// Light directions (NerfCoordinate::set_with_optional_light_dir, nerf.h:73-93; n_extra_dims = 3 when dataset.has_light_dirs, testbed.cu:2318): three more network
+		// inputs per sample that this path does not carry.  Neither save_snapshot nor the dataset's to_json stores the flag (json_binding.h:136-160), so it is
+		// recognised by the keys a writer MAY add and -- below -- by the size of the parameter blob, which such a network cannot hide.
+		{
+			const Value* nerf_v = snap->find("nerf");
+			const Value* ds = nerf_v ? nerf_v->find("dataset") : nullptr;
+			auto truthy = [](const Value* v) { return v && ((v->kind == Value::Bool && v->b) || (v->is_number() && v->number() != 0.0)); };
+			if ((ds && (truthy(ds->find("has_light_dirs")) || truthy(ds->find("n_extra_dims")))) || (nerf_v && truthy(nerf_v->find("n_extra_dims"))) || truthy(root.find("n_extra_dims")))
+				throw Unsupported("the snapshot was trained with light directions (has_light_dirs / n_extra_dims = 3): this path renders position + view direction only");
+		}
 		// every hyper-parameter is validated BEFORE it is used in arithmetic (a crafted file must be refused, not divide by zero or shift by 200)
 		auto bounded = [](double v, double lo, double hi, const char* what) -> uint32_t {
 			if (!(v >= lo && v <= hi) || v != std::floor(v)) throw std::runtime_error(std::string("snapshot: ") + what + " out of range");
@@ -420,7 +472,12 @@ int nrs_snapshot_open(const char* path, nrs_snapshot** out) {
 		if (pb.kind != Value::Bin) throw std::runtime_error("params_binary is not binary");
 		const std::string ptype = snap->string_or("params_type", "__half");
 		const size_t n_expected = nrs_model_n_params(&d);
-		if (n_expected == 0) throw std::runtime_error("network architecture outside configs/nerf/base.json's family (hash grid 16 x 2, 64-wide density network with one hidden layer, rgb network of 0..3 hidden layers on SH degree 4 or none)");
+		if (n_expected == 0) throw Unsupported("network architecture outside configs/nerf/base.json's family (hash grid 16 x 2, 64-wide density network with one hidden layer, rgb network of 0..3 hidden layers on SH degree 4 or none)");
+		{ // a network with 3 extra input dimensions: the direction encoding grows from 16 to 16 + 3 -> padded to 32, i.e. the rgb network's first matrix from [64 x 32] to [64 x 48]
+			const size_t n_light = n_expected + (size_t)d.n_neurons * 16u, bytes = ptype == "float" ? 4u : 2u;
+			if (has_dir && d.rgb_hidden_layers > 0 && pb.s.size() == n_light * bytes)
+				throw Unsupported("params_binary has the size of this architecture WITH 3 extra input dimensions (light directions, n_extra_dims = 3): not rendered by this path");
+		}
 		if (ptype == "float") {
 			if (pb.s.size() != n_expected * 4) throw std::runtime_error("params_binary has the wrong size for this architecture");
 			s->params.resize(n_expected);
@@ -452,6 +509,8 @@ int nrs_snapshot_open(const char* path, nrs_snapshot** out) {
 				}
 		*out = s.release();
 		return NRS_OK;
+	} catch (const Unsupported& e) {
+		return fmt_fail(NRS_ERR_UNSUPPORTED, std::string("nrs_snapshot_open('") + path + "'): unsupported: " + e.what());
 	} catch (const std::exception& e) {
 		return fmt_fail(NRS_ERR_INVALID_ARG, std::string("nrs_snapshot_open('") + path + "'): " + e.what());
 	}

@@ -185,7 +185,7 @@ constexpr uint32_t kBrick = 8, kBrickCells = kBrick * kBrick * kBrick; // sparse
 #define NRS_BRICK_MORTON 0
 #endif
 // position of cell (x, y, z) (each 0..7) among its brick's records -- shared by the kernel that writes the records and the gather that reads them
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline uint32_t brick_slot(uint32_t x, uint32_t y, uint32_t z) {

@@ -97,6 +97,25 @@ def test_snapshot_float_params_and_errors(built, tmp_path):
     expect(lambda c: c["snapshot"].__setitem__("params_binary", b"123"), "wrong size")
     expect(lambda c: c["snapshot"]["nerf"].__setitem__("aabb_scale", 3), "power of two")
     expect(lambda c: c["encoding"].__setitem__("n_levels", 8), "architecture")
+    # what the path does not render is REFUSED with NRS_ERR_UNSUPPORTED (-2), never mis-rendered: other encodings (configs/nerf/{frequency,densegrid,...}.json),
+    # other activations, light directions (dataset.has_light_dirs -> n_extra_dims = 3, testbed.cu:2318, nerf.h:73-93) -- by flag and by the parameter blob's size
+    expect(lambda c: c["encoding"].__setitem__("otype", "Frequency"), "nrs error -2")
+    expect(lambda c: c["encoding"].__setitem__("otype", "DenseGrid"), "only HashGrid")
+    expect(lambda c: c["encoding"].__setitem__("type", "Tiled"), "nrs error -2")
+    expect(lambda c: c["encoding"].__setitem__("interpolation", "Smoothstep"), "nrs error -2")
+    expect(lambda c: c["network"].__setitem__("activation", "Sine"), "nrs error -2")
+    expect(lambda c: c["rgb_network"].__setitem__("output_activation", "Sigmoid"), "nrs error -2")
+    expect(lambda c: c["dir_encoding"].__setitem__("otype", "Frequency"), "nrs error -2")
+    expect(lambda c: c["dir_encoding"].__setitem__("nested", [{"otype": "OneBlob", "n_dims_to_encode": 3}]), "SphericalHarmonics")
+    expect(lambda c: c["snapshot"]["nerf"].__setitem__("dataset", {"aabb_scale": 1, "has_light_dirs": True}), "light directions")
+    expect(lambda c: c["snapshot"]["nerf"].__setitem__("n_extra_dims", 3), "light directions")
+    expect(lambda c: c["snapshot"].__setitem__("params_binary", np.zeros(n + 64 * 16, np.float32).tobytes()), "3 extra input dimensions")
+    # (otype is compared case-insensitively, as tiny-cuda-nn's create_encoding does)
+    c_ok = {k: (dict(v) if isinstance(v, dict) else v) for k, v in cfg.items()}
+    c_ok["encoding"]["otype"] = "hashgrid"
+    ok = tmp_path / "lower.msgpack"
+    ok.write_bytes(msgpack.packb(c_ok, use_bin_type=True))
+    assert np.array_equal(formats.load_snapshot(ok).params, s.params)
     trunc = tmp_path / "trunc.msgpack"
     trunc.write_bytes(p.read_bytes()[:1000])
     with pytest.raises(_abi.NrsError):

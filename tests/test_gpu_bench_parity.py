@@ -104,3 +104,38 @@ def test_tcnn_numerics_1080p_against_the_oracle(built):
     bs.tb.nerf_network.set_numerics(0, 0)
     frame_def = bs.render(bs.params(0, 480, 270))[0]
     assert not np.array_equal(frame_num, frame_def) and np.abs(frame_num - frame_def).max() < 0.1
+
+
+def test_membrane_bench_scene_1080p_against_the_oracle(built):
+    """`lego_cage_membrane` exactly as bench.py times it: bench.build_scene's edit with the membrane correction (amplitude 0.8), `poisson_target = 1`
+    (NerfTracer::m_poisson_target, testbed.h:219), bench view 0 at 1920x1080 on the automatic schedule -- the POISSON instantiation -- against the oracle's
+    compute_residual_poisson_kernel (cage_deformation.cu:431-541) + the consumer in composite_kernel_nerf (tn:770-780)."""
+    bs = BenchScene("lego_cage_membrane")
+    assert bs.sc["edit"].tet_mesh_struct().apply_poisson
+    p = bs.params(0)
+    p.poisson_target = 1
+    check_against_oracle(bs, p, bs.edits, 10_000_000)
+    # the correction shows: the same view through the bench's plain cage edit differs
+    plain = BenchScene("lego_cage")
+    f_plain = plain.render(plain.params(0, 480, 270))[0]
+    pm = bs.params(0, 480, 270)
+    pm.poisson_target = 1
+    assert np.abs(bs.render(pm)[0] - f_plain).max() > 0.02
+
+
+def test_base_3layer_bench_scene_1080p_against_the_oracle(built):
+    """`lego_cage_base_3layer` (configs/nerf/base_3layer.json: three hidden rgb layers) as bench.py times it: the DEEP instantiation of the automatic schedule,
+    bench view 0 at 1920x1080, against the oracle evaluating the three-hidden-layer network natively."""
+    bs = BenchScene("lego_cage_base_3layer")
+    assert bs.sc["desc"].rgb_hidden_layers == 3
+    check_against_oracle(bs, bs.params(0), bs.edits, 10_000_000)
+
+
+def test_garden_bench_scene_1080p_against_the_oracle(built):
+    """`garden_cage` (BASELINE configs[3]) exactly as bench.build_scene makes it: aabb_scale 16, cone stepping, cage lattice 10 at scene scale 6, the dense cell records
+    of levels 0..7 AND the sparse brick records from the `edited | unedited` occupancy mask under the bench's own byte budget (NRS_SPARSE_GB, 64 GiB by default) --
+    bench view 0 at 1920x1080 against the oracle (depth bar scaled to the scene's extent as in tests/test_gpu_numerics.py)."""
+    bs = BenchScene("garden_cage")
+    nbytes, first, count = bs.tb.nerf_network.sparse_cell_cache()
+    assert count > 0 and nbytes > (1 << 30), (nbytes, first, count)  # the brick records are really installed: this is the path the bench line times
+    check_against_oracle(bs, bs.params(0), bs.edits, 20_000_000, depth_scale=16.0)
