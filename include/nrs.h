@@ -501,7 +501,9 @@ int          nrs_snapshot_camera(const nrs_snapshot* snapshot, float* camera_mat
  * "proxy_cage": Cage (cage.h:100-145), "interpolation_mesh": TetMesh (tet_mesh.h:136-174), ...}]}.
  * nrs_edits_cage fills an nrs_tet_mesh for DEVICE authoring (vertices, original vertices, tets; LUT / bitfield /
  * rotations left NULL so nrs_edit_create builds them, as the reference's JSON constructor rebuilds the tet grid,
- * growing_selection.cu:112-115) and hands out the MVC weights and the proxy cage.  Pointers live as long as `edits`. */
+ * growing_selection.cu:112-115) and hands out the MVC weights and the proxy cage.  Pointers live as long as `edits`.
+ * An operator saved before its cage was tetrahedralised has no interpolation mesh (growing_selection.cu:2477): mesh_out->n_tets == 0, the cage is still returned.
+ * Empty lists may appear as `null` in the file (the reference's vector writers leave an empty vector's value untouched, json_binding.h:231-321): read as empty. */
 typedef struct nrs_edits nrs_edits;
 int          nrs_edits_open(const char* path, nrs_edits** out);
 void         nrs_edits_close(nrs_edits* edits);

@@ -326,7 +326,10 @@ inline uint16_t float_to_half(float f) { // round to nearest even
 int fmt_fail(int code, const std::string& msg) { set_last_error(msg.c_str()); return code; }
 
 // Eigen::Vector3f list -> flat floats (json_binding.h:231-248)
+// (The reference's vector writers -- json_binding.h:231-321: `for (e : vec) j.push_back(e)` -- leave the json value untouched, i.e. `null`, for an EMPTY vector, and
+// its readers loop `row < j.size()`, 0 for null: null reads as an empty list here too.)
 void read_vec3_list(const Value& v, std::vector<float>& out, const char* what) {
+	if (v.kind == Value::Null) return;
 	if (v.kind != Value::Arr) throw std::runtime_error(std::string(what) + ": expected an array");
 	out.reserve(v.a.size() * 3);
 	for (const Value& row : v.a) {
@@ -335,6 +338,7 @@ void read_vec3_list(const Value& v, std::vector<float>& out, const char* what) {
 	}
 }
 void read_u32_list(const Value& v, std::vector<uint32_t>& out, const char* what) {
+	if (v.kind == Value::Null) return;
 	if (v.kind != Value::Arr) throw std::runtime_error(std::string(what) + ": expected an array");
 	out.reserve(v.a.size());
 	for (const Value& c : v.a) {
@@ -570,7 +574,7 @@ int nrs_edits_open(const char* path, nrs_edits** out) {
 					for (uint32_t i : c.tets)
 						if (i >= nv) throw std::runtime_error("interpolation_mesh.tets out of range");
 					const Value& mvc = mesh->at("mvc_coordinates");            // std::vector<std::vector<float>>, one row per tet vertex
-					if (mvc.kind != Value::Arr) throw std::runtime_error("interpolation_mesh.mvc_coordinates is not an array");
+					if (mvc.kind != Value::Arr && mvc.kind != Value::Null) throw std::runtime_error("interpolation_mesh.mvc_coordinates is not an array");
 					if (!mvc.a.empty()) {
 						if (mvc.a.size() != nv) throw std::runtime_error("interpolation_mesh.mvc_coordinates: one row per vertex expected");
 						c.mvc.reserve((size_t)nv * c.n_cage_vertices);
@@ -627,13 +631,14 @@ int nrs_edits_cage(const nrs_edits* e, uint32_t i, nrs_tet_mesh* mesh_out, const
 	if (!e || i >= e->ops.size() || !mesh_out) return fmt_fail(NRS_ERR_INVALID_ARG, "nrs_edits_cage: bad argument");
 	const CageOperator& c = e->ops[i];
 	if (c.type != "cage_deformation") return fmt_fail(NRS_ERR_UNSUPPORTED, "nrs_edits_cage: operator " + std::to_string(i) + " is '" + c.type + "'");
-	if (c.tets.empty()) return fmt_fail(NRS_ERR_STATE, "nrs_edits_cage: the operator has no interpolation_mesh (cage not yet tetrahedralised)");
+	// (an operator saved before its cage was tetrahedralised has no "interpolation_mesh" key, growing_selection.cu:2477: mesh_out then says n_vertices = n_tets = 0
+	// with NULL arrays, and the proxy cage is handed out all the same)
 	memset(mesh_out, 0, sizeof(*mesh_out));
 	mesh_out->n_vertices = (uint32_t)(c.vertices.size() / 3);
 	mesh_out->n_tets = (uint32_t)(c.tets.size() / 4);
-	mesh_out->h_vertices = c.vertices.data();
-	mesh_out->h_original_vertices = c.original_vertices.data();
-	mesh_out->h_tets = c.tets.data();
+	mesh_out->h_vertices = c.vertices.empty() ? nullptr : c.vertices.data();
+	mesh_out->h_original_vertices = c.original_vertices.empty() ? nullptr : c.original_vertices.data();
+	mesh_out->h_tets = c.tets.empty() ? nullptr : c.tets.data();
 	mesh_out->residual_amplitude = 1.0f;
 	mesh_out->correct_direction = 1; // GrowingSelection::m_correct_direction defaults to true (growing_selection.h)
 	if (h_mvc_weights_out) *h_mvc_weights_out = c.mvc.empty() ? nullptr : c.mvc.data();

@@ -132,7 +132,7 @@ def save_edits(path, cage_edits):
                 "gamma_coordinates": [], "tets": [int(i) for i in e.tets.reshape(-1)], "labels": [0] * V, "colors": [], "all_indices": []}
         ops.append({"type": "cage_deformation", "projected_pixels": [], "projected_labels": [], "projected_cell_idx": [], "selection_points": [],
                     "selection_labels": [], "selection_cell_idx": [], "m_selection_grid_bitfield": [], "growing_level": 0, "region_growing": {},
-                    "selection_mesh": {"vertices": [], "indices": []}, "proxy_cage": cage, "interpolation_mesh": mesh})
+                    "selection_mesh": {"vertices": [], "indices": [], "normals": []}, "proxy_cage": cage, "interpolation_mesh": mesh})
     with open(str(path), "w") as f:
         json.dump({"edit_operators": ops}, f)
         f.write("\n")
@@ -181,10 +181,10 @@ def load_edits(path):
 
             c = LoadedCage()
             V, T = mesh.n_vertices, mesh.n_tets
-            c.vertices = f32(mesh.h_vertices, 3 * V).reshape(V, 3)
-            c.original_vertices = f32(mesh.h_original_vertices, 3 * V).reshape(V, 3)
-            c.tets = u32(mesh.h_tets, 4 * T).reshape(T, 4)
-            c.mvc_weights = f32(mvc.value, V * ncv.value).reshape(V, ncv.value) if mvc.value else None
+            c.vertices = f32(mesh.h_vertices, 3 * V).reshape(V, 3) if V else np.zeros((0, 3), np.float32)
+            c.original_vertices = f32(mesh.h_original_vertices, 3 * V).reshape(V, 3) if V else np.zeros((0, 3), np.float32)
+            c.tets = u32(mesh.h_tets, 4 * T).reshape(T, 4) if T else np.zeros((0, 4), np.uint32)
+            c.mvc_weights = f32(mvc.value, V * ncv.value).reshape(V, ncv.value) if (mvc.value and V) else None
             c.cage_deformed = f32(cv.value, 3 * ncv.value).reshape(-1, 3)
             c.cage_vertices = f32(cov.value, 3 * ncv.value).reshape(-1, 3)
             c.cage_triangles = u32(ct.value, 3 * nct.value).reshape(-1, 3)

@@ -77,6 +77,12 @@ FRAGMENTS = [
     # pass (canonical mesh, sets original_bitfield): the bodies of the two std::async lambdas
     ("src/editing/datastructures/tet_mesh.cu", "build_tet_grid_mark_deformed", r"^\t\t\tfor \(int i = beginn; i < endingg; i\+\+\) \{", "block:build_tet_grid:0"),
     ("src/editing/datastructures/tet_mesh.cu", "build_tet_grid_mark_canonical", r"^\t\t\tfor \(int i = beginn; i < endingg; i\+\+\) \{", "block:build_tet_grid:1"),
+    # oracle/ref_json.cpp: the to_json members of the edit operators and Testbed::save_edits (the on-disk edits format)
+    ("src/editing/tools/region_growing.cu", "region_growing_to_json", r"^nlohmann::json RegionGrowing::to_json\(\) \{", r"until:^\s+\}\s*$"),
+    ("src/editing/tools/growing_selection.cu", "growing_selection_to_json", r"^void GrowingSelection::to_json\(nlohmann::json& j\) \{", "fn"),
+    ("src/editing/cage_deformation.cu", "cage_deformation_to_json", r"^nlohmann::json CageDeformation::to_json\(\) \{", "fn"),
+    ("src/editing/affine_duplication.cu", "affine_duplication_to_json", r"^nlohmann::json AffineDuplication::to_json\(\) \{", "fn"),
+    ("src/testbed.cu", "testbed_save_edits", r"^void Testbed::save_edits\(const std::string& filepath_string\) \{", "fn"),
 ]
 
 

@@ -198,3 +198,86 @@ def test_accumulate_golden(golden):
 @live
 def test_accumulate_live():
     _check_live(cases.accumulate_cases("ref"), cases.accumulate_cases("orc"))
+
+
+# ---- on-disk edits format: nrs_edits_open against files written by the REFERENCE's own writer ---------------------------------
+# oracle/_ref/libref_json.so = Testbed::save_edits + the to_json / from_json it reaches, compiled from /root/reference (oracle/ref_json.cpp).
+# Golden: tests/golden/ref_edits_golden.json.gz (+ .npz: the arrays that went into the reference's writer), tests/golden/make_ref_edits_golden.py.
+def _check_edits_against(ops, a):
+    from nerfshop_amd import _abi
+    assert len(ops) == 4
+    c0, ad, c2, c3 = ops
+    for c, k in ((c0, "op0"), (c2, "op2")):
+        for got, name in ((c.vertices, "vertices"), (c.original_vertices, "original_vertices"), (c.tets, "tets"), (c.cage_deformed, "cage_vertices"),
+                          (c.cage_vertices, "cage_original_vertices"), (c.cage_triangles, "cage_triangles")):
+            want = a[f"{k}/{name}"]
+            assert got.dtype == want.dtype and np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{k}/{name}"  # bit for bit (-0, denormals, FLT_MAX included)
+    assert np.array_equal(c0.mvc_weights.view(np.uint32), a["op0/mvc"].view(np.uint32))
+    assert c2.mvc_weights is None  # an empty mvc_coordinates vector: the reference writes null
+    assert isinstance(ad, _abi.AffineDuplicationOp)
+    for name in ("selection_center", "selection_scale", "selection_rot", "translation", "scale", "rotation"):
+        assert np.array_equal(np.array(list(getattr(ad, name)), np.float32).view(np.uint32), a["op1/" + name].reshape(-1).view(np.uint32)), name
+    assert int(ad.hide_original) == 1 and int(ad.correct_dir) == 0
+    # an operator without interpolation mesh: the proxy cage is there, the mesh is empty
+    assert c3.tets.shape == (0, 4) and c3.vertices.shape == (0, 3)
+    assert np.array_equal(c3.cage_deformed, a["op3/cage_vertices"]) and np.array_equal(c3.cage_vertices, a["op3/cage_original_vertices"]) and np.array_equal(c3.cage_triangles, a["op3/cage_triangles"])
+
+
+def test_edits_reader_golden(built, tmp_path):
+    """nrs_edits_open on a file written by the reference's Testbed::save_edits returns the arrays that went into the writer, bit for bit."""
+    import gzip
+    from nerfshop_amd import formats
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    path = tmp_path / "ref_edits.json"
+    path.write_bytes(gzip.open(os.path.join(gdir, "ref_edits_golden.json.gz"), "rb").read())
+    text = path.read_text()
+    # what makes this file the reference's and not the harness's: untouched values are null, keys are sorted, the selection bookkeeping is all there
+    assert '"all_indices":null' in text and '"mvc_coordinates":null' in text and '"region_growing":{"density_grid_host":[]' in text and text.endswith("\n")
+    _check_edits_against(formats.load_edits(path), np.load(os.path.join(gdir, "ref_edits_golden.npz")))
+
+
+ref_json_live = pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref", "libref_json.so")),
+                                   reason="oracle/_ref/libref_json.so needs /root/reference (build: make -C oracle)")
+
+
+@ref_json_live
+def test_edits_reader_live(built, tmp_path):
+    """The same with the file written NOW by the reference's code, and the committed golden file is what that code writes today (byte for byte)."""
+    import gzip
+    import importlib.util
+    from nerfshop_amd import formats
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_ref_edits_golden", os.path.join(gdir, "make_ref_edits_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    a = mk.inputs()
+    path = tmp_path / "live.json"
+    mk.write_with_reference(str(path), a)
+    _check_edits_against(formats.load_edits(path), a)
+    assert path.read_bytes() == gzip.open(os.path.join(gdir, "ref_edits_golden.json.gz"), "rb").read()
+    g = np.load(os.path.join(gdir, "ref_edits_golden.npz"))
+    assert sorted(g.files) == sorted(a) and all(np.array_equal(g[k], a[k]) for k in a)
+
+
+@ref_json_live
+def test_harness_writer_is_read_by_the_reference_live(scene, tmp_path):
+    """The other direction: a file of the harness's own writer (nerfshop_amd/formats.py, which the round-trip tests and the synthetic scenes use) goes through the
+    REFERENCE's readers -- Testbed::load_edits' dispatch, from_json of Cage / TetMesh / Mesh / AffineBoundingBox (every `at(key)` they demand must be there) -- and what
+    they loaded, written back by the reference's writers, is read by nrs_edits_open as the same arrays."""
+    from nerfshop_amd import _abi, formats
+    from oracle import ref_json
+    ad = _abi.AffineDuplicationOp()
+    ad.selection_center, ad.selection_scale = (C3 := type(ad.selection_center))(0.5, 0.5, 0.5), C3(0.1, 0.2, 0.3)
+    ad.selection_rot = type(ad.selection_rot)(1, 0, 0, 0, 1, 0, 0, 0, 1)
+    ad.translation, ad.scale = C3(0.25, 0.0, -0.125), C3(1, 1, 1)
+    ad.rotation = type(ad.rotation)(0, 1, 0, -1, 0, 0, 0, 0, 1)
+    ad.hide_original, ad.correct_dir = 0, 1
+    mine = tmp_path / "mine.json"
+    formats.save_edits(mine, [scene.edit, ad])
+    back = tmp_path / "through_the_reference.json"
+    assert ref_json.reload_edits(mine, back) == 2
+    a, b = formats.load_edits(mine), formats.load_edits(back)
+    for name in ("vertices", "original_vertices", "tets", "mvc_weights", "cage_deformed", "cage_vertices", "cage_triangles"):
+        x, y = getattr(a[0], name), getattr(b[0], name)
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)) and np.array_equal(x, getattr(scene.edit, name)), name
+    assert bytes(a[1]) == bytes(b[1]) == bytes(ad)
