@@ -27,9 +27,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 BYTES_PER_SAMPLE = 512          # 16 levels x 8 corners x (2 x fp16): SURVEY 8(d)
-FLOP_PER_SAMPLE = 20480         # density MLP 6144 + rgb MLP 14336
+FLOP_PER_SAMPLE = 20480         # density MLP 6144 + rgb MLP 14336 (configs/nerf/base.json; flop_per_sample() for the other members of the family)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 TILE = int(os.environ.get("NRS_BENCH_TILE", "32"))  # image tiles dealt round-robin to the ranks (multiple of 8): 32 halves the load imbalance of 64 (profiles/r03_scaling.md)
+
+
+def flop_per_sample(desc):
+    """2 x the multiply-adds of the two MLPs of `desc` (20 480 for base.json)."""
+    density = 2 * (32 * 64 + 64 * 16) if desc.density_hidden_layers else 2 * (32 * 16)
+    L = int(desc.rgb_hidden_layers)
+    if not desc.sh_degree:
+        return density
+    rgb = 2 * (32 * 64 + (L - 1) * 64 * 64 + 64 * 16) if L >= 1 else 2 * (32 * 8)
+    return density + rgb
 
 
 def build_scene(workload, rt, synth, ctx, torch):
@@ -123,7 +133,10 @@ def cpu_baseline(synth, scene=None):
         wl_model, edits, what = model, [], "the lego-like scene, no edits"
     pbig = synth.render_params(960, 540, camera_for(0, synth, 1), aabb_scale=1, apply_operators=bool(edits))
     tbig, sbig = best_of(wl_model, pbig, 3, edits=edits)
+    # `value` = the bounded sample of the N = 1 workload, as the bench contract defines it; BASELINE config #1 (the 256 x 256 CPU frame the reference's config list names) sits
+    # next to it at the top level (`config1_value`, `config1_ms_per_frame_256`: VERDICT r4 #9) and in full under `config1`
     return {"value": round(sbig / tbig / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "config1_value": round(s256 / t256 / 1e6, 3), "config1_ms_per_frame_256": round(t256 * 1e3, 1),
             "note": "oracle/ restatement in its CPU-baseline flavour (F16C conversions, fp32-accumulated MLP sums, OpenMP over rays); the reference has no CPU path",
             "sample": f"bounded sample of the N = 1 workload: {what}, bench view 0 at 960x540 (a quarter of the pixels), best of 3: {sbig} samples in {tbig * 1e3:.0f} ms ({1.0 / tbig:.2f} FPS)",
             "config1": {"sample": f"BASELINE config #1: one 256x256 frame, no edits, best of 5: {s256} samples in {t256 * 1e3:.0f} ms ({1.0 / t256:.2f} FPS)",
@@ -204,6 +217,39 @@ def live_traffic(workload, width, height):
                      f"mean of its {n_disp} render_kernel dispatches; 2 x FETCH_SIZE ({kb['FETCH_SIZE']:.0f} KB) + WRITE_SIZE ({kb['WRITE_SIZE']:.0f} KB), gfx950 correction of MI355X_MICROARCH.md")
 
 
+def time_gather(torch, dist, ctx, sharder, stream, p, frame, depth, reps, world, stats_dev):
+    """The frame's exchange step alone (VERDICT r4 next #4c): `reps` x nrs_gather_tiles (ncclSend / ncclRecv of every rank's tile block to rank 0 + de-tile there) on
+    `stream`, each bracketed by HIP events recorded on that stream; plus the wall clock of the `reps` calls back to back between barriers.  Every rank takes part.
+    Returns {"ms_event_mean", "ms_event_min", "ms_event_max_rank_mean", "ms_wall_per_gather", "bytes_to_root", "impl"} (rank 0's events; the slowest rank's mean)."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            sharder.gather(ctx, p, frame, depth)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for a, b in ev:
+            a.record(stream)
+            sharder.gather(ctx, p, frame, depth)
+            b.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    ms = [a.elapsed_time(b) for a, b in ev]
+    mine = torch.tensor([sum(ms) / len(ms), wall], dtype=torch.float64, device=stats_dev)
+    if world > 1:
+        dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+    n_px = sharder.padded * sharder.tile * sharder.tile
+    return {"ms_event_mean": round(sum(ms) / len(ms), 4), "ms_event_min": round(min(ms), 4), "ms_event_max_rank_mean": round(float(mine[0]), 4),
+            "ms_wall_per_gather": round(float(mine[1]), 4), "reps": reps, "bytes_to_root": int((world - 1) * n_px * 5 * 4),
+            "payload_gbs_at_event_mean": round((world - 1) * n_px * 20 / (sum(ms) / len(ms) * 1e-3) / 1e9, 1) if world > 1 else None,
+            "impl": sharder.gather_impl, "note": "rank 0's HIP events around nrs_gather_tiles on the frame's stream (send/recv of (N - 1) tile blocks [frame | depth] + de-tile kernel); "
+                                                 "`ms_event_max_rank_mean` = the slowest rank's mean, `ms_wall_per_gather` = host wall clock of the calls back to back, max over ranks"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,6 +261,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary no-edit measurement")
     ap.add_argument("--frames-in-flight", type=int, default=1, help="frames rendered concurrently (double-buffered streams when > 1)")
+    ap.add_argument("--gather-only", action="store_true", help="N > 1: time nrs_gather_tiles (the frame's one exchange step: RCCL send/recv to rank 0 + de-tile) alone, with HIP events; no rendering")
     args = ap.parse_args()
 
     import torch
@@ -246,6 +293,22 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     ctx = rt.Context(dev_index)
+    if args.gather_only:
+        # the exchange alone: no model, no rendering -- the tile buffers hold zeros (the transfer does not care)
+        sh = tiles.TileSharder(args.width, args.height, TILE, rank, world, dev)
+        aabb_scale = 16 if args.workload.startswith("garden") else 1
+        p = sh.fill(synth.render_params(args.width, args.height, camera_for(0, synth, aabb_scale), aabb_scale=aabb_scale))
+        frame = torch.zeros((args.height, args.width, 4), dtype=torch.float32, device=dev)
+        depth = torch.zeros((args.height, args.width), dtype=torch.float32, device=dev)
+        g = time_gather(torch, dist, ctx, sh, torch.cuda.Stream(device=dev), p, frame, depth, max(args.steps, 1), world, stats_dev)
+        if rank == 0:
+            print(json.dumps({"metric": "gather_tiles_ms", "value": g["ms_event_mean"], "unit": "ms", "n_gpus": world, "steps": max(args.steps, 1), "warmup": 3, "higher_is_better": False,
+                              "config": {"workload": f"the frame's exchange step alone: {args.width}x{args.height} RGBA + depth, {TILE}x{TILE} tiles round-robin over {world} GPU(s), gather to rank 0 + de-tile"},
+                              "gather": g}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     scene = build_scene(args.workload, rt, synth, ctx, torch)
     tb = scene["tb"]
     W, H = args.width, args.height
@@ -350,20 +413,24 @@ def main():
         lib = abi.load()
         accum = torch.zeros_like(frame)
 
-        def spp8_view(view):
+        def spp8_view(view, count=False):
+            n = 0
             for k in range(8):
                 p = synth.render_params(W, H, camera_for(view, synth, scene["aabb_scale"]), aabb_scale=scene["aabb_scale"], apply_operators=False, spp_index=k, snap=False)
                 frame.zero_()
-                tb.render_with_params(tb.nerf_network, p, frame, depth, None, None)
+                st = tb.render_with_params(tb.nerf_network, p, frame, depth, None, None, want_stats=count)
+                if count:
+                    n += int(st.n_samples)
                 abi.check(lib.nrs_accumulate(ctx.h, None, W, H, frame.data_ptr(), accum.data_ptr(), k, 0))
-        spp8_view(0)
+            return n
+        ns_spp8 = sum(spp8_view(v, count=True) for v in range(4))  # (untimed pass over the SAME 32 jittered frames: ADVICE r4)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for v in range(4):
             spp8_view(v)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
-        extra["noedit_spp8"] = {"images_per_s": round(4 / dt, 2), "ms_per_8spp_image": round(dt / 4 * 1e3, 2), "msamples_per_s": round(ns / 8 * 32 / dt / 1e6, 2),
+        extra["noedit_spp8"] = {"images_per_s": round(4 / dt, 2), "ms_per_8spp_image": round(dt / 4 * 1e3, 2), "msamples_per_s": round(ns_spp8 / dt / 1e6, 2),
                                 "note": "BASELINE configs[1] offline: 8 frames (Sobol offsets of spp_index 0..7) + nrs_accumulate per 1920x1080 image, no edits"}
 
     if not args.no_extra:
@@ -437,6 +504,37 @@ def main():
                 extra[name]["l2_misses_per_sample"] = round(tr / 128.0 / (ns / 8), 2)  # every L2 miss is one 128-byte fabric request (profiles/r02_gather_probe.md)
                 extra[name]["traffic_source"] = src
 
+    n1_ref, gather_leg = None, None
+    if world > 1 and not args.no_extra:
+        # (VERDICT r4 next #4b) the same run's N = 1 figure: rank 0 renders the WHOLE frames alone, one at a time, while the other ranks wait at the barrier --
+        # `retention_k` below = per-GPU sample throughput of the N-GPU job with k frames in flight relative to this
+        sync_all()
+        if rank == 0:
+            whole_f = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+            whole_d = torch.zeros((H, W), dtype=torch.float32, device=dev)
+
+            def whole_step(step, want_stats=False):
+                pw = synth.render_params(W, H, camera_for(step, synth, scene["aabb_scale"]), aabb_scale=scene["aabb_scale"], apply_operators=True)
+                pw.poisson_target = 1 if args.workload.endswith("membrane") else 0
+                whole_f.zero_()
+                return tb.render_with_params(tb.nerf_network, pw, whole_f, whole_d, None, None, want_stats=want_stats)
+            ns1 = sum(int(whole_step(s1, want_stats=True).n_samples) for s1 in range(8))
+            for s1 in range(3):
+                whole_step(s1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s1 in range(16):
+                whole_step(s1)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            n1_ref = {"msamples_per_s": round(ns1 * 2 / dt1 / 1e6, 2), "fps": round(16 / dt1, 2), "ms_per_frame": round(dt1 / 16 * 1e3, 3),
+                      "note": "this run's own N = 1 figure: rank 0 renders the whole frames alone, one at a time (16 frames over the 8 views), the other ranks idle"}
+        sync_all()
+        # (next #4c) the exchange step alone, so that a multi-GPU record separates exchange from render
+        p_g = make_params(0)
+        gather_leg = time_gather(torch, dist, ctx, all_sharders[0], all_streams[0], p_g, frames[0], depths[0], 20, world, stats_dev)
+        sync_all()
+
     gather_check = None
     if world > 1:
         # the exchanged frame against the same view rendered WHOLE on rank 0 (every rank takes part in the exchange; outside the timed region): what the
@@ -505,7 +603,10 @@ def main():
                        "cell_records": "levels 0..%d, %.1f GB (nrs_model_set_cell_cache default)" % (tb.nerf_network.cell_cache()[1] - 1, tb.nerf_network.cell_cache()[0] / 1e9) +
                                        ("; sparse brick records for levels %d..%d, %.1f GB" % (tb.nerf_network.sparse_cell_cache()[1], sum(tb.nerf_network.sparse_cell_cache()[1:]) - 1,
                                                                                                tb.nerf_network.sparse_cell_cache()[0] / 1e9) if tb.nerf_network.sparse_cell_cache()[2] else "")},
-            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "roofline": {"bound": "hbm",
+                         #  what `bound` / `frac` are: the contract's ALGORITHMIC figure -- 512 B per sample over the HBM peak -- not the kernel's limiter
+                         "bound_kind": "algorithmic-hbm (figure of merit: algorithmic bytes / kernel time / HBM peak; the kernel's own limiter is in `limiter`, its real HBM rate in `traffic_rate_frac`)",
+                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": traffic if world == 1 else None, "traffic_source": traffic_source if world == 1 else None,
                          #  `frac` is the ALGORITHMIC fraction the contract asks for (512 B per sample / kernel time / peak); the HBM rate the
                          # kernel really runs at is the measured traffic over the same time -- about half of it on this scene: the kernel is not HBM-bound
@@ -513,7 +614,7 @@ def main():
                          "limiter": "VALU issue (DESIGN.md 4): algorithmic bytes over the HBM peak is the contract's figure of merit, not the kernel's bound",
                          "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 3),
                          "algorithmic_bytes_per_launch": int(per_launch_samples * BYTES_PER_SAMPLE),
-                         "mfma_tflops": round(per_launch_samples * FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12, 2)},
+                         "mfma_tflops": round(per_launch_samples * flop_per_sample(scene["desc"]) / (kernel_ms * 1e-3) / 1e12, 2)},
         }
         if world > 1 and all_sharders[0].comm is not None:  # what the exchange actually ran on: ranks RCCL connected, its version, the library loaded
             import ctypes as C
@@ -525,6 +626,16 @@ def main():
         if gather_check is not None:
             line["config"]["gather_check"] = gather_check
         line.update(extra)
+        if n1_ref is not None:
+            # per-GPU sample throughput retained at N GPUs (north_star: >= 0.9 at 8): whole-job Msamples/s / N over this run's own N = 1 figure.  `value` is and stays the
+            # one-frame-at-a-time figure (retention_1); retention_2 / _4 are the same frames with 2 / 4 in flight per rank (the `pipelined` / `pipelined4` keys)
+            line["n1_reference"] = n1_ref
+            line["retention_1"] = round(value / world / n1_ref["msamples_per_s"], 4)
+            for k, key in ((2, "pipelined"), (4, "pipelined4")):
+                if key in extra:
+                    line[f"retention_{k}"] = round(extra[key]["msamples_per_s"] / world / n1_ref["msamples_per_s"], 4)
+        if gather_leg is not None:
+            line["gather"] = gather_leg
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(synth, scene)
         print(json.dumps(line), flush=True)
