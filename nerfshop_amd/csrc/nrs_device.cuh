@@ -419,6 +419,92 @@ __device__ __forceinline__ float coarse_safe_until(const DeviceModel& m, const u
 	return 0.f; // unreachable (a ray crosses at most 3 * kCoarse - 2 blocks); "nothing is known" keeps the plain walk
 }
 
+// ---- the lean walk in O(1) (round 5) ----------------------------------------------------------------------------------------------------------------
+// With a constant step (cone_angle == 0: dt = MIN_STEP everywhere) every parameter the walk ever stands on is a LATTICE point t_0 (+) dt (+) dt ... -- the same
+// chain of float additions whatever the cells are; the cells only decide at which lattice points the walk STOPS (the first lattice point at or behind each cell
+// border: advance_to_next_voxel).  Inside one binade [2^e, 2^(e+1)) the rounded addition t (+) dt adds a CONSTANT number q of ulps (dt = (I + f) ulp(t), f != 1/2:
+// q = I + (f > 1/2) -- no ties, so no dependence on the parity of t), so the lattice point k steps on is the integer addition bits(t) + k q: no chain needed.
+// What the chain-free jump cannot know is at which lattice points the walk stopped on the way -- and over a stretch that is known to be empty (t < t_safe,
+// coarse_safe_until) it does not need to, with one exception: the walk must continue from a lattice point at which the reference's walk STOPS, because the border
+// parameter t + distance_to_next_voxel(pos(t)) carries the rounding of the stop it is computed from.  So: jump to a lattice point t_k a cell and a half short of
+// t_safe, take ONE ordinary step of the walk from there to u = the first lattice point behind the border g of t_k's cell, and accept u only if no lattice point
+// lies within +-B of g, where B bounds the difference between the border parameters computed from any two lattice points of one cell (derivation: DESIGN.md 4,
+// "lattice jump": |g - exact border| <= (1.2e-7 t + 6e-8) |1/d_axis| + 1.2e-7 t; B is ten times that).  Then every evaluation of that border -- the reference's,
+// from its own stop in that cell, included -- selects the same u: u IS the reference's next stop, and the walk goes on from it bit for bit.  If a lattice point
+// sits inside the band (about 1 % of the jumps), or anything else is unusual (a tie, a sub-normal, the stretch leaves the unit cube where the cascade could
+// change), the function declines and the ordinary lean walk runs.  The (t, dt) streams stay bit-identical to the oracle's cell-by-cell walk (tests/test_gpu_parity.py).
+constexpr uint32_t kJumpMinSteps = 14u; // (a cell is 4.6 steps; the jump costs about two cells of lean walk)
+__device__ __forceinline__ bool lattice_jump(f3 o, f3 d, f3 idir, float t_safe, uint32_t mip, float& t) {
+	// (Straight-line: every condition is folded into one predicate and the candidate is computed whether or not it will be taken -- nested early exits cost this
+	// kernel scalar registers for the saved execution masks.  And written with VOP2-encodable literals: a literal operand of a three-source instruction needs a
+	// register on gfx9, which the compiler hoists out of the frame loop -- a dozen such constants once pushed the kernel past its 128 registers.)
+	const float margin = 0.02f * (float)(1u << mip); // a cell diagonal (1.35e-2 at cascade 0) + two steps + slack
+	const float k_want = floorf((t_safe - t - margin) * (1.0f / NRS_MIN_STEP)); // lattice steps to take (a lattice increment differs from dt by < ulp(t) / 2: 1e-5 over a stretch)
+	bool ok = k_want >= (float)kJumpMinSteps && k_want < 60000.0f; // (false for a NaN)
+	float k_left = ok ? k_want : 0.0f;
+	float tc = t;
+	// Two binade segments with three ordinary additions behind each: a stretch of the lego-like scenes starts below t = 1 and ends above it, and a jump that stopped
+	// at the binade's end would leave the rest to the cell-by-cell walk of the slowest lane.  (The additions are lattice steps like any other.)
+	#pragma unroll 1
+	for (int seg = 0; seg < 2; ++seg) {
+		const uint32_t b = __float_as_uint(tc);
+		const int e_t = (int)(b >> 23); // tc > 0: the sign bit is clear
+		// dt in ulps of this binade: x = dt 2^(150 - e_t), exact (a power of two); the lattice increment is x rounded to an integer, a constant as long as x is not
+		// half-way between two (round-to-even would then look at the parity of t): such a binade -- or one out of range -- is not jumped through
+		const float x = ldexpf(NRS_MIN_STEP, 150 - e_t), qf = rintf(x);
+		const bool seg_ok = e_t >= 24 && e_t <= 137 && fabsf(x - qf) != 0.5f && qf >= 1.0f && qf < 8388608.0f; // (e_t <= 137: ulp(t) <= 2^-9 < dt)
+		const float left = (float)(0x7fffffu - (b & 0x7fffffu)); // ulps to the binade's last value
+		const float k_bin = fmaxf(floorf(left * __builtin_amdgcn_rcpf(qf)) - 1.0f, 0.0f); // lattice points left in the binade (rounded down with room)
+		const float k = seg_ok ? fminf(k_left, k_bin) : 0.0f;
+		tc = __uint_as_float(b + (uint32_t)k * (uint32_t)qf);
+		k_left -= k;
+		#pragma unroll
+		for (int i = 0; i < 3; ++i) {
+			const bool step = k_left > 0.0f;
+			tc = step ? tc + NRS_MIN_STEP : tc;
+			k_left = step ? k_left - 1.0f : k_left;
+		}
+	}
+	ok = ok && (k_want - k_left) >= (float)kJumpMinSteps + 8.0f;
+	// the cascade must be the same at every stop on the way: both ends strictly inside the unit cube, where mip_from_pos is 0 (cone_angle == 0: mip_from_dt adds nothing)
+	ok = ok && mip_from_pos(o + d * t) == 0 && mip_from_pos(o + d * tc) == 0;
+	__builtin_amdgcn_sched_barrier(0); // (stage by stage: interleaved, the stages' temporaries add up)
+	// Up to three candidates: the lattice point reached, then the ones 4 and 8 steps before it (integer subtraction inside the binade: the same lattice).  A candidate
+	// that fails the band test below would fail it again on every later attempt from this walk -- the attempts all aim at the same lattice point -- and ONE lane per
+	// packet walking its stretch cell by cell is what the whole wave then waits for (measured: 36 instead of 9 wave trips per packet).
+	const uint32_t bk = __float_as_uint(tc);
+	const float q_here = rintf(ldexpf(NRS_MIN_STEP, 150 - (int)(bk >> 23)));
+	const uint32_t back = 4u * (uint32_t)q_here;
+	const uint32_t res = kGrid >> mip;
+	const float inv_res = ldexpf(1.0f, (int)mip - 7);
+	const float B = (fmaxf(fmaxf(fabsf(idir.x), fabsf(idir.y)), fabsf(idir.z)) + 1.0f) * 2e-6f * fmaxf(t_safe, 1.0f);
+	bool taken = false;
+	float t_new = t;
+	#pragma unroll 1
+	for (uint32_t attempt = 0; attempt < 3u; ++attempt) {
+		const bool in_binade = (bk & 0x7fffffu) >= attempt * back;
+		const float tk = __uint_as_float(bk - (in_binade ? attempt * back : 0u));
+		const f3 pk = o + d * tk;
+		const float g = tk + distance_to_next_voxel(pk, d, idir, res, inv_res);
+		// one ordinary step of the walk from t_k (advance_to_next_voxel's constant-step chain; the candidate's own while-loop tail cannot run: a cell of the unit cube's
+		// cascade is at most 8 steps, and for coarser cells -- min_mip > 0 -- the predicate below declines when the eight steps did not reach the border)
+		float u = tk + NRS_MIN_STEP;
+		#pragma unroll
+		for (int i = 0; i < 7; ++i) {
+			const float mstep = __builtin_amdgcn_fmed3f((g - u) * 0x1p100f, 0.0f, 1.0f);
+			u = fmaf(mstep, NRS_MIN_STEP, u);
+		}
+		bool pass = ok && in_binade && u >= g;
+		pass = pass && (g + NRS_MIN_STEP + B < t_safe);             // the lean walk's own hand-over test at the stop in t_k's cell, band included
+		pass = pass && (u - g > B) && (g - (u - NRS_MIN_STEP) > B); // no lattice point inside the band (also false for a non-finite B: axis-parallel rays)
+		t_new = (pass && !taken) ? u : t_new;
+		taken = taken || pass;
+		if (!__any(ok && !taken)) break; // (wave-uniform: every lane that can jump has its stop)
+	}
+	t = t_new;
+	return taken;
+}
+
 // The inner loop shared by advance_pos_nerf (tn:589-603) and generate_next_nerf_network_inputs (tn:668-692):
 // advance t until the ray sits in an occupied cell (returns true; pos/dt valid) or leaves the render box (false).
 //
@@ -439,6 +525,10 @@ __device__ __forceinline__ float coarse_safe_until(const DeviceModel& m, const u
 // retired at once (or lean-walked to the next marked block).  Measured (Gsamples/s, lego + cage edit; ms for a 64x40-pixel
 // frame): once per walk 9.0 / 0.84, every 3rd cell 9.43 / 0.58, 6th 9.92 / 0.56, 10th 9.80 / 0.55, 16th 9.82 / 0.58, 32nd 9.54 / 0.65.
 constexpr int kLookEvery = 6;
+// NRS_OPT_LATTICE_JUMP (round 5): the lean walk in O(1) for constant steps -- lattice_jump above.
+#ifndef NRS_OPT_LATTICE_JUMP
+#define NRS_OPT_LATTICE_JUMP 1
+#endif
 // NRS_OPT_MORTON: the Morton code of an occupancy cell from a 128-entry table in LDS (spread3(v) = the bits of v at every third position; staged
 // behind the look-ahead mask by stage_march_lds) -- three ds_read + two v_lshl_or instead of 28 VALU instructions per occupancy test; the cell index
 // and therefore every decision stay the same.
@@ -509,6 +599,9 @@ __device__ __forceinline__ bool occupied_at(f3 pos, const uint8_t* __restrict__ 
 #ifndef NRS_OPT_LAZY_IDIR
 #define NRS_OPT_LAZY_IDIR 1
 #endif
+// JUMP: compile lattice_jump into this instance (the two hot ones: the fill's first_hit and the per-round walk of one-lane rounds; the team walks keep the plain lean
+// walk -- every inlined copy costs scalar registers in a kernel that spills them)
+template <bool JUMP = false>
 __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, const DeviceModel& m, const uint32_t* __restrict__ march_lds, f3 o, f3 d,
                                                   float& t, f3& pos, float& dt, uint32_t* n_iter = nullptr, const OccWord* seed = nullptr) {
 	const uint32_t* __restrict__ coarse_mask = march_lds;
@@ -563,6 +656,17 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 			}
 			// lean walk: every position it stands on has parameter < t_safe
 			while (1) {
+#if NRS_OPT_LATTICE_JUMP
+				// (tried in EVERY pass of the lean walk, not once in front of it: a lane that declines -- a lattice point in the guard band, the end of a binade, the
+				// entry point on the cube's face -- takes one ordinary step and tries again from there; a wave is as slow as its slowest lane, and one lane in a
+				// hundred walking the whole stretch cell by cell would keep most waves waiting)
+				if (JUMP && cone == 0.f && t_safe - t > 0.06f /* 22 steps + the margin: nothing to gain below */ && lattice_jump(o, d, idir, t_safe, mip, t)) {
+					if (n_iter) ++*n_iter;
+					pos = o + d * t;
+					dt = calc_dt(t, cone);
+					mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
+				}
+#endif
 				const uint32_t lres = kGrid >> mip;
 				const float linv = ldexpf(1.0f, (int)mip - 7);
 				// one step past the border is the farthest the next position can be (first lattice point >= the border)
@@ -600,7 +704,7 @@ __device__ __forceinline__ bool first_hit(const nrs_render_params& p, const Devi
 	float dt = calc_dt(r.t, p.cone_angle_constant);
 	r.t += ld_random_val(p.spp_index, pixel_idx * 786433u) * dt;
 	f3 pos;
-	return march_to_occupied(p, m, march_lds, r.o, r.d, r.t, pos, dt, n_iter);
+	return march_to_occupied<true>(p, m, march_lds, r.o, r.d, r.t, pos, dt, n_iter);
 }
 
 // ---- tet warp: selection_utils.h:10-47, cage_deformation.cu:136-269 -----------------------------------------------

@@ -70,6 +70,9 @@ constexpr int kRing = 128; // pending-ray ring entries per wave (>= 63 + 64)
 #ifndef NRS_EXP_DBL
 #define NRS_EXP_DBL 0 // measurement builds: 1 fill, 2 cage warp, 3 gather, 4 MLPs, 5 march executed twice (results unchanged) -- the frame time's difference is that phase's marginal cost
 #endif
+#ifndef NRS_OPT_SAT_WRITE
+#define NRS_OPT_SAT_WRITE 1 // a saturated ray (alpha normalised to exactly 1) writes its pixel without reading the frame value it would multiply by 0 (render_body's shade)
+#endif
 #ifndef NRS_OPT_NOZERO
 #define NRS_OPT_NOZERO 1 // the render rounds do not zero the features of idle lanes (nobody reads them): one select per level saved
 #endif
@@ -840,7 +843,10 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 
 		NRS_FRESH_ARGS(m3, a3);
 		const nrs_render_params& p3 = a3.p;
-		NRS_PHASE(5); // composite + march + shade
+#ifndef NRS_EXP_STAMP
+#define NRS_EXP_STAMP 0 // measurement build (profiling instantiation, one-lane rounds): 1 = the phase stamps cut "composite + march + shade" in three -- the compositing is
+#endif                  // booked on "sh+mlp", the walk to the next sample stays on "composite+march+shade", the shade (frame read-modify-write) goes to "refill"
+		if (!NRS_EXP_STAMP) NRS_PHASE(5); // composite + march + shade
 		// (read here, not in front of the frame loop: six scalar registers that would otherwise live through every phase)
 		const f3 cam_fwd = mk3(p3.camera_matrix1[6], p3.camera_matrix1[7], p3.camera_matrix1[8]);
 		const f3 cam_o = mk3(p3.camera_matrix1[9], p3.camera_matrix1[10], p3.camera_matrix1[11]);
@@ -948,9 +954,13 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 							tr = srgb_to_linear(tr); tg = srgb_to_linear(tg); tb = srgb_to_linear(tb);
 						}
 						float4* fb = reinterpret_cast<float4*>(a3.frame) + out_idx;
+						if (NRS_OPT_SAT_WRITE && ta == 1.0f) {
+							*fb = make_float4(tr, tg, tb, 1.0f); // (see the one-lane path)
+						} else {
 						const float4 prev = *fb;
 						const float om = 1.0f - ta;
 						*fb = make_float4(tr + prev.x * om, tg + prev.y * om, tb + prev.z * om, ta + prev.w * om);
+						}
 						if (ta > 0.2f) a3.depth[out_idx] = ray_depth;
 						++st_hit;
 					}
@@ -1014,6 +1024,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			}
 			++n_steps;
 			++st_samples;
+			if (NRS_EXP_STAMP) NRS_PHASE(5);
 			bool done = false, shade = true, exited = false;
 			if (ca > (1.0f - p3.min_transmittance)) {
 				// rgba /= alpha (tn:951-953): one v_rcp (1 ulp) + three multiplies instead of four IEEE divisions -- this block runs
@@ -1029,9 +1040,10 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 #if NRS_EXP_DBL == 5
 				{ float t2 = t; asm volatile("" : "+v"(t2)); f3 np2; float nd2; const bool v2 = march_to_occupied(p3, m3, sm.coarse, o, d, t2, np2, nd2, nullptr, nullptr); asm volatile("" :: "v"(t2), "s"((int)__ballot(v2))); }
 #endif
-				done = !march_to_occupied(p3, m3, sm.coarse, o, d, t, npos, ndt, PROF ? &it_march : nullptr, NRS_OPT_EARLY_MARCH ? &occ_seed : nullptr);
+				done = !march_to_occupied<true>(p3, m3, sm.coarse, o, d, t, npos, ndt, PROF ? &it_march : nullptr, NRS_OPT_EARLY_MARCH ? &occ_seed : nullptr);
 				exited = done;
 			}
+			if (NRS_EXP_STAMP) NRS_PHASE(1);
 			if (done) {
 				if (shade && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
 					float tr = cr, tg = cg, tb = cb, ta = ca;
@@ -1048,9 +1060,17 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 						tr = srgb_to_linear(tr); tg = srgb_to_linear(tg); tb = srgb_to_linear(tb);
 					}
 					float4* fb = reinterpret_cast<float4*>(a3.frame) + out_idx;
+					// NRS_OPT_SAT_WRITE: a ray that saturated was normalised to alpha = 1 exactly (tn:951-953), so shade_kernel_nerf's `tmp + frame * (1 - tmp.w)` is
+					// `tmp + frame * 0` = tmp for every finite frame value: such a ray WRITES its pixel without reading it -- the frame read is an HBM miss on the
+					// round's dependency chain, and nearly every round of a wave retires some ray.  (A non-finite value in the caller's frame would have turned into NaN
+					// through the multiplication by 0; it is overwritten instead.)
+					if (NRS_OPT_SAT_WRITE && ta == 1.0f) {
+						*fb = make_float4(tr, tg, tb, 1.0f);
+					} else {
 					const float4 prev = *fb;
 					const float om = 1.0f - ta;
 					*fb = make_float4(tr + prev.x * om, tg + prev.y * om, tb + prev.z * om, ta + prev.w * om);
+					}
 					if (ta > 0.2f) a3.depth[out_idx] = ray_depth;
 					++st_hit;
 				}

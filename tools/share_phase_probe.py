@@ -3,7 +3,7 @@ PROFILING instantiation (NRS_DEBUG=4: s_memtime per phase, the per-wave log), ne
 
     python tools/share_phase_probe.py [workload] > gpurun_out/share_phases.md        (runs on the GPU box; spawns itself once per N with NRS_DEBUG=4)
 
-Per N the report gives, from the wave log (wall_clock64, 100 MHz, common to all XCDs): when the last wave started, when the queue ran dry (the last wave to see it),
+Per N the report gives, from the wave log (wall_clock64, 100 MHz, common to all XCDs): when the last wave started, when the queue ran dry (the first wave to see it),
 when half of the waves had finished, when the last one had -- i.e. the launch's critical path cut into
    start   launch begins .. every wave runs (dispatch + LDS staging of the weights)
    fill    .. the frame's queue is dry: packets claimed, primary rays set up, first hits found (rounds of earlier generations overlap here)
@@ -60,14 +60,16 @@ def report(N, log_path, prof_line, prod_line, stderr_text):
     start = (start - start.min()) / 100.0
     end = start + wall
     t_start = start.max()
-    t_dry = (start + tq)[tq > 0].max() if (tq > 0).any() else float("nan")
+    t_dry = (start + tq)[tq > 0].min() if (tq > 0).any() else float("nan")  # the FIRST wave to find the queue dry: from here on no new rays enter
     t_half = np.median(end)
     t_end = end.max()
     phases = dict(re.findall(r" ([a-z+]+)=([0-9.]+)%", re.search(r"\[nrs phases\].*", stderr_text).group(0)))
     life = re.search(r"mean wave lifetime = ([0-9.]+)% of the longest", stderr_text).group(1)
+    walk = re.search(r"\[nrs walk\].*", stderr_text)
     g = lambda line, key: float(re.search(key + r"=([0-9.]+)", line).group(1))
     return dict(N=N, prod_ms=g(prod_line, "kernel_ms_median"), prof_ms=g(prof_line, "kernel_ms_median"), samples=int(g(prof_line, "samples")), rays=int(g(prof_line, "rays")),
-                waves=len(end), t_start=t_start, t_dry=t_dry, t_half=t_half, t_end=t_end, rounds_mean=rounds.mean(), rounds_max=int(rounds.max()), phases=phases, life=life)
+                waves=len(end), t_start=t_start, t_dry=t_dry, t_half=t_half, t_end=t_end, rounds_mean=rounds.mean(), rounds_max=int(rounds.max()), phases=phases, life=life,
+                walk=walk.group(0) if walk else "")
 
 
 def main():
@@ -76,7 +78,7 @@ def main():
         return
     workload = sys.argv[1] if len(sys.argv) > 1 else "lego_cage"
     rows = []
-    for N in (1, 2, 4, 8):
+    for N in tuple(int(v) for v in os.environ.get("NRS_PROBE_N", "1,2,4,8").split(",")):
         log_path = f"/tmp/nrs_wave_{N}.bin"
         cmd = [sys.executable, os.path.abspath(__file__), "--child", workload, str(N), log_path]
         prod = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, NRS_DEBUG="0"))
@@ -109,6 +111,9 @@ def main():
     print("|---|" + "---|" * len(names))
     for r in rows:
         print(f"| {r['N']} | " + " | ".join(f"{r['phases'].get(n, '0')} %" for n in names) + " |")
+    print("\nVoxel-walk counters of the same launches (a `trip` = one pass of the wave through the walk's loop body; a round's march costs as many trips as its slowest lane needs):\n")
+    for r in rows:
+        print(f"* N = {r['N']}: `{r['walk']}`")
 
 
 if __name__ == "__main__":
