@@ -46,7 +46,7 @@ def build_scene(workload, rt, synth, ctx, torch):
     aabb_scale = 16 if workload.startswith("garden") else 1
     with_edit = "cage" in workload
     # (configs/nerf/base_1layer.json / base_3layer.json: the rgb network with one hidden layer is lowered onto the kernels' network and runs the default
-    # instantiations; the third hidden layer has its own: DESIGN.md 4 "The network family")
+    # instantiations; the third hidden layer has its own: DESIGN.md 4 "Instantiations")
     desc = synth.model_desc(aabb_scale, rgb_hidden_layers=1 if workload.endswith("base_1layer") else (3 if workload.endswith("base_3layer") else 2))
     if workload.endswith("varied"):
         # non-uniform opacity: geometry inside the network (shaped) and a strong density noise, so that per-sample alpha -- and with

@@ -458,7 +458,7 @@ int  nrs_edit_download(nrs_edit* edit, float* h_vertices, uint32_t* h_lut_offset
 /* ---- renderer -------------------------------------------------------------------------------------- */
 /* d_frame: f32x4 premultiplied linear RGBA, pre-cleared by the caller (clear_frame, testbed.cu:2635);
  * d_depth: f32 (written 1e10 for every pixel of the owned tiles first, as init_rays does);
- * d_steps: optional u32 per pixel = samples composited (payload.n_steps - 1 ... see DESIGN.md), may be NULL.
+ * d_steps: optional u32 per pixel = samples composited (the reference's payload.n_steps, tn:957-960, minus the one it counts for a ray that ran out of samples), may be NULL.
  * edits are applied last-to-first (testbed_nerf.cu:2899).  h_stats may be NULL; when non-NULL the call
  * synchronises the stream before returning (the reference's trace() syncs to read n_hit). */
 int nrs_render_nerf(nrs_model* model, const nrs_render_params* params, nrs_edit* const* edits, int n_edits,

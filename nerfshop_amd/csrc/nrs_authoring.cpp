@@ -1,7 +1,7 @@
 // nrs_authoring.cpp -- host-side edit authoring behind include/nrs.h: cell->tet LUT builder, MVC weights, per-tet
 // rotations.  SURVEY 8(f) row 1: the steps that run on the CPU in the reference too, immediately BEFORE the render path
 // on every gizmo move.  They are here so a cage edit can be produced without the reference's GUI; a device version of
-// the LUT builder is later-round work.  No HIP calls: usable without a GPU.
+// the LUT builder runs in nrs_cage.hip.  No HIP calls: usable without a GPU.
 //
 //   nrs_tet_lut_build        TetMesh::build_tet_grid / build_original_tet_grid   src/editing/datastructures/tet_mesh.cu:368 / :76
 //   nrs_mvc_compute / apply  Cage::compute_mvc / interpolate_with_mvc            src/editing/datastructures/cage.cu:6 / :38,

@@ -180,7 +180,7 @@ int launch_cell_records(const DeviceModel& m, uint32_t n_levels, void* d_records
 int launch_weight_fragments(const uint16_t* d_params, const uint16_t* d_src, uint16_t* d_frag, uint32_t n, void* stream);
 constexpr uint32_t kBrick = 8, kBrickCells = kBrick * kBrick * kBrick; // sparse cell records: 8^3 cells = 16 KiB of records per brick
 // Order of the 512 records inside a brick.  0: x fastest (a 128-byte line = the 4 records of a 4 x 1 x 1 run of cells); 1: Morton (a line = a 2 x 2 x 1 block, two
-// lines = 2 x 2 x 2): VERDICT r3 next #7's experiment -- measured on the aabb-16 scene in round 4, see DESIGN.md 4 / profiles/r04_garden.md.
+// lines = 2 x 2 x 2): VERDICT r3 next #7's experiment -- measured on the aabb-16 scene in round 4, see HISTORY.md (round 4) / profiles/r04_garden.md.
 #ifndef NRS_BRICK_MORTON
 #define NRS_BRICK_MORTON 0
 #endif
