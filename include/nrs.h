@@ -274,6 +274,10 @@ int  nrs_ctx_set_lane_teams(nrs_ctx* ctx, int lanes_per_ray);
 int  nrs_ctx_set_ray_handover(nrs_ctx* ctx, int enabled);
 int  nrs_ctx_ray_handovers(const nrs_ctx* ctx, uint64_t* n_rays, uint64_t* n_handovers);
 
+/* MEMORY NOTE: a model keeps a cell-record cache by DEFAULT (budget 10 GiB; 9.2 GB for base.json's table: nrs_model_set_cell_cache below).  It is allocated and filled
+ * inside the first nrs_model_set_params and rebuilt inside every later one (1.9 ms for 9.2 GB).  A caller whose parameters change every frame -- a training viewer -- or
+ * that cannot spare the memory calls nrs_model_set_cell_cache(model, 0) right after nrs_model_create: results are bit-identical, the frame is about 15 % slower
+ * (bench.py key lego_cage_norecords).  NRS_CELL_CACHE_GB in the environment overrides the default budget. */
 int    nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out);
 void   nrs_model_destroy(nrs_model* model);
 /* number of fp16 parameters the description implies (density MLP | rgb MLP | hash grid), host-only */

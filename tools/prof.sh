@@ -1,4 +1,4 @@
-# usage: tools/prof_r02.sh <workload> <tag> [quick]   -- rocprofv3 trace + PMC passes of bench.py for one workload -> gpurun_out/prof_<tag>/
+# usage: tools/prof.sh <workload> <tag> [quick]   -- rocprofv3 trace + PMC passes of bench.py for one workload -> gpurun_out/prof_<tag>/
 set -x
 R=$GRAFT_REPO_ROOT
 W=$1; TAG=$2
@@ -7,6 +7,8 @@ OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 B="python $R/bench.py --workload $W --steps 8 --warmup 2 --no-cpu-baseline --no-extra"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $B > $OUT/trace.log 2>&1
+# (a warmed-up run: the average launch the bench's HIP events report)
+rocprofv3 --kernel-trace --stats -d $OUT/trace32 -o bench -- python $R/bench.py --workload $W --steps 32 --warmup 4 --no-cpu-baseline --no-extra > $OUT/trace32.log 2>&1
 B2="python $R/bench.py --workload $W --steps 4 --warmup 1 --no-cpu-baseline --no-extra"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o bench -- $B2 > $OUT/pmc1.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o bench -- $B2 > $OUT/pmc2.log 2>&1

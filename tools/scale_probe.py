@@ -1,7 +1,7 @@
-"""Single-GPU probe of the multi-GPU compute leg (round 3): (1) one rank's share of the 1080p bench frame (tiles r, r + N, ...) for N = 1, 2, 4, 8 with
+"""Single-GPU probe of the multi-GPU compute leg (rounds 3-5; was tools/scale_probe_r03.py): (1) one rank's share of the 1080p bench frame (tiles r, r + N, ...) for N = 1, 2, 4, 8 with
 1 / 2 / 4 frames in flight -- what a rank of an N-GPU job does between gathers; (2) the load balance of the round-robin deal of 32x32 tiles: samples per rank
 for the 8 bench views at N = 2 / 4 / 8, from the per-pixel step counts of whole-frame renders.  Writes markdown to stdout.
-    python tools/scale_probe_r03.py > gpurun_out/r03_scaling.md   (NRS_PROBE_QUICK=1: 1 and 2 frames in flight only, no load-balance table)"""
+    python tools/scale_probe.py > gpurun_out/scaling.md   (NRS_PROBE_QUICK=1: 1 and 2 frames in flight only, no load-balance table)"""
 import os
 import sys
 import time
@@ -24,7 +24,7 @@ def main():
     for _ in range(150):
         tb.render_with_params(tb.nerf_network, warm, wf, wd, None, None)
     torch.cuda.synchronize()
-    print("# Strong-scaling compute leg on ONE MI355X (round 3)\n")
+    print("# Strong-scaling compute leg on ONE MI355X\n")
     print("One rank's share of the 1080p lego + cage frame (32x32 tiles dealt round-robin on the odd-pitch tile index), 32 frames over the 8 bench views, automatic lane-team choice.")
     print("`retained` = this GPU's samples/s relative to the whole frame rendered one at a time (N = 1, 1 in flight): the quantity north_star's 0.9 target is about.\n")
     print("| ranks N | share | frames in flight | ms per share-frame | Msamples/s on this GPU | retained |")
