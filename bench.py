@@ -146,7 +146,7 @@ def cpu_baseline(synth, scene=None):
             "one_thread": {"value": round(s1 / t1 / 1e6, 4), "unit": "Msamples/s", "sample": f"64x64 view of the same camera, {s1} samples in {t1:.2f} s"}}
 
 
-TRAFFIC_FILE = "profiles/r04_traffic.json"
+TRAFFIC_FILE = "profiles/r05_traffic.json"
 
 
 def measured_traffic(workload):
