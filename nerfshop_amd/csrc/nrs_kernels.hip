@@ -73,9 +73,6 @@ constexpr int kRing = 128; // pending-ray ring entries per wave (>= 63 + 64)
 #ifndef NRS_OPT_SAT_WRITE
 #define NRS_OPT_SAT_WRITE 1 // a saturated ray (alpha normalised to exactly 1) writes its pixel without reading the frame value it would multiply by 0 (render_body's shade)
 #endif
-#ifndef NRS_OPT_DEFER_SHADE
-#define NRS_OPT_DEFER_SHADE 1 // finished rays write their pixels when their lanes are about to be reused, all at once, instead of at the end of the round they finish in
-#endif
 #ifndef NRS_OPT_NOZERO
 #define NRS_OPT_NOZERO 1 // the render rounds do not zero the features of idle lanes (nobody reads them): one select per level saved
 #endif
@@ -391,69 +388,13 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 						mb[11 * 32 + r] = __float_as_uint(ray_depth); mb[12 * 32 + r] = __float_as_uint(max_weight);
 						mb[13 * 32 + r] = out_idx; mb[14 * 32 + r] = n_steps;
 					}
-					if (moved) { have = false; max_weight = 0.f; } // (an idle lane with nothing to write: see "deferred shade" below)
+					if (moved) have = false;
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 					__builtin_amdgcn_wave_barrier();
 					if (ln == 0) { lds_poke(&sm.mail[target], give); atomicAdd(&a1.counters->walk[7], (unsigned long long)give | (1ull << 32)); }
 				}
 			}
 		}
-#if NRS_OPT_DEFER_SHADE
-		// ---- deferred shade (round 5).  A ray that ends keeps its result in its lane -- nothing refills a lane before the generation is over -- and leaves a mark in the
-		// bits of max_weight (1 = a pixel to finish, 2 = it is shaded, 4 = the ray ran out of samples); the pixels are written HERE, for all the lanes that have one, when
-		// the lanes are about to be reused: the generation is over (all 64 idle) or the survivors are about to be spread over the idle lanes.  Shading used to run at the end
-		// of nearly every round for the one or two lanes that had just finished -- a divergent block with a frame read (an HBM miss) on the round's dependency chain, 7.5 % of a
-		// wave's time (profiles/r05/phase_stamp_split.md) -- and now runs three or four times per generation on many lanes at once.  A pixel is written by one ray: same bits.
-		{
-			// (the mark is a NORMAL float no weight can be -- 2^23 + flags -- so that nothing that touches the register as a float can flush it)
-			const uint32_t mbits = __float_as_uint(max_weight);
-			const uint32_t fbits = (!have && (mbits >> 24) == 0x4bu) ? (mbits & 7u) : 0u;
-			if (__ballot(fbits != 0u) != 0ull) {
-				bool flush = __ballot(have) == 0ull;
-				if (TEAM == 0 && a1.reteam && (((a1.reteam & 2u) && tail_seen) || (!more && ring_count == 0u))) {
-					const uint32_t live_now = (uint32_t)__popcll(__ballot(have && tk == 0));
-					const uint32_t t_now = (NRS_TEAM_MAX >= 8 && live_now <= 8u) ? 8u : (live_now <= 16u ? 4u : (live_now <= 32u ? 2u : 1u));
-					flush = flush || (live_now != 0u && t_now > gen_t);
-				}
-				if (flush) {
-					if (fbits != 0u) {
-						if ((fbits & 2u) && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
-							float tr = cr, tg = cg, tb = cb, ta = ca;
-							if (INTRO && p1.render_mode == NRS_RENDER_NORMALS) { // tn:2466-2468
-								const f3 v = mk3(tr, tg, tb);
-								const float z = dot3(v, v);
-								f3 n = v;
-								if (z > 0.f) { const float len = sqrtf(z); n = mk3(v.x / len, v.y / len, v.z / len); }
-								tr = (0.5f * n.x + 0.5f) * ta; tg = (0.5f * n.y + 0.5f) * ta; tb = (0.5f * n.z + 0.5f) * ta;
-							} else if (p1.render_mode == NRS_RENDER_COST) {
-								// payload.n_steps = j + current_step (tn:957-960): the samples composited for a ray that saturated (the loop broke AT sample j), one more for a
-								// ray that ran out of samples (j is then the count, and current_step starts at 1)
-								const float col = (float)(n_steps + ((fbits & 4u) ? 1u : 0u)) / 128;
-								tr = tg = tb = col; ta = 1.0f;
-							} else if (!p1.linear_colors && (!EXTRA || p1.render_mode == NRS_RENDER_SHADE)) { // tn:2474: only Shade (and Slice) accumulate in linear colours
-								tr = srgb_to_linear(tr); tg = srgb_to_linear(tg); tb = srgb_to_linear(tb);
-							}
-							float4* fb = reinterpret_cast<float4*>(a1.frame) + out_idx;
-							// NRS_OPT_SAT_WRITE: a ray that saturated was normalised to alpha = 1 exactly (tn:951-953), so shade_kernel_nerf's `tmp + frame * (1 - tmp.w)` is
-							// `tmp + frame * 0` = tmp for every finite frame value: such a ray WRITES its pixel without reading it.  (A non-finite value in the caller's frame
-							// would have turned into NaN through the multiplication by 0; it is overwritten instead.)
-							if (NRS_OPT_SAT_WRITE && ta == 1.0f) {
-								*fb = make_float4(tr, tg, tb, 1.0f);
-							} else {
-								const float4 prev = *fb;
-								const float om = 1.0f - ta;
-								*fb = make_float4(tr + prev.x * om, tg + prev.y * om, tb + prev.z * om, ta + prev.w * om);
-							}
-							if (ta > 0.2f) a1.depth[out_idx] = ray_depth;
-							++st_hit;
-						}
-						if (a1.steps) a1.steps[out_idx] = n_steps;
-						max_weight = 0.f;
-					}
-				}
-			}
-		}
-#endif
 		if (TEAM == 0 && a1.reteam && (((a1.reteam & 2u) && tail_seen) || (!more && ring_count == 0u))) { // (bit 1: at any time once the wave runs tail generations, not only at its end)
 			const unsigned long long lead_mask = __ballot(have && tk == 0);
 			const uint32_t live = (uint32_t)__popcll(lead_mask);
@@ -474,7 +415,6 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				ray_depth = __shfl(ray_depth, src, 64); max_weight = __shfl(max_weight, src, 64);
 				out_idx = (uint32_t)__shfl((int)out_idx, src, 64); n_steps = (uint32_t)__shfl((int)n_steps, src, 64);
 				have = r < live;
-				if (NRS_OPT_DEFER_SHADE && !have) max_weight = 0.f; // (pending pixels were written in front of this block; what these lanes hold now is a live ray's copy)
 				valid = true;
 				gen_t = new_t;
 				tk = lane & (int)(gen_t - 1u);
@@ -1001,12 +941,6 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			}
 			const bool lead_valid = __shfl((int)valid, team_base, 64) != 0;
 			if (have && !done && !lead_valid) { done = true; exited = true; } // no further sample: the ray is finished now rather than a round later
-#if NRS_OPT_DEFER_SHADE
-			if (have && done) { // the pixel is finished when the lanes are reused (the flush on top of the frame loop)
-				max_weight = __uint_as_float(tk == 0 ? (0x4b000001u | (shade ? 2u : 0u) | (exited ? 4u : 0u)) : 0u);
-				have = false;
-			}
-#else
 			if (have && done) {
 				if (tk == 0) {
 					if (shade && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
@@ -1034,7 +968,6 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				}
 				have = false;
 			}
-#endif
 		} else
 		if (have) { // one lane per ray
 			const f3 cpos = unwarp_position(wpos, m3.aabb);
@@ -1111,12 +1044,6 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				exited = done;
 			}
 			if (NRS_EXP_STAMP) NRS_PHASE(1);
-#if NRS_OPT_DEFER_SHADE
-			if (done) { // (see the team path)
-				max_weight = __uint_as_float(0x4b000001u | (shade ? 2u : 0u) | (exited ? 4u : 0u));
-				have = false;
-			}
-#else
 			if (done) {
 				if (shade && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
 					float tr = cr, tg = cg, tb = cb, ta = ca;
@@ -1150,7 +1077,6 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				if (a3.steps) a3.steps[out_idx] = n_steps;
 				have = false;
 			}
-#endif
 		}
 		if (PROF) {
 			uint32_t mx = it_march;
