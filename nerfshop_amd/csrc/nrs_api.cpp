@@ -615,7 +615,7 @@ int nrs_model_set_sparse_cell_cache(nrs_model* m, const uint8_t* h_mask_bitfield
 			nbs[k] = nb;
 			pair_tables += entries; pair_bricks += counts[k];
 			pair_bytes += entries * 4ull + (uint64_t)counts[k] * ((uint64_t)kBrickCells * 32ull + 4ull);
-			if (getenv("NRS_SPARSE_LOG"))
+			if (dev_knob("NRS_SPARSE_LOG"))
 				fprintf(stderr, "[nrs sparse] level %u: res %u, %u^3 bricks (table %.1f MB), %u bricks marked = %.2f GB of records\n", k, m->dm.levels[k].resolution, nb, entries * 4e-6,
 				        counts[k], counts[k] * 16384e-9);
 		}
@@ -1432,7 +1432,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	}
 	a.edits = d_edits_slot;
 	{
-		static const uint32_t dbg = []() { const char* e = getenv("NRS_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
+		static const uint32_t dbg = []() { const char* e = dev_knob("NRS_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
 		a.dbg = dbg;
 	}
 	// everything of render_nerf's surface beyond Shade / Cost with a pinhole camera runs the EXTRA instantiation (one lane per ray)
@@ -1441,7 +1441,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	if (m->dm.rgb_deep && !a.extra) {
 		// A third rgb hidden layer: the automatic schedule has a DEEP instantiation for the plain case (Shade / Cost, cage edits without the membrane correction, default
 		// roundings, no forced schedule); everything else of such a network runs the DEEP twins of the catch-all (launch_render)
-		static const bool env_sched = (getenv("NRS_TEAM") && atoi(getenv("NRS_TEAM")) != 0) || (getenv("NRS_HYBRID") && atoi(getenv("NRS_HYBRID")) == 0) || getenv("NRS_RENDER_CFG");
+		static const bool env_sched = (dev_knob("NRS_TEAM") && atoi(dev_knob("NRS_TEAM")) != 0) || (dev_knob("NRS_HYBRID") && atoi(dev_knob("NRS_HYBRID")) == 0) || dev_knob("NRS_RENDER_CFG");
 		const bool plain = !a.any_poisson && !a.any_affine && m->dm.numerics == 0u && !ctx->lane_teams && !env_sched && !(a.dbg & 4u);
 		if (!plain) a.extra = 1u;
 	}
@@ -1469,8 +1469,8 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	  // 0.25 until one has finished).  Measured on 1080p lego (0.22 of the pixels hit), frame shares 1/1 .. 1/8, ms per
 	  // launch with 1 / 2 / 4 lanes per ray: 3.09 2.89 3.31 | 2.07 1.78 1.95 | 1.56 1.25 1.21 | 1.19 0.93 0.88; 8 and 16
 	  // lanes lose everywhere (1.07, 1.72 at 1/8); 2560x1440: 4.31 4.52 5.64; aabb-16 1080p (every pixel hits): 9.64 9.76 10.9
-		static const bool hybrid_on = []() { const char* e = getenv("NRS_HYBRID"); return !e || atoi(e) != 0; }();
-		static const int env_forced = []() { const char* e = getenv("NRS_TEAM"); return e ? atoi(e) : 0; }();
+		static const bool hybrid_on = []() { const char* e = dev_knob("NRS_HYBRID"); return !e || atoi(e) != 0; }();
+		static const int env_forced = []() { const char* e = dev_knob("NRS_TEAM"); return e ? atoi(e) : 0; }();
 		const int forced = ctx->lane_teams ? ctx->lane_teams : env_forced;
 		const unsigned long long fb = ctx->h_feedback ? __atomic_load_n(ctx->h_feedback, __ATOMIC_RELAXED) : 0ull;
 		const double hit_share = (fb >> 32) ? (double)(uint32_t)fb / (double)(fb >> 32) : 0.25;
@@ -1512,13 +1512,13 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		const bool poisson_teams = a.any_poisson && !a.any_affine && !a.extra && m->dm.numerics == 0u;
 		const bool one_lane_only = (a.any_poisson && !poisson_teams) || a.any_affine || a.extra;
 		if (one_lane_only || a.any_poisson) team = 1; // (fixed 2 / 4 lanes per ray exist for the default kernel only; a forced size leaves the membrane path on the catch-all)
-		static const bool log_teams = getenv("NRS_TEAM_LOG") != nullptr;
+		static const bool log_teams = dev_knob("NRS_TEAM_LOG") != nullptr;
 		if (log_teams) fprintf(stderr, "[nrs team] pixels=%u hit_share=%.3f busy=%u rays/lane=%.3f small-launch=%d fill lanes=%u forced=%d\n", a.pixels_owned, hit_share, busy, rays_per_lane, (int)small_launch, fill_lanes, forced);
-		static const uint32_t tail_target = []() { const char* e = getenv("NRS_TAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)std::min(atoi(e), 64) : 24u; }(); // (<= kRing - 64: the fill adds up to 64 rays per packet to a 128-entry ring) 8 / 16 / 24 / 32 / 48: 8.92 / 8.91 / 9.11 / 9.01 / 8.47 Gsamples/s
+		static const uint32_t tail_target = []() { const char* e = dev_knob("NRS_TAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)std::min(atoi(e), 64) : 24u; }(); // (<= kRing - 64: the fill adds up to 64 rays per packet to a 128-entry ring) 8 / 16 / 24 / 32 / 48: 8.92 / 8.91 / 9.11 / 9.01 / 8.47 Gsamples/s
 		a.tail_target = tail_target;
-		static const uint32_t reteam = []() { const char* e = getenv("NRS_RETEAM"); return e ? (uint32_t)atoi(e) : 3u; }(); // bit 0: at the end of a wave's work, bit 1: whenever a tail generation has thinned out
+		static const uint32_t reteam = []() { const char* e = dev_knob("NRS_RETEAM"); return e ? (uint32_t)atoi(e) : 3u; }(); // bit 0: at the end of a wave's work, bit 1: whenever a tail generation has thinned out
 		a.reteam = reteam;
-		static const uint32_t steal = []() { const char* e = getenv("NRS_STEAL"); return e ? (uint32_t)atoi(e) : 1u; }();
+		static const uint32_t steal = []() { const char* e = dev_knob("NRS_STEAL"); return e ? (uint32_t)atoi(e) : 1u; }();
 		a.steal = ctx->handover >= 0 ? (uint32_t)ctx->handover : steal;
 		if (((small_launch && !forced && hybrid_on) || forced == -2 || forced == -3 || forced == -4) && !one_lane_only) {
 			// few rays for the GPU: 4x4 packets only, and every generation takes ALL the rays its wave has pending with as many
@@ -1528,7 +1528,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 			a.all_tail = 1;
 			a.fill_lanes = forced == -4 ? 1u : (forced == -3 ? 2u : (forced == -2 ? 4u : fill_lanes));
 			NRS_TRY(tile_geometry(*p, a.fill_lanes, a.tiles_x, owned_tiles, a.n_packets, a.packets_per_tile_x));
-			static const uint32_t all_tail_target = []() { const char* e = getenv("NRS_ALLTAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)std::min(atoi(e), 64) : 16u; }(); // (<= kRing - 64, as above)
+			static const uint32_t all_tail_target = []() { const char* e = dev_knob("NRS_ALLTAIL_TARGET"); return e && atoi(e) >= 1 ? (uint32_t)std::min(atoi(e), 64) : 16u; }(); // (<= kRing - 64, as above)
 			a.tail_target = all_tail_target;
 		} else if (team > 1 && (forced > 0 || p->tile_size != 0 || !hybrid_on)) {
 			a.team = team;
@@ -1537,11 +1537,11 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 			// whole images with more rays than the small-launch schedule is for: hybrid (one lane per ray, lane teams for the tail of the queue)
 			// hybrid: every 3rd packet row leaves the 8x8 list and joins the end of the queue as 4x4 tail packets (packet_pixel_bulk/_tail);
 			// measured on 1080p lego + cage, every 2nd / 3rd / 4th / 6th / 8th / 16th row: 8.88 / 8.89 / 8.79 / 8.75 / 8.65 / 8.65 Gsamples/s
-			static const uint32_t tail_every = []() { const char* e = getenv("NRS_TAIL_EVERY"); return e && atoi(e) >= 2 ? (uint32_t)atoi(e) : 3u; }();
+			static const uint32_t tail_every = []() { const char* e = dev_knob("NRS_TAIL_EVERY"); return e && atoi(e) >= 2 ? (uint32_t)atoi(e) : 3u; }();
 			const uint32_t rows = ((uint32_t)p->resolution[1] + 7u) / 8u, tail_rows = rows / tail_every;
 			a.tail_every = tail_every;
 			if (tail_rows) {
-				static const uint32_t tail_fill = []() { const char* e = getenv("NRS_TAIL_FILL"); return e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4) ? (uint32_t)atoi(e) : 4u; }();
+				static const uint32_t tail_fill = []() { const char* e = dev_knob("NRS_TAIL_FILL"); return e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4) ? (uint32_t)atoi(e) : 4u; }();
 				a.team = 0;
 				a.fill_lanes = tail_fill; // lanes on a pixel while a tail packet is filled: packets of 4x4 / 8x4 / 8x8 pixels (packet_pixel_tail)
 				a.p_big = (rows - tail_rows) * a.tiles_x;
@@ -1596,7 +1596,7 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 			// per-wave log: when did each wave finish (wall clock), when did it first find the frame's queue empty
 			std::vector<unsigned long long> wl(8192 * 4);
 			HIP_TRY(hipMemcpy(wl.data(), ctx->d_wave_log, wl.size() * 8, hipMemcpyDeviceToHost));
-			if (const char* dump = getenv("NRS_WAVE_LOG_FILE")) { // raw log of the LAST launch with statistics, for tools/wave_log_report.py
+			if (const char* dump = dev_knob("NRS_WAVE_LOG_FILE")) { // raw log of the LAST launch with statistics, for tools/wave_log_report.py
 				if (FILE* f = fopen(dump, "wb")) { fwrite(wl.data(), 8, wl.size(), f); fclose(f); }
 			}
 			std::vector<std::array<unsigned long long, 4>> rec; // {end tick (10 ns), rounds | rounds before queue-empty << 16 | t_queue_empty << 32, packets, xcc}

@@ -5,7 +5,17 @@
 #include <stddef.h>
 #include "../../include/nrs.h"
 
+#include <stdlib.h>
+
 namespace nrs {
+
+// Measurement knobs (NRS_DEBUG, NRS_TEAM, NRS_RENDER_CFG, NRS_TAIL_*, NRS_RETEAM, NRS_STEAL, the logs ...) are read from the environment ONLY when NRS_DEV_KNOBS is
+// set: a production process ignores them.  The two documented overrides -- NRS_CELL_CACHE_GB (nrs.h) and NRS_RCCL_LIB (the RCCL test double, announced
+// on stderr) -- are not knobs of this kind.  tools/*.sh and the probes set NRS_DEV_KNOBS=1.
+inline const char* dev_knob(const char* name) {
+	static const bool on = []() { const char* e = getenv("NRS_DEV_KNOBS"); return e && e[0] && e[0] != '0'; }();
+	return on ? getenv(name) : nullptr;
+}
 
 constexpr uint32_t kGrid = 128;                  // NERF_GRIDSIZE
 constexpr uint32_t kCascades = 5;                // NERF_CASCADES

@@ -1158,7 +1158,7 @@ static int launch_render_c128(const DeviceModel& m, const RenderArgs& a, int n_c
 	const uint32_t max_useful = (a.n_packets + WAVES - 1) / WAVES; // at least one packet per wave
 	if (grid > max_useful) grid = max_useful;
 	if (grid == 0) return NRS_OK;
-	static const bool log_kernel = getenv("NRS_KERNEL_LOG") != nullptr;
+	static const bool log_kernel = dev_knob("NRS_KERNEL_LOG") != nullptr;
 	if (log_kernel) fprintf(stderr, "[nrs kernel] render_kernel_c128<%d, team %d>\n", WAVES, TEAM);
 	hipLaunchKernelGGL((render_kernel_c128<WAVES, PROF, POISSON, AFFINE, TEAM, NUM>), dim3(grid), dim3(64 * WAVES), 0, stream, m, a);
 	NRS_LAUNCH_CHECK("render_kernel launch");
@@ -1167,7 +1167,7 @@ static int launch_render_c128(const DeviceModel& m, const RenderArgs& a, int n_c
 
 template <int WAVES, int OCC, bool PROF = false, bool POISSON = false, bool AFFINE = false, int TEAM = 1, int NUM = 0, int EXTRA = 0>
 static int launch_render_cfg(const DeviceModel& m, const RenderArgs& a, int n_cus, hipStream_t stream) {
-	static const bool log_kernel = getenv("NRS_KERNEL_LOG") != nullptr;
+	static const bool log_kernel = dev_knob("NRS_KERNEL_LOG") != nullptr;
 	if (log_kernel) fprintf(stderr, "[nrs kernel] render_kernel<%d, %d, prof %d, poisson %d, affine %d, team %d, num %d, extra %d>\n", WAVES, OCC, (int)PROF, (int)POISSON, (int)AFFINE, TEAM, NUM, (int)EXTRA);
 	int blocks_per_cu = 0;
 	hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<WAVES, OCC, PROF, POISSON, AFFINE, TEAM, NUM, EXTRA>, 64 * WAVES, 0);
@@ -1186,7 +1186,7 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 	// launch shape: tuned default; NRS_RENDER_CFG = <waves per workgroup><waves per SIMD> (e.g. "84") overrides it for
 	// the A/B measurements recorded under profiles/
 	static const int cfg = []() {
-		const char* e = getenv("NRS_RENDER_CFG");
+		const char* e = dev_knob("NRS_RENDER_CFG");
 		return e ? atoi(e) : 0;
 	}();
 	hipStream_t s = (hipStream_t)stream;
@@ -2293,7 +2293,7 @@ int launch_grid_update(const DeviceModel& m, const DeviceEdit* d_edits, int n_ed
 	a.rng_state = u.rng_state;
 	a.rng_inc = u.rng_inc;
 	a.rng_state_nonuniform = rng_state_nonuniform;
-	static const uint32_t cell_order = []() { const char* e = getenv("NRS_REFRESH_ORDER"); return e ? (uint32_t)atoi(e) : 1u; }();
+	static const uint32_t cell_order = []() { const char* e = dev_knob("NRS_REFRESH_ORDER"); return e ? (uint32_t)atoi(e) : 1u; }();
 	a.cell_order = cell_order;
 	const uint32_t n = a.n_uniform + a.n_nonuniform;
 	if (n > 0) {

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of libnrs builds on one box: tools/ab_bench.sh <out file> <workload> <name=path-or-"default"> ...   (run through gpurun)
 # Each build runs bench.py twice, interleaved (A B C A B C), to see the box's own noise.
+export NRS_DEV_KNOBS=1  # the measurement knobs of libnrs are ignored without it (nrs_internal.h: dev_knob)
 out=$1; wl=$2; shift 2
 : > $out
 for rep in 1 2; do

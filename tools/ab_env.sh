@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of ONE library under different environments: tools/ab_env.sh <out> <workload> "NAME=ENVVAR=VALUE" ...  (interleaved, two repetitions)
+export NRS_DEV_KNOBS=1  # the measurement knobs of libnrs are ignored without it (nrs_internal.h: dev_knob)
 out=$1; wl=$2; shift 2
 : > $out
 for rep in 1 2; do

@@ -1,4 +1,5 @@
 # usage: tools/noise_sweep.sh -> gpurun_out/noise_sweep.txt : the varied-opacity workload at several density-noise amplitudes (Gsamples/s, lanes busy, wave balance)
+export NRS_DEV_KNOBS=1  # the measurement knobs of libnrs are ignored without it (nrs_internal.h: dev_knob)
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/noise_sweep.txt
 : > $OUT

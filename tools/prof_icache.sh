@@ -1,4 +1,5 @@
 # instruction-fetch / scalar-cache / stall counters of the render kernel: tools/prof_icache.sh <workload> <tag>  (through gpurun)
+export NRS_DEV_KNOBS=1  # the measurement knobs of libnrs are ignored without it (nrs_internal.h: dev_knob)
 R=$GRAFT_REPO_ROOT
 W=$1; TAG=$2
 cd /tmp && export TMPDIR=/tmp

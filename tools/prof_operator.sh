@@ -1,4 +1,5 @@
 # usage: tools/prof_operator.sh <tag>  -- rocprofv3 trace + PMC passes of tools/op_driver.py -> gpurun_out/prof_<tag>/summary.md
+export NRS_DEV_KNOBS=1  # the measurement knobs of libnrs are ignored without it (nrs_internal.h: dev_knob)
 R=$GRAFT_REPO_ROOT
 TAG=$1
 cd /tmp && export TMPDIR=/tmp

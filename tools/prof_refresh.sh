@@ -1,3 +1,4 @@
+export NRS_DEV_KNOBS=1  # the measurement knobs of libnrs are ignored without it (nrs_internal.h: dev_knob)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for ORD in 0 1; do

@@ -81,8 +81,8 @@ def main():
     for N in tuple(int(v) for v in os.environ.get("NRS_PROBE_N", "1,2,4,8").split(",")):
         log_path = f"/tmp/nrs_wave_{N}.bin"
         cmd = [sys.executable, os.path.abspath(__file__), "--child", workload, str(N), log_path]
-        prod = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, NRS_DEBUG="0"))
-        prof = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, NRS_DEBUG="4", NRS_WAVE_LOG_FILE=log_path))
+        prod = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, NRS_DEV_KNOBS="1", NRS_DEBUG="0"))
+        prof = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, NRS_DEV_KNOBS="1", NRS_DEBUG="4", NRS_WAVE_LOG_FILE=log_path))
         pl = [l for l in prod.stdout.splitlines() if l.startswith("PROBE")]
         fl = [l for l in prof.stdout.splitlines() if l.startswith("PROBE")]
         if not pl or not fl:
