@@ -71,9 +71,17 @@ def cell_centres(level):
 # Model
 # ----------------------------------------------------------------------------------------------------------------
 def per_level_scale(aabb_scale, base_resolution=16, n_levels=16):
-    """testbed.cu:2288-2292, evaluated in float like the reference."""
+    """testbed.cu:2288-2292: std::exp(std::log(2048.f * aabb_scale / base_resolution) / (n_levels - 1)), every step in float -- through the C library's logf / expf, as
+    the reference (and nrs_snapshot_open) evaluate it: numpy's float32 log / exp are its own SIMD kernels and differ from libm by an ulp for some arguments (aabb_scale 4:
+    found by the snapshot pin of round 5, tests/test_ref_pin.py::test_snapshot_reader_golden)."""
+    import ctypes
+    import ctypes.util
+    libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    libm.logf.restype = libm.expf.restype = ctypes.c_float
+    libm.logf.argtypes = libm.expf.argtypes = [ctypes.c_float]
     v = np.float32(2048.0) * np.float32(aabb_scale) / np.float32(base_resolution)
-    return float(np.exp(np.log(v, dtype=np.float32) / np.float32(n_levels - 1), dtype=np.float32))
+    x = np.float32(libm.logf(ctypes.c_float(float(v)))) / np.float32(n_levels - 1)
+    return float(np.float32(libm.expf(ctypes.c_float(float(x)))))
 
 
 def scene_aabb(aabb_scale):

@@ -83,6 +83,8 @@ FRAGMENTS = [
     ("src/editing/cage_deformation.cu", "cage_deformation_to_json", r"^nlohmann::json CageDeformation::to_json\(\) \{", "fn"),
     ("src/editing/affine_duplication.cu", "affine_duplication_to_json", r"^nlohmann::json AffineDuplication::to_json\(\) \{", "fn"),
     ("src/testbed.cu", "testbed_save_edits", r"^void Testbed::save_edits\(const std::string& filepath_string\) \{", "fn"),
+    ("src/testbed.cu", "merge_parent_network_config", r"^json merge_parent_network_config\(const json& child, const fs::path& child_filename\) \{", "fn"),
+    ("src/testbed.cu", "testbed_save_snapshot", r"^void Testbed::save_snapshot\(const std::string& filepath_string, bool include_optimizer_state\) \{", "fn"),
 ]
 
 

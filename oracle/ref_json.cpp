@@ -8,7 +8,8 @@
 //     tet_mesh.h (to_json / from_json of TetMesh :136-174), cage.h (:100-145), editing/tools/affine_bounding_box.cuh (:105-143);
 //   * member functions cut out of the .cu files by oracle/ref_extract.py (each fragment carries a #line into the reference):
 //     GrowingSelection::to_json (growing_selection.cu:2459-2480), RegionGrowing::to_json (region_growing.cu:187-198), CageDeformation::to_json
-//     (cage_deformation.cu:817-825), AffineDuplication::to_json (affine_duplication.cu:356-369), Testbed::save_edits (testbed.cu:3190-3204).
+//     (cage_deformation.cu:817-825), AffineDuplication::to_json (affine_duplication.cu:356-369), Testbed::save_edits (testbed.cu:3190-3204),
+//     Testbed::save_snapshot (testbed.cu:3090-3113; its trainer and GPU-memory conversions are tiny-cuda-nn's and restated: see there).
 // What is NOT the reference's code: <json/json.hpp> (nlohmann/json is vendored through the empty tiny-cuda-nn submodule: oracle/ref_stubs/json/json.hpp models
 // its conversion dispatch, sorted keys and null-for-untouched values; floats are printed with 17 significant digits where nlohmann prints the shortest
 // round-trip form -- same doubles), <Eigen/Dense>, and the CLASSES the cut-out members belong to: the real GrowingSelection / CageDeformation /
@@ -89,15 +90,52 @@ struct AffineDuplication : EditOperator { // affine_duplication.h:86-95 (the ser
 };
 #include "affine_duplication_to_json.inc"
 
-struct Testbed { // testbed.h:206-208 (NerfTracer::edit_operators) under Testbed::m_nerf.tracer
+// ---- Testbed::save_snapshot (testbed.cu:3090-3113) --------------------------------------------------------------------------------------------------------
+// Compiled: the member function itself (key names under "snapshot", what goes where) and to_json(NerfDataset) (json_binding.h:136-160, whole header).
+// Stand-ins, because tiny-cuda-nn is absent: Trainer::serialize (restated as recalled: {"n_params", "params_type": "__half", "params_binary": the half parameters as
+// a binary value}) and the conversion of the density grid's GPUMemory<float> to json (tiny-cuda-nn's gpu_memory_json.h as recalled: the raw bytes as a binary value).
+// The three keys of the trainer therefore stay UNPINNED; everything else in the file is written by reference code.
+using json = nlohmann::json; // (testbed.cu:77: `using namespace tcnn`, whose `json` is nlohmann::json)
+struct HostBytes { std::vector<uint8_t> bytes; };
+inline void to_json(nlohmann::json& j, const HostBytes& b) { j = nlohmann::json::binary(b.bytes); }
+struct SnapshotTrainer {
+	HostBytes params_half;
+	size_t n_params = 0;
+	nlohmann::json serialize(bool /*serialize_optimizer*/) {
+		nlohmann::json data;
+		data["n_params"] = n_params;
+		data["params_type"] = "__half";
+		data["params_binary"] = params_half;
+		return data;
+	}
+};
+
+#include "merge_parent_network_config.inc" // testbed.cu:86-97: the "parent" chain of configs/nerf/*.json (json::parse with comments, merge_patch)
+
+struct Testbed { // testbed.h:206-208 (NerfTracer::edit_operators) under Testbed::m_nerf.tracer; the members save_snapshot touches (testbed.h:507-640)
 	struct Tracer {
 		std::vector<std::shared_ptr<EditOperator>> m_edit_operators;
 		std::vector<std::shared_ptr<EditOperator>>& edit_operators() { return m_edit_operators; }
 	};
-	struct Nerf { Tracer tracer; } m_nerf;
+	struct Nerf {
+		Tracer tracer;
+		HostBytes density_grid; // tcnn::GPUMemory<float> (testbed.h): 5 * 128^3 floats
+		struct Training {
+			struct Counters { uint32_t rays_per_batch = 1 << 16, measured_batch_size = 0, measured_batch_size_before_compaction = 0; } counters_rgb; // testbed.h:565-573
+			NerfDataset dataset;
+		} training;
+	} m_nerf;
+	nlohmann::json m_network_config;
+	fs::path m_network_config_path;
+	std::shared_ptr<SnapshotTrainer> m_trainer;
+	ETestbedMode m_testbed_mode = ETestbedMode::Nerf;
+	uint32_t m_training_step = 0;
+	float m_loss_scalar = 0.f;
 	void save_edits(const std::string& filepath_string);
+	void save_snapshot(const std::string& filepath_string, bool include_optimizer_state);
 };
 #include "testbed_save_edits.inc"
+#include "testbed_save_snapshot.inc"
 
 NGP_NAMESPACE_END
 
@@ -214,6 +252,35 @@ int refjson_save_edits(const char* path, const RefJsonOp* ops, uint32_t n_ops) {
 			}
 		}
 		tb.save_edits(path);
+		return 0;
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return -1;
+	}
+}
+
+// Testbed::save_snapshot(path) with `config_path` (one of the reference's configs/nerf/*.json, parsed as it lies there) as m_network_config; log2_hashmap_size > 0
+// overrides the encoding's table size (a smaller golden file).  params: n_params halfs; grid: 5 * 128^3 floats.
+int refjson_save_snapshot(const char* path, const char* config_path, int log2_hashmap_size, const uint16_t* params, uint64_t n_params, const float* grid, uint64_t n_grid,
+                          int aabb_scale, uint32_t training_step, float loss) {
+	try {
+		Testbed tb;
+		{ // Testbed::load_network_config's .json branch (testbed.cu:177-181)
+			const fs::path network_config_path = config_path;
+			std::ifstream f{network_config_path.str()};
+			if (!f) { g_err = "cannot open the network config"; return -1; }
+			nlohmann::json result = json::parse(f, nullptr, true, true);
+			tb.m_network_config = merge_parent_network_config(result, network_config_path);
+		}
+		if (log2_hashmap_size > 0) tb.m_network_config["encoding"]["log2_hashmap_size"] = log2_hashmap_size;
+		tb.m_trainer = std::make_shared<SnapshotTrainer>();
+		tb.m_trainer->n_params = (size_t)n_params;
+		tb.m_trainer->params_half.bytes.assign((const uint8_t*)params, (const uint8_t*)params + 2 * n_params);
+		tb.m_nerf.density_grid.bytes.assign((const uint8_t*)grid, (const uint8_t*)grid + 4 * n_grid);
+		tb.m_nerf.training.dataset.aabb_scale = aabb_scale;
+		tb.m_training_step = training_step;
+		tb.m_loss_scalar = loss;
+		tb.save_snapshot(path, false);
 		return 0;
 	} catch (const std::exception& e) {
 		g_err = e.what();

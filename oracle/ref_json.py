@@ -43,6 +43,8 @@ def load():
         _lib.refjson_save_edits.argtypes = [C.c_char_p, C.POINTER(RefJsonOp), C.c_uint32]
         _lib.refjson_reload_edits.restype = C.c_int
         _lib.refjson_reload_edits.argtypes = [C.c_char_p, C.c_char_p]
+        _lib.refjson_save_snapshot.restype = C.c_int
+        _lib.refjson_save_snapshot.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_float]
     return _lib
 
 
@@ -111,3 +113,14 @@ def reload_edits(path, out_path):
     if n < 0:
         raise RuntimeError("refjson_reload_edits: " + lib.refjson_last_error().decode())
     return n
+
+
+def save_snapshot(path, config_path, params_u16, density_grid, aabb_scale, log2_hashmap_size=0, training_step=35000, loss=0.001):
+    """Testbed::save_snapshot (src/testbed.cu:3090-3113) with `config_path` -- one of the reference's configs/nerf/*.json, parsed where it lies -- as the network
+    config.  The trainer's three keys (params_binary / params_type / n_params) and the binary conversion of the density grid are tiny-cuda-nn's, restated in
+    oracle/ref_json.cpp; every other byte of the file comes out of reference code."""
+    lib = load()
+    p = np.ascontiguousarray(params_u16, np.uint16)
+    g = np.ascontiguousarray(density_grid, np.float32)
+    if lib.refjson_save_snapshot(str(path).encode(), str(config_path).encode(), int(log2_hashmap_size), p.ctypes.data, p.size, g.ctypes.data, g.size, int(aabb_scale), int(training_step), float(loss)) != 0:
+        raise RuntimeError("refjson_save_snapshot: " + lib.refjson_last_error().decode())

@@ -13,12 +13,14 @@
 //   * operator[] on null creates an object (string key) or array (index); push_back / emplace_back on null create an array;
 //   * dump(): integers as integers, floats with 17 significant digits (round-trip exact; nlohmann prints the SHORTEST round-trip form -- the text differs, the
 //     parsed doubles are identical), no whitespace, keys in sorted order.  parse(): RFC 8259.
+//   * binary values (json::binary) and to_msgpack() as nlohmann 3.8+ writes it -- for Testbed::save_snapshot's container (oracle/ref_json.cpp).
 #pragma once
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <istream>
 #include <iterator>
 #include <map>
@@ -37,9 +39,18 @@ struct to_json_fn { template <class T> void operator()(json& j, T&& v) const; };
 struct from_json_fn { template <class T> void operator()(const json& j, T& v) const; };
 } // namespace detail
 
+template <class T> struct is_std_vector : std::false_type {};
+template <class T, class A> struct is_std_vector<std::vector<T, A>> : std::true_type {};
+namespace detail {
+// is there a user from_json(const json&, T&) reachable by argument-dependent lookup (T's own namespaces)?  Standard-library types have none.
+template <class T, class = void> struct has_adl_from_json_impl : std::false_type {};
+template <class T> struct has_adl_from_json_impl<T, decltype(from_json(std::declval<const json&>(), std::declval<T&>()), void())> : std::true_type {};
+} // namespace detail
+template <class T> struct has_adl_from_json : detail::has_adl_from_json_impl<T> {};
+
 class json {
 public:
-	enum class value_t : uint8_t { null, object, array, string, boolean, number_integer, number_unsigned, number_float };
+	enum class value_t : uint8_t { null, object, array, string, boolean, number_integer, number_unsigned, number_float, binary };
 	typedef std::vector<json> array_t;
 	typedef std::vector<std::pair<std::string, json>> object_t; // kept sorted by key
 	typedef std::size_t size_type;
@@ -54,6 +65,9 @@ public:
 	json(T&& v) { detail::to_json_fn{}(*this, std::forward<T>(v)); }
 
 	static json array() { json j; j.t = value_t::array; return j; }
+	static json binary(std::vector<uint8_t> bytes) { json j; j.t = value_t::binary; j.s.assign(bytes.begin(), bytes.end()); return j; } // (nlohmann::json::binary: a byte container)
+	bool is_binary() const { return t == value_t::binary; }
+	const std::string& raw_binary() const { return s; }
 	static json object() { json j; j.t = value_t::object; return j; }
 
 	value_t type() const { return t; }
@@ -125,8 +139,9 @@ public:
 
 	// ---- conversions out ----
 	template <class T> T get() const { T v{}; detail::from_json_fn{}(*this, v); return v; }
-	template <class T, typename = typename std::enable_if<!std::is_pointer<T>::value && !std::is_same<T, json>::value && !std::is_same<T, std::nullptr_t>::value &&
-	                                                       !std::is_same<T, char>::value && !std::is_same<T, std::initializer_list<char>>::value>::type>
+	// (as nlohmann constrains it: only to types a from_json exists for, so that `std::string(j)` sees ONE viable constructor)
+	template <class T, typename = typename std::enable_if<std::is_arithmetic<T>::value || std::is_enum<T>::value || std::is_same<T, std::string>::value ||
+	                                                       is_std_vector<T>::value || (std::is_class<T>::value && !std::is_same<T, json>::value && has_adl_from_json<T>::value)>::type>
 	operator T() const { return get<T>(); }
 	template <class T> T value(const std::string& key, const T& dflt) const { return contains(key) ? at(key).template get<T>() : dflt; }
 	std::string value(const std::string& key, const char* dflt) const { return contains(key) ? at(key).get<std::string>() : std::string(dflt); }
@@ -156,6 +171,37 @@ public:
 
 	// ---- text ----
 	std::string dump(int /*indent*/ = -1) const { std::string out; dump_to(out); return out; }
+	// parse(stream, callback, allow_exceptions, ignore_comments) as load_network_config calls it (testbed.cu:93, :179): // and /* */ comments are skipped
+	static json parse(std::istream& is, std::nullptr_t = nullptr, bool /*allow_exceptions*/ = true, bool ignore_comments = false) {
+		std::string text((std::istreambuf_iterator<char>(is)), std::istreambuf_iterator<char>());
+		if (ignore_comments) {
+			std::string out;
+			bool in_string = false;
+			for (size_t k = 0; k < text.size(); ++k) {
+				const char c = text[k];
+				if (in_string) { out += c; if (c == '\\' && k + 1 < text.size()) out += text[++k]; else if (c == '"') in_string = false; continue; }
+				if (c == '"') { in_string = true; out += c; continue; }
+				if (c == '/' && k + 1 < text.size() && text[k + 1] == '/') { while (k < text.size() && text[k] != '\n') ++k; out += '\n'; continue; }
+				if (c == '/' && k + 1 < text.size() && text[k + 1] == '*') { k += 2; while (k + 1 < text.size() && !(text[k] == '*' && text[k + 1] == '/')) ++k; ++k; out += ' '; continue; }
+				out += c;
+			}
+			text.swap(out);
+		}
+		return parse(text);
+	}
+	// RFC 7386, as nlohmann::json::merge_patch: objects merge key by key, a null value removes the key, anything else replaces
+	void merge_patch(const json& patch) {
+		if (!patch.is_object()) { *this = patch; return; }
+		if (!is_object()) *this = object();
+		for (const auto& kv : patch.o) {
+			if (kv.second.is_null()) {
+				auto it = std::lower_bound(o.begin(), o.end(), kv.first, [](const std::pair<std::string, json>& e, const std::string& k) { return e.first < k; });
+				if (it != o.end() && it->first == kv.first) o.erase(it);
+			} else {
+				(*this)[kv.first].merge_patch(kv.second);
+			}
+		}
+	}
 	static json parse(const std::string& text) {
 		size_t p = 0;
 		json j = parse_value(text, p, 0);
@@ -163,6 +209,10 @@ public:
 		if (p != text.size()) throw std::runtime_error("json: trailing characters");
 		return j;
 	}
+	// nlohmann::json::to_msgpack (binary_writer::write_msgpack, 3.8+): the smallest integer encoding, float32 when the double is exactly a float (else float64),
+	// maps with their keys in sorted order, bin 8 / 16 / 32 for binary values.
+	static void to_msgpack(const json& j, std::ostream& os) { std::string out; j.msgpack_to(out); os.write(out.data(), (std::streamsize)out.size()); }
+	static std::vector<uint8_t> to_msgpack(const json& j) { std::string out; j.msgpack_to(out); return std::vector<uint8_t>(out.begin(), out.end()); }
 	friend std::ostream& operator<<(std::ostream& os, const json& j) { return os << j.dump(); }
 	friend std::istream& operator>>(std::istream& is, json& j) {
 		std::string text((std::istreambuf_iterator<char>(is)), std::istreambuf_iterator<char>());
@@ -175,7 +225,7 @@ public:
 		switch (x.t) {
 		case value_t::null: return true;
 		case value_t::boolean: return x.b == y.b;
-		case value_t::string: return x.s == y.s;
+		case value_t::string: case value_t::binary: return x.s == y.s;
 		case value_t::array: return x.a == y.a;
 		case value_t::object: return x.o == y.o;
 		default: return false;
@@ -195,6 +245,60 @@ private:
 	array_t a;
 	object_t o;
 
+	static void be(std::string& out, uint64_t v, int n) { for (int k = n - 1; k >= 0; --k) out += (char)((v >> (8 * k)) & 0xff); }
+	static void msgpack_uint(std::string& out, uint64_t v) {
+		if (v <= 0x7f) out += (char)v;
+		else if (v <= 0xff) { out += (char)0xcc; be(out, v, 1); }
+		else if (v <= 0xffff) { out += (char)0xcd; be(out, v, 2); }
+		else if (v <= 0xffffffffull) { out += (char)0xce; be(out, v, 4); }
+		else { out += (char)0xcf; be(out, v, 8); }
+	}
+	void msgpack_to(std::string& out) const {
+		switch (t) {
+		case value_t::null: out += (char)0xc0; break;
+		case value_t::boolean: out += (char)(b ? 0xc3 : 0xc2); break;
+		case value_t::number_unsigned: msgpack_uint(out, u); break;
+		case value_t::number_integer:
+			if (i >= 0) msgpack_uint(out, (uint64_t)i);
+			else if (i >= -32) out += (char)(int8_t)i;
+			else if (i >= -128) { out += (char)0xd0; be(out, (uint64_t)i, 1); }
+			else if (i >= -32768) { out += (char)0xd1; be(out, (uint64_t)i, 2); }
+			else if (i >= -2147483648ll) { out += (char)0xd2; be(out, (uint64_t)i, 4); }
+			else { out += (char)0xd3; be(out, (uint64_t)i, 8); }
+			break;
+		case value_t::number_float: {
+			const float as_float = (float)f;
+			if ((double)as_float == f) { uint32_t w; memcpy(&w, &as_float, 4); out += (char)0xca; be(out, w, 4); }
+			else { uint64_t w; memcpy(&w, &f, 8); out += (char)0xcb; be(out, w, 8); }
+			break;
+		}
+		case value_t::string:
+			if (s.size() <= 31) out += (char)(0xa0 | s.size());
+			else if (s.size() <= 0xff) { out += (char)0xd9; be(out, s.size(), 1); }
+			else if (s.size() <= 0xffff) { out += (char)0xda; be(out, s.size(), 2); }
+			else { out += (char)0xdb; be(out, s.size(), 4); }
+			out += s;
+			break;
+		case value_t::binary:
+			if (s.size() <= 0xff) { out += (char)0xc4; be(out, s.size(), 1); }
+			else if (s.size() <= 0xffff) { out += (char)0xc5; be(out, s.size(), 2); }
+			else { out += (char)0xc6; be(out, s.size(), 4); }
+			out += s;
+			break;
+		case value_t::array:
+			if (a.size() <= 15) out += (char)(0x90 | a.size());
+			else if (a.size() <= 0xffff) { out += (char)0xdc; be(out, a.size(), 2); }
+			else { out += (char)0xdd; be(out, a.size(), 4); }
+			for (const json& e : a) e.msgpack_to(out);
+			break;
+		case value_t::object:
+			if (o.size() <= 15) out += (char)(0x80 | o.size());
+			else if (o.size() <= 0xffff) { out += (char)0xde; be(out, o.size(), 2); }
+			else { out += (char)0xdf; be(out, o.size(), 4); }
+			for (const auto& kv : o) { json(kv.first).msgpack_to(out); kv.second.msgpack_to(out); }
+			break;
+		}
+	}
 	static void dump_string(const std::string& v, std::string& out) {
 		out += '"';
 		for (unsigned char c : v) {
@@ -227,6 +331,7 @@ private:
 			if (!strpbrk_any(buf)) out += ".0"; // nlohmann keeps a float recognisable as one ("1.0", not "1")
 			break;
 		case value_t::string: dump_string(s, out); break;
+		case value_t::binary: out += "{\"bytes\":["; for (size_t k = 0; k < s.size(); ++k) { if (k) out += ','; out += std::to_string((unsigned)(unsigned char)s[k]); } out += "],\"subtype\":null}"; break;
 		case value_t::array:
 			out += '[';
 			for (size_t k = 0; k < a.size(); ++k) { if (k) out += ','; a[k].dump_to(out); }

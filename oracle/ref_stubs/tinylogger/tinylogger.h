@@ -3,3 +3,10 @@
 #include <iostream>
 #include <string>
 #include <vector>
+namespace tlog { // (round 5: merge_parent_network_config logs the parent's path through tlog::info(); swallowed)
+struct Sink { template <class T> Sink& operator<<(const T&) { return *this; } };
+inline Sink info() { return Sink(); }
+inline Sink warning() { return Sink(); }
+inline Sink success() { return Sink(); }
+inline Sink error() { return Sink(); }
+} // namespace tlog

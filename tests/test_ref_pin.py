@@ -281,3 +281,77 @@ def test_harness_writer_is_read_by_the_reference_live(scene, tmp_path):
         x, y = getattr(a[0], name), getattr(b[0], name)
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32)) and np.array_equal(x, getattr(scene.edit, name)), name
     assert bytes(a[1]) == bytes(b[1]) == bytes(ad)
+
+
+# ---- snapshot container and keys: nrs_snapshot_open against a file written by the REFERENCE's Testbed::save_snapshot over its own configs/nerf/*.json ---------------
+# (oracle/ref_json.cpp: save_snapshot, merge_parent_network_config and to_json(NerfDataset) are the reference's code; Trainer::serialize's three keys and the binary
+# conversions are tiny-cuda-nn's, restated there -- those stay unpinned.)  Golden: tests/golden/ref_snapshot_golden.msgpack.gz + .npz, make_ref_snapshot_golden.py.
+def _load_snapshot_golden_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_ref_snapshot_golden", os.path.join(os.path.dirname(__file__), "golden", "make_ref_snapshot_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    return mk
+
+
+def _check_snapshot(s, params, idx, val, per_level_scale, log2_t, aabb_scale):
+    d = s.desc
+    assert (d.n_levels, d.n_features_per_level, d.log2_hashmap_size, d.base_resolution) == (16, 2, log2_t, 16)          # configs/nerf/base.json:23-29
+    assert (d.n_neurons, d.density_hidden_layers, d.density_output_dims, d.rgb_hidden_layers, d.sh_degree) == (64, 1, 16, 2, 4)
+    assert np.float32(d.per_level_scale) == np.float32(per_level_scale)                                                 # derived on load (testbed.cu:2280-2292)
+    assert s.aabb_scale == aabb_scale                                                                                   # snapshot.nerf.dataset.aabb_scale (json_binding.h:154)
+    assert np.array_equal(s.params, params)
+    grid = np.zeros(5 * 128 ** 3, np.float32)
+    grid[idx] = val
+    assert np.array_equal(s.density_grid.view(np.uint32), grid.view(np.uint32))
+    assert s.camera is None                                                                                             # save_snapshot stores no camera (export_snapshot does)
+
+
+def test_snapshot_reader_golden(built, tmp_path):
+    import gzip
+    from nerfshop_amd import formats
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    path = tmp_path / "ref_snapshot.msgpack"
+    path.write_bytes(gzip.open(os.path.join(gdir, "ref_snapshot_golden.msgpack.gz"), "rb").read())
+    g = np.load(os.path.join(gdir, "ref_snapshot_golden.npz"))
+    _check_snapshot(formats.load_snapshot(path), g["params"], g["grid_idx"], g["grid_val"], g["per_level_scale"], 12, 4)
+
+
+@ref_json_live
+def test_snapshot_reader_live(built, tmp_path):
+    """The golden file is what the reference's code writes today, byte for byte; and EVERY config of the reference's configs/nerf/ -- parsed where it lies, through the
+    reference's own parent chain -- is either read back as the network it describes or refused as outside the path (NRS_ERR_UNSUPPORTED), never misread."""
+    import ctypes as C
+    import gzip
+    from nerfshop_amd import _abi, formats, synth
+    from oracle import ref_json
+    mk = _load_snapshot_golden_module()
+    desc, params, idx, val = mk.inputs()
+    path = tmp_path / "live.msgpack"
+    ref_json.save_snapshot(path, mk.CONFIG, params, mk.grid_from(idx, val), mk.AABB_SCALE, log2_hashmap_size=mk.LOG2_T, training_step=12345, loss=0.0123)
+    assert path.read_bytes() == gzip.open(os.path.join(os.path.dirname(__file__), "golden", "ref_snapshot_golden.msgpack.gz"), "rb").read()
+    _check_snapshot(formats.load_snapshot(path), params, idx, val, desc.per_level_scale, mk.LOG2_T, mk.AABB_SCALE)
+
+    cfg_dir = "/root/reference/configs/nerf"
+    # (density hidden layers, rgb hidden layers, sh degree) of the members of base.json's family; None = an encoding / network the path does not render
+    expect = {"base.json": (1, 2, 4), "hashgrid.json": (1, 2, 4), "small.json": (1, 2, 4), "base_14.json": (1, 2, 4), "big.json": (1, 2, 4), "base_2layer.json": (1, 2, 4),
+              "base_0layer.json": (1, 0, 4), "base_1layer.json": (1, 1, 4), "base_3layer.json": (1, 3, 4), "linear.json": (0, 0, 4), "base_nodir.json": (1, 0, 0),
+              "frequency.json": None, "densegrid.json": None, "densegrid_1res.json": None, "tensor.json": None, "none.json": None}
+    assert sorted(os.listdir(cfg_dir)) == sorted(expect), "a config this test does not know"
+    grid = np.zeros(5 * 128 ** 3, np.float32)
+    lib = _abi.load()
+    for name, arch in expect.items():
+        out = tmp_path / (name + ".msgpack")
+        if arch is None:
+            ref_json.save_snapshot(out, os.path.join(cfg_dir, name), np.zeros(64, np.uint16), grid, 1)
+            with pytest.raises(_abi.NrsError) as ei:
+                formats.load_snapshot(out)
+            assert "nrs error -2" in str(ei.value), (name, str(ei.value))
+            continue
+        d = synth.model_desc(1, log2_hashmap_size=12, density_hidden_layers=arch[0], rgb_hidden_layers=arch[1], no_dir=arch[2] == 0)
+        n = lib.nrs_model_n_params(C.byref(d))
+        p = (np.arange(n) % 0x7bff).astype(np.uint16)
+        ref_json.save_snapshot(out, os.path.join(cfg_dir, name), p, grid, 1, log2_hashmap_size=12)
+        s = formats.load_snapshot(out)
+        assert (s.desc.density_hidden_layers, s.desc.rgb_hidden_layers, s.desc.sh_degree, s.desc.log2_hashmap_size) == (arch[0], arch[1], arch[2], 12), name
+        assert np.array_equal(s.params, p), name
