@@ -433,7 +433,10 @@ __device__ __forceinline__ float coarse_safe_until(const DeviceModel& m, const u
 // from its own stop in that cell, included -- selects the same u: u IS the reference's next stop, and the walk goes on from it bit for bit.  If a lattice point
 // sits inside the band (about 1 % of the jumps), or anything else is unusual (a tie, a sub-normal, the stretch leaves the unit cube where the cascade could
 // change), the function declines and the ordinary lean walk runs.  The (t, dt) streams stay bit-identical to the oracle's cell-by-cell walk (tests/test_gpu_parity.py).
-constexpr uint32_t kJumpMinSteps = 14u; // (a cell is 4.6 steps; the jump costs about two cells of lean walk)
+#ifndef NRS_JUMP_MIN
+#define NRS_JUMP_MIN 14u
+#endif
+constexpr uint32_t kJumpMinSteps = NRS_JUMP_MIN; // (a cell is 4.6 steps; the jump costs about two cells of lean walk)
 __device__ __forceinline__ bool lattice_jump(f3 o, f3 d, f3 idir, float t_safe, uint32_t mip, float& t) {
 	// (Straight-line: every condition is folded into one predicate and the candidate is computed whether or not it will be taken -- nested early exits cost this
 	// kernel scalar registers for the saved execution masks.  And written with VOP2-encodable literals: a literal operand of a three-source instruction needs a
@@ -524,7 +527,13 @@ __device__ __forceinline__ bool lattice_jump(f3 o, f3 d, f3 idir, float t_safe, 
 // with a full test each, until it left the occupied bounds; a few cells on, nothing is marked ahead any more and it can be
 // retired at once (or lean-walked to the next marked block).  Measured (Gsamples/s, lego + cage edit; ms for a 64x40-pixel
 // frame): once per walk 9.0 / 0.84, every 3rd cell 9.43 / 0.58, 6th 9.92 / 0.56, 10th 9.80 / 0.55, 16th 9.82 / 0.58, 32nd 9.54 / 0.65.
-constexpr int kLookEvery = 6;
+#ifndef NRS_JUMP_SPAN
+#define NRS_JUMP_SPAN 0.06f
+#endif
+#ifndef NRS_LOOK_EVERY
+#define NRS_LOOK_EVERY 6
+#endif
+constexpr int kLookEvery = NRS_LOOK_EVERY;
 // NRS_OPT_LATTICE_JUMP (round 5): the lean walk in O(1) for constant steps -- lattice_jump above.
 #ifndef NRS_OPT_LATTICE_JUMP
 #define NRS_OPT_LATTICE_JUMP 1
@@ -660,7 +669,7 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 				// (tried in EVERY pass of the lean walk, not once in front of it: a lane that declines -- a lattice point in the guard band, the end of a binade, the
 				// entry point on the cube's face -- takes one ordinary step and tries again from there; a wave is as slow as its slowest lane, and one lane in a
 				// hundred walking the whole stretch cell by cell would keep most waves waiting)
-				if (JUMP && cone == 0.f && t_safe - t > 0.06f /* 22 steps + the margin: nothing to gain below */ && lattice_jump(o, d, idir, t_safe, mip, t)) {
+				if (JUMP && cone == 0.f && t_safe - t > NRS_JUMP_SPAN /* 22 steps + the margin: nothing to gain below */ && lattice_jump(o, d, idir, t_safe, mip, t)) {
 					if (n_iter) ++*n_iter;
 					pos = o + d * t;
 					dt = calc_dt(t, cone);
