@@ -24,3 +24,20 @@ for k in range(300):
     bad += 0 if ok else 1
     rays += W * H; hit += int((c_ref > 0).sum())
 print(f"soak: {300} cameras, {rays} rays, {hit} with samples, cameras with ANY differing bit: {bad}")
+
+# ---- whole frames: the per-round walk of the render kernel (its own copy of the jump), per-pixel sample counts against the oracle
+worst, off = 1.0, 0
+for k in range(120):
+    if k % 40 == 0:
+        rig.use_edit(k % 80 == 0)
+    az, el = float(rng.uniform(0, 360)), float(rng.uniform(-85, 85))
+    if k % 8 == 0:
+        az, el = float(rng.choice([0, 90, 180, 270])) + float(rng.normal(0, 0.01)), float(rng.normal(0, 0.01))
+    p = scene.synth.render_params(W, H, scene.synth.orbit_camera(az, el, scale=0.33), snap=True)
+    frame, depth, steps, stats = rig.render(p)
+    edits = [scene.oracle_edit] if rig.testbed.edit_operators else []
+    ref_frame, ref_depth, ref_steps, ref_stats = scene.oracle_model.render(p, edits)
+    ds = np.abs(steps.astype(np.int64) - ref_steps.astype(np.int64))
+    off += int(ds.max() > 1) + int(stats.n_rays_alive != ref_stats.n_alive0)
+    worst = min(worst, float((ds == 0).mean()))
+print(f"soak: 120 frames, frames with a pixel more than one sample apart or a different ray count: {off}; smallest share of pixels with equal sample counts: {worst:.6f}")
