@@ -1,7 +1,8 @@
 """Soak of the lattice jump (nrs_device.cuh): the first samples of every pixel of 300 random cameras (a tenth of them within a hundredth of a degree of a coordinate
 axis), 11 M rays, bit for bit against the oracle's cell-by-cell walk.  Too long for the test tier (tests/test_gpu_lattice_jump.py is its short form); run through gpurun:
     python tools/lattice_soak.py
-Round 5's run: 11 059 200 rays, 5 028 799 with samples, cameras with any differing bit: 0."""
+Round 5's run: 11 059 200 rays, 5 028 799 with samples, cameras with any differing bit: 0; then 120 whole frames (the render kernel's per-round walk): none with a
+pixel more than one sample apart or a different ray count, smallest share of pixels with equal sample counts 0.999946."""
 import sys, os, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
 import torch
