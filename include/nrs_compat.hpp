@@ -223,7 +223,8 @@ public:
 	void render_nerf(NerfNetwork& network, RenderBuffer& render_buffer, const int /*max_res*/[2], const float focal_length[2],
 	                 const float camera_matrix0[12], const float camera_matrix1[12], const float rolling_shutter[4], const float screen_center[2],
 	                 bool apply_operators, void* stream, nrs_render_stats* stats = nullptr) {
-		nrs_render_params p = NRS_RENDER_PARAMS_INIT;
+		nrs_render_params p{}; // = NRS_RENDER_PARAMS_INIT, spelled so that -Wextra stays quiet in C++
+		p.struct_size = (uint32_t)sizeof(nrs_render_params);
 		p.resolution[0] = render_buffer.width;
 		p.resolution[1] = render_buffer.height;
 		for (int i = 0; i < 2; ++i) { p.focal_length[i] = focal_length[i]; p.screen_center[i] = screen_center[i]; }
@@ -234,7 +235,7 @@ public:
 		p.snap_to_pixel_centers = m_snap_to_pixel_centers;
 		p.min_transmittance = m_nerf.rendering_min_transmittance;
 		p.cone_angle_constant = m_nerf.cone_angle_constant;
-		p.render_mode = m_visualized_dimension > -1 ? (uint32_t)NRS_RENDER_ENCODING_VIS : m_render_mode; // testbed_nerf.cu:3072
+		p.render_mode = m_visualized_dimension > -1 ? (uint32_t)NRS_RENDER_ENCODING_VIS : (uint32_t)m_render_mode; // testbed_nerf.cu:3072
 		p.visualized_layer = (uint32_t)m_visualized_layer;
 		p.visualized_dimension = m_visualized_dimension > -1 ? (uint32_t)m_visualized_dimension : 0u;
 		p.linear_colors = m_nerf.training_linear_colors;
