@@ -146,6 +146,79 @@ def cpu_baseline(synth, scene=None):
             "one_thread": {"value": round(s1 / t1 / 1e6, 4), "unit": "Msamples/s", "sample": f"64x64 view of the same camera, {s1} samples in {t1:.2f} s"}}
 
 
+def next_rows(rt, synth, ctx, torch):
+    """SURVEY 8(f)'s "next" rows re-measured on THIS build (the code of profiles/bench_next_rows.py and tools/op_driver.py): the per-gizmo-move
+    chain `nrs_edit_update_cage` (MVC apply + bbox + cell -> tet LUT + rotations + plane records; tet_mesh.cu:368-673) at 6 k and 48 k tets, the deformed-space occupancy
+    refresh `nrs_model_update_density_grid` (tn:3533-3657) at aabb 1 / 16, and `network_kernel` (NerfNetwork::inference_mixed_precision on a caller's batch) on 2^22
+    ray-ordered and random samples.  ms host-timed over back-to-back calls; `frac` = the row's algorithmic bytes over the time over the 8 TB/s HBM peak (gathers:
+    512 B per sample + the batch's own 28 B in / 32 B out; the cage move: the bytes the chain must write -- LUT offsets, ids, plane records, vertices, rotations)."""
+    rows = {}
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / reps
+
+    desc = synth.model_desc(1)
+    for n in (10, 20):
+        e = synth.make_cage_edit(lattice_n=n)
+        op = rt.CageDeformation(ctx, desc, e, device_authoring=True)
+        op.set_mvc(e.mvc_weights)
+        poses = [synth.deform_cage(e.cage_vertices, (0.10 * k / 10, 0.05, 0.0), 20.0 * k / 10) for k in range(1, 11)]
+        it = iter(range(1 << 30))
+        ms = timed(lambda: op.update_cage(None, poses[next(it) % 10]), 20)
+        n_idx, mx = op.lut_size()
+        n_t, n_v = int(e.tets.shape[0]), int(e.vertices.shape[0])
+        alg = 4 * (5 * 128 ** 3 + 1) + 4 * n_idx + 128 * n_t + 12 * n_v + 36 * n_t  # offsets + ids + plane records + vertices + rotations
+        rows[f"cage_move_{n_t // 1000}k_tets"] = {"ms": round(ms, 3), "tets": n_t, "lut_entries": int(n_idx), "algorithmic_bytes": alg, "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        op.close()
+    N = 1 << 22
+    params = synth.make_params(desc, sigma_raw=synth.default_sigma_raw(1), shaped=True)
+    net = rt.NerfNetwork(ctx, desc)
+    net.set_params(params)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    rnd = torch.rand((N, 7), generator=g, device="cuda", dtype=torch.float32)
+    W, H, S = 2048, 512, 4  # ray-ordered: a 2048 x 512 pinhole image, 4 consecutive steps; sample index = step * n_rays + ray (tn:1023)
+    xs = (torch.arange(W, device="cuda", dtype=torch.float32) + 0.5) / W - 0.5
+    ys = ((torch.arange(H, device="cuda", dtype=torch.float32) + 0.5) / H - 0.5) * (H / W)
+    dirs = torch.stack([xs[None, :].expand(H, W), ys[:, None].expand(H, W), torch.full((H, W), 0.9, device="cuda")], -1).reshape(-1, 3)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    o = torch.tensor([0.5, 0.5, -0.6], device="cuda")
+    t = 0.9 + torch.arange(S, device="cuda", dtype=torch.float32) * (3 ** 0.5 / 1024)
+    ordered = torch.zeros((N, 7), device="cuda", dtype=torch.float32)
+    ordered[:, :3] = (o[None, None, :] + t[:, None, None] * dirs[None, :, :]).reshape(-1, 3).clamp(0.0, 1.0)
+    ordered[:, 3] = 3 ** 0.5 / 1024
+    ordered[:, 4:] = ((dirs + 1) * 0.5).repeat(S, 1)
+    out = torch.zeros((N, 16), device="cuda", dtype=torch.float16)
+    for key, batch in (("network_ray_ordered", ordered), ("network_random", rnd)):
+        ms = timed(lambda: net.inference_mixed_precision(None, batch, out), 6)
+        rows[key] = {"ms": round(ms, 3), "samples": N, "msamples_per_s": round(N / ms / 1e3, 1), "frac": round(N * (BYTES_PER_SAMPLE + 28 + 32) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    net.close()
+    del rnd, ordered, out
+    for aabb_scale, max_cascade in ((1, 0), (16, 4)):
+        d = synth.model_desc(aabb_scale)
+        tb = rt.Testbed(ctx, d, aabb_scale)
+        tb.nerf_network.set_cell_cache(0)  # (a refresh follows a parameter change: a training viewer keeps no records)
+        tb.nerf_network.set_params(synth.make_params(d, sigma_raw=synth.default_sigma_raw(aabb_scale), shaped=True, aabb_scale=aabb_scale))
+        e = synth.make_cage_edit(lattice_n=10, scene_scale=1.0 if aabb_scale == 1 else 6.0)
+        tb.add_edit_operator(rt.CageDeformation(ctx, d, e))
+        u = tb.new_grid_update(max_cascade=max_cascade)
+        u.reset_grid = 1
+        tb.update_density_grid_nerf_operator(u)
+        u.reset_grid = 0
+        ms = timed(lambda: tb.update_density_grid_nerf_operator(u), 6)
+        n_s = 128 ** 3 * (max_cascade + 1)
+        rows[f"occupancy_refresh_aabb{aabb_scale}"] = {"ms": round(ms, 3), "samples": n_s, "msamples_per_s": round(n_s / ms / 1e3, 1),
+                                                       "frac": round(n_s * BYTES_PER_SAMPLE / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del tb
+    torch.cuda.empty_cache()
+    return rows
+
+
 TRAFFIC_FILE = "profiles/r05_traffic.json"
 
 
@@ -504,6 +577,12 @@ def main():
                 extra[name]["l2_misses_per_sample"] = round(tr / 128.0 / (ns / 8), 2)  # every L2 miss is one 128-byte fabric request (profiles/r02_gather_probe.md)
                 extra[name]["traffic_source"] = src
 
+    if rank == 0 and world == 1 and not args.no_extra and args.workload == "lego_cage":
+        try:
+            extra["next_rows"] = next_rows(rt, synth, ctx, torch)
+        except Exception as e:  # (a secondary measurement must not take the headline down)
+            extra["next_rows"] = {"error": f"{type(e).__name__}: {e}"}
+
     n1_ref, gather_leg = None, None
     if world > 1 and not args.no_extra:
         # (VERDICT r4 next #4b) the same run's N = 1 figure: rank 0 renders the WHOLE frames alone, one at a time, while the other ranks wait at the barrier --
@@ -626,6 +705,12 @@ def main():
         if gather_check is not None:
             line["config"]["gather_check"] = gather_check
         line.update(extra)
+        if "lego_cage_varied" in extra:
+            #  the second headline: the varied-opacity scene -- the workload that resembles a trained snapshot (ray lengths spread widely) -- one frame at a
+            # time like `value`, on the same 8 views; `value` keeps its meaning (the uniform lego-like scene BASELINE's target is quoted on)
+            line["value_varied"] = extra["lego_cage_varied"]["msamples_per_s"]
+            line["fps_varied"] = extra["lego_cage_varied"]["fps"]
+            line["roofline_frac_varied"] = extra["lego_cage_varied"]["roofline_frac"]
         if n1_ref is not None:
             # per-GPU sample throughput retained at N GPUs (north_star: >= 0.9 at 8): whole-job Msamples/s / N over this run's own N = 1 figure.  `value` is and stays the
             # one-frame-at-a-time figure (retention_1); retention_2 / _4 are the same frames with 2 / 4 in flight per rank (the `pipelined` / `pipelined4` keys)

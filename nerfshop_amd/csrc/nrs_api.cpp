@@ -1432,7 +1432,11 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	}
 	a.edits = d_edits_slot;
 	{
-		static const uint32_t dbg = []() { const char* e = dev_knob("NRS_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
+		static const uint32_t dbg = []() {
+			const char* e = dev_knob("NRS_DEBUG");
+			const char* sk = dev_knob("NRS_SKIP_PAIRS"); // bit it: level pair (2 it, 2 it + 1) is not gathered (nrs_mlp.cuh: KIND_SKIP; measurement only)
+			return (e ? (uint32_t)atoi(e) & 0xffu : 0u) | (sk ? ((uint32_t)strtoul(sk, nullptr, 0) & 0xffu) << 8 : 0u);
+		}();
 		a.dbg = dbg;
 	}
 	// everything of render_nerf's surface beyond Shade / Cost with a pinhole camera runs the EXTRA instantiation (one lane per ray)
@@ -1593,6 +1597,11 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 			        "(%.1f lanes/trip), %llu of %llu rounds needed > 1 trip; live lanes per round %.1f\n",
 			        c.walk[0], c.walk[1], c.walk[1] ? (double)c.walk[0] / (double)c.walk[1] : 0.0, c.walk[2], c.walk[3],
 			        c.walk[3] ? (double)c.walk[2] / (double)c.walk[3] : 0.0, c.walk[6], c.walk[4], c.walk[4] ? (double)c.walk[5] / (double)c.walk[4] : 0.0);
+			if (c.walk[8])
+				fprintf(stderr, "[nrs cage scan] %llu samples inside a deformed box (%.1f %% of the samples), %llu of them found a tet; rounds with such a sample: %llu of %llu (%.1f %%); "
+				        "candidates tested %llu (%.2f per sample in the box), scan wave trips %llu (%.2f per round that scans)\n",
+				        c.walk[8], 100.0 * (double)c.walk[8] / (double)std::max<unsigned long long>(c.n_samples, 1), c.walk[12], c.walk[9], c.walk[4], 100.0 * (double)c.walk[9] / (double)std::max<unsigned long long>(c.walk[4], 1),
+				        c.walk[10], (double)c.walk[10] / (double)c.walk[8], c.walk[11], (double)c.walk[11] / (double)std::max<unsigned long long>(c.walk[9], 1));
 			// per-wave log: when did each wave finish (wall clock), when did it first find the frame's queue empty
 			std::vector<unsigned long long> wl(8192 * 4);
 			HIP_TRY(hipMemcpy(wl.data(), ctx->d_wave_log, wl.size() * 8, hipMemcpyDeviceToHost));

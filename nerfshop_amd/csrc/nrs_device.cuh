@@ -485,7 +485,9 @@ __device__ __forceinline__ bool lattice_jump(f3 o, f3 d, f3 idir, float t_safe, 
 	float t_new = t;
 	#pragma unroll 1
 	for (uint32_t attempt = 0; attempt < 3u; ++attempt) {
-		const bool in_binade = (bk & 0x7fffffu) >= attempt * back;
+		//  a back-off candidate needs one full increment of room above the binade's start: the first lattice point of a binade can sit q ulps above 2^e,
+		// and bk - 4q could then land ON 2^e, which is not on the lattice
+		const bool in_binade = attempt == 0u || (bk & 0x7fffffu) >= attempt * back + (uint32_t)q_here;
 		const float tk = __uint_as_float(bk - (in_binade ? attempt * back : 0u));
 		const f3 pk = o + d * tk;
 		const float g = tk + distance_to_next_voxel(pk, d, idir, res, inv_res);
@@ -777,7 +779,7 @@ __device__ __forceinline__ bool point_in_tet_rec(const float* __restrict__ recs,
 	return got == __float_as_uint(sg.x);
 }
 // first tet of the cell's list that contains p (0xffffffff: none); the next candidate's id is fetched while the current one is tested
-__device__ __forceinline__ uint32_t scan_cell_for_tet(const DeviceEdit& e, uint32_t cell, f3 p) {
+__device__ __forceinline__ uint32_t scan_cell_for_tet(const DeviceEdit& e, uint32_t cell, f3 p, uint32_t* n_tested = nullptr) {
 	const NRS_GLOBAL uint32_t* lut_off = gp(e.lut_off);
 	const NRS_GLOBAL uint32_t* lut_idx = gp(e.lut_idx);
 	const uint32_t j0 = lut_off[cell], j1 = lut_off[cell + 1];
@@ -787,6 +789,7 @@ __device__ __forceinline__ uint32_t scan_cell_for_tet(const DeviceEdit& e, uint3
 		#pragma unroll 1
 		for (uint32_t j = j0; j < j1; ++j) {
 			const uint32_t t_next = lut_idx[min(j + 1, j1 - 1)];
+			if (n_tested) ++*n_tested; // (profiling instantiation only)
 			if (point_in_tet_rec(e.planes, t, p)) { found = t; break; }
 			t = t_next;
 		}
@@ -806,7 +809,8 @@ __device__ __forceinline__ uint32_t scan_cell_for_tet(const DeviceEdit& e, uint3
 // scan_out (optional): what the tet search found (a tet number or 0xffffffff), kTetNotSearched when the sample is outside the deformed mesh's box -- the membrane
 // correction of the same operator looks for the same tet at the same position (poisson_residual_find) and takes it from here.
 constexpr uint32_t kTetNotSearched = 0xfffffffeu;
-__device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3& wpos, f3& wdir, const uint32_t* __restrict__ march_lds = nullptr, uint32_t* scan_out = nullptr) {
+__device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3& wpos, f3& wdir, const uint32_t* __restrict__ march_lds = nullptr, uint32_t* scan_out = nullptr,
+                                         uint32_t* n_tested = nullptr) {
 	bool in_deformed = false;
 	if (scan_out) *scan_out = kTetNotSearched;
 	if (box_contains(e.warped_bbox, wpos)) {
@@ -814,7 +818,9 @@ __device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3&
 		const int level = mip_from_pos(u);
 		const uint32_t cell = (NRS_OPT_WARP_MORTON && march_lds) ? occupancy_bit_index(u, (uint32_t)level, march_lds)
 		                                                         : (uint32_t)level * kGridVol + cascaded_grid_idx_at(u, (uint32_t)level);
-		const uint32_t found = scan_cell_for_tet(e, cell, u);
+		if (n_tested) *n_tested |= 0x10000u; // (profiling: the sample stands inside the deformed mesh's box; low half = candidates tested)
+		const uint32_t found = scan_cell_for_tet(e, cell, u, n_tested);
+		if (n_tested && found != 0xffffffffu) *n_tested |= 0x20000u;
 		if (scan_out) *scan_out = found;
 		__builtin_amdgcn_sched_barrier(0);
 		if (found != 0xffffffffu) {

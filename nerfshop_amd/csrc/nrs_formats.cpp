@@ -417,17 +417,17 @@ int nrs_snapshot_open(const char* path, nrs_snapshot** out) {
 		if (has_dir) {
 			check_mlp(*rgb, "rgb_network");
 			// configs/nerf/base.json:37-51: Composite[SphericalHarmonics on 3 dims; Identity on the rest] -- or SphericalHarmonics alone
-			const std::string dt = lower(dir->string_or("otype", "Composite"));
+			const std::string dt = lower(dir->string_or("otype", "OneBlob")); // (a missing otype is tiny-cuda-nn's default, OneBlob: refused below, not taken for the supported kind -- ADVICE r5)
 			const Value* first = dir;
 			if (dt == "composite") {
 				const Value* nested = dir->find("nested");
 				if (!nested || nested->kind != Value::Arr || nested->a.empty()) throw Unsupported("dir_encoding: Composite without nested encodings");
 				first = &nested->a[0];
 				for (size_t k = 1; k < nested->a.size(); ++k)
-					if (lower(nested->a[k].string_or("otype", "Identity")) != "identity") throw Unsupported("dir_encoding.nested[" + std::to_string(k) + "]: only Identity may follow the spherical harmonics");
+					if (lower(nested->a[k].string_or("otype", "OneBlob")) != "identity") throw Unsupported("dir_encoding.nested[" + std::to_string(k) + "]: only Identity may follow the spherical harmonics");
 				if ((uint32_t)first->number_or("n_dims_to_encode", 3) != 3u) throw Unsupported("dir_encoding.nested[0].n_dims_to_encode must be 3");
 			} else if (dt != "sphericalharmonics") throw Unsupported("dir_encoding.otype \"" + dir->string_or("otype", "") + "\": only SphericalHarmonics (alone or first in a Composite)");
-			if (lower(first->string_or("otype", "SphericalHarmonics")) != "sphericalharmonics") throw Unsupported("dir_encoding: the view direction must be encoded by SphericalHarmonics");
+			if (lower(first->string_or("otype", "OneBlob")) != "sphericalharmonics") throw Unsupported("dir_encoding: the view direction must be encoded by SphericalHarmonics");
 		}
 		// Light directions (NerfCoordinate::set_with_optional_light_dir, nerf.h:73-93; n_extra_dims = 3 when dataset.has_light_dirs, testbed.cu:2318): three more network
 		// inputs per sample that this path does not carry.  Neither save_snapshot nor the dataset's to_json stores the flag (json_binding.h:136-160), so it is
@@ -561,6 +561,8 @@ int nrs_edits_open(const char* path, nrs_edits** out) {
 				read_vec3_list(cage.at("original_vertices"), c.cage_original_vertices, "proxy_cage.original_vertices");
 				read_u32_list(cage.at("indices"), c.cage_indices, "proxy_cage.indices");
 				c.n_cage_vertices = (uint32_t)(c.cage_vertices.size() / 3);
+				//  nrs_edits_cage hands out both arrays under ONE count: a file whose original_vertices is shorter (or `null` beside a non-empty `vertices`) is refused
+				if (c.cage_original_vertices.size() != c.cage_vertices.size()) throw std::runtime_error("proxy_cage: vertices / original_vertices differ in size");
 				if (c.cage_indices.size() % 3) throw std::runtime_error("proxy_cage.indices is not a triangle list");
 				for (uint32_t i : c.cage_indices)
 					if (i >= c.n_cage_vertices) throw std::runtime_error("proxy_cage.indices out of range");
@@ -642,9 +644,9 @@ int nrs_edits_cage(const nrs_edits* e, uint32_t i, nrs_tet_mesh* mesh_out, const
 	mesh_out->residual_amplitude = 1.0f;
 	mesh_out->correct_direction = 1; // GrowingSelection::m_correct_direction defaults to true (growing_selection.h)
 	if (h_mvc_weights_out) *h_mvc_weights_out = c.mvc.empty() ? nullptr : c.mvc.data();
-	if (h_cage_vertices_out) *h_cage_vertices_out = c.cage_vertices.data();
-	if (h_cage_original_vertices_out) *h_cage_original_vertices_out = c.cage_original_vertices.data();
-	if (h_cage_triangles_out) *h_cage_triangles_out = c.cage_indices.data();
+	if (h_cage_vertices_out) *h_cage_vertices_out = c.cage_vertices.empty() ? nullptr : c.cage_vertices.data();
+	if (h_cage_original_vertices_out) *h_cage_original_vertices_out = c.cage_original_vertices.empty() ? nullptr : c.cage_original_vertices.data();
+	if (h_cage_triangles_out) *h_cage_triangles_out = c.cage_indices.empty() ? nullptr : c.cage_indices.data();
 	if (n_cage_vertices_out) *n_cage_vertices_out = c.n_cage_vertices;
 	if (n_cage_triangles_out) *n_cage_triangles_out = (uint32_t)(c.cage_indices.size() / 3);
 	return NRS_OK;

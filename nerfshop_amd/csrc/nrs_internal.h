@@ -140,7 +140,9 @@ struct RenderCounters {    // zeroed before every launch
 	unsigned long long phase_cycles[8]; // NRS_DEBUG & 4: per-phase wave cycles (profiling build of the kernel only)
 	// NRS_DEBUG & 4: voxel-walk statistics. [0]/[1] fill: lane iterations / wave trips (= max over lanes per call);
 	// [2]/[3] the same for the per-sample march; [4] sample rounds, [5] live lanes summed over rounds, [6] march calls with > 1 trip
-	unsigned long long walk[8];
+	// [8] samples inside a cage's deformed box (they scan a LUT cell), [9] rounds with such a sample, [10] candidates tested (lane iterations of the scan),
+	// [11] the scan's wave trips (max over the lanes of a round), [12] samples that found their tet
+	unsigned long long walk[13];
 };
 
 struct RenderArgs {

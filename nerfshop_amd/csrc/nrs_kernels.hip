@@ -320,7 +320,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 	uint32_t st_samples = 0, st_alive = 0, st_hit = 0;
 	unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
 	unsigned long long pf_rounds = 0, pf_packets = 0, pf_tq = 0, pf_rounds_q = 0;
-	unsigned long long pf_walk[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // see RenderCounters::walk
+	unsigned long long pf_walk[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // see RenderCounters::walk
 	const unsigned long long pf_wall0 = PROF ? wall_clock64() : 0ull; // 100 MHz, identical on every XCD (s_memtime is the per-XCD shader clock)
 	int ph_cur = 0;
 
@@ -613,6 +613,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		// POISSON: the tet the first operator's search found for this sample (its membrane terms are interpolated in the same tet: poisson_residual_find)
 		uint32_t warp_scan = kTetNotSearched;
 		const bool act = TEAM != 1 ? (have && valid) : have; // this lane evaluates a sample in this round
+		uint32_t pf_scan = 0; // (PROF: bit 16 in a deformed box, bit 17 tet found, low half candidates tested)
 		if (ops && act) { // map_rays, last-to-first (tn:2899-2902)
 #if NRS_EXP_DBL == 2
 			{ f3 wp2 = wpos, wd2 = wdir; asm volatile("" : "+v"(wp2.x), "+v"(wp2.y), "+v"(wp2.z)); bool e2 = false;
@@ -627,9 +628,15 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					empty |= tet_warp(a2.edits[ei], true, wpos, wdir, sm.coarse, &scan);
 					if (ei == a2.n_edits - 1) warp_scan = scan;
 				} else {
-					empty |= tet_warp(a2.edits[ei], true, wpos, wdir, sm.coarse);
+					empty |= tet_warp(a2.edits[ei], true, wpos, wdir, sm.coarse, nullptr, PROF ? &pf_scan : nullptr);
 				}
 			}
+		}
+		if (PROF && !POISSON && !AFFINE) {
+			uint32_t mx = pf_scan & 0xffffu;
+			for (int sh = 32; sh > 0; sh >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, sh, 64));
+			pf_walk[8] += (pf_scan >> 16) & 1u; pf_walk[9] += (lane == 0 && __any((pf_scan >> 16) & 1u)) ? 1u : 0u;
+			pf_walk[10] += pf_scan & 0xffffu; pf_walk[11] += (lane == 0) ? mx : 0u; pf_walk[12] += (pf_scan >> 17) & 1u;
 		}
 		if (NRS_OPT_POISSON_REUSE && POISSON && !AFFINE) poisson_stash[wave * 64 + lane] = warp_scan; // (through LDS, not a register across the gather -- this instantiation's peak)
 		NRS_PHASE(3); // gather
@@ -1086,7 +1093,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 	}
 
 	if (PROF) {
-		for (int i = 0; i < 8; ++i) if (pf_walk[i]) atomicAdd(&a.counters->walk[i], pf_walk[i]);
+		for (int i = 0; i < 13; ++i) if (pf_walk[i]) atomicAdd(&a.counters->walk[i], pf_walk[i]);
 		NRS_PHASE(7);
 		if (lane == 0) {
 			unsigned long long life = 0;

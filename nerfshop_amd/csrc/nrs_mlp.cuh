@@ -38,7 +38,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define NRS_FRAG_R3(ks) (20 + (ks))
 #define NRS_FRAG_R2B(mb, ks) (30 + (mb) * 4 + (ks)) // (HBM only, like NRS_FRAG_BWD: the third rgb hidden layer of base_3layer.json)
 
-enum { KIND_DENSE = 0, KIND_HASHED = 1, KIND_MIXED = 2, KIND_RECORD = 3, KIND_SPARSE = 4 };
+enum { KIND_DENSE = 0, KIND_HASHED = 1, KIND_MIXED = 2, KIND_RECORD = 3, KIND_SPARSE = 4, KIND_SKIP = 5 };
 
 // Per-block model state in LDS: weight fragments, kind of each level pair (the level table itself is read with scalar loads).
 struct ModelLds {
@@ -60,6 +60,9 @@ __device__ __forceinline__ void stage_model_to_lds(const DeviceModel& m, ModelLd
 		const uint32_t native = (h0 && h1) ? KIND_HASHED : ((!h0 && !h1) ? KIND_DENSE : KIND_MIXED);
 		s.kinds[threadIdx.x] = (c0 == 1u && c1 == 1u) ? KIND_RECORD : ((c0 == 2u && c1 == 2u) ? KIND_SPARSE : ((c0 == 1u || c1 == 1u) ? KIND_MIXED : native));
 		s.kinds_native[threadIdx.x] = native;
+		// measurement (NRS_SKIP_PAIRS, dbg bits 8..15): level pairs that are not gathered at all (their features read 0) -- the L2 misses of a frame
+		// attributed level pair by level pair (profiles/r06_garden_levels.md).  Pictures are wrong; a production process cannot set it (dev_knob).
+		if ((dbg >> 8) & (1u << threadIdx.x)) s.kinds[threadIdx.x] = s.kinds_native[threadIdx.x] = KIND_SKIP;
 	}
 	if (threadIdx.x == 0) s.one_line = dbg & 1u;
 	__syncthreads();
@@ -513,6 +516,7 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 		else if (kind == KIND_HASHED) level_eval_two<KIND_HASHED, NETACC, ZERO>(gv, lp0, lp1, pos, act, f0, f1);
 		else if (kind == KIND_DENSE) level_eval_two<KIND_DENSE, NETACC, ZERO>(gv, lp0, lp1, pos, act, f0, f1);
 		else if (kind == KIND_SPARSE) level_eval_two<KIND_SPARSE, NETACC, ZERO>(gv, lp0, lp1, pos, act, f0, f1);
+		else if (kind == KIND_SKIP) { f0 = 0u; f1 = 0u; } // (measurement only: stage_model_to_lds)
 		else {
 			f0 = level_eval_one<NETACC, ZERO>(gv, lp0, !outside && !one_line && lp0.cached == 1u, pos, act);
 			f1 = level_eval_one<NETACC, ZERO>(gv, lp1, !outside && !one_line && lp1.cached == 1u, pos, act);

@@ -63,15 +63,58 @@ def lego_cage(built):
     return BenchScene("lego_cage")
 
 
-@pytest.mark.parametrize("step", [0, 3])
+@pytest.mark.parametrize("step", list(range(8)))
 def test_bench_scene_1080p_views_against_the_oracle(lego_cage, step):
-    """`value`'s workload itself: BASELINE configs[2], bench scene (lattice 10), bench views 0 and 3 at 1920x1080."""
+    """`value`'s workload itself: BASELINE configs[2], bench scene (lattice 10), EVERY view bench.py times (camera_for(0..7)) at 1920x1080
+    (VERDICT r5 next #2: the parity net as wide as the bench).  The early-out / normalisation at stake: tn:951-960."""
     check_against_oracle(lego_cage, lego_cage.params(step), lego_cage.edits, 10_000_000)
 
 
 def test_bench_scene_noedit_1080p_against_the_oracle(lego_cage):
     """The bench's `noedit` key (BASELINE configs[1]): the same scene and occupancy with apply_operators off, view 1, 1920x1080."""
     check_against_oracle(lego_cage, lego_cage.params(1, apply_operators=False), [], 10_000_000)
+
+
+def test_bench_scene_noedit_spp_jitter_1080p_against_the_oracle(lego_cage):
+    """What `noedit_spp8` times: a 1920x1080 frame with the Sobol pixel offset of spp_index 5 (snap_to_pixel_centers off), no edits, bench view 2 --
+    against the oracle with the same offset (random_val.cuh:159-322; ld_random_pixel_offset)."""
+    p = lego_cage.synth.render_params(1920, 1080, lego_cage.bench.camera_for(2, lego_cage.synth, 1), aabb_scale=1, apply_operators=False, spp_index=5, snap=False)
+    check_against_oracle(lego_cage, p, [], 10_000_000)
+
+
+@pytest.mark.parametrize("n_streams", [2, 4])
+def test_pipelined_path_1080p_is_the_whole_frame(lego_cage, n_streams):
+    """What `pipelined` / `pipelined4` time: the tiled path (tile_size 32, the rank's tiles into a compact buffer, gather with N = 1 + de-tile) on 2 / 4 HIP
+    streams with as many frames in flight -- every frame bit-equal to the same view rendered whole (which the tests above hold against the oracle)."""
+    torch, bench, synth = lego_cage.torch, lego_cage.bench, lego_cage.synth
+    from nerfshop_amd import tiles
+    W, H = 1920, 1080
+    sharders = [tiles.TileSharder(W, H, bench.TILE, 0, 1, "cuda:0") for _ in range(n_streams)]
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(n_streams)]
+    frames = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0") for _ in range(n_streams)]
+    depths = [torch.zeros((H, W), dtype=torch.float32, device="cuda:0") for _ in range(n_streams)]
+    views = list(range(n_streams))
+    torch.cuda.synchronize()
+    for b, v in enumerate(views):  # (all frames in flight before any is looked at)
+        p = sharders[b].fill(lego_cage.params(v))
+        with torch.cuda.stream(streams[b]):
+            sharders[b].clear()
+            lego_cage.tb.render_with_params(lego_cage.tb.nerf_network, p, sharders[b].local_frame, sharders[b].local_depth, None, streams[b])
+            sharders[b].gather(lego_cage.ctx, p, frames[b], depths[b])
+    torch.cuda.synchronize()
+    for b, v in enumerate(views):
+        whole, whole_depth, _, _ = lego_cage.render(lego_cage.params(v))
+        assert np.array_equal(frames[b].cpu().numpy().view(np.uint32), whole.view(np.uint32)), v
+        hit = whole[..., 3] > 0
+        assert np.array_equal(depths[b].cpu().numpy()[hit], whole_depth[hit]), v
+
+
+def test_varied_opacity_scene_1080p_against_the_oracle(built):
+    """`lego_cage_varied` -- the bench's second headline (`value_varied`) -- at the size it is timed: 1920x1080, bench view 0, against the oracle."""
+    bs = BenchScene("lego_cage_varied")
+    check_against_oracle(bs, bs.params(0), bs.edits, 20_000_000)
+    rays, handovers = bs.ctx.ray_handovers()
+    assert rays > 0 and handovers > 0, (rays, handovers)
 
 
 def test_varied_opacity_scene_against_the_oracle(built):

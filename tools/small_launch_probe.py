@@ -1,11 +1,12 @@
 """Where does a small launch spend its time?  One rank's 1/N share of the 1080p bench frame under NRS_DEBUG=4 (profiling instantiation: per-phase
-s_memtime shares, voxel-walk counters, per-wave end times), plus plain timings of the same share.  usage: NRS_DEBUG=4 python tools/small_launch_probe.py [N]"""
+s_memtime shares, voxel-walk counters, per-wave end times), plus plain timings of the same share.  usage: NRS_DEV_KNOBS=1 NRS_DEBUG=4 python tools/small_launch_probe.py [N]  (the library ignores NRS_DEBUG without NRS_DEV_KNOBS=1)"""
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ["NRS_DEV_KNOBS"] = "1"  # (before libnrs is loaded: its measurement knobs are ignored without it)
 
 
 def main():

@@ -1,4 +1,4 @@
-"""Reads the raw per-wave log of the profiling instantiation (NRS_DEBUG=4 NRS_WAVE_LOG_FILE=path: written by nrs_render_nerf after a launch with statistics)
+"""Reads the raw per-wave log of the profiling instantiation (NRS_DEV_KNOBS=1 NRS_DEBUG=4 NRS_WAVE_LOG_FILE=path: written by nrs_render_nerf after a launch with statistics)
 and prints how the launch's time is distributed over waves, SIMDs and CUs.  Record per wave (4 x u64): [0] lifetime in shader cycles | rays << 48,
 [1] rounds | rounds before the queue was found dry << 16 | time of that << 32, [2] packets | HW_ID[15:0] << 16 | fill cycles >> 8 << 32 | xcc << 56,
 [3] wall-clock lifetime (10 ns ticks) | start tick << 32.
