@@ -433,10 +433,7 @@ __device__ __forceinline__ float coarse_safe_until(const DeviceModel& m, const u
 // from its own stop in that cell, included -- selects the same u: u IS the reference's next stop, and the walk goes on from it bit for bit.  If a lattice point
 // sits inside the band (about 1 % of the jumps), or anything else is unusual (a tie, a sub-normal, the stretch leaves the unit cube where the cascade could
 // change), the function declines and the ordinary lean walk runs.  The (t, dt) streams stay bit-identical to the oracle's cell-by-cell walk (tests/test_gpu_parity.py).
-#ifndef NRS_JUMP_MIN
-#define NRS_JUMP_MIN 14u
-#endif
-constexpr uint32_t kJumpMinSteps = NRS_JUMP_MIN; // (a cell is 4.6 steps; the jump costs about two cells of lean walk)
+constexpr uint32_t kJumpMinSteps = 14u; // (a cell is 4.6 steps; the jump costs about two cells of lean walk)
 __device__ __forceinline__ bool lattice_jump(f3 o, f3 d, f3 idir, float t_safe, uint32_t mip, float& t) {
 	// (Straight-line: every condition is folded into one predicate and the candidate is computed whether or not it will be taken -- nested early exits cost this
 	// kernel scalar registers for the saved execution masks.  And written with VOP2-encodable literals: a literal operand of a three-source instruction needs a
@@ -529,35 +526,20 @@ __device__ __forceinline__ bool lattice_jump(f3 o, f3 d, f3 idir, float t_safe, 
 // with a full test each, until it left the occupied bounds; a few cells on, nothing is marked ahead any more and it can be
 // retired at once (or lean-walked to the next marked block).  Measured (Gsamples/s, lego + cage edit; ms for a 64x40-pixel
 // frame): once per walk 9.0 / 0.84, every 3rd cell 9.43 / 0.58, 6th 9.92 / 0.56, 10th 9.80 / 0.55, 16th 9.82 / 0.58, 32nd 9.54 / 0.65.
-#ifndef NRS_JUMP_SPAN
-#define NRS_JUMP_SPAN 0.06f
-#endif
-#ifndef NRS_LOOK_EVERY
-#define NRS_LOOK_EVERY 6
-#endif
-constexpr int kLookEvery = NRS_LOOK_EVERY;
-// NRS_OPT_LATTICE_JUMP (round 5): the lean walk in O(1) for constant steps -- lattice_jump above.
-#ifndef NRS_OPT_LATTICE_JUMP
-#define NRS_OPT_LATTICE_JUMP 1
-#endif
-// NRS_OPT_MORTON: the Morton code of an occupancy cell from a 128-entry table in LDS (spread3(v) = the bits of v at every third position; staged
+constexpr float kJumpSpan = 0.06f; // remaining stretch from which the lattice jump is attempted (22 steps + the margin: nothing to gain below; 0.04 / 0.10 measured the same)
+constexpr int kLookEvery = 6;
+// The Morton code of an occupancy cell from a 128-entry table in LDS (spread3(v) = the bits of v at every third position; staged
 // behind the look-ahead mask by stage_march_lds) -- three ds_read + two v_lshl_or instead of 28 VALU instructions per occupancy test; the cell index
 // and therefore every decision stay the same.
-#ifndef NRS_OPT_MORTON
-#define NRS_OPT_MORTON 1
-#endif
 constexpr uint32_t kMarchLdsWords = kCoarseWords + kGrid; // look-ahead mask | spread3 table
 __device__ __forceinline__ void stage_march_lds(uint32_t* __restrict__ lds, const uint32_t* __restrict__ mask) { // (the caller's barrier publishes it)
 	for (uint32_t i = threadIdx.x; i < kCoarseWords; i += blockDim.x) lds[i] = mask[i];
 	for (uint32_t i = threadIdx.x; i < kGrid; i += blockDim.x) lds[kCoarseWords + i] = expand_bits(i);
 }
-// NRS_OPT_OCCWORD: the voxel walk keeps the 64-bit word of the bitfield it last read -- in Morton order that is one 4 x 4 x 4 block of cells of one
+// The voxel walk keeps the 64-bit word of the bitfield it last read -- in Morton order that is one 4 x 4 x 4 block of cells of one
 // cascade -- and a test that falls into the same block is answered from the registers.  A ray that walks through empty cells next to the surface (the
 // silhouette rays that bound small launches: DESIGN 5) then pays the bitfield's load latency once per block instead of once per cell; when no lane of
 // the wave needs a new word the load is skipped altogether.  Pure caching: the decisions are the bitfield's.
-#ifndef NRS_OPT_OCCWORD
-#define NRS_OPT_OCCWORD 1
-#endif
 struct OccWord { uint32_t tag; uint32_t lo, hi; };
 // bit number of the cell of cascade `mip` that holds pos, in the concatenated bitfield (cn:117-141 through the LDS spread table)
 __device__ __forceinline__ uint32_t occupancy_bit_index(f3 pos, uint32_t mip, const uint32_t* __restrict__ march_lds) {
@@ -568,18 +550,6 @@ __device__ __forceinline__ uint32_t occupancy_bit_index(f3 pos, uint32_t mip, co
 	const int ix = (int)(q.x * (float)kGrid), iy = (int)(q.y * (float)kGrid), iz = (int)(q.z * (float)kGrid);
 	const uint32_t* spread = march_lds + kCoarseWords;
 	return (spread[clampi_(ix, 0, kGrid - 1)] | (spread[clampi_(iy, 0, kGrid - 1)] << 1) | (spread[clampi_(iz, 0, kGrid - 1)] << 2)) + mip * kGridVol;
-}
-// The occupancy word the walk from parameter t will ask for first, requested NOW (the caller issues this in front of the MLPs and hands the word to
-// march_to_occupied behind the compositing: the bitfield's round trip then overlaps the MFMA chain instead of extending the round).
-__device__ __forceinline__ OccWord prefetch_occupancy_word(const nrs_render_params& p, const DeviceModel& m, const uint32_t* __restrict__ march_lds, f3 o, f3 d, float t) {
-	const f3 pos = o + d * t;
-	const float dt = calc_dt(t, p.cone_angle_constant);
-	const uint32_t mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
-	OccWord w;
-	w.tag = occupancy_bit_index(pos, mip, march_lds) >> 6;
-	const uint2 v = reinterpret_cast<const uint2*>(m.bitfield)[w.tag];
-	w.lo = v.x; w.hi = v.y;
-	return w;
 }
 __device__ __forceinline__ bool occupied_at_cached(f3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip, const uint32_t* __restrict__ march_lds, OccWord& w) {
 	const uint32_t idx = occupancy_bit_index(pos, mip, march_lds);
@@ -592,7 +562,6 @@ __device__ __forceinline__ bool occupied_at_cached(f3 pos, const uint8_t* __rest
 	return (((bit & 32u) ? w.hi : w.lo) >> (bit & 31u)) & 1u;
 }
 __device__ __forceinline__ bool occupied_at(f3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip, const uint32_t* __restrict__ march_lds) {
-#if NRS_OPT_MORTON
 	const float mip_scale = ldexpf(1.0f, -(int)mip);
 	f3 q = pos - mk3(0.5f, 0.5f, 0.5f);
 	q = q * mip_scale;
@@ -601,20 +570,14 @@ __device__ __forceinline__ bool occupied_at(f3 pos, const uint8_t* __restrict__ 
 	const uint32_t* spread = march_lds + kCoarseWords;
 	const uint32_t idx = spread[clampi_(ix, 0, kGrid - 1)] | (spread[clampi_(iy, 0, kGrid - 1)] << 1) | (spread[clampi_(iz, 0, kGrid - 1)] << 2);
 	return get_bitfield_at(idx, mip, bitfield);
-#else
-	return density_grid_occupied_at(pos, bitfield, mip);
-#endif
 }
-// NRS_OPT_LAZY_IDIR: 1 / d (three IEEE divisions, ~40 issue slots) is only needed once the ray stands in an EMPTY cell; the common call -- the next
+// 1 / d (three IEEE divisions, ~40 issue slots) is only needed once the ray stands in an EMPTY cell; the common call -- the next
 // sample of a ray inside the object -- finds an occupied cell at once.  The first test is peeled off in front of the loop, the reciprocal formed behind it.
-#ifndef NRS_OPT_LAZY_IDIR
-#define NRS_OPT_LAZY_IDIR 1
-#endif
 // JUMP: compile lattice_jump into this instance (the two hot ones: the fill's first_hit and the per-round walk of one-lane rounds; the team walks keep the plain lean
 // walk -- every inlined copy costs scalar registers in a kernel that spills them)
 template <bool JUMP = false>
 __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, const DeviceModel& m, const uint32_t* __restrict__ march_lds, f3 o, f3 d,
-                                                  float& t, f3& pos, float& dt, uint32_t* n_iter = nullptr, const OccWord* seed = nullptr) {
+                                                  float& t, f3& pos, float& dt, uint32_t* n_iter = nullptr) {
 	const uint32_t* __restrict__ coarse_mask = march_lds;
 	const uint8_t* __restrict__ bitfield = m.bitfield;
 	const Box3& occ_box = m.occ.box;
@@ -625,14 +588,8 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 	int until_look = 0; // trips until the next look-ahead
 	uint32_t mip;
 	bool in_occ;
-#if NRS_OPT_OCCWORD && NRS_OPT_MORTON
 	OccWord occ_word{0xffffffffu, 0u, 0u};
-	if (seed) occ_word = *seed;
 	#define NRS_OCCUPIED(pos_, mip_) occupied_at_cached(pos_, bitfield, mip_, march_lds, occ_word)
-#else
-	#define NRS_OCCUPIED(pos_, mip_) occupied_at(pos_, bitfield, mip_, march_lds)
-#endif
-#if NRS_OPT_LAZY_IDIR
 	if (n_iter) ++*n_iter; // profiling build only
 	pos = o + d * t;
 	if (!box_contains(bb, pos)) return false;
@@ -640,9 +597,8 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 	mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
 	in_occ = box_contains(occ_box, pos);
 	if (in_occ && NRS_OCCUPIED(pos, mip)) return true;
-#endif
 	const f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-	bool first = NRS_OPT_LAZY_IDIR != 0;
+	bool first = true;
 	while (1) {
 		if (!first) {
 			if (n_iter) ++*n_iter; // profiling build only
@@ -667,17 +623,15 @@ __device__ __forceinline__ bool march_to_occupied(const nrs_render_params& p, co
 			}
 			// lean walk: every position it stands on has parameter < t_safe
 			while (1) {
-#if NRS_OPT_LATTICE_JUMP
 				// (tried in EVERY pass of the lean walk, not once in front of it: a lane that declines -- a lattice point in the guard band, the end of a binade, the
 				// entry point on the cube's face -- takes one ordinary step and tries again from there; a wave is as slow as its slowest lane, and one lane in a
 				// hundred walking the whole stretch cell by cell would keep most waves waiting)
-				if (JUMP && cone == 0.f && t_safe - t > NRS_JUMP_SPAN /* 22 steps + the margin: nothing to gain below */ && lattice_jump(o, d, idir, t_safe, mip, t)) {
+				if (JUMP && cone == 0.f && t_safe - t > kJumpSpan && lattice_jump(o, d, idir, t_safe, mip, t)) {
 					if (n_iter) ++*n_iter;
 					pos = o + d * t;
 					dt = calc_dt(t, cone);
 					mip = max(p.min_mip, (uint32_t)mip_from_dt(dt, pos));
 				}
-#endif
 				const uint32_t lres = kGrid >> mip;
 				const float linv = ldexpf(1.0f, (int)mip - 7);
 				// one step past the border is the farthest the next position can be (first lattice point >= the border)
@@ -741,25 +695,14 @@ __device__ __forceinline__ void bary_tet(f3 a, f3 b, f3 c, f3 d, f3 p, float out
 }
 // The operator tables are reached through pointers that sit in a device-memory struct (DeviceEdit): left alone, the compiler cannot tell their address
 // space and emits FLAT loads (an aperture check per access, both wait counters) with one 64-bit address computation per dword.  They are global memory:
-// NRS_OPT_GLOBAL_EDIT casts them so (global_load), and a vertex / matrix column is one 12-byte load.
-#ifndef NRS_OPT_GLOBAL_EDIT
-#define NRS_OPT_GLOBAL_EDIT 1
-#endif
-#if NRS_OPT_GLOBAL_EDIT
+// gp() casts them so (global_load), and a vertex / matrix column is one 12-byte load.
 #define NRS_GLOBAL __attribute__((address_space(1)))
-#else
-#define NRS_GLOBAL
-#endif
 template <typename T>
 __device__ __forceinline__ const NRS_GLOBAL T* gp(const T* p) { return (const NRS_GLOBAL T*)p; }
 __device__ __forceinline__ f3 ld3(const float* __restrict__ a, uint32_t i) {
-#if NRS_OPT_GLOBAL_EDIT
 	typedef float f3a __attribute__((ext_vector_type(3), aligned(4)));
 	const f3a v = *(const NRS_GLOBAL f3a*)(gp(a) + 3 * (size_t)i);
 	return {v.x, v.y, v.z};
-#else
-	return {a[3 * i], a[3 * i + 1], a[3 * i + 2]};
-#endif
 }
 
 // point_in_tet with the per-tet part of same_side_tet hoisted out of the sample loop, and the tet's own vertices stored next to
@@ -803,9 +746,6 @@ __device__ __forceinline__ uint32_t scan_cell_for_tet(const DeviceEdit& e, uint3
 // tet's vertices afterwards.  Fusing them keeps ~48 more VGPRs live across the scan and costs the kernel a wave of occupancy.
 // march_lds (optional): the kernel's LDS copy of the Morton spread table (stage_march_lds) -- the cell index then costs three LDS reads instead of 28 VALU
 // instructions (the same index: occupancy_bit_index is cascaded_grid_idx_at through the table)
-#ifndef NRS_OPT_WARP_MORTON
-#define NRS_OPT_WARP_MORTON 1
-#endif
 // scan_out (optional): what the tet search found (a tet number or 0xffffffff), kTetNotSearched when the sample is outside the deformed mesh's box -- the membrane
 // correction of the same operator looks for the same tet at the same position (poisson_residual_find) and takes it from here.
 constexpr uint32_t kTetNotSearched = 0xfffffffeu;
@@ -816,7 +756,7 @@ __device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3&
 	if (box_contains(e.warped_bbox, wpos)) {
 		const f3 u = unwarp_position(wpos, e.aabb);
 		const int level = mip_from_pos(u);
-		const uint32_t cell = (NRS_OPT_WARP_MORTON && march_lds) ? occupancy_bit_index(u, (uint32_t)level, march_lds)
+		const uint32_t cell = march_lds ? occupancy_bit_index(u, (uint32_t)level, march_lds)
 		                                                         : (uint32_t)level * kGridVol + cascaded_grid_idx_at(u, (uint32_t)level);
 		if (n_tested) *n_tested |= 0x10000u; // (profiling: the sample stands inside the deformed mesh's box; low half = candidates tested)
 		const uint32_t found = scan_cell_for_tet(e, cell, u, n_tested);
@@ -840,12 +780,8 @@ __device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3&
 			__builtin_amdgcn_sched_barrier(0);
 			if (with_dir && e.rot) {
 				const f3 ud = unwarp_direction(wdir);
-#if NRS_OPT_GLOBAL_EDIT
 				const f3 c0 = ld3(e.rot, 3u * found), c1 = ld3(e.rot, 3u * found + 1u), c2 = ld3(e.rot, 3u * found + 2u); // the three columns
 				const float R[9] = {c0.x, c0.y, c0.z, c1.x, c1.y, c1.z, c2.x, c2.y, c2.z};
-#else
-				const float* R = e.rot + 9 * (size_t)found;
-#endif
 				const f3 rd = mat3_mul(R, ud);
 				wdir = warp_direction(rd);
 			}
@@ -898,12 +834,6 @@ __device__ __forceinline__ bool edit_warp(const DeviceEdit& e, bool with_dir, f3
 // sample position BEFORE map_rays (residuals live in deformed space), dir the un-warped view direction AFTER map_rays.
 // The barycentric interpolation of the 27 SH9RGB coefficients and the dot product with the SH basis are evaluated in the
 // reference's order, coefficient by coefficient, so no 27-float array is kept.  Outputs untouched when no tet contains it.
-#ifndef NRS_SH_GROUP
-#define NRS_SH_GROUP 2
-#endif
-#ifndef NRS_SH_OPAQUE
-#define NRS_SH_OPAQUE 0
-#endif
 // Two steps (round 4), so that the renderer can run the un-deformed network pass between them with only three values live: _find decides which tet of the
 // deformed mesh holds the sample and interpolates the two densities; _colour re-derives the barycentric weights of that tet (the same arithmetic: the same
 // bits) and evaluates the SH9 colour.
@@ -916,7 +846,7 @@ __device__ __forceinline__ bool poisson_residual_find(const DeviceEdit& e, f3 wp
 	uint32_t found = searched;
 	if (searched == kTetNotSearched) {
 		const int level = mip_from_pos(pos);
-		const uint32_t cell = (NRS_OPT_WARP_MORTON && march_lds) ? occupancy_bit_index(pos, (uint32_t)level, march_lds)
+		const uint32_t cell = march_lds ? occupancy_bit_index(pos, (uint32_t)level, march_lds)
 		                                                         : (uint32_t)level * kGridVol + cascaded_grid_idx_at(pos, (uint32_t)level);
 		found = scan_cell_for_tet(e, cell, pos);
 	}
@@ -948,7 +878,7 @@ __device__ __forceinline__ void poisson_residual_colour(const DeviceEdit& e, uin
 	}
 	// The 4 x 27 coefficients are read through a buffer descriptor (wave-uniform base in scalar registers, one 32-bit offset per vertex, the coefficient in
 	// the instruction's immediate) and in small groups: the registers of a wave, not the latency of a few more round trips, are what this instantiation is
-	// short of (the kernel must fit the 128 VGPRs of the default launch shape).  NRS_SH_GROUP terms of the dot product are in flight at once.
+	// short of (the kernel must fit the 128 VGPRs of the default launch shape).  Two terms of the dot product are in flight at once.
 	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)e.shs, 0, 0x7fffffff, 0x00020000);
 	const uint32_t o0 = tv.x * 108u, o1 = tv.y * 108u, o2 = tv.z * 108u, o3 = tv.w * 108u; // byte offset of a vertex's 27 floats
 	#pragma unroll 1 // one colour at a time (the unrolled form holds all 108 coefficient loads in flight: 250 VGPRs)
@@ -956,10 +886,7 @@ __device__ __forceinline__ void poisson_residual_colour(const DeviceEdit& e, uin
 		const int cb = c * 36;
 		// SH basis (evaluate_sh9, cn:222-240), each coefficient formed where it is used from an opaque copy of the direction: nine basis values kept across
 		// the colour loop are nine registers this instantiation does not have (the products are the reference's, term by term)
-		float dx = dir.x, dy = dir.y, dz = dir.z;
-#if NRS_SH_OPAQUE
-		asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dz));
-#endif
+		const float dx = dir.x, dy = dir.y, dz = dir.z;
 		auto pSH = [&](int k) -> float {
 			switch (k) {
 				case 0: return 0.2820947917738781f;
@@ -976,7 +903,6 @@ __device__ __forceinline__ void poisson_residual_colour(const DeviceEdit& e, uin
 		// pSH.dot(sh.block<9, 1>(0, c)): Eigen's unrolled 9-term reduction, 4 | 5 -> (2|2) | (2|(1|2))
 		auto L = [&](uint32_t ov, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)ov, cb + 4 * k, 0)); };
 		auto term = [&](int k) { return pSH(k) * (((bc[0] * L(o0, k) + bc[1] * L(o1, k)) + bc[2] * L(o2, k)) + bc[3] * L(o3, k)); };
-#if NRS_SH_GROUP == 2
 		const float q0 = term(0), q1 = term(1); const float a01 = q0 + q1;
 		__builtin_amdgcn_sched_barrier(0);
 		const float q2 = term(2), q3 = term(3); const float lo4 = a01 + (q2 + q3);
@@ -987,13 +913,6 @@ __device__ __forceinline__ void poisson_residual_colour(const DeviceEdit& e, uin
 		__builtin_amdgcn_sched_barrier(0);
 		const float q6 = term(6);
 		rgb[c] = lo4 + (a45 + (q6 + a78));
-#else
-		const float q0 = term(0), q1 = term(1), q2 = term(2), q3 = term(3);
-		const float lo4 = (q0 + q1) + (q2 + q3);
-		__builtin_amdgcn_sched_barrier(0);
-		const float q4 = term(4), q5 = term(5), q6 = term(6), q7 = term(7), q8 = term(8);
-		rgb[c] = lo4 + ((q4 + q5) + (q6 + (q7 + q8)));
-#endif
 	}
 }
 // (the two steps in one call, for callers without anything in between)

@@ -51,35 +51,19 @@ constexpr int kRing = 128; // pending-ray ring entries per wave (>= 63 + 64)
 // 1 (refill every idle lane at once, 98 % of lanes busy) 7.41 Gsamples/s, 16/32 7.08, 48 7.60, 56 7.78, 60 7.80, 64 8.09 -- once
 // the marcher's VALU diet made the gather's L1/TA path the first limiter, coherence became worth more than occupancy (aabb-16
 // scene: 3.49 -> 3.92).
-#ifndef NRS_QUADS_NUM3
-#define NRS_QUADS_NUM3 3 // four record levels in flight for the compile-time tcnn-numerics instantiation too (-100: off)
-#endif
-// NRS_TEAM_MAX (experiment): the widest lane team of the automatic schedule (4; 8 = eight lanes per ray once a wave holds <= 8 rays)
-#ifndef NRS_TEAM_MAX
-#define NRS_TEAM_MAX 4
-#endif
-#ifndef NRS_OPT_POISSON_REUSE
-#define NRS_OPT_POISSON_REUSE 1
-#endif
-#ifndef NRS_OPT_POISSON_SIGN
-#define NRS_OPT_POISSON_SIGN 1
-#endif
-#ifndef NRS_EXP_P
-#define NRS_EXP_P 0 // register experiments on the membrane path: bit 0 no old-density pass, bit 1 no boundary colour, bit 2 no tet search (wrong pictures)
-#endif
-#ifndef NRS_EXP_DBL
-#define NRS_EXP_DBL 0 // measurement builds: 1 fill, 2 cage warp, 3 gather, 4 MLPs, 5 march executed twice (results unchanged) -- the frame time's difference is that phase's marginal cost
-#endif
-#ifndef NRS_OPT_SAT_WRITE
-#define NRS_OPT_SAT_WRITE 1 // a saturated ray (alpha normalised to exactly 1) writes its pixel without reading the frame value it would multiply by 0 (render_body's shade)
-#endif
-#ifndef NRS_OPT_NOZERO
-#define NRS_OPT_NOZERO 1 // the render rounds do not zero the features of idle lanes (nobody reads them): one select per level saved
-#endif
-#ifndef NRS_OPT_GIVE_RING
-#define NRS_OPT_GIVE_RING 1 // ray hand-over: rays pending in a busy wave's ring go to a waiting sibling (0: only rays already in lanes are handed over)
+constexpr int kTeamMax = 4; // the widest lane team of the automatic schedule (eight lanes per ray once a wave holds <= 8 rays was measured and loses: profiles/r03_schedules.md)
+// Measurement builds (-DNRS_MEASURE=<n>; production: undefined): 1 fill, 2 cage warp, 3 gather, 4 MLPs, 5 march executed twice (results unchanged) -- the frame time's
+// difference is that phase's marginal cost; 9 = ISA listing with phase markers (tools/isa_phases.py: comments only, for counting instructions per phase).
+#ifndef NRS_MEASURE
+#define NRS_MEASURE 0
 #endif
 constexpr uint32_t kRefillWhenIdle = 64;
+// NRS_REFILL_BULK (round 6 A/B, default 64 = generations everywhere): idle lanes from which a wave of the automatic schedule takes new rays while the frame's queue still
+// has packets and its running generation is one lane per ray.  Below 64 the idle lanes are refilled in place (rank among the idle lanes, as TEAM == 1 does) while the
+// other rays run on: higher lane occupancy where ray lengths vary, less coherence between a wave's samples.
+#ifndef NRS_REFILL_BULK
+#define NRS_REFILL_BULK 64
+#endif
 
 template <int WAVES>
 struct RenderSmem {
@@ -107,16 +91,9 @@ struct RenderSmem {
 // packets in step; chunks of 16 / 8 / 4 / 2 / 1: 10.0 / 11.2 / 11.8 / 12.0 / 11.7 Gsamples/s on lego + cage, 8.4 / 9.6 / 10.3 / 10.6 / 10.8 on the varied scene, a 1/8 share
 // 0.509 (8) / 0.494 / 0.496 / 0.532 ms (chunks of 1 pay the atomics: 16 640 of them in half a millisecond); shrinking chunks towards the end of the queue only
 // ("guided") was no better than a constant 4.
-#ifndef NRS_GIVE_MIN
-#define NRS_GIVE_MIN 16u // ray hand-over: a wave gives half of the rays it holds in lanes when it holds more than this many
-#endif
-#ifndef NRS_FULL_GEN
-#define NRS_FULL_GEN 56u // small-launch schedule with 64-pixel packets: pending rays from which a generation runs one lane per ray
-#endif
-#ifndef NRS_QUEUE_CHUNK
-#define NRS_QUEUE_CHUNK 2
-#endif
-constexpr uint32_t kQueueChunk = NRS_QUEUE_CHUNK;
+constexpr uint32_t kGiveMin = 16u; // ray hand-over: a wave gives half of the rays it holds in lanes when it holds more than this many
+constexpr uint32_t kFullGen = 56u; // small-launch schedule with 64-pixel packets: pending rays from which a generation runs one lane per ray
+constexpr uint32_t kQueueChunk = 2;
 constexpr uint32_t kNoPacket = 0xffffffffu;
 __device__ __forceinline__ uint32_t claim_packet(unsigned long long* state, uint32_t* global_next, uint32_t n_packets, int lane) {
 	uint32_t result = kNoPacket;
@@ -180,29 +157,16 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 // WAVES = waves per workgroup (they share one LDS copy of the weights); OCC = waves per SIMD the register allocator must
 // leave room for (__launch_bounds__' second argument).
 // PROF adds s_memtime stamps around the phases of a round (NRS_DEBUG & 4); the production instantiation has none.
-#ifdef NRS_MARKERS // ISA listing with phase boundaries (tools/isa_phases.py): comments only, for counting instructions per phase
+#if NRS_MEASURE == 9
 #define NRS_MARK(i) asm volatile("; NRS_MARK " #i)
 #else
 #define NRS_MARK(i)
 #endif
-// NRS_PRIO (experiment knob, default 0 = off): wave priorities per phase (s_setprio).  1: memory phases (warp, gather) above the rest;
-// 2: the MFMA chain above the rest; 3: gather only.
-#ifndef NRS_PRIO
-#define NRS_PRIO 0
-#endif
-#define NRS_SETPRIO(i)                                                                                         \
-	do {                                                                                                       \
-		if (NRS_PRIO == 1) { if ((i) == 2 || (i) == 3) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); } \
-		if (NRS_PRIO == 2) { if ((i) == 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }             \
-		if (NRS_PRIO == 3) { if ((i) == 3) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }             \
-	} while (0)
-#ifndef NRS_OPT_EARLY_MARCH
-#define NRS_OPT_EARLY_MARCH 0 // measured +-0 (lego 9.85 -> 9.86, aabb-16 4.70 -> 4.71 Gsamples/s) for 4 more VGPRs: off
-#endif
+// (wave priorities per phase -- s_setprio around the memory phases or the MFMA chain -- and the next sample's occupancy word requested ahead of the MLPs were
+// measured and are gone: profiles/r03_schedules.md, profiles/r05/ab_small_knobs.txt)
 #define NRS_PHASE(i)                                                         \
 	do {                                                                     \
 		NRS_MARK(i);                                                         \
-		NRS_SETPRIO(i);                                                      \
 		if (PROF) {                                                          \
 			const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
 			ph_acc[ph_cur] += now_ - ph_last;                                \
@@ -356,7 +320,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				}
 				return (uint32_t)__builtin_amdgcn_readfirstlane((int)target);
 			};
-			if (NRS_OPT_GIVE_RING && ring_count != 0u) {
+			if (ring_count != 0u) {
 				if (__any(have)) { // (a wave without running rays starts its pending ones itself, below)
 					const uint32_t target = claim_waiting_wave();
 					if (target != 0xffffffffu) {
@@ -372,7 +336,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			} else if (ring_count == 0u) {
 				const unsigned long long lead_mask = __ballot(have && tk == 0);
 				const uint32_t live = (uint32_t)__popcll(lead_mask);
-				const uint32_t target = live > NRS_GIVE_MIN ? claim_waiting_wave() : 0xffffffffu;
+				const uint32_t target = live > kGiveMin ? claim_waiting_wave() : 0xffffffffu;
 				if (target != 0xffffffffu) {
 					const uint32_t keep = (live + 1u) / 2u, give = live - keep;
 					const bool team_live = ((lead_mask >> team_base) & 1ull) != 0ull;
@@ -395,10 +359,10 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				}
 			}
 		}
-		if (TEAM == 0 && a1.reteam && (((a1.reteam & 2u) && tail_seen) || (!more && ring_count == 0u))) { // (bit 1: at any time once the wave runs tail generations, not only at its end)
+		if (TEAM == 0 && a1.reteam && (((a1.reteam & 2u) && tail_seen && !(NRS_REFILL_BULK < 64 && more)) || (!more && ring_count == 0u))) { // (NRS_REFILL_BULK < 64: idle lanes take new rays instead while the queue has some) // (bit 1: at any time once the wave runs tail generations, not only at its end)
 			const unsigned long long lead_mask = __ballot(have && tk == 0);
 			const uint32_t live = (uint32_t)__popcll(lead_mask);
-			const uint32_t new_t = (NRS_TEAM_MAX >= 8 && live <= 8u) ? 8u : (live <= 16u ? 4u : (live <= 32u ? 2u : 1u));
+			const uint32_t new_t = live <= 16u ? 4u : (live <= 32u ? 2u : 1u);
 			if (live != 0u && new_t > gen_t) {
 				if (have && tk == 0) {
 					const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lead_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lead_mask, 0u));
@@ -430,11 +394,14 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		}
 		const unsigned long long free_mask = __ballot(!have);
 		const uint32_t nfree = (uint32_t)__popcll(free_mask);
+		// (the refill threshold of this pass: generations of 64, or NRS_REFILL_BULK idle lanes in the bulk phase of the automatic schedule)
+		const bool partial = NRS_REFILL_BULK < 64 && TEAM == 0 && gen_t == 1u && more && nfree < kRefillWhenIdle;
+		const uint32_t refill_at = partial ? (uint32_t)NRS_REFILL_BULK : kRefillWhenIdle;
 
 		// ---- fill the ring with rays that found an occupied cell (init_rays + advance_pos_nerf) ----
 		// (Measured: moving this into its own lean kernel does not pay -- the DDA's dependent bitfield loads overlap with
 		// other waves' gather/MLP work here for free, while a separate launch adds ~1 ms of serial time at 1080p.)
-		while (more && ring_count < (TEAM > 1 ? 64u / gen_t : (TEAM == 0 && tail_seen ? a1.tail_target : nfree)) && nfree >= kRefillWhenIdle) {
+		while (more && ring_count < (TEAM > 1 ? 64u / gen_t : (TEAM == 0 && tail_seen && !partial ? a1.tail_target : nfree)) && nfree >= refill_at) {
 			const uint32_t pk = claim_packet(&sm.queue, &a1.counters->next_packet, a1.n_packets, lane);
 			if (pk == kNoPacket) { more = false; if (PROF) { pf_tq = wall_clock64() - pf_wall0; pf_rounds_q = pf_rounds; } break; }
 			if (PROF) ++pf_packets;
@@ -478,7 +445,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					}
 				}
 				uint32_t it_fill = 0;
-#if NRS_EXP_DBL == 1
+#if NRS_MEASURE == 1
 				if (alive) { Ray r2 = r; const bool a2 = first_hit(p1, m1, sm.coarse, x + (uint32_t)p1.resolution[0] * y, r2, nullptr); asm volatile("" :: "v"(r2.t), "s"((int)__ballot(a2))); }
 #endif
 				if (alive) alive = first_hit(p1, m1, sm.coarse, x + (uint32_t)p1.resolution[0] * y, r, PROF ? &it_fill : nullptr);
@@ -502,16 +469,17 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		NRS_PHASE(1); // refill
 
 		// ---- hand pending rays to idle lanes ----
-		if (nfree >= kRefillWhenIdle && ring_count) {
-			if (TEAM == 0) { // hybrid: full generations until the tail packets, then as many lanes per ray as the pending rays allow
+		if (nfree >= refill_at && ring_count) {
+			if (TEAM == 0 && !partial) { // (a partial refill joins the running one-lane generation) // hybrid: full generations until the tail packets, then as many lanes per ray as the pending rays allow
 				// (a launch of tail packets only runs one lane per ray only where it is large -- 64-pixel packets -- and the wave can fill its lanes:
 				// otherwise more than 32 pending rays = 32 now as teams of two, the rest in the next generation or handed to a waiting sibling)
-				gen_t = tail_seen ? (ring_count > 32u && (!a1.all_tail || (a1.fill_lanes == 1u && ring_count >= NRS_FULL_GEN)) ? 1u : (ring_count > 16u ? 2u : ((NRS_TEAM_MAX >= 8 && ring_count <= 8u) ? 8u : 4u))) : 1u;
+				gen_t = tail_seen ? (ring_count > 32u && (!a1.all_tail || (a1.fill_lanes == 1u && ring_count >= kFullGen)) ? 1u : (ring_count > 16u ? 2u : 4u)) : 1u;
 				tk = lane & (int)(gen_t - 1u);
 				team_base = lane & ~(int)(gen_t - 1u);
 			}
-			const uint32_t take = min(TEAM != 1 ? 64u / gen_t : nfree, ring_count);
-			const uint32_t rank = TEAM != 1 ? (uint32_t)lane / gen_t // (all 64 lanes are idle: kRefillWhenIdle)
+			const bool in_place = TEAM == 1 || partial; // (rank among the idle lanes)
+			const uint32_t take = min(in_place ? nfree : 64u / gen_t, ring_count);
+			const uint32_t rank = !in_place ? (uint32_t)lane / gen_t // (all 64 lanes are idle: kRefillWhenIdle)
 			                                : __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
 			if (!have && rank < take) {
 				const uint2 e = ring[(ring_head + rank) & (kRing - 1)];
@@ -570,7 +538,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					continue;
 				}
 				const uint32_t* mb = &sm.fl[wave].feat[0][0][0];
-				gen_t = (NRS_TEAM_MAX >= 8 && got <= 8u) ? 8u : (got <= 16u ? 4u : 2u); // (a sibling hands over at most 32 rays)
+				gen_t = got <= 16u ? 4u : 2u; // (a sibling hands over at most 32 rays)
 				tk = ln & (int)(gen_t - 1u);
 				team_base = ln & ~(int)(gen_t - 1u);
 				const uint32_t r = (uint32_t)ln / gen_t;
@@ -615,7 +583,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		const bool act = TEAM != 1 ? (have && valid) : have; // this lane evaluates a sample in this round
 		uint32_t pf_scan = 0; // (PROF: bit 16 in a deformed box, bit 17 tet found, low half candidates tested)
 		if (ops && act) { // map_rays, last-to-first (tn:2899-2902)
-#if NRS_EXP_DBL == 2
+#if NRS_MEASURE == 2
 			{ f3 wp2 = wpos, wd2 = wdir; asm volatile("" : "+v"(wp2.x), "+v"(wp2.y), "+v"(wp2.z)); bool e2 = false;
 			  for (int ei = a2.n_edits - 1; ei >= 0; --ei) e2 |= AFFINE ? edit_warp(a2.edits[ei], true, wp2, wd2) : tet_warp(a2.edits[ei], true, wp2, wd2);
 			  asm volatile("" :: "v"(wp2.x), "v"(wp2.y), "v"(wp2.z), "v"(wd2.x), "v"(wd2.y), "v"(wd2.z), "s"((int)__ballot(e2))); }
@@ -623,7 +591,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			for (int ei = a2.n_edits - 1; ei >= 0; --ei) {
 				if (AFFINE) {
 					empty |= edit_warp(a2.edits[ei], true, wpos, wdir);
-				} else if (NRS_OPT_POISSON_REUSE && POISSON) {
+				} else if (POISSON) {
 					uint32_t scan; // (a local of the iteration, selected below: a pointer that is sometimes null made warp_scan a stack object)
 					empty |= tet_warp(a2.edits[ei], true, wpos, wdir, sm.coarse, &scan);
 					if (ei == a2.n_edits - 1) warp_scan = scan;
@@ -638,28 +606,21 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			pf_walk[8] += (pf_scan >> 16) & 1u; pf_walk[9] += (lane == 0 && __any((pf_scan >> 16) & 1u)) ? 1u : 0u;
 			pf_walk[10] += pf_scan & 0xffffu; pf_walk[11] += (lane == 0) ? mx : 0u; pf_walk[12] += (pf_scan >> 17) & 1u;
 		}
-		if (NRS_OPT_POISSON_REUSE && POISSON && !AFFINE) poisson_stash[wave * 64 + lane] = warp_scan; // (through LDS, not a register across the gather -- this instantiation's peak)
+		if (POISSON && !AFFINE) poisson_stash[wave * 64 + lane] = warp_scan; // (through LDS, not a register across the gather -- this instantiation's peak)
 		NRS_PHASE(3); // gather
 		// ---- gather: own sample (block g) and the partner lane's sample (block 1-g), levels 2*it+g ----
-#if NRS_EXP_DBL == 3
+#if NRS_MEASURE == 3
 		{ f3 wp2 = wpos; asm volatile("" : "+v"(wp2.x), "+v"(wp2.y), "+v"(wp2.z));
 		  encode_num<NUM, (TEAM == 0 && !POISSON && !AFFINE && !EXTRA && NUM == 0)>(nm, gv, m2.levels, sm.ml, fl, lane, g, wp2, act); }
 #endif
-		encode_num<NUM, (TEAM == 0 && !POISSON && !AFFINE && !EXTRA && (NUM == 0 || NUM == NRS_QUADS_NUM3)), !NRS_OPT_NOZERO>(nm, gv, m2.levels, sm.ml, fl, lane, g, wpos, act); // (four record levels in flight: the hybrid instantiation has the registers; features of idle lanes are never looked at: not zeroed)
-		// NRS_OPT_EARLY_MARCH: the walk to the NEXT sample does not depend on the network, and its first step is nearly always its last (the next
-		// sample of a ray inside the object stands in an occupied cell).  The bitfield word that first test needs is requested HERE, in front of the
-		// MLPs, and handed to march_to_occupied behind the compositing: one memory round trip less on the round's dependency chain.
-		OccWord occ_seed{0xffffffffu, 0u, 0u};
-		bool one_lane_round = true;
-		if constexpr (TEAM != 1) one_lane_round = gen_t <= 1u;
-		if (NRS_OPT_EARLY_MARCH && one_lane_round && have) occ_seed = prefetch_occupancy_word(p2, m2, sm.coarse, o, d, t + dt);
+		encode_num<NUM, (TEAM == 0 && !POISSON && !AFFINE && !EXTRA && (NUM == 0 || NUM == 3)), false>(nm, gv, m2.levels, sm.ml, fl, lane, g, wpos, act); // (four record levels in flight: the hybrid instantiation has the registers; features of idle lanes are never looked at: not zeroed)
 		NRS_PHASE(4); // SH + MLP
 		const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
 		half8 sh_own, sh_par;
 		encode_sh4_2(g, wdir, pdir, sh_own, sh_par);
 
 		// ---- fused MLPs on MFMA, one 32-sample block at a time ----
-#if NRS_EXP_DBL == 4
+#if NRS_MEASURE == 4
 		{ uint32_t sink = 0;
 		  #pragma unroll 1
 		  for (int b = 0; b < 2; ++b) {
@@ -787,8 +748,8 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				// step 1: which tet of which membrane edit holds the sample (the last one in the reference's operator order that does), and its two densities
 				uint32_t found_tet = 0u;
 				int found_edit = -1;
-				if (act && !(NRS_EXP_P & 4)) {
-					const uint32_t searched = (NRS_OPT_POISSON_REUSE && !AFFINE) ? poisson_stash[wave * 64 + lane] : kTetNotSearched;
+				if (act) {
+					const uint32_t searched = !AFFINE ? poisson_stash[wave * 64 + lane] : kTetNotSearched;
 					for (int ei = a2b.n_edits - 1; ei >= 0; --ei)
 						if (a2b.edits[ei].apply_poisson && poisson_residual_find(a2b.edits[ei], wpos0, found_tet, p_out, p_res, sm.coarse, ei == a2b.n_edits - 1 ? searched : kTetNotSearched)) found_edit = ei;
 				}
@@ -797,8 +758,8 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				// samples with a residual when m_poisson_target is set (the reference's default) -- otherwise the pass is skipped, results unchanged.
 				// (round 4, late: and of those only the samples whose residual is POSITIVE -- min(max(target, s), s + res) = s + res whatever the target is when
 				// res <= 0, because max(., s) >= s >= s + res: a round whose residuals are all negative or zero skips the pass, the others gather for fewer lanes)
-				const bool need_old = NRS_OPT_POISSON_SIGN ? (has_res && p_res > 0.f) : has_res;
-				if (!(NRS_EXP_P & 1) && p2b.poisson_target && __any(need_old)) {
+				const bool need_old = has_res && p_res > 0.f;
+				if (p2b.poisson_target && __any(need_old)) {
 					const GridView gvb = make_grid_view(m2b);
 					encode_num<NUM>(nm, gvb, m2b.levels, sm.ml, fl, lane, g, wpos0, need_old);
 					uint32_t old_d = 0;
@@ -813,7 +774,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 					sigma_old_raw = (float)__builtin_bit_cast(half2v, old_d)[0];
 				}
 				// step 3: the boundary colour of the samples with a residual (the only ones whose colour is mixed, tn:796-805)
-				if (!(NRS_EXP_P & 2) && (EXTRA ? (found_edit >= 0) : has_res)) {
+				if (EXTRA ? (found_edit >= 0) : has_res) {
 					NRS_FRESH_ARGS(m2d, a2d);
 					const f3 pos1 = o + d * t;
 					const f3 wpos1 = m2d.diag_pow2 ? mk3((pos1.x - m2d.aabb.mn[0]) * m2d.inv_diag[0], (pos1.y - m2d.aabb.mn[1]) * m2d.inv_diag[1], (pos1.z - m2d.aabb.mn[2]) * m2d.inv_diag[2])
@@ -850,10 +811,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 
 		NRS_FRESH_ARGS(m3, a3);
 		const nrs_render_params& p3 = a3.p;
-#ifndef NRS_EXP_STAMP
-#define NRS_EXP_STAMP 0 // measurement build (profiling instantiation, one-lane rounds): 1 = the phase stamps cut "composite + march + shade" in three -- the compositing is
-#endif                  // booked on "sh+mlp", the walk to the next sample stays on "composite+march+shade", the shade (frame read-modify-write) goes to "refill"
-		if (!NRS_EXP_STAMP) NRS_PHASE(5); // composite + march + shade
+		NRS_PHASE(5); // composite + march + shade
 		// (read here, not in front of the frame loop: six scalar registers that would otherwise live through every phase)
 		const f3 cam_fwd = mk3(p3.camera_matrix1[6], p3.camera_matrix1[7], p3.camera_matrix1[8]);
 		const f3 cam_o = mk3(p3.camera_matrix1[9], p3.camera_matrix1[10], p3.camera_matrix1[11]);
@@ -880,7 +838,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			// every lane of the team composites the team's samples in marching order (composite_kernel_nerf, tn:750-955)
 			bool done = false, shade = true, exited = false; // exited: the ray left the render box un-saturated (Cost mode counts one more step for it, below)
 			#pragma unroll
-			for (int k = 0; k < (TEAM ? TEAM : NRS_TEAM_MAX); ++k) {
+			for (int k = 0; k < (TEAM ? TEAM : kTeamMax); ++k) {
 				if (TEAM == 0 && k >= (int)gen_t) break;
 				const int src = team_base + k;
 				const bool v_k = __shfl((int)act, src, 64) != 0;
@@ -923,7 +881,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				const bool chain = __shfl((int)valid, last, 64) != 0; // the last lane stands on a sample, hence every lane of the team does
 				float cand = u0;
 				#pragma unroll
-				for (int j = 0; j < (TEAM ? TEAM : NRS_TEAM_MAX); ++j)
+				for (int j = 0; j < (TEAM ? TEAM : kTeamMax); ++j)
 					if (j <= tk) cand += calc_dt(cand, p3.cone_angle_constant);
 				const bool holds = need && chain && stands_in_occupied_cell(p3, m3, sm.coarse, o, d, cand);
 				const uint32_t team_bits = (uint32_t)(__ballot(holds) >> team_base) & ((1u << gen_t) - 1u);
@@ -961,12 +919,12 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 							tr = srgb_to_linear(tr); tg = srgb_to_linear(tg); tb = srgb_to_linear(tb);
 						}
 						float4* fb = reinterpret_cast<float4*>(a3.frame) + out_idx;
-						if (NRS_OPT_SAT_WRITE && ta == 1.0f) {
+						if (ta == 1.0f) {
 							*fb = make_float4(tr, tg, tb, 1.0f); // (see the one-lane path)
 						} else {
-						const float4 prev = *fb;
-						const float om = 1.0f - ta;
-						*fb = make_float4(tr + prev.x * om, tg + prev.y * om, tb + prev.z * om, ta + prev.w * om);
+							const float4 prev = *fb;
+							const float om = 1.0f - ta;
+							*fb = make_float4(tr + prev.x * om, tg + prev.y * om, tb + prev.z * om, ta + prev.w * om);
 						}
 						if (ta > 0.2f) a3.depth[out_idx] = ray_depth;
 						++st_hit;
@@ -1031,7 +989,6 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			}
 			++n_steps;
 			++st_samples;
-			if (NRS_EXP_STAMP) NRS_PHASE(5);
 			bool done = false, shade = true, exited = false;
 			if (ca > (1.0f - p3.min_transmittance)) {
 				// rgba /= alpha (tn:951-953): one v_rcp (1 ulp) + three multiplies instead of four IEEE divisions -- this block runs
@@ -1044,13 +1001,12 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			} else {
 				t += dt;
 				f3 npos; float ndt;
-#if NRS_EXP_DBL == 5
-				{ float t2 = t; asm volatile("" : "+v"(t2)); f3 np2; float nd2; const bool v2 = march_to_occupied(p3, m3, sm.coarse, o, d, t2, np2, nd2, nullptr, nullptr); asm volatile("" :: "v"(t2), "s"((int)__ballot(v2))); }
+#if NRS_MEASURE == 5
+				{ float t2 = t; asm volatile("" : "+v"(t2)); f3 np2; float nd2; const bool v2 = march_to_occupied(p3, m3, sm.coarse, o, d, t2, np2, nd2, nullptr); asm volatile("" :: "v"(t2), "s"((int)__ballot(v2))); }
 #endif
-				done = !march_to_occupied<true>(p3, m3, sm.coarse, o, d, t, npos, ndt, PROF ? &it_march : nullptr, NRS_OPT_EARLY_MARCH ? &occ_seed : nullptr);
+				done = !march_to_occupied<true>(p3, m3, sm.coarse, o, d, t, npos, ndt, PROF ? &it_march : nullptr);
 				exited = done;
 			}
-			if (NRS_EXP_STAMP) NRS_PHASE(1);
 			if (done) {
 				if (shade && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
 					float tr = cr, tg = cg, tb = cb, ta = ca;
@@ -1067,16 +1023,16 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 						tr = srgb_to_linear(tr); tg = srgb_to_linear(tg); tb = srgb_to_linear(tb);
 					}
 					float4* fb = reinterpret_cast<float4*>(a3.frame) + out_idx;
-					// NRS_OPT_SAT_WRITE: a ray that saturated was normalised to alpha = 1 exactly (tn:951-953), so shade_kernel_nerf's `tmp + frame * (1 - tmp.w)` is
+					// A ray that saturated was normalised to alpha = 1 exactly (tn:951-953), so shade_kernel_nerf's `tmp + frame * (1 - tmp.w)` is
 					// `tmp + frame * 0` = tmp for every finite frame value: such a ray WRITES its pixel without reading it -- the frame read is an HBM miss on the
 					// round's dependency chain, and nearly every round of a wave retires some ray.  (A non-finite value in the caller's frame would have turned into NaN
 					// through the multiplication by 0; it is overwritten instead.)
-					if (NRS_OPT_SAT_WRITE && ta == 1.0f) {
+					if (ta == 1.0f) {
 						*fb = make_float4(tr, tg, tb, 1.0f);
 					} else {
-					const float4 prev = *fb;
-					const float om = 1.0f - ta;
-					*fb = make_float4(tr + prev.x * om, tg + prev.y * om, tb + prev.z * om, ta + prev.w * om);
+						const float4 prev = *fb;
+						const float om = 1.0f - ta;
+						*fb = make_float4(tr + prev.x * om, tg + prev.y * om, tb + prev.z * om, ta + prev.w * om);
 					}
 					if (ta > 0.2f) a3.depth[out_idx] = ray_depth;
 					++st_hit;

@@ -132,17 +132,8 @@ __device__ __forceinline__ void level_eval_slow(const GridView gv, const LevelPa
 // Index arithmetic on the full-rate 24-bit multiplier.  v_mul_lo_u32 is a quarter-rate instruction (16 cycles per wave64 against 4), and the gather
 // issues four of them per level pair.  v_mul_u32_u24 returns the low 32 bits of the product of the operands' low 24 bits -- the same number whenever
 // both operands are below 2^24 (grid coordinates, resolutions, and resolution^2 of every level that can have dense storage or records: res < 4096),
-// and the same LOW 24 BITS for any operands, which is all a hashed index keeps (mask = 2^log2_T - 1, log2_T <= 24).  NRS_OPT_U24=0: the plain products.
-#ifndef NRS_OPT_U24
-#define NRS_OPT_U24 1
-#endif
-__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
-#if NRS_OPT_U24
-	return __umul24(a, b);
-#else
-	return a * b;
-#endif
-}
+// and the same LOW 24 BITS for any operands, which is all a hashed index keeps (mask = 2^log2_T - 1, log2_T <= 24).
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32x2 grid_load2_bytes(const GridView& v, uint32_t byte_offset) {
@@ -162,29 +153,15 @@ __device__ __forceinline__ CellCoords cell_coords(const LevelParams& lp, f3 pos)
 // The same for a position inside [0,1]^3 (every caller of the record paths: a wave with a sample outside the cube gathers the native way): there
 // p = scale * x + 0.5 >= 0.5, so the cell is the truncation of p (v_cvt_u32_f32: no floor, no second conversion) and the weight its fractional part
 // (v_fract_f32 = p - floor(p), exact for p >= 0): the same cell and the same weight bits in 9 instructions per level instead of 12.
-#ifndef NRS_OPT_FRACT
-#define NRS_OPT_FRACT 1
-#endif
-#ifndef NRS_OPT_PKCOORD
-#define NRS_OPT_PKCOORD 1 // scale * (x, y) + 0.5 as one v_pk_fma_f32 (two IEEE fmas: same bits), z alone
-#endif
 __device__ __forceinline__ CellCoords cell_coords_incube(const LevelParams& lp, f3 pos) {
-#if NRS_OPT_FRACT
 	CellCoords c;
-#if NRS_OPT_PKCOORD
-	typedef float f2p __attribute__((ext_vector_type(2)));
+	typedef float f2p __attribute__((ext_vector_type(2))); // scale * (x, y) + 0.5 as one v_pk_fma_f32 (two IEEE fmas: same bits), z alone
 	const f2p sc = {lp.scale, lp.scale}, xy = {pos.x, pos.y}, hf = {0.5f, 0.5f};
 	const f2p pxy = __builtin_elementwise_fma(sc, xy, hf);
 	const float px = pxy.x, py = pxy.y, pz = fmaf(lp.scale, pos.z, 0.5f);
-#else
-	const float px = fmaf(lp.scale, pos.x, 0.5f), py = fmaf(lp.scale, pos.y, 0.5f), pz = fmaf(lp.scale, pos.z, 0.5f);
-#endif
 	c.gx = (uint32_t)px; c.gy = (uint32_t)py; c.gz = (uint32_t)pz;
 	c.wx = __builtin_amdgcn_fractf(px); c.wy = __builtin_amdgcn_fractf(py); c.wz = __builtin_amdgcn_fractf(pz);
 	return c;
-#else
-	return cell_coords(lp, pos);
-#endif
 }
 typedef float f2 __attribute__((ext_vector_type(2)));
 // dense fast path precondition: no index of the cell reaches `count`, so no wrap and x-neighbours are adjacent entries
@@ -193,16 +170,12 @@ __device__ __forceinline__ bool dense_needs_slow(const LevelParams& lp, const Ce
 	       c.gx + mul24(c.gy, lp.resolution) + mul24(c.gz, lp.res2) + 1u + lp.resolution + lp.res2 >= lp.count; // (the products are only used when the three tests before passed)
 }
 // Issue the gathers of one sample at one level: v[2q + bx] = entry of corner (bx, q&1, q>>1).
-#ifndef NRS_OPT_HASH4
-#define NRS_OPT_HASH4 1 // hashed levels: the entry's byte offset formed directly (pre-shifted hash terms, level offset in the load's scalar offset)
-#endif
 // Dense levels fetch the two x-neighbours with ONE 8-byte load (entry(x+1) = entry(x) + 1; MUBUF needs dword alignment only).
 template <bool HASHED>
 __device__ __forceinline__ void issue_gathers(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t v[8]) {
 	const uint32_t off4 = lp.offset * 4u;
 	if (HASHED) {
 		// (only the bits under lp.mask < 2^24 survive: the low 24 bits of the primes on the 24-bit multiplier give the same index)
-#if NRS_OPT_U24 && NRS_OPT_HASH4
 		// The BYTE offset of an entry directly: 4 e = (4 x ^ 4 y P1 ^ 4 z P2) & 4 mask (shifts commute with xor and and), with 4 P < 2^24 on the 24-bit
 		// multiplier (the low 24 bits of the primes, as above: 4 mask < 2^26 keeps bits 2..25 of the products, i.e. bits 0..23 of y P), and the level's
 		// first entry in the instruction's scalar offset -- no shift and no add per corner.
@@ -214,15 +187,6 @@ __device__ __forceinline__ void issue_gathers(const GridView& gv, const LevelPar
 			const uint32_t e4 = (((k & 1) ? hx1 : hx0) ^ ((k & 2) ? hy1 : hy0) ^ ((k & 4) ? hz1 : hz0)) & mask4;
 			v[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(gv.rsrc, (int)e4, (int)off4, 0);
 		}
-#else
-		const uint32_t hx0 = c.gx, hx1 = c.gx + 1u, hy0 = mul24(c.gy, NRS_OPT_U24 ? (2654435761u & 0xffffffu) : 2654435761u), hy1 = hy0 + 2654435761u,
-		               hz0 = mul24(c.gz, NRS_OPT_U24 ? (805459861u & 0xffffffu) : 805459861u), hz1 = hz0 + 805459861u;
-		#pragma unroll
-		for (int k = 0; k < 8; ++k) {
-			const uint32_t e = (((k & 1) ? hx1 : hx0) ^ ((k & 2) ? hy1 : hy0) ^ ((k & 4) ? hz1 : hz0)) & lp.mask;
-			v[k] = grid_load_bytes(gv, (e << 2) + off4);
-		}
-#endif
 	} else {
 		const uint32_t base = c.gx + mul24(c.gy, lp.resolution) + mul24(c.gz, lp.res2); // dense level: res^3 <= 2^24, coordinates checked by dense_needs_slow
 		#pragma unroll
@@ -248,12 +212,6 @@ __device__ __forceinline__ void issue_record_loads(const GridView& gv, const Lev
 	v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
 	v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
 }
-#ifndef NRS_OPT_NETACC_MIX
-#define NRS_OPT_NETACC_MIX 1 // NETACC interpolation: per-corner products by v_fma_mix_f32 + one packed conversion (0: convert + packed multiply, as the compiler lowers the plain expression; 2: v_fma_mixlo/hi_f16, an experiment that is neither bit-exact nor faster)
-#endif
-#ifndef NRS_OPT_PKW
-#define NRS_OPT_PKW 1 // trilinear weights as packed fp32 products (v_pk_mul_f32: twelve products in six issue slots; 0: scalar products)
-#endif
 // Trilinear interpolation in the oracle's order (corner 0..7, x fastest; weight = (wx' * wy') * wz') -> packed fp16 pair.
 // NETACC (nrs_grid_acc NETWORK): tiny-cuda-nn's kernel_grid as recalled -- every corner's fp32 product is rounded to fp16 and added in fp16.
 template <bool NETACC = false>
@@ -265,30 +223,15 @@ __device__ __forceinline__ uint32_t interpolate(const CellCoords& c, const uint3
 		#pragma unroll
 		for (int k = 0; k < 8; ++k) {
 			const float weight = wxy[k & 3] * ((k & 4) ? c.wz : uz);
-#if NRS_OPT_NETACC_MIX == 2
-			// EXPERIMENT, not the shipped path: (T)(weight * (float)value) for both features by v_fma_mixlo_f16 / v_fma_mixhi_f16 (fp32 x fp16 -> fp16 into the low /
-			// high half of one register) + one v_pk_add_f16, 3 issue slots per corner.  Measured on the GPU (round 4): the features are NOT bit-identical to the
-			// oracle's two-step rounding (tests/test_gpu_numerics.py::test_operator_in_each_mode fails) and the frame is 2.5 % SLOWER than with NRS_OPT_NETACC_MIX=1
-			// (9.09 against 9.32 Gsamples/s: three dependent instructions per corner) -- profiles/r04/ab_numerics_variants.txt.
-			uint32_t pr = 0;
-			asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(pr) : "v"(weight), "v"(v[k]));
-			asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(pr) : "v"(weight), "v"(v[k]));
-			r = r + __builtin_bit_cast(half2v, pr);
-#elif NRS_OPT_NETACC_MIX == 1
 			// the two fp32 products straight from the packed fp16 entry (v_fma_mix_f32 with a zero addend: the product's own rounding), one v_cvt_pk_f16_f32,
-			// one v_pk_add_f16: 4 issue slots per corner
+			// one v_pk_add_f16: 4 issue slots per corner.  (v_fma_mixlo/hi_f16 -- 3 slots -- is neither bit-identical to the two-step rounding nor faster:
+			// profiles/r04/ab_numerics_variants.txt.)
 			const half2v pr = {(_Float16)fma_mix_lo(weight, v[k], 0.f), (_Float16)fma_mix_hi(weight, v[k], 0.f)};
 			r = r + pr;
-#else
-			const half2v hv = __builtin_bit_cast(half2v, v[k]);
-			r[0] = r[0] + (_Float16)(weight * (float)hv[0]);
-			r[1] = r[1] + (_Float16)(weight * (float)hv[1]);
-#endif
 		}
 		return __builtin_bit_cast(uint32_t, r);
 	}
 	float acc0 = 0.f, acc1 = 0.f;
-#if NRS_OPT_PKW
 	{ // the same twelve products as packed fp32 multiplies (v_pk_mul_f32: two IEEE products per issue slot; same bits)
 		typedef float f2v __attribute__((ext_vector_type(2)));
 		const f2v xs = {ux, c.wx};
@@ -301,14 +244,6 @@ __device__ __forceinline__ uint32_t interpolate(const CellCoords& c, const uint3
 			acc1 = fma_mix_hi(wk[k], v[k], acc1);
 		}
 	}
-#else
-	#pragma unroll
-	for (int k = 0; k < 8; ++k) {
-		const float weight = wxy[k & 3] * ((k & 4) ? c.wz : uz);
-		acc0 = fma_mix_lo(weight, v[k], acc0);
-		acc1 = fma_mix_hi(weight, v[k], acc1);
-	}
-#endif
 	half2v r;
 	r[0] = (_Float16)acc0;
 	r[1] = (_Float16)acc1;
@@ -405,9 +340,6 @@ __device__ __forceinline__ void level_eval_two(const GridView& gv, const LevelPa
 // trips and the gather is eight of them; the twelve record levels then cost three trips instead of six.  The price is registers (32 loaded dwords
 // instead of 16): the interpolation weights are therefore NOT kept across the loads but recomputed from the position (9 instructions per level),
 // behind an opaque copy of the position so that the compiler cannot keep the first set alive.
-#ifndef NRS_OPT_QUADS
-#define NRS_OPT_QUADS 1
-#endif
 template <bool NETACC = false, bool ZERO = true>
 __device__ __forceinline__ void record_eval_four(const GridView& gv, const LevelParams& lp0, const LevelParams& lp1, const LevelParams& lp2, const LevelParams& lp3, f3 pos, bool act,
                                                  uint32_t& f0, uint32_t& f1, uint32_t& f2, uint32_t& f3_) {
@@ -426,9 +358,6 @@ __device__ __forceinline__ void record_eval_four(const GridView& gv, const Level
 
 // The same for FOUR hashed levels (the two pairs behind the cell records: levels 12..15 of base.json's table): 32 single-dword gathers in flight, one round trip
 // instead of two.  The hashes need the cells before the loads; the weights are recomputed behind them (as above).
-#ifndef NRS_OPT_HQUADS
-#define NRS_OPT_HQUADS 1
-#endif
 // INCUBE: every sample of the wave lies in [0, 1]^3 (the caller's wave-uniform test): truncation / v_fract instead of floor / subtract, as for the records
 template <bool NETACC = false, bool ZERO = true, bool INCUBE = false>
 __device__ __forceinline__ void hashed_eval_four(const GridView& gv, const LevelParams& lp0, const LevelParams& lp1, const LevelParams& lp2, const LevelParams& lp3, f3 pos, bool act,
@@ -490,7 +419,7 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 		LevelParams lp0 = lv[2 * it], lp1 = lv[2 * it + 1];
 		if (one_line) { lp0.hashed = lp1.hashed = 1u; lp0.mask = lp1.mask = 31u; lp0.offset = lp1.offset = 0u; lp0.count = lp1.count = 32u; }
 		const uint32_t kind = __builtin_amdgcn_readfirstlane(kinds[it]);
-		if (NRS_OPT_QUADS && QUADS && kind == KIND_RECORD && it + 1 < 8 && __builtin_amdgcn_readfirstlane(kinds[it + 1]) == KIND_RECORD) {
+		if (QUADS && kind == KIND_RECORD && it + 1 < 8 && __builtin_amdgcn_readfirstlane(kinds[it + 1]) == KIND_RECORD) {
 			uint32_t f0, f1, f2, f3_;
 			record_eval_four<NETACC, ZERO>(gv, lp0, lp1, lv[2 * it + 2], lv[2 * it + 3], pos, act, f0, f1, f2, f3_);
 			fl.feat[it][0][lane] = g ? f1 : f0;
@@ -500,7 +429,7 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 			it += 2;
 			continue;
 		}
-		if (NRS_OPT_HQUADS && QUADS && kind == KIND_HASHED && it + 1 < 8 && __builtin_amdgcn_readfirstlane(kinds[it + 1]) == KIND_HASHED) {
+		if (QUADS && kind == KIND_HASHED && it + 1 < 8 && __builtin_amdgcn_readfirstlane(kinds[it + 1]) == KIND_HASHED) {
 			uint32_t f0, f1, f2, f3_;
 			if (!outside) hashed_eval_four<NETACC, ZERO, true>(gv, lp0, lp1, lv[2 * it + 2], lv[2 * it + 3], pos, act, f0, f1, f2, f3_);
 			else hashed_eval_four<NETACC, ZERO, false>(gv, lp0, lp1, lv[2 * it + 2], lv[2 * it + 3], pos, act, f0, f1, f2, f3_);
@@ -627,19 +556,13 @@ __device__ __forceinline__ floatx16 zero16() {
 #define NRS_FRAG_SEL(h) (24 + (h))
 #define NRS_FRAG_BWD(ks) (26 + (ks)) // (HBM only: DeviceModel::wfrag + ...; see nrs_internal.h)
 // ACC16 (nrs_mlp_acc FP16): the running sums are rounded to fp16 after every 16-wide k step, the model of tiny-cuda-nn's fp16 accumulator fragments.
-// NRS_OPT_ACC16_SEL (round 4): the rounded sums go back into the accumulator registers THROUGH THE MATRIX CORE -- pack to fp16 (8 v_cvt_pk_f16_f32: the
+// (round 4) the rounded sums go back into the accumulator registers THROUGH THE MATRIX CORE -- pack to fp16 (8 v_cvt_pk_f16_f32: the
 // rounding), then MFMA(Sel0, lo, 0) and MFMA(Sel1, hi, .) with the two constant 0 / 1 fragments, which reproduce the packed values exactly in fp32
 // (1.0 x h summed with zeros) in the D layout -- and the k step's own MFMA accumulates on top as before.  8 VALU slots per rounding instead of 24-32 on a
-// kernel that is VALU-bound, paid with two issues on a pipe that is 10 % busy; same values (tests/test_gpu_numerics.py; A/B: NRS_OPT_ACC16_SEL=0).
-#ifndef NRS_OPT_ACC16_SEL
-#define NRS_OPT_ACC16_SEL 1
-#endif
-#ifndef NRS_ACC16_FENCE
-#define NRS_ACC16_FENCE 1
-#endif
+// kernel that is VALU-bound (the packed-conversion round trip on the vector pipe: profiles/r04/ab_numerics_variants.txt), paid with two issues on a pipe
+// that is 10 % busy; same values (tests/test_gpu_numerics.py).
 template <bool ACC16>
 __device__ __forceinline__ floatx16 mfma_step(const half8* lds_w, int lane, half8 a, half8 b, floatx16 c) {
-#if NRS_OPT_ACC16_SEL
 	if (ACC16) {
 		half8 lo, hi;
 		#pragma unroll
@@ -647,27 +570,11 @@ __device__ __forceinline__ floatx16 mfma_step(const half8* lds_w, int lane, half
 		floatx16 z;
 		#pragma unroll
 		for (int i = 0; i < 16; ++i) z[i] = 0.f;
-#if NRS_ACC16_FENCE
 		__builtin_amdgcn_sched_barrier(0); // (keeps the selection fragments' LDS reads of later steps from being hoisted over this one: registers)
-#endif
 		c = NRS_MFMA(lds_w[NRS_FRAG_SEL(0) * 64 + lane], lo, z);
 		c = NRS_MFMA(lds_w[NRS_FRAG_SEL(1) * 64 + lane], hi, c);
 	}
 	return NRS_MFMA(a, b, c);
-#else
-	if (ACC16) {
-		// round-trip through PACKED halfs: 8 v_cvt_pk_f16_f32 + 16 v_cvt_f32_f16 (the odd ones read the high half through SDWA) instead of 16 + 16 scalar
-		// conversions -- the same round-to-nearest-even values.  (The opaque copy keeps the compiler from splitting the pair again.)
-		#pragma unroll
-		for (int i = 0; i < 8; ++i) {
-			half2v h = {(_Float16)c[2 * i], (_Float16)c[2 * i + 1]};
-			asm volatile("" : "+v"(h));
-			c[2 * i] = (float)h[0];
-			c[2 * i + 1] = (float)h[1];
-		}
-	}
-	return NRS_MFMA(a, b, c);
-#endif
 }
 // the first k step of a layer: nothing to round yet
 __device__ __forceinline__ floatx16 mfma_first(half8 a, half8 b) {

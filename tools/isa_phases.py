@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Instruction counts per basic block of one kernel in a hipcc -S listing built with -DNRS_MARKERS (nrs_kernels.hip: NRS_MARK comments at
+"""Instruction counts per basic block of one kernel in a hipcc -S listing built with -DNRS_MEASURE=9 (nrs_kernels.hip: NRS_MARK comments at
 the phase boundaries of render_kernel).  usage: isa_phases.py listing.s <mangled kernel substring>"""
 import re
 import sys
