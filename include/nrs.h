@@ -274,10 +274,10 @@ int  nrs_ctx_set_lane_teams(nrs_ctx* ctx, int lanes_per_ray);
 int  nrs_ctx_set_ray_handover(nrs_ctx* ctx, int enabled);
 int  nrs_ctx_ray_handovers(const nrs_ctx* ctx, uint64_t* n_rays, uint64_t* n_handovers);
 
-/* MEMORY NOTE: a model keeps a cell-record cache by DEFAULT (budget 10 GiB; 9.2 GB for base.json's table: nrs_model_set_cell_cache below).  It is allocated and filled
- * inside the first nrs_model_set_params and rebuilt inside every later one (1.9 ms for 9.2 GB).  A caller whose parameters change every frame -- a training viewer -- or
- * that cannot spare the memory calls nrs_model_set_cell_cache(model, 0) right after nrs_model_create: results are bit-identical, the frame is about 15 % slower
- * (bench.py key lego_cage_norecords).  NRS_CELL_CACHE_GB in the environment overrides the default budget. */
+/* MEMORY NOTE: a model holds its parameters only (24-27 MB).  The cell-record cache -- a memory-for-instructions trade, about 15 % of a lego frame (bench.py key
+ * lego_cage_norecords) -- is OPT-IN: nrs_model_set_cell_cache(model, budget) below (10 GiB holds levels 0..11 of base.json's table: 9.2 GB), allocated and filled inside
+ * that call and rebuilt inside every later nrs_model_set_params (1.9 ms for 9.2 GB); a caller whose parameters change every frame -- a training viewer -- leaves it off.
+ * Results are bit-identical either way.  NRS_CELL_CACHE_GB in the environment switches it on at nrs_model_create for a host that cannot be changed. */
 int    nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out);
 void   nrs_model_destroy(nrs_model* model);
 /* number of fp16 parameters the description implies (density MLP | rgb MLP | hash grid), host-only */

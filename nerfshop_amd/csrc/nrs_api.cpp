@@ -72,9 +72,8 @@ struct nrs_ctx {
 	static constexpr int kMaxEdits = 32;
 };
 
-// default budget of the cell-record cache: levels 0..11 of base.json's table (9.3 GB); measured best on 1080p lego (12 levels
-// 8.80, 14 levels (64 GB) 8.64, 10 levels 8.52, none 8.05 Gsamples/s)
-constexpr size_t kDefaultCellCacheBytes = 10ull << 30;
+// (the cell-record cache's measured optimum on 1080p lego is 10 GiB = levels 0..11 of base.json's table, 9.2 GB: 12 levels 8.80, 14 levels (64 GB) 8.64, 10 levels 8.52,
+// none 8.05 Gsamples/s -- the budget a caller who opts in would pass: include/nrs.h MEMORY NOTE)
 
 struct nrs_model {
 	nrs_ctx* ctx = nullptr;
@@ -510,9 +509,10 @@ int nrs_model_create(nrs_ctx* ctx, const nrs_model_desc* desc, nrs_model** out) 
 	m->dm.grid = m->d_grid;
 	m->dm.wfrag = m->d_wfrag;
 	m->dm.bitfield = m->d_bitfield;
-	{ // cell-record cache: on by default for the levels that fit kDefaultCellCacheBytes, never more than a quarter of the free HBM
-		size_t budget = kDefaultCellCacheBytes, free_b = 0, total_b = 0;
-		if (const char* e = getenv("NRS_CELL_CACHE_GB")) budget = (size_t)(atof(e) * 1073741824.0);
+	// The cell-record cache is OPT-IN since round 6 (a 24 MB model does not reserve gigabytes unasked): nrs_model_set_cell_cache(model, budget), or NRS_CELL_CACHE_GB in
+	// the environment for a host that cannot be changed -- never more than a quarter of the free HBM.
+	if (const char* e = getenv("NRS_CELL_CACHE_GB")) {
+		size_t budget = (size_t)(atof(e) * 1073741824.0), free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, free_b / 4);
 		if (nrs_model_set_cell_cache(m, budget) != NRS_OK) (void)nrs_model_set_cell_cache(m, 0); // an optimisation: render without it
 	}

@@ -11,6 +11,7 @@ PyTorch is plumbing only: device memory (torch tensors), streams.  All arithmeti
 there is no CPU path -- a missing library or GPU raises NrsError.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -74,13 +75,24 @@ class Context:
             pass
 
 
+DEFAULT_CELL_CACHE_BYTES = 10 << 30  # levels 0..11 of base.json's table (9.2 GB)
+
+
 class NerfNetwork:
     """pos-encoding (HashGrid) -> density MLP -> (SH dir-encoding | density features) -> RGB MLP -> extract_density."""
 
-    def __init__(self, ctx, desc):
+    def __init__(self, ctx, desc, cell_cache_bytes=DEFAULT_CELL_CACHE_BYTES):
+        """cell_cache_bytes: budget of the cell-record cache this HARNESS opts into (nrs_model_set_cell_cache: opt-in at the C-ABI since round 6; never more than a
+        quarter of the free HBM); 0 = none."""
         self.ctx, self.lib, self.desc = ctx, ctx.lib, desc
         self.h = C.c_void_p()
         check(self.lib.nrs_model_create(ctx.h, C.byref(desc), C.byref(self.h)))
+        if cell_cache_bytes and "NRS_CELL_CACHE_GB" not in os.environ:
+            free_b = torch.cuda.mem_get_info(ctx.device)[0]
+            try:
+                self.set_cell_cache(min(int(cell_cache_bytes), free_b // 4))
+            except NrsError:
+                self.set_cell_cache(0)  # an optimisation: render without it
 
     # -- NerfNetwork<T> accessors (nerf_network.h:97-120)
     def padded_output_width(self):

@@ -2,8 +2,9 @@
 // aabb-16 frame -- 2 MB each -- compete for the 4 MB L2 of an XCD with 56 GB of record lines per frame that are used once.)
 // Every lane issues, per round, HOT_PER loads of 4 B at random offsets of a hot table of HOT_MB megabytes (plain loads) and COLD_PER loads of 32 B at random offsets of a
 // cold table of COLD_MB megabytes with policy P: 0 plain, 1 nt, 2 sc1 (agent-scope atomic 8 B x 4), 3 sc0 sc1, 4 = `buffer_load ... nt` through a buffer descriptor,
-// 5 = `buffer_load ... sc1 nt`, 6 = `buffer_load ... sc0 sc1 nt`.
-//   l2_retention_probe <hot MB> <cold MB> <policy> [rounds = 64] [hot loads per round = 8] [cold per round = 8]
+// 5 = `buffer_load ... sc1 nt`, 6 = `buffer_load ... sc0 sc1 nt`, 7 = first 16 B plain + second 16 B nt (the line is allocated by the first load; does the nt HIT demote it?),
+// 8 = first 16 B nt + second 16 B plain, 9 = ONE 16-byte nt load per gather (half a record: what a no-allocate policy costs without the second fetch).
+//   l2_retention_probe <hot MB> <cold MB> <policy> [rounds = 64] [hot loads per round = 8] [cold per round = 8] [cold alloc: 0 hipMalloc, 1 uncached, 2 fine-grained]
 // Run under rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum: misses beyond the cold gathers' own (lanes x rounds x COLD_PER) are hot-table misses.
 #include <hip/hip_runtime.h>
 
@@ -26,6 +27,9 @@ __device__ __forceinline__ uint32_t cold_load(const uint8_t* base, uint64_t slot
 	const uint8_t* p = base + slot * 32;
 	if (POLICY == 0) { const u32x4n a = reinterpret_cast<const u32x4n*>(p)[0], b = reinterpret_cast<const u32x4n*>(p)[1]; return a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w; }
 	if (POLICY == 1) { const u32x4n a = __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(p) + 1); return a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w; }
+	if (POLICY == 7) { const u32x4n a = reinterpret_cast<const u32x4n*>(p)[0], b = __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(p) + 1); return a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w; }
+	if (POLICY == 8) { const u32x4n a = __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(p)), b = reinterpret_cast<const u32x4n*>(p)[1]; return a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w; }
+	if (POLICY == 9) { const u32x4n a = __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(p)); return a.x ^ a.y ^ a.z ^ a.w; }
 	if (POLICY == 2 || POLICY == 3) {
 		uint64_t v = 0;
 		#pragma unroll
@@ -55,17 +59,18 @@ __global__ __launch_bounds__(256) void probe_kernel(const uint32_t* __restrict__
 }
 
 template <int POLICY>
-static int run(size_t hot_mb, size_t cold_mb, uint32_t rounds, uint32_t hot_per, uint32_t cold_per) {
+static int run(size_t hot_mb, size_t cold_mb, uint32_t rounds, uint32_t hot_per, uint32_t cold_per, int cold_alloc) {
 	const uint32_t lanes = 256u * 2048u;
 	uint32_t* d_hot = nullptr; uint8_t* d_cold = nullptr; uint32_t* d_out = nullptr;
 	CHECK(hipMalloc((void**)&d_hot, hot_mb << 20));
 	CHECK(hipMemset(d_hot, 1, hot_mb << 20));
-	CHECK(hipMalloc((void**)&d_cold, cold_mb << 20));
+	if (cold_alloc == 0) CHECK(hipMalloc((void**)&d_cold, cold_mb << 20));
+	else CHECK(hipExtMallocWithFlags((void**)&d_cold, cold_mb << 20, cold_alloc == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
 	CHECK(hipMemset(d_cold, 1, cold_mb << 20));
 	CHECK(hipMalloc((void**)&d_out, (size_t)lanes * 4));
 	hipEvent_t e0, e1;
 	CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-	hipLaunchKernelGGL((probe_kernel<POLICY>), dim3(lanes / 256), dim3(256), 0, 0, d_hot, (uint64_t)(hot_mb << 20) / 4, d_cold, (uint64_t)(cold_mb << 20) / 32, 2u, hot_per, cold_per, d_out);
+	hipLaunchKernelGGL((probe_kernel<POLICY>), dim3(lanes / 256), dim3(256), 0, 0, d_hot, (uint64_t)(hot_mb << 20) / 4, d_cold, (uint64_t)(cold_mb << 20) / 32, rounds, hot_per, cold_per, d_out); // (warm-up = a full launch: every dispatch of a PMC pass is the same)
 	CHECK(hipDeviceSynchronize());
 	float best = 1e30f;
 	for (int rep = 0; rep < 3; ++rep) {
@@ -77,7 +82,7 @@ static int run(size_t hot_mb, size_t cold_mb, uint32_t rounds, uint32_t hot_per,
 		CHECK(hipEventElapsedTime(&ms, e0, e1));
 		if (ms < best) best = ms;
 	}
-	printf("{\"policy\": %d, \"hot_mb\": %zu, \"cold_mb\": %zu, \"rounds\": %u, \"hot_per\": %u, \"cold_per\": %u, \"hot_gathers\": %.0f, \"cold_gathers\": %.0f, \"ms\": %.3f}\n", POLICY, hot_mb, cold_mb, rounds,
+	printf("{\"cold_alloc\": %d, \"policy\": %d, \"hot_mb\": %zu, \"cold_mb\": %zu, \"rounds\": %u, \"hot_per\": %u, \"cold_per\": %u, \"hot_gathers\": %.0f, \"cold_gathers\": %.0f, \"ms\": %.3f}\n", cold_alloc, POLICY, hot_mb, cold_mb, rounds,
 	       hot_per, cold_per, (double)lanes * rounds * hot_per, (double)lanes * rounds * cold_per, best);
 	return 0;
 }
@@ -87,14 +92,18 @@ int main(int argc, char** argv) {
 	const size_t hot = strtoull(argv[1], nullptr, 10), cold = strtoull(argv[2], nullptr, 10);
 	const int pol = atoi(argv[3]);
 	const uint32_t rounds = argc > 4 ? (uint32_t)atoi(argv[4]) : 64u, hp = argc > 5 ? (uint32_t)atoi(argv[5]) : 8u, cp = argc > 6 ? (uint32_t)atoi(argv[6]) : 8u;
+	const int ca = argc > 7 ? atoi(argv[7]) : 0;
 	switch (pol) {
-		case 0: return run<0>(hot, cold, rounds, hp, cp);
-		case 1: return run<1>(hot, cold, rounds, hp, cp);
-		case 2: return run<2>(hot, cold, rounds, hp, cp);
-		case 3: return run<3>(hot, cold, rounds, hp, cp);
-		case 4: return run<4>(hot, cold, rounds, hp, cp);
-		case 5: return run<5>(hot, cold, rounds, hp, cp);
-		case 6: return run<6>(hot, cold, rounds, hp, cp);
+		case 0: return run<0>(hot, cold, rounds, hp, cp, ca);
+		case 1: return run<1>(hot, cold, rounds, hp, cp, ca);
+		case 2: return run<2>(hot, cold, rounds, hp, cp, ca);
+		case 3: return run<3>(hot, cold, rounds, hp, cp, ca);
+		case 4: return run<4>(hot, cold, rounds, hp, cp, ca);
+		case 5: return run<5>(hot, cold, rounds, hp, cp, ca);
+		case 6: return run<6>(hot, cold, rounds, hp, cp, ca);
+		case 7: return run<7>(hot, cold, rounds, hp, cp, ca);
+		case 8: return run<8>(hot, cold, rounds, hp, cp, ca);
+		case 9: return run<9>(hot, cold, rounds, hp, cp, ca);
 	}
 	return 2;
 }

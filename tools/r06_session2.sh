@@ -15,16 +15,27 @@ V=$R/nerfshop_amd/csrc/variants
 for WL in lego_cage lego_cage_varied; do
   bash tools/ab_bench.sh $OUT/ab_refill_$WL.txt $WL base=default r16=$V/libnrs_refill16.so r32=$V/libnrs_refill32.so r48=$V/libnrs_refill48.so
 done
-# --- L2 retention probe
+# --- L2 retention probe: hot table (plain 4-byte gathers) + cold 32-byte gathers under a policy / an allocation kind
 P=$R/tools/probe/l2_retention_probe
 cd /tmp && export TMPDIR=/tmp
+run_ret() { # hot_mb policy hot_per cold_per alloc
+  $P $1 32768 $2 32 $3 $4 $5 >> $OUT/l2ret_time.jsonl 2>&1
+  D=/tmp/l2r; rm -rf $D
+  timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace -d $D -o gp -- $P $1 32768 $2 32 $3 $4 $5 > /tmp/gp.log 2>&1
+  echo "{\"hot_mb\": $1, \"policy\": $2, \"hot_per\": $3, \"cold_per\": $4, \"alloc\": $5, \"pmc\": $(python $R/tools/pmc_kernel.py $D probe_kernel)}" >> $OUT/l2ret_pmc.jsonl
+}
 for HOT in 2 4; do
-  for POL in 0 1 2 3 4 5 6; do
-    $P $HOT 32768 $POL 32 8 8 >> $OUT/l2ret_time.jsonl 2>&1
-    D=/tmp/l2r; rm -rf $D
-    timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace -d $D -o gp -- $P $HOT 32768 $POL 32 8 8 > /tmp/gp.log 2>&1
-    echo "{\"policy\": $POL, \"hot_mb\": $HOT, \"pmc\": $(python $R/tools/pmc_kernel.py $D probe_kernel)}" >> $OUT/l2ret_pmc.jsonl
-  done
+  run_ret $HOT 0 8 0 0          # the hot table alone
+  for POL in 0 1 4 7 8 9; do run_ret $HOT $POL 8 2 0; done
+  run_ret $HOT 0 8 2 1          # cold table in uncached memory
+  run_ret $HOT 0 8 2 2          # cold table in fine-grained memory
+done
+# request sizes of cold gathers alone from uncached / fine-grained memory
+for AL in 0 1 2; do
+  D=/tmp/l2r; rm -rf $D
+  timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace -d $D -o gp -- $P 2 32768 0 32 0 8 $AL > /tmp/gp.log 2>&1
+  echo "{\"cold_only_alloc\": $AL, \"pmc\": $(python $R/tools/pmc_kernel.py $D probe_kernel)}" >> $OUT/l2ret_pmc.jsonl
+  $P 2 32768 0 32 0 8 $AL >> $OUT/l2ret_time.jsonl 2>&1
 done
 cat $OUT/l2ret_time.jsonl $OUT/l2ret_pmc.jsonl
 cd $R
