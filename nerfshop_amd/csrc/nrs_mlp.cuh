@@ -23,6 +23,13 @@
 #include <hip/hip_runtime.h>
 #include "nrs_device.cuh"
 
+#ifndef NRS_PHASE_GATE
+#define NRS_PHASE_GATE 0 // (open A/B: see encode_to_lds)
+#endif
+#ifndef NRS_NT_BRICKS
+#define NRS_NT_BRICKS 0 // (open A/B: see issue_brick_record_loads)
+#endif
+
 namespace nrs {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -269,7 +276,15 @@ __device__ __forceinline__ uint32_t brick_entry(const GridView& gv, const LevelP
 __device__ __forceinline__ void issue_brick_record_loads(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t brick, uint32_t v[8]) {
 	const uint32_t rec = lp.rec_first + (brick - 1u) * 512u + brick_slot(c.gx & 7u, c.gy & 7u, c.gz & 7u);
 	const uint4* p = gv.records2 + 2 * (size_t)rec;
-	const uint4 lo = p[0], hi = p[1]; // (streaming these with non-temporal loads was measured: no gain on the aabb-16 scene)
+#if NRS_NT_BRICKS
+	// EXPERIMENT (round 6): `nt` on both halves -- the L2 then treats the record's line as streaming and the hot hashed tables keep their lines (tools/probe/l2_retention_probe:
+	// hot-table misses 30 % -> 10 % beside a cold stream); the two halves are issued back to back, so the second merges with the first one's miss
+	typedef uint32_t u4nt __attribute__((ext_vector_type(4)));
+	const u4nt lo_ = __builtin_nontemporal_load(reinterpret_cast<const u4nt*>(p)), hi_ = __builtin_nontemporal_load(reinterpret_cast<const u4nt*>(p) + 1);
+	const uint4 lo = make_uint4(lo_.x, lo_.y, lo_.z, lo_.w), hi = make_uint4(hi_.x, hi_.y, hi_.z, hi_.w);
+#else
+	const uint4 lo = p[0], hi = p[1];
+#endif
 	v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
 	v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
 }
@@ -413,9 +428,37 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 	const bool outside = __any(act && outside_unit_cube(pos));
 	const uint32_t* kinds = outside ? ml.kinds_native : ml.kinds;
 	const bool one_line = __builtin_amdgcn_readfirstlane(ml.one_line) != 0u; // profiling (NRS_DEBUG & 1): every gather of a wave hits one 128-byte line
-	int it = 0;
+	int it = 0, it_end = 8;
+#if NRS_PHASE_GATE
+	// EXPERIMENT (round 6, aabb-16 scenes; profiles/r06_garden.md): the four finest levels are hashed tables of 2 MB each -- 8 MB against the 4 MB L2 of an XCD: alone, each
+	// PAIR of them hits (0.15 L2 misses per sample), together they thrash (7.8).  Time-multiplex the L2: the wall clock (100 MHz, the same on every XCD) is cut into
+	// phases of 2^NRS_PHASE_GATE ticks; levels 12-13 are gathered in even phases, 14-15 in odd ones, by every wave of the GPU, with the record levels in between as filler.
+	// Results cannot change (the same loads, another order); a wave waits at most one phase.
+	bool gated = false;
+	uint32_t gate_ph = 0;
+	auto gate_wait = [&](uint32_t ph) {
+		uint32_t spins = 0;
+		while ((((uint32_t)(wall_clock64() >> NRS_PHASE_GATE)) & 1u) != ph && spins++ < (96u << (NRS_PHASE_GATE > 10 ? NRS_PHASE_GATE - 10 : 0))) __builtin_amdgcn_s_sleep(8);
+	};
+	auto gate_pair = [&](int itp) {
+		uint32_t f0, f1;
+		level_eval_two<KIND_HASHED, NETACC, ZERO>(gv, lv[2 * itp], lv[2 * itp + 1], pos, act, f0, f1);
+		fl.feat[itp][0][lane] = g ? f1 : f0;
+		fl.feat[itp][1][lane ^ 32] = g ? f0 : f1;
+	};
+	if (QUADS && !one_line && __builtin_amdgcn_readfirstlane(kinds[6]) == KIND_HASHED && __builtin_amdgcn_readfirstlane(kinds[7]) == KIND_HASHED &&
+	    __builtin_amdgcn_readfirstlane(kinds[5]) != KIND_HASHED) {
+		gated = true;
+		const unsigned long long now = wall_clock64();
+		constexpr unsigned long long kPhaseMask = (1ull << NRS_PHASE_GATE) - 1ull;
+		gate_ph = (uint32_t)(now >> NRS_PHASE_GATE) & 1u;
+		if ((now & kPhaseMask) > kPhaseMask * 13ull / 16ull) { gate_ph ^= 1u; gate_wait(gate_ph); } // (late in a phase: this gather would run into the next one -- take that)
+		gate_pair(6 + (int)gate_ph);
+		it_end = 6;
+	}
+#endif
 	#pragma unroll 1
-	while (it < 8) {
+	while (it < it_end) {
 		LevelParams lp0 = lv[2 * it], lp1 = lv[2 * it + 1];
 		if (one_line) { lp0.hashed = lp1.hashed = 1u; lp0.mask = lp1.mask = 31u; lp0.offset = lp1.offset = 0u; lp0.count = lp1.count = 32u; }
 		const uint32_t kind = __builtin_amdgcn_readfirstlane(kinds[it]);
@@ -454,6 +497,9 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 		fl.feat[it][1][lane ^ 32] = g ? f0 : f1;
 		++it;
 	}
+#if NRS_PHASE_GATE
+	if (gated) { gate_wait(gate_ph ^ 1u); gate_pair(7 - (int)gate_ph); }
+#endif
 	// feat[..][1][lane ^ 32] is another lane's slot: order the wave's writes before load_features' reads (no instruction: LDS operations of a wave
 	// stay in order; this keeps the compiler from moving a read above the write it cannot see through the xor)
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
