@@ -122,6 +122,14 @@ struct nrs_edit {
 	float* d_cage = nullptr;           // [n_cv x 3]
 	uint32_t n_cv = 0;
 	uint32_t lut_n_idx = 0, lut_max_per_cell = 0;
+	// fine look-up table under the LUT (DeviceEdit::fine_*, nrs_cage.hip): rebuilt with the LUT
+	uint32_t* d_fine_off = nullptr;    // [fine_cells_cap + 1]
+	uint32_t* d_fine_counts = nullptr; // [fine_cells_cap]
+	uint32_t* d_fine_idx = nullptr;
+	uint32_t* d_fine_tiles = nullptr;  // [kFineScanTiles]
+	int32_t* d_fine_win = nullptr;     // [kCascades * 6] window + [30] total entries
+	size_t fine_cells_cap = 0, fine_idx_cap = 0;
+	uint32_t fine_n_idx = 0;
 };
 
 // Marching parameters every ray-marching entry point hands to the kernels: min_mip indexes the 5-cascade bitfield (min_mip > 4 reads past
@@ -1024,6 +1032,74 @@ static int build_lut_on_device(nrs_edit* e, const float* d_verts, uint8_t* d_bit
 	e->lut_n_idx = total;
 	return NRS_OK;
 }
+// The fine look-up table of e's CURRENT LUT and plane records (both on the device, written on stream s): DeviceEdit::fine_*.  Leaves the operator without one (the kernels
+// then scan the LUT's own lists) when the mesh reaches no cell, when even one fine cell per LUT cell would exceed kFineMaxCells, or when NRS_NO_FINE_LUT is set (A/B).
+// Two small read-backs (the window, the entry count), like the LUT's own build.
+static int build_fine_lut(nrs_edit* e, hipStream_t s) {
+	static const bool off = dev_knob("NRS_NO_FINE_LUT") != nullptr;
+	DeviceEdit& de = e->de;
+	de.fine_off = nullptr;
+	de.fine_idx = nullptr;
+	de.fine_shift = 0;
+	memset(de.fine_win, 0, sizeof(de.fine_win));
+	e->fine_n_idx = 0;
+	if (off) return NRS_OK;
+	if (!e->d_fine_win) HIP_TRY(hipMalloc((void**)&e->d_fine_win, 32 * 4));
+	if (!e->d_fine_tiles) HIP_TRY(hipMalloc((void**)&e->d_fine_tiles, kFineScanTiles * 4));
+	CAGE_TRY(launch_fine_window(de.lut_off, e->d_fine_win, s));
+	int32_t win[kCascades * 6];
+	HIP_TRY(hipMemcpyAsync(win, e->d_fine_win, sizeof(win), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	int shift = 2;
+	uint64_t total = 0;
+	for (; shift >= 0; --shift) {
+		total = 0;
+		for (uint32_t c = 0; c < kCascades; ++c) {
+			const int32_t* w = win + 6 * c;
+			if (w[0] > w[3]) continue;
+			total += ((uint64_t)(w[3] - w[0] + 1) << shift) * ((uint64_t)(w[4] - w[1] + 1) << shift) * ((uint64_t)(w[5] - w[2] + 1) << shift);
+		}
+		if (total <= kFineMaxCells) break;
+	}
+	if (shift < 0 || total == 0) return NRS_OK;
+	de.fine_shift = (uint32_t)shift;
+	uint32_t base = 0;
+	for (uint32_t c = 0; c < kCascades; ++c) {
+		const int32_t* w = win + 6 * c;
+		int32_t* f = de.fine_win[c];
+		f[3] = (int32_t)base;
+		if (w[0] > w[3]) continue; // (extent 0: nothing of the mesh in this cascade)
+		for (int a = 0; a < 3; ++a) { f[a] = w[a] << shift; f[4 + a] = (w[3 + a] - w[a] + 1) << shift; }
+		base += (uint32_t)f[4] * (uint32_t)f[5] * (uint32_t)f[6];
+	}
+	const uint32_t n_cells = (uint32_t)total, n_padded = (n_cells + 4095u) / 4096u * 4096u;
+	if (n_padded > e->fine_cells_cap) {
+		(void)hipFree(e->d_fine_off); (void)hipFree(e->d_fine_counts);
+		e->d_fine_off = e->d_fine_counts = nullptr;
+		e->fine_cells_cap = 0;
+		const size_t cap = std::min<size_t>(kFineMaxCells, (size_t)n_padded + n_padded / 4 + 4095) / 4096 * 4096;
+		HIP_TRY(hipMalloc((void**)&e->d_fine_off, (cap + 1) * 4));
+		HIP_TRY(hipMalloc((void**)&e->d_fine_counts, cap * 4));
+		e->fine_cells_cap = cap;
+	}
+	CAGE_TRY(launch_fine_count_scan(de, n_cells, e->d_fine_counts, e->d_fine_tiles, e->d_fine_off, (uint32_t*)e->d_fine_win + 30, s));
+	uint32_t n_idx = 0;
+	HIP_TRY(hipMemcpyAsync(&n_idx, e->d_fine_win + 30, 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	if ((size_t)n_idx > e->fine_idx_cap || !e->d_fine_idx) {
+		(void)hipFree(e->d_fine_idx);
+		e->d_fine_idx = nullptr;
+		e->fine_idx_cap = 0;
+		const size_t cap = std::max<size_t>((size_t)n_idx + n_idx / 2, 1024);
+		HIP_TRY(hipMalloc((void**)&e->d_fine_idx, cap * 4));
+		e->fine_idx_cap = cap;
+	}
+	CAGE_TRY(launch_fine_fill(de, n_cells, e->d_fine_off, e->d_fine_idx, s));
+	e->fine_n_idx = n_idx;
+	de.fine_off = e->d_fine_off;
+	de.fine_idx = e->d_fine_idx;
+	return NRS_OK;
+}
 // everything that follows new deformed vertices in e->d_verts: bbox, LUT, rotations.  Synchronous.
 static int rebuild_after_vertices(nrs_edit* e, hipStream_t s) {
 	NRS_TRY(ensure_build_scratch(e));
@@ -1031,6 +1107,7 @@ static int rebuild_after_vertices(nrs_edit* e, hipStream_t s) {
 	NRS_TRY(build_lut_on_device(e, e->d_verts, nullptr, s));
 	if (e->d_rot) CAGE_TRY(launch_local_rotations(e->n_tets, e->d_verts, e->de.orig, e->de.tets, e->d_rot, s));
 	CAGE_TRY(launch_tet_planes(e->n_tets, e->d_verts, e->de.tets, e->d_planes, s));
+	NRS_TRY(build_fine_lut(e, s));
 	uint32_t host[8];
 	HIP_TRY(hipMemcpyAsync(host, e->d_scratch, sizeof(host), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
@@ -1131,6 +1208,10 @@ int nrs_edit_create(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_tet_mesh
 			if (st != NRS_OK) return bail((g_err = cage_last_error(), st));
 			if (hipDeviceSynchronize() != hipSuccess) return bail(fail(NRS_ERR_HIP, "nrs_edit_create: tet_planes_kernel failed"));
 		}
+		{ // (the fine look-up table of the LUT that was handed over)
+			const int st = build_fine_lut(e, nullptr);
+			if (st != NRS_OK) return bail(st);
+		}
 		if (mesh->h_local_rotations) {
 			he = hipMemcpy(e->d_rot, mesh->h_local_rotations, 36 * (size_t)mesh->n_tets, hipMemcpyHostToDevice);
 			if (he != hipSuccess) return bail(fail_hip(he, "nrs_edit_create: rotation upload"));
@@ -1211,6 +1292,7 @@ void nrs_edit_destroy(nrs_edit* e) {
 	for (void* p : e->allocs) (void)hipFree(p);
 	(void)hipFree(e->d_verts); (void)hipFree(e->d_lut_off); (void)hipFree(e->d_lut_idx); (void)hipFree(e->d_rot); (void)hipFree(e->d_planes);
 	(void)hipFree(e->d_big_cells); (void)hipFree(e->d_counts); (void)hipFree(e->d_tile_sums); (void)hipFree(e->d_scratch); (void)hipFree(e->d_mvc); (void)hipFree(e->d_cage);
+	(void)hipFree(e->d_fine_off); (void)hipFree(e->d_fine_counts); (void)hipFree(e->d_fine_idx); (void)hipFree(e->d_fine_tiles); (void)hipFree(e->d_fine_win);
 	delete e;
 }
 

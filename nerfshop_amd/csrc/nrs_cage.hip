@@ -33,6 +33,7 @@ constexpr uint32_t kCells = kGridVol * kCascades;
 constexpr uint32_t kScanTile = 4096; // cells per scan block: 256 threads x 16
 static_assert(kCells % kScanTile == 0, "scan tiles must cover the cell array exactly");
 constexpr uint32_t kScanTiles = kCells / kScanTile; // 2560
+static_assert(kFineMaxCells % kScanTile == 0 && kFineScanTiles == kFineMaxCells / kScanTile, "fine look-up table: scan tiles");
 
 // ---- Cage::interpolate_with_mvc (cage.cu:38-49): points[i] = sum_v w[i][v] * cage[v], v ascending, per component ----------
 __global__ void mvc_apply_kernel(uint32_t n_points, uint32_t n_cv, const float* __restrict__ weights, const float* __restrict__ cage,
@@ -212,11 +213,14 @@ __global__ __launch_bounds__(256) void scan_tile_sum_kernel(const uint32_t* __re
 	if (threadIdx.x == 0) tile_sums[blockIdx.x] = part[0];
 }
 // one block: tile_sums -> exclusive prefix in place; total -> offsets[kCells] and scratch_total
+constexpr uint32_t kMaxScanTiles = 4096; // (the cell -> tet LUT scans 2560 tiles, the fine look-up table up to kFineScanTiles = 4096)
 __global__ __launch_bounds__(1024) void scan_tile_prefix_kernel(uint32_t* __restrict__ tile_sums, uint32_t* __restrict__ offsets_last,
-                                                                 uint32_t* __restrict__ total_out) {
+                                                                 uint32_t* __restrict__ total_out, uint32_t n_tiles) {
 	__shared__ uint32_t part[1024];
-	constexpr uint32_t per = (kScanTiles + 1023) / 1024;
+	constexpr uint32_t per = (kMaxScanTiles + 1023) / 1024;
 	uint32_t v[per], s = 0;
+	const uint32_t kScanTiles = n_tiles; // (<= kMaxScanTiles)
+	#pragma unroll
 	for (uint32_t q = 0; q < per; ++q) {
 		const uint32_t i = threadIdx.x * per + q;
 		v[q] = i < kScanTiles ? tile_sums[i] : 0u;
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(1024) void scan_tile_prefix_kernel(uint32_t* __rest
 		__syncthreads();
 	}
 	uint32_t run = part[threadIdx.x] - s;
+	#pragma unroll
 	for (uint32_t q = 0; q < per; ++q) {
 		const uint32_t i = threadIdx.x * per + q;
 		if (i < kScanTiles) tile_sums[i] = run;
@@ -379,6 +384,92 @@ __global__ void tet_planes_kernel(uint32_t n_tets, const float* __restrict__ ver
 	for (int q = 0; q < 8; ++q) dst[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
 }
 
+// ---- fine look-up table under the reference's 128^3 cell -> tet LUT (DeviceEdit::fine_*; round 6) -------------------------------------------
+// The render path's scan of a LUT cell tests the cell's tets one after the other until one contains the sample: on the bench's cage 3.9 candidates per sample and --
+// a wave is as slow as its slowest lane -- 7 dependent round trips per round that scans.  The fine table cuts every LUT cell of the mesh's window into S^3 fine
+// cells (S = 4, 2 or 1 by the window's size) and gives each fine cell its LUT cell's list FILTERED IN ORDER: a tet stays unless one of its four face tests fails for EVERY
+// position of the fine cell.  The test is made on the plane records -- the very floats point_in_tet_rec compares -- in double precision, with the rounding error of the
+// float evaluation (four roundings per term: <= 4.0001 * 2^-24 * sum |n_i| |p_i - v_i|) doubled as slack, and the fine cell's box widened by what the index arithmetic can
+// round (1e-6 / cascade scale): a tet that the float predicate accepts for some position of the fine cell is never dropped, so the first containing tet of the
+// fine list is the first containing tet of the LUT cell's list -- the reference's result, bit for bit (tests/test_gpu_parity.py::test_map_rays_bit_exact and the 1080p frames).
+// window: per cascade the box of LUT cells with a non-empty list (from the LUT itself: whatever built it)
+__global__ __launch_bounds__(256) void fine_window_kernel(const uint32_t* __restrict__ offsets, int32_t* __restrict__ win) {
+	const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) * 16u; // 16 cells in Morton order: a 4 x 2 x 2 block
+	if (first >= kCells) return;
+	const uint32_t o0 = offsets[first], o1 = offsets[first + 16];
+	if (o0 == o1) return;
+	const uint32_t level = first / kGridVol;
+	int32_t lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+	uint32_t prev = o0;
+	for (uint32_t k = 0; k < 16; ++k) {
+		const uint32_t nxt = offsets[first + k + 1];
+		if (nxt != prev) {
+			const uint32_t m = (first + k) % kGridVol;
+			const int32_t c[3] = {(int32_t)morton3D_invert(m), (int32_t)morton3D_invert(m >> 1), (int32_t)morton3D_invert(m >> 2)};
+			for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], c[a]); hi[a] = max(hi[a], c[a]); }
+		}
+		prev = nxt;
+	}
+	for (int a = 0; a < 3; ++a) { atomicMin(win + level * 6 + a, lo[a]); atomicMax(win + level * 6 + 3 + a, hi[a]); }
+}
+// can tet `t` contain (by the float predicate of point_in_tet_rec) a position of the box [lo, hi]?  Conservative: false only when some face test fails everywhere.
+__device__ __forceinline__ bool tet_may_contain_box(const float* __restrict__ planes, uint32_t t, const double lo[3], const double hi[3]) {
+	const float* r = planes + 32 * (size_t)t;
+	const uint32_t signs = __float_as_uint(r[24]);
+	for (int f = 0; f < 4; ++f) {
+		double mx = 0.0, mn = 0.0, err = 0.0;
+		for (int i = 0; i < 3; ++i) {
+			const double n = (double)r[12 + 3 * f + i], v = (double)r[3 * f + i];
+			const double a = n * (lo[i] - v), b = n * (hi[i] - v);
+			mx += fmax(a, b);
+			mn += fmin(a, b);
+			err += fabs(n) * fmax(fabs(lo[i] - v), fabs(hi[i] - v));
+		}
+		const double slack = err * (8.0 / 16777216.0) + 1e-30; // twice the float evaluation's error bound
+		if ((signs >> f) & 1u) { if (mn > slack) return false; }   // the test wants the sign bit set: impossible when dot > 0 everywhere
+		else { if (mx < -slack) return false; }                    // ... clear: impossible when dot < 0 everywhere
+	}
+	return true;
+}
+// One thread per fine cell.  FILL == false: counts[cell] = survivors of its LUT cell's list.  FILL == true: writes them, in list order, at fine_off[cell].
+template <bool FILL>
+__global__ __launch_bounds__(256) void fine_lists_kernel(const DeviceEdit e, uint32_t n_cells, uint32_t* __restrict__ counts, const uint32_t* __restrict__ fine_off,
+                                                         uint32_t* __restrict__ fine_idx) {
+	const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
+	if (cell >= n_cells) return;
+	uint32_t level = 0;
+	#pragma unroll
+	for (uint32_t c = 1; c < kCascades; ++c)
+		if (e.fine_win[c][4] != 0 && cell >= (uint32_t)e.fine_win[c][3]) level = c; // (the windows follow one another in the offset array; empty ones have extent 0)
+	if (e.fine_win[level][4] == 0) { if (!FILL) counts[cell] = 0u; return; }
+	const uint32_t ex = (uint32_t)e.fine_win[level][4], ey = (uint32_t)e.fine_win[level][5];
+	const uint32_t rel = cell - (uint32_t)e.fine_win[level][3];
+	const uint32_t fx = rel % ex + (uint32_t)e.fine_win[level][0], fy = (rel / ex) % ey + (uint32_t)e.fine_win[level][1], fz = rel / (ex * ey) + (uint32_t)e.fine_win[level][2];
+	const uint32_t S = e.fine_shift, res = kGrid << S;
+	const uint32_t parent = level * kGridVol + morton3D(fx >> S, fy >> S, fz >> S);
+	const uint32_t j0 = e.lut_off[parent], j1 = e.lut_off[parent + 1];
+	uint32_t n = 0;
+	if (j0 < j1) {
+		// the positions u whose fine coordinate is (fx, fy, fz): q = ((u - 0.5) * 2^-level + 0.5), floor(q * res) = f  =>  u in 0.5 + ((f .. f + 1) / res - 0.5) * 2^level,
+		// widened by what the three float operations can round; the outermost fine cells take everything beyond (the index clamps)
+		const double scale = (double)(1u << level), margin = 1e-6 * scale;
+		const uint32_t f[3] = {fx, fy, fz};
+		double lo[3], hi[3];
+		for (int i = 0; i < 3; ++i) {
+			lo[i] = f[i] == 0 ? -1e30 : 0.5 + ((double)f[i] / (double)res - 0.5) * scale - margin;
+			hi[i] = f[i] == res - 1 ? 1e30 : 0.5 + ((double)(f[i] + 1) / (double)res - 0.5) * scale + margin;
+		}
+		uint32_t w = FILL ? fine_off[cell] : 0u;
+		for (uint32_t j = j0; j < j1; ++j) {
+			const uint32_t t = e.lut_idx[j];
+			if (!tet_may_contain_box(e.planes, t, lo, hi)) continue;
+			if (FILL) fine_idx[w++] = t;
+			++n;
+		}
+	}
+	if (!FILL) counts[cell] = n;
+}
+
 // ---- launchers ----------------------------------------------------------------------------------------------------------------
 int launch_mvc_apply(uint32_t n_points, uint32_t n_cv, const float* d_weights, const float* d_cage, float* d_points, void* stream) {
 	hipLaunchKernelGGL(mvc_apply_kernel, dim3((n_points + 127) / 128), dim3(128), 0, (hipStream_t)stream, n_points, n_cv, d_weights, d_cage, d_points);
@@ -403,7 +494,7 @@ int launch_lut_count_scan(uint32_t n_tets, const float* d_verts, const uint32_t*
 	hipLaunchKernelGGL(tet_mark_kernel<false>, dim3((n_waves + 3) / 4), dim3(256), 0, s, n_tets, d_verts, d_tets, d_counts, (const uint32_t*)nullptr,
 	                   (uint32_t*)nullptr);
 	hipLaunchKernelGGL(scan_tile_sum_kernel, dim3(kScanTiles), dim3(256), 0, s, d_counts, d_tile_sums);
-	hipLaunchKernelGGL(scan_tile_prefix_kernel, dim3(1), dim3(1024), 0, s, d_tile_sums, d_offsets + kCells, d_total);
+	hipLaunchKernelGGL(scan_tile_prefix_kernel, dim3(1), dim3(1024), 0, s, d_tile_sums, d_offsets + kCells, d_total, kScanTiles);
 	hipLaunchKernelGGL(scan_write_kernel, dim3(kScanTiles), dim3(256), 0, s, d_counts, d_tile_sums, d_offsets);
 	NRS_CAGE_CHECK("tet LUT count/scan launch");
 	return NRS_OK;
@@ -431,6 +522,33 @@ int launch_tet_planes(uint32_t n_tets, const float* d_verts, const uint32_t* d_t
 int launch_local_rotations(uint32_t n_tets, const float* d_verts, const float* d_orig, const uint32_t* d_tets, float* d_out, void* stream) {
 	hipLaunchKernelGGL(local_rotations_kernel, dim3((n_tets + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_tets, d_verts, d_orig, d_tets, d_out);
 	NRS_CAGE_CHECK("local_rotations_kernel launch");
+	return NRS_OK;
+}
+
+int launch_fine_window(const uint32_t* d_lut_off, int32_t* d_window_out, void* stream) {
+	hipStream_t s = (hipStream_t)stream;
+	static const int32_t init[kCascades * 6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1, 0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1, 0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1,
+	                                            0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1, 0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1};
+	if (hipMemcpyAsync(d_window_out, init, sizeof(init), hipMemcpyHostToDevice, s) != hipSuccess) { snprintf(g_cage_err, sizeof(g_cage_err), "fine look-up table: window init failed"); return NRS_ERR_HIP; }
+	hipLaunchKernelGGL(fine_window_kernel, dim3(kCells / 16 / 256), dim3(256), 0, s, d_lut_off, d_window_out);
+	NRS_CAGE_CHECK("fine_window_kernel launch");
+	return NRS_OK;
+}
+int launch_fine_count_scan(const DeviceEdit& de, uint32_t n_fine_cells, uint32_t* d_counts, uint32_t* d_tile_sums, uint32_t* d_fine_off, uint32_t* d_total, void* stream) {
+	hipStream_t s = (hipStream_t)stream;
+	const uint32_t n_tiles = (n_fine_cells + kScanTile - 1) / kScanTile, n_padded = n_tiles * kScanTile;
+	if (n_tiles == 0 || n_tiles > kMaxScanTiles) { snprintf(g_cage_err, sizeof(g_cage_err), "fine look-up table: %u fine cells", n_fine_cells); return NRS_ERR_INVALID_ARG; }
+	if (n_padded != n_fine_cells && hipMemsetAsync(d_counts + n_fine_cells, 0, (size_t)(n_padded - n_fine_cells) * 4, s) != hipSuccess) { snprintf(g_cage_err, sizeof(g_cage_err), "fine look-up table: memset failed"); return NRS_ERR_HIP; }
+	hipLaunchKernelGGL(fine_lists_kernel<false>, dim3((n_fine_cells + 255) / 256), dim3(256), 0, s, de, n_fine_cells, d_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+	hipLaunchKernelGGL(scan_tile_sum_kernel, dim3(n_tiles), dim3(256), 0, s, d_counts, d_tile_sums);
+	hipLaunchKernelGGL(scan_tile_prefix_kernel, dim3(1), dim3(1024), 0, s, d_tile_sums, d_fine_off + n_padded, d_total, n_tiles);
+	hipLaunchKernelGGL(scan_write_kernel, dim3(n_tiles), dim3(256), 0, s, d_counts, d_tile_sums, d_fine_off);
+	NRS_CAGE_CHECK("fine look-up table count/scan launch");
+	return NRS_OK;
+}
+int launch_fine_fill(const DeviceEdit& de, uint32_t n_fine_cells, const uint32_t* d_fine_off, uint32_t* d_fine_idx, void* stream) {
+	hipLaunchKernelGGL(fine_lists_kernel<true>, dim3((n_fine_cells + 255) / 256), dim3(256), 0, (hipStream_t)stream, de, n_fine_cells, (uint32_t*)nullptr, d_fine_off, d_fine_idx);
+	NRS_CAGE_CHECK("fine_lists_kernel launch");
 	return NRS_OK;
 }
 

@@ -722,9 +722,9 @@ __device__ __forceinline__ bool point_in_tet_rec(const float* __restrict__ recs,
 	return got == __float_as_uint(sg.x);
 }
 // first tet of the cell's list that contains p (0xffffffff: none); the next candidate's id is fetched while the current one is tested
-__device__ __forceinline__ uint32_t scan_cell_for_tet(const DeviceEdit& e, uint32_t cell, f3 p, uint32_t* n_tested = nullptr) {
-	const NRS_GLOBAL uint32_t* lut_off = gp(e.lut_off);
-	const NRS_GLOBAL uint32_t* lut_idx = gp(e.lut_idx);
+__device__ __forceinline__ uint32_t scan_list_for_tet(const DeviceEdit& e, const uint32_t* __restrict__ off, const uint32_t* __restrict__ idx, uint32_t cell, f3 p, uint32_t* n_tested = nullptr) {
+	const NRS_GLOBAL uint32_t* lut_off = gp(off);
+	const NRS_GLOBAL uint32_t* lut_idx = gp(idx);
 	const uint32_t j0 = lut_off[cell], j1 = lut_off[cell + 1];
 	uint32_t found = 0xffffffffu;
 	if (j0 < j1) {
@@ -738,6 +738,31 @@ __device__ __forceinline__ uint32_t scan_cell_for_tet(const DeviceEdit& e, uint3
 		}
 	}
 	return found;
+}
+__device__ __forceinline__ uint32_t scan_cell_for_tet(const DeviceEdit& e, uint32_t cell, f3 p, uint32_t* n_tested = nullptr) { return scan_list_for_tet(e, e.lut_off, e.lut_idx, cell, p, n_tested); }
+// The tet of e's deformed mesh that contains position u (un-warped), as the reference's scan of u's LUT cell finds it (0xffffffff: none).  With a fine look-up table
+// (DeviceEdit::fine_off) the candidates are the fine cell's -- the same first hit by construction (nrs_cage.hip: fine_lists_kernel), after fewer tests: on the bench's cage
+// the scan of a wave drops from 7 dependent trips per round to 2-3.  The fine coordinates are the LUT cell's arithmetic with a finer multiplier (cn:117-141), so fine >> shift
+// IS the LUT cell; a position outside the window stands in a LUT cell whose list is empty.
+__device__ __forceinline__ uint32_t find_tet(const DeviceEdit& e, f3 u, const uint32_t* __restrict__ march_lds, uint32_t* n_tested = nullptr) {
+	const int level = mip_from_pos(u);
+	if (e.fine_off) {
+		typedef int32_t i4n __attribute__((ext_vector_type(4)));
+		const NRS_GLOBAL i4n* win = gp(reinterpret_cast<const i4n*>(&e.fine_win[0][0])) + 2 * level;
+		const i4n lo = win[0], ext = win[1];
+		const float mip_scale = ldexpf(1.0f, -level);
+		f3 q = u - mk3(0.5f, 0.5f, 0.5f);
+		q = q * mip_scale;
+		q = q + mk3(0.5f, 0.5f, 0.5f);
+		const float fres = (float)(kGrid << e.fine_shift);
+		const int hi = (int)(kGrid << e.fine_shift) - 1;
+		const int fx = clampi_((int)(q.x * fres), 0, hi) - lo.x, fy = clampi_((int)(q.y * fres), 0, hi) - lo.y, fz = clampi_((int)(q.z * fres), 0, hi) - lo.z;
+		if ((uint32_t)fx >= (uint32_t)ext.x || (uint32_t)fy >= (uint32_t)ext.y || (uint32_t)fz >= (uint32_t)ext.z) return 0xffffffffu;
+		const uint32_t cell = (uint32_t)lo.w + ((uint32_t)fz * (uint32_t)ext.y + (uint32_t)fy) * (uint32_t)ext.x + (uint32_t)fx;
+		return scan_list_for_tet(e, e.fine_off, e.fine_idx, cell, u, n_tested);
+	}
+	const uint32_t cell = march_lds ? occupancy_bit_index(u, (uint32_t)level, march_lds) : (uint32_t)level * kGridVol + cascaded_grid_idx_at(u, (uint32_t)level);
+	return scan_cell_for_tet(e, cell, u, n_tested);
 }
 
 // interpolate_tet (with_dir, honours copy) / interpolate_tet_pos (!with_dir, ignores copy).  pos/dir are the warped
@@ -755,11 +780,8 @@ __device__ __forceinline__ bool tet_warp(const DeviceEdit& e, bool with_dir, f3&
 	if (scan_out) *scan_out = kTetNotSearched;
 	if (box_contains(e.warped_bbox, wpos)) {
 		const f3 u = unwarp_position(wpos, e.aabb);
-		const int level = mip_from_pos(u);
-		const uint32_t cell = march_lds ? occupancy_bit_index(u, (uint32_t)level, march_lds)
-		                                                         : (uint32_t)level * kGridVol + cascaded_grid_idx_at(u, (uint32_t)level);
 		if (n_tested) *n_tested |= 0x10000u; // (profiling: the sample stands inside the deformed mesh's box; low half = candidates tested)
-		const uint32_t found = scan_cell_for_tet(e, cell, u, n_tested);
+		const uint32_t found = find_tet(e, u, march_lds, n_tested);
 		if (n_tested && found != 0xffffffffu) *n_tested |= 0x20000u;
 		if (scan_out) *scan_out = found;
 		__builtin_amdgcn_sched_barrier(0);
@@ -845,10 +867,7 @@ __device__ __forceinline__ bool poisson_residual_find(const DeviceEdit& e, f3 wp
 	if (!box_contains(e.bbox, pos)) return false;
 	uint32_t found = searched;
 	if (searched == kTetNotSearched) {
-		const int level = mip_from_pos(pos);
-		const uint32_t cell = march_lds ? occupancy_bit_index(pos, (uint32_t)level, march_lds)
-		                                                         : (uint32_t)level * kGridVol + cascaded_grid_idx_at(pos, (uint32_t)level);
-		found = scan_cell_for_tet(e, cell, pos);
+		found = find_tet(e, pos, march_lds);
 	}
 	if (found == 0xffffffffu) return false;
 	typedef uint32_t u4n __attribute__((ext_vector_type(4)));
@@ -979,9 +998,7 @@ __device__ __forceinline__ uint32_t generate_grid_sample(Pcg32 rng, uint32_t i, 
 __device__ __forceinline__ bool poisson_residual_density(const DeviceEdit& e, f3 wpos, float& residual) {
 	const f3 pos = unwarp_position(wpos, e.aabb);
 	if (!box_contains(e.bbox, pos)) return false;
-	const int level = mip_from_pos(pos);
-	const uint32_t cell = (uint32_t)level * kGridVol + cascaded_grid_idx_at(pos, (uint32_t)level);
-	const uint32_t t = scan_cell_for_tet(e, cell, pos);
+	const uint32_t t = find_tet(e, pos, nullptr);
 	if (t == 0xffffffffu) return false;
 	const uint4 tv = reinterpret_cast<const uint4*>(e.tets)[t];
 	const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), d = ld3(e.verts, tv.w);

@@ -26,6 +26,9 @@
 #ifndef NRS_PHASE_GATE
 #define NRS_PHASE_GATE 0 // (open A/B: see encode_to_lds)
 #endif
+#ifndef NRS_PHASE_WAITCAP
+#define NRS_PHASE_WAITCAP 8
+#endif
 #ifndef NRS_NT_BRICKS
 #define NRS_NT_BRICKS 0 // (open A/B: see issue_brick_record_loads)
 #endif
@@ -436,9 +439,13 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 	// Results cannot change (the same loads, another order); a wave waits at most one phase.
 	bool gated = false;
 	uint32_t gate_ph = 0;
-	auto gate_wait = [&](uint32_t ph) {
-		uint32_t spins = 0;
-		while ((((uint32_t)(wall_clock64() >> NRS_PHASE_GATE)) & 1u) != ph && spins++ < (96u << (NRS_PHASE_GATE > 10 ? NRS_PHASE_GATE - 10 : 0))) __builtin_amdgcn_s_sleep(8);
+	auto gate_wait = [&](uint32_t ph) { // (NRS_PHASE_WAITCAP: the longest wait in eighths of a phase -- 8 = a whole phase, the hard gate; less = go ahead in the wrong phase)
+		const unsigned long long t_in = wall_clock64(), cap = ((unsigned long long)NRS_PHASE_WAITCAP << NRS_PHASE_GATE) >> 3;
+		for (;;) {
+			const unsigned long long now = wall_clock64();
+			if ((((uint32_t)(now >> NRS_PHASE_GATE)) & 1u) == ph || now - t_in >= cap) break;
+			__builtin_amdgcn_s_sleep(8);
+		}
 	};
 	auto gate_pair = [&](int itp) {
 		uint32_t f0, f1;
