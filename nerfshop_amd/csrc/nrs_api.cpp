@@ -1040,39 +1040,40 @@ static int build_fine_lut(nrs_edit* e, hipStream_t s) {
 	DeviceEdit& de = e->de;
 	de.fine_off = nullptr;
 	de.fine_idx = nullptr;
-	de.fine_shift = 0;
 	memset(de.fine_win, 0, sizeof(de.fine_win));
 	e->fine_n_idx = 0;
 	if (off) return NRS_OK;
-	if (!e->d_fine_win) HIP_TRY(hipMalloc((void**)&e->d_fine_win, 32 * 4));
+	if (!e->d_fine_win) HIP_TRY(hipMalloc((void**)&e->d_fine_win, (kCascades * 8 + 8) * 4));
 	if (!e->d_fine_tiles) HIP_TRY(hipMalloc((void**)&e->d_fine_tiles, kFineScanTiles * 4));
 	CAGE_TRY(launch_fine_window(de.lut_off, e->d_fine_win, s));
-	int32_t win[kCascades * 6];
+	int32_t win[kCascades * 8];
 	HIP_TRY(hipMemcpyAsync(win, e->d_fine_win, sizeof(win), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
-	int shift = 2;
-	uint64_t total = 0;
-	for (; shift >= 0; --shift) {
-		total = 0;
-		for (uint32_t c = 0; c < kCascades; ++c) {
-			const int32_t* w = win + 6 * c;
-			if (w[0] > w[3]) continue;
-			total += ((uint64_t)(w[3] - w[0] + 1) << shift) * ((uint64_t)(w[4] - w[1] + 1) << shift) * ((uint64_t)(w[5] - w[2] + 1) << shift);
-		}
-		if (total <= kFineMaxCells) break;
-	}
-	if (shift < 0 || total == 0) return NRS_OK;
-	de.fine_shift = (uint32_t)shift;
+	// per cascade, finest first: 4 x 4 x 4 fine cells per LUT cell while the budget lasts (then 2 x 2 x 2, then none); a cascade whose longest list is a mesh-in-a-cell
+	// (thousands of tets: the coarse cascades of a small cage) keeps the LUT's own lists -- the scene's samples hardly stand there and the build would walk them 64 times
+	uint64_t budget = kFineMaxCells;
 	uint32_t base = 0;
+	bool any = false;
 	for (uint32_t c = 0; c < kCascades; ++c) {
-		const int32_t* w = win + 6 * c;
+		const int32_t* w = win + 8 * c;
 		int32_t* f = de.fine_win[c];
 		f[3] = (int32_t)base;
-		if (w[0] > w[3]) continue; // (extent 0: nothing of the mesh in this cascade)
-		for (int a = 0; a < 3; ++a) { f[a] = w[a] << shift; f[4 + a] = (w[3 + a] - w[a] + 1) << shift; }
-		base += (uint32_t)f[4] * (uint32_t)f[5] * (uint32_t)f[6];
+		f[7] = kFinePlain;
+		if (w[0] > w[3]) { f[7] = 0; continue; } // no tet reaches this cascade: extent 0, every look-up finds nothing (as the LUT's empty lists say)
+		if (w[7] > kFineMaxList) continue;
+		for (int shift = 2; shift >= 1; --shift) {
+			const uint64_t cells = ((uint64_t)(w[3] - w[0] + 1) << shift) * ((uint64_t)(w[4] - w[1] + 1) << shift) * ((uint64_t)(w[5] - w[2] + 1) << shift);
+			if (cells > budget) continue;
+			for (int a = 0; a < 3; ++a) { f[a] = w[a] << shift; f[4 + a] = (w[3 + a] - w[a] + 1) << shift; }
+			f[7] = shift;
+			budget -= cells;
+			base += (uint32_t)cells;
+			any = true;
+			break;
+		}
 	}
-	const uint32_t n_cells = (uint32_t)total, n_padded = (n_cells + 4095u) / 4096u * 4096u;
+	if (!any) { memset(de.fine_win, 0, sizeof(de.fine_win)); return NRS_OK; }
+	const uint32_t n_cells = base, n_padded = (n_cells + 4095u) / 4096u * 4096u;
 	if (n_padded > e->fine_cells_cap) {
 		(void)hipFree(e->d_fine_off); (void)hipFree(e->d_fine_counts);
 		e->d_fine_off = e->d_fine_counts = nullptr;
@@ -1082,9 +1083,9 @@ static int build_fine_lut(nrs_edit* e, hipStream_t s) {
 		HIP_TRY(hipMalloc((void**)&e->d_fine_counts, cap * 4));
 		e->fine_cells_cap = cap;
 	}
-	CAGE_TRY(launch_fine_count_scan(de, n_cells, e->d_fine_counts, e->d_fine_tiles, e->d_fine_off, (uint32_t*)e->d_fine_win + 30, s));
+	CAGE_TRY(launch_fine_count_scan(de, n_cells, e->d_fine_counts, e->d_fine_tiles, e->d_fine_off, (uint32_t*)e->d_fine_win + kCascades * 8, s));
 	uint32_t n_idx = 0;
-	HIP_TRY(hipMemcpyAsync(&n_idx, e->d_fine_win + 30, 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(&n_idx, e->d_fine_win + kCascades * 8, 4, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	if ((size_t)n_idx > e->fine_idx_cap || !e->d_fine_idx) {
 		(void)hipFree(e->d_fine_idx);

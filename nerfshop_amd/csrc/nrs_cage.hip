@@ -392,14 +392,15 @@ __global__ void tet_planes_kernel(uint32_t n_tets, const float* __restrict__ ver
 // float evaluation (four roundings per term: <= 4.0001 * 2^-24 * sum |n_i| |p_i - v_i|) doubled as slack, and the fine cell's box widened by what the index arithmetic can
 // round (1e-6 / cascade scale): a tet that the float predicate accepts for some position of the fine cell is never dropped, so the first containing tet of the
 // fine list is the first containing tet of the LUT cell's list -- the reference's result, bit for bit (tests/test_gpu_parity.py::test_map_rays_bit_exact and the 1080p frames).
-// window: per cascade the box of LUT cells with a non-empty list (from the LUT itself: whatever built it)
+// window: per cascade the box of LUT cells with a non-empty list (from the LUT itself: whatever built it), the number of such cells and the longest list
+// win[c * 8 + 0..2] min x, y, z; [3..5] max; [6] non-empty cells; [7] longest list
 __global__ __launch_bounds__(256) void fine_window_kernel(const uint32_t* __restrict__ offsets, int32_t* __restrict__ win) {
 	const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) * 16u; // 16 cells in Morton order: a 4 x 2 x 2 block
 	if (first >= kCells) return;
 	const uint32_t o0 = offsets[first], o1 = offsets[first + 16];
 	if (o0 == o1) return;
 	const uint32_t level = first / kGridVol;
-	int32_t lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+	int32_t lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1}, cells = 0, longest = 0;
 	uint32_t prev = o0;
 	for (uint32_t k = 0; k < 16; ++k) {
 		const uint32_t nxt = offsets[first + k + 1];
@@ -407,17 +408,24 @@ __global__ __launch_bounds__(256) void fine_window_kernel(const uint32_t* __rest
 			const uint32_t m = (first + k) % kGridVol;
 			const int32_t c[3] = {(int32_t)morton3D_invert(m), (int32_t)morton3D_invert(m >> 1), (int32_t)morton3D_invert(m >> 2)};
 			for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], c[a]); hi[a] = max(hi[a], c[a]); }
+			++cells;
+			longest = max(longest, (int32_t)(nxt - prev));
 		}
 		prev = nxt;
 	}
-	for (int a = 0; a < 3; ++a) { atomicMin(win + level * 6 + a, lo[a]); atomicMax(win + level * 6 + 3 + a, hi[a]); }
+	for (int a = 0; a < 3; ++a) { atomicMin(win + level * 8 + a, lo[a]); atomicMax(win + level * 8 + 3 + a, hi[a]); }
+	atomicAdd(win + level * 8 + 6, cells);
+	atomicMax(win + level * 8 + 7, longest);
 }
-// can tet `t` contain (by the float predicate of point_in_tet_rec) a position of the box [lo, hi]?  Conservative: false only when some face test fails everywhere.
-__device__ __forceinline__ bool tet_may_contain_box(const float* __restrict__ planes, uint32_t t, const double lo[3], const double hi[3]) {
-	const float* r = planes + 32 * (size_t)t;
+// can the tet of plane record `r` contain (by the float predicate of point_in_tet_rec) a position of the box [lo, hi]?  Conservative: false only when some face test
+// fails everywhere.  (r: wave-uniform -- the record arrives through scalar loads)
+__device__ __forceinline__ bool tet_may_contain_box(const float* __restrict__ r, const double lo[3], const double hi[3]) {
 	const uint32_t signs = __float_as_uint(r[24]);
+	bool may = true;
+	#pragma unroll
 	for (int f = 0; f < 4; ++f) {
 		double mx = 0.0, mn = 0.0, err = 0.0;
+		#pragma unroll
 		for (int i = 0; i < 3; ++i) {
 			const double n = (double)r[12 + 3 * f + i], v = (double)r[3 * f + i];
 			const double a = n * (lo[i] - v), b = n * (hi[i] - v);
@@ -426,48 +434,58 @@ __device__ __forceinline__ bool tet_may_contain_box(const float* __restrict__ pl
 			err += fabs(n) * fmax(fabs(lo[i] - v), fabs(hi[i] - v));
 		}
 		const double slack = err * (8.0 / 16777216.0) + 1e-30; // twice the float evaluation's error bound
-		if ((signs >> f) & 1u) { if (mn > slack) return false; }   // the test wants the sign bit set: impossible when dot > 0 everywhere
-		else { if (mx < -slack) return false; }                    // ... clear: impossible when dot < 0 everywhere
+		// the test wants the sign bit set: impossible when dot > 0 everywhere; ... clear: impossible when dot < 0 everywhere
+		may = may && (((signs >> f) & 1u) ? !(mn > slack) : !(mx < -slack));
 	}
-	return true;
+	return may;
 }
-// One thread per fine cell.  FILL == false: counts[cell] = survivors of its LUT cell's list.  FILL == true: writes them, in list order, at fine_off[cell].
+// One WAVE per LUT cell of a cascade's window, one LANE per fine cell of it (4 x 4 x 4 = 64 with shift 2): every lane walks the LUT cell's list -- ids fetched 64 at a
+// time, the plane record of a candidate is wave-uniform -- and keeps what its fine cell's box cannot exclude.  FILL == false: counts[fine cell] = survivors.
+// FILL == true: writes them, in list order, at fine_off[fine cell].  (Thread-per-fine-cell, the first version, walked the coarse cascades' lists of thousands of
+// tets serially with a dependent load per step: 20 ms per cage move at 48 k tets.)
 template <bool FILL>
-__global__ __launch_bounds__(256) void fine_lists_kernel(const DeviceEdit e, uint32_t n_cells, uint32_t* __restrict__ counts, const uint32_t* __restrict__ fine_off,
+__global__ __launch_bounds__(256) void fine_lists_kernel(const DeviceEdit e, uint32_t level, uint32_t* __restrict__ counts, const uint32_t* __restrict__ fine_off,
                                                          uint32_t* __restrict__ fine_idx) {
-	const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
-	if (cell >= n_cells) return;
-	uint32_t level = 0;
-	#pragma unroll
-	for (uint32_t c = 1; c < kCascades; ++c)
-		if (e.fine_win[c][4] != 0 && cell >= (uint32_t)e.fine_win[c][3]) level = c; // (the windows follow one another in the offset array; empty ones have extent 0)
-	if (e.fine_win[level][4] == 0) { if (!FILL) counts[cell] = 0u; return; }
-	const uint32_t ex = (uint32_t)e.fine_win[level][4], ey = (uint32_t)e.fine_win[level][5];
-	const uint32_t rel = cell - (uint32_t)e.fine_win[level][3];
-	const uint32_t fx = rel % ex + (uint32_t)e.fine_win[level][0], fy = (rel / ex) % ey + (uint32_t)e.fine_win[level][1], fz = rel / (ex * ey) + (uint32_t)e.fine_win[level][2];
-	const uint32_t S = e.fine_shift, res = kGrid << S;
-	const uint32_t parent = level * kGridVol + morton3D(fx >> S, fy >> S, fz >> S);
+	const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t S = (uint32_t)e.fine_win[level][7], sub = 1u << S; // fine cells per LUT cell and axis
+	const uint32_t ex = (uint32_t)e.fine_win[level][4], ey = (uint32_t)e.fine_win[level][5], ez = (uint32_t)e.fine_win[level][6];
+	const uint32_t px = ex >> S, py = ey >> S, pz = ez >> S; // the window in LUT cells
+	if (w >= px * py * pz) return;
+	const uint32_t cx = w % px, cy = (w / px) % py, cz = w / (px * py);
+	const uint32_t lx = ((uint32_t)e.fine_win[level][0] >> S) + cx, ly = ((uint32_t)e.fine_win[level][1] >> S) + cy, lz = ((uint32_t)e.fine_win[level][2] >> S) + cz;
+	const uint32_t parent = level * kGridVol + morton3D(lx, ly, lz);
 	const uint32_t j0 = e.lut_off[parent], j1 = e.lut_off[parent + 1];
-	uint32_t n = 0;
-	if (j0 < j1) {
-		// the positions u whose fine coordinate is (fx, fy, fz): q = ((u - 0.5) * 2^-level + 0.5), floor(q * res) = f  =>  u in 0.5 + ((f .. f + 1) / res - 0.5) * 2^level,
-		// widened by what the three float operations can round; the outermost fine cells take everything beyond (the index clamps)
-		const double scale = (double)(1u << level), margin = 1e-6 * scale;
-		const uint32_t f[3] = {fx, fy, fz};
-		double lo[3], hi[3];
-		for (int i = 0; i < 3; ++i) {
-			lo[i] = f[i] == 0 ? -1e30 : 0.5 + ((double)f[i] / (double)res - 0.5) * scale - margin;
-			hi[i] = f[i] == res - 1 ? 1e30 : 0.5 + ((double)(f[i] + 1) / (double)res - 0.5) * scale + margin;
-		}
-		uint32_t w = FILL ? fine_off[cell] : 0u;
-		for (uint32_t j = j0; j < j1; ++j) {
-			const uint32_t t = e.lut_idx[j];
-			if (!tet_may_contain_box(e.planes, t, lo, hi)) continue;
-			if (FILL) fine_idx[w++] = t;
-			++n;
+	const bool owner = lane < sub * sub * sub;
+	const uint32_t sx = lane & (sub - 1u), sy = (lane >> S) & (sub - 1u), sz = lane >> (2u * S);
+	const uint32_t rx = (cx << S) + sx, ry = (cy << S) + sy, rz = (cz << S) + sz; // fine cell inside the window
+	const uint32_t cell = (uint32_t)e.fine_win[level][3] + (rz * ey + ry) * ex + rx;
+	if (j0 == j1) { if (!FILL && owner) counts[cell] = 0u; return; }
+	// the positions u whose fine coordinate is f: q = ((u - 0.5) * 2^-level + 0.5), floor(q * res) = f  =>  u in 0.5 + ((f .. f + 1) / res - 0.5) * 2^level, widened by
+	// what the three float operations can round; the outermost fine cells take everything beyond (the index clamps)
+	const uint32_t res = kGrid << S;
+	const double scale = (double)(1u << level), margin = 1e-6 * scale;
+	const uint32_t f[3] = {(uint32_t)e.fine_win[level][0] + rx, (uint32_t)e.fine_win[level][1] + ry, (uint32_t)e.fine_win[level][2] + rz};
+	double lo[3], hi[3];
+	#pragma unroll
+	for (int i = 0; i < 3; ++i) {
+		lo[i] = f[i] == 0 ? -1e30 : 0.5 + ((double)f[i] / (double)res - 0.5) * scale - margin;
+		hi[i] = f[i] >= res - 1 ? 1e30 : 0.5 + ((double)(f[i] + 1) / (double)res - 0.5) * scale + margin;
+	}
+	uint32_t n = 0, wpos = (FILL && owner) ? fine_off[cell] : 0u;
+	for (uint32_t b = j0; b < j1; b += 64u) {
+		const uint32_t mine = b + lane < j1 ? e.lut_idx[b + lane] : 0u; // 64 candidates, one per lane
+		const uint32_t nb = min(64u, j1 - b);
+		for (uint32_t k = 0; k < nb; ++k) {
+			const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)k); // wave-uniform: the record below is read with scalar loads
+			const float* r = e.planes + 32 * (size_t)t;
+			if (tet_may_contain_box(r, lo, hi) && owner) {
+				if (FILL) fine_idx[wpos++] = t;
+				++n;
+			}
 		}
 	}
-	if (!FILL) counts[cell] = n;
+	if (!FILL && owner) counts[cell] = n;
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------------
@@ -527,19 +545,29 @@ int launch_local_rotations(uint32_t n_tets, const float* d_verts, const float* d
 
 int launch_fine_window(const uint32_t* d_lut_off, int32_t* d_window_out, void* stream) {
 	hipStream_t s = (hipStream_t)stream;
-	static const int32_t init[kCascades * 6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1, 0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1, 0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1,
-	                                            0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1, 0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1};
+	static int32_t init[kCascades * 8];
+	for (uint32_t c = 0; c < kCascades; ++c) { int32_t* w = init + 8 * c; w[0] = w[1] = w[2] = 0x7fffffff; w[3] = w[4] = w[5] = -1; w[6] = w[7] = 0; }
 	if (hipMemcpyAsync(d_window_out, init, sizeof(init), hipMemcpyHostToDevice, s) != hipSuccess) { snprintf(g_cage_err, sizeof(g_cage_err), "fine look-up table: window init failed"); return NRS_ERR_HIP; }
 	hipLaunchKernelGGL(fine_window_kernel, dim3(kCells / 16 / 256), dim3(256), 0, s, d_lut_off, d_window_out);
 	NRS_CAGE_CHECK("fine_window_kernel launch");
 	return NRS_OK;
+}
+// one launch per cascade that has a fine table (DeviceEdit::fine_win[c][7] <= 2), one wave per LUT cell of its window
+template <bool FILL>
+static void launch_fine_lists(const DeviceEdit& de, uint32_t* d_counts, const uint32_t* d_fine_off, uint32_t* d_fine_idx, hipStream_t s) {
+	for (uint32_t c = 0; c < kCascades; ++c) {
+		const int32_t* f = de.fine_win[c];
+		if (f[4] == 0 || (uint32_t)f[7] > 2u) continue;
+		const uint32_t S = (uint32_t)f[7], n_parents = ((uint32_t)f[4] >> S) * ((uint32_t)f[5] >> S) * ((uint32_t)f[6] >> S);
+		hipLaunchKernelGGL(fine_lists_kernel<FILL>, dim3((n_parents + 3) / 4), dim3(256), 0, s, de, c, d_counts, d_fine_off, d_fine_idx);
+	}
 }
 int launch_fine_count_scan(const DeviceEdit& de, uint32_t n_fine_cells, uint32_t* d_counts, uint32_t* d_tile_sums, uint32_t* d_fine_off, uint32_t* d_total, void* stream) {
 	hipStream_t s = (hipStream_t)stream;
 	const uint32_t n_tiles = (n_fine_cells + kScanTile - 1) / kScanTile, n_padded = n_tiles * kScanTile;
 	if (n_tiles == 0 || n_tiles > kMaxScanTiles) { snprintf(g_cage_err, sizeof(g_cage_err), "fine look-up table: %u fine cells", n_fine_cells); return NRS_ERR_INVALID_ARG; }
 	if (n_padded != n_fine_cells && hipMemsetAsync(d_counts + n_fine_cells, 0, (size_t)(n_padded - n_fine_cells) * 4, s) != hipSuccess) { snprintf(g_cage_err, sizeof(g_cage_err), "fine look-up table: memset failed"); return NRS_ERR_HIP; }
-	hipLaunchKernelGGL(fine_lists_kernel<false>, dim3((n_fine_cells + 255) / 256), dim3(256), 0, s, de, n_fine_cells, d_counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+	launch_fine_lists<false>(de, d_counts, nullptr, nullptr, s);
 	hipLaunchKernelGGL(scan_tile_sum_kernel, dim3(n_tiles), dim3(256), 0, s, d_counts, d_tile_sums);
 	hipLaunchKernelGGL(scan_tile_prefix_kernel, dim3(1), dim3(1024), 0, s, d_tile_sums, d_fine_off + n_padded, d_total, n_tiles);
 	hipLaunchKernelGGL(scan_write_kernel, dim3(n_tiles), dim3(256), 0, s, d_counts, d_tile_sums, d_fine_off);
@@ -547,7 +575,8 @@ int launch_fine_count_scan(const DeviceEdit& de, uint32_t n_fine_cells, uint32_t
 	return NRS_OK;
 }
 int launch_fine_fill(const DeviceEdit& de, uint32_t n_fine_cells, const uint32_t* d_fine_off, uint32_t* d_fine_idx, void* stream) {
-	hipLaunchKernelGGL(fine_lists_kernel<true>, dim3((n_fine_cells + 255) / 256), dim3(256), 0, (hipStream_t)stream, de, n_fine_cells, (uint32_t*)nullptr, d_fine_off, d_fine_idx);
+	(void)n_fine_cells;
+	launch_fine_lists<true>(de, nullptr, d_fine_off, d_fine_idx, (hipStream_t)stream);
 	NRS_CAGE_CHECK("fine_lists_kernel launch");
 	return NRS_OK;
 }

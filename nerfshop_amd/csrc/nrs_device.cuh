@@ -754,12 +754,15 @@ __device__ __forceinline__ uint32_t find_tet(const DeviceEdit& e, f3 u, const ui
 		f3 q = u - mk3(0.5f, 0.5f, 0.5f);
 		q = q * mip_scale;
 		q = q + mk3(0.5f, 0.5f, 0.5f);
-		const float fres = (float)(kGrid << e.fine_shift);
-		const int hi = (int)(kGrid << e.fine_shift) - 1;
-		const int fx = clampi_((int)(q.x * fres), 0, hi) - lo.x, fy = clampi_((int)(q.y * fres), 0, hi) - lo.y, fz = clampi_((int)(q.z * fres), 0, hi) - lo.z;
-		if ((uint32_t)fx >= (uint32_t)ext.x || (uint32_t)fy >= (uint32_t)ext.y || (uint32_t)fz >= (uint32_t)ext.z) return 0xffffffffu;
-		const uint32_t cell = (uint32_t)lo.w + ((uint32_t)fz * (uint32_t)ext.y + (uint32_t)fy) * (uint32_t)ext.x + (uint32_t)fx;
-		return scan_list_for_tet(e, e.fine_off, e.fine_idx, cell, u, n_tested);
+		if (ext.w != kFinePlain) { // (else: this cascade keeps the LUT's own lists -- below)
+			const int fres_i = (int)(kGrid << ext.w);
+			const float fres = (float)fres_i;
+			const int hi = fres_i - 1;
+			const int fx = clampi_((int)(q.x * fres), 0, hi) - lo.x, fy = clampi_((int)(q.y * fres), 0, hi) - lo.y, fz = clampi_((int)(q.z * fres), 0, hi) - lo.z;
+			if ((uint32_t)fx >= (uint32_t)ext.x || (uint32_t)fy >= (uint32_t)ext.y || (uint32_t)fz >= (uint32_t)ext.z) return 0xffffffffu;
+			const uint32_t cell = (uint32_t)lo.w + ((uint32_t)fz * (uint32_t)ext.y + (uint32_t)fy) * (uint32_t)ext.x + (uint32_t)fx;
+			return scan_list_for_tet(e, e.fine_off, e.fine_idx, cell, u, n_tested);
+		}
 	}
 	const uint32_t cell = march_lds ? occupancy_bit_index(u, (uint32_t)level, march_lds) : (uint32_t)level * kGridVol + cascaded_grid_idx_at(u, (uint32_t)level);
 	return scan_cell_for_tet(e, cell, u, n_tested);

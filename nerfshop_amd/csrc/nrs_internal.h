@@ -120,14 +120,13 @@ struct DeviceEdit {
 	const float*    verts;
 	const float*    orig;
 	const float*    rot;           // nullable
-	// Fine look-up table under the reference's 128^3 one (round 6; nrs_cage.hip fine_*_kernel; nullable): every LUT cell of the window is cut into (1 << fine_shift)^3 fine
+	// Fine look-up table under the reference's 128^3 one (round 6; nrs_cage.hip fine_*_kernel; nullable): every LUT cell of a cascade's window is cut into 4 x 4 x 4 (or 2 x 2 x 2) fine
 	// cells, and a fine cell's list is its LUT cell's list FILTERED IN ORDER -- the tets whose four face tests can pass for some position of the fine cell (a conservative
 	// box-against-half-spaces test on the very floats the scan compares) -- so the first containing tet is the one the reference's scan finds, after fewer candidates.
 	const uint32_t* fine_off;      // CSR offsets over the windows' fine cells, cascade after cascade
 	const uint32_t* fine_idx;
-	uint32_t        fine_shift;
-	uint32_t        fine_pad[3];
-	int32_t         fine_win[kCascades][8]; // per cascade: first fine cell x, y, z, first offset index | extent x, y, z (0: no tet reaches this cascade), 0
+	int32_t         fine_win[kCascades][8]; // per cascade: first fine cell x, y, z, first offset index | extent x, y, z in fine cells (0: no tet reaches this cascade),
+	                                        // log2 of the fine cells per LUT cell and axis (0..2) or kFinePlain: this cascade keeps the LUT's own lists
 	const float*    planes;        // [T x 32] one 128-byte record per tet: its 4 vertices, the 4 face normals exactly as same_side_tet forms them, the 4 sign bits of dotV4 (tet_planes_kernel)
 	const uint8_t*  orig_bitfield;
 	const float*    shs;           // nullable unless apply_poisson
@@ -237,6 +236,8 @@ const char* launch_last_error();
 constexpr uint32_t kLutScanTiles = kGridVol * kCascades / 4096;
 constexpr uint32_t kFineMaxCells = 16u << 20; // fine look-up table: at most 16 M fine cells (64 MB of offsets) per edit; the subdivision is chosen to fit
 constexpr uint32_t kFineScanTiles = kFineMaxCells / 4096;
+constexpr int32_t kFinePlain = 0xff;          // DeviceEdit::fine_win[c][7]: no fine table for cascade c
+constexpr int32_t kFineMaxList = 512;         // cascades whose longest LUT list exceeds this keep the plain scan (a mesh of thousands of tets inside one coarse cell)
 int launch_mvc_apply(uint32_t n_points, uint32_t n_cv, const float* d_weights, const float* d_cage, float* d_points, void* stream);
 int launch_bbox(uint32_t n, const float* d_verts, float* d_out6, void* stream);
 int launch_poisson_interpolate(uint32_t n_points, uint32_t n_cv, const float* d_gamma, const float* d_per_cage, float* d_shs, float* d_out_density, float* d_res_density, void* stream);
@@ -246,7 +247,7 @@ int launch_lut_fill(uint32_t n_tets, const float* d_verts, const uint32_t* d_tet
                     uint8_t* d_bitfield, uint32_t* d_scratch_u32, uint32_t* d_big_cells, void* stream);
 uint32_t lut_big_list_capacity(size_t idx_capacity);
 int launch_tet_planes(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, float* d_planes, void* stream);
-// fine look-up table (DeviceEdit::fine_*): d_window_out[kCascades][6] = min x, y, z / max x, y, z of the LUT cells with a non-empty list (min > max: none)
+// fine look-up table (DeviceEdit::fine_*): d_window_out[kCascades][8] = min x, y, z / max x, y, z of the LUT cells with a non-empty list (min > max: none), their number, the longest list
 int launch_fine_window(const uint32_t* d_lut_off, int32_t* d_window_out, void* stream);
 // counts (FILL = false: d_counts[n_padded], then the exclusive scan into d_fine_off[n_padded + 1] and *d_total) or fills (FILL = true: d_fine_idx) the fine lists of `de`'s windows
 int launch_fine_count_scan(const DeviceEdit& de, uint32_t n_fine_cells, uint32_t* d_counts, uint32_t* d_tile_sums, uint32_t* d_fine_off, uint32_t* d_total, void* stream);
