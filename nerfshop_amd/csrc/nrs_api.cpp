@@ -130,6 +130,10 @@ struct nrs_edit {
 	int32_t* d_fine_win = nullptr;     // [kCascades * 6] window + [30] total entries
 	size_t fine_cells_cap = 0, fine_idx_cap = 0;
 	uint32_t fine_n_idx = 0;
+	// A cage MOVE does not rebuild the fine table (0.3 ms of a 1.0 ms move at 6 k tets): it drops it -- the kernels scan the LUT's own lists, as before round 6 -- and
+	// the second nrs_render_nerf after the last move builds it (a gizmo drag renders one frame per move and never pays; a cage at rest renders 2-3 % faster)
+	bool fine_stale = false;
+	uint32_t renders_since_move = 0;
 };
 
 // Marching parameters every ray-marching entry point hands to the kernels: min_mip indexes the 5-cascade bitfield (min_mip > 4 reads past
@@ -1099,16 +1103,26 @@ static int build_fine_lut(nrs_edit* e, hipStream_t s) {
 	e->fine_n_idx = n_idx;
 	de.fine_off = e->d_fine_off;
 	de.fine_idx = e->d_fine_idx;
+	static const bool log_fine = dev_knob("NRS_FINE_LOG") != nullptr;
+	if (log_fine) fprintf(stderr, "[nrs fine lut] %u fine cells, %u entries (the LUT holds %u), subdivision per cascade %d %d %d %d %d\n", n_cells, n_idx, e->lut_n_idx, de.fine_win[0][7],
+	                      de.fine_win[1][7], de.fine_win[2][7], de.fine_win[3][7], de.fine_win[4][7]);
 	return NRS_OK;
 }
 // everything that follows new deformed vertices in e->d_verts: bbox, LUT, rotations.  Synchronous.
-static int rebuild_after_vertices(nrs_edit* e, hipStream_t s) {
+static int rebuild_after_vertices(nrs_edit* e, hipStream_t s, bool build_fine_now = false) {
 	NRS_TRY(ensure_build_scratch(e));
 	CAGE_TRY(launch_bbox(e->n_vertices, e->d_verts, (float*)e->d_scratch, s));
 	NRS_TRY(build_lut_on_device(e, e->d_verts, nullptr, s));
 	if (e->d_rot) CAGE_TRY(launch_local_rotations(e->n_tets, e->d_verts, e->de.orig, e->de.tets, e->d_rot, s));
 	CAGE_TRY(launch_tet_planes(e->n_tets, e->d_verts, e->de.tets, e->d_planes, s));
-	NRS_TRY(build_fine_lut(e, s));
+	if (build_fine_now) NRS_TRY(build_fine_lut(e, s));
+	else { // (see nrs_edit::fine_stale)
+		e->de.fine_off = nullptr;
+		e->de.fine_idx = nullptr;
+		memset(e->de.fine_win, 0, sizeof(e->de.fine_win));
+		e->fine_stale = true;
+		e->renders_since_move = 0;
+	}
 	uint32_t host[8];
 	HIP_TRY(hipMemcpyAsync(host, e->d_scratch, sizeof(host), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
@@ -1222,7 +1236,7 @@ int nrs_edit_create(nrs_ctx* ctx, const nrs_model_desc* desc, const nrs_tet_mesh
 			if (hipDeviceSynchronize() != hipSuccess) return bail(fail(NRS_ERR_HIP, "nrs_edit_create: rotation kernel failed"));
 		}
 	} else {
-		int st = rebuild_after_vertices(e, nullptr); // LUT (+ rotations) of the deformed mesh, on the device
+		int st = rebuild_after_vertices(e, nullptr, true); // LUT (+ rotations) of the deformed mesh, on the device; an operator at rest: with its fine table
 		if (st != NRS_OK) return bail(st);
 		if (mesh->h_local_rotations && hipMemcpy(e->d_rot, mesh->h_local_rotations, 36 * (size_t)mesh->n_tets, hipMemcpyHostToDevice) != hipSuccess)
 			return bail(fail(NRS_ERR_HIP, "nrs_edit_create: rotation upload failed"));
@@ -1501,6 +1515,10 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		DeviceEdit host_edits[nrs_ctx::kMaxEdits];
 		for (int i = 0; i < n_edits; ++i) {
 			if (!edits[i]) return fail(NRS_ERR_INVALID_ARG, "nrs_render_nerf: NULL edit operator");
+			if (edits[i]->fine_stale && ++edits[i]->renders_since_move >= 2u) { // the cage has come to rest: its fine look-up table (nrs_edit::fine_stale)
+				edits[i]->fine_stale = false;
+				NRS_TRY(build_fine_lut(edits[i], s));
+			}
 			host_edits[i] = edits[i]->de;
 			a.any_poisson |= edits[i]->de.apply_poisson;
 			a.any_affine |= (edits[i]->de.kind == kEditAffine) ? 1u : 0u;

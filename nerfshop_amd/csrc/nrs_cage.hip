@@ -395,47 +395,61 @@ __global__ void tet_planes_kernel(uint32_t n_tets, const float* __restrict__ ver
 // window: per cascade the box of LUT cells with a non-empty list (from the LUT itself: whatever built it), the number of such cells and the longest list
 // win[c * 8 + 0..2] min x, y, z; [3..5] max; [6] non-empty cells; [7] longest list
 __global__ __launch_bounds__(256) void fine_window_kernel(const uint32_t* __restrict__ offsets, int32_t* __restrict__ win) {
+	// (a block covers 4096 consecutive cells of ONE cascade; its threads reduce in LDS and the block issues at most 8 device atomics: thousands of threads hitting
+	// the same eight words took 0.28 ms of a cage move)
+	__shared__ int32_t red[8];
+	if (threadIdx.x < 8) red[threadIdx.x] = threadIdx.x < 3 ? 0x7fffffff : (threadIdx.x < 6 ? -1 : 0);
+	__syncthreads();
 	const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) * 16u; // 16 cells in Morton order: a 4 x 2 x 2 block
-	if (first >= kCells) return;
-	const uint32_t o0 = offsets[first], o1 = offsets[first + 16];
-	if (o0 == o1) return;
-	const uint32_t level = first / kGridVol;
-	int32_t lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1}, cells = 0, longest = 0;
-	uint32_t prev = o0;
-	for (uint32_t k = 0; k < 16; ++k) {
-		const uint32_t nxt = offsets[first + k + 1];
-		if (nxt != prev) {
-			const uint32_t m = (first + k) % kGridVol;
-			const int32_t c[3] = {(int32_t)morton3D_invert(m), (int32_t)morton3D_invert(m >> 1), (int32_t)morton3D_invert(m >> 2)};
-			for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], c[a]); hi[a] = max(hi[a], c[a]); }
-			++cells;
-			longest = max(longest, (int32_t)(nxt - prev));
+	uint32_t o[17];
+	#pragma unroll
+	for (int q = 0; q < 4; ++q) { const uint4 v = reinterpret_cast<const uint4*>(offsets + first)[q]; o[4 * q] = v.x; o[4 * q + 1] = v.y; o[4 * q + 2] = v.z; o[4 * q + 3] = v.w; }
+	o[16] = offsets[first + 16];
+	if (o[0] != o[16]) {
+		int32_t lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1}, cells = 0, longest = 0;
+		#pragma unroll
+		for (uint32_t k = 0; k < 16; ++k) {
+			if (o[k + 1] != o[k]) {
+				const uint32_t m = (first + k) % kGridVol;
+				const int32_t c[3] = {(int32_t)morton3D_invert(m), (int32_t)morton3D_invert(m >> 1), (int32_t)morton3D_invert(m >> 2)};
+				for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], c[a]); hi[a] = max(hi[a], c[a]); }
+				++cells;
+				longest = max(longest, (int32_t)(o[k + 1] - o[k]));
+			}
 		}
-		prev = nxt;
+		for (int a = 0; a < 3; ++a) { atomicMin(&red[a], lo[a]); atomicMax(&red[3 + a], hi[a]); }
+		atomicAdd(&red[6], cells);
+		atomicMax(&red[7], longest);
 	}
-	for (int a = 0; a < 3; ++a) { atomicMin(win + level * 8 + a, lo[a]); atomicMax(win + level * 8 + 3 + a, hi[a]); }
-	atomicAdd(win + level * 8 + 6, cells);
-	atomicMax(win + level * 8 + 7, longest);
+	__syncthreads();
+	if (threadIdx.x < 8 && red[6] != 0) {
+		int32_t* dst = win + (blockIdx.x * blockDim.x * 16u / kGridVol) * 8 + threadIdx.x;
+		if (threadIdx.x < 3) atomicMin(dst, red[threadIdx.x]);
+		else if (threadIdx.x < 6 || threadIdx.x == 7) atomicMax(dst, red[threadIdx.x]);
+		else atomicAdd(dst, red[6]);
+	}
 }
-// can the tet of plane record `r` contain (by the float predicate of point_in_tet_rec) a position of the box [lo, hi]?  Conservative: false only when some face test
-// fails everywhere.  (r: wave-uniform -- the record arrives through scalar loads)
-__device__ __forceinline__ bool tet_may_contain_box(const float* __restrict__ r, const double lo[3], const double hi[3]) {
+// can the tet of plane record `r` contain (by the float predicate of point_in_tet_rec) a position of the box centre c, half extents h?  Conservative: false only when
+// some face test fails everywhere.  dot(n, p - v) over the box is dot(n, c - v) +- sum |n_i| h_i; the predicate's own float evaluation is off by at most
+// 4.0001 * 2^-24 * sum |n_i| |p_i - v_i| <= that bound with |c_i - v_i| + h_i, this function's float arithmetic by as much again: the slack is 20 * 2^-24 of it.
+// (First version: double precision, min / max per axis -- 160 us per launch, the vector unit's double rate; this form is a third of the operations at four times the rate.)
+// (r: wave-uniform -- the record arrives through scalar loads)
+__device__ __forceinline__ bool tet_may_contain_box(const float* __restrict__ r, const float c[3], const float h[3]) {
 	const uint32_t signs = __float_as_uint(r[24]);
 	bool may = true;
 	#pragma unroll
 	for (int f = 0; f < 4; ++f) {
-		double mx = 0.0, mn = 0.0, err = 0.0;
+		float dc = 0.f, rad = 0.f, err = 0.f;
 		#pragma unroll
 		for (int i = 0; i < 3; ++i) {
-			const double n = (double)r[12 + 3 * f + i], v = (double)r[3 * f + i];
-			const double a = n * (lo[i] - v), b = n * (hi[i] - v);
-			mx += fmax(a, b);
-			mn += fmin(a, b);
-			err += fabs(n) * fmax(fabs(lo[i] - v), fabs(hi[i] - v));
+			const float n = r[12 + 3 * f + i], d = c[i] - r[3 * f + i];
+			dc = fmaf(n, d, dc);
+			rad = fmaf(fabsf(n), h[i], rad);
+			err = fmaf(fabsf(n), fabsf(d) + h[i], err);
 		}
-		const double slack = err * (8.0 / 16777216.0) + 1e-30; // twice the float evaluation's error bound
-		// the test wants the sign bit set: impossible when dot > 0 everywhere; ... clear: impossible when dot < 0 everywhere
-		may = may && (((signs >> f) & 1u) ? !(mn > slack) : !(mx < -slack));
+		const float slack = fmaf(err, 20.0f / 16777216.0f, 1e-30f);
+		// the test wants the sign bit set: impossible when dot > 0 everywhere (dc - rad > slack); ... clear: impossible when dot < 0 everywhere
+		may = may && (((signs >> f) & 1u) ? !(dc - rad > slack) : !(dc + rad < -slack));
 	}
 	return may;
 }
@@ -444,14 +458,21 @@ __device__ __forceinline__ bool tet_may_contain_box(const float* __restrict__ r,
 // FILL == true: writes them, in list order, at fine_off[fine cell].  (Thread-per-fine-cell, the first version, walked the coarse cascades' lists of thousands of
 // tets serially with a dependent load per step: 20 ms per cage move at 48 k tets.)
 template <bool FILL>
-__global__ __launch_bounds__(256) void fine_lists_kernel(const DeviceEdit e, uint32_t level, uint32_t* __restrict__ counts, const uint32_t* __restrict__ fine_off,
+__global__ __launch_bounds__(256) void fine_lists_kernel(const DeviceEdit e, uint32_t* __restrict__ counts, const uint32_t* __restrict__ fine_off,
                                                          uint32_t* __restrict__ fine_idx) {
-	const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); // one launch for every cascade: the few long lists of the coarse ones run beside the many short ones
 	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t level = kCascades;
+	#pragma unroll
+	for (uint32_t c = 0; c < kCascades; ++c) {
+		const int32_t* f = e.fine_win[c];
+		const uint32_t n_par = (f[4] == 0 || (uint32_t)f[7] > 2u) ? 0u : ((uint32_t)f[4] >> f[7]) * ((uint32_t)f[5] >> f[7]) * ((uint32_t)f[6] >> f[7]);
+		if (level == kCascades) { if (w < n_par) level = c; else w -= n_par; }
+	}
+	if (level == kCascades) return;
 	const uint32_t S = (uint32_t)e.fine_win[level][7], sub = 1u << S; // fine cells per LUT cell and axis
-	const uint32_t ex = (uint32_t)e.fine_win[level][4], ey = (uint32_t)e.fine_win[level][5], ez = (uint32_t)e.fine_win[level][6];
-	const uint32_t px = ex >> S, py = ey >> S, pz = ez >> S; // the window in LUT cells
-	if (w >= px * py * pz) return;
+	const uint32_t ex = (uint32_t)e.fine_win[level][4], ey = (uint32_t)e.fine_win[level][5];
+	const uint32_t px = ex >> S, py = ey >> S; // the window in LUT cells
 	const uint32_t cx = w % px, cy = (w / px) % py, cz = w / (px * py);
 	const uint32_t lx = ((uint32_t)e.fine_win[level][0] >> S) + cx, ly = ((uint32_t)e.fine_win[level][1] >> S) + cy, lz = ((uint32_t)e.fine_win[level][2] >> S) + cz;
 	const uint32_t parent = level * kGridVol + morton3D(lx, ly, lz);
@@ -464,25 +485,43 @@ __global__ __launch_bounds__(256) void fine_lists_kernel(const DeviceEdit e, uin
 	// the positions u whose fine coordinate is f: q = ((u - 0.5) * 2^-level + 0.5), floor(q * res) = f  =>  u in 0.5 + ((f .. f + 1) / res - 0.5) * 2^level, widened by
 	// what the three float operations can round; the outermost fine cells take everything beyond (the index clamps)
 	const uint32_t res = kGrid << S;
-	const double scale = (double)(1u << level), margin = 1e-6 * scale;
+	const double scale = (double)(1u << level), margin = 2e-6 * scale; // (1e-6: the index arithmetic; the rest: c and h below are rounded to float)
 	const uint32_t f[3] = {(uint32_t)e.fine_win[level][0] + rx, (uint32_t)e.fine_win[level][1] + ry, (uint32_t)e.fine_win[level][2] + rz};
-	double lo[3], hi[3];
+	float c[3], h[3];
+	bool border = false; // an outermost fine cell of the grid takes every position beyond it: no box, nothing is filtered
 	#pragma unroll
 	for (int i = 0; i < 3; ++i) {
-		lo[i] = f[i] == 0 ? -1e30 : 0.5 + ((double)f[i] / (double)res - 0.5) * scale - margin;
-		hi[i] = f[i] >= res - 1 ? 1e30 : 0.5 + ((double)(f[i] + 1) / (double)res - 0.5) * scale + margin;
+		const double lo = 0.5 + ((double)f[i] / (double)res - 0.5) * scale - margin, hi = 0.5 + ((double)(f[i] + 1) / (double)res - 0.5) * scale + margin;
+		c[i] = (float)(0.5 * (lo + hi));
+		h[i] = (float)(0.5 * (hi - lo));
+		border = border || f[i] == 0 || f[i] >= res - 1;
 	}
 	uint32_t n = 0, wpos = (FILL && owner) ? fine_off[cell] : 0u;
 	for (uint32_t b = j0; b < j1; b += 64u) {
 		const uint32_t mine = b + lane < j1 ? e.lut_idx[b + lane] : 0u; // 64 candidates, one per lane
 		const uint32_t nb = min(64u, j1 - b);
+		// (the record of candidate k + 1 is requested before candidate k is tested: a list is a chain of dependent loads otherwise, 1.5 us per tet)
+		float4 cur[7], nxt[7];
+		{
+			const float4* q = reinterpret_cast<const float4*>(e.planes) + 8 * (size_t)(uint32_t)__builtin_amdgcn_readlane((int)mine, 0);
+			#pragma unroll
+			for (int i = 0; i < 7; ++i) cur[i] = q[i];
+		}
 		for (uint32_t k = 0; k < nb; ++k) {
-			const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)k); // wave-uniform: the record below is read with scalar loads
-			const float* r = e.planes + 32 * (size_t)t;
-			if (tet_may_contain_box(r, lo, hi) && owner) {
+			const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)k); // wave-uniform
+			const uint32_t t_next = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)min(k + 1u, nb - 1u));
+			{
+				const float4* q = reinterpret_cast<const float4*>(e.planes) + 8 * (size_t)t_next;
+				#pragma unroll
+				for (int i = 0; i < 7; ++i) nxt[i] = q[i];
+			}
+			const float* r = reinterpret_cast<const float*>(cur);
+			if ((border || tet_may_contain_box(r, c, h)) && owner) {
 				if (FILL) fine_idx[wpos++] = t;
 				++n;
 			}
+			#pragma unroll
+			for (int i = 0; i < 7; ++i) cur[i] = nxt[i];
 		}
 	}
 	if (!FILL && owner) counts[cell] = n;
@@ -552,15 +591,15 @@ int launch_fine_window(const uint32_t* d_lut_off, int32_t* d_window_out, void* s
 	NRS_CAGE_CHECK("fine_window_kernel launch");
 	return NRS_OK;
 }
-// one launch per cascade that has a fine table (DeviceEdit::fine_win[c][7] <= 2), one wave per LUT cell of its window
 template <bool FILL>
 static void launch_fine_lists(const DeviceEdit& de, uint32_t* d_counts, const uint32_t* d_fine_off, uint32_t* d_fine_idx, hipStream_t s) {
+	uint32_t n_parents = 0;
 	for (uint32_t c = 0; c < kCascades; ++c) {
 		const int32_t* f = de.fine_win[c];
 		if (f[4] == 0 || (uint32_t)f[7] > 2u) continue;
-		const uint32_t S = (uint32_t)f[7], n_parents = ((uint32_t)f[4] >> S) * ((uint32_t)f[5] >> S) * ((uint32_t)f[6] >> S);
-		hipLaunchKernelGGL(fine_lists_kernel<FILL>, dim3((n_parents + 3) / 4), dim3(256), 0, s, de, c, d_counts, d_fine_off, d_fine_idx);
+		n_parents += ((uint32_t)f[4] >> f[7]) * ((uint32_t)f[5] >> f[7]) * ((uint32_t)f[6] >> f[7]);
 	}
+	if (n_parents) hipLaunchKernelGGL(fine_lists_kernel<FILL>, dim3((n_parents + 3) / 4), dim3(256), 0, s, de, d_counts, d_fine_off, d_fine_idx);
 }
 int launch_fine_count_scan(const DeviceEdit& de, uint32_t n_fine_cells, uint32_t* d_counts, uint32_t* d_tile_sums, uint32_t* d_fine_off, uint32_t* d_total, void* stream) {
 	hipStream_t s = (hipStream_t)stream;

@@ -237,7 +237,8 @@ constexpr uint32_t kLutScanTiles = kGridVol * kCascades / 4096;
 constexpr uint32_t kFineMaxCells = 16u << 20; // fine look-up table: at most 16 M fine cells (64 MB of offsets) per edit; the subdivision is chosen to fit
 constexpr uint32_t kFineScanTiles = kFineMaxCells / 4096;
 constexpr int32_t kFinePlain = 0xff;          // DeviceEdit::fine_win[c][7]: no fine table for cascade c
-constexpr int32_t kFineMaxList = 512;         // cascades whose longest LUT list exceeds this keep the plain scan (a mesh of thousands of tets inside one coarse cell)
+constexpr int32_t kFineMaxList = 96;          // cascades whose longest LUT list exceeds this keep the plain scan (the coarse cascades of a small cage: hundreds of tets inside one cell,
+                                              // hardly a sample; one wave of the build would walk such a list 64 fine cells wide -- 95 us at 285 tets)
 int launch_mvc_apply(uint32_t n_points, uint32_t n_cv, const float* d_weights, const float* d_cage, float* d_points, void* stream);
 int launch_bbox(uint32_t n, const float* d_verts, float* d_out6, void* stream);
 int launch_poisson_interpolate(uint32_t n_points, uint32_t n_cv, const float* d_gamma, const float* d_per_cage, float* d_shs, float* d_out_density, float* d_res_density, void* stream);

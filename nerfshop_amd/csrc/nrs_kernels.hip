@@ -61,6 +61,9 @@ constexpr uint32_t kRefillWhenIdle = 64;
 // NRS_REFILL_BULK (round 6 A/B, default 64 = generations everywhere): idle lanes from which a wave of the automatic schedule takes new rays while the frame's queue still
 // has packets and its running generation is one lane per ray.  Below 64 the idle lanes are refilled in place (rank among the idle lanes, as TEAM == 1 does) while the
 // other rays run on: higher lane occupancy where ray lengths vary, less coherence between a wave's samples.
+#ifndef NRS_ROW_ORDER
+#define NRS_ROW_ORDER 0
+#endif
 #ifndef NRS_REFILL_BULK
 #define NRS_REFILL_BULK 64
 #endif
@@ -136,7 +139,14 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 	if (a.p.tile_size == 0) {
 		// whole image: packets in row-major order (runs of neighbouring packets per claim were measured and lose: a wave's
 		// unstarted packets are invisible to idle waves)
-		const uint32_t bx = pk % a.tiles_x, by = pk / a.tiles_x;
+		const uint32_t bx = pk % a.tiles_x;
+		uint32_t by = pk / a.tiles_x;
+#if NRS_ROW_ORDER
+		{ // (A/B, round 6) packet rows from the middle of the image outwards: the rays through the thick of an object start first, the frame's last generations are silhouettes
+			const uint32_t rows = a.n_packets / a.tiles_x, mid = rows >> 1;
+			by = (by & 1u) ? mid - 1u - (by >> 1) : mid + (by >> 1);
+		}
+#endif
 		x = bx * PW + lx;
 		y = by * PH + ly;
 		out_idx = x + W * y;

@@ -61,6 +61,17 @@ probe("created", edit.vertices)
 pose = synth.deform_cage(edit.cage_vertices, tuple(t * scale for t in (0.07, 0.03, -0.02)), 33.0)
 op.update_cage(None, pose)
 torch.cuda.synchronize()
+# a move drops the fine table; the second frame rendered after it builds the new one (nrs_api.cpp: nrs_edit::fine_stale)
+tb = runtime.Testbed(ctx, desc, aabb_scale)
+tb.nerf_network.set_cell_cache(0)
+tb.nerf_network.set_params(synth.make_params(desc, sigma_raw=synth.default_sigma_raw(aabb_scale)))
+tb.nerf_network.set_density_bitfield(synth.grid_to_bitfield(synth.density_grid(aabb_scale)))
+tb.add_edit_operator(op)
+p = synth.render_params(64, 36, synth.orbit_camera(30.0, 30.0, scale=0.33 * scale), aabb_scale=aabb_scale)
+frame = torch.zeros((36, 64, 4), device="cuda:0"); depth = torch.zeros((36, 64), device="cuda:0")
+for _ in range(2):
+    tb.render_with_params(tb.nerf_network, p, frame, depth, None, None)
+torch.cuda.synchronize()
 verts2 = synth.mvc_apply(edit.mvc_weights, pose).astype(np.float32)
 probe("moved", verts2)
 np.savez(out, **res)
@@ -70,12 +81,14 @@ np.savez(out, **res)
 @pytest.mark.parametrize("aabb_scale,lattice", [(1, 10), (16, 6), (1, 20)])
 def test_fine_lut_is_the_plain_scan(built, tmp_path, aabb_scale, lattice):
     outs = {}
-    for tag, env_extra in (("fine", {}), ("plain", {"NRS_DEV_KNOBS": "1", "NRS_NO_FINE_LUT": "1"})):
+    for tag, env_extra in (("fine", {"NRS_DEV_KNOBS": "1", "NRS_FINE_LOG": "1"}), ("plain", {"NRS_DEV_KNOBS": "1", "NRS_FINE_LOG": "1", "NRS_NO_FINE_LUT": "1"})):
         out = str(tmp_path / f"{tag}.npz")
         env = dict(os.environ, **env_extra)
         r = subprocess.run([sys.executable, "-c", CHILD, ROOT, str(aabb_scale), str(lattice), out], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[tag] = np.load(out)
+        # the table was built at creation and again by the second frame after the move -- and never in the plain run
+        assert r.stderr.count("[nrs fine lut]") == (2 if tag == "fine" else 0), r.stderr[-2000:]
     for key in outs["fine"].files:
         a, b = outs["fine"][key], outs["plain"][key]
         assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b), key
