@@ -1540,6 +1540,16 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		}();
 		a.dbg = dbg;
 	}
+	{ // Cone stepping is what the reference switches on for aabb_scale > 1 (tn:3410-3425): scenes whose fine hashed levels no two samples of a wave share, so that their
+	  // 8 MB of table lines thrash the 4 MB L2 of an XCD -- the GATE instantiation time-multiplexes it (nrs_mlp.cuh encode_to_lds; profiles/r06_garden.md: L2 misses per
+	  // sample 11.5 -> 7.2, +5 % on the garden frame).  A unit-cube scene (constant steps) never takes it: there the gate costs 18 %.
+		static const bool gate_on = []() { const char* e = dev_knob("NRS_L2_GATE"); return !e || atoi(e) != 0; }();
+		// (only where the gate has something to separate: levels 12..15 hashed without records, the pair below them on records -- a model without sparse brick records
+		// gathers eight hashed levels, which two phases do not fit either, and keeps the default instantiation)
+		const LevelParams* lv = m->dm.levels;
+		const bool fine_hashed = lv[12].hashed && lv[13].hashed && lv[14].hashed && lv[15].hashed && !lv[12].cached && !lv[13].cached && !lv[14].cached && !lv[15].cached;
+		a.gate = (gate_on && p->cone_angle_constant > 0.f && fine_hashed && lv[10].cached && lv[11].cached) ? 1u : 0u;
+	}
 	// everything of render_nerf's surface beyond Shade / Cost with a pinhole camera runs the EXTRA instantiation (one lane per ray)
 	a.extra = ((p->render_mode != NRS_RENDER_SHADE && p->render_mode != NRS_RENDER_COST) || p->show_accel || p->dof != 0.f || p->distortion_mode || p->d_distortion_map ||
 	           p->d_envmap || p->glow_mode) ? 1u : 0u;

@@ -159,6 +159,7 @@ struct RenderArgs {
 	uint32_t any_poisson;      // some edit has apply_poisson set
 	uint32_t any_affine;       // some edit is an AffineDuplication
 	uint32_t extra;            // a render mode other than Shade / Cost, show_accel or dof != 0: render_kernel's EXTRA instantiation
+	uint32_t gate;             // cone stepping (aabb_scale > 1 scenes): the plain kernel's GATE instantiation (L2 phase gate on the four finest hashed levels)
 	uint32_t n_packets;        // pixel packets owned by this call (8x8 pixels; 8x4 / 4x4 with lane teams of 2 / 4)
 	uint32_t tiles_x;          // image width in tiles (tiled mode) or in packets (whole-image mode)
 	uint32_t packets_per_tile_x;

@@ -58,15 +58,8 @@ constexpr int kTeamMax = 4; // the widest lane team of the automatic schedule (e
 #define NRS_MEASURE 0
 #endif
 constexpr uint32_t kRefillWhenIdle = 64;
-// NRS_REFILL_BULK (round 6 A/B, default 64 = generations everywhere): idle lanes from which a wave of the automatic schedule takes new rays while the frame's queue still
-// has packets and its running generation is one lane per ray.  Below 64 the idle lanes are refilled in place (rank among the idle lanes, as TEAM == 1 does) while the
-// other rays run on: higher lane occupancy where ray lengths vary, less coherence between a wave's samples.
-#ifndef NRS_ROW_ORDER
-#define NRS_ROW_ORDER 0
-#endif
-#ifndef NRS_REFILL_BULK
-#define NRS_REFILL_BULK 64
-#endif
+// (Round 6 measured the middle ground once more on the automatic schedule: idle lanes refilled in place from 16 / 32 / 48 idle lanes while the queue has packets, instead of
+// re-teaming the survivors of a thinned generation: lego + cage 12.5 -> 11.4 / 11.4 / 11.8, varied 11.2 -> 9.7 / 9.1 / 9.8 Gsamples/s; profiles/r06/ab_refill_*.txt.)
 
 template <int WAVES>
 struct RenderSmem {
@@ -139,14 +132,9 @@ __device__ __forceinline__ bool packet_pixel(const RenderArgs& a, uint32_t pk, i
 	if (a.p.tile_size == 0) {
 		// whole image: packets in row-major order (runs of neighbouring packets per claim were measured and lose: a wave's
 		// unstarted packets are invisible to idle waves)
-		const uint32_t bx = pk % a.tiles_x;
-		uint32_t by = pk / a.tiles_x;
-#if NRS_ROW_ORDER
-		{ // (A/B, round 6) packet rows from the middle of the image outwards: the rays through the thick of an object start first, the frame's last generations are silhouettes
-			const uint32_t rows = a.n_packets / a.tiles_x, mid = rows >> 1;
-			by = (by & 1u) ? mid - 1u - (by >> 1) : mid + (by >> 1);
-		}
-#endif
+		// (packet rows from the middle of the image outwards -- thick rays first, silhouettes last -- measured in round 6: -4 % lego, -1 % varied, -11 % membrane:
+		// neighbouring rows share more than a shorter tail saves; profiles/r06/ab_roworder_*.txt)
+		const uint32_t bx = pk % a.tiles_x, by = pk / a.tiles_x;
 		x = bx * PW + lx;
 		y = by * PH + ly;
 		out_idx = x + W * y;
@@ -238,10 +226,11 @@ __device__ __forceinline__ bool packet_pixel_tail(const RenderArgs& a, uint32_t 
 // XTRA: 0 = none of it, 1 = EXTRA, 2 = EXTRA + INTRO: render modes Normals and EncodingVis (the network's input gradient / a visualised activation per sample,
 //      tn:2923-2927: a second pass over the hash grid and a backward or partial forward pass of the MLPs -- a separate instantiation again);
 //      3 / 4 = 1 / 2 with a third hidden layer in the rgb MLP (DeviceModel::rgb_deep, configs/nerf/base_3layer.json), 5 = that layer and nothing else of EXTRA: the
-//      automatic schedule's instantiation for such a network (plain Shade / Cost frames; nrs_render_nerf decides).
+//      automatic schedule's instantiation for such a network (plain Shade / Cost frames; nrs_render_nerf decides); 6 = the plain kernel with the L2 phase gate (GATE).
 template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0, int XTRA = 0>
 __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const RenderArgs& a_arg) {
-	constexpr bool EXTRA = XTRA >= 1 && XTRA <= 4, INTRO = XTRA == 2 || XTRA == 4, DEEP = XTRA >= 3; // (3 / 4: 1 / 2 for a network whose rgb MLP has a third hidden layer, base_3layer.json; 5: that layer alone)
+	constexpr bool EXTRA = XTRA >= 1 && XTRA <= 4, INTRO = XTRA == 2 || XTRA == 4, DEEP = XTRA >= 3 && XTRA <= 5; // (3 / 4: 1 / 2 for a network whose rgb MLP has a third hidden layer, base_3layer.json; 5: that layer alone)
+	constexpr bool GATE = XTRA == 6; // the plain kernel with the L2 phase gate on the four finest hashed levels (encode_to_lds): cone-stepping scenes
 	// The two argument structs (~1.3 KB of wave-uniform values) live in the kernel-argument segment and are read with scalar loads.
 	// Left alone, the compiler hoists every such load out of the frame loop and then spills ~150 scalar registers into VGPR lanes
 	// (v_writelane / v_readlane: VALU slots in the round loop, 3 VGPRs).  NRS_FRESH_ARGS re-derives the two references from an
@@ -369,7 +358,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				}
 			}
 		}
-		if (TEAM == 0 && a1.reteam && (((a1.reteam & 2u) && tail_seen && !(NRS_REFILL_BULK < 64 && more)) || (!more && ring_count == 0u))) { // (NRS_REFILL_BULK < 64: idle lanes take new rays instead while the queue has some) // (bit 1: at any time once the wave runs tail generations, not only at its end)
+		if (TEAM == 0 && a1.reteam && (((a1.reteam & 2u) && tail_seen) || (!more && ring_count == 0u))) { // (bit 1: at any time once the wave runs tail generations, not only at its end) // (bit 1: at any time once the wave runs tail generations, not only at its end)
 			const unsigned long long lead_mask = __ballot(have && tk == 0);
 			const uint32_t live = (uint32_t)__popcll(lead_mask);
 			const uint32_t new_t = live <= 16u ? 4u : (live <= 32u ? 2u : 1u);
@@ -404,14 +393,11 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		}
 		const unsigned long long free_mask = __ballot(!have);
 		const uint32_t nfree = (uint32_t)__popcll(free_mask);
-		// (the refill threshold of this pass: generations of 64, or NRS_REFILL_BULK idle lanes in the bulk phase of the automatic schedule)
-		const bool partial = NRS_REFILL_BULK < 64 && TEAM == 0 && gen_t == 1u && more && nfree < kRefillWhenIdle;
-		const uint32_t refill_at = partial ? (uint32_t)NRS_REFILL_BULK : kRefillWhenIdle;
 
 		// ---- fill the ring with rays that found an occupied cell (init_rays + advance_pos_nerf) ----
 		// (Measured: moving this into its own lean kernel does not pay -- the DDA's dependent bitfield loads overlap with
 		// other waves' gather/MLP work here for free, while a separate launch adds ~1 ms of serial time at 1080p.)
-		while (more && ring_count < (TEAM > 1 ? 64u / gen_t : (TEAM == 0 && tail_seen && !partial ? a1.tail_target : nfree)) && nfree >= refill_at) {
+		while (more && ring_count < (TEAM > 1 ? 64u / gen_t : (TEAM == 0 && tail_seen ? a1.tail_target : nfree)) && nfree >= kRefillWhenIdle) {
 			const uint32_t pk = claim_packet(&sm.queue, &a1.counters->next_packet, a1.n_packets, lane);
 			if (pk == kNoPacket) { more = false; if (PROF) { pf_tq = wall_clock64() - pf_wall0; pf_rounds_q = pf_rounds; } break; }
 			if (PROF) ++pf_packets;
@@ -479,17 +465,16 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		NRS_PHASE(1); // refill
 
 		// ---- hand pending rays to idle lanes ----
-		if (nfree >= refill_at && ring_count) {
-			if (TEAM == 0 && !partial) { // (a partial refill joins the running one-lane generation) // hybrid: full generations until the tail packets, then as many lanes per ray as the pending rays allow
+		if (nfree >= kRefillWhenIdle && ring_count) {
+			if (TEAM == 0) { // hybrid: full generations until the tail packets, then as many lanes per ray as the pending rays allow
 				// (a launch of tail packets only runs one lane per ray only where it is large -- 64-pixel packets -- and the wave can fill its lanes:
 				// otherwise more than 32 pending rays = 32 now as teams of two, the rest in the next generation or handed to a waiting sibling)
 				gen_t = tail_seen ? (ring_count > 32u && (!a1.all_tail || (a1.fill_lanes == 1u && ring_count >= kFullGen)) ? 1u : (ring_count > 16u ? 2u : 4u)) : 1u;
 				tk = lane & (int)(gen_t - 1u);
 				team_base = lane & ~(int)(gen_t - 1u);
 			}
-			const bool in_place = TEAM == 1 || partial; // (rank among the idle lanes)
-			const uint32_t take = min(in_place ? nfree : 64u / gen_t, ring_count);
-			const uint32_t rank = !in_place ? (uint32_t)lane / gen_t // (all 64 lanes are idle: kRefillWhenIdle)
+			const uint32_t take = min(TEAM != 1 ? 64u / gen_t : nfree, ring_count);
+			const uint32_t rank = TEAM != 1 ? (uint32_t)lane / gen_t // (all 64 lanes are idle: kRefillWhenIdle)
 			                                : __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
 			if (!have && rank < take) {
 				const uint2 e = ring[(ring_head + rank) & (kRing - 1)];
@@ -623,7 +608,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		{ f3 wp2 = wpos; asm volatile("" : "+v"(wp2.x), "+v"(wp2.y), "+v"(wp2.z));
 		  encode_num<NUM, (TEAM == 0 && !POISSON && !AFFINE && !EXTRA && NUM == 0)>(nm, gv, m2.levels, sm.ml, fl, lane, g, wp2, act); }
 #endif
-		encode_num<NUM, (TEAM == 0 && !POISSON && !AFFINE && !EXTRA && (NUM == 0 || NUM == 3)), false>(nm, gv, m2.levels, sm.ml, fl, lane, g, wpos, act); // (four record levels in flight: the hybrid instantiation has the registers; features of idle lanes are never looked at: not zeroed)
+		encode_num<NUM, (TEAM == 0 && !POISSON && !AFFINE && !EXTRA && (NUM == 0 || NUM == 3)), false, GATE>(nm, gv, m2.levels, sm.ml, fl, lane, g, wpos, act); // (four record levels in flight: the hybrid instantiation has the registers; features of idle lanes are never looked at: not zeroed)
 		NRS_PHASE(4); // SH + MLP
 		const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
 		half8 sh_own, sh_par;
@@ -1177,6 +1162,8 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 		return m.numerics ? launch_render_cfg<12, 3, false, true, true, 1, R, 1>(m, a, n_cus, s) : launch_render_cfg<12, 3, false, true, true, 1, 0, 1>(m, a, n_cus, s);
 	}
 	if (m.rgb_deep) return launch_render_cfg<8, 4, false, false, false, 0, 0, 5>(m, a, n_cus, s); // (nrs_render_nerf sends only the plain case here: a.team == 0, default roundings)
+	// cone-stepping scenes (aabb_scale > 1): the plain automatic schedule with the L2 phase gate (nrs_render_nerf sets a.gate for plain frames only; NRS_L2_GATE=0: A/B)
+	if (a.gate && !m.numerics && !a.any_poisson && !a.any_affine && a.team == 0 && !(a.dbg & 4u) && cfg == 0) return launch_render_cfg<8, 4, false, false, false, 0, 0, 6>(m, a, n_cus, s);
 	if (m.numerics) { // tiny-cuda-nn's other roundings: the run-time twin of every schedule (nrs_render_nerf computed the packet geometry for a.team)
 		// ... except the pair a parity-minded integrator switches on -- per-corner fp16 grid accumulation + fp16 MLP accumulators, what tiny-cuda-nn's
 		// kernel_grid and fully fused MLP do as recalled -- on the automatic schedule: a compile-time instantiation like NUM = 0 (VERDICT r3 weak #1:

@@ -23,15 +23,9 @@
 #include <hip/hip_runtime.h>
 #include "nrs_device.cuh"
 
-#ifndef NRS_PHASE_GATE
-#define NRS_PHASE_GATE 0 // (open A/B: see encode_to_lds)
-#endif
-#ifndef NRS_PHASE_WAITCAP
-#define NRS_PHASE_WAITCAP 8
-#endif
-#ifndef NRS_NT_BRICKS
-#define NRS_NT_BRICKS 0 // (open A/B: see issue_brick_record_loads)
-#endif
+// L2 time-multiplexing of the four finest hashed levels (encode_to_lds, GATE): a phase is 2^kGateShift ticks of the 100 MHz wall clock (20.5 us); a wave waits at most
+// kGateWaitCap eighths of a phase for the right one (profiles/r06_garden.md: 10 / 20 / 41 us phases, wait caps 2 / 4 / 8 eighths measured)
+constexpr uint32_t kGateShift = 11, kGateWaitCap = 2;
 
 namespace nrs {
 
@@ -279,15 +273,9 @@ __device__ __forceinline__ uint32_t brick_entry(const GridView& gv, const LevelP
 __device__ __forceinline__ void issue_brick_record_loads(const GridView& gv, const LevelParams& lp, const CellCoords& c, uint32_t brick, uint32_t v[8]) {
 	const uint32_t rec = lp.rec_first + (brick - 1u) * 512u + brick_slot(c.gx & 7u, c.gy & 7u, c.gz & 7u);
 	const uint4* p = gv.records2 + 2 * (size_t)rec;
-#if NRS_NT_BRICKS
-	// EXPERIMENT (round 6): `nt` on both halves -- the L2 then treats the record's line as streaming and the hot hashed tables keep their lines (tools/probe/l2_retention_probe:
-	// hot-table misses 30 % -> 10 % beside a cold stream); the two halves are issued back to back, so the second merges with the first one's miss
-	typedef uint32_t u4nt __attribute__((ext_vector_type(4)));
-	const u4nt lo_ = __builtin_nontemporal_load(reinterpret_cast<const u4nt*>(p)), hi_ = __builtin_nontemporal_load(reinterpret_cast<const u4nt*>(p) + 1);
-	const uint4 lo = make_uint4(lo_.x, lo_.y, lo_.z, lo_.w), hi = make_uint4(hi_.x, hi_.y, hi_.z, hi_.w);
-#else
+	// (`nt` on both halves keeps the record's line from displacing hot table lines -- tools/probe/l2_retention_probe: hot-table misses 30 % -> 10 % beside a cold stream --
+	// and is worth +2.5 % on the garden frame alone, nothing on top of the phase gate: profiles/r06/ab_garden_gate.txt)
 	const uint4 lo = p[0], hi = p[1];
-#endif
 	v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
 	v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
 }
@@ -425,25 +413,25 @@ __device__ __forceinline__ uint32_t level_eval_one(const GridView& gv, const Lev
 // same bits as before: the arithmetic per (sample, level) did not change.  The slab layout the MLP reads is unchanged too:
 // feat[it][0][l] = level 2 it + g(l) of lane l's sample, feat[it][1][l] = the same level of lane (l ^ 32)'s sample; so the level
 // of the lane's own parity goes to [0][lane] and the other one to [1][lane ^ 32] (a conflict-free permutation of the banks).
-template <bool NETACC = false, bool QUADS = false, bool ZERO = true>
+template <bool NETACC = false, bool QUADS = false, bool ZERO = true, bool GATE = false>
 __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelParams* __restrict__ lv, const ModelLds& ml, FeatLds& fl, int lane, int g, f3 pos, bool act) {
 	// the records cover [0,1]^3; a wave with a sample outside it (a warped sample of an edit, rarely) gathers the native way
 	const bool outside = __any(act && outside_unit_cube(pos));
 	const uint32_t* kinds = outside ? ml.kinds_native : ml.kinds;
 	const bool one_line = __builtin_amdgcn_readfirstlane(ml.one_line) != 0u; // profiling (NRS_DEBUG & 1): every gather of a wave hits one 128-byte line
 	int it = 0, it_end = 8;
-#if NRS_PHASE_GATE
-	// EXPERIMENT (round 6, aabb-16 scenes; profiles/r06_garden.md): the four finest levels are hashed tables of 2 MB each -- 8 MB against the 4 MB L2 of an XCD: alone, each
-	// PAIR of them hits (0.15 L2 misses per sample), together they thrash (7.8).  Time-multiplex the L2: the wall clock (100 MHz, the same on every XCD) is cut into
-	// phases of 2^NRS_PHASE_GATE ticks; levels 12-13 are gathered in even phases, 14-15 in odd ones, by every wave of the GPU, with the record levels in between as filler.
-	// Results cannot change (the same loads, another order); a wave waits at most one phase.
+	// GATE (round 6, the instantiation for cone-stepping scenes -- aabb_scale > 1; profiles/r06_garden.md): there the four finest levels are hashed tables of 2 MB each whose
+	// lines no two samples of a wave share -- 8 MB of hot lines against the 4 MB L2 of an XCD: alone, each PAIR of them hits (0.15 L2 misses per sample), together they
+	// thrash (7.8 of the frame's 11.5).  So the L2 is time-multiplexed: the wall clock (100 MHz, the same on every XCD) is cut into phases of 2^kGateShift ticks; levels
+	// 12-13 are gathered in even phases and 14-15 in odd ones by every wave of the GPU, whichever phase a wave arrives in first, with the record levels in between as
+	// filler; a wave waits at most kGateWaitCap eighths of a phase for the other one, then goes ahead.  Results cannot change (the same loads in another order).
 	bool gated = false;
 	uint32_t gate_ph = 0;
-	auto gate_wait = [&](uint32_t ph) { // (NRS_PHASE_WAITCAP: the longest wait in eighths of a phase -- 8 = a whole phase, the hard gate; less = go ahead in the wrong phase)
-		const unsigned long long t_in = wall_clock64(), cap = ((unsigned long long)NRS_PHASE_WAITCAP << NRS_PHASE_GATE) >> 3;
+	auto gate_wait = [&](uint32_t ph) {
+		const unsigned long long t_in = wall_clock64(), cap = ((unsigned long long)kGateWaitCap << kGateShift) >> 3;
 		for (;;) {
 			const unsigned long long now = wall_clock64();
-			if ((((uint32_t)(now >> NRS_PHASE_GATE)) & 1u) == ph || now - t_in >= cap) break;
+			if ((((uint32_t)(now >> kGateShift)) & 1u) == ph || now - t_in >= cap) break;
 			__builtin_amdgcn_s_sleep(8);
 		}
 	};
@@ -453,17 +441,16 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 		fl.feat[itp][0][lane] = g ? f1 : f0;
 		fl.feat[itp][1][lane ^ 32] = g ? f0 : f1;
 	};
-	if (QUADS && !one_line && __builtin_amdgcn_readfirstlane(kinds[6]) == KIND_HASHED && __builtin_amdgcn_readfirstlane(kinds[7]) == KIND_HASHED &&
+	if (GATE && !one_line && __builtin_amdgcn_readfirstlane(kinds[6]) == KIND_HASHED && __builtin_amdgcn_readfirstlane(kinds[7]) == KIND_HASHED &&
 	    __builtin_amdgcn_readfirstlane(kinds[5]) != KIND_HASHED) {
 		gated = true;
 		const unsigned long long now = wall_clock64();
-		constexpr unsigned long long kPhaseMask = (1ull << NRS_PHASE_GATE) - 1ull;
-		gate_ph = (uint32_t)(now >> NRS_PHASE_GATE) & 1u;
+		constexpr unsigned long long kPhaseMask = (1ull << kGateShift) - 1ull;
+		gate_ph = (uint32_t)(now >> kGateShift) & 1u;
 		if ((now & kPhaseMask) > kPhaseMask * 13ull / 16ull) { gate_ph ^= 1u; gate_wait(gate_ph); } // (late in a phase: this gather would run into the next one -- take that)
 		gate_pair(6 + (int)gate_ph);
 		it_end = 6;
 	}
-#endif
 	#pragma unroll 1
 	while (it < it_end) {
 		LevelParams lp0 = lv[2 * it], lp1 = lv[2 * it + 1];
@@ -504,9 +491,7 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 		fl.feat[it][1][lane ^ 32] = g ? f0 : f1;
 		++it;
 	}
-#if NRS_PHASE_GATE
-	if (gated) { gate_wait(gate_ph ^ 1u); gate_pair(7 - (int)gate_ph); }
-#endif
+	if (GATE && gated) { gate_wait(gate_ph ^ 1u); gate_pair(7 - (int)gate_ph); }
 	// feat[..][1][lane ^ 32] is another lane's slot: order the wave's writes before load_features' reads (no instruction: LDS operations of a wave
 	// stay in order; this keeps the compiler from moving a read above the write it cannot see through the xor)
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -829,10 +814,10 @@ __device__ __forceinline__ void level_input_gradient(const GridView& gv, const L
 // tiny-cuda-nn's roundings as a template value: NUM >= 0 fixes them at compile time (bit 0 grid accumulation in network precision, bit 1 fp16 MLP
 // accumulators), kNumRuntime reads them from `nm` (DeviceModel::numerics, wave-uniform) -- both flavours compiled in, one scalar branch.
 constexpr int kNumRuntime = -1;
-template <int NUM, bool QUADS = false, bool ZERO = true>
+template <int NUM, bool QUADS = false, bool ZERO = true, bool GATE = false>
 __device__ __forceinline__ void encode_num(uint32_t nm, const GridView& gv, const LevelParams* __restrict__ lv, const ModelLds& ml, FeatLds& fl, int lane, int g, f3 pos, bool act) {
-	if (NUM == kNumRuntime ? (nm & 1u) != 0u : (NUM & 1) != 0) encode_to_lds<true, QUADS, ZERO>(gv, lv, ml, fl, lane, g, pos, act);
-	else encode_to_lds<false, QUADS, ZERO>(gv, lv, ml, fl, lane, g, pos, act);
+	if (NUM == kNumRuntime ? (nm & 1u) != 0u : (NUM & 1) != 0) encode_to_lds<true, QUADS, ZERO, GATE>(gv, lv, ml, fl, lane, g, pos, act);
+	else encode_to_lds<false, QUADS, ZERO, GATE>(gv, lv, ml, fl, lane, g, pos, act);
 }
 template <int NUM>
 __device__ __forceinline__ half8 density_mlp_num(uint32_t nm, const half8* lds_w, int lane, half8 x0, half8 x1) {
