@@ -898,30 +898,6 @@ __device__ __forceinline__ void poisson_residual_colour(const DeviceEdit& e, uin
 		const f3 a = ld3(e.verts, tv.x), b = ld3(e.verts, tv.y), c = ld3(e.verts, tv.z), dd = ld3(e.verts, tv.w);
 		bary_tet(a, b, c, dd, pos, bc);
 	}
-		load9(ov[0], cb, L0);
-		load9(ov[1], cb, L1);
-		#pragma unroll
-		for (int k = 0; k < 9; ++k) a[k] = bc[0] * L0[k] + bc[1] * L1[k];
-		__builtin_amdgcn_sched_barrier(0);
-		load9(ov[2], cb, L0);
-		load9(ov[3], cb, L1);
-		#pragma unroll
-		for (int k = 0; k < 9; ++k) a[k] = (a[k] + bc[2] * L0[k]) + bc[3] * L1[k];
-#endif
-		// SH basis (evaluate_sh9, cn:222-240): the products are the reference's, term by term
-		const float q0 = 0.2820947917738781f * a[0];
-		const float q1 = (-0.48860251190292f * dy) * a[1];                         // fTmpA * fS0
-		const float q2 = (0.4886025119029199f * dz) * a[2];
-		const float q3 = (-0.48860251190292f * dx) * a[3];                         // fTmpA * fC0
-		const float q4 = (0.5462742152960395f * (dx * dy + dy * dx)) * a[4];        // fTmpC * fS1
-		const float q5 = ((-1.092548430592079f * dz) * dy) * a[5];                 // fTmpB * fS0
-		const float q6 = (0.9461746957575601f * (dz * dz) + -0.3153915652525201f) * a[6];
-		const float q7 = ((-1.092548430592079f * dz) * dx) * a[7];                 // fTmpB * fC0
-		const float q8 = (0.5462742152960395f * (dx * dx - dy * dy)) * a[8];       // fTmpC * fC1
-		// pSH.dot(sh.block<9, 1>(0, c)): Eigen's unrolled 9-term reduction, 4 | 5 -> (2|2) | (2|(1|2))
-		rgb[c] = ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + (q7 + q8)));
-	}
-#else
 	// The 4 x 27 coefficients are read through a buffer descriptor (wave-uniform base in scalar registers, one 32-bit offset per vertex, the coefficient in
 	// the instruction's immediate) and in small groups: the registers of a wave, not the latency of a few more round trips, are what this instantiation is
 	// short of (the kernel must fit the 128 VGPRs of the default launch shape).  Two terms of the dot product are in flight at once.
