@@ -44,6 +44,9 @@ def flop_per_sample(desc):
 
 def build_scene(workload, rt, synth, ctx, torch):
     aabb_scale = 16 if workload.startswith("garden") else 1
+    # garden_cage = the KNEE of the record-budget curve (profiles/r06_garden.md: 0 / 3.2 / 60.7 GB of sparse brick records -> 4.51 / 4.62 / 4.97 Gsamples/s without the L2
+    # phase gate): a 4 GiB budget, levels 8..9; garden_cage_records64 = the 64 GiB budget (levels 8..11: the configuration the L2 phase gate applies to)
+    sparse_gb = os.environ.get("NRS_SPARSE_GB", "64" if workload.endswith("records64") else "4")
     with_edit = "cage" in workload
     # (configs/nerf/base_1layer.json / base_3layer.json: the rgb network with one hidden layer is lowered onto the kernels' network and runs the default
     # instantiations; the third hidden layer has its own: DESIGN.md 4 "Instantiations")
@@ -81,11 +84,11 @@ def build_scene(workload, rt, synth, ctx, torch):
 
         grid = synth.deformed_density_grid(grid, desc, map_positions, aabb_scale)
     tb.nerf_network.set_density_grid(grid)  # threshold + mip pooling on the device
-    if aabb_scale > 1 and os.environ.get("NRS_SPARSE_GB", "64") != "0" and not workload.endswith("norecords"):
+    if aabb_scale > 1 and sparse_gb != "0" and not workload.endswith("norecords"):
         # aabb-16 scenes: the dense cell records end at level 7 (7.3 GB); levels 8.. get occupancy-sparse brick records wherever lookups can
         # happen: the occupancy of the edited scene OR the un-edited one (the cage carries samples back to canonical space)
         mask = synth.grid_to_bitfield(grid) | synth.grid_to_bitfield(synth.density_grid(aabb_scale))
-        tb.nerf_network.set_sparse_cell_cache(mask, int(float(os.environ.get("NRS_SPARSE_GB", "64")) * (1 << 30)))
+        tb.nerf_network.set_sparse_cell_cache(mask, int(float(sparse_gb) * (1 << 30)))
     return dict(desc=desc, params=params, grid=grid, edit=edit, tb=tb, aabb_scale=aabb_scale)
 
 
@@ -328,7 +331,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage", "garden", "lego_cage_varied", "lego_cage_membrane", "garden_cage_norecords", "lego_cage_tcnn_numerics", "lego_cage_norecords", "lego_cage_base_1layer", "lego_cage_base_3layer"])
+    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage", "garden_cage_records64", "garden", "lego_cage_varied", "lego_cage_membrane", "garden_cage_norecords", "lego_cage_tcnn_numerics", "lego_cage_norecords", "lego_cage_base_1layer", "lego_cage_base_3layer"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -536,7 +539,7 @@ def main():
         # cage edit) and the lego-like scene with non-uniform opacity (a wide distribution of ray lengths, as a trained snapshot has)
         # plus the membrane correction on (SURVEY 8d's "one extra run with it on") and the garden scene WITHOUT the 64 GB of sparse brick records
         # (they are an option of the boundary, INTEGRATION.md: the figure a caller gets who does not install them)
-        for name in ("garden_cage", "garden_cage_norecords", "lego_cage_varied", "lego_cage_membrane", "lego_cage_tcnn_numerics", "lego_cage_norecords", "lego_cage_base_1layer",
+        for name in ("garden_cage", "garden_cage_records64", "garden_cage_norecords", "lego_cage_varied", "lego_cage_membrane", "lego_cage_tcnn_numerics", "lego_cage_norecords", "lego_cage_base_1layer",
                      "lego_cage_base_3layer"):
             sc2 = build_scene(name, rt, synth, ctx, torch)
             tb2 = sc2["tb"]
@@ -564,7 +567,7 @@ def main():
             # the HBM rate the frame really runs at: PMC traffic of this workload's kernel, measured NOW for the garden scene (two more child runs,
             # like the headline's), else the figure profiles/ holds, if any (`traffic_source` says which)
             tr, src = (None, None)
-            if name == "garden_cage":
+            if name in ("garden_cage", "garden_cage_records64"):
                 tr, src = live_traffic(name, W, H)
             if tr is None:
                 why = src
@@ -667,7 +670,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": {"lego_cage": "lego-like snapshot 1920x1080, one cage edit (BASELINE configs[2]/[4])",
                                     "lego": "lego-like snapshot 1920x1080, no edits (BASELINE configs[1])",
-                                    "garden_cage": "garden-style aabb_scale 16 1920x1080, one cage edit (BASELINE configs[3])",
+                                    "garden_cage": "garden-style aabb_scale 16 1920x1080, one cage edit (BASELINE configs[3]); sparse brick records at the knee of the budget curve (4 GiB)",
+                                    "garden_cage_records64": "garden-style aabb_scale 16 1920x1080, one cage edit, 64 GiB budget of sparse brick records (levels 8..11; the L2 phase gate applies)",
                                     "garden": "garden-style aabb_scale 16 1920x1080, no edits",
                                     "lego_cage_varied": "lego-like snapshot with non-uniform opacity (geometry in the network, density noise 1.5) 1920x1080, one cage edit",
                                     "lego_cage_membrane": "lego-like snapshot 1920x1080, one cage edit with the membrane (Poisson) correction on",
@@ -716,6 +720,12 @@ def main():
             # one-frame-at-a-time figure (retention_1); retention_2 / _4 are the same frames with 2 / 4 in flight per rank (the `pipelined` / `pipelined4` keys)
             line["n1_reference"] = n1_ref
             line["retention_1"] = round(value / world / n1_ref["msamples_per_s"], 4)
+            #  what retention_1 can read AT MOST with this design, so that a SCALE record is not misread: a rank's 1/N share of this frame measured on
+            # ONE MI355X with a free exchange (profiles/r06_scaling.md: 2.076 ms whole frame; shares 1.173 / 0.671 / 0.449 ms one frame at a time).  The share's launch is
+            # launch + fill + first hits (0.37 / 0.33 / 0.26 ms, the intercept of the cut-off probe) + the rounds of its longest rays; north_star's 0.9 at N = 8 would need
+            # the whole share in 0.288 ms -- the non-round part alone takes 0.26.  Frames in flight are what reaches it (retention_2 / _4).
+            line["retention_floor_1"] = {2: 0.885, 4: 0.773, 8: 0.578}.get(world)
+            line["retention_floor_note"] = "one-GPU share measurement of the same frame, exchange free (profiles/r06_scaling.md): the most `retention_1` can read with one frame in flight"
             for k, key in ((2, "pipelined"), (4, "pipelined4")):
                 if key in extra:
                     line[f"retention_{k}"] = round(extra[key]["msamples_per_s"] / world / n1_ref["msamples_per_s"], 4)

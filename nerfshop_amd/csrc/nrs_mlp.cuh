@@ -362,6 +362,31 @@ __device__ __forceinline__ void record_eval_four(const GridView& gv, const Level
 	f3_ = zero_if<ZERO>(!act, interpolate<NETACC>(cell_coords_incube(lp3, q), v3));
 }
 
+// FOUR sparse levels (two consecutive pairs of brick-record levels: levels 8..11 of an aabb-16 scene) in TWO round trips instead of four: the four brick-table entries
+// first, then -- when every lane of the wave has a brick at every one of them, the usual case inside the occupancy mask -- all eight 16-byte record loads at once (round 6:
+// the garden frame's round is a chain of ~12 dependent trips of 3-4 us each).  Weights recomputed behind the loads, as above.  Returns false (nothing written) when
+// some lane lacks a brick: the caller then takes the pairs one by one (level_eval_two's fallback).
+template <bool NETACC = false, bool ZERO = true>
+__device__ __forceinline__ bool sparse_eval_four(const GridView& gv, const LevelParams& lp0, const LevelParams& lp1, const LevelParams& lp2, const LevelParams& lp3, f3 pos, bool act,
+                                                 uint32_t& f0, uint32_t& f1, uint32_t& f2, uint32_t& f3_) {
+	f3 q = act ? pos : mk3(0.f, 0.f, 0.f);
+	const CellCoords c0 = cell_coords_incube(lp0, q), c1 = cell_coords_incube(lp1, q), c2 = cell_coords_incube(lp2, q), c3 = cell_coords_incube(lp3, q);
+	uint32_t b0 = brick_entry(gv, lp0, c0), b1 = brick_entry(gv, lp1, c1), b2 = brick_entry(gv, lp2, c2), b3 = brick_entry(gv, lp3, c3);
+	if (!act) { b0 = 1u; b1 = 1u; b2 = 1u; b3 = 1u; } // idle lanes read the levels' first records
+	if (!__builtin_expect(__all(b0 != 0u && b1 != 0u && b2 != 0u && b3 != 0u), 1)) return false;
+	uint32_t v0[8], v1[8], v2[8], v3[8];
+	issue_brick_record_loads(gv, lp0, c0, b0, v0);
+	issue_brick_record_loads(gv, lp1, c1, b1, v1);
+	issue_brick_record_loads(gv, lp2, c2, b2, v2);
+	issue_brick_record_loads(gv, lp3, c3, b3, v3);
+	asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z)); // the weights below are recomputed, not carried across the loads
+	f0 = zero_if<ZERO>(!act, interpolate<NETACC>(cell_coords_incube(lp0, q), v0));
+	f1 = zero_if<ZERO>(!act, interpolate<NETACC>(cell_coords_incube(lp1, q), v1));
+	f2 = zero_if<ZERO>(!act, interpolate<NETACC>(cell_coords_incube(lp2, q), v2));
+	f3_ = zero_if<ZERO>(!act, interpolate<NETACC>(cell_coords_incube(lp3, q), v3));
+	return true;
+}
+
 // The same for FOUR hashed levels (the two pairs behind the cell records: levels 12..15 of base.json's table): 32 single-dword gathers in flight, one round trip
 // instead of two.  The hashes need the cells before the loads; the weights are recomputed behind them (as above).
 // INCUBE: every sample of the wave lies in [0, 1]^3 (the caller's wave-uniform test): truncation / v_fract instead of floor / subtract, as for the records
@@ -465,6 +490,17 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 			fl.feat[it + 1][1][lane ^ 32] = g ? f2 : f3_;
 			it += 2;
 			continue;
+		}
+		if (QUADS && kind == KIND_SPARSE && it + 1 < it_end && __builtin_amdgcn_readfirstlane(kinds[it + 1]) == KIND_SPARSE) {
+			uint32_t f0, f1, f2, f3_;
+			if (sparse_eval_four<NETACC, ZERO>(gv, lp0, lp1, lv[2 * it + 2], lv[2 * it + 3], pos, act, f0, f1, f2, f3_)) {
+				fl.feat[it][0][lane] = g ? f1 : f0;
+				fl.feat[it][1][lane ^ 32] = g ? f0 : f1;
+				fl.feat[it + 1][0][lane] = g ? f3_ : f2;
+				fl.feat[it + 1][1][lane ^ 32] = g ? f2 : f3_;
+				it += 2;
+				continue;
+			}
 		}
 		if (QUADS && kind == KIND_HASHED && it + 1 < 8 && __builtin_amdgcn_readfirstlane(kinds[it + 1]) == KIND_HASHED) {
 			uint32_t f0, f1, f2, f3_;

@@ -176,11 +176,14 @@ def test_base_3layer_bench_scene_1080p_against_the_oracle(built):
     check_against_oracle(bs, bs.params(0), bs.edits, 10_000_000)
 
 
-def test_garden_bench_scene_1080p_against_the_oracle(built):
-    """`garden_cage` (BASELINE configs[3]) exactly as bench.build_scene makes it: aabb_scale 16, cone stepping, cage lattice 10 at scene scale 6, the dense cell records
+@pytest.mark.parametrize("workload", ["garden_cage", "garden_cage_records64"])
+def test_garden_bench_scene_1080p_against_the_oracle(built, workload):
+    """`garden_cage` (the knee of the record-budget curve: 4 GiB, levels 8..9) and `garden_cage_records64` (64 GiB, levels 8..11: the frame runs the GATE instantiation --
+    L2 phase gate, four brick levels in two round trips) (BASELINE configs[3]) exactly as bench.build_scene makes them: aabb_scale 16, cone stepping, cage lattice 10 at scene scale 6, the dense cell records
     of levels 0..7 AND the sparse brick records from the `edited | unedited` occupancy mask under the bench's own byte budget (NRS_SPARSE_GB, 64 GiB by default) --
     bench view 0 at 1920x1080 against the oracle (depth bar scaled to the scene's extent as in tests/test_gpu_numerics.py)."""
-    bs = BenchScene("garden_cage")
+    bs = BenchScene(workload)
     nbytes, first, count = bs.tb.nerf_network.sparse_cell_cache()
+    assert count == (4 if workload.endswith("records64") else 2), (nbytes, first, count)
     assert count > 0 and nbytes > (1 << 30), (nbytes, first, count)  # the brick records are really installed: this is the path the bench line times
     check_against_oracle(bs, bs.params(0), bs.edits, 20_000_000, depth_scale=16.0)

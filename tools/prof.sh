@@ -19,6 +19,13 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MF
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM --kernel-trace -d $OUT/pmc_sq2 -o bench -- $B2 > $OUT/pmc5.log 2>&1
 fi
 python $R/profiles/summarize.py $OUT $OUT/summary.md "$W ($TAG)"
+python - "$OUT" <<PY
+import json, os, sys
+sys.path.insert(0, "$R/tools")
+from pmc_kernel import read
+out = sys.argv[1]
+json.dump({d: read(os.path.join(out, d)) for d in sorted(os.listdir(out)) if os.path.isdir(os.path.join(out, d))}, open(os.path.join(out, "counters.json"), "w"), indent=1)
+PY
 find $OUT -name "*.db" -delete
 find $OUT -name "*.csv" -size +2M -delete
 cat $OUT/summary.md | grep -v "^$" | head -70

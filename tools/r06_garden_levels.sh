@@ -1,6 +1,6 @@
 #!/bin/bash
 # the L2 misses of the garden frame attributed level pair by level pair.  For each mask a rocprofv3 PMC pass (TCC hit / miss / req) over a short
-# bench run of garden_cage with NRS_SKIP_PAIRS=mask (level pairs that are not gathered at all: nrs_mlp.cuh KIND_SKIP).  usage: tools/r06_garden_levels.sh <out dir> [masks...]
+# bench run of garden_cage_records64 (64 GiB of brick records: levels 8..11) with NRS_SKIP_PAIRS=mask (level pairs that are not gathered at all: nrs_mlp.cuh KIND_SKIP).  usage: tools/r06_garden_levels.sh <out dir> [masks...]
 export NRS_DEV_KNOBS=1
 R=$GRAFT_REPO_ROOT
 OUT=$1; shift
@@ -11,7 +11,7 @@ MASKS="$@"
 for M in $MASKS; do
   D=/tmp/gl_$M; rm -rf $D
   NRS_SKIP_PAIRS=$M timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace -d $D -o b -- \
-     python $R/bench.py --workload garden_cage --steps 4 --warmup 1 --no-cpu-baseline --no-extra > $D.log 2>&1
+     python $R/bench.py --workload garden_cage_records64 --steps 4 --warmup 1 --no-cpu-baseline --no-extra > $D.log 2>&1
   LINE=$(grep '^{"metric"' $D.log | tail -1)
   echo "{\"mask\": \"$M\", \"pmc\": $(python $R/tools/pmc_kernel.py $D), \"bench\": ${LINE:-null}}" >> $OUT/levels.jsonl
   rm -rf $D
