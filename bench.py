@@ -222,7 +222,7 @@ def next_rows(rt, synth, ctx, torch):
     return rows
 
 
-TRAFFIC_FILE = "profiles/r05_traffic.json"
+TRAFFIC_FILE = "profiles/r06_traffic.json"
 
 
 def measured_traffic(workload):
