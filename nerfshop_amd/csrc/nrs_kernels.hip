@@ -54,9 +54,6 @@ constexpr int kRing = 128; // pending-ray ring entries per wave (>= 63 + 64)
 constexpr int kTeamMax = 4; // the widest lane team of the automatic schedule (eight lanes per ray once a wave holds <= 8 rays was measured and loses: profiles/r03_schedules.md)
 // Measurement builds (-DNRS_MEASURE=<n>; production: undefined): 1 fill, 2 cage warp, 3 gather, 4 MLPs, 5 march executed twice (results unchanged) -- the frame time's
 // difference is that phase's marginal cost; 9 = ISA listing with phase markers (tools/isa_phases.py: comments only, for counting instructions per phase).
-#ifndef NRS_OCC_PREFETCH
-#define NRS_OCC_PREFETCH 0
-#endif
 #ifndef NRS_MEASURE
 #define NRS_MEASURE 0
 #endif
@@ -605,24 +602,6 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 			pf_walk[10] += pf_scan & 0xffffu; pf_walk[11] += (lane == 0) ? mx : 0u; pf_walk[12] += (pf_scan >> 17) & 1u;
 		}
 		if (POISSON && !AFFINE) poisson_stash[wave * 64 + lane] = warp_scan; // (through LDS, not a register across the gather -- this instantiation's peak)
-#if NRS_OCC_PREFETCH
-		// ---- the occupancy word of this ray's NEXT position, fetched with the gather (one-lane rounds): `t + dt` does not depend on what the network says about
-		// this sample, so the first test of the walk at the bottom of the round (march_to_occupied: inside both boxes, bit set) is answered by a load issued here,
-		// a dependent memory trip less on the round's chain.  The same index, the same bit: the walk runs as before whenever the answer is not "occupied".
-		uint32_t pre_word = 0u, pre_bit = 0u;
-		if (TEAM == 1 || (TEAM == 0 && gen_t == 1u)) {
-			const float tn = t + dt;
-			const f3 pn = o + d * tn;
-			Box3 bbn;
-			#pragma unroll
-			for (int i = 0; i < 3; ++i) { bbn.mn[i] = p2.render_aabb_min[i]; bbn.mx[i] = p2.render_aabb_max[i]; }
-			const bool okn = have && box_contains(bbn, pn) && box_contains(m2.occ.box, pn);
-			const uint32_t mipn = max(p2.min_mip, (uint32_t)mip_from_dt(calc_dt(tn, p2.cone_angle_constant), pn));
-			const uint32_t idxn = occupancy_bit_index(pn, mipn, sm.coarse);
-			pre_bit = idxn & 31u;
-			pre_word = okn ? reinterpret_cast<const uint32_t*>(m2.bitfield)[idxn >> 5] : 0u;
-		}
-#endif
 		NRS_PHASE(3); // gather
 		// ---- gather: own sample (block g) and the partner lane's sample (block 1-g), levels 2*it+g ----
 #if NRS_MEASURE == 3
@@ -1020,11 +999,8 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 #if NRS_MEASURE == 5
 				{ float t2 = t; asm volatile("" : "+v"(t2)); f3 np2; float nd2; const bool v2 = march_to_occupied(p3, m3, sm.coarse, o, d, t2, np2, nd2, nullptr); asm volatile("" :: "v"(t2), "s"((int)__ballot(v2))); }
 #endif
-#if NRS_OCC_PREFETCH
-				if (!((pre_word >> pre_bit) & 1u))
-#endif
-				{ done = !march_to_occupied<true>(p3, m3, sm.coarse, o, d, t, npos, ndt, PROF ? &it_march : nullptr);
-				exited = done; }
+				done = !march_to_occupied<true>(p3, m3, sm.coarse, o, d, t, npos, ndt, PROF ? &it_march : nullptr);
+				exited = done;
 			}
 			if (done) {
 				if (shade && ca > 0.001f) { // compact_kernel_nerf's hit test (tn:2503) + shade_kernel_nerf (tn:2448-2483)
