@@ -49,6 +49,17 @@ def inputs():
     return {k: np.ascontiguousarray(v) for k, v in a.items()}
 
 
+def redump_with_nlohmann(raw):
+    """bytes of a JSON file -> the bytes nlohmann/json 3.1.1 writes for the same value tree (`f << j << std::endl`), through oracle/_ref/json_redump"""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        a, b = os.path.join(d, "a.json"), os.path.join(d, "b.json")
+        open(a, "wb").write(raw)
+        subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "json_redump"), a, b])
+        return open(b, "rb").read()
+
+
 def write_with_reference(path, a):
     from oracle import ref_json
     from nerfshop_amd import _abi
@@ -76,3 +87,12 @@ if __name__ == "__main__":
         f.write(raw)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_edits_golden.npz"), **a)
     print("wrote", out, len(raw), "->", os.path.getsize(out), "bytes")
+    # the same value tree as the REAL nlohmann/json prints it (oracle/ref_json_redump.cpp: this image's 3.1.1 reads the file above and writes it back the way
+    # Testbed::save_edits does -- shortest round-trip floats instead of the stand-in's 17 digits)
+    redump = os.path.join(ROOT, "oracle", "_ref", "json_redump")
+    if os.path.exists(redump):
+        raw2 = redump_with_nlohmann(raw)
+        out2 = os.path.join(ROOT, "tests", "golden", "ref_edits_golden_nlohmann.json.gz")
+        with gzip.GzipFile(out2, "wb", mtime=0) as f:
+            f.write(raw2)
+        print("wrote", out2, len(raw2), "->", os.path.getsize(out2), "bytes")

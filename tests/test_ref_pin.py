@@ -236,6 +236,59 @@ def test_edits_reader_golden(built, tmp_path):
     _check_edits_against(formats.load_edits(path), np.load(os.path.join(gdir, "ref_edits_golden.npz")))
 
 
+def test_edits_reader_golden_in_nlohmann_text(built, tmp_path):
+    """The same value tree as the REAL nlohmann/json prints it (tests/golden/ref_edits_golden_nlohmann.json.gz: the file above read and written back by this image's
+    nlohmann/json 3.1.1 the way Testbed::save_edits / load_edits do, oracle/ref_json_redump.cpp) -- shortest round-trip floats where the stand-in the reference's
+    to_json code was compiled against prints 17 digits: nrs_edits_open returns the same arrays, bit for bit."""
+    import gzip
+    import json
+    from nerfshop_amd import formats
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    raw = gzip.open(os.path.join(gdir, "ref_edits_golden_nlohmann.json.gz"), "rb").read()
+    standin = gzip.open(os.path.join(gdir, "ref_edits_golden.json.gz"), "rb").read()
+    assert raw != standin and len(raw) < len(standin) and json.loads(raw) == json.loads(standin)  # another text, the same doubles
+    assert b"0.712745189666748," in raw and b"0.71274518966674805," in standin  # (the first float of the file, both ways)
+    path = tmp_path / "ref_edits_nlohmann.json"
+    path.write_bytes(raw)
+    _check_edits_against(formats.load_edits(path), np.load(os.path.join(gdir, "ref_edits_golden.npz")))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref", "json_redump")),
+                    reason="oracle/_ref/json_redump is needed (make -C oracle where /opt/conda/include/json.hpp exists)")
+def test_nlohmann_golden_is_what_the_library_writes_live():
+    """The committed nlohmann-text golden is what the real library writes NOW from the stand-in's golden, and a second pass through the library is a fixed point."""
+    import gzip
+    import importlib.util
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_ref_edits_golden", os.path.join(gdir, "make_ref_edits_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    raw = mk.redump_with_nlohmann(gzip.open(os.path.join(gdir, "ref_edits_golden.json.gz"), "rb").read())
+    assert raw == gzip.open(os.path.join(gdir, "ref_edits_golden_nlohmann.json.gz"), "rb").read()
+    assert mk.redump_with_nlohmann(raw) == raw
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref", "json_redump")),
+                    reason="oracle/_ref/json_redump is needed (make -C oracle where /opt/conda/include/json.hpp exists)")
+def test_harness_writer_is_parsed_by_nlohmann_live(built, tmp_path):
+    """The other direction: the real library's parser accepts a file of the harness's own writer (nerfshop_amd/formats.py), and its own print of what it parsed is
+    read by nrs_edits_open as the same arrays."""
+    import importlib.util
+    from nerfshop_amd import formats, synth
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_ref_edits_golden", os.path.join(gdir, "make_ref_edits_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    edit = synth.make_cage_edit(lattice_n=3)
+    mine, back = tmp_path / "mine.json", tmp_path / "through_nlohmann.json"
+    formats.save_edits(mine, [edit])
+    back.write_bytes(mk.redump_with_nlohmann(mine.read_bytes()))
+    a, b = formats.load_edits(mine), formats.load_edits(back)
+    for name in ("vertices", "original_vertices", "tets", "mvc_weights", "cage_deformed", "cage_vertices", "cage_triangles"):
+        x, y = getattr(a[0], name), getattr(b[0], name)
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)) and np.array_equal(x, getattr(edit, name)), name
+
+
 # (the library travels with the repo snapshot to boxes where /root/reference does not exist; the live tests also read the reference's configs/nerf/ there)
 ref_json_live = pytest.mark.skipif(not (os.path.exists(os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref", "libref_json.so")) and
                                         os.path.isdir("/root/reference/configs/nerf")),
