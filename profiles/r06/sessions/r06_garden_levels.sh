@@ -1,6 +1,6 @@
 #!/bin/bash
 # the L2 misses of the garden frame attributed level pair by level pair.  For each mask a rocprofv3 PMC pass (TCC hit / miss / req) over a short
-# bench run of garden_cage_records64 (64 GiB of brick records: levels 8..11) with NRS_SKIP_PAIRS=mask (level pairs that are not gathered at all: nrs_mlp.cuh KIND_SKIP).  usage: tools/r06_garden_levels.sh <out dir> [masks...]
+# bench run of garden_cage_records64 (64 GiB of brick records: levels 8..11) with NRS_SKIP_PAIRS=mask (level pairs that are not gathered at all: nrs_mlp.cuh KIND_SKIP).  usage: profiles/r06/sessions/r06_garden_levels.sh <out dir> [masks...]
 export NRS_DEV_KNOBS=1
 R=$GRAFT_REPO_ROOT
 OUT=$1; shift

@@ -23,7 +23,7 @@ done
 cat $OUT/policy_time.jsonl $OUT/policy_pmc.jsonl
 # --- garden: misses per level pair
 cd $R
-bash tools/r06_garden_levels.sh $OUT
+bash profiles/r06/sessions/r06_garden_levels.sh $OUT
 # --- garden: the record budget curve (no profiler)
 for GB in 0 4 8 16 24 32 48 64; do
   L=$(NRS_SPARSE_GB=$GB python bench.py --workload garden_cage --steps 16 --warmup 3 --no-cpu-baseline --no-extra 2>/dev/null | tail -1)
