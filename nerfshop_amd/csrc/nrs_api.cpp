@@ -116,6 +116,7 @@ struct nrs_edit {
 	float* d_planes = nullptr;         // == de.planes, [T x 32] one 128-byte record per tet (tet_planes_kernel), follows the deformed vertices
 	uint32_t* d_counts = nullptr;      // [5*128^3], all zero between builds
 	uint32_t* d_tile_sums = nullptr;
+	unsigned long long* d_hit_masks = nullptr; // per (tet, cascade): the count pass's first 64 cell / tet tests, reused by the fill pass (nrs_cage.hip tet_mark_kernel)
 	uint32_t* d_scratch = nullptr;     // [0..5] bbox (float bits), [6] total entries, [7] max tets per cell, [8] long-list counter
 	uint32_t* d_big_cells = nullptr;   // worklist of cells with long tet lists (sized with d_lut_idx)
 	float* d_mvc = nullptr;            // [V x n_cv] weights
@@ -1009,6 +1010,7 @@ static int ensure_build_scratch(nrs_edit* e) {
 		HIP_TRY(hipMemset(e->d_counts, 0, n_cells * 4));
 	}
 	if (!e->d_tile_sums) HIP_TRY(hipMalloc((void**)&e->d_tile_sums, kLutScanTiles * 4));
+	if (!e->d_hit_masks) HIP_TRY(hipMalloc((void**)&e->d_hit_masks, (size_t)e->n_tets * kCascades * 8));
 	if (!e->d_scratch) HIP_TRY(hipMalloc((void**)&e->d_scratch, 64));
 	return NRS_OK;
 }
@@ -1016,7 +1018,15 @@ static int ensure_build_scratch(nrs_edit* e) {
 // Synchronises the stream once (the entry count decides the idx allocation), like the reference's host builder does.
 static int build_lut_on_device(nrs_edit* e, const float* d_verts, uint8_t* d_bitfield_out, hipStream_t s) {
 	NRS_TRY(ensure_build_scratch(e));
-	CAGE_TRY(launch_lut_count_scan(e->n_tets, d_verts, e->de.tets, e->d_counts, e->d_tile_sums, e->d_lut_off, e->d_scratch + 6, s));
+	// cells of cascade 0 in an average tet's bounding box, from the mesh's box and tet count (six tets share a lattice cube's box): only the kernels' team size hangs on it
+	float cells0 = 0.f;
+	{
+		const Box3& bb = e->de.bbox;
+		const double vol = (double)std::max(bb.mx[0] - bb.mn[0], 0.f) * std::max(bb.mx[1] - bb.mn[1], 0.f) * std::max(bb.mx[2] - bb.mn[2], 0.f);
+		const double side = std::cbrt(vol / std::max<double>(e->n_tets / 6.0, 1.0)) * kGrid;
+		cells0 = (float)((side + 1.0) * (side + 1.0) * (side + 1.0));
+	}
+	CAGE_TRY(launch_lut_count_scan(e->n_tets, d_verts, e->de.tets, e->d_counts, e->d_tile_sums, e->d_lut_off, e->d_scratch + 6, e->d_hit_masks, cells0, s));
 	uint32_t total = 0;
 	HIP_TRY(hipMemcpyAsync(&total, e->d_scratch + 6, 4, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
@@ -1032,7 +1042,7 @@ static int build_lut_on_device(nrs_edit* e, const float* d_verts, uint8_t* d_bit
 		e->lut_idx_cap = cap;
 		e->de.lut_idx = fresh;
 	}
-	CAGE_TRY(launch_lut_fill(e->n_tets, d_verts, e->de.tets, e->d_counts, e->d_lut_off, e->d_lut_idx, d_bitfield_out, e->d_scratch + 7, e->d_big_cells, s));
+	CAGE_TRY(launch_lut_fill(e->n_tets, d_verts, e->de.tets, e->d_counts, e->d_lut_off, e->d_lut_idx, d_bitfield_out, e->d_scratch + 7, e->d_big_cells, e->d_hit_masks, cells0, s));
 	e->lut_n_idx = total;
 	return NRS_OK;
 }
@@ -1306,7 +1316,7 @@ void nrs_edit_destroy(nrs_edit* e) {
 	if (!e) return;
 	for (void* p : e->allocs) (void)hipFree(p);
 	(void)hipFree(e->d_verts); (void)hipFree(e->d_lut_off); (void)hipFree(e->d_lut_idx); (void)hipFree(e->d_rot); (void)hipFree(e->d_planes);
-	(void)hipFree(e->d_big_cells); (void)hipFree(e->d_counts); (void)hipFree(e->d_tile_sums); (void)hipFree(e->d_scratch); (void)hipFree(e->d_mvc); (void)hipFree(e->d_cage);
+	(void)hipFree(e->d_big_cells); (void)hipFree(e->d_counts); (void)hipFree(e->d_tile_sums); (void)hipFree(e->d_hit_masks); (void)hipFree(e->d_scratch); (void)hipFree(e->d_mvc); (void)hipFree(e->d_cage);
 	(void)hipFree(e->d_fine_off); (void)hipFree(e->d_fine_counts); (void)hipFree(e->d_fine_idx); (void)hipFree(e->d_fine_tiles); (void)hipFree(e->d_fine_win);
 	delete e;
 }

@@ -99,22 +99,28 @@ __global__ void bbox_kernel(uint32_t n, const float* __restrict__ v, float* __re
 
 // ---- cell / tet intersection tests of build_tet_grid (tet_mesh.cu:402-470) -------------------------------------------------
 __device__ __forceinline__ float comp3(const f3& p, int i) { return i == 0 ? p.x : (i == 1 ? p.y : p.z); }
-__device__ __forceinline__ void span3(const f3* pts, int n, f3 axis, float& lo, float& hi) {
+// (round 6: everything below is inlined and fully unrolled -- the point lists are compile-time sized, so the corner / vertex arrays live in registers instead of the
+// 12 KiB of LDS the compiler parked them in, and the per-face normals of the eight point-in-tet tests are computed once: same operations on the same operands in
+// the same order, a cell / tet test ~4 x shorter; the LUT pass of a cage move is a chain of such tests.  -ffp-contract=off: unrolling fuses nothing.)
+template <int N>
+__device__ __forceinline__ void span3(const f3 (&pts)[N], f3 axis, float& lo, float& hi) {
 	lo = __builtin_huge_valf();
 	hi = -lo;
-	for (int i = 0; i < n; ++i) {
+	#pragma unroll
+	for (int i = 0; i < N; ++i) {
 		const float v = dot3(axis, pts[i]);
 		if (v < lo) lo = v;
 		if (v > hi) hi = v;
 	}
 }
 // BoundingBox::intersects(Triangle), bounding_box.cuh:126-178: separating axes = 3 box normals, the triangle normal, 9 edge x axis
-__device__ bool cube_hits_triangle(f3 bmin, f3 bmax, f3 a, f3 b, f3 c) {
+__device__ __forceinline__ bool cube_hits_triangle(f3 bmin, f3 bmax, f3 a, f3 b, f3 c) {
 	const f3 axes[3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
 	const f3 tri[3] = {a, b, c};
 	float tlo, thi, blo, bhi;
+	#pragma unroll
 	for (int i = 0; i < 3; ++i) {
-		span3(tri, 3, axes[i], tlo, thi);
+		span3(tri, axes[i], tlo, thi);
 		if (thi < comp3(bmin, i) || tlo > comp3(bmax, i)) return false;
 	}
 	f3 n = cross3(b - a, c - a);
@@ -123,16 +129,19 @@ __device__ bool cube_hits_triangle(f3 bmin, f3 bmax, f3 a, f3 b, f3 c) {
 	const f3 corners[8] = {{bmin.x, bmin.y, bmin.z}, {bmin.x, bmin.y, bmax.z}, {bmin.x, bmax.y, bmin.z}, {bmin.x, bmax.y, bmax.z},
 	                       {bmax.x, bmin.y, bmin.z}, {bmax.x, bmin.y, bmax.z}, {bmax.x, bmax.y, bmin.z}, {bmax.x, bmax.y, bmax.z}};
 	const float off = dot3(n, a);
-	span3(corners, 8, n, blo, bhi);
+	span3(corners, n, blo, bhi);
 	if (bhi < off || blo > off) return false;
 	const f3 edges[3] = {a - b, a - c, b - c};
-	for (int i = 0; i < 3; ++i)
+	#pragma unroll
+	for (int i = 0; i < 3; ++i) {
+		#pragma unroll
 		for (int j = 0; j < 3; ++j) {
 			const f3 ax = cross3(edges[i], axes[j]);
-			span3(corners, 8, ax, blo, bhi);
-			span3(tri, 3, ax, tlo, thi);
+			span3(corners, ax, blo, bhi);
+			span3(tri, ax, tlo, thi);
 			if (bhi < tlo || blo > thi) return false;
 		}
+	}
 	return true;
 }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t)(127 + e) << 23); } // scalbnf(1, e), |e| <= 4
@@ -150,50 +159,109 @@ __device__ __forceinline__ f3 cell_centre(uint32_t x, uint32_t y, uint32_t z, ui
 	return {(((float)x + 0.5f) / (float)kGrid - 0.5f) * s + 0.5f, (((float)y + 0.5f) / (float)kGrid - 0.5f) * s + 0.5f,
 	        (((float)z + 0.5f) / (float)kGrid - 0.5f) * s + 0.5f};
 }
-__device__ bool cell_meets_tet(const f3 tv[4], uint32_t x, uint32_t y, uint32_t z, uint32_t level) {
+__device__ __forceinline__ bool cell_meets_tet(f3 t0, f3 t1, f3 t2, f3 t3, uint32_t x, uint32_t y, uint32_t z, uint32_t level) { // (four values, not an array: an indexed private array is parked in LDS)
 	const float kC[8][3] = {{-0.5f, -0.5f, -0.5f}, {-0.5f, -0.5f, 0.5f}, {-0.5f, 0.5f, -0.5f}, {0.5f, -0.5f, -0.5f},
 	                        {0.5f, 0.5f, -0.5f}, {-0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.5f, 0.5f, 0.5f}}; // tet_mesh.h:34-43
 	const float cell = pow2f((int)level) * (1.0f / (float)kGrid);
 	const f3 ctr = cell_centre(x, y, z, level);
+	#pragma unroll
 	for (int k = 0; k < 8; ++k)
-		if (point_in_tet(tv[0], tv[1], tv[2], tv[3], ctr + mk3(kC[k][0], kC[k][1], kC[k][2]) * cell)) return true;
+		if (point_in_tet(t0, t1, t2, t3, ctr + mk3(kC[k][0], kC[k][1], kC[k][2]) * cell)) return true;
 	const f3 h = mk3(0.5f, 0.5f, 0.5f) * cell;
 	const f3 a = ctr - h, b = ctr + h;
 	const f3 bmin = {fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)};
 	const f3 bmax = {fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)};
-	for (int j = 0; j < 4; ++j)
-		if (cube_hits_triangle(bmin, bmax, tv[j], tv[(j + 1) & 3], tv[(j + 2) & 3])) return true;
+	// faces (j, j + 1, j + 2) mod 4, j = 0..3 (tet_mesh.cu:441-452)
+	if (cube_hits_triangle(bmin, bmax, t0, t1, t2)) return true;
+	if (cube_hits_triangle(bmin, bmax, t1, t2, t3)) return true;
+	if (cube_hits_triangle(bmin, bmax, t2, t3, t0)) return true;
+	if (cube_hits_triangle(bmin, bmax, t3, t0, t1)) return true;
 	return false;
 }
 
-// One wave per (tet, cascade); lanes stride over the cells of the tet's bounding box at that cascade.
-// FILL == false: counts[cell] += 1.   FILL == true: idx[offsets[cell] + --counts[cell]] = tet (leaves counts zeroed).
-template <bool FILL>
-__global__ __launch_bounds__(256) void tet_mark_kernel(uint32_t n_tets, const float* __restrict__ verts, const uint32_t* __restrict__ tets,
+// T lanes per (tet, cascade) item, 64 / T items per wave; a team strides over the cells of its tet's bounding box at that cascade.  Items are numbered cascade-major
+// (item = cascade * n_tets + tet) and a launch covers the items [item_begin, item_end) of ONE team size (launch_tet_mark chooses: 64 / 8 / 1).  Round 6 (profiles/r06/cage_move_kernels.md): one WAVE per item left 56-63 lanes
+// idle, and in the coarse cascades -- where the whole mesh stands in a handful of cells -- every item's atomic went to the same address (6 000 serialised atomics per
+// cascade and pass: that, not the tests, was the pass's time); now the hits of a wave that fall into its first hit's cell share ONE atomic.
+// FILL == false: counts[cell] += 1, and the item's first 64 test results go to hit_masks[item] (bit k = cell k of the box).
+// FILL == true: idx[offsets[cell] + --counts[cell]] = tet (leaves counts zeroed; the order inside a list is free: lut_finish_kernel sorts); the first 64 cells take the
+// count pass's answers instead of repeating cell_meets_tet (8 point-in-tet + 4 box / triangle tests per cell).
+template <bool FILL, int T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void tet_mark_kernel(uint32_t n_tets, uint32_t item_begin, uint32_t item_end, const float* __restrict__ verts, const uint32_t* __restrict__ tets,
                                                         uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                                        uint32_t* __restrict__ idx) {
-	const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63;
-	if (w >= n_tets * kCascades) return;
-	const uint32_t t = w / kCascades, level = w % kCascades;
+                                                        uint32_t* __restrict__ idx, unsigned long long* __restrict__ hit_masks) {
+	const uint32_t wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63, sub = lane / T, r = lane % T;
+	const uint32_t item = item_begin + wv * (64 / T) + (uint32_t)sub;
+	const bool live = item < item_end;
+	const uint32_t level = live ? item / n_tets : 0u, t = live ? item % n_tets : 0u;
 	const uint4 tvid = reinterpret_cast<const uint4*>(tets)[t];
-	const f3 tv[4] = {ld3(verts, tvid.x), ld3(verts, tvid.y), ld3(verts, tvid.z), ld3(verts, tvid.w)};
-	f3 lo = tv[0], hi = tv[0];
-	for (int j = 1; j < 4; ++j) {
-		lo = {fminf(lo.x, tv[j].x), fminf(lo.y, tv[j].y), fminf(lo.z, tv[j].z)};
-		hi = {fmaxf(hi.x, tv[j].x), fmaxf(hi.y, tv[j].y), fmaxf(hi.z, tv[j].z)};
-	}
+	const f3 t0 = ld3(verts, tvid.x), t1 = ld3(verts, tvid.y), t2 = ld3(verts, tvid.z), t3 = ld3(verts, tvid.w);
+	f3 lo = t0, hi = t0;
+	lo = {fminf(lo.x, t1.x), fminf(lo.y, t1.y), fminf(lo.z, t1.z)}; hi = {fmaxf(hi.x, t1.x), fmaxf(hi.y, t1.y), fmaxf(hi.z, t1.z)};
+	lo = {fminf(lo.x, t2.x), fminf(lo.y, t2.y), fminf(lo.z, t2.z)}; hi = {fmaxf(hi.x, t2.x), fmaxf(hi.y, t2.y), fmaxf(hi.z, t2.z)};
+	lo = {fminf(lo.x, t3.x), fminf(lo.y, t3.y), fminf(lo.z, t3.z)}; hi = {fmaxf(hi.x, t3.x), fmaxf(hi.y, t3.y), fmaxf(hi.z, t3.z)};
 	int c0[3], c1[3];
 	cell_of(lo, level, c0);
 	cell_of(hi, level, c1);
 	const uint32_t ny = (uint32_t)(c1[1] - c0[1] + 1), nz = (uint32_t)(c1[2] - c0[2] + 1);
-	const uint32_t total = (uint32_t)(c1[0] - c0[0] + 1) * ny * nz;
-	for (uint32_t k = (uint32_t)lane; k < total; k += 64) {
+	const uint32_t total = live ? (uint32_t)(c1[0] - c0[0] + 1) * ny * nz : 0u;
+	unsigned long long mask = (FILL && live) ? hit_masks[item] : 0ull;
+	for (uint32_t it = 0;; ++it) { // (wave-uniform trip count: the longest box of the wave's items)
+		const uint32_t k = it * T + (uint32_t)r;
+		const bool in = k < total;
+		if (!__any(in)) break;
 		const uint32_t x = (uint32_t)c0[0] + k / (ny * nz), y = (uint32_t)c0[1] + (k / nz) % ny, z = (uint32_t)c0[2] + k % nz;
-		if (!cell_meets_tet(tv, x, y, z, level)) continue;
+		bool hit = false;
+		if (in) hit = (FILL && k < 64u) ? ((mask >> k) & 1ull) != 0ull : cell_meets_tet(t0, t1, t2, t3, x, y, z, level);
+		const unsigned long long votes = __ballot(hit);
+		if (!FILL && it < 64u / T) mask |= ((votes >> (sub * T)) & ((T == 64 ? 0ull : (1ull << T)) - 1ull)) << (it * T);
+		if (votes == 0ull) continue;
+		// the hits that stand in the wave's first hit's cell take one atomic together; the others their own
 		const uint32_t cell = level * kGridVol + morton3D(x, y, z);
-		if (!FILL) atomicAdd(counts + cell, 1u);
-		else idx[offsets[cell] + (atomicSub(counts + cell, 1u) - 1u)] = t;
+		const int leader = __ffsll((long long)votes) - 1;
+		const uint32_t lead_cell = (uint32_t)__shfl((int)cell, leader, 64);
+		const bool grouped = hit && cell == lead_cell;
+		const unsigned long long group = __ballot(grouped);
+		const uint32_t n_group = (uint32_t)__popcll(group);
+		uint32_t base = 0;
+		if (lane == leader) {
+			if (!FILL) atomicAdd(counts + lead_cell, n_group);
+			else base = atomicSub(counts + lead_cell, n_group);
+		}
+		if (FILL) {
+			base = (uint32_t)__shfl((int)base, leader, 64);
+			const uint32_t rank = (uint32_t)__popcll(group & ((1ull << lane) - 1ull));
+			if (grouped) idx[offsets[cell] + (base - 1u - rank)] = t;
+		}
+		if (hit && !grouped) {
+			if (!FILL) atomicAdd(counts + cell, 1u);
+			else idx[offsets[cell] + (atomicSub(counts + cell, 1u) - 1u)] = t;
+		}
+	}
+	if (!FILL && live && r == 0) hit_masks[item] = mask;
+}
+template <bool FILL, int T>
+static void launch_tet_mark_range(uint32_t n_tets, uint32_t item_begin, uint32_t item_end, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, const uint32_t* d_offsets,
+                                  uint32_t* d_idx, unsigned long long* d_hit_masks, hipStream_t s) {
+	const uint32_t waves = (item_end - item_begin + 64 / T - 1) / (64 / T);
+	hipLaunchKernelGGL((tet_mark_kernel<FILL, T>), dim3((waves + 3) / 4), dim3(256), 0, s, n_tets, item_begin, item_end, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks);
+}
+// Team sizes per cascade.  A small mesh (a pass is as long as its longest wave: the GPU is not full) takes the widest teams its boxes fill -- a wave per item at cascade 0
+// when a tet's box there holds >= 32 cells (`cells0`: the caller's estimate from the mesh's bounding box and tet count), eight lanes elsewhere; a large mesh (throughput)
+// eight lanes at the two finest cascades and one lane per item at the coarse ones, where a tet touches one or two cells.
+template <bool FILL>
+static void launch_tet_mark(uint32_t n_tets, float cells0, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, const uint32_t* d_offsets, uint32_t* d_idx,
+                            unsigned long long* d_hit_masks, hipStream_t s) {
+	const bool small = n_tets <= 16384u;
+	const uint32_t n = n_tets;
+	if (small && cells0 >= 32.f) launch_tet_mark_range<FILL, 64>(n, 0u, n, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks, s);
+	else launch_tet_mark_range<FILL, 8>(n, 0u, n, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks, s);
+	if (small) {
+		launch_tet_mark_range<FILL, 8>(n, n, n * kCascades, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks, s);
+	} else {
+		launch_tet_mark_range<FILL, 8>(n, n, 2u * n, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks, s);
+		launch_tet_mark_range<FILL, 1>(n, 2u * n, n * kCascades, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks, s);
 	}
 }
 
@@ -281,29 +349,39 @@ constexpr uint32_t kSmallList = 24;
 __global__ __launch_bounds__(256) void lut_finish_kernel(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx,
                                                           uint8_t* __restrict__ bitfield, uint32_t* __restrict__ max_per_cell,
                                                           uint32_t* __restrict__ big_cells, uint32_t* __restrict__ n_big) {
-	const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; // kCells / 8 bytes, grid sized exactly
-	uint32_t o[9];
-	#pragma unroll
-	for (int q = 0; q < 9; ++q) o[q] = offsets[(size_t)b * 8 + q];
-	uint32_t bits = 0, mx = 0;
-	if (o[8] != o[0]) {
-		for (int q = 0; q < 8; ++q) {
-			const uint32_t n = o[q + 1] - o[q];
-			if (n == 0) continue;
-			bits |= 1u << q;
-			mx = max(mx, n);
-			if (n > kSmallList) { big_cells[atomicAdd(n_big, 1u)] = b * 8 + q; continue; }
-			uint32_t* a = idx + o[q];
-			for (uint32_t i = 1; i < n; ++i) {
-				const uint32_t key = a[i];
-				uint32_t j = i;
-				while (j > 0 && a[j - 1] > key) { a[j] = a[j - 1]; --j; }
-				a[j] = key;
-			}
+	// (round 6: one thread per CELL, not per byte of eight cells -- the kernel is as slow as its slowest thread, and that thread's work is a chain of dependent
+	// memory trips; the list is fetched eight entries per trip into a per-thread row of LDS, sorted there and written back; the maximum is reduced per wave --
+	// one atomicMax per non-empty cell was ~10^5 atomics on ONE address per cage move.  0.40 -> 0.0x ms per move: profiles/r06/cage_move_kernels.md)
+	__shared__ uint32_t rows[256][kSmallList + 1]; // (+1: consecutive threads' rows start in consecutive banks)
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; // kCells threads, grid sized exactly
+	const uint32_t o0 = offsets[c], n = offsets[c + 1] - o0;
+	if (n > kSmallList) {
+		big_cells[atomicAdd(n_big, 1u)] = c;
+	} else if (n > 1) {
+		uint32_t* row = rows[threadIdx.x];
+		uint32_t* a = idx + o0;
+		for (uint32_t i = 0; i < n; i += 8) { // (eight independent loads per trip; indices clamped, the surplus is not stored)
+			uint32_t v[8];
+			#pragma unroll
+			for (uint32_t q = 0; q < 8; ++q) v[q] = a[min(i + q, n - 1u)];
+			#pragma unroll
+			for (uint32_t q = 0; q < 8; ++q) if (i + q < n) row[i + q] = v[q];
 		}
+		for (uint32_t i = 1; i < n; ++i) {
+			const uint32_t key = row[i];
+			uint32_t j = i;
+			while (j > 0 && row[j - 1] > key) { row[j] = row[j - 1]; --j; }
+			row[j] = key;
+		}
+		for (uint32_t i = 0; i < n; ++i) a[i] = row[i];
 	}
-	if (bitfield) bitfield[b] = (uint8_t)bits;
-	if (mx) atomicMax(max_per_cell, mx);
+	if (bitfield) { // the touched-cell byte of eight consecutive cells: their lanes' votes
+		const unsigned long long votes = __ballot(n != 0u);
+		if ((threadIdx.x & 7u) == 0u) bitfield[c >> 3] = (uint8_t)((votes >> (threadIdx.x & 63u)) & 0xffull);
+	}
+	uint32_t mx = n;
+	for (int sh = 32; sh > 0; sh >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, sh, 64));
+	if ((threadIdx.x & 63) == 0 && mx) atomicMax(max_per_cell, mx);
 }
 
 // Normalised bitonic network (every comparator puts the smaller key at the lower index): valid for any n, because the
@@ -545,11 +623,9 @@ int launch_bbox(uint32_t n, const float* d_verts, float* d_out6, void* stream) {
 }
 // counts must be all zero on entry (it is again on exit of launch_lut_fill).  Writes offsets[kCells + 1] and *d_total.
 int launch_lut_count_scan(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, uint32_t* d_tile_sums,
-                          uint32_t* d_offsets, uint32_t* d_total, void* stream) {
+                          uint32_t* d_offsets, uint32_t* d_total, unsigned long long* d_hit_masks, float cells0, void* stream) {
 	hipStream_t s = (hipStream_t)stream;
-	const uint32_t n_waves = n_tets * kCascades;
-	hipLaunchKernelGGL(tet_mark_kernel<false>, dim3((n_waves + 3) / 4), dim3(256), 0, s, n_tets, d_verts, d_tets, d_counts, (const uint32_t*)nullptr,
-	                   (uint32_t*)nullptr);
+	launch_tet_mark<false>(n_tets, cells0, d_verts, d_tets, d_counts, nullptr, nullptr, d_hit_masks, s);
 	hipLaunchKernelGGL(scan_tile_sum_kernel, dim3(kScanTiles), dim3(256), 0, s, d_counts, d_tile_sums);
 	hipLaunchKernelGGL(scan_tile_prefix_kernel, dim3(1), dim3(1024), 0, s, d_tile_sums, d_offsets + kCells, d_total, kScanTiles);
 	hipLaunchKernelGGL(scan_write_kernel, dim3(kScanTiles), dim3(256), 0, s, d_counts, d_tile_sums, d_offsets);
@@ -559,12 +635,11 @@ int launch_lut_count_scan(uint32_t n_tets, const float* d_verts, const uint32_t*
 // d_scratch_u32[0] = max tets per cell (out), [1] = big-cell counter; both zeroed here.  d_bitfield may be NULL.
 // d_big_cells: worklist of at least (entries / kSmallList + 1) cells.
 int launch_lut_fill(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, const uint32_t* d_offsets, uint32_t* d_idx,
-                    uint8_t* d_bitfield, uint32_t* d_scratch_u32, uint32_t* d_big_cells, void* stream) {
+                    uint8_t* d_bitfield, uint32_t* d_scratch_u32, uint32_t* d_big_cells, unsigned long long* d_hit_masks, float cells0, void* stream) {
 	hipStream_t s = (hipStream_t)stream;
-	const uint32_t n_waves = n_tets * kCascades;
 	if (hipMemsetAsync(d_scratch_u32, 0, 8, s) != hipSuccess) { snprintf(g_cage_err, sizeof(g_cage_err), "tet LUT fill: memset failed"); return NRS_ERR_HIP; }
-	hipLaunchKernelGGL(tet_mark_kernel<true>, dim3((n_waves + 3) / 4), dim3(256), 0, s, n_tets, d_verts, d_tets, d_counts, d_offsets, d_idx);
-	hipLaunchKernelGGL(lut_finish_kernel, dim3(kCells / 8 / 256), dim3(256), 0, s, d_offsets, d_idx, d_bitfield, d_scratch_u32, d_big_cells,
+	launch_tet_mark<true>(n_tets, cells0, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks, s);
+	hipLaunchKernelGGL(lut_finish_kernel, dim3(kCells / 256), dim3(256), 0, s, d_offsets, d_idx, d_bitfield, d_scratch_u32, d_big_cells,
 	                   d_scratch_u32 + 1);
 	hipLaunchKernelGGL(lut_sort_big_kernel, dim3(512), dim3(1024), 0, s, d_offsets, d_idx, d_big_cells, d_scratch_u32 + 1);
 	NRS_CAGE_CHECK("tet LUT fill launch");
