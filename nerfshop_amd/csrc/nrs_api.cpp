@@ -116,7 +116,7 @@ struct nrs_edit {
 	float* d_planes = nullptr;         // == de.planes, [T x 32] one 128-byte record per tet (tet_planes_kernel), follows the deformed vertices
 	uint32_t* d_counts = nullptr;      // [5*128^3], all zero between builds
 	uint32_t* d_tile_sums = nullptr;
-	unsigned long long* d_hit_masks = nullptr; // per (tet, cascade): the count pass's first 64 cell / tet tests, reused by the fill pass (nrs_cage.hip tet_mark_kernel)
+	unsigned long long* d_hit_masks = nullptr; // per (tet, cascade): the count pass's first 128 cell / tet tests (two words per item), reused by the fill pass (nrs_cage.hip tet_mark_kernel)
 	uint32_t* d_scratch = nullptr;     // [0..5] bbox (float bits), [6] total entries, [7] max tets per cell, [8] long-list counter
 	uint32_t* d_big_cells = nullptr;   // worklist of cells with long tet lists (sized with d_lut_idx)
 	float* d_mvc = nullptr;            // [V x n_cv] weights
@@ -1010,7 +1010,7 @@ static int ensure_build_scratch(nrs_edit* e) {
 		HIP_TRY(hipMemset(e->d_counts, 0, n_cells * 4));
 	}
 	if (!e->d_tile_sums) HIP_TRY(hipMalloc((void**)&e->d_tile_sums, kLutScanTiles * 4));
-	if (!e->d_hit_masks) HIP_TRY(hipMalloc((void**)&e->d_hit_masks, (size_t)e->n_tets * kCascades * 8));
+	if (!e->d_hit_masks) HIP_TRY(hipMalloc((void**)&e->d_hit_masks, (size_t)e->n_tets * kCascades * 16));
 	if (!e->d_scratch) HIP_TRY(hipMalloc((void**)&e->d_scratch, 64));
 	return NRS_OK;
 }
@@ -1042,7 +1042,7 @@ static int build_lut_on_device(nrs_edit* e, const float* d_verts, uint8_t* d_bit
 		e->lut_idx_cap = cap;
 		e->de.lut_idx = fresh;
 	}
-	CAGE_TRY(launch_lut_fill(e->n_tets, d_verts, e->de.tets, e->d_counts, e->d_lut_off, e->d_lut_idx, d_bitfield_out, e->d_scratch + 7, e->d_big_cells, e->d_hit_masks, cells0, s));
+	CAGE_TRY(launch_lut_fill(e->n_tets, d_verts, e->de.tets, e->d_counts, e->d_lut_off, e->d_lut_idx, d_bitfield_out, e->d_scratch + 7, e->d_big_cells, lut_big_list_capacity(e->lut_idx_cap), e->d_hit_masks, cells0, s));
 	e->lut_n_idx = total;
 	return NRS_OK;
 }

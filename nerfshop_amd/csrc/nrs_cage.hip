@@ -183,8 +183,8 @@ __device__ __forceinline__ bool cell_meets_tet(f3 t0, f3 t1, f3 t2, f3 t3, uint3
 // (item = cascade * n_tets + tet) and a launch covers the items [item_begin, item_end) of ONE team size (launch_tet_mark chooses: 64 / 8 / 1).  Round 6 (profiles/r06/cage_move_kernels.md): one WAVE per item left 56-63 lanes
 // idle, and in the coarse cascades -- where the whole mesh stands in a handful of cells -- every item's atomic went to the same address (6 000 serialised atomics per
 // cascade and pass: that, not the tests, was the pass's time); now the hits of a wave that fall into its first hit's cell share ONE atomic.
-// FILL == false: counts[cell] += 1, and the item's first 64 test results go to hit_masks[item] (bit k = cell k of the box).
-// FILL == true: idx[offsets[cell] + --counts[cell]] = tet (leaves counts zeroed; the order inside a list is free: lut_finish_kernel sorts); the first 64 cells take the
+// FILL == false: counts[cell] += 1, and the item's first 128 test results go to hit_masks[2 item .. 2 item + 1] (bit k = cell k of the box).
+// FILL == true: idx[offsets[cell] + --counts[cell]] = tet (leaves counts zeroed; the order inside a list is free: lut_finish_kernel sorts); the first 128 cells take the
 // count pass's answers instead of repeating cell_meets_tet (8 point-in-tet + 4 box / triangle tests per cell).
 template <bool FILL, int T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void tet_mark_kernel(uint32_t n_tets, uint32_t item_begin, uint32_t item_end, const float* __restrict__ verts, const uint32_t* __restrict__ tets,
@@ -206,16 +206,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 	cell_of(hi, level, c1);
 	const uint32_t ny = (uint32_t)(c1[1] - c0[1] + 1), nz = (uint32_t)(c1[2] - c0[2] + 1);
 	const uint32_t total = live ? (uint32_t)(c1[0] - c0[0] + 1) * ny * nz : 0u;
-	unsigned long long mask = (FILL && live) ? hit_masks[item] : 0ull;
+	unsigned long long mask0 = (FILL && live) ? hit_masks[2 * (size_t)item] : 0ull, mask1 = (FILL && live) ? hit_masks[2 * (size_t)item + 1] : 0ull; // cells 0..63, 64..127 of the box
 	for (uint32_t it = 0;; ++it) { // (wave-uniform trip count: the longest box of the wave's items)
 		const uint32_t k = it * T + (uint32_t)r;
 		const bool in = k < total;
 		if (!__any(in)) break;
 		const uint32_t x = (uint32_t)c0[0] + k / (ny * nz), y = (uint32_t)c0[1] + (k / nz) % ny, z = (uint32_t)c0[2] + k % nz;
 		bool hit = false;
-		if (in) hit = (FILL && k < 64u) ? ((mask >> k) & 1ull) != 0ull : cell_meets_tet(t0, t1, t2, t3, x, y, z, level);
+		if (in) hit = (FILL && k < 128u) ? (((k < 64u ? mask0 : mask1) >> (k & 63u)) & 1ull) != 0ull : cell_meets_tet(t0, t1, t2, t3, x, y, z, level);
 		const unsigned long long votes = __ballot(hit);
-		if (!FILL && it < 64u / T) mask |= ((votes >> (sub * T)) & ((T == 64 ? 0ull : (1ull << T)) - 1ull)) << (it * T);
+		if (!FILL && it < 128u / T) { // (it is wave-uniform; a team's T votes of one trip never straddle the two words: T divides 64)
+			const unsigned long long mine = ((votes >> (sub * T)) & ((T == 64 ? 0ull : (1ull << T)) - 1ull)) << ((it * T) & 63u);
+			if (it * T < 64u) mask0 |= mine; else mask1 |= mine;
+		}
 		if (votes == 0ull) continue;
 		// the hits that stand in the wave's first hit's cell take one atomic together; the others their own
 		const uint32_t cell = level * kGridVol + morton3D(x, y, z);
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 			else idx[offsets[cell] + (atomicSub(counts + cell, 1u) - 1u)] = t;
 		}
 	}
-	if (!FILL && live && r == 0) hit_masks[item] = mask;
+	if (!FILL && live && r == 0) { hit_masks[2 * (size_t)item] = mask0; hit_masks[2 * (size_t)item + 1] = mask1; }
 }
 template <bool FILL, int T>
 static void launch_tet_mark_range(uint32_t n_tets, uint32_t item_begin, uint32_t item_end, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, const uint32_t* d_offsets,
@@ -346,17 +349,21 @@ __global__ __launch_bounds__(256) void scan_write_kernel(const uint32_t* __restr
 // Lists of up to kSmallList tets are sorted by the thread (insertion sort); longer ones -- the few coarse-cascade cells that
 // contain most of the mesh -- go to a worklist that lut_sort_big_kernel sorts with one workgroup each.
 constexpr uint32_t kSmallList = 24;
+constexpr uint32_t kMidList = 128; // lists of kSmallList + 1 .. kMidList tets: sorted by one wave in LDS (sixteen cells per workgroup at a time, no workgroup barrier); longer ones by a workgroup
+// (measured with 1024: the longest list of a wave sets the kernel's time, 0.10 ms per move)
 __global__ __launch_bounds__(256) void lut_finish_kernel(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx,
                                                           uint8_t* __restrict__ bitfield, uint32_t* __restrict__ max_per_cell,
-                                                          uint32_t* __restrict__ big_cells, uint32_t* __restrict__ n_big) {
+                                                          uint32_t* __restrict__ big_cells, uint32_t* __restrict__ n_big, uint32_t n_work) {
 	// (round 6: one thread per CELL, not per byte of eight cells -- the kernel is as slow as its slowest thread, and that thread's work is a chain of dependent
 	// memory trips; the list is fetched eight entries per trip into a per-thread row of LDS, sorted there and written back; the maximum is reduced per wave --
 	// one atomicMax per non-empty cell was ~10^5 atomics on ONE address per cage move.  0.40 -> 0.0x ms per move: profiles/r06/cage_move_kernels.md)
 	__shared__ uint32_t rows[256][kSmallList + 1]; // (+1: consecutive threads' rows start in consecutive banks)
 	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; // kCells threads, grid sized exactly
 	const uint32_t o0 = offsets[c], n = offsets[c + 1] - o0;
-	if (n > kSmallList) {
-		big_cells[atomicAdd(n_big, 1u)] = c;
+	if (n > kMidList) {
+		big_cells[atomicAdd(n_big, 1u)] = c;                      // a workgroup per cell (lut_sort_big_kernel): from the front of the worklist
+	} else if (n > kSmallList) {
+		big_cells[n_work - 1u - atomicAdd(n_big + 1, 1u)] = c;     // a wave per cell (lut_sort_mid_kernel): from its back (n_big[1] = their number)
 	} else if (n > 1) {
 		uint32_t* row = rows[threadIdx.x];
 		uint32_t* a = idx + o0;
@@ -405,22 +412,92 @@ __device__ __forceinline__ void bitonic_ascending(Ptr a, uint32_t n, uint32_t ti
 		}
 	}
 }
+// The same network run by ONE wave on an LDS array: the lanes of a wave execute in lockstep and a wave's LDS operations stay in order, so a step needs no
+// workgroup barrier -- only the compiler must not move one step's reads above the previous step's writes of other lanes (fences at wavefront scope).
+__device__ __forceinline__ void bitonic_ascending_wave(uint32_t* a, uint32_t n, uint32_t lane) {
+	uint32_t p2 = 1;
+	while (p2 < n) p2 <<= 1;
+	for (uint32_t k = 2; k <= p2; k <<= 1) {
+		for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+			const uint32_t mask = (j == (k >> 1)) ? (k - 1) : j;
+			for (uint32_t i = lane; i < p2; i += 64) {
+				const uint32_t l = i ^ mask;
+				if (l > i && l < n) {
+					const uint32_t x = a[i], y = a[l];
+					if (x > y) { a[i] = y; a[l] = x; }
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		}
+	}
+}
 constexpr uint32_t kSortLdsEntries = 16384; // 64 KiB of LDS per workgroup
+// the middle worklist (kSmallList < n <= kMidList; it grows from the BACK of big_cells: entry n_work - 1 - i): one wave per cell
+__global__ __launch_bounds__(1024) void lut_sort_mid_kernel(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx,
+                                                             const uint32_t* __restrict__ big_cells, const uint32_t* __restrict__ n_mid, uint32_t n_work) {
+	__shared__ uint32_t sh[16 * kMidList]; // sixteen waves, one list each
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	uint32_t* a = sh + wave * kMidList;
+	const uint32_t nm = *n_mid;
+	for (uint32_t w = blockIdx.x * 16u + wave; w < nm; w += gridDim.x * 16u) {
+		const uint32_t cell = big_cells[n_work - 1u - w];
+		const uint32_t o = offsets[cell], n = offsets[cell + 1] - o;
+		for (uint32_t i = lane; i < n; i += 64) a[i] = idx[o + i];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		bitonic_ascending_wave(a, n, lane);
+		for (uint32_t i = lane; i < n; i += 64) idx[o + i] = a[i];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+}
+constexpr uint32_t kSortScanWords = kSortLdsEntries - 1024u; // bitmap path: the bitmap's words in front, the 1024 scan partials behind them
 __global__ __launch_bounds__(1024) void lut_sort_big_kernel(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ idx,
-                                                             const uint32_t* __restrict__ big_cells, const uint32_t* __restrict__ n_big) {
+                                                             const uint32_t* __restrict__ big_cells, const uint32_t* __restrict__ n_big, uint32_t n_tets) {
 	__shared__ uint32_t sh[kSortLdsEntries];
 	const uint32_t nb = *n_big;
 	for (uint32_t w = blockIdx.x; w < nb; w += gridDim.x) {
 		const uint32_t cell = big_cells[w];
 		const uint32_t o = offsets[cell], n = offsets[cell + 1] - o;
-		if (n <= kSortLdsEntries) {
+		if ((n_tets + 31u) / 32u <= kSortScanWords) { // (every list of this worklist is longer than kMidList)
+			// a long list (the coarse cascades' cells hold thousands of a large mesh's tets).  A list holds distinct tet numbers below n_tets: set their bits in an LDS
+			// bitmap, scan the words' populations, write the set bits out in ascending order -- O(n + n_tets / 32) instead of a bitonic network's O(n log^2 n) with a
+			// barrier per step (round 6: profiles/r06/cage_move_kernels.md)
+			const uint32_t words = (n_tets + 31u) / 32u, per = (words + 1023u) / 1024u;
+			uint32_t* part = sh + kSortScanWords;
+			for (uint32_t i = threadIdx.x; i < words; i += 1024) sh[i] = 0u;
+			__syncthreads();
+			for (uint32_t i = threadIdx.x; i < n; i += 1024) { const uint32_t t = idx[o + i]; atomicOr(&sh[t >> 5], 1u << (t & 31u)); }
+			__syncthreads();
+			const uint32_t w0 = min(threadIdx.x * per, words), w1 = min(w0 + per, words);
+			uint32_t mine = 0;
+			for (uint32_t ww = w0; ww < w1; ++ww) mine += (uint32_t)__popc(sh[ww]);
+			part[threadIdx.x] = mine;
+			__syncthreads();
+			for (uint32_t d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan
+				const uint32_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+				__syncthreads();
+				part[threadIdx.x] += add;
+				__syncthreads();
+			}
+			uint32_t pos = o + part[threadIdx.x] - mine;
+			for (uint32_t ww = w0; ww < w1; ++ww) {
+				uint32_t bits = sh[ww];
+				while (bits) { idx[pos++] = ww * 32u + (uint32_t)__builtin_ctz(bits); bits &= bits - 1u; }
+			}
+			__syncthreads();
+		} else if (n <= kSortLdsEntries) {
 			for (uint32_t i = threadIdx.x; i < n; i += 1024) sh[i] = idx[o + i];
 			__syncthreads();
 			bitonic_ascending(sh, n, threadIdx.x, 1024u);
 			for (uint32_t i = threadIdx.x; i < n; i += 1024) idx[o + i] = sh[i];
 			__syncthreads();
 		} else {
-			bitonic_ascending(idx + o, n, threadIdx.x, 1024u); // in HBM/L2: only meshes with > 16 K tets in ONE cell get here
+			bitonic_ascending(idx + o, n, threadIdx.x, 1024u); // in HBM/L2: a mesh of more than 491 520 tets with more than 16 K of them in ONE cell
 		}
 	}
 }
@@ -632,16 +709,17 @@ int launch_lut_count_scan(uint32_t n_tets, const float* d_verts, const uint32_t*
 	NRS_CAGE_CHECK("tet LUT count/scan launch");
 	return NRS_OK;
 }
-// d_scratch_u32[0] = max tets per cell (out), [1] = big-cell counter; both zeroed here.  d_bitfield may be NULL.
-// d_big_cells: worklist of at least (entries / kSmallList + 1) cells.
+// d_scratch_u32[0] = max tets per cell (out), [1] / [2] = counters of the two sort worklists; all zeroed here.  d_bitfield may be NULL.
+// d_big_cells: worklist of n_work >= (entries / kSmallList + 1) cells (long lists from its front, middle ones from its back).
 int launch_lut_fill(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, const uint32_t* d_offsets, uint32_t* d_idx,
-                    uint8_t* d_bitfield, uint32_t* d_scratch_u32, uint32_t* d_big_cells, unsigned long long* d_hit_masks, float cells0, void* stream) {
+                    uint8_t* d_bitfield, uint32_t* d_scratch_u32, uint32_t* d_big_cells, uint32_t n_work, unsigned long long* d_hit_masks, float cells0, void* stream) {
 	hipStream_t s = (hipStream_t)stream;
-	if (hipMemsetAsync(d_scratch_u32, 0, 8, s) != hipSuccess) { snprintf(g_cage_err, sizeof(g_cage_err), "tet LUT fill: memset failed"); return NRS_ERR_HIP; }
+	if (hipMemsetAsync(d_scratch_u32, 0, 12, s) != hipSuccess) { snprintf(g_cage_err, sizeof(g_cage_err), "tet LUT fill: memset failed"); return NRS_ERR_HIP; }
 	launch_tet_mark<true>(n_tets, cells0, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks, s);
 	hipLaunchKernelGGL(lut_finish_kernel, dim3(kCells / 256), dim3(256), 0, s, d_offsets, d_idx, d_bitfield, d_scratch_u32, d_big_cells,
-	                   d_scratch_u32 + 1);
-	hipLaunchKernelGGL(lut_sort_big_kernel, dim3(512), dim3(1024), 0, s, d_offsets, d_idx, d_big_cells, d_scratch_u32 + 1);
+	                   d_scratch_u32 + 1, n_work);
+	hipLaunchKernelGGL(lut_sort_mid_kernel, dim3(512), dim3(1024), 0, s, d_offsets, d_idx, d_big_cells, d_scratch_u32 + 2, n_work);
+	hipLaunchKernelGGL(lut_sort_big_kernel, dim3(512), dim3(1024), 0, s, d_offsets, d_idx, d_big_cells, d_scratch_u32 + 1, n_tets);
 	NRS_CAGE_CHECK("tet LUT fill launch");
 	return NRS_OK;
 }

@@ -244,10 +244,10 @@ int launch_mvc_apply(uint32_t n_points, uint32_t n_cv, const float* d_weights, c
 int launch_bbox(uint32_t n, const float* d_verts, float* d_out6, void* stream);
 int launch_poisson_interpolate(uint32_t n_points, uint32_t n_cv, const float* d_gamma, const float* d_per_cage, float* d_shs, float* d_out_density, float* d_res_density, void* stream);
 int launch_lut_count_scan(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, uint32_t* d_tile_sums,
-                          uint32_t* d_offsets, uint32_t* d_total, unsigned long long* d_hit_masks /* [n_tets * kCascades]: written */,
+                          uint32_t* d_offsets, uint32_t* d_total, unsigned long long* d_hit_masks /* [2 * n_tets * kCascades]: written */,
                           float cells0 /* estimate: cells of cascade 0 in a tet's bounding box (team size) */, void* stream);
 int launch_lut_fill(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, const uint32_t* d_offsets, uint32_t* d_idx,
-                    uint8_t* d_bitfield, uint32_t* d_scratch_u32, uint32_t* d_big_cells, unsigned long long* d_hit_masks /* as the count pass left them */, float cells0, void* stream);
+                    uint8_t* d_bitfield, uint32_t* d_scratch_u32 /* 3 words */, uint32_t* d_big_cells, uint32_t n_work /* its entries */, unsigned long long* d_hit_masks /* as the count pass left them */, float cells0, void* stream);
 uint32_t lut_big_list_capacity(size_t idx_capacity);
 int launch_tet_planes(uint32_t n_tets, const float* d_verts, const uint32_t* d_tets, float* d_planes, void* stream);
 // fine look-up table (DeviceEdit::fine_*): d_window_out[kCascades][8] = min x, y, z / max x, y, z of the LUT cells with a non-empty list (min > max: none), their number, the longest list

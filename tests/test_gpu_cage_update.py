@@ -80,6 +80,31 @@ def test_cage_moves_rebuild_on_device(rig, via):
         op.close()
 
 
+@pytest.mark.parametrize("lattice", [10, 18])
+def test_large_meshes_take_the_other_launch_shapes(rig, lattice):
+    """The LUT passes choose their lane teams by mesh size and tet size (nrs_cage.hip launch_tet_mark: a wave per item at cascade 0 for the bench's 6 000-tet cage,
+    eight lanes / one lane per item for a 35 000-tet one), cells with more than 24 tets are sorted by a wave in LDS and cells with more than 128 (the coarse
+    cascades of the large mesh) by a workgroup's bitmap pass: the tables are the oracle's builder's whatever the shape, after creation and after a move."""
+    scene = rig.scene
+    synth, orc = scene.synth, scene.orc
+    e = synth.make_cage_edit(lattice_n=lattice)
+    op = rig.rt.CageDeformation(rig.ctx, scene.desc, e, device_authoring=True)
+    op.set_mvc(e.mvc_weights)
+    try:
+        for verts in (e.vertices, orc.mvc_apply(e.mvc_weights, synth.deform_cage(e.cage_vertices, (0.05, -0.04, 0.03), 47.0))):
+            if verts is not e.vertices:
+                op.update_vertices(None, verts)
+            got = op.download(rotations=False)
+            off, idx, _, mx = orc.tet_lut_build(verts, e.tets)
+            assert np.array_equal(got["lut_offsets"], off) and np.array_equal(got["lut_idx"], idx) and op.lut_size() == (idx.size, mx)
+            if lattice == 18:
+                assert mx > 1024   # the bitmap pass ran (lists longer than a wave's share of LDS)
+            if verts is e.vertices:
+                assert np.array_equal(got["original_bitfield"], e.original_bitfield)   # (built at creation from the canonical mesh by the same passes)
+    finally:
+        op.close()
+
+
 def test_cage_update_on_aabb16(rig16):
     """Tets that span several cascades (scene box [-7.5, 8.5]^3): cells of cascades 1..4 are exercised."""
     scene = rig16.scene
