@@ -1,0 +1,58 @@
+"""Soak of whole frames on the bench's own scenes: every instantiation a bench workload runs (default, varied opacity, membrane, tiny-cuda-nn's roundings, the third rgb
+layer, the garden scene's GATE instantiation with 64 GiB of brick records and its 4 GiB knee) on RANDOM cameras -- azimuth 0..360, elevation -80..80, a fifth of them within a
+hundredth of a degree of a coordinate axis, orbit radius 0.7..1.4 of the bench's -- at 480x270 against the oracle, with the bars of tests/test_gpu_bench_parity.py (colours
+max 1.5e-2 with at most max(3, share x pixels) above 6e-3, per-pixel sample counts never more than one apart -- two for the varied scene -- equal ray counts).  Too long for
+the test tier (the tests hold each workload at 1920x1080 on the bench's views); run through gpurun:
+    python tools/frame_soak.py [cameras per workload]
+Prints one line per workload; exit code 1 when a bar is missed."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_gpu_bench_parity import BenchScene  # noqa: E402
+
+n_cam = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+W, H = 480, 270
+rng = np.random.default_rng(2606)
+WORKLOADS = [("lego_cage", {}), ("lego_cage_varied", dict(two=1)), ("lego_cage_membrane", dict(poisson=1)), ("lego_cage_tcnn_numerics", dict(num=1, flip=1e-4, eq=0.999)),
+             ("lego_cage_base_3layer", {}), ("garden_cage_records64", dict(depth=16.0)), ("garden_cage", dict(depth=16.0))]
+failed = 0
+for workload, opt in WORKLOADS:
+    bs = BenchScene(workload)
+    if opt.get("num"):
+        bs.model.set_numerics(1, 1)
+    scale = 0.33 * (1.0 if bs.sc["aabb_scale"] == 1 else 6.0)
+    worst_d, above, worst_eq, worst_ds, two_apart, rays_off, samples = 0.0, 0, 1.0, 0, 0, 0, 0
+    for k in range(n_cam):
+        az, el = float(rng.uniform(0, 360)), float(rng.uniform(-80, 80))
+        if k % 5 == 0:
+            az, el = float(rng.choice([0, 90, 180, 270])) + float(rng.normal(0, 0.01)), float(rng.normal(0, 0.01))
+        p = bs.synth.render_params(W, H, bs.synth.orbit_camera(az, el, scale=scale * float(rng.uniform(0.7, 1.4))), aabb_scale=bs.sc["aabb_scale"])
+        if opt.get("poisson"):
+            p.poisson_target = 1
+        frame, depth, steps, stats = bs.render(p)
+        ref_frame, ref_depth, ref_steps, ref_stats = bs.model.render(p, bs.edits)
+        d = np.abs(frame - ref_frame).max(axis=-1)
+        ds = np.abs(steps.astype(np.int64) - ref_steps.astype(np.int64))
+        worst_d = max(worst_d, float(d.max()))
+        above = max(above, int((d > 6e-3).sum()))
+        worst_eq = min(worst_eq, float((ds == 0).mean()))
+        worst_ds = max(worst_ds, int(ds.max()))
+        two_apart = max(two_apart, int((ds >= 2).sum()))
+        rays_off += int(stats.n_rays_alive != ref_stats.n_alive0)
+        samples += int(ref_stats.composited)
+        hit = (ref_frame[..., 3] > 0.2) & (frame[..., 3] > 0.2) & (ds == 0)
+        if hit.any() and not np.allclose(depth[hit], ref_depth[hit], rtol=0, atol=2e-3 * opt.get("depth", 1.0)):
+            rays_off += 1000
+    allowed = max(3, int(opt.get("flip", 1e-5) * W * H))
+    ok = worst_d < 1.5e-2 and above <= allowed and worst_ds <= (2 if opt.get("two") else 1) and two_apart <= (3 if opt.get("two") else 0) and worst_eq >= opt.get("eq", 0.9998) - 2e-4 and rays_off == 0
+    failed += 0 if ok else 1
+    print(f"{workload:28s} {n_cam} cameras, {samples} samples: max|dRGBA| {worst_d:.3e}, most pixels above 6e-3 in a frame {above} (allowed {allowed}), smallest share of pixels with "
+          f"equal sample counts {worst_eq:.6f}, largest difference {worst_ds}, frames with another ray count or a depth beyond the bar {rays_off}: {'ok' if ok else 'MISSED'}", flush=True)
+    del bs
+print(f"frame soak: {len(WORKLOADS)} workloads x {n_cam} random cameras at {W}x{H}, workloads that missed a bar: {failed}")
+sys.exit(1 if failed else 0)
