@@ -1553,12 +1553,13 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 	{ // Cone stepping is what the reference switches on for aabb_scale > 1 (tn:3410-3425): scenes whose fine hashed levels no two samples of a wave share, so that their
 	  // 8 MB of table lines thrash the 4 MB L2 of an XCD -- the GATE instantiation time-multiplexes it (nrs_mlp.cuh encode_to_lds; profiles/r06_garden.md: L2 misses per
 	  // sample 11.5 -> 7.2, +5 % on the garden frame).  A unit-cube scene (constant steps) never takes it: there the gate costs 18 %.
-		static const bool gate_on = []() { const char* e = dev_knob("NRS_L2_GATE"); return !e || atoi(e) != 0; }();
-		// (only where the gate has something to separate: levels 12..15 hashed without records, the pair below them on records -- a model without sparse brick records
-		// gathers eight hashed levels, which two phases do not fit either, and keeps the default instantiation)
+		static const int gate_on = []() { const char* e = dev_knob("NRS_L2_GATE"); return e ? atoi(e) : 1; }(); // (0: off -- A/B)
+		// (only where the gate has something to separate: the two, three or four finest level PAIRS hashed without records -- one phase each -- and records below them;
+		// more hashed pairs than phases would run the GATE instantiation ungated, 5 % behind the default kernel: profiles/r06/ab_gate_phases_*.txt)
 		const LevelParams* lv = m->dm.levels;
-		const bool fine_hashed = lv[12].hashed && lv[13].hashed && lv[14].hashed && lv[15].hashed && !lv[12].cached && !lv[13].cached && !lv[14].cached && !lv[15].cached;
-		a.gate = (gate_on && p->cone_angle_constant > 0.f && fine_hashed && lv[10].cached && lv[11].cached) ? 1u : 0u;
+		int hashed_pairs = 0;
+		for (int it = 7; it >= 0 && lv[2 * it].hashed && lv[2 * it + 1].hashed && !lv[2 * it].cached && !lv[2 * it + 1].cached; --it) ++hashed_pairs;
+		a.gate = (gate_on && p->cone_angle_constant > 0.f && hashed_pairs >= 2 && hashed_pairs <= 4) ? 1u : 0u;
 	}
 	// everything of render_nerf's surface beyond Shade / Cost with a pinhole camera runs the EXTRA instantiation (one lane per ray)
 	a.extra = ((p->render_mode != NRS_RENDER_SHADE && p->render_mode != NRS_RENDER_COST) || p->show_accel || p->dof != 0.f || p->distortion_mode || p->d_distortion_map ||

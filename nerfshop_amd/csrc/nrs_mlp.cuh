@@ -25,7 +25,18 @@
 
 // L2 time-multiplexing of the four finest hashed levels (encode_to_lds, GATE): a phase is 2^kGateShift ticks of the 100 MHz wall clock (20.5 us); a wave waits at most
 // kGateWaitCap eighths of a phase for the right one (profiles/r06_garden.md: 10 / 20 / 41 us phases, wait caps 2 / 4 / 8 eighths measured)
-constexpr uint32_t kGateShift = 11, kGateWaitCap = 2;
+#ifndef NRS_GATE_SHIFT
+#define NRS_GATE_SHIFT 11
+#endif
+#ifndef NRS_GATE_WAIT_CAP
+#define NRS_GATE_WAIT_CAP 2
+#endif
+constexpr uint32_t kGateShift = NRS_GATE_SHIFT, kGateWaitCap = NRS_GATE_WAIT_CAP;
+#ifndef NRS_GATE_MAX_PHASES
+#define NRS_GATE_MAX_PHASES 4
+#endif
+constexpr uint32_t kGateMaxPhases = NRS_GATE_MAX_PHASES; // 2: levels 12..15 only; 3 / 4: the pairs below too when they are hashed without records.  Measured (profiles/r06/ab_gate_phases_*.txt):
+// the records budget's knee (levels 10..15 hashed) 4.59 -> 4.96 Gsamples/s with three phases, no sparse records (8..15 hashed) 4.48 -> 4.60 with four, 64 GiB (two phases) unchanged
 
 namespace nrs {
 
@@ -450,13 +461,17 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 	// thrash (7.8 of the frame's 11.5).  So the L2 is time-multiplexed: the wall clock (100 MHz, the same on every XCD) is cut into phases of 2^kGateShift ticks; levels
 	// 12-13 are gathered in even phases and 14-15 in odd ones by every wave of the GPU, whichever phase a wave arrives in first, with the record levels in between as
 	// filler; a wave waits at most kGateWaitCap eighths of a phase for the other one, then goes ahead.  Results cannot change (the same loads in another order).
-	bool gated = false;
-	uint32_t gate_ph = 0;
+	// (round 6, late: the same with THREE or FOUR phases when the pairs below are hashed without records too -- the knee of the records budget gathers levels 10..15
+	// from 12 MB of tables, a model without sparse records levels 8..15 from 16 MB: gate_m = the number of trailing hashed pairs, one phase each.)
+	// Phase length: 2^kGateShift ticks (20.5 us) for two and three phases, half of it for four (profiles/r06/ab_gate_tune_*.txt: 10 / 20 / 41 us x wait caps of a quarter / half
+	// a phase, per number of phases).
+	uint32_t gate_m = 0, gate_ph = 0, gate_shift = kGateShift;
+	auto gate_phase = [&](unsigned long long now) { return ((uint32_t)(now >> gate_shift)) % gate_m; };
 	auto gate_wait = [&](uint32_t ph) {
-		const unsigned long long t_in = wall_clock64(), cap = ((unsigned long long)kGateWaitCap << kGateShift) >> 3;
+		const unsigned long long t_in = wall_clock64(), cap = ((unsigned long long)kGateWaitCap << gate_shift) >> 3;
 		for (;;) {
 			const unsigned long long now = wall_clock64();
-			if ((((uint32_t)(now >> kGateShift)) & 1u) == ph || now - t_in >= cap) break;
+			if (gate_phase(now) == ph || now - t_in >= cap) break;
 			__builtin_amdgcn_s_sleep(8);
 		}
 	};
@@ -466,15 +481,22 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 		fl.feat[itp][0][lane] = g ? f1 : f0;
 		fl.feat[itp][1][lane ^ 32] = g ? f0 : f1;
 	};
-	if (GATE && !one_line && __builtin_amdgcn_readfirstlane(kinds[6]) == KIND_HASHED && __builtin_amdgcn_readfirstlane(kinds[7]) == KIND_HASHED &&
-	    __builtin_amdgcn_readfirstlane(kinds[5]) != KIND_HASHED) {
-		gated = true;
+	if (GATE && !one_line && __builtin_amdgcn_readfirstlane(kinds[6]) == KIND_HASHED && __builtin_amdgcn_readfirstlane(kinds[7]) == KIND_HASHED) {
+		gate_m = 2;
+		if (kGateMaxPhases >= 3 && __builtin_amdgcn_readfirstlane(kinds[5]) == KIND_HASHED) {
+			gate_m = 3;
+			if (kGateMaxPhases >= 4 && __builtin_amdgcn_readfirstlane(kinds[4]) == KIND_HASHED) gate_m = 4;
+		}
+		if (__builtin_amdgcn_readfirstlane(kinds[7 - (int)gate_m]) == KIND_HASHED) gate_m = 0; // (more hashed pairs than phases: no gate)
+		if (gate_m >= 4u) gate_shift = kGateShift - 1u;
+	}
+	if (GATE && gate_m) {
 		const unsigned long long now = wall_clock64();
-		constexpr unsigned long long kPhaseMask = (1ull << kGateShift) - 1ull;
-		gate_ph = (uint32_t)(now >> kGateShift) & 1u;
-		if ((now & kPhaseMask) > kPhaseMask * 13ull / 16ull) { gate_ph ^= 1u; gate_wait(gate_ph); } // (late in a phase: this gather would run into the next one -- take that)
-		gate_pair(6 + (int)gate_ph);
-		it_end = 6;
+		const unsigned long long kPhaseMask = (1ull << gate_shift) - 1ull;
+		gate_ph = gate_phase(now);
+		if ((now & kPhaseMask) > kPhaseMask * 13ull / 16ull) { gate_ph = (gate_ph + 1u) % gate_m; gate_wait(gate_ph); } // (late in a phase: this gather would run into the next one -- take that)
+		gate_pair(8 - (int)gate_m + (int)gate_ph);
+		it_end = 8 - (int)gate_m;
 	}
 	#pragma unroll 1
 	while (it < it_end) {
@@ -527,7 +549,14 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 		fl.feat[it][1][lane ^ 32] = g ? f0 : f1;
 		++it;
 	}
-	if (GATE && gated) { gate_wait(gate_ph ^ 1u); gate_pair(7 - (int)gate_ph); }
+	if (GATE && gate_m) {
+		#pragma unroll 1
+		for (uint32_t k = 1; k < gate_m; ++k) {
+			const uint32_t ph = (gate_ph + k) % gate_m;
+			gate_wait(ph);
+			gate_pair(8 - (int)gate_m + (int)ph);
+		}
+	}
 	// feat[..][1][lane ^ 32] is another lane's slot: order the wave's writes before load_features' reads (no instruction: LDS operations of a wave
 	// stay in order; this keeps the compiler from moving a read above the write it cannot see through the xor)
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

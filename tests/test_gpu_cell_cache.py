@@ -184,6 +184,14 @@ def test_sparse_brick_records_are_a_layout_of_the_same_numbers(rig16):
             frame, depth, steps, stats = rig.render(p)
             assert np.array_equal(frame.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(depth.view(np.uint32), ref[1].view(np.uint32))
             assert np.array_equal(steps, ref[2]) and stats.n_samples == ref[3].n_samples
+        # every launch above ran the GATE instantiation (cone stepping, 2 / 3 / 4 trailing hashed level pairs behind records: two, three or four L2 phases); without any
+        # records six pairs are hashed and nrs_render_nerf takes the default kernel: the ungated picture is the same picture, bit for bit
+        rig.net.set_cell_cache(0)
+        assert rig.net.cell_cache()[1] == 0 and rig.net.sparse_cell_cache() == (0, 0, 0)
+        frame, depth, steps, stats = rig.render(p)
+        assert np.array_equal(frame.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(depth.view(np.uint32), ref[1].view(np.uint32))
+        assert np.array_equal(steps, ref[2]) and stats.n_samples == ref[3].n_samples
+        rig.net.set_cell_cache(10 << 30)
         # the records follow the parameters, and the dense budget drops the sparse levels (they start where the dense ones end)
         rig.net.set_sparse_cell_cache(mask, 4 << 30)
         other = scene.params.copy()
