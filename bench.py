@@ -45,7 +45,7 @@ def flop_per_sample(desc):
 def build_scene(workload, rt, synth, ctx, torch):
     aabb_scale = 16 if workload.startswith("garden") else 1
     # garden_cage = the KNEE of the record-budget curve (profiles/r06_garden.md: 0 / 3.2 / 60.7 GB of sparse brick records -> 4.51 / 4.62 / 4.97 Gsamples/s without the L2
-    # phase gate): a 4 GiB budget, levels 8..9; garden_cage_records64 = the 64 GiB budget (levels 8..11: the configuration the L2 phase gate applies to)
+    # phase gate): a 4 GiB budget, levels 8..9 (three hashed pairs left: the three-phase gate, 4.97); garden_cage_records64 = the 64 GiB budget (levels 8..11: two phases, 5.3)
     sparse_gb = os.environ.get("NRS_SPARSE_GB", "64" if workload.endswith("records64") else "4")
     with_edit = "cage" in workload
     # (configs/nerf/base_1layer.json / base_3layer.json: the rgb network with one hidden layer is lowered onto the kernels' network and runs the default
