@@ -2203,7 +2203,10 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 			f3 unused = mk3(0.5f, 0.5f, 0.5f);
 			for (int k = a.n_edits - 1; k >= 0; --k) (void)edit_warp(a.edits[k], false, wpos, unused);
 		}
-		encode_num<NUM>(nm, gv, m.levels, sm.ml, fl, lane, g, wpos, have);
+		// (round 6: one sample per occupancy cell shares no line with its neighbours at the fine levels -- the refresh runs on the fabric's request roof like the garden
+		// frame, so it takes the same medicine: the L2 phase gate on the trailing hashed level pairs and four record levels per round trip.  aabb 1: 0.81 -> 0.76 ms,
+		// aabb 16: 5.10 -> 4.54 ms per refresh; the same loads in another order, bit-identical grids: profiles/r06/ab_refresh_gate.txt)
+		encode_num<NUM, true, true, true>(nm, gv, m.levels, sm.ml, fl, lane, g, wpos, have);
 		_Float16 raw_b0 = (_Float16)0, raw_b1 = (_Float16)0; // (two scalars, not an array indexed by the rolled loop's counter: that one lived in scratch)
 		#pragma unroll 1
 		for (int b = 0; b < 2; ++b) {
