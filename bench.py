@@ -202,10 +202,13 @@ def next_rows(rt, synth, ctx, torch):
         rows[key] = {"ms": round(ms, 3), "samples": N, "msamples_per_s": round(N / ms / 1e3, 1), "frac": round(N * (BYTES_PER_SAMPLE + 28 + 32) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     net.close()
     del rnd, ordered, out
-    for aabb_scale, max_cascade in ((1, 0), (16, 4)):
+    for aabb_scale, max_cascade, records in ((1, 0, False), (16, 4, False), (1, 0, True), (16, 4, True)):
         d = synth.model_desc(aabb_scale)
         tb = rt.Testbed(ctx, d, aabb_scale)
-        tb.nerf_network.set_cell_cache(0)  # (a refresh follows a parameter change: a training viewer keeps no records)
+        # without records: a refresh that follows a parameter change (a training viewer keeps none); with the harness's default 10 GiB of cell records: the refresh that
+        # follows a cage move on a frozen model (the editing viewer; the kernel then runs the L2 phase gate over the trailing hashed level pairs: profiles/r06/ab_refresh_gate.txt)
+        if not records:
+            tb.nerf_network.set_cell_cache(0)
         tb.nerf_network.set_params(synth.make_params(d, sigma_raw=synth.default_sigma_raw(aabb_scale), shaped=True, aabb_scale=aabb_scale))
         e = synth.make_cage_edit(lattice_n=10, scene_scale=1.0 if aabb_scale == 1 else 6.0)
         tb.add_edit_operator(rt.CageDeformation(ctx, d, e))
@@ -215,7 +218,7 @@ def next_rows(rt, synth, ctx, torch):
         u.reset_grid = 0
         ms = timed(lambda: tb.update_density_grid_nerf_operator(u), 6)
         n_s = 128 ** 3 * (max_cascade + 1)
-        rows[f"occupancy_refresh_aabb{aabb_scale}"] = {"ms": round(ms, 3), "samples": n_s, "msamples_per_s": round(n_s / ms / 1e3, 1),
+        rows[f"occupancy_refresh_aabb{aabb_scale}" + ("_records" if records else "")] = {"ms": round(ms, 3), "samples": n_s, "msamples_per_s": round(n_s / ms / 1e3, 1),
                                                        "frac": round(n_s * BYTES_PER_SAMPLE / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         del tb
     torch.cuda.empty_cache()
