@@ -1559,6 +1559,8 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		const LevelParams* lv = m->dm.levels;
 		int hashed_pairs = 0;
 		for (int it = 7; it >= 0 && lv[2 * it].hashed && lv[2 * it + 1].hashed && !lv[2 * it].cached && !lv[2 * it + 1].cached; --it) ++hashed_pairs;
+		// (= kGateMaxPhases of the kernels.  Six phases for a model without any records: 4.36 -> 4.18 Gsamples/s, profiles/r06/ab_gate6_garden_nocache.txt -- a frame's round has
+		// no time for six waits; the occupancy refresh, one gather per wave, gains with up to six: NRS_REFRESH_GATE_PHASES)
 		a.gate = (gate_on && p->cone_angle_constant > 0.f && hashed_pairs >= 2 && hashed_pairs <= 4) ? 1u : 0u;
 	}
 	// everything of render_nerf's surface beyond Shade / Cost with a pinhole camera runs the EXTRA instantiation (one lane per ray)

@@ -230,7 +230,7 @@ __device__ __forceinline__ bool packet_pixel_tail(const RenderArgs& a, uint32_t 
 template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0, int XTRA = 0>
 __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const RenderArgs& a_arg) {
 	constexpr bool EXTRA = XTRA >= 1 && XTRA <= 4, INTRO = XTRA == 2 || XTRA == 4, DEEP = XTRA >= 3 && XTRA <= 5; // (3 / 4: 1 / 2 for a network whose rgb MLP has a third hidden layer, base_3layer.json; 5: that layer alone)
-	constexpr bool GATE = XTRA == 6; // the plain kernel with the L2 phase gate on the four finest hashed levels (encode_to_lds): cone-stepping scenes
+	constexpr int GATE = XTRA == 6 ? (int)kGateMaxPhases : 0; // the plain kernel with the L2 phase gate on the four finest hashed levels (encode_to_lds): cone-stepping scenes
 	// The two argument structs (~1.3 KB of wave-uniform values) live in the kernel-argument segment and are read with scalar loads.
 	// Left alone, the compiler hoists every such load out of the frame loop and then spills ~150 scalar registers into VGPR lanes
 	// (v_writelane / v_readlane: VALU slots in the round loop, 3 VGPRs).  NRS_FRESH_ARGS re-derives the two references from an
@@ -2206,7 +2206,7 @@ __global__ __launch_bounds__(256) void grid_refresh_kernel(const DeviceModel m, 
 		// (round 6: one sample per occupancy cell shares no line with its neighbours at the fine levels -- the refresh runs on the fabric's request roof like the garden
 		// frame, so it takes the same medicine: the L2 phase gate on the trailing hashed level pairs and four record levels per round trip.  aabb 1: 0.81 -> 0.76 ms,
 		// aabb 16: 5.10 -> 4.54 ms per refresh; the same loads in another order, bit-identical grids: profiles/r06/ab_refresh_gate.txt)
-		encode_num<NUM, true, true, true>(nm, gv, m.levels, sm.ml, fl, lane, g, wpos, have);
+		encode_num<NUM, true, true, NRS_REFRESH_GATE_PHASES>(nm, gv, m.levels, sm.ml, fl, lane, g, wpos, have);
 		_Float16 raw_b0 = (_Float16)0, raw_b1 = (_Float16)0; // (two scalars, not an array indexed by the rolled loop's counter: that one lived in scratch)
 		#pragma unroll 1
 		for (int b = 0; b < 2; ++b) {

@@ -35,6 +35,9 @@ constexpr uint32_t kGateShift = NRS_GATE_SHIFT, kGateWaitCap = NRS_GATE_WAIT_CAP
 #ifndef NRS_GATE_MAX_PHASES
 #define NRS_GATE_MAX_PHASES 4
 #endif
+#ifndef NRS_REFRESH_GATE_PHASES
+#define NRS_REFRESH_GATE_PHASES 6 // (grid_refresh_kernel: without cell records five / six level pairs are hashed; 5.68 -> 5.04 ms at aabb 16, profiles/r06/ab_refresh_gate_phases.txt)
+#endif
 constexpr uint32_t kGateMaxPhases = NRS_GATE_MAX_PHASES; // 2: levels 12..15 only; 3 / 4: the pairs below too when they are hashed without records.  Measured (profiles/r06/ab_gate_phases_*.txt):
 // the records budget's knee (levels 10..15 hashed) 4.59 -> 4.96 Gsamples/s with three phases, no sparse records (8..15 hashed) 4.48 -> 4.60 with four, 64 GiB (two phases) unchanged
 
@@ -449,7 +452,7 @@ __device__ __forceinline__ uint32_t level_eval_one(const GridView& gv, const Lev
 // same bits as before: the arithmetic per (sample, level) did not change.  The slab layout the MLP reads is unchanged too:
 // feat[it][0][l] = level 2 it + g(l) of lane l's sample, feat[it][1][l] = the same level of lane (l ^ 32)'s sample; so the level
 // of the lane's own parity goes to [0][lane] and the other one to [1][lane ^ 32] (a conflict-free permutation of the banks).
-template <bool NETACC = false, bool QUADS = false, bool ZERO = true, bool GATE = false>
+template <bool NETACC = false, bool QUADS = false, bool ZERO = true, int GATE = 0> // (GATE: 0, or the largest number of L2 phases -- trailing hashed level pairs -- to gate)
 __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelParams* __restrict__ lv, const ModelLds& ml, FeatLds& fl, int lane, int g, f3 pos, bool act) {
 	// the records cover [0,1]^3; a wave with a sample outside it (a warped sample of an edit, rarely) gathers the native way
 	const bool outside = __any(act && outside_unit_cube(pos));
@@ -481,13 +484,10 @@ __device__ __forceinline__ void encode_to_lds(const GridView& gv, const LevelPar
 		fl.feat[itp][0][lane] = g ? f1 : f0;
 		fl.feat[itp][1][lane ^ 32] = g ? f0 : f1;
 	};
-	if (GATE && !one_line && __builtin_amdgcn_readfirstlane(kinds[6]) == KIND_HASHED && __builtin_amdgcn_readfirstlane(kinds[7]) == KIND_HASHED) {
-		gate_m = 2;
-		if (kGateMaxPhases >= 3 && __builtin_amdgcn_readfirstlane(kinds[5]) == KIND_HASHED) {
-			gate_m = 3;
-			if (kGateMaxPhases >= 4 && __builtin_amdgcn_readfirstlane(kinds[4]) == KIND_HASHED) gate_m = 4;
-		}
-		if (__builtin_amdgcn_readfirstlane(kinds[7 - (int)gate_m]) == KIND_HASHED) gate_m = 0; // (more hashed pairs than phases: no gate)
+	if (GATE && !one_line) {
+		uint32_t n_hashed = 0; // trailing hashed level pairs (wave-uniform: scalar loop)
+		for (int itp = 7; itp >= 0 && __builtin_amdgcn_readfirstlane(kinds[itp]) == KIND_HASHED; --itp) ++n_hashed;
+		gate_m = (n_hashed >= 2u && n_hashed <= (uint32_t)GATE) ? n_hashed : 0u; // (more hashed pairs than phases: no gate)
 		if (gate_m >= 4u) gate_shift = kGateShift - 1u;
 	}
 	if (GATE && gate_m) {
@@ -879,7 +879,7 @@ __device__ __forceinline__ void level_input_gradient(const GridView& gv, const L
 // tiny-cuda-nn's roundings as a template value: NUM >= 0 fixes them at compile time (bit 0 grid accumulation in network precision, bit 1 fp16 MLP
 // accumulators), kNumRuntime reads them from `nm` (DeviceModel::numerics, wave-uniform) -- both flavours compiled in, one scalar branch.
 constexpr int kNumRuntime = -1;
-template <int NUM, bool QUADS = false, bool ZERO = true, bool GATE = false>
+template <int NUM, bool QUADS = false, bool ZERO = true, int GATE = 0>
 __device__ __forceinline__ void encode_num(uint32_t nm, const GridView& gv, const LevelParams* __restrict__ lv, const ModelLds& ml, FeatLds& fl, int lane, int g, f3 pos, bool act) {
 	if (NUM == kNumRuntime ? (nm & 1u) != 0u : (NUM & 1) != 0) encode_to_lds<true, QUADS, ZERO, GATE>(gv, lv, ml, fl, lane, g, pos, act);
 	else encode_to_lds<false, QUADS, ZERO, GATE>(gv, lv, ml, fl, lane, g, pos, act);
