@@ -230,6 +230,9 @@ __device__ __forceinline__ bool packet_pixel_tail(const RenderArgs& a, uint32_t 
 template <int WAVES, int OCC, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0, int XTRA = 0>
 __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const RenderArgs& a_arg) {
 	constexpr bool EXTRA = XTRA >= 1 && XTRA <= 4, INTRO = XTRA == 2 || XTRA == 4, DEEP = XTRA >= 3 && XTRA <= 5; // (3 / 4: 1 / 2 for a network whose rgb MLP has a third hidden layer, base_3layer.json; 5: that layer alone)
+	// four levels per round trip in the gathers (encode_to_lds QUADS): the automatic schedule's instantiations with the default or the fully tiny-cuda-nn roundings -- since
+	// round 6 the membrane instantiation too (both of its gathers: 9.68 -> 10.06 Gsamples/s, same registers; profiles/r06/ab_poisson_quads.txt)
+	constexpr bool kQuads = TEAM == 0 && !AFFINE && !EXTRA && (NUM == 0 || NUM == 3);
 	constexpr int GATE = XTRA == 6 ? (int)kGateMaxPhases : 0; // the plain kernel with the L2 phase gate on the four finest hashed levels (encode_to_lds): cone-stepping scenes
 	// The two argument structs (~1.3 KB of wave-uniform values) live in the kernel-argument segment and are read with scalar loads.
 	// Left alone, the compiler hoists every such load out of the frame loop and then spills ~150 scalar registers into VGPR lanes
@@ -606,9 +609,9 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 		// ---- gather: own sample (block g) and the partner lane's sample (block 1-g), levels 2*it+g ----
 #if NRS_MEASURE == 3
 		{ f3 wp2 = wpos; asm volatile("" : "+v"(wp2.x), "+v"(wp2.y), "+v"(wp2.z));
-		  encode_num<NUM, (TEAM == 0 && !POISSON && !AFFINE && !EXTRA && NUM == 0)>(nm, gv, m2.levels, sm.ml, fl, lane, g, wp2, act); }
+		  encode_num<NUM, kQuads>(nm, gv, m2.levels, sm.ml, fl, lane, g, wp2, act); }
 #endif
-		encode_num<NUM, (TEAM == 0 && !POISSON && !AFFINE && !EXTRA && (NUM == 0 || NUM == 3)), false, GATE>(nm, gv, m2.levels, sm.ml, fl, lane, g, wpos, act); // (four record levels in flight: the hybrid instantiation has the registers; features of idle lanes are never looked at: not zeroed)
+		encode_num<NUM, kQuads, false, GATE>(nm, gv, m2.levels, sm.ml, fl, lane, g, wpos, act); // (four record levels in flight: the hybrid instantiation has the registers; features of idle lanes are never looked at: not zeroed)
 		NRS_PHASE(4); // SH + MLP
 		const f3 pdir = mk3(xchg32(wdir.x), xchg32(wdir.y), xchg32(wdir.z));
 		half8 sh_own, sh_par;
@@ -756,7 +759,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 				const bool need_old = has_res && p_res > 0.f;
 				if (p2b.poisson_target && __any(need_old)) {
 					const GridView gvb = make_grid_view(m2b);
-					encode_num<NUM>(nm, gvb, m2b.levels, sm.ml, fl, lane, g, wpos0, need_old);
+					encode_num<NUM, kQuads>(nm, gvb, m2b.levels, sm.ml, fl, lane, g, wpos0, need_old);
 					uint32_t old_d = 0;
 					#pragma unroll 1
 					for (int b = 0; b < 2; ++b) {
