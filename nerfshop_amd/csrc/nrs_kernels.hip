@@ -1683,7 +1683,7 @@ __global__ __launch_bounds__(64 * kNetWaves, (MODE == 3 || MODE == 4) ? 3 : 6) v
 			// (NerfNetworkNoDir never looks at the direction rows: a caller may leave them unset, and 0-weights do not stop a NaN)
 			if ((FULL || MODE == 4) && !m.no_dir) wdir = mk3(c[4], c[5], c[6]);
 		}
-		encode_to_lds<(NUM & 1) != 0>(gv, m.levels, sm.ml, fl, lane, g, wpos, have);
+		encode_to_lds<(NUM & 1) != 0>(gv, m.levels, sm.ml, fl, lane, g, wpos, have); // (four levels per round trip measured here: ray-ordered batches +-0, random ones -3.5 %: profiles/r06/ab_net_quads.txt; six waves per SIMD hide the trips)
 
 		if (MODE == 3) {
 			uint32_t dfe[2][8];
