@@ -180,17 +180,16 @@ __device__ __forceinline__ bool cell_meets_tet(f3 t0, f3 t1, f3 t2, f3 t3, uint3
 }
 
 // T lanes per (tet, cascade) item, 64 / T items per wave; a team strides over the cells of its tet's bounding box at that cascade.  Items are numbered cascade-major
-// (item = cascade * n_tets + tet) and a launch covers the items [item_begin, item_end) of ONE team size (launch_tet_mark chooses: 64 / 8 / 1).  Round 6 (profiles/r06/cage_move_kernels.md): one WAVE per item left 56-63 lanes
+// (item = cascade * n_tets + tet); a segment of a launch covers the items [item_begin, item_end) with ONE team size (launch_tet_mark chooses: 64 / 8 / 1).  Round 6 (profiles/r06/cage_move_kernels.md): one WAVE per item left 56-63 lanes
 // idle, and in the coarse cascades -- where the whole mesh stands in a handful of cells -- every item's atomic went to the same address (6 000 serialised atomics per
 // cascade and pass: that, not the tests, was the pass's time); now the hits of a wave that fall into its first hit's cell share ONE atomic.
 // FILL == false: counts[cell] += 1, and the item's first 128 test results go to hit_masks[2 item .. 2 item + 1] (bit k = cell k of the box).
 // FILL == true: idx[offsets[cell] + --counts[cell]] = tet (leaves counts zeroed; the order inside a list is free: lut_finish_kernel sorts); the first 128 cells take the
 // count pass's answers instead of repeating cell_meets_tet (8 point-in-tet + 4 box / triangle tests per cell).
 template <bool FILL, int T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void tet_mark_kernel(uint32_t n_tets, uint32_t item_begin, uint32_t item_end, const float* __restrict__ verts, const uint32_t* __restrict__ tets,
-                                                        uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                                        uint32_t* __restrict__ idx, unsigned long long* __restrict__ hit_masks) {
-	const uint32_t wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+__device__ __forceinline__ void tet_mark_wave(uint32_t wv, uint32_t n_tets, uint32_t item_begin, uint32_t item_end, const float* __restrict__ verts, const uint32_t* __restrict__ tets,
+                                              uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                                              uint32_t* __restrict__ idx, unsigned long long* __restrict__ hit_masks) {
 	const int lane = threadIdx.x & 63, sub = lane / T, r = lane % T;
 	const uint32_t item = item_begin + wv * (64 / T) + (uint32_t)sub;
 	const bool live = item < item_end;
@@ -244,11 +243,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 	}
 	if (!FILL && live && r == 0) { hit_masks[2 * (size_t)item] = mask0; hit_masks[2 * (size_t)item + 1] = mask1; }
 }
-template <bool FILL, int T>
-static void launch_tet_mark_range(uint32_t n_tets, uint32_t item_begin, uint32_t item_end, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, const uint32_t* d_offsets,
-                                  uint32_t* d_idx, unsigned long long* d_hit_masks, hipStream_t s) {
-	const uint32_t waves = (item_end - item_begin + 64 / T - 1) / (64 / T);
-	hipLaunchKernelGGL((tet_mark_kernel<FILL, T>), dim3((waves + 3) / 4), dim3(256), 0, s, n_tets, item_begin, item_end, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks);
+// One launch per pass: up to three segments of items, each with its own team size (T0 = 64 or 8 for the first, 8 for the second, 1 for the third; an empty segment has
+// no blocks), so that the segments' waves share the GPU instead of queueing behind each other (two launches of a 6 000-tet cage's count pass: 0.08 + 0.08 ms).
+struct MarkSegments { uint32_t item_begin[3], item_end[3], first_block[4]; };
+template <bool FILL, int T0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void tet_mark_kernel(uint32_t n_tets, MarkSegments sg, const float* __restrict__ verts, const uint32_t* __restrict__ tets,
+                                                        uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                                                        uint32_t* __restrict__ idx, unsigned long long* __restrict__ hit_masks) {
+	const uint32_t wave = threadIdx.x >> 6;
+	if (blockIdx.x < sg.first_block[1]) tet_mark_wave<FILL, T0>(blockIdx.x * 4u + wave, n_tets, sg.item_begin[0], sg.item_end[0], verts, tets, counts, offsets, idx, hit_masks);
+	else if (blockIdx.x < sg.first_block[2]) tet_mark_wave<FILL, 8>((blockIdx.x - sg.first_block[1]) * 4u + wave, n_tets, sg.item_begin[1], sg.item_end[1], verts, tets, counts, offsets, idx, hit_masks);
+	else tet_mark_wave<FILL, 1>((blockIdx.x - sg.first_block[2]) * 4u + wave, n_tets, sg.item_begin[2], sg.item_end[2], verts, tets, counts, offsets, idx, hit_masks);
 }
 // Team sizes per cascade.  A small mesh (a pass is as long as its longest wave: the GPU is not full) takes the widest teams its boxes fill -- a wave per item at cascade 0
 // when a tet's box there holds >= 32 cells (`cells0`: the caller's estimate from the mesh's bounding box and tet count), eight lanes elsewhere; a large mesh (throughput)
@@ -256,16 +261,20 @@ static void launch_tet_mark_range(uint32_t n_tets, uint32_t item_begin, uint32_t
 template <bool FILL>
 static void launch_tet_mark(uint32_t n_tets, float cells0, const float* d_verts, const uint32_t* d_tets, uint32_t* d_counts, const uint32_t* d_offsets, uint32_t* d_idx,
                             unsigned long long* d_hit_masks, hipStream_t s) {
-	const bool small = n_tets <= 16384u;
-	const uint32_t n = n_tets;
-	if (small && cells0 >= 32.f) launch_tet_mark_range<FILL, 64>(n, 0u, n, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks, s);
-	else launch_tet_mark_range<FILL, 8>(n, 0u, n, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks, s);
-	if (small) {
-		launch_tet_mark_range<FILL, 8>(n, n, n * kCascades, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks, s);
-	} else {
-		launch_tet_mark_range<FILL, 8>(n, n, 2u * n, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks, s);
-		launch_tet_mark_range<FILL, 1>(n, 2u * n, n * kCascades, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks, s);
+	const bool small = n_tets <= 16384u, wide0 = small && cells0 >= 32.f;
+	const uint32_t n = n_tets, all = n_tets * kCascades;
+	MarkSegments sg;
+	const uint32_t bounds[4] = {0u, n, small ? all : 2u * n, all}; // segment k: items [bounds[k], bounds[k + 1])
+	const uint32_t per_wave[3] = {wide0 ? 1u : 8u, 8u, 64u};       // items per wave (64 / team size)
+	uint32_t block = 0;
+	for (int k = 0; k < 3; ++k) {
+		sg.item_begin[k] = bounds[k]; sg.item_end[k] = bounds[k + 1]; sg.first_block[k] = block;
+		const uint32_t waves = (bounds[k + 1] - bounds[k] + per_wave[k] - 1u) / per_wave[k];
+		block += (waves + 3u) / 4u;
 	}
+	sg.first_block[3] = block;
+	if (wide0) hipLaunchKernelGGL((tet_mark_kernel<FILL, 64>), dim3(block), dim3(256), 0, s, n_tets, sg, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks);
+	else hipLaunchKernelGGL((tet_mark_kernel<FILL, 8>), dim3(block), dim3(256), 0, s, n_tets, sg, d_verts, d_tets, d_counts, d_offsets, d_idx, d_hit_masks);
 }
 
 // ---- exclusive scan of counts[kCells] -> offsets[kCells + 1] ----------------------------------------------------------------
