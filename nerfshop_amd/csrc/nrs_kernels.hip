@@ -1099,8 +1099,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void render_kernel(const DeviceMod
 // The same kernel scheduled for 3 waves per SIMD but held to the 128 VGPRs that still give 4 (512-thread workgroups, 2 per CU): the
 // scheduler hides more latency per wave when it does not aim at occupancy 4, and the cap keeps the occupancy it did not aim at.
 // (An attribute argument cannot depend on a template parameter, hence a second entry point rather than a template flag.)
+// Scheduled for TWO waves per SIMD measured +-0 on the lego scenes and +1 % on the garden frame (profiles/r06/ab_c128_occ2_*.txt): the GATE instantiation takes that.
 template <int WAVES, bool PROF, bool POISSON, bool AFFINE, int TEAM, int NUM = 0, int XTRA = 0>
-__global__ __launch_bounds__(64 * WAVES, 3) __attribute__((amdgpu_num_vgpr(128))) void render_kernel_c128(const DeviceModel m_arg, const RenderArgs a_arg) {
+__global__ __launch_bounds__(64 * WAVES, XTRA == 6 ? 2 : 3) __attribute__((amdgpu_num_vgpr(128))) void render_kernel_c128(const DeviceModel m_arg, const RenderArgs a_arg) {
 	render_body<WAVES, 3, PROF, POISSON, AFFINE, TEAM, NUM, XTRA>(m_arg, a_arg);
 }
 #ifndef NRS_BODY_ONLY // (tools/one_kernel.sh compiles ONE explicit instantiation of render_kernel for register work: everything below is left out)
