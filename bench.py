@@ -83,13 +83,29 @@ def build_scene(workload, rt, synth, ctx, torch):
             return d.cpu().numpy(), m.cpu().numpy()
 
         grid = synth.deformed_density_grid(grid, desc, map_positions, aabb_scale)
+    affine = None
+    if workload == "lego_affine":
+        # one AffineDuplication (editing/affine_duplication.h: the solid's arm shown again translated, scaled and rotated); since round 6 on the
+        # automatic schedule (the AFFINE instantiation with lane teams, re-teaming, hand-over and four levels per round trip)
+        affine = synth.make_affine_edit()
+        aop = rt.AffineDuplication(ctx, desc, affine)
+        tb.add_edit_operator(aop)
+
+        def map_positions_a(warped):
+            d = torch.from_numpy(np.ascontiguousarray(warped, np.float32)).cuda()
+            m = torch.zeros(d.shape[0], dtype=torch.uint8, device=d.device)
+            aop.map_positions(None, d, m)
+            torch.cuda.synchronize()
+            return d.cpu().numpy(), m.cpu().numpy()
+
+        grid = synth.deformed_density_grid(grid, desc, map_positions_a, aabb_scale)
     tb.nerf_network.set_density_grid(grid)  # threshold + mip pooling on the device
     if aabb_scale > 1 and sparse_gb != "0" and not workload.endswith("norecords"):
         # aabb-16 scenes: the dense cell records end at level 7 (7.3 GB); levels 8.. get occupancy-sparse brick records wherever lookups can
         # happen: the occupancy of the edited scene OR the un-edited one (the cage carries samples back to canonical space)
         mask = synth.grid_to_bitfield(grid) | synth.grid_to_bitfield(synth.density_grid(aabb_scale))
         tb.nerf_network.set_sparse_cell_cache(mask, int(float(sparse_gb) * (1 << 30)))
-    return dict(desc=desc, params=params, grid=grid, edit=edit, tb=tb, aabb_scale=aabb_scale)
+    return dict(desc=desc, params=params, grid=grid, edit=edit, affine=affine, tb=tb, aabb_scale=aabb_scale)
 
 
 def camera_for(step, synth, aabb_scale):
@@ -334,7 +350,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage", "garden_cage_records64", "garden", "lego_cage_varied", "lego_cage_membrane", "garden_cage_norecords", "lego_cage_tcnn_numerics", "lego_cage_norecords", "lego_cage_base_1layer", "lego_cage_base_3layer"])
+    ap.add_argument("--workload", default="lego_cage", choices=["lego_cage", "lego", "garden_cage", "garden_cage_records64", "garden", "lego_cage_varied", "lego_cage_membrane", "garden_cage_norecords", "lego_cage_tcnn_numerics", "lego_cage_norecords", "lego_cage_base_1layer", "lego_cage_base_3layer", "lego_affine"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -543,7 +559,7 @@ def main():
         # plus the membrane correction on (SURVEY 8d's "one extra run with it on") and the garden scene WITHOUT the 64 GB of sparse brick records
         # (they are an option of the boundary, INTEGRATION.md: the figure a caller gets who does not install them)
         for name in ("garden_cage", "garden_cage_records64", "garden_cage_norecords", "lego_cage_varied", "lego_cage_membrane", "lego_cage_tcnn_numerics", "lego_cage_norecords", "lego_cage_base_1layer",
-                     "lego_cage_base_3layer"):
+                     "lego_cage_base_3layer", "lego_affine"):
             sc2 = build_scene(name, rt, synth, ctx, torch)
             tb2 = sc2["tb"]
 
@@ -682,7 +698,8 @@ def main():
                                     "lego_cage_tcnn_numerics": "lego-like snapshot 1920x1080, one cage edit, tiny-cuda-nn's roundings (fp16 per-corner grid accumulation, fp16 MLP accumulators)",
                                     "lego_cage_norecords": "lego-like snapshot 1920x1080, one cage edit, no cell records (nrs_model_set_cell_cache(0))",
                                     "lego_cage_base_1layer": "lego-like snapshot of configs/nerf/base_1layer.json (rgb network with one hidden layer) 1920x1080, one cage edit",
-                                    "lego_cage_base_3layer": "lego-like snapshot of configs/nerf/base_3layer.json (rgb network with three hidden layers) 1920x1080, one cage edit"}[args.workload],
+                                    "lego_cage_base_3layer": "lego-like snapshot of configs/nerf/base_3layer.json (rgb network with three hidden layers) 1920x1080, one cage edit",
+                                    "lego_affine": "lego-like snapshot 1920x1080, one AffineDuplication edit (no cage)"}[args.workload],
                        "resolution": [W, H], "samples_per_frame": int(total_samples / args.steps),
                        "sharding": f"{TILE}x{TILE} image tiles round-robin over {world} GPU(s)" + (f", gather to rank 0 by {all_sharders[0].gather_impl}" if world > 1 else ""),
                        "frames_in_flight": n_buf,

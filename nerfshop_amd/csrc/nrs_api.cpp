@@ -1635,10 +1635,11 @@ int nrs_render_nerf(nrs_model* m, const nrs_render_params* p, nrs_edit* const* e
 		uint32_t team = 1; // fixed lanes per ray: only when forced
 		if (forced == 1 || forced == 2 || forced == 4) team = (uint32_t)forced;
 		if (forced == -1) team = 1;
-		// (the AffineDuplication / EXTRA / run-time-numerics membrane instantiations are built for one lane per ray; the membrane correction of cage edits
-		// alone runs the automatic schedule since round 4)
+		// (the EXTRA / run-time-numerics / mixed membrane + affine instantiations are built for one lane per ray; the membrane correction of cage edits
+		// alone runs the automatic schedule since round 4, AffineDuplication since round 6)
 		const bool poisson_teams = a.any_poisson && !a.any_affine && !a.extra && m->dm.numerics == 0u;
-		const bool one_lane_only = (a.any_poisson && !poisson_teams) || a.any_affine || a.extra;
+		const bool affine_teams = a.any_affine && !a.any_poisson && !a.extra && m->dm.numerics == 0u; // (round 6: the AFFINE instantiation of the automatic schedule)
+		const bool one_lane_only = (a.any_poisson && !poisson_teams) || (a.any_affine && !affine_teams) || a.extra;
 		if (one_lane_only || a.any_poisson) team = 1; // (fixed 2 / 4 lanes per ray exist for the default kernel only; a forced size leaves the membrane path on the catch-all)
 		static const bool log_teams = dev_knob("NRS_TEAM_LOG") != nullptr;
 		if (log_teams) fprintf(stderr, "[nrs team] pixels=%u hit_share=%.3f busy=%u rays/lane=%.3f small-launch=%d fill lanes=%u forced=%d\n", a.pixels_owned, hit_share, busy, rays_per_lane, (int)small_launch, fill_lanes, forced);

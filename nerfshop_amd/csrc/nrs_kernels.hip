@@ -232,7 +232,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 	constexpr bool EXTRA = XTRA >= 1 && XTRA <= 4, INTRO = XTRA == 2 || XTRA == 4, DEEP = XTRA >= 3 && XTRA <= 5; // (3 / 4: 1 / 2 for a network whose rgb MLP has a third hidden layer, base_3layer.json; 5: that layer alone)
 	// four levels per round trip in the gathers (encode_to_lds QUADS): the automatic schedule's instantiations with the default or the fully tiny-cuda-nn roundings -- since
 	// round 6 the membrane instantiation too (both of its gathers: 9.68 -> 10.06 Gsamples/s, same registers; profiles/r06/ab_poisson_quads.txt)
-	constexpr bool kQuads = TEAM == 0 && !AFFINE && !EXTRA && (NUM == 0 || NUM == 3);
+	constexpr bool kQuads = TEAM == 0 && !EXTRA && (NUM == 0 || NUM == 3);
 	constexpr int GATE = XTRA == 6 ? (int)kGateMaxPhases : 0; // the plain kernel with the L2 phase gate on the four finest hashed levels (encode_to_lds): cone-stepping scenes
 	// The two argument structs (~1.3 KB of wave-uniform values) live in the kernel-argument segment and are read with scalar loads.
 	// Left alone, the compiler hoists every such load out of the frame loop and then spills ~150 scalar registers into VGPR lanes
@@ -1208,6 +1208,8 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 	// (the 10-wave / 5-waves-per-SIMD probe of rounds 1-3, NRS_RENDER_CFG=105, left the library in round 4: it spilled 77 registers at 96 VGPRs and, with the
 	// two selection fragments in the LDS image, ten waves no longer fit the LDS budget of two workgroups per CU either)
 	if (cfg == 42 && a.team == 1 && !a.any_affine) return launch_render_cfg<4, 2>(m, a, n_cus, s);
+	// AffineDuplication (alone or with cage edits, no membrane correction, default roundings) on the automatic schedule since round 6 (nrs_render_nerf: a.team == 0)
+	if (a.any_affine && a.team == 0) return launch_render_cfg<8, 4, false, false, true, 0>(m, a, n_cus, s);
 	if (a.any_affine) return launch_render_cfg<8, 4, false, false, true>(m, a, n_cus, s); // (its c128 build takes 133 VGPRs: the attribute is a target, not a limit)
 	if (a.team == 0) return launch_render_c128<8, false, false, false, 0>(m, a, n_cus, s);
 	if (a.team == 2) return launch_render_c128<8, false, false, false, 2>(m, a, n_cus, s);

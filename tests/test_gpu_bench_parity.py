@@ -24,6 +24,8 @@ class BenchScene:
         assert np.array_equal(self.tb.nerf_network.get_density_bitfield(), bitfield)
         self.model = orc.Model(sc["desc"], sc["params"], bitfield)
         self.edits = [orc.Edit(sc["desc"], sc["edit"].tet_mesh_struct(), keepalive=sc["edit"])] if sc["edit"] is not None else []
+        if sc.get("affine") is not None:
+            self.edits.append(orc.AffineEdit(sc["desc"], sc["affine"]))
 
     def params(self, step, w=1920, h=1080, apply_operators=True):
         return self.synth.render_params(w, h, self.bench.camera_for(step, self.synth, self.sc["aabb_scale"]), aabb_scale=self.sc["aabb_scale"], apply_operators=apply_operators)
@@ -174,6 +176,16 @@ def test_base_3layer_bench_scene_1080p_against_the_oracle(built):
     bs = BenchScene("lego_cage_base_3layer")
     assert bs.sc["desc"].rgb_hidden_layers == 3
     check_against_oracle(bs, bs.params(0), bs.edits, 10_000_000)
+
+
+def test_affine_bench_scene_1080p_against_the_oracle(built):
+    """`lego_affine` as bench.py times it: one AffineDuplication (affine_duplication.cu:69-118) on the automatic schedule -- the AFFINE instantiation with lane teams,
+    re-teaming, hand-over and four levels per round trip (round 6; before: one lane per ray) -- bench view 0 at 1920x1080 against the oracle."""
+    bs = BenchScene("lego_affine")
+    assert len(bs.edits) == 1
+    check_against_oracle(bs, bs.params(0), bs.edits, 10_000_000)
+    rays, handovers = bs.ctx.ray_handovers()
+    assert rays > 0 and handovers > 0, (rays, handovers)   # the automatic schedule ran (a one-lane launch hands nothing over)
 
 
 @pytest.mark.parametrize("workload", ["garden_cage", "garden_cage_records64"])
