@@ -23,7 +23,7 @@ n_cam = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 W, H = 480, 270
 rng = np.random.default_rng(2606)
 WORKLOADS = [("lego_cage", {}), ("lego_cage_varied", dict(two=1)), ("lego_cage_membrane", dict(poisson=1)), ("lego_cage_tcnn_numerics", dict(num=1, flip=1e-4, eq=0.999)),
-             ("lego_cage_base_3layer", {}), ("garden_cage_records64", dict(depth=16.0)), ("garden_cage", dict(depth=16.0))]
+             ("lego_cage_base_3layer", {}), ("garden_cage_records64", dict(depth=16.0)), ("garden_cage", dict(depth=16.0)), ("lego_affine", {})]
 only = sys.argv[2:]
 failed = 0
 for workload, opt in WORKLOADS:
