@@ -65,7 +65,8 @@ def build_scene(workload, rt, synth, ctx, torch):
     if workload.endswith("tcnn_numerics"):
         # tiny-cuda-nn's roundings as recalled: per-corner fp16 grid accumulation + fp16 MLP accumulators (nrs_model_set_numerics) -- the
         # pair a parity-minded integrator switches on; a compile-time instantiation of the automatic schedule since round 4
-        tb.nerf_network.set_numerics(1, 1)
+        g_acc, m_acc = (int(v) for v in os.environ.get("NRS_BENCH_NUMERICS", "1,1").split(","))  # (A/B of the single-rounding instantiations: "1,0" / "0,1")
+        tb.nerf_network.set_numerics(g_acc, m_acc)
     tb.nerf_network.set_params(params)
     edit = None
     if with_edit:

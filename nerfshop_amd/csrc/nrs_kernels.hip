@@ -232,7 +232,7 @@ __device__ __forceinline__ void render_body(const DeviceModel& m_arg, const Rend
 	constexpr bool EXTRA = XTRA >= 1 && XTRA <= 4, INTRO = XTRA == 2 || XTRA == 4, DEEP = XTRA >= 3 && XTRA <= 5; // (3 / 4: 1 / 2 for a network whose rgb MLP has a third hidden layer, base_3layer.json; 5: that layer alone)
 	// four levels per round trip in the gathers (encode_to_lds QUADS): the automatic schedule's instantiations with the default or the fully tiny-cuda-nn roundings -- since
 	// round 6 the membrane instantiation too (both of its gathers: 9.68 -> 10.06 Gsamples/s, same registers; profiles/r06/ab_poisson_quads.txt)
-	constexpr bool kQuads = TEAM == 0 && !EXTRA && (NUM == 0 || NUM == 3);
+	constexpr bool kQuads = TEAM == 0 && !EXTRA && NUM >= 0;
 	constexpr int GATE = XTRA == 6 ? (int)kGateMaxPhases : 0; // the plain kernel with the L2 phase gate on the four finest hashed levels (encode_to_lds): cone-stepping scenes
 	// The two argument structs (~1.3 KB of wave-uniform values) live in the kernel-argument segment and are read with scalar loads.
 	// Left alone, the compiler hoists every such load out of the frame loop and then spills ~150 scalar registers into VGPR lanes
@@ -1173,7 +1173,13 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 		// ... except the pair a parity-minded integrator switches on -- per-corner fp16 grid accumulation + fp16 MLP accumulators, what tiny-cuda-nn's
 		// kernel_grid and fully fused MLP do as recalled -- on the automatic schedule: a compile-time instantiation like NUM = 0 (VERDICT r3 weak #1:
 		// the run-time twin carries both flavours, 131 VGPRs = 3 waves per SIMD)
-		if ((m.numerics & 3u) == 3u && !a.any_poisson && !a.any_affine && a.team == 0 && !(a.dbg & 4u) && cfg == 0) return launch_render_c128<8, false, false, false, 0, 3>(m, a, n_cus, s);
+		if (!a.any_poisson && !a.any_affine && a.team == 0 && !(a.dbg & 4u) && cfg == 0) {
+			if ((m.numerics & 3u) == 3u) return launch_render_c128<8, false, false, false, 0, 3>(m, a, n_cus, s);
+			// (round 6: one of the two roundings alone -- per-corner fp16 grid accumulation, or fp16 MLP accumulators -- has its compile-time instantiation too:
+			// 125 / 123 VGPRs at 4 waves per SIMD instead of the run-time twin's 131 at 3)
+			if ((m.numerics & 3u) == 1u) return launch_render_c128<8, false, false, false, 0, 1>(m, a, n_cus, s);
+			if ((m.numerics & 3u) == 2u) return launch_render_c128<8, false, false, false, 0, 2>(m, a, n_cus, s);
+		}
 		if (a.any_poisson) return launch_render_cfg<12, 3, false, true, true, 1, R>(m, a, n_cus, s);
 		if (a.any_affine) return launch_render_cfg<8, 3, false, false, true, 1, R>(m, a, n_cus, s);
 		if (a.team == 0) return launch_render_cfg<8, 3, false, false, false, 0, R>(m, a, n_cus, s);
