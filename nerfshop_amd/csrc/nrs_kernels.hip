@@ -1215,7 +1215,7 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 	// two selection fragments in the LDS image, ten waves no longer fit the LDS budget of two workgroups per CU either)
 	if (cfg == 42 && a.team == 1 && !a.any_affine) return launch_render_cfg<4, 2>(m, a, n_cus, s);
 	// AffineDuplication (alone or with cage edits, no membrane correction, default roundings) on the automatic schedule since round 6 (nrs_render_nerf: a.team == 0)
-	if (a.any_affine && a.team == 0) return launch_render_cfg<8, 4, false, false, true, 0>(m, a, n_cus, s);
+	if (a.any_affine && a.team == 0) return launch_render_c128<8, false, false, true, 0>(m, a, n_cus, s); // (121 VGPRs on the 128-register entry point)
 	if (a.any_affine) return launch_render_cfg<8, 4, false, false, true>(m, a, n_cus, s); // (its c128 build takes 133 VGPRs: the attribute is a target, not a limit)
 	if (a.team == 0) return launch_render_c128<8, false, false, false, 0>(m, a, n_cus, s);
 	if (a.team == 2) return launch_render_c128<8, false, false, false, 2>(m, a, n_cus, s);
