@@ -1157,6 +1157,9 @@ int launch_render(const DeviceModel& m, const RenderArgs& a, int n_cus, void* st
 	{
 		// Normals / EncodingVis: the INTRO instantiation (145 / 165 VGPRs, no scratch: 12-wave workgroups at 3 waves per SIMD like the other modes)
 		const bool intro = a.p.render_mode == NRS_RENDER_NORMALS || a.p.render_mode == NRS_RENDER_ENCODING_VIS;
+		// (round 6: the common case -- a render mode / DoF / envmap / glow over plain cage edits or none, default roundings -- has a lean instantiation without the membrane and
+		// AffineDuplication code: 123 VGPRs on the 128-register entry point, 8-wave workgroups, 4 waves per SIMD instead of the catch-all's 145 at 3)
+		if (!intro && !m.rgb_deep && !m.numerics && !a.any_poisson && !a.any_affine && a.team == 1 && !(a.dbg & 4u) && cfg == 0) return launch_render_c128<8, false, false, false, 1, 0, 1>(m, a, n_cus, s);
 		if (m.rgb_deep) { // a network whose rgb MLP has a third hidden layer (base_3layer.json): the DEEP twins of the two catch-all instantiations, every mode
 			if (intro) return m.numerics ? launch_render_cfg<12, 3, false, true, true, 1, R, 4>(m, a, n_cus, s) : launch_render_cfg<12, 3, false, true, true, 1, 0, 4>(m, a, n_cus, s);
 			return m.numerics ? launch_render_cfg<12, 3, false, true, true, 1, R, 3>(m, a, n_cus, s) : launch_render_cfg<12, 3, false, true, true, 1, 0, 3>(m, a, n_cus, s);
